@@ -1,0 +1,161 @@
+/*
+ * spx.h -- C-ABI of the MI355X-native secphase scoring path (libspx.so).
+ *
+ * secphase has no plugin/FFI layer; the seams this library replaces are
+ * (all paths relative to /root/reference/programs):
+ *
+ *   spx_score_batch / spx_prepare+spx_launch+spx_collect
+ *       = the marker branch of runOneThread for every dispatched group,
+ *         src/secphase.c:156-192 (markers, consensus blocks, BAQ, marker
+ *         filter, score, get_best_record_index), i.e. what
+ *         tpool_add_work(tm, runOneThread, arg) at src/secphase.c:303 runs.
+ *   spx_group_is_dispatched
+ *       = the dispatch filter, src/secphase.c:285-288.
+ *   spx_finalize
+ *       = the rand() dependent tail of get_best_record_index,
+ *         submodules/ptAlignment/ptAlignment.c:163-176, replayed in file order
+ *         (= the reference at -@1).
+ *   spx_write_relabel_log
+ *       = the record writer, src/secphase.c:194-200 + print_alignment_scores
+ *         src/secphase.c:32-57 (the list correct_bam.c:32-88 parses).
+ *   spx_probaln_glocal
+ *       = htslib-1.17 probaln_glocal as called at
+ *         submodules/ptMarker/ptMarker.c:755-757 (same contract: caller owns
+ *         state[l_query] and q[l_query]; INT_MIN on failure).
+ *
+ * Plain pointers and sizes only; no torch / HIP types.  Every entry point
+ * returns 0 on success or a negative SPX_E* code; nothing calls exit().
+ * There is NO CPU fallback: without a usable gfx950 device spx_create fails
+ * with SPX_ENODEVICE.
+ */
+#ifndef SPX_H
+#define SPX_H
+
+#include <stdint.h>
+
+#include "spx_records.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPX_OK 0
+#define SPX_ENODEVICE (-1) /* no HIP device / wrong architecture                     */
+#define SPX_EHIP (-2)      /* a HIP runtime call failed (see spx_last_error)          */
+#define SPX_EINVAL (-3)    /* malformed argument                                      */
+#define SPX_ENOMEM (-4)
+#define SPX_EUNSUPPORTED (-5) /* input uses a construct the reference leaves undefined  */
+#define SPX_ENOREF (-6)    /* spx_set_reference has not been called                   */
+
+typedef struct spx_ctx spx_ctx;
+typedef struct spx_work spx_work;
+
+/* htslib hts.h probaln_par_t */
+typedef struct spx_probaln_par {
+    float d, e;
+    int bw;
+} spx_probaln_par;
+
+/* per-group result (fixed size so that ranks can gather it with one collective) */
+typedef struct spx_group_out {
+    double score[10];   /* marker-consistency score of each alignment (ptAlignment.score) */
+    int32_t rfe[10];    /* ptAlignment.rfe, printed in the relabel list                     */
+    int8_t n_aln;       /* alignments scored (0: group not dispatched, <0: SPX_E* for the group) */
+    int8_t prim_idx;    /* the non-secondary record                                         */
+    int8_t max_idx;     /* first secondary with the greatest score                          */
+    int8_t pass;        /* max > prim + prim_margin && max >= min_score                     */
+    uint16_t tie_mask;  /* secondaries whose score >= max                                   */
+    int8_t best_idx;    /* filled by spx_finalize: return of get_best_record_index          */
+    int8_t relabel;     /* filled by spx_finalize: best is a secondary                      */
+    int32_t n_problems; /* banded DP problems this group produced                           */
+    int32_t n_markers;  /* markers entering the filter                                      */
+    int64_t dp_cells;   /* band cells of those problems                                     */
+} spx_group_out;
+
+typedef struct spx_stats {
+    int64_t n_groups, n_dispatched, n_problems, n_rows, dp_cells;
+    int64_t n_markers;
+    int64_t bytes_h2d, bytes_d2h;
+    int64_t problems_per_class[8];
+    double prep_seconds, h2d_seconds, kernel_seconds, d2h_seconds;
+    /* dominant kernel, measured with HIP events on the launch stream */
+    double baq_kernel_ms;
+    double score_kernel_ms;
+} spx_stats;
+
+const char *spx_strerror(int code);
+const char *spx_last_error(void);
+int spx_device_count(void);
+
+int spx_create(int device, spx_ctx **out);
+void spx_destroy(spx_ctx *ctx);
+
+/* copy the assembly into HBM as 4-bit codes (resident for the ctx lifetime) */
+int spx_set_reference(spx_ctx *ctx, const spx_ref *ref);
+
+int spx_group_is_dispatched(const spx_batch *bt, int32_t g);
+
+/* one call: prepare + launch + collect */
+int spx_score_batch(spx_ctx *ctx, const spx_batch *bt, const spx_params *par, spx_group_out *out, spx_stats *stats);
+
+/* split phase (what bench.py times; also lets a caller overlap host parsing of the next batch) */
+int spx_prepare(spx_ctx *ctx, const spx_batch *bt, const spx_params *par, int host_threads, spx_work **work);
+int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */
+int spx_sync(spx_ctx *ctx);
+int spx_collect(spx_ctx *ctx, spx_work *work, spx_group_out *out);
+int spx_work_stats(const spx_work *work, spx_stats *stats);
+void spx_work_free(spx_ctx *ctx, spx_work *work);
+
+/* rand() replay + decision, in file order */
+int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups);
+
+/* append the relabel records of a finalized batch to `path` (mode "w" or "a") */
+int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *bt, const spx_ref *ref,
+                          const spx_group_out *out);
+
+/* single banded-HMM problem on the device (unit tests / drop-in for the htslib symbol).
+ * Uses a process-wide context on device 0 created on first use. */
+int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+                       const spx_probaln_par *c, int *state, uint8_t *q);
+
+/* batched form of the above on an explicit ctx: n problems, all rows wanted.
+ * ref/query are concatenated 0..4 codes; *_off have n+1 entries; outputs are
+ * concatenated like query. set_q is the constant base quality of every row. */
+int spx_probaln_batch(spx_ctx *ctx, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
+                      const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t *state,
+                      uint8_t *q, double *kernel_ms);
+
+/* ---- host-only view of the work list (no device needed) ------------------
+ * What spx_prepare would upload: the banded DP problems and the marker table.
+ * Lets CPU-only tests check the host logic against the oracle, and documents
+ * the device batch layout for integrators. */
+typedef struct spx_plan spx_plan;
+typedef struct spx_plan_view {
+    int32_t n_problems, n_rows, n_groups, n_markers;
+    const int32_t *L, *R, *bw;           /* per problem; bw is the effective half band width */
+    const int32_t *ref_tid, *ref_rfs;    /* reference window = contig tid, [rfs, rfs+R) */
+    const int64_t *qry_nib;              /* nibble offset of the query window in qry4 */
+    const uint8_t *qry4;                 /* 0..4 codes, low nibble first */
+    const double *hmm;                   /* 16 doubles per problem, see spx_device.h */
+    const int32_t *row_off, *n_rows_of;  /* wanted rows of each problem */
+    const int32_t *rows, *row_expect;    /* 1-based query row; expected window-relative ref index */
+    const uint8_t *row_rawq;
+    const int32_t *grp_index;            /* dispatched group -> group of the input batch */
+    const int32_t *mk_first;             /* [n_groups+1] */
+    const int32_t *mk_row;               /* [n_markers] wanted-row index or -1 */
+    const uint8_t *mk_qfix, *mk_is_match, *mk_aln, *mk_first_of_pos;
+    const uint8_t *n_aln;
+    const uint16_t *sec_mask;
+    const int32_t *rfe;                  /* 10 per group */
+    const int32_t *grp_error;            /* per INPUT group: 0 ok, 1 not dispatched, <0 SPX_E* */
+} spx_plan_view;
+int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const spx_params *par, spx_plan **out);
+int spx_plan_get(const spx_plan *plan, spx_plan_view *view);
+void spx_plan_free(spx_plan *plan);
+/* the tables the kernels use: phred thresholds thr[102], match_tbl[256], mis_tbl[256] */
+void spx_host_tables(double *thr, double *match_tbl, double *mis_tbl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

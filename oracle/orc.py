@@ -1,0 +1,85 @@
+"""ctypes wrapper of oracle/liborc.so -- TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+from secphase_amd.records import SpxBatch, SpxParams, SpxRef
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+class ProbalnPar(C.Structure):
+    _fields_ = [("d", C.c_float), ("e", C.c_float), ("bw", C.c_int)]
+
+
+class HmmConsts(C.Structure):
+    _fields_ = [("m", C.c_double * 9), ("bM", C.c_double), ("bI", C.c_double), ("sM", C.c_double),
+                ("sI", C.c_double), ("e_match", C.c_double), ("e_mis", C.c_double)]
+
+
+class Rand(C.Structure):
+    _fields_ = [("r", C.c_int32 * 34), ("f", C.c_int), ("b", C.c_int), ("tbl", C.c_uint32 * 31)]
+
+
+class Op(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("op", "len", "ret", "sqs", "sqe", "rfs", "rfe", "rds_f", "rde_f")]
+
+
+class BaqCall(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("aln", "block", "sqs", "sqe", "rfs", "rfe", "bw")]
+
+
+class GroupResult(C.Structure):
+    _fields_ = [
+        ("n_aln", C.c_int), ("best_idx", C.c_int), ("prim_idx", C.c_int), ("relabel", C.c_int), ("n_rand", C.c_int),
+        ("score", C.c_double * 16), ("rfe", C.c_int * 16),
+        ("n_markers_initial", C.c_int), ("n_markers_final", C.c_int), ("n_blocks", C.c_int),
+        ("n_baq_calls", C.c_int), ("dp_cells", C.c_longlong),
+    ]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_DIR, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        u8p = C.POINTER(C.c_uint8)
+        L.orc_probaln_glocal.restype = C.c_int
+        L.orc_probaln_glocal.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.POINTER(ProbalnPar),
+                                         C.POINTER(C.c_int), u8p]
+        L.orc_phred_from_posterior.restype = C.c_int
+        L.orc_phred_from_posterior.argtypes = [C.c_double]
+        L.orc_probaln_consts.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(HmmConsts)]
+        L.orc_srand.argtypes = [C.POINTER(Rand), C.c_uint]
+        L.orc_rand_next.restype = C.c_int
+        L.orc_rand_next.argtypes = [C.POINTER(Rand)]
+        L.orc_score_group.restype = C.c_int
+        L.orc_score_group.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.c_int, C.POINTER(SpxParams),
+                                      C.POINTER(Rand), C.POINTER(GroupResult), C.c_void_p,
+                                      C.POINTER(BaqCall), C.c_int]
+        L.orc_group_is_dispatched.restype = C.c_int
+        L.orc_group_is_dispatched.argtypes = [C.POINTER(SpxBatch), C.c_int]
+        L.orc_run_batch.restype = C.c_int
+        L.orc_run_batch.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
+                                    C.c_uint, C.POINTER(GroupResult), C.c_char_p]
+        L.orc_walk_cigar.restype = C.c_int
+        L.orc_walk_cigar.argtypes = [C.POINTER(SpxBatch), C.c_int, C.POINTER(C.POINTER(Op))]
+        _lib = L
+    return _lib
+
+
+def run_batch(batch, ref, params, threads=1, seed=1, log_path=None):
+    n = batch.contents.n_groups if hasattr(batch, "contents") else batch.n_groups
+    res = (GroupResult * n)()
+    nre = lib().orc_run_batch(batch, ref, C.byref(params), threads, seed, res,
+                              log_path.encode() if log_path else None)
+    return nre, res

@@ -1,0 +1,245 @@
+"""ctypes binding of libspx.so (include/spx.h) -- plumbing for tests and bench.
+
+The library is the product; this file only loads it and mirrors its structs.
+There is no Python or CPU fallback: if the shared object is missing the import
+of `lib()` raises, and without a gfx950 device `Context()` raises SpxError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from .records import SpxBatch, SpxParams, SpxRef
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libspx.so")
+
+OK, ENODEVICE, EHIP, EINVAL, ENOMEM, EUNSUPPORTED, ENOREF = 0, -1, -2, -3, -4, -5, -6
+
+
+class SpxError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().spx_strerror(code).decode()
+        detail = lib().spx_last_error().decode()
+        super().__init__(f"{where}: {msg} ({code}) {detail}")
+
+
+class ProbalnPar(C.Structure):
+    _fields_ = [("d", C.c_float), ("e", C.c_float), ("bw", C.c_int)]
+
+
+class GroupOut(C.Structure):
+    _fields_ = [
+        ("score", C.c_double * 10), ("rfe", C.c_int32 * 10),
+        ("n_aln", C.c_int8), ("prim_idx", C.c_int8), ("max_idx", C.c_int8), ("pass_", C.c_int8),
+        ("tie_mask", C.c_uint16), ("best_idx", C.c_int8), ("relabel", C.c_int8),
+        ("n_problems", C.c_int32), ("n_markers", C.c_int32), ("dp_cells", C.c_int64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_groups", C.c_int64), ("n_dispatched", C.c_int64), ("n_problems", C.c_int64), ("n_rows", C.c_int64),
+        ("dp_cells", C.c_int64), ("n_markers", C.c_int64), ("bytes_h2d", C.c_int64), ("bytes_d2h", C.c_int64),
+        ("problems_per_class", C.c_int64 * 8),
+        ("prep_seconds", C.c_double), ("h2d_seconds", C.c_double), ("kernel_seconds", C.c_double),
+        ("d2h_seconds", C.c_double), ("baq_kernel_ms", C.c_double), ("score_kernel_ms", C.c_double),
+    ]
+
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_f64p = C.POINTER(C.c_double)
+
+
+class PlanView(C.Structure):
+    _fields_ = [
+        ("n_problems", C.c_int32), ("n_rows", C.c_int32), ("n_groups", C.c_int32), ("n_markers", C.c_int32),
+        ("L", _i32p), ("R", _i32p), ("bw", _i32p), ("ref_tid", _i32p), ("ref_rfs", _i32p),
+        ("qry_nib", _i64p), ("qry4", _u8p), ("hmm", _f64p),
+        ("row_off", _i32p), ("n_rows_of", _i32p), ("rows", _i32p), ("row_expect", _i32p), ("row_rawq", _u8p),
+        ("grp_index", _i32p), ("mk_first", _i32p), ("mk_row", _i32p),
+        ("mk_qfix", _u8p), ("mk_is_match", _u8p), ("mk_aln", _u8p), ("mk_first_of_pos", _u8p),
+        ("n_aln", _u8p), ("sec_mask", _u16p), ("rfe", _i32p), ("grp_error", _i32p),
+    ]
+
+
+EXPORTS = [
+    "spx_strerror", "spx_last_error", "spx_device_count", "spx_create", "spx_destroy", "spx_set_reference",
+    "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_launch", "spx_sync", "spx_collect",
+    "spx_work_stats", "spx_work_free", "spx_finalize", "spx_write_relabel_log", "spx_probaln_glocal",
+    "spx_probaln_batch", "spx_plan_create", "spx_plan_get", "spx_plan_free", "spx_host_tables",
+]
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_DIR, "csrc")])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                          "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.spx_strerror.restype = C.c_char_p
+    L.spx_strerror.argtypes = [C.c_int]
+    L.spx_last_error.restype = C.c_char_p
+    L.spx_device_count.restype = C.c_int
+    L.spx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.spx_destroy.argtypes = [vp]
+    L.spx_destroy.restype = None
+    L.spx_set_reference.argtypes = [vp, C.POINTER(SpxRef)]
+    L.spx_group_is_dispatched.argtypes = [C.POINTER(SpxBatch), C.c_int32]
+    L.spx_score_batch.argtypes = [vp, C.POINTER(SpxBatch), C.POINTER(SpxParams), C.POINTER(GroupOut), C.POINTER(Stats)]
+    L.spx_prepare.argtypes = [vp, C.POINTER(SpxBatch), C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
+    L.spx_launch.argtypes = [vp, vp]
+    L.spx_sync.argtypes = [vp]
+    L.spx_collect.argtypes = [vp, vp, C.POINTER(GroupOut)]
+    L.spx_work_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.spx_work_free.argtypes = [vp, vp]
+    L.spx_work_free.restype = None
+    L.spx_finalize.argtypes = [C.POINTER(SpxParams), C.c_uint, C.POINTER(GroupOut), C.c_int32]
+    L.spx_write_relabel_log.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SpxBatch), C.POINTER(SpxRef),
+                                        C.POINTER(GroupOut)]
+    L.spx_probaln_glocal.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _u8p, C.POINTER(ProbalnPar), C.POINTER(C.c_int), _u8p]
+    L.spx_probaln_batch.argtypes = [vp, C.c_int32, _u8p, _i64p, _u8p, _i64p, _i32p, C.POINTER(ProbalnPar), _i32p, _u8p,
+                                    _f64p]
+    L.spx_plan_create.argtypes = [C.POINTER(SpxRef), C.POINTER(SpxBatch), C.POINTER(SpxParams), C.POINTER(vp)]
+    L.spx_plan_get.argtypes = [vp, C.POINTER(PlanView)]
+    L.spx_plan_free.argtypes = [vp]
+    L.spx_plan_free.restype = None
+    L.spx_host_tables.argtypes = [_f64p, _f64p, _f64p]
+    L.spx_host_tables.restype = None
+    _lib = L
+    return L
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise SpxError(rc, where)
+
+
+class Context:
+    """One context per (process, device): stream, HBM-resident reference, tables."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().spx_create(device, C.byref(self.h)), "spx_create")
+
+    def set_reference(self, ref):
+        _chk(lib().spx_set_reference(self.h, ref), "spx_set_reference")
+
+    def score_batch(self, batch, params, finalize_seed=1):
+        n = batch.contents.n_groups
+        out = (GroupOut * n)()
+        st = Stats()
+        _chk(lib().spx_score_batch(self.h, batch, C.byref(params), out, C.byref(st)), "spx_score_batch")
+        if finalize_seed is not None:
+            _chk(lib().spx_finalize(C.byref(params), finalize_seed, out, n), "spx_finalize")
+        return out, st
+
+    def prepare(self, batch, params, host_threads=0):
+        return Work(self, batch, params, host_threads)
+
+    def probaln_batch(self, refs, queries, set_q, pars):
+        """refs/queries: lists of uint8 numpy arrays of 0..4 codes; returns (states, qs, kernel_ms)."""
+        import numpy as np
+        n = len(refs)
+        ro = np.zeros(n + 1, np.int64)
+        qo = np.zeros(n + 1, np.int64)
+        ro[1:] = np.cumsum([len(r) for r in refs])
+        qo[1:] = np.cumsum([len(q) for q in queries])
+        rcat = np.ascontiguousarray(np.concatenate(refs).astype(np.uint8))
+        qcat = np.ascontiguousarray(np.concatenate(queries).astype(np.uint8))
+        sq = np.ascontiguousarray(np.asarray(set_q, np.int32))
+        P = (ProbalnPar * n)(*[ProbalnPar(*p) for p in pars])
+        state = np.zeros(int(qo[-1]), np.int32)
+        q = np.zeros(int(qo[-1]), np.uint8)
+        ms = C.c_double(0)
+        _chk(lib().spx_probaln_batch(self.h, n, rcat.ctypes.data_as(_u8p), ro.ctypes.data_as(_i64p),
+                                     qcat.ctypes.data_as(_u8p), qo.ctypes.data_as(_i64p), sq.ctypes.data_as(_i32p), P,
+                                     state.ctypes.data_as(_i32p), q.ctypes.data_as(_u8p), C.byref(ms)),
+             "spx_probaln_batch")
+        return ([state[qo[i]:qo[i + 1]] for i in range(n)], [q[qo[i]:qo[i + 1]] for i in range(n)], ms.value)
+
+    def close(self):
+        if self.h:
+            lib().spx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Work:
+    def __init__(self, ctx, batch, params, host_threads):
+        self.ctx = ctx
+        self.n = batch.contents.n_groups
+        self.params = params
+        self.h = C.c_void_p()
+        _chk(lib().spx_prepare(ctx.h, batch, C.byref(params), host_threads, C.byref(self.h)), "spx_prepare")
+
+    def launch(self):
+        _chk(lib().spx_launch(self.ctx.h, self.h), "spx_launch")
+
+    def sync(self):
+        _chk(lib().spx_sync(self.ctx.h), "spx_sync")
+
+    def collect(self, finalize_seed=1):
+        out = (GroupOut * self.n)()
+        _chk(lib().spx_collect(self.ctx.h, self.h, out), "spx_collect")
+        if finalize_seed is not None:
+            _chk(lib().spx_finalize(C.byref(self.params), finalize_seed, out, self.n), "spx_finalize")
+        return out
+
+    def stats(self):
+        st = Stats()
+        _chk(lib().spx_work_stats(self.h, C.byref(st)), "spx_work_stats")
+        return st
+
+    def free(self):
+        if self.h:
+            lib().spx_work_free(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Plan:
+    """Host-only work list (no device)."""
+
+    def __init__(self, ref, batch, params):
+        self.h = C.c_void_p()
+        _chk(lib().spx_plan_create(ref, batch, C.byref(params), C.byref(self.h)), "spx_plan_create")
+        self.view = PlanView()
+        _chk(lib().spx_plan_get(self.h, C.byref(self.view)), "spx_plan_get")
+
+    def close(self):
+        if self.h:
+            lib().spx_plan_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_relabel_log(path, batch, ref, out, mode="w"):
+    _chk(lib().spx_write_relabel_log(path.encode(), mode.encode(), batch, ref, out), "spx_write_relabel_log")

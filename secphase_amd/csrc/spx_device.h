@@ -1,0 +1,100 @@
+/*
+ * spx_device.h -- device-side batch layout shared by the host runtime
+ * (spx_runtime.cpp) and the HIP kernels (spx_kernels.hip).  Internal.
+ */
+#ifndef SPX_DEVICE_H
+#define SPX_DEVICE_H
+
+#include <stdint.h>
+
+/* ref/query base codes on the device: 0..3 = ACGT, 4 = N/ambiguous,
+ * SPX_CODE_OUT = column outside [1,R] (no such DP cell) */
+#define SPX_CODE_N 4
+#define SPX_CODE_OUT 8
+
+/* per-problem HMM constants, all computed on the host exactly as
+ * probaln_glocal's initialisation does (float/double mix), 16 doubles */
+enum {
+    SPX_H_M0 = 0, /* M->M */
+    SPX_H_M1,     /* M->I */
+    SPX_H_M2,     /* M->D */
+    SPX_H_M3,     /* I->M */
+    SPX_H_M4,     /* I->I */
+    SPX_H_M6,     /* D->M */
+    SPX_H_M8,     /* D->D */
+    SPX_H_BM,
+    SPX_H_BI,
+    SPX_H_SM,
+    SPX_H_SI,
+    SPX_H_EMATCH,
+    SPX_H_EMIS,
+    SPX_H_PAD0,
+    SPX_H_PAD1,
+    SPX_H_PAD2,
+    SPX_H_N
+};
+
+/* One batch of DP problems resident in HBM (structure of arrays). */
+typedef struct spx_dev_batch {
+    /* launch list of one band class: problem ids ordered by (W, L desc), padded
+     * with -1 so that every wave holds problems of one W */
+    const int32_t *order;
+    int32_t n_order;
+    /* per problem */
+    const int64_t *ref_nib; /* nibble index of ref window start in ref4   */
+    const int64_t *qry_nib; /* nibble index of query window start in qry4 */
+    const int32_t *L;       /* query length  */
+    const int32_t *R;       /* ref length    */
+    const int32_t *bw;      /* effective half band width */
+    const double *hmm;      /* [n][SPX_H_N] */
+    const int32_t *row_off; /* first wanted row of the problem */
+    const int32_t *n_rows;
+    const int64_t *s_off;   /* offset into sinv[] (L+2 doubles per problem) */
+    /* pools */
+    const uint8_t *ref4; /* reference, 4-bit codes, low nibble first */
+    const uint8_t *qry4; /* query windows, same packing */
+    /* wanted rows (ascending per problem) */
+    const int32_t *rows;       /* 1-based query row */
+    const int32_t *row_expect; /* ref index (0-based, window-relative) the CIGAR puts this base on */
+    const uint8_t *row_rawq;   /* raw base quality */
+    /* scratch */
+    double *sinv;  /* 1/s[i] per row */
+    double *fsave; /* scaled forward M,I rows at wanted rows: [row][2][slots] */
+    int64_t fsave_stride; /* doubles per wanted row = 2*slots of the class */
+    const int64_t *fsave_off; /* per problem: offset (in doubles) of its first saved row */
+    /* outputs per wanted row */
+    uint8_t *out_bq;    /* min(raw, q) with the CIGAR/MAP consistency check, capped at 93 */
+    int32_t *out_state; /* may be NULL */
+    uint8_t *out_q;     /* may be NULL */
+    const double *qthr; /* [102] phred thresholds on 1 - max/sum */
+} spx_dev_batch;
+
+/* marker table for the scoring kernel: one entry per (position, alignment) */
+typedef struct spx_dev_marker {
+    int32_t row;     /* index into out_bq, or -1: use qfix */
+    uint8_t qfix;    /* quality when row < 0 (raw, or 0 at block edges) */
+    uint8_t is_match;
+    uint8_t aln;
+    uint8_t first_of_pos; /* 1 on the first marker of a read position */
+} spx_dev_marker;
+
+typedef struct spx_dev_groups {
+    int32_t n_groups;
+    const int32_t *mk_first; /* [n_groups+1] */
+    const spx_dev_marker *markers;
+    const uint8_t *n_aln;     /* [n_groups] */
+    const uint16_t *sec_mask; /* bit a set: alignment a is secondary */
+    const uint8_t *out_bq;
+    const double *match_tbl; /* [256] -1*reverse_quality(q)    */
+    const double *mis_tbl;   /* [256] -1*q - 10*log(3)         */
+    int32_t min_q;
+    double prim_margin, min_score;
+    /* outputs */
+    double *score;      /* [n_groups][10] */
+    uint8_t *prim_idx;  /* [n_groups] */
+    uint8_t *max_idx;   /* first secondary with the greatest score */
+    uint16_t *tie_mask; /* secondaries with score >= max */
+    uint8_t *pass;      /* max > prim+margin && max >= min_score */
+} spx_dev_groups;
+
+#endif

@@ -1,0 +1,764 @@
+/*
+ * spx_prep.cpp -- host-side group preparation of the MI355X path.
+ *
+ * Integer bookkeeping that stays on the host (SURVEY.md section 8 rows A1-A8 and the
+ * control flow of A10); everything FP64 per DP cell runs on the device.  Every
+ * alignment's CIGAR+cs is scanned ONCE into a flat op table (the reference
+ * re-runs a regex iterator >= 7 times per alignment); markers, consensus
+ * blocks and the BAQ window list are then derived from the tables.
+ *
+ * Behavioural contract, by reference line (/root/reference/programs):
+ *   op table            submodules/cigar_it/cigar_it.c:14-69,145-211,213-308
+ *   aligned extents     submodules/ptAlignment/ptAlignment.c:42-95
+ *   markers             submodules/ptMarker/ptMarker.c:42-107,156-295
+ *   blocks              submodules/ptMarker/ptMarker.c:328-667, src/secphase.c:162-170
+ *   BAQ windows / rows  submodules/ptMarker/ptMarker.c:670-831
+ *   HMM constants       htslib-1.17 probaln.c initialisation
+ */
+#include "spx_prep.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace spx {
+
+static const unsigned char kNt16Int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};
+
+void HostBatch::clear()
+{
+    ref_nib.clear(); qry_nib.clear(); ref_tid.clear(); ref_rfs.clear(); L.clear(); R.clear(); bw.clear(); row_off.clear(); n_rows.clear();
+    hmm.clear(); rows.clear(); row_expect.clear(); row_rawq.clear(); qry4.clear(); qry_nibbles = 0;
+    grp_index.clear(); mk_first.clear(); markers.clear(); n_aln.clear(); sec_mask.clear(); rfe.clear();
+    grp_problems.clear(); grp_cells.clear(); grp_error.clear(); dp_cells = 0;
+}
+
+template <class T>
+static void cat(std::vector<T> &a, const std::vector<T> &b) { a.insert(a.end(), b.begin(), b.end()); }
+
+void HostBatch::append(const HostBatch &o)
+{
+    const int32_t row_base = (int32_t)rows.size();
+    const int64_t nib_base = qry_nibbles;
+    const int32_t mk_base = (int32_t)markers.size();
+    /* query windows are nibble packed: keep every appended part byte aligned */
+    for (size_t i = 0; i < o.qry_nib.size(); ++i) qry_nib.push_back(o.qry_nib[i] + nib_base);
+    cat(ref_nib, o.ref_nib); cat(ref_tid, o.ref_tid); cat(ref_rfs, o.ref_rfs); cat(L, o.L); cat(R, o.R); cat(bw, o.bw); cat(n_rows, o.n_rows); cat(hmm, o.hmm);
+    for (size_t i = 0; i < o.row_off.size(); ++i) row_off.push_back(o.row_off[i] + row_base);
+    cat(rows, o.rows); cat(row_expect, o.row_expect); cat(row_rawq, o.row_rawq);
+    cat(qry4, o.qry4);
+    qry_nibbles += (int64_t)o.qry4.size() * 2;
+    cat(grp_index, o.grp_index);
+    if (mk_first.empty()) mk_first.push_back(0);
+    for (size_t i = 1; i < o.mk_first.size(); ++i) mk_first.push_back(o.mk_first[i] + mk_base);
+    for (size_t i = 0; i < o.markers.size(); ++i) {
+        spx_dev_marker m = o.markers[i];
+        if (m.row >= 0) m.row += row_base;
+        markers.push_back(m);
+    }
+    cat(n_aln, o.n_aln); cat(sec_mask, o.sec_mask); cat(rfe, o.rfe); cat(grp_problems, o.grp_problems);
+    cat(grp_cells, o.grp_cells);
+    dp_cells += o.dp_cells;
+}
+
+/* ---------------- HMM set-up (host, once per problem) ---------------- */
+void hmm_constants(int l_ref, int l_query, float d, float e, int set_q, double *h)
+{
+    /* the float/double mix below is the one of probaln_glocal's initialisation:
+     * probaln_par_t holds floats, 1 - c->d - c->d and (1 - c->d) / l_ref are float expressions */
+    const double sM = 1. / (2 * l_query + 2), sI = sM;
+    const float qf = (float)pow(10, -set_q / 10.);
+    h[SPX_H_M0] = (double)((1 - d) - d) * (1 - sM);
+    h[SPX_H_M1] = (double)d * (1 - sM);
+    h[SPX_H_M2] = h[SPX_H_M1];
+    h[SPX_H_M3] = (double)(1 - e) * (1 - sI);
+    h[SPX_H_M4] = (double)e * (1 - sI);
+    h[SPX_H_M6] = (double)(1 - e);
+    h[SPX_H_M8] = (double)e;
+    h[SPX_H_BM] = (double)((1 - d) / l_ref);
+    h[SPX_H_BI] = (double)(d / l_ref);
+    h[SPX_H_SM] = sM;
+    h[SPX_H_SI] = sI;
+    h[SPX_H_EMATCH] = 1. - (double)qf;
+    h[SPX_H_EMIS] = (double)qf * .33333333333;
+    h[SPX_H_PAD0] = h[SPX_H_PAD1] = h[SPX_H_PAD2] = 0.;
+}
+
+int effective_bw(int l_ref, int l_query, int bw_in)
+{
+    int bw = l_ref > l_query ? l_ref : l_query;
+    if (bw > bw_in) bw = bw_in;
+    if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);
+    return bw;
+}
+
+int64_t band_cells(int L, int R, int bw)
+{
+    int64_t c = 0;
+    for (int i = 1; i <= L; ++i) {
+        int beg = std::max(1, i - bw), end = std::min(R, i + bw);
+        if (end >= beg) c += end - beg + 1;
+    }
+    return c;
+}
+
+static const int kClassSlots[7] = {48, 64, 128, 256, 512, 1024, 2048};
+int band_class(int W)
+{
+    for (int c = 0; c < 7; ++c)
+        if (W <= kClassSlots[c]) return c;
+    return -1;
+}
+int class_slots(int cls) { return kClassSlots[cls]; }
+
+/* largest x in (0,1] with (int)(-4.343*log(x)+.499) >= k, by bisection on the
+ * double lattice with the HOST libm -- the same log() the reference's CPU path calls */
+static int phred_of(double x) { return (int)(-4.343 * log(x) + .499); }
+void phred_thresholds(double *thr)
+{
+    thr[0] = 1.0;
+    for (int k = 1; k <= 101; ++k) {
+        double lo = 4.9406564584124654e-324, hi = 1.0; /* f(lo) >= k, f(hi) = 0 < k */
+        uint64_t a, b;
+        memcpy(&a, &lo, 8);
+        memcpy(&b, &hi, 8);
+        while (b - a > 1) {
+            uint64_t m = a + (b - a) / 2;
+            double x;
+            memcpy(&x, &m, 8);
+            if (phred_of(x) >= k) a = m; else b = m;
+        }
+        memcpy(&thr[k], &a, 8);
+    }
+}
+
+void score_tables(double *match_tbl, double *mis_tbl)
+{
+    /* calc_alignment_score + reverse_quality, ptMarker.c:298-325 */
+    for (int q = 0; q < 256; ++q) {
+        double rq;
+        if (q >= 93) rq = 0;
+        else if (q == 0) rq = 93;
+        else {
+            double p = 1 - pow(10, (double)q / -10);
+            rq = -10 * log(p);
+        }
+        match_tbl[q] = -1 * rq;
+        mis_tbl[q] = -1 * q - 10 * log(3);
+    }
+}
+
+/* ---------------- per-alignment op table ---------------- */
+struct Op {
+    int32_t op, len, ret;
+    int32_t sqs, sqe, rfs, rfe, rds, rde;
+};
+
+struct Blk {
+    int32_t rfs, rfe, sqs, sqe, rds, rde;
+};
+
+struct Mk {
+    int32_t pos;  /* read_pos_f */
+    int32_t aln;
+    int32_t base_idx;
+    int32_t q;
+    int32_t is_match;
+    int32_t row;  /* wanted-row index (batch global) or -1 */
+};
+
+struct Aln {
+    int32_t rec; /* record index in the batch */
+    uint32_t flag;
+    int32_t tid, pos, l_qseq, n_cigar;
+    bool rev;
+    const uint32_t *cigar;
+    const uint8_t *seq4, *qual;
+    const char *cs;
+    std::vector<Op> ops; /* ops[0] = state before the first step */
+    int32_t n_visit;     /* states a while(next) loop visits: ops[1..n_visit-1] */
+    int32_t rest;        /* state the iterator rests on afterwards */
+    int32_t lclip, rclip;
+    int32_t rfs, rfe, rds, rde;
+    std::vector<Blk> conf, flank;
+    bool have_conf;
+};
+
+static inline bool lower_c(char c) { return c >= 'a' && c <= 'z'; }
+static inline bool digit_c(char c) { return c >= '0' && c <= '9'; }
+
+/* first short-form cs token at or after s (what an un-anchored POSIX search of
+ * (:[0-9]+)|([+-][a-z]+)|((\*[a-z]+)+) returns); 0 if none */
+static inline bool next_cs_token(const char *s, int &so, int &eo)
+{
+    for (int p = 0; s[p]; ++p) {
+        const char c = s[p];
+        if (c == ':') {
+            if (!digit_c(s[p + 1])) continue;
+            int e = p + 1;
+            while (digit_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+        if (c == '+' || c == '-') {
+            if (!lower_c(s[p + 1])) continue;
+            int e = p + 1;
+            while (lower_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+        if (c == '*') {
+            if (!lower_c(s[p + 1])) continue;
+            int e = p;
+            while (s[e] == '*' && lower_c(s[e + 1])) {
+                ++e;
+                while (lower_c(s[e])) ++e;
+            }
+            so = p; eo = e;
+            return true;
+        }
+    }
+    return false;
+}
+
+static int build_ops(Aln &a)
+{
+    a.ops.clear();
+    a.lclip = ((a.cigar[0] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(a.cigar[0] >> 4) : 0;
+    a.rclip = ((a.cigar[a.n_cigar - 1] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(a.cigar[a.n_cigar - 1] >> 4) : 0;
+    if (!a.cs) return SPX_EUNSUPPORTED; /* MD-only records: not supported yet */
+    Op cur;
+    cur.op = 255; cur.len = 0; cur.ret = 0;
+    cur.sqs = 0; cur.sqe = -1;
+    cur.rfs = a.pos; cur.rfe = a.pos - 1;
+    const int32_t T = a.lclip + a.rclip + a.l_qseq;
+    cur.rds = a.rev ? T : 0;
+    cur.rde = a.rev ? T - 1 : -1;
+    a.ops.push_back(cur);
+    int idx = -1, remain = 0, cs_at = 0;
+    while (idx != a.n_cigar - 1) {
+        ++idx;
+        const int op = a.cigar[idx] & 0xf, len = (int)(a.cigar[idx] >> 4);
+        int rd, sq, rf;
+        const bool mtype = op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF;
+        if (mtype || op == SPX_CINS || op == SPX_CDEL) {
+            int so, eo;
+            const char *s = a.cs + cs_at;
+            if (next_cs_token(s, so, eo)) {
+                const char c = s[so];
+                if (c == ':') { cur.op = SPX_CEQUAL; cur.len = atoi(s + so + 1); }
+                else if (c == '*') { cur.op = SPX_CDIFF; cur.len = (eo - so + 1) / 3; }
+                else if (c == '+') { cur.op = SPX_CINS; cur.len = eo - so - 1; }
+                else { cur.op = SPX_CDEL; cur.len = eo - so - 1; }
+                cs_at += eo;
+            }
+        }
+        if (mtype) {
+            if (remain == 0) remain = len;
+            remain -= cur.len;
+            if (remain > 0) --idx; /* stay on this CIGAR op until cs has covered it */
+            rd = sq = rf = cur.len;
+        } else if (op == SPX_CINS) {
+            cur.len = len; cur.op = op;
+            rd = sq = len; rf = 0;
+        } else if (op == SPX_CDEL) {
+            rd = sq = 0; rf = len;
+        } else if (op == SPX_CSOFT_CLIP) {
+            cur.len = len; cur.op = op;
+            rd = sq = len; rf = 0;
+        } else if (op == SPX_CHARD_CLIP) {
+            cur.len = len; cur.op = op;
+            rd = len; sq = 0; rf = 0;
+        } else {
+            return SPX_EUNSUPPORTED; /* N / P / B: undefined in the reference (cigar_it.c:225-291) */
+        }
+        if (a.rev) { cur.rde = cur.rds - 1; cur.rds -= rd; }
+        else { cur.rds = cur.rde + 1; cur.rde += rd; }
+        cur.sqs = cur.sqe + 1; cur.sqe += sq;
+        cur.rfs = cur.rfe + 1; cur.rfe += rf;
+        cur.ret = cur.len;
+        a.ops.push_back(cur);
+        if (a.ops.size() > 40000000u) return SPX_EINVAL;
+    }
+    const int n = (int)a.ops.size();
+    a.n_visit = n;
+    a.rest = n - 1;
+    for (int t = 1; t < n; ++t)
+        if (a.ops[t].ret == 0) { a.n_visit = t; a.rest = t; break; }
+    return 0;
+}
+
+static inline bool mx(int op) { return op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF; }
+
+static void aligned_extents(Aln &a)
+{
+    a.rfs = a.rfe = a.rds = a.rde = -1;
+    for (int t = 1; t < a.n_visit; ++t) {
+        const Op &o = a.ops[t];
+        if (a.rfs == -1 && mx(o.op)) {
+            a.rfs = o.rfs;
+            if (a.rev) a.rde = o.rde; else a.rds = o.rds;
+        }
+        if (a.rfe == -1 && a.rfs != -1 && (o.op == SPX_CHARD_CLIP || o.op == SPX_CSOFT_CLIP)) {
+            a.rfe = o.rfe;
+            if (a.rev) a.rds = o.rde + 1; else a.rde = o.rds - 1;
+        }
+    }
+    const Op &o = a.ops[a.rest];
+    if (a.rfe == -1 && mx(o.op)) {
+        a.rfe = o.rfe;
+        if (a.rev) a.rds = o.rds; else a.rde = o.rde;
+    }
+}
+
+/* ---------------- markers ---------------- */
+static inline bool mk_less(const Mk &x, const Mk &y) { return x.pos != y.pos ? x.pos < y.pos : x.aln < y.aln; }
+
+static Mk match_marker(const Aln &a, int ai, int pos)
+{
+    Mk m;
+    m.pos = pos; m.aln = ai; m.is_match = 1; m.row = -1;
+    m.base_idx = a.rev ? a.l_qseq + a.rclip - pos - 1 : pos - a.lclip;
+    m.q = (m.base_idx >= 0 && m.base_idx < a.l_qseq) ? a.qual[m.base_idx] : 0;
+    return m;
+}
+
+static void collect_markers(std::vector<Aln> &al, int min_q, std::vector<Mk> &mk, std::vector<Mk> &tmp)
+{
+    const int n = (int)al.size();
+    mk.clear();
+    /* mismatch bases with raw quality >= min_q */
+    for (int i = 0; i < n; ++i) {
+        const Aln &a = al[i];
+        for (int t = 1; t < a.n_visit; ++t) {
+            const Op &o = a.ops[t];
+            if (o.op != SPX_CDIFF) continue;
+            for (int j = 0; j < o.len; ++j) {
+                const int q = a.qual[o.sqs + j];
+                if (q < min_q) continue;
+                Mk m;
+                m.aln = i; m.base_idx = o.sqs + j; m.pos = a.rev ? o.rde - j : o.rds + j;
+                m.q = q; m.is_match = 0; m.row = -1;
+                mk.push_back(m);
+            }
+        }
+    }
+    std::sort(mk.begin(), mk.end(), mk_less);
+    /* drop positions where every alignment mismatches; give the others a full column of n markers */
+    tmp.clear();
+    for (size_t s = 0; s < mk.size();) {
+        size_t e = s;
+        while (e < mk.size() && mk[e].pos == mk[s].pos) ++e;
+        if ((int)(e - s) != n) {
+            size_t k = s;
+            for (int ai = 0; ai < n; ++ai) {
+                if (k < e && mk[k].aln == ai) tmp.push_back(mk[k++]);
+                else tmp.push_back(match_marker(al[ai], ai, mk[s].pos));
+            }
+        }
+        s = e;
+    }
+    mk.swap(tmp);
+    /* positions inside an insertion / clip of any alignment are not comparable: drop the column */
+    if (mk.empty()) return;
+    const int ncol = (int)mk.size() / n;
+    std::vector<char> keep(ncol, 1);
+    for (int i = 0; i < n; ++i) {
+        const Aln &a = al[i];
+        int col = a.rev ? ncol - 1 : 0;
+        const int step = a.rev ? -1 : 1;
+        for (int t = 1; t < a.n_visit && col >= 0 && col < ncol; ++t) {
+            const Op &o = a.ops[t];
+            while (col >= 0 && col < ncol) {
+                const int p = mk[(size_t)col * n].pos;
+                if (!(o.rds <= p && p <= o.rde)) break;
+                if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) keep[col] = 0;
+                col += step;
+            }
+        }
+    }
+    tmp.clear();
+    for (int c = 0; c < ncol; ++c)
+        if (keep[c])
+            for (int i = 0; i < n; ++i) tmp.push_back(mk[(size_t)c * n + i]);
+    mk.swap(tmp);
+}
+
+/* ---------------- blocks ---------------- */
+static void confident_blocks(Aln &a, int thr)
+{
+    a.conf.clear();
+    int c_sqs = 0, c_rfs = a.pos;
+    int c_rd = a.rev ? a.ops[0].rde : a.ops[0].rds;
+    auto emit = [&](const Op &o) {
+        Blk b;
+        b.rfs = c_rfs; b.rfe = o.rfs - 1; b.sqs = c_sqs; b.sqe = o.sqs - 1;
+        if (a.rev) { b.rds = o.rde + 1; b.rde = c_rd; } else { b.rds = c_rd; b.rde = o.rds - 1; }
+        a.conf.push_back(b);
+    };
+    for (int t = 1; t < a.n_visit; ++t) {
+        const Op &o = a.ops[t];
+        const bool indel = o.op == SPX_CINS || o.op == SPX_CDEL;
+        const bool clip = o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP;
+        if (!(indel || clip)) continue;
+        if (indel && o.len <= thr) continue;
+        if (c_sqs < o.sqs && c_rfs < o.rfs) emit(o);
+        c_sqs = o.sqe + 1;
+        c_rfs = o.rfe + 1;
+        c_rd = a.rev ? o.rds - 1 : o.rde + 1;
+    }
+    const Op &o = a.ops[a.rest];
+    if (c_sqs <= o.sqe) {
+        Blk b;
+        b.rfs = c_rfs; b.rfe = o.rfe; b.sqs = c_sqs; b.sqe = o.sqe;
+        if (a.rev) { b.rds = o.rds; b.rde = c_rd; } else { b.rds = c_rd; b.rde = o.rde; }
+        a.conf.push_back(b);
+    }
+    a.have_conf = true;
+}
+
+static void flank_blocks(Aln &a, const std::vector<Mk> &mk, int margin)
+{
+    a.flank.clear();
+    int start = std::max(a.rds, mk[0].pos - margin), end = std::min(a.rde, mk[0].pos + margin);
+    for (size_t i = 1; i < mk.size(); ++i) {
+        const int cs = std::max(a.rds, mk[i].pos - margin), ce = std::min(a.rde, mk[i].pos + margin);
+        if (cs < end) end = ce;
+        else {
+            Blk b = {-1, -1, -1, -1, start, end};
+            a.flank.push_back(b);
+            start = cs; end = ce;
+        }
+    }
+    Blk b = {-1, -1, -1, -1, start, end};
+    a.flank.push_back(b);
+}
+
+static void intersect(const std::vector<Blk> &x, const std::vector<Blk> &y, std::vector<Blk> &out)
+{
+    out.clear();
+    if (x.empty() || y.empty()) return;
+    size_t j = 0;
+    for (size_t i = 0; i < x.size(); ++i) {
+        while (j < y.size() && y[j].rde < x[i].rds) ++j;
+        while (j < y.size() && y[j].rds < x[i].rde) {
+            Blk b = {-1, -1, -1, -1, std::max(x[i].rds, y[j].rds), std::min(x[i].rde, y[j].rde)};
+            out.push_back(b);
+            if (y[j].rde <= x[i].rde) ++j; else break;
+        }
+    }
+}
+
+static inline bool by_rds(const Blk &x, const Blk &y) { return x.rds < y.rds; }
+static inline bool by_sqs(const Blk &x, const Blk &y) { return x.sqs < y.sqs; }
+
+/* consensus windows in read coordinates, then projected onto each alignment */
+static int consensus_blocks(std::vector<Aln> &al, int thr, std::vector<Blk> &cur, std::vector<Blk> &nxt)
+{
+    const int n = (int)al.size();
+    std::sort(al[0].conf.begin(), al[0].conf.end(), by_rds);
+    cur = al[0].conf;
+    for (int i = 1; i < n; ++i) {
+        std::sort(al[i].conf.begin(), al[i].conf.end(), by_rds);
+        intersect(cur, al[i].conf, nxt);
+        cur.swap(nxt);
+    }
+    for (int i = 0; i < n; ++i) {
+        std::sort(al[i].flank.begin(), al[i].flank.end(), by_rds);
+        intersect(cur, al[i].flank, nxt);
+        cur.swap(nxt);
+    }
+    if (cur.empty()) {
+        for (int i = 0; i < n; ++i) al[i].conf.clear();
+        return 0;
+    }
+    const int nb = (int)cur.size();
+    for (int i = 0; i < n; ++i) {
+        Aln &a = al[i];
+        std::vector<Blk> &out = nxt;
+        out.clear();
+        const bool rev = a.rev;
+        int j = rev ? nb - 1 : 0;
+        bool have = true, del_flag = false;
+        int bs = rev ? -cur[j].rde : cur[j].rds, be = rev ? -cur[j].rds : cur[j].rde;
+        int rfs = -1, rfe = -1, sqs = -1, sqe = -1;
+        for (int t = 1; t < a.n_visit; ++t) {
+            const Op &o = a.ops[t];
+            const int cs = rev ? -o.rde : o.rds, ce = rev ? -o.rds : o.rde;
+            if (mx(o.op) || o.op == SPX_CINS) {
+                const bool ins = o.op == SPX_CINS;
+                while (have && be <= ce) {
+                    if (cs <= bs && !(del_flag && cs == bs)) {
+                        rfs = ins ? o.rfs : o.rfs + (bs - cs);
+                        sqs = o.sqs + (bs - cs);
+                    }
+                    rfe = ins ? o.rfe : o.rfs + (be - cs);
+                    sqe = o.sqs + (be - cs);
+                    Blk b = {rfs, rfe, sqs, sqe, cur[j].rds, cur[j].rde};
+                    out.push_back(b);
+                    if (rev && j > 0) { --j; bs = -cur[j].rde; be = -cur[j].rds; }
+                    else if (!rev && j < nb - 1) { ++j; bs = cur[j].rds; be = cur[j].rde; }
+                    else have = false;
+                }
+                if (!have) break;
+                if (cs <= bs && bs <= ce && !(del_flag && cs == bs)) {
+                    rfs = ins ? o.rfs : o.rfs + (bs - cs);
+                    sqs = o.sqs + (bs - cs);
+                }
+                del_flag = false;
+            } else if (o.op == SPX_CDEL) {
+                if (have && bs == cs && o.len <= thr) {
+                    del_flag = true;
+                    rfs = o.rfs;
+                    sqs = o.sqs;
+                }
+            }
+        }
+        std::sort(out.begin(), out.end(), by_sqs);
+        a.conf = out;
+    }
+    return nb;
+}
+
+static bool blocks_too_long(const std::vector<Aln> &al, int thr)
+{
+    bool flag = false;
+    for (size_t j = 0; j < al.size(); ++j) {
+        if (!al[j].have_conf || al[j].conf.empty()) return true;
+        for (const Blk &b : al[j].conf)
+            if ((b.sqe - b.sqs) > thr || (b.rfe - b.rfs) > thr) flag = true;
+    }
+    return flag;
+}
+
+/* ---------------- BAQ windows of one alignment ---------------- */
+struct GroupScratch {
+    std::vector<Aln> al;
+    std::vector<Mk> mk, mtmp;
+    std::vector<Blk> b1, b2;
+    std::vector<int32_t> own;      /* indices into mk of this alignment's markers, in seq order */
+    std::vector<int32_t> rows_t, rows_mk;
+};
+
+static int plan_baq(const Aln &a, int ai, const std::vector<Mk> &mkc, std::vector<Mk> &mk, const RefIndex &ref,
+                    const spx_params *par, GroupScratch &S, HostBatch &out, int &n_prob, int64_t &cells)
+{
+    const int nm = (int)mkc.size();
+    const int step = a.rev ? -1 : 1;
+    int j = a.rev ? nm - 1 : 0;
+    int ci = 0;
+    const int margin = 10;
+    const int last = (int)a.ops.size() - 1;
+    auto adv = [&]() -> int { if (ci < last) { ++ci; return a.ops[ci].ret; } return 0; };
+    const float d = (float)par->conf_d, e = (float)par->conf_e;
+    for (size_t bi = 0; bi < a.conf.size(); ++bi) {
+        const Blk &b = a.conf[bi];
+        while (a.ops[ci].sqe < b.sqs || a.ops[ci].rfe < b.rfs)
+            if (adv() == 0) break;
+        /* markers of this alignment in the leading margin lose their quality */
+        while (j >= 0 && j < nm && (mk[j].base_idx < b.sqs + margin || mk[j].aln != ai)) {
+            if (mk[j].aln == ai && b.sqs <= mk[j].base_idx) { mk[j].q = 0; mk[j].row = -1; }
+            j += step;
+        }
+        if (j >= 0 && j < nm && mk[j].base_idx <= b.sqe - margin && b.sqs + margin <= mk[j].base_idx) {
+            const int L = b.sqe - b.sqs + 1, R = b.rfe - b.rfs + 1;
+            if (L <= 0 || R <= 0) return SPX_EINVAL;
+            if (b.rfs < 0 || b.rfe >= ref.len[a.tid]) return SPX_EINVAL;
+            const int bw_in = (int)(abs(R - L) + par->conf_b);
+            const int bw = effective_bw(R, L, bw_in);
+            if (band_class(2 * bw + 1) < 0) return SPX_EUNSUPPORTED;
+            /* wanted rows: this alignment's markers in [sqs+margin, sqe-margin) keep a BAQ value */
+            S.rows_t.clear(); S.rows_mk.clear();
+            for (int k = j; k >= 0 && k < nm; k += step) {
+                if (mk[k].aln != ai) continue;
+                if (mk[k].base_idx > b.sqe) break;
+                const int t = mk[k].base_idx - b.sqs;
+                if (t >= margin && t < L - margin) { S.rows_t.push_back(t); S.rows_mk.push_back(k); }
+            }
+            const int32_t row0 = (int32_t)out.rows.size();
+            for (size_t w = 0; w < S.rows_t.size(); ++w) {
+                out.rows.push_back(S.rows_t[w] + 1);
+                out.row_expect.push_back(-1);
+                out.row_rawq.push_back(a.qual[b.sqs + S.rows_t[w]]);
+            }
+            /* expected reference index of every wanted base, from the CIGAR walk of the write-back loop */
+            std::vector<char> covered(S.rows_t.size(), 0);
+            while (a.ops[ci].sqs <= b.sqe || a.ops[ci].rfs <= b.rfe) {
+                const Op &o = a.ops[ci];
+                int x = o.rfs - b.rfs, y = o.sqs - b.sqs;
+                if (x < 0) x = 0;
+                if (y < 0) y = 0;
+                if (mx(o.op)) {
+                    const int len = std::min(o.len, std::min(o.sqe, b.sqe) - std::max(o.sqs, b.sqs) + 1);
+                    for (size_t w = 0; w < S.rows_t.size(); ++w) {
+                        const int t = S.rows_t[w];
+                        if (t >= y && t < y + len) { out.row_expect[row0 + w] = x + (t - y); covered[w] = 1; }
+                    }
+                }
+                if (o.sqe <= b.sqe || o.rfe <= b.rfe) { if (adv() == 0) break; }
+                else break;
+            }
+            for (size_t w = 0; w < S.rows_t.size(); ++w) {
+                Mk &m = mk[S.rows_mk[w]];
+                if (covered[w]) m.row = row0 + (int32_t)w;
+                else { m.row = -1; m.q = par->set_q < 94 ? par->set_q : 93; } /* base not under an M op: keeps set_q */
+            }
+            /* the problem itself */
+            out.ref_nib.push_back(ref.nib_off[a.tid] + b.rfs);
+            out.ref_tid.push_back(a.tid);
+            out.ref_rfs.push_back(b.rfs);
+            out.qry_nib.push_back(out.qry_nibbles);
+            out.L.push_back(L); out.R.push_back(R); out.bw.push_back(bw);
+            out.row_off.push_back(row0);
+            out.n_rows.push_back((int32_t)S.rows_t.size());
+            out.hmm.resize(out.hmm.size() + SPX_H_N);
+            hmm_constants(R, L, d, e, par->set_q, &out.hmm[out.hmm.size() - SPX_H_N]);
+            {
+                const size_t nb = (size_t)(L + 1) / 2, at = out.qry4.size();
+                out.qry4.resize(at + nb, 0);
+                for (int k = 0; k < L; ++k) {
+                    const int p = b.sqs + k;
+                    const unsigned code = kNt16Int[(a.seq4[p >> 1] >> ((~p & 1) << 2)) & 0xf];
+                    out.qry4[at + (k >> 1)] |= (uint8_t)(code << ((k & 1) << 2));
+                }
+                out.qry_nibbles += (int64_t)nb * 2;
+            }
+            ++n_prob;
+            cells += band_cells(L, R, bw);
+        }
+        /* markers in the trailing margin lose their quality */
+        while (j >= 0 && j < nm && ((mk[j].base_idx <= b.sqe && mk[j].aln == ai) || mk[j].aln != ai)) {
+            if (b.sqe - margin <= mk[j].base_idx && mk[j].aln == ai) { mk[j].q = 0; mk[j].row = -1; }
+            j += step;
+        }
+    }
+    (void)mkc;
+    return 0;
+}
+
+static int group_records(const spx_batch *bt, int g, int *rec)
+{
+    int n = 0;
+    for (int a = bt->grp_first[g]; a < bt->grp_first[g + 1]; ++a) {
+        if (bt->flag[a] & SPX_FUNMAP) continue;
+        if (n > 10) continue;
+        rec[n++] = a;
+    }
+    return n;
+}
+
+static bool dispatched(const spx_batch *bt, int g)
+{
+    int rec[16], n = group_records(bt, g, rec), supp = 0, prim = 0;
+    for (int i = 0; i < n; ++i) {
+        if (bt->flag[rec[i]] & SPX_FSUPPLEMENTARY) ++supp;
+        if (!(bt->flag[rec[i]] & SPX_FSECONDARY)) ++prim;
+    }
+    return n > 1 && n <= 10 && supp == 0 && prim == 1;
+}
+
+static int prepare_one(const spx_batch *bt, const RefIndex &ref, const spx_params *par, int g, GroupScratch &S,
+                       HostBatch &out)
+{
+    int rec[16];
+    const int n = group_records(bt, g, rec);
+    S.al.resize(n);
+    uint16_t sec = 0;
+    for (int i = 0; i < n; ++i) {
+        Aln &a = S.al[i];
+        const int r = rec[i];
+        a.rec = r; a.flag = bt->flag[r]; a.tid = bt->tid[r]; a.pos = bt->pos[r]; a.l_qseq = bt->l_qseq[r];
+        a.n_cigar = bt->n_cigar[r];
+        a.rev = (a.flag & SPX_FREVERSE) != 0;
+        a.cigar = bt->cigar + bt->cigar_off[r];
+        a.seq4 = bt->seq4 + bt->seq_off[r];
+        a.qual = bt->qual + bt->qual_off[r];
+        a.cs = bt->cs_off[r] >= 0 ? bt->cs + bt->cs_off[r] : nullptr;
+        a.conf.clear(); a.flank.clear(); a.have_conf = false;
+        if (a.n_cigar <= 0) return SPX_EINVAL;
+        if (a.tid < 0 || (size_t)a.tid >= ref.len.size()) return SPX_EINVAL;
+        int rc = build_ops(a);
+        if (rc) return rc;
+        aligned_extents(a);
+        if (a.flag & SPX_FSECONDARY) sec |= (uint16_t)(1u << i);
+    }
+    collect_markers(S.al, par->min_q, S.mk, S.mtmp);
+    /* snapshot of the state this group appends to, so a failing group leaves nothing behind */
+    const size_t s_prob = out.L.size(), s_rows = out.rows.size(), s_q = out.qry4.size(), s_hmm = out.hmm.size();
+    const int64_t s_nib = out.qry_nibbles;
+    int n_prob = 0;
+    int64_t cells = 0;
+    bool scored = false;
+    if (!S.mk.empty()) {
+        int margin = par->flank_margin, nblk = 1 /* see DESIGN.md U1 */, iter = 0;
+        for (Aln &a : S.al) confident_blocks(a, par->indel_threshold);
+        while (par->consensus && blocks_too_long(S.al, 1000)) {
+            margin = (int)(margin * 0.8);
+            for (Aln &a : S.al) flank_blocks(a, S.mk, margin);
+            nblk = consensus_blocks(S.al, par->indel_threshold, S.b1, S.b2);
+            if (nblk == 0) break;
+            if (++iter >= 64) break;
+        }
+        if (nblk > 0 || !par->consensus) {
+            scored = true;
+            if (par->baq_flag) {
+                for (int i = 0; i < n; ++i) {
+                    int rc = plan_baq(S.al[i], i, S.mk, S.mk, ref, par, S, out, n_prob, cells);
+                    if (rc) {
+                        out.ref_nib.resize(s_prob); out.ref_tid.resize(s_prob); out.ref_rfs.resize(s_prob);
+                        out.qry_nib.resize(s_prob); out.L.resize(s_prob);
+                        out.R.resize(s_prob); out.bw.resize(s_prob); out.row_off.resize(s_prob);
+                        out.n_rows.resize(s_prob); out.hmm.resize(s_hmm); out.rows.resize(s_rows);
+                        out.row_expect.resize(s_rows); out.row_rawq.resize(s_rows); out.qry4.resize(s_q);
+                        out.qry_nibbles = s_nib;
+                        return rc;
+                    }
+                }
+            }
+        }
+    }
+    /* marker table for the scoring kernel (empty when the group is not scored) */
+    out.grp_index.push_back(g);
+    if (out.mk_first.empty()) out.mk_first.push_back(0);
+    if (scored) {
+        for (size_t k = 0; k < S.mk.size(); ++k) {
+            const Mk &m = S.mk[k];
+            spx_dev_marker dm;
+            dm.row = m.row;
+            dm.qfix = (uint8_t)m.q;
+            dm.is_match = (uint8_t)m.is_match;
+            dm.aln = (uint8_t)m.aln;
+            dm.first_of_pos = (k == 0 || S.mk[k - 1].pos != m.pos) ? 1 : 0;
+            out.markers.push_back(dm);
+        }
+    }
+    out.mk_first.push_back((int32_t)out.markers.size());
+    out.n_aln.push_back((uint8_t)n);
+    out.sec_mask.push_back(sec);
+    for (int i = 0; i < 10; ++i) out.rfe.push_back(i < n ? S.al[i].rfe : 0);
+    out.grp_problems.push_back(n_prob);
+    out.grp_cells.push_back(cells);
+    out.dp_cells += cells;
+    return 0;
+}
+
+int prepare_groups(const spx_batch *bt, const RefIndex &ref, const spx_params *par, int32_t g0, int32_t g1,
+                   HostBatch &out)
+{
+    GroupScratch S;
+    out.clear();
+    out.grp_error.assign(g1 - g0, 0);
+    out.mk_first.push_back(0);
+    for (int g = g0; g < g1; ++g) {
+        if (!dispatched(bt, g)) { out.grp_error[g - g0] = 1; continue; }
+        int rc = prepare_one(bt, ref, par, g, S, out);
+        if (rc) out.grp_error[g - g0] = rc;
+    }
+    return 0;
+}
+
+} // namespace spx
+
+extern "C" int spx_group_is_dispatched(const spx_batch *bt, int32_t g) { return spx::dispatched(bt, g) ? 1 : 0; }

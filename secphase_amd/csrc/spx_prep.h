@@ -1,0 +1,63 @@
+/*
+ * spx_prep.h -- host-side preparation of a batch of alignment groups for the
+ * device: CIGAR/cs walk, markers, consensus blocks, and the list of banded
+ * DP problems + the marker table the scoring kernel consumes.  Internal.
+ */
+#ifndef SPX_PREP_H
+#define SPX_PREP_H
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/spx.h"
+#include "spx_device.h"
+
+namespace spx {
+
+struct HostBatch {
+    /* DP problems */
+    std::vector<int64_t> ref_nib, qry_nib;
+    std::vector<int32_t> ref_tid, ref_rfs; /* where the ref window lies (debug / host-plan view) */
+    std::vector<int32_t> L, R, bw, row_off, n_rows;
+    std::vector<double> hmm; /* SPX_H_N per problem */
+    std::vector<int32_t> rows, row_expect;
+    std::vector<uint8_t> row_rawq;
+    std::vector<uint8_t> qry4; /* 4-bit codes, low nibble first */
+    int64_t qry_nibbles = 0;
+    /* dispatched groups */
+    std::vector<int32_t> grp_index; /* index in the input batch */
+    std::vector<int32_t> mk_first;  /* per dispatched group (+1) */
+    std::vector<spx_dev_marker> markers;
+    std::vector<uint8_t> n_aln;
+    std::vector<uint16_t> sec_mask;
+    std::vector<int32_t> rfe;       /* 10 per dispatched group */
+    std::vector<int32_t> grp_problems;
+    std::vector<int64_t> grp_cells;
+    std::vector<int32_t> grp_error; /* per input group: 0 or SPX_E* */
+    int64_t dp_cells = 0;
+
+    void clear();
+    void append(const HostBatch &o);
+};
+
+/* nibble offset of every contig inside the device reference pool */
+struct RefIndex {
+    std::vector<int64_t> nib_off; /* [n_contigs] first nibble of each contig (byte aligned) */
+    std::vector<int64_t> len;     /* [n_contigs] bases */
+};
+
+/* prepares groups [g0,g1) of bt */
+int prepare_groups(const spx_batch *bt, const RefIndex &ref, const spx_params *par, int32_t g0, int32_t g1,
+                   HostBatch &out);
+
+void hmm_constants(int l_ref, int l_query, float d, float e, int set_q, double *h /* SPX_H_N */);
+int effective_bw(int l_ref, int l_query, int bw_in);
+int64_t band_cells(int L, int R, int bw_eff);
+int band_class(int W); /* index into the (G,C) table, -1 if too wide */
+int class_slots(int cls);
+void phred_thresholds(double *thr /* 102 */);
+void score_tables(double *match_tbl /*256*/, double *mis_tbl /*256*/);
+
+} // namespace spx
+#endif

@@ -1,0 +1,690 @@
+/*
+ * spx_runtime.cpp -- C-ABI (include/spx.h) over the HIP kernels: device
+ * context, HBM-resident reference, batch upload, launches, collection,
+ * decision replay and the relabel-list writer.
+ *
+ * The product path has no CPU fallback: every scoring entry point needs a
+ * live gfx950 device and fails with SPX_ENODEVICE / SPX_EHIP otherwise.
+ */
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/spx.h"
+#include "spx_device.h"
+#include "spx_prep.h"
+
+extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st);
+extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, hipStream_t st);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(SPX_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static const unsigned char kNt16Table[256] = {
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 1,  2,  4,  8,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 0,  15, 15, 15, 1,  14, 2,  13, 15, 15, 4,  11, 15, 15, 12, 15, 3,
+    15, 15, 15, 15, 5,  6,  8,  15, 7,  9,  15, 10, 15, 15, 15, 15, 15, 15, 15, 1,  14, 2,  13, 15, 15, 4,
+    11, 15, 15, 12, 15, 3,  15, 15, 15, 15, 5,  6,  8,  15, 7,  9,  15, 10, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15,
+    15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};
+static const unsigned char kNt16Int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};
+
+struct spx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t *d_ref4 = nullptr;
+    int64_t ref_bytes = 0;
+    spx::RefIndex ref;
+    double *d_tables = nullptr; /* qthr[102] | match[256] | mis[256] */
+    /* a tiny private reference pool for spx_probaln_batch */
+};
+
+struct spx_work {
+    spx::HostBatch hb;
+    int32_t n_groups_in = 0;
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    spx_dev_batch cls_batch[7];
+    int cls_used[7] = {0, 0, 0, 0, 0, 0, 0};
+    spx_dev_groups dg;
+    bool have_groups = false;
+    /* device output mirrors */
+    double *d_score = nullptr;
+    uint8_t *d_prim = nullptr, *d_max = nullptr, *d_pass = nullptr;
+    uint16_t *d_tie = nullptr;
+    uint8_t *d_bq = nullptr, *d_q = nullptr;
+    int32_t *d_state = nullptr;
+    spx_stats st;
+    spx_params par;
+    bool launched = false;
+};
+
+extern "C" const char *spx_strerror(int code)
+{
+    switch (code) {
+    case SPX_OK: return "ok";
+    case SPX_ENODEVICE: return "no usable HIP device (gfx950 required, no CPU fallback)";
+    case SPX_EHIP: return "HIP runtime error";
+    case SPX_EINVAL: return "invalid argument";
+    case SPX_ENOMEM: return "out of memory";
+    case SPX_EUNSUPPORTED: return "construct left undefined by the reference / not supported";
+    case SPX_ENOREF: return "reference not set";
+    default: return "unknown error";
+    }
+}
+extern "C" const char *spx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int spx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int spx_create(int device, spx_ctx **out)
+{
+    if (!out) return fail(SPX_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SPX_ENODEVICE, "hipGetDeviceCount found no device");
+    if (device < 0 || device >= n) return fail(SPX_ENODEVICE, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SPX_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    spx_ctx *c = new spx_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    {
+        std::vector<double> t(102 + 512);
+        spx::phred_thresholds(t.data());
+        spx::score_tables(t.data() + 102, t.data() + 102 + 256);
+        HIPCHK(hipMalloc((void **)&c->d_tables, t.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(c->d_tables, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    *out = c;
+    return SPX_OK;
+}
+
+extern "C" void spx_destroy(spx_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->d_ref4) hipFree(c->d_ref4);
+    if (c->d_tables) hipFree(c->d_tables);
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int spx_set_reference(spx_ctx *c, const spx_ref *ref)
+{
+    if (!c || !ref) return fail(SPX_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    const int nc = ref->n_contigs;
+    c->ref.nib_off.assign(nc, 0);
+    c->ref.len.assign(nc, 0);
+    int64_t nib = 0;
+    for (int i = 0; i < nc; ++i) {
+        c->ref.nib_off[i] = nib;
+        c->ref.len[i] = ref->seq_off[i + 1] - ref->seq_off[i];
+        nib += (c->ref.len[i] + 1) & ~(int64_t)1; /* every contig starts on a byte boundary */
+    }
+    std::vector<uint8_t> packed((size_t)(nib / 2) + 16, 0);
+    unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    auto work = [&](unsigned tid) {
+        for (int i = (int)tid; i < nc; i += (int)nthr) {
+            const char *s = ref->bases + ref->seq_off[i];
+            uint8_t *d = packed.data() + c->ref.nib_off[i] / 2;
+            const int64_t len = c->ref.len[i];
+            for (int64_t k = 0; k + 1 < len; k += 2)
+                d[k >> 1] = (uint8_t)(kNt16Int[kNt16Table[(unsigned char)s[k]]] |
+                                      (kNt16Int[kNt16Table[(unsigned char)s[k + 1]]] << 4));
+            if (len & 1) d[len >> 1] = kNt16Int[kNt16Table[(unsigned char)s[len - 1]]];
+        }
+    };
+    for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+    if (c->d_ref4) { hipFree(c->d_ref4); c->d_ref4 = nullptr; }
+    c->ref_bytes = (int64_t)packed.size();
+    HIPCHK(hipMalloc((void **)&c->d_ref4, packed.size()));
+    HIPCHK(hipMemcpy(c->d_ref4, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    return SPX_OK;
+}
+
+/* ------------------------------------------------------------------ */
+struct Carver {
+    size_t off = 0;
+    template <class T>
+    size_t take(size_t n)
+    {
+        off = (off + 255) & ~(size_t)255;
+        size_t at = off;
+        off += n * sizeof(T);
+        return at;
+    }
+};
+
+static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
+{
+    spx::HostBatch &hb = w->hb;
+    const size_t np = hb.L.size(), nr = hb.rows.size(), ng = hb.grp_index.size(), nm = hb.markers.size();
+    /* per-class launch order: (W, L desc), each W padded to whole waves */
+    static const int kG[7] = {4, 4, 8, 16, 32, 64, 64};
+    std::vector<int32_t> order[7];
+    std::vector<int32_t> ids[7];
+    for (size_t p = 0; p < np; ++p) {
+        int cls = spx::band_class(2 * hb.bw[p] + 1);
+        ids[cls].push_back((int32_t)p);
+    }
+    for (int cls = 0; cls < 7; ++cls) {
+        auto &v = ids[cls];
+        w->st.problems_per_class[cls] = (int64_t)v.size();
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end(), [&](int32_t a, int32_t b) {
+            if (hb.bw[a] != hb.bw[b]) return hb.bw[a] < hb.bw[b];
+            if (hb.L[a] != hb.L[b]) return hb.L[a] > hb.L[b];
+            return a < b;
+        });
+        const int ppw = 64 / kG[cls];
+        for (size_t i = 0; i < v.size();) {
+            size_t j = i;
+            while (j < v.size() && hb.bw[v[j]] == hb.bw[v[i]]) ++j;
+            for (size_t k = i; k < j; ++k) order[cls].push_back(v[k]);
+            while (order[cls].size() % ppw) order[cls].push_back(-1);
+            i = j;
+        }
+    }
+    /* scratch offsets */
+    std::vector<int64_t> s_off(np), fsave_off(np);
+    int64_t s_tot = 0, f_tot = 0;
+    for (size_t p = 0; p < np; ++p) {
+        s_off[p] = s_tot;
+        s_tot += hb.L[p] + 2;
+        fsave_off[p] = f_tot;
+        f_tot += (int64_t)hb.n_rows[p] * 2 * spx::class_slots(spx::band_class(2 * hb.bw[p] + 1));
+    }
+    /* arena layout */
+    Carver cv;
+    size_t o_ref_nib = cv.take<int64_t>(np), o_qry_nib = cv.take<int64_t>(np), o_L = cv.take<int32_t>(np),
+           o_R = cv.take<int32_t>(np), o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N),
+           o_row_off = cv.take<int32_t>(np), o_n_rows = cv.take<int32_t>(np), o_s_off = cv.take<int64_t>(np),
+           o_fs_off = cv.take<int64_t>(np), o_qry4 = cv.take<uint8_t>(hb.qry4.size() + 16),
+           o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr), o_rawq = cv.take<uint8_t>(nr);
+    size_t o_order[7];
+    for (int cls = 0; cls < 7; ++cls) o_order[cls] = cv.take<int32_t>(order[cls].size());
+    size_t o_mk_first = cv.take<int32_t>(ng + 1), o_markers = cv.take<spx_dev_marker>(nm), o_naln = cv.take<uint8_t>(ng),
+           o_sec = cv.take<uint16_t>(ng);
+    const size_t in_bytes = cv.off;
+    size_t o_sinv = cv.take<double>((size_t)s_tot), o_fsave = cv.take<double>((size_t)f_tot),
+           o_bq = cv.take<uint8_t>(nr + 16), o_state = want_state_q ? cv.take<int32_t>(nr) : 0,
+           o_q = want_state_q ? cv.take<uint8_t>(nr + 16) : 0, o_score = cv.take<double>(ng * 10),
+           o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
+           o_tie = cv.take<uint16_t>(ng);
+    w->arena_bytes = cv.off + 256;
+    HIPCHK(hipMalloc(&w->arena, w->arena_bytes));
+    char *base = (char *)w->arena;
+    double t0 = now_s();
+#define UP(off, vec)                                                                                         \
+    if (!(vec).empty())                                                                                      \
+    HIPCHK(hipMemcpyAsync(base + (off), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, \
+                          c->stream))
+    UP(o_ref_nib, hb.ref_nib); UP(o_qry_nib, hb.qry_nib); UP(o_L, hb.L); UP(o_R, hb.R); UP(o_bw, hb.bw);
+    UP(o_hmm, hb.hmm); UP(o_row_off, hb.row_off); UP(o_n_rows, hb.n_rows); UP(o_s_off, s_off); UP(o_fs_off, fsave_off);
+    UP(o_qry4, hb.qry4); UP(o_rows, hb.rows); UP(o_expect, hb.row_expect); UP(o_rawq, hb.row_rawq);
+    for (int cls = 0; cls < 7; ++cls) UP(o_order[cls], order[cls]);
+    UP(o_mk_first, hb.mk_first); UP(o_markers, hb.markers); UP(o_naln, hb.n_aln); UP(o_sec, hb.sec_mask);
+#undef UP
+    HIPCHK(hipStreamSynchronize(c->stream));
+    w->st.h2d_seconds = now_s() - t0;
+    w->st.bytes_h2d = (int64_t)in_bytes;
+    w->d_bq = (uint8_t *)(base + o_bq);
+    w->d_state = want_state_q ? (int32_t *)(base + o_state) : nullptr;
+    w->d_q = want_state_q ? (uint8_t *)(base + o_q) : nullptr;
+    w->d_score = (double *)(base + o_score);
+    w->d_prim = (uint8_t *)(base + o_prim);
+    w->d_max = (uint8_t *)(base + o_max);
+    w->d_pass = (uint8_t *)(base + o_pass);
+    w->d_tie = (uint16_t *)(base + o_tie);
+    for (int cls = 0; cls < 7; ++cls) {
+        spx_dev_batch &B = w->cls_batch[cls];
+        memset(&B, 0, sizeof B);
+        w->cls_used[cls] = !order[cls].empty();
+        B.order = (const int32_t *)(base + o_order[cls]);
+        B.n_order = (int32_t)order[cls].size();
+        B.ref_nib = (const int64_t *)(base + o_ref_nib);
+        B.qry_nib = (const int64_t *)(base + o_qry_nib);
+        B.L = (const int32_t *)(base + o_L);
+        B.R = (const int32_t *)(base + o_R);
+        B.bw = (const int32_t *)(base + o_bw);
+        B.hmm = (const double *)(base + o_hmm);
+        B.row_off = (const int32_t *)(base + o_row_off);
+        B.n_rows = (const int32_t *)(base + o_n_rows);
+        B.s_off = (const int64_t *)(base + o_s_off);
+        B.ref4 = c->d_ref4;
+        B.qry4 = (const uint8_t *)(base + o_qry4);
+        B.rows = (const int32_t *)(base + o_rows);
+        B.row_expect = (const int32_t *)(base + o_expect);
+        B.row_rawq = (const uint8_t *)(base + o_rawq);
+        B.sinv = (double *)(base + o_sinv);
+        B.fsave = (double *)(base + o_fsave);
+        B.fsave_stride = 2 * spx::class_slots(cls);
+        B.fsave_off = (const int64_t *)(base + o_fs_off);
+        B.out_bq = w->d_bq;
+        B.out_state = w->d_state;
+        B.out_q = w->d_q;
+        B.qthr = c->d_tables;
+    }
+    spx_dev_groups &G = w->dg;
+    memset(&G, 0, sizeof G);
+    G.n_groups = (int32_t)ng;
+    G.mk_first = (const int32_t *)(base + o_mk_first);
+    G.markers = (const spx_dev_marker *)(base + o_markers);
+    G.n_aln = (const uint8_t *)(base + o_naln);
+    G.sec_mask = (const uint16_t *)(base + o_sec);
+    G.out_bq = w->d_bq;
+    G.match_tbl = c->d_tables + 102;
+    G.mis_tbl = c->d_tables + 102 + 256;
+    G.min_q = w->par.min_q;
+    G.prim_margin = w->par.prim_margin_score;
+    G.min_score = (double)w->par.min_score;
+    G.score = w->d_score;
+    G.prim_idx = w->d_prim;
+    G.max_idx = w->d_max;
+    G.tie_mask = w->d_tie;
+    G.pass = w->d_pass;
+    w->have_groups = ng > 0;
+    return SPX_OK;
+}
+
+extern "C" int spx_prepare(spx_ctx *c, const spx_batch *bt, const spx_params *par, int host_threads, spx_work **out)
+{
+    if (!c || !bt || !par || !out) return fail(SPX_EINVAL, "NULL argument");
+    if (!c->d_ref4) return fail(SPX_ENOREF, "spx_set_reference has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    *out = nullptr;
+    spx_work *w = new spx_work();
+    memset(&w->st, 0, sizeof w->st);
+    w->par = *par;
+    w->n_groups_in = bt->n_groups;
+    double t0 = now_s();
+    int nthr = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
+    nthr = std::max(1, std::min(nthr, 64));
+    if (bt->n_groups < nthr * 8) nthr = 1;
+    const spx::RefIndex &ri = c->ref;
+    std::vector<spx::HostBatch> parts(nthr);
+    std::vector<std::thread> th;
+    const int32_t ng = bt->n_groups;
+    auto run = [&](int t) {
+        int32_t g0 = (int32_t)((int64_t)ng * t / nthr), g1 = (int32_t)((int64_t)ng * (t + 1) / nthr);
+        spx::prepare_groups(bt, ri, par, g0, g1, parts[t]);
+    };
+    if (nthr == 1) run(0);
+    else {
+        for (int t = 0; t < nthr; ++t) th.emplace_back(run, t);
+        for (auto &t : th) t.join();
+    }
+    w->hb.clear();
+    w->hb.mk_first.push_back(0);
+    for (int t = 0; t < nthr; ++t) {
+        w->hb.append(parts[t]);
+        w->hb.grp_error.insert(w->hb.grp_error.end(), parts[t].grp_error.begin(), parts[t].grp_error.end());
+    }
+    w->st.prep_seconds = now_s() - t0;
+    w->st.n_groups = ng;
+    w->st.n_dispatched = (int64_t)w->hb.grp_index.size();
+    w->st.n_problems = (int64_t)w->hb.L.size();
+    w->st.n_rows = (int64_t)w->hb.rows.size();
+    w->st.dp_cells = w->hb.dp_cells;
+    w->st.n_markers = (int64_t)w->hb.markers.size();
+    int rc = build_device_batch(c, w, false);
+    if (rc) { spx_work_free(c, w); return rc; }
+    *out = w;
+    return SPX_OK;
+}
+
+extern "C" int spx_launch(spx_ctx *c, spx_work *w)
+{
+    if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    for (int cls = 0; cls < 7; ++cls)
+        if (w->cls_used[cls]) HIPCHK(spx_launch_baq(cls, &w->cls_batch[cls], c->stream));
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, c->stream));
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    w->launched = true;
+    return SPX_OK;
+}
+
+extern "C" int spx_sync(spx_ctx *c)
+{
+    if (!c) return fail(SPX_EINVAL, "NULL argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SPX_OK;
+}
+
+extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
+{
+    if (!c || !w || !out) return fail(SPX_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (w->launched) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        w->st.baq_kernel_ms = ms;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+        w->st.score_kernel_ms = ms;
+        w->st.kernel_seconds = (w->st.baq_kernel_ms + w->st.score_kernel_ms) * 1e-3;
+    }
+    const size_t ng = w->hb.grp_index.size();
+    std::vector<double> score(ng * 10);
+    std::vector<uint8_t> prim(ng), mx(ng), pass(ng);
+    std::vector<uint16_t> tie(ng);
+    double t0 = now_s();
+    if (ng) {
+        HIPCHK(hipMemcpy(score.data(), w->d_score, ng * 10 * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(prim.data(), w->d_prim, ng, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(mx.data(), w->d_max, ng, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pass.data(), w->d_pass, ng, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tie.data(), w->d_tie, ng * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    }
+    w->st.d2h_seconds = now_s() - t0;
+    w->st.bytes_d2h = (int64_t)(ng * (80 + 5));
+    for (int32_t g = 0; g < w->n_groups_in; ++g) {
+        memset(&out[g], 0, sizeof out[g]);
+        int e = w->hb.grp_error[g];
+        out[g].n_aln = (int8_t)(e < 0 ? e : 0);
+        out[g].prim_idx = out[g].max_idx = out[g].best_idx = -1;
+    }
+    for (size_t k = 0; k < ng; ++k) {
+        spx_group_out &o = out[w->hb.grp_index[k]];
+        o.n_aln = (int8_t)w->hb.n_aln[k];
+        for (int i = 0; i < 10; ++i) { o.score[i] = score[k * 10 + i]; o.rfe[i] = w->hb.rfe[k * 10 + i]; }
+        o.prim_idx = (int8_t)prim[k];
+        o.max_idx = (int8_t)mx[k];
+        o.pass = (int8_t)pass[k];
+        o.tie_mask = tie[k];
+        o.n_problems = w->hb.grp_problems[k];
+        o.n_markers = w->hb.mk_first[k + 1] - w->hb.mk_first[k];
+        o.dp_cells = w->hb.grp_cells[k];
+    }
+    return SPX_OK;
+}
+
+extern "C" int spx_work_stats(const spx_work *w, spx_stats *st)
+{
+    if (!w || !st) return fail(SPX_EINVAL, "NULL argument");
+    *st = w->st;
+    return SPX_OK;
+}
+
+extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
+{
+    if (!w) return;
+    if (c) hipSetDevice(c->device);
+    if (w->arena) hipFree(w->arena);
+    delete w;
+}
+
+extern "C" int spx_score_batch(spx_ctx *c, const spx_batch *bt, const spx_params *par, spx_group_out *out,
+                               spx_stats *stats)
+{
+    spx_work *w = nullptr;
+    int rc = spx_prepare(c, bt, par, 0, &w);
+    if (rc) return rc;
+    rc = spx_launch(c, w);
+    if (!rc) rc = spx_collect(c, w, out);
+    if (!rc && stats) *stats = w->st;
+    spx_work_free(c, w);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* get_best_record_index's rand()-dependent tail (ptAlignment.c:163-176), replayed in file order.
+ * random_r with a private state is glibc's rand() algorithm without the process-global state. */
+extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups)
+{
+    if (!par || !out) return fail(SPX_EINVAL, "NULL argument");
+    struct random_data rd;
+    char statebuf[128];
+    memset(&rd, 0, sizeof rd);
+    initstate_r(rand_seed, statebuf, sizeof statebuf, &rd);
+    for (int32_t g = 0; g < n_groups; ++g) {
+        spx_group_out &o = out[g];
+        o.best_idx = -1;
+        o.relabel = 0;
+        if (o.n_aln < 2) continue;
+        int tied[16], cnt = 0, max_idx = o.max_idx;
+        for (int a = 0; a < o.n_aln; ++a)
+            if ((o.tie_mask >> a) & 1) tied[cnt++] = a;
+        int32_t r;
+        if (cnt > 1) { random_r(&rd, &r); max_idx = tied[r % cnt]; }
+        random_r(&rd, &r);
+        const int rnd = r % 2;
+        const double max_score = o.max_idx >= 0 ? o.score[o.max_idx] : -DBL_MAX;
+        const double prim_score = o.prim_idx >= 0 ? o.score[o.prim_idx] : -DBL_MAX;
+        double dd = max_score - prim_score;
+        int d = (dd > -2147483649.0 && dd < 2147483648.0) ? (int)dd : INT_MIN;
+        if (d < 0 && d != INT_MIN) d = -d;
+        int best;
+        if (d < par->prim_margin_random) best = rnd == 0 ? o.prim_idx : max_idx;
+        else best = o.pass ? max_idx : o.prim_idx;
+        o.best_idx = (int8_t)best;
+        o.relabel = (best >= 0 && best != o.prim_idx) ? 1 : 0;
+    }
+    return SPX_OK;
+}
+
+extern "C" int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *bt, const spx_ref *ref,
+                                     const spx_group_out *out)
+{
+    if (!path || !bt || !ref || !out) return fail(SPX_EINVAL, "NULL argument");
+    FILE *f = fopen(path, mode && *mode ? mode : "w");
+    if (!f) return fail(SPX_EINVAL, std::string("cannot open ") + path);
+    for (int32_t g = 0; g < bt->n_groups; ++g) {
+        const spx_group_out &o = out[g];
+        if (!o.relabel) continue;
+        fprintf(f, "#MARKER SCORE\n");
+        fprintf(f, "$\t%s\n", bt->qnames + bt->qname_off[g]);
+        int i = 0;
+        for (int a = bt->grp_first[g]; a < bt->grp_first[g + 1]; ++a) {
+            if (bt->flag[a] & SPX_FUNMAP) continue;
+            if (i >= o.n_aln) break;
+            const char *tag = !(bt->flag[a] & SPX_FSECONDARY) ? "*" : (i == o.best_idx ? "@" : "!");
+            fprintf(f, "%s\t%.2f\t%s\t%ld\t%d\n", tag, o.score[i], ref->names + ref->name_off[bt->tid[a]],
+                    (long)bt->pos[a], o.rfe[i]);
+            ++i;
+        }
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    return SPX_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* raw banded-HMM problems, all rows wanted */
+extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
+                                 const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars,
+                                 int32_t *state, uint8_t *q, double *kernel_ms)
+{
+    if (!c || n < 0 || !ref || !ref_off || !query || !qry_off || !set_q || !pars || !state || !q)
+        return fail(SPX_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    spx_work *w = new spx_work();
+    memset(&w->st, 0, sizeof w->st);
+    memset(&w->par, 0, sizeof w->par);
+    spx::HostBatch &hb = w->hb;
+    hb.clear();
+    hb.mk_first.push_back(0);
+    /* private reference pool: the problems' own ref windows */
+    std::vector<uint8_t> ref4;
+    int64_t rn = 0;
+    for (int32_t p = 0; p < n; ++p) {
+        const int R = (int)(ref_off[p + 1] - ref_off[p]), L = (int)(qry_off[p + 1] - qry_off[p]);
+        if (R <= 0 || L <= 0) { delete w; return fail(SPX_EINVAL, "empty problem"); }
+        const int bw = spx::effective_bw(R, L, pars[p].bw);
+        if (spx::band_class(2 * bw + 1) < 0) { delete w; return fail(SPX_EUNSUPPORTED, "band wider than 2048 columns"); }
+        hb.ref_nib.push_back(rn);
+        ref4.resize((size_t)(rn / 2) + (size_t)(R + 1) / 2, 0);
+        for (int k = 0; k < R; ++k) {
+            unsigned code = ref[ref_off[p] + k] > 3 ? 4u : ref[ref_off[p] + k];
+            ref4[(size_t)(rn / 2) + (k >> 1)] |= (uint8_t)(code << ((k & 1) << 2));
+        }
+        rn += ((R + 1) / 2) * 2;
+        hb.qry_nib.push_back(hb.qry_nibbles);
+        const size_t at = hb.qry4.size(), nb = (size_t)(L + 1) / 2;
+        hb.qry4.resize(at + nb, 0);
+        for (int k = 0; k < L; ++k) {
+            unsigned code = query[qry_off[p] + k] > 3 ? 4u : query[qry_off[p] + k];
+            hb.qry4[at + (k >> 1)] |= (uint8_t)(code << ((k & 1) << 2));
+        }
+        hb.qry_nibbles += (int64_t)nb * 2;
+        hb.L.push_back(L); hb.R.push_back(R); hb.bw.push_back(bw);
+        hb.row_off.push_back((int32_t)hb.rows.size());
+        hb.n_rows.push_back(L);
+        for (int i = 1; i <= L; ++i) { hb.rows.push_back(i); hb.row_expect.push_back(i - 1); hb.row_rawq.push_back(93); }
+        hb.hmm.resize(hb.hmm.size() + SPX_H_N);
+        spx::hmm_constants(R, L, pars[p].d, pars[p].e, set_q[p], &hb.hmm[hb.hmm.size() - SPX_H_N]);
+        hb.dp_cells += spx::band_cells(L, R, bw);
+    }
+    ref4.resize(ref4.size() + 16, 0);
+    uint8_t *d_ref = nullptr, *saved = c->d_ref4;
+    HIPCHK(hipMalloc((void **)&d_ref, ref4.size()));
+    HIPCHK(hipMemcpy(d_ref, ref4.data(), ref4.size(), hipMemcpyHostToDevice));
+    c->d_ref4 = d_ref;
+    int rc = build_device_batch(c, w, true);
+    c->d_ref4 = saved;
+    if (!rc) rc = spx_launch(c, w);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(SPX_EHIP, "kernel execution failed");
+    if (!rc) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        if (kernel_ms) *kernel_ms = ms;
+        const size_t nr = hb.rows.size();
+        if (hipMemcpy(state, w->d_state, nr * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(q, w->d_q, nr, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(SPX_EHIP, "copy back failed");
+    }
+    hipFree(d_ref);
+    spx_work_free(c, w);
+    return rc;
+}
+
+static std::mutex g_single_mu;
+static spx_ctx *g_single = nullptr;
+
+extern "C" int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+                                  const spx_probaln_par *cpar, int *state, uint8_t *q)
+{
+    if (l_ref <= 0 || l_query <= 0) return 0; /* as htslib */
+    if (!ref || !query || !cpar || !state || !q) return INT_MIN;
+    int sq = iqual ? iqual[0] : 30;
+    if (iqual)
+        for (int i = 1; i < l_query; ++i)
+            if (iqual[i] != sq) { fail(SPX_EUNSUPPORTED, "per-base iqual: secphase always passes a constant (ptMarker.c:747-749)"); return INT_MIN; }
+    std::lock_guard<std::mutex> lk(g_single_mu);
+    if (!g_single && spx_create(0, &g_single) != SPX_OK) return INT_MIN;
+    int64_t ro[2] = {0, l_ref}, qo[2] = {0, l_query};
+    int32_t sq32 = sq;
+    std::vector<int32_t> st32(l_query);
+    int rc = spx_probaln_batch(g_single, 1, ref, ro, query, qo, &sq32, cpar, st32.data(), q, nullptr);
+    if (rc) return INT_MIN;
+    for (int i = 0; i < l_query; ++i) state[i] = st32[i];
+    /* phred-scaled likelihood: not used by secphase (ptMarker.c:755-760 only tests for INT_MIN) */
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* host-only plan view */
+struct spx_plan {
+    spx::HostBatch hb;
+    std::vector<int32_t> mk_row;
+    std::vector<uint8_t> mk_qfix, mk_is_match, mk_aln, mk_fop;
+};
+
+extern "C" int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const spx_params *par, spx_plan **out)
+{
+    if (!ref || !bt || !par || !out) return fail(SPX_EINVAL, "NULL argument");
+    spx::RefIndex ri;
+    int64_t nib = 0;
+    for (int i = 0; i < ref->n_contigs; ++i) {
+        ri.nib_off.push_back(nib);
+        ri.len.push_back(ref->seq_off[i + 1] - ref->seq_off[i]);
+        nib += (ri.len[i] + 1) & ~(int64_t)1;
+    }
+    spx_plan *p = new spx_plan();
+    spx::prepare_groups(bt, ri, par, 0, bt->n_groups, p->hb);
+    for (const spx_dev_marker &m : p->hb.markers) {
+        p->mk_row.push_back(m.row);
+        p->mk_qfix.push_back(m.qfix);
+        p->mk_is_match.push_back(m.is_match);
+        p->mk_aln.push_back(m.aln);
+        p->mk_fop.push_back(m.first_of_pos);
+    }
+    *out = p;
+    return SPX_OK;
+}
+
+extern "C" int spx_plan_get(const spx_plan *p, spx_plan_view *v)
+{
+    if (!p || !v) return fail(SPX_EINVAL, "NULL argument");
+    const spx::HostBatch &h = p->hb;
+    v->n_problems = (int32_t)h.L.size();
+    v->n_rows = (int32_t)h.rows.size();
+    v->n_groups = (int32_t)h.grp_index.size();
+    v->n_markers = (int32_t)h.markers.size();
+    v->L = h.L.data(); v->R = h.R.data(); v->bw = h.bw.data();
+    v->ref_tid = h.ref_tid.data(); v->ref_rfs = h.ref_rfs.data();
+    v->qry_nib = h.qry_nib.data(); v->qry4 = h.qry4.data(); v->hmm = h.hmm.data();
+    v->row_off = h.row_off.data(); v->n_rows_of = h.n_rows.data();
+    v->rows = h.rows.data(); v->row_expect = h.row_expect.data(); v->row_rawq = h.row_rawq.data();
+    v->grp_index = h.grp_index.data(); v->mk_first = h.mk_first.data();
+    v->mk_row = p->mk_row.data(); v->mk_qfix = p->mk_qfix.data(); v->mk_is_match = p->mk_is_match.data();
+    v->mk_aln = p->mk_aln.data(); v->mk_first_of_pos = p->mk_fop.data();
+    v->n_aln = h.n_aln.data(); v->sec_mask = h.sec_mask.data(); v->rfe = h.rfe.data();
+    v->grp_error = h.grp_error.data();
+    return SPX_OK;
+}
+
+extern "C" void spx_plan_free(spx_plan *p) { delete p; }
+
+extern "C" void spx_host_tables(double *thr, double *match_tbl, double *mis_tbl)
+{
+    if (thr) spx::phred_thresholds(thr);
+    if (match_tbl && mis_tbl) spx::score_tables(match_tbl, mis_tbl);
+}

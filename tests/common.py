@@ -1,0 +1,108 @@
+"""Shared helpers of the test-suite (oracle access, synthetic inputs, emulation of the
+device kernels with the oracle's DP so that the HOST logic can be checked without a GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import orc
+from secphase_amd import api, records, synth
+
+NT16_TABLE = np.full(256, 15, np.uint8)
+for ch, v in zip("=ACMGRSVTWYHKDBN", range(16)):
+    NT16_TABLE[ord(ch)] = v
+    NT16_TABLE[ord(ch.lower())] = v
+for ch, v in zip("0123", (1, 2, 4, 8)):
+    NT16_TABLE[ord(ch)] = v
+NT16_INT = np.array([4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4], np.uint8)
+
+
+def small_genome(platform, **kw):
+    base = dict(n_contigs=2, contig_len=150000)
+    base.update(kw)
+    cfg = synth.default_cfg(platform, **base)
+    return synth.Genome(cfg)
+
+
+def ref_codes(ref, tid, start, n):
+    r = ref.contents
+    off = r.seq_off[tid] + start
+    raw = np.frombuffer(C.string_at(C.cast(r.bases, C.c_void_p).value + off, n), np.uint8)
+    return NT16_INT[NT16_TABLE[raw]]
+
+
+def nibbles(buf_ptr, nib_off, n):
+    """decode n 4-bit codes starting at nibble nib_off (low nibble first)"""
+    b0 = nib_off // 2
+    nb = (nib_off + n + 1) // 2 - b0
+    raw = np.ctypeslib.as_array(buf_ptr, shape=(b0 + nb,))[b0:b0 + nb]
+    out = np.empty(nb * 2, np.uint8)
+    out[0::2] = raw & 0xf
+    out[1::2] = raw >> 4
+    s = nib_off - 2 * b0
+    return out[s:s + n].copy()
+
+
+def oracle_probaln(ref, qry, set_q, d, e, bw):
+    L = orc.lib()
+    ref = np.ascontiguousarray(ref, np.uint8)
+    qry = np.ascontiguousarray(qry, np.uint8)
+    iq = np.full(len(qry), set_q, np.uint8)
+    st = np.zeros(len(qry), np.int32)
+    q = np.zeros(len(qry), np.uint8)
+    par = orc.ProbalnPar(d, e, bw)
+    u8 = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint8))
+    pr = L.orc_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), u8(iq), C.byref(par),
+                              st.ctypes.data_as(C.POINTER(C.c_int)), u8(q))
+    return pr, st, q
+
+
+def emulate_plan(plan, ref, params):
+    """Run the oracle DP on every problem of a host plan and apply the device-side
+    write-back + scoring rules in numpy: returns {input group index: (scores, prim, max, tie, pass)}."""
+    v = plan.view
+    bq = np.zeros(max(v.n_rows, 1), np.int64)
+    for p in range(v.n_problems):
+        L_, R_, bw = v.L[p], v.R[p], v.bw[p]
+        r = ref_codes(ref, v.ref_tid[p], v.ref_rfs[p], R_)
+        q = nibbles(v.qry4, v.qry_nib[p], L_)
+        _, st, qq = oracle_probaln(r, q, params.set_q, params.conf_d, params.conf_e, bw)
+        for w in range(v.n_rows_of[p]):
+            ri = v.row_off[p] + w
+            t = v.rows[ri] - 1
+            if (st[t] & 3) != 0 or (st[t] >> 2) != v.row_expect[ri]:
+                b = 0
+            else:
+                b = min(int(v.row_rawq[ri]), int(qq[t]))
+            bq[ri] = min(b, 93)
+    match_tbl = (C.c_double * 256)()
+    mis_tbl = (C.c_double * 256)()
+    thr = (C.c_double * 102)()
+    api.lib().spx_host_tables(thr, match_tbl, mis_tbl)
+    res = {}
+    for k in range(v.n_groups):
+        n = v.n_aln[k]
+        sec = v.sec_mask[k]
+        m0, m1 = v.mk_first[k], v.mk_first[k + 1]
+        scores = [0.0] * n
+        p = m0
+        while p < m1:
+            e = p + 1
+            while e < m1 and not v.mk_first_of_pos[e]:
+                e += 1
+            qs = [int(bq[v.mk_row[i]]) if v.mk_row[i] >= 0 else int(v.mk_qfix[i]) for i in range(p, e)]
+            mn = min(min(qs), 100)
+            if mn > params.min_q:
+                for i in range(p, e):
+                    a = v.mk_aln[i]
+                    scores[a] += match_tbl[mn] if v.mk_is_match[i] else mis_tbl[mn]
+            p = e
+        prim, mx, mxs, prs = -1, -1, -1.7976931348623157e308, -1.7976931348623157e308
+        for a in range(n):
+            if not (sec >> a) & 1:
+                prim, prs = a, scores[a]
+            elif mxs < scores[a]:
+                mx, mxs = a, scores[a]
+        tie = sum(1 << a for a in range(n) if (sec >> a) & 1 and mxs <= scores[a])
+        ok = not (prim == -1 or mxs <= prs + params.prim_margin_score or mxs < params.min_score)
+        res[v.grp_index[k]] = (scores, prim, mx, tie, ok)
+    return res

@@ -1,0 +1,148 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle, bit for bit."""
+import ctypes as C
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from common import oracle_probaln, small_genome
+from oracle import orc
+from secphase_amd import api, records, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _rand_problem(rng, L, indel_rate, sub_rate, n_frac=0.0):
+    ref = rng.integers(0, 4, size=L + 40).astype(np.uint8)
+    q = []
+    i = 0
+    while i < len(ref) and len(q) < L:
+        u = rng.random()
+        if u < indel_rate / 2:
+            i += 1  # deletion
+            continue
+        if u < indel_rate:
+            q.append(rng.integers(0, 4))  # insertion
+            continue
+        b = ref[i]
+        if rng.random() < sub_rate:
+            b = (b + 1 + rng.integers(0, 3)) % 4
+        q.append(b)
+        i += 1
+    qry = np.array(q, np.uint8)
+    ref = ref[:max(1, i)]
+    if n_frac > 0:
+        ref = ref.copy()
+        ref[rng.random(len(ref)) < n_frac] = 4
+        qry[rng.random(len(qry)) < n_frac] = 4
+    return ref, qry
+
+
+def _check(ctx, probs, set_q, pars):
+    refs = [p[0] for p in probs]
+    qrys = [p[1] for p in probs]
+    st, qq, ms = ctx.probaln_batch(refs, qrys, set_q, pars)
+    for i, (r, q) in enumerate(probs):
+        _, est, eq = oracle_probaln(r, q, set_q[i], pars[i][0], pars[i][1], pars[i][2])
+        assert np.array_equal(st[i], est), f"state differs, problem {i} L={len(q)} R={len(r)} bw={pars[i][2]}"
+        assert np.array_equal(qq[i], eq), f"q differs, problem {i} L={len(q)} R={len(r)} bw={pars[i][2]}"
+
+
+def test_probaln_hifi_windows(ctx):
+    rng = np.random.default_rng(7)
+    probs = [_rand_problem(rng, int(rng.integers(600, 1001)), 0.002, 0.003) for _ in range(96)]
+    pars = [(1e-4, 0.1, abs(len(r) - len(q)) + 20) for r, q in probs]
+    _check(ctx, probs, [40] * len(probs), pars)
+
+
+def test_probaln_ont_windows(ctx):
+    rng = np.random.default_rng(8)
+    probs = [_rand_problem(rng, int(rng.integers(300, 900)), 0.04, 0.02) for _ in range(48)]
+    pars = [(1e-3, 0.1, abs(len(r) - len(q)) + 50) for r, q in probs]
+    _check(ctx, probs, [20] * len(probs), pars)
+
+
+def test_probaln_small_and_degenerate(ctx):
+    rng = np.random.default_rng(9)
+    probs, pars = [], []
+    for L in (1, 2, 3, 5, 8, 13, 21, 22, 40, 41, 42, 60):
+        for bw in (1, 3, 20):
+            r, q = _rand_problem(rng, L, 0.05, 0.05)
+            probs.append((r, q))
+            pars.append((1e-4, 0.1, abs(len(r) - len(q)) + bw))
+    # ref much shorter / longer than query
+    probs.append((np.array([0, 1, 2], np.uint8), rng.integers(0, 4, 30).astype(np.uint8)))
+    pars.append((1e-3, 0.1, 27 + 5))
+    probs.append((rng.integers(0, 4, 90).astype(np.uint8), rng.integers(0, 4, 25).astype(np.uint8)))
+    pars.append((1e-3, 0.1, 65 + 2))
+    _check(ctx, probs, [30] * len(probs), pars)
+
+
+def test_probaln_ambiguous_bases(ctx):
+    rng = np.random.default_rng(10)
+    probs = [_rand_problem(rng, int(rng.integers(100, 400)), 0.01, 0.01, n_frac=0.03) for _ in range(32)]
+    pars = [(1e-4, 0.1, abs(len(r) - len(q)) + 20) for r, q in probs]
+    _check(ctx, probs, [40] * len(probs), pars)
+
+
+def test_probaln_wide_bands(ctx):
+    rng = np.random.default_rng(11)
+    probs, pars = [], []
+    for bw in (70, 130, 260):
+        r, q = _rand_problem(rng, 700, 0.02, 0.02)
+        probs.append((r, q))
+        pars.append((1e-3, 0.1, abs(len(r) - len(q)) + bw))
+    _check(ctx, probs, [20] * len(probs), pars)
+
+
+def _batch_parity(ctx, genome, reads, params, tmp_path, tag):
+    ctx.set_reference(genome.ref)
+    out, st = ctx.score_batch(reads.batch, params, finalize_seed=1)
+    log_o = str(tmp_path / f"{tag}.oracle.log")
+    log_g = str(tmp_path / f"{tag}.gpu.log")
+    nre, res = orc.run_batch(reads.batch, genome.ref, params, threads=2, seed=1, log_path=log_o)
+    api.write_relabel_log(log_g, reads.batch, genome.ref, out)
+    n = reads.batch.contents.n_groups
+    assert st.n_problems == sum(r.n_baq_calls for r in res)
+    assert st.dp_cells == sum(r.dp_cells for r in res)
+    for i in range(n):
+        o, e = out[i], res[i]
+        assert o.n_aln == e.n_aln, i
+        for a in range(max(e.n_aln, 0)):
+            assert o.score[a] == e.score[a], (i, a, o.score[a], e.score[a])
+        assert o.best_idx == e.best_idx, i
+        assert bool(o.relabel) == bool(e.relabel), i
+    assert filecmp.cmp(log_o, log_g, shallow=False)
+    assert sum(o.relabel for o in out) == nre
+    return st
+
+
+def test_batch_hifi(ctx, tmp_path):
+    g = small_genome(synth.HIFI)
+    r = g.reads(0, 96)
+    _batch_parity(ctx, g, r, records.preset("hifi"), tmp_path, "hifi")
+
+
+def test_batch_ont(ctx, tmp_path):
+    g = small_genome(synth.ONT, n_paralogs=3)
+    r = g.reads(0, 24)
+    _batch_parity(ctx, g, r, records.preset("ont", bandwidth=50), tmp_path, "ont")
+
+
+def test_batch_edge_cases(ctx, tmp_path):
+    g = small_genome(synth.HIFI, hardclip_frac=0.5, softclip_frac=0.5, shuffle_records=1, inverted_paralogs=1,
+                     n_paralogs=3, max_secondaries=4, n_base_frac=0.002, read_len=6000)
+    r = g.reads(100, 64)
+    _batch_parity(ctx, g, r, records.preset("hifi"), tmp_path, "edge")
+
+
+def test_no_cpu_fallback():
+    assert api.lib().spx_device_count() >= 1
