@@ -102,6 +102,11 @@ int spx_score_batch(spx_ctx *ctx, const spx_batch *bt, const spx_params *par, sp
 int spx_prepare(spx_ctx *ctx, const spx_batch *bt, const spx_params *par, int host_threads, spx_work **work);
 int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */
 int spx_sync(spx_ctx *ctx);
+/* multi-GPU: write one 8-byte decision record per dispatched group of `work` into a caller-owned
+ * DEVICE buffer (e.g. a torch tensor that is then handed to an RCCL gather): bits 0-31 global
+ * group index (= index in the batch + group_base), 32-39 prim_idx, 40-47 max_idx, 48-62 tie_mask,
+ * 63 pass.  Asynchronous on the ctx stream; returns the number of records (>= 0) or SPX_E*. */
+int spx_pack_decisions(spx_ctx *ctx, spx_work *work, int32_t group_base, void *device_out, int64_t capacity);
 int spx_collect(spx_ctx *ctx, spx_work *work, spx_group_out *out);
 int spx_work_stats(const spx_work *work, spx_stats *stats);
 void spx_work_free(spx_ctx *ctx, spx_work *work);

@@ -70,7 +70,7 @@ EXPORTS = [
     "spx_strerror", "spx_last_error", "spx_device_count", "spx_create", "spx_destroy", "spx_set_reference",
     "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_launch", "spx_sync", "spx_collect",
     "spx_work_stats", "spx_work_free", "spx_finalize", "spx_write_relabel_log", "spx_probaln_glocal",
-    "spx_probaln_batch", "spx_plan_create", "spx_plan_get", "spx_plan_free", "spx_host_tables",
+    "spx_probaln_batch", "spx_pack_decisions", "spx_plan_create", "spx_plan_get", "spx_plan_free", "spx_host_tables",
 ]
 
 _lib = None
@@ -102,6 +102,7 @@ def lib():
     L.spx_prepare.argtypes = [vp, C.POINTER(SpxBatch), C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
     L.spx_launch.argtypes = [vp, vp]
     L.spx_sync.argtypes = [vp]
+    L.spx_pack_decisions.argtypes = [vp, vp, C.c_int32, vp, C.c_int64]
     L.spx_collect.argtypes = [vp, vp, C.POINTER(GroupOut)]
     L.spx_work_stats.argtypes = [vp, C.POINTER(Stats)]
     L.spx_work_free.argtypes = [vp, vp]
@@ -195,6 +196,12 @@ class Work:
 
     def sync(self):
         _chk(lib().spx_sync(self.ctx.h), "spx_sync")
+
+    def pack_decisions(self, group_base, device_ptr, capacity):
+        n = lib().spx_pack_decisions(self.ctx.h, self.h, group_base, C.c_void_p(device_ptr), capacity)
+        if n < 0:
+            raise SpxError(n, "spx_pack_decisions")
+        return n
 
     def collect(self, finalize_seed=1):
         out = (GroupOut * self.n)()

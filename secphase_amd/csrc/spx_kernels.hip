@@ -516,6 +516,30 @@ __global__ __launch_bounds__(256) void score_kernel(spx_dev_groups Gd)
     Gd.pass[gi] = !(prim_idx == -1 || max_score <= (prim_score + Gd.prim_margin) || max_score < Gd.min_score);
 }
 
+/* fixed-size decision records for the cross-rank gather (one RCCL collective):
+ * {group index u32 | prim i8 | max_idx i8 | tie_mask u16 low byte.. } packed in 8 bytes */
+__global__ __launch_bounds__(256) void pack_kernel(spx_dev_groups Gd, const int32_t *__restrict__ grp_index,
+                                                   int32_t group_base, unsigned long long *__restrict__ out)
+{
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= Gd.n_groups) return;
+    unsigned long long r = (unsigned long long)(uint32_t)(grp_index[gi] + group_base);
+    r |= (unsigned long long)Gd.prim_idx[gi] << 32;
+    r |= (unsigned long long)Gd.max_idx[gi] << 40;
+    r |= (unsigned long long)Gd.tie_mask[gi] << 48;
+    r |= (unsigned long long)(Gd.pass[gi] ? 1 : 0) << 63;
+    out[gi] = r;
+}
+
+extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
+                                      unsigned long long *out, hipStream_t st)
+{
+    if (Gd->n_groups <= 0) return hipSuccess;
+    int blocks = (Gd->n_groups + 255) / 256;
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, *Gd, grp_index, group_base, out);
+    return hipGetLastError();
+}
+
 /* ---------------------------------------------------------------------- */
 extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st)
 {

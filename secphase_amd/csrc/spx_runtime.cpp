@@ -27,6 +27,8 @@
 
 extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st);
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, hipStream_t st);
+extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
+                                      unsigned long long *out, hipStream_t st);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
@@ -82,6 +84,7 @@ struct spx_work {
     double *d_score = nullptr;
     uint8_t *d_prim = nullptr, *d_max = nullptr, *d_pass = nullptr;
     uint16_t *d_tie = nullptr;
+    int32_t *d_grp_index = nullptr;
     uint8_t *d_bq = nullptr, *d_q = nullptr;
     int32_t *d_state = nullptr;
     spx_stats st;
@@ -248,7 +251,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     size_t o_order[7];
     for (int cls = 0; cls < 7; ++cls) o_order[cls] = cv.take<int32_t>(order[cls].size());
     size_t o_mk_first = cv.take<int32_t>(ng + 1), o_markers = cv.take<spx_dev_marker>(nm), o_naln = cv.take<uint8_t>(ng),
-           o_sec = cv.take<uint16_t>(ng);
+           o_sec = cv.take<uint16_t>(ng), o_gidx = cv.take<int32_t>(ng);
     const size_t in_bytes = cv.off;
     size_t o_sinv = cv.take<double>((size_t)s_tot), o_fsave = cv.take<double>((size_t)f_tot),
            o_bq = cv.take<uint8_t>(nr + 16), o_state = want_state_q ? cv.take<int32_t>(nr) : 0,
@@ -268,6 +271,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     UP(o_qry4, hb.qry4); UP(o_rows, hb.rows); UP(o_expect, hb.row_expect); UP(o_rawq, hb.row_rawq);
     for (int cls = 0; cls < 7; ++cls) UP(o_order[cls], order[cls]);
     UP(o_mk_first, hb.mk_first); UP(o_markers, hb.markers); UP(o_naln, hb.n_aln); UP(o_sec, hb.sec_mask);
+    UP(o_gidx, hb.grp_index);
 #undef UP
     HIPCHK(hipStreamSynchronize(c->stream));
     w->st.h2d_seconds = now_s() - t0;
@@ -280,6 +284,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     w->d_max = (uint8_t *)(base + o_max);
     w->d_pass = (uint8_t *)(base + o_pass);
     w->d_tie = (uint16_t *)(base + o_tie);
+    w->d_grp_index = (int32_t *)(base + o_gidx);
     for (int cls = 0; cls < 7; ++cls) {
         spx_dev_batch &B = w->cls_batch[cls];
         memset(&B, 0, sizeof B);
@@ -389,6 +394,15 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     w->launched = true;
     return SPX_OK;
+}
+
+extern "C" int spx_pack_decisions(spx_ctx *c, spx_work *w, int32_t group_base, void *device_out, int64_t capacity)
+{
+    if (!c || !w || !device_out) return fail(SPX_EINVAL, "NULL argument");
+    if (capacity < (int64_t)w->hb.grp_index.size()) return fail(SPX_EINVAL, "decision buffer too small");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(spx_launch_pack(&w->dg, w->d_grp_index, group_base, (unsigned long long *)device_out, c->stream));
+    return (int)w->hb.grp_index.size();
 }
 
 extern "C" int spx_sync(spx_ctx *c)
