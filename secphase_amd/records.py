@@ -17,17 +17,17 @@ FUNMAP, FREVERSE, FSECONDARY, FSUPPLEMENTARY = 0x4, 0x10, 0x100, 0x800
 class SpxBatch(C.Structure):
     _fields_ = [
         ("n_groups", C.c_int32), ("n_alns", C.c_int32),
-        ("grp_first", c_i32p), ("qname_off", c_i64p), ("qnames", C.c_char_p),
+        ("grp_first", c_i32p), ("qname_off", c_i64p), ("qnames", C.c_void_p),
         ("flag", c_u16p), ("tid", c_i32p), ("pos", c_i32p), ("l_qseq", c_i32p), ("n_cigar", c_i32p),
         ("cigar_off", c_i64p), ("seq_off", c_i64p), ("qual_off", c_i64p), ("cs_off", c_i64p),
-        ("cigar", c_u32p), ("seq4", c_u8p), ("qual", c_u8p), ("cs", C.c_char_p),
+        ("cigar", c_u32p), ("seq4", c_u8p), ("qual", c_u8p), ("cs", C.c_void_p),
     ]
 
 
 class SpxRef(C.Structure):
     _fields_ = [
-        ("n_contigs", C.c_int32), ("name_off", c_i64p), ("names", C.c_char_p),
-        ("seq_off", c_i64p), ("bases", C.c_char_p),
+        ("n_contigs", C.c_int32), ("name_off", c_i64p), ("names", C.c_void_p),
+        ("seq_off", c_i64p), ("bases", C.c_void_p),
     ]
 
 

@@ -26,7 +26,7 @@ def small_genome(platform, **kw):
 def ref_codes(ref, tid, start, n):
     r = ref.contents
     off = r.seq_off[tid] + start
-    raw = np.frombuffer(C.string_at(C.cast(r.bases, C.c_void_p).value + off, n), np.uint8)
+    raw = np.frombuffer(C.string_at(r.bases + off, n), np.uint8)
     return NT16_INT[NT16_TABLE[raw]]
 
 
@@ -106,3 +106,88 @@ def emulate_plan(plan, ref, params):
         ok = not (prim == -1 or mxs <= prs + params.prim_margin_score or mxs < params.min_score)
         res[v.grp_index[k]] = (scores, prim, mx, tie, ok)
     return res
+
+
+# ---------------------------------------------------------------------------
+# hand-built batches (SAM-like tuples) for targeted tests
+_CIG = {c: i for i, c in enumerate("MIDNSHP=X")}
+_NT = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15}
+
+
+class HandBatch:
+    """groups = [(qname, [(flag, tid, pos, cigar_str, seq, qual_list_or_int, cs_or_None), ...]), ...]"""
+
+    def __init__(self, groups):
+        import re
+        self.keep = []
+        grp_first, qname_off, qnames = [0], [], b""
+        flag, tid, pos, lq, ncig, cig_off, seq_off, qual_off, cs_off = [], [], [], [], [], [], [], [], []
+        cig, seq4, qual, cs = [], bytearray(), bytearray(), bytearray()
+        for name, recs in groups:
+            qname_off.append(len(qnames))
+            qnames += name.encode() + b"\0"
+            for (f, t, p, cg, sq, ql, c) in recs:
+                flag.append(f); tid.append(t); pos.append(p); lq.append(len(sq))
+                ops = re.findall(r"(\d+)([MIDNSHP=X])", cg)
+                ncig.append(len(ops)); cig_off.append(len(cig))
+                cig += [(int(n) << 4) | _CIG[o] for n, o in ops]
+                seq_off.append(len(seq4))
+                for i in range(0, len(sq), 2):
+                    hi = _NT.get(sq[i], 15)
+                    lo = _NT.get(sq[i + 1], 15) if i + 1 < len(sq) else 0
+                    seq4.append(hi << 4 | lo)
+                qual_off.append(len(qual))
+                qual += bytes([ql] * len(sq)) if isinstance(ql, int) else bytes(ql)
+                if c is None:
+                    cs_off.append(-1)
+                else:
+                    cs_off.append(len(cs)); cs += c.encode() + b"\0"
+            grp_first.append(len(flag))
+        A = lambda x, dt: np.ascontiguousarray(np.array(x, dt))
+        self.arr = dict(grp_first=A(grp_first, np.int32), qname_off=A(qname_off, np.int64), flag=A(flag, np.uint16),
+                        tid=A(tid, np.int32), pos=A(pos, np.int32), l_qseq=A(lq, np.int32), n_cigar=A(ncig, np.int32),
+                        cigar_off=A(cig_off, np.int64), seq_off=A(seq_off, np.int64), qual_off=A(qual_off, np.int64),
+                        cs_off=A(cs_off, np.int64), cigar=A(cig if cig else [0], np.uint32),
+                        seq4=A(list(seq4) + [0], np.uint8), qual=A(list(qual) + [0], np.uint8))
+        self.qnames = C.create_string_buffer(bytes(qnames) + b"\0")
+        self.cs = C.create_string_buffer(bytes(cs) + b"\0")
+        b = records.SpxBatch()
+        b.n_groups = len(groups)
+        b.n_alns = len(flag)
+        for k, v in self.arr.items():
+            setattr(b, k, v.ctypes.data_as(dict(records.SpxBatch._fields_)[k]))
+        b.qnames = C.cast(self.qnames, C.c_void_p)
+        b.cs = C.cast(self.cs, C.c_void_p)
+        self.struct = b
+        self.batch = C.pointer(b)
+
+
+class HandRef:
+    def __init__(self, contigs):
+        """contigs = [(name, sequence_str), ...]"""
+        names, name_off, seq_off, bases = b"", [], [0], b""
+        for n, s in contigs:
+            name_off.append(len(names)); names += n.encode() + b"\0"
+            bases += s.encode(); seq_off.append(len(bases))
+        self.names = C.create_string_buffer(names + b"\0")
+        self.bases = C.create_string_buffer(bases + b"\0")
+        self.name_off = np.array(name_off, np.int64)
+        self.seq_off = np.array(seq_off, np.int64)
+        r = records.SpxRef()
+        r.n_contigs = len(contigs)
+        r.name_off = self.name_off.ctypes.data_as(records.c_i64p)
+        r.names = C.cast(self.names, C.c_void_p)
+        r.seq_off = self.seq_off.ctypes.data_as(records.c_i64p)
+        r.bases = C.cast(self.bases, C.c_void_p)
+        self.struct = r
+        self.ref = C.pointer(r)
+
+
+def walk(batch, a):
+    """oracle CIGAR/cs iterator states of alignment a: list of dicts"""
+    ops = C.POINTER(orc.Op)()
+    n = orc.lib().orc_walk_cigar(batch, a, C.byref(ops))
+    assert n > 0, n
+    out = [{f: getattr(ops[i], f) for f, _ in orc.Op._fields_} for i in range(n)]
+    C.CDLL("libc.so.6").free(ops)
+    return out

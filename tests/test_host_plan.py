@@ -1,0 +1,107 @@
+"""CPU: the product's host logic (CIGAR/cs scan, markers, consensus blocks, BAQ window list,
+marker table) against the oracle.  The DP itself is supplied by the oracle here (no GPU), the
+device-side write-back / scoring rules are applied in numpy (tests/common.py emulate_plan)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import HandBatch, HandRef, emulate_plan, small_genome
+from oracle import orc
+from secphase_amd import api, records, synth
+
+
+def _compare(genome_or_ref, batch, params):
+    ref = genome_or_ref
+    nre, res = orc.run_batch(batch, ref, params, threads=2, seed=1)
+    plan = api.Plan(ref, batch, params)
+    v = plan.view
+    assert v.n_problems == sum(r.n_baq_calls for r in res if r.n_aln > 0)
+    em = emulate_plan(plan, ref, params)
+    n = batch.contents.n_groups
+    n_disp = 0
+    for g in range(n):
+        if orc.lib().orc_group_is_dispatched(batch, g):
+            n_disp += 1
+            assert api.lib().spx_group_is_dispatched(batch, g) == 1
+            sc, prim, mx, tie, ok = em[g]
+            o = res[g]
+            assert [o.score[a] for a in range(o.n_aln)] == sc, g
+            assert o.prim_idx == prim
+            assert [v.rfe[10 * list(v.grp_index[:v.n_groups]).index(g) + a] for a in range(o.n_aln)] == \
+                   [o.rfe[a] for a in range(o.n_aln)]
+        else:
+            assert api.lib().spx_group_is_dispatched(batch, g) == 0
+            assert g not in em
+    assert n_disp == v.n_groups
+    return plan, res
+
+
+def test_plan_hifi(built):
+    g = small_genome(synth.HIFI)
+    r = g.reads(0, 40)
+    _compare(g.ref, r.batch, records.preset("hifi"))
+
+
+def test_plan_ont(built):
+    g = small_genome(synth.ONT, n_paralogs=3)
+    r = g.reads(0, 10)
+    _compare(g.ref, r.batch, records.preset("ont", bandwidth=50))
+
+
+def test_plan_edge_cases(built):
+    g = small_genome(synth.HIFI, hardclip_frac=0.5, softclip_frac=0.5, shuffle_records=1, inverted_paralogs=1,
+                     n_paralogs=3, max_secondaries=4, n_base_frac=0.002, read_len=5000)
+    r = g.reads(100, 40)
+    _compare(g.ref, r.batch, records.preset("hifi"))
+
+
+def test_plan_mixed_lengths(built):
+    g = small_genome(synth.MIXED, n_paralogs=7, contig_len=250000, max_read_len=40000)
+    r = g.reads(7, 12)
+    _compare(g.ref, r.batch, records.preset("hifi"))
+
+
+def test_plan_no_baq_no_consensus(built):
+    g = small_genome(synth.HIFI, read_len=3000)
+    r = g.reads(0, 20)
+    p = records.preset("hifi")
+    p.baq_flag = 0
+    plan, _ = _compare(g.ref, r.batch, p)
+    assert plan.view.n_problems == 0
+    p = records.preset("hifi")
+    p.consensus = 0  # BAQ over whole confident blocks (thousands of rows per problem)
+    g2 = small_genome(synth.HIFI, read_len=1500, max_secondaries=1)
+    r2 = g2.reads(0, 6)
+    _compare(g2.ref, r2.batch, p)
+
+
+def test_plan_rejects_undefined_cigar_ops(built):
+    seq = "ACGT" * 10
+    hr = HandRef([("c0", seq * 4)])
+    hb = HandBatch([("r", [(0, 0, 0, "20M5N20M", seq, 30, ":20:20"), (256, 0, 3, "40M", seq, 30, ":40")])])
+    plan = api.Plan(hr.ref, hb.batch, records.preset("hifi"))
+    assert plan.view.grp_error[0] == api.EUNSUPPORTED and plan.view.n_groups == 0
+    o = orc.GroupResult()
+    st = orc.Rand()
+    orc.lib().orc_srand(C.byref(st), 1)
+    assert orc.lib().orc_score_group(hb.batch, hr.ref, 0, C.byref(records.preset("hifi")), C.byref(st), C.byref(o), None,
+                                     None, 0) == -2
+
+
+def test_host_tables_match_libm(built):
+    import math
+    thr = (C.c_double * 102)()
+    mt = (C.c_double * 256)()
+    ms = (C.c_double * 256)()
+    api.lib().spx_host_tables(thr, mt, ms)
+    f = orc.lib().orc_phred_from_posterior
+    for k in range(1, 102):
+        x = thr[k]
+        # thr[k] is the largest x with phred(x) >= k: check both sides of the boundary on the double lattice
+        assert int(-4.343 * math.log(x) + .499) >= k
+        assert int(-4.343 * math.log(np.nextafter(x, 2.0)) + .499) < k
+        for ulps in range(1, 40):
+            x = np.nextafter(x, 0.0)
+            assert int(-4.343 * math.log(x) + .499) >= k
+    assert mt[0] == -93.0 and mt[93] == 0.0 and ms[10] == -10 - 10 * math.log(3)
