@@ -27,20 +27,30 @@
 
 #define SPX_EI 0.25
 
-template <int G>
-__device__ __forceinline__ double shfl_up1(double v)
+/* ---- neighbour exchange inside a group of G adjacent lanes -------------- */
+/* G <= 16: DPP row shifts (VALU, no LDS round trip); wider groups: ds_bpermute */
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-    return __shfl_up(v, 1, G);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 template <int G>
-__device__ __forceinline__ double shfl_down1(double v)
+__device__ __forceinline__ double shfl_up1(double v) /* lane l <- lane l-1 */
 {
-    return __shfl_down(v, 1, G);
+    if constexpr (G == 1) return v;
+    else if constexpr (G <= 16) return dpp_f64<0x111>(v); /* row_shr:1 */
+    else return __shfl_up(v, 1, G);
 }
-template <>
-__device__ __forceinline__ double shfl_up1<1>(double v) { return v; }
-template <>
-__device__ __forceinline__ double shfl_down1<1>(double v) { return v; }
+template <int G>
+__device__ __forceinline__ double shfl_down1(double v) /* lane l <- lane l+1 */
+{
+    if constexpr (G == 1) return v;
+    else if constexpr (G <= 16) return dpp_f64<0x101>(v); /* row_shl:1 */
+    else return __shfl_down(v, 1, G);
+}
 
 __device__ __forceinline__ uint32_t fetch_code(const uint8_t *__restrict__ pool, int64_t nib0, int idx, int n)
 {
@@ -77,11 +87,17 @@ struct CodeWin {
     }
 };
 
+/* FAST: interior rows of problems without ambiguous bases -- every band slot below W is a real
+ * cell, so the emission is a two-way select and no validity masks are needed.  (Slots whose column
+ * is < 1 hold exact zeros by induction and stay zero whatever finite emission they are given.) */
+template <bool FAST>
 __device__ __forceinline__ double emission(uint32_t code, uint32_t qy, double e_match, double e_mis)
 {
     double e = (code == qy) ? e_match : e_mis;
-    if ((code | qy) & SPX_CODE_N) e = 1.0;
-    if (code & SPX_CODE_OUT) e = 0.0;
+    if constexpr (!FAST) {
+        if ((code | qy) & SPX_CODE_N) e = 1.0;
+        if (code & SPX_CODE_OUT) e = 0.0;
+    }
     return e;
 }
 
@@ -92,7 +108,7 @@ __device__ __forceinline__ uint32_t phred_from_x(double x, const double *__restr
 {
     if (!(x > 0.0)) return 0; /* x == 0 (log = -inf) or NaN: x86 (int) conversion gives INT_MIN -> 0 */
     /* thr[k] = largest x with f(x) >= k, k = 1..101, decreasing in k */
-    int lo = 0, hi = 101; /* invariant: f(x) >= lo ; f(x) < hi+1 */
+    int lo = 0, hi = 101;
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
         if (x <= thr[mid]) lo = mid; else hi = mid - 1;
@@ -100,8 +116,150 @@ __device__ __forceinline__ uint32_t phred_from_x(double x, const double *__restr
     return lo > 100 ? 99u : (uint32_t)lo;
 }
 
+struct HmmC {
+    double m0, m1, m2, m3, m4, m6, m8, e_match, e_mis;
+};
+
+/* one forward row (i >= 2), in place: on entry fM,fI,fD = scaled row i-1; on exit scaled row i.
+ * Returns the row sum s[i]. */
+template <int G, int C, bool FAST>
+__device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], double (&fD)[C], const CodeWin<C> &ew,
+                                          uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double &inv_out)
+{
+    double nM = shfl_down1<G>(fM[0]), nI = shfl_down1<G>(fI[0]);
+    if (g == G - 1) { nM = 0.0; nI = 0.0; }
+    /* parallel phase: fM<-M(i,.), fI<-I(i,.), fD<-m2*M(i,k-1) */
+    double prevM;
+    {
+        const double S0 = (h.m0 * fM[0] + h.m3 * fI[0]) + h.m6 * fD[0];
+        const double e0 = emission<FAST>(ew.get(0), qy, h.e_match, h.e_mis);
+        const double pMn = C > 1 ? fM[1] : nM, pIn = C > 1 ? fI[1] : nI;
+        prevM = e0 * S0;
+        fI[0] = SPX_EI * (h.m1 * pMn + h.m4 * pIn);
+        fM[0] = prevM;
+    }
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+        const double S = (h.m0 * fM[c] + h.m3 * fI[c]) + h.m6 * fD[c];
+        const double e = emission<FAST>(ew.get(c), qy, h.e_match, h.e_mis);
+        const double pMn = (c + 1 < C) ? fM[c + 1] : nM, pIn = (c + 1 < C) ? fI[c + 1] : nI;
+        const double newM = e * S;
+        fI[c] = SPX_EI * (h.m1 * pMn + h.m4 * pIn);
+        fD[c] = h.m2 * prevM;
+        fM[c] = newM;
+        prevM = newM;
+    }
+    {
+        double pl = shfl_up1<G>(prevM);
+        if (g == 0 || g > tlast) pl = 0.0; /* lanes beyond the band keep exact zeros */
+        fD[0] = h.m2 * pl;
+    }
+    /* serial phase: D recurrence and row sum in column order, one lane of the group at a time.
+     * Straight-line code only (uniform selects, no branches inside the unrolled register arrays). */
+    double carryD = 0.0, carryS = 0.0, mysum = 0.0;
+    for (int t = 0; t <= tlast; ++t) {
+        if (g == t) {
+            double d = carryD, s = carryS;
+            if (FAST && t < tlast) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    d = fD[c] + h.m8 * d;
+                    fD[c] = d;
+                    s = s + ((fM[c] + fI[c]) + d);
+                }
+            } else {
+                const int nc = min(C, Wu - t * C);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    /* slots beyond the band (c >= nc) keep D = 0: it feeds M of that slot in the next row */
+                    const bool valid = (c < nc) && (FAST || !(ew.get(c) & SPX_CODE_OUT));
+                    const double dn = fD[c] + h.m8 * d;
+                    d = valid ? dn : 0.0;
+                    fD[c] = d;
+                    const double tt = (fM[c] + fI[c]) + d;
+                    s = (FAST || valid) ? s + tt : s; /* FAST: pad slots hold exact zeros */
+                }
+            }
+            carryD = d; carryS = s; mysum = s;
+        }
+        if (t < tlast) {
+            carryD = shfl_up1<G>(carryD);
+            carryS = shfl_up1<G>(carryS);
+        }
+    }
+    const double tot = __shfl(mysum, tlast, G);
+    const double inv = 1.0 / tot;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { fM[c] *= inv; fI[c] *= inv; fD[c] *= inv; }
+    inv_out = inv;
+    return tot;
+}
+
+/* one backward row (1 <= i <= L-1), in place: on entry bM,bI = scaled row i+1; on exit scaled row i.
+ * ew holds the code of column k+1 (ref index i - bw + j) per slot. */
+template <int G, int C, bool FAST>
+__device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double (&bD)[C], const CodeWin<C> &ew,
+                                        uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double inv, bool first_row)
+{
+    double lI = shfl_up1<G>(bI[C - 1]);
+    if (g == 0) lI = 0.0;
+    const double em1 = SPX_EI * h.m1, em4 = SPX_EI * h.m4;
+    /* parallel phase A (descending, in place): bM<-e*m0+EI*m1*bI', bI<-e*m3+EI*m4*bI', bD<-e*m6 */
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {
+        const double e = emission<FAST>(ew.get(c), qy, h.e_match, h.e_mis) * bM[c];
+        const double bin = c > 0 ? bI[c - 1] : lI;
+        const double u = e * h.m0 + em1 * bin;
+        const double v = e * h.m3 + em4 * bin;
+        bD[c] = e * h.m6;
+        bM[c] = u;
+        bI[c] = v;
+    }
+    /* serial phase: D recurrence over descending columns; row 1 has y = 0 */
+    if (!first_row) {
+        double carryD = 0.0;
+        for (int t = tlast; t >= 0; --t) {
+            if (g == t) {
+                double d = carryD;
+                if (t < tlast) {
+#pragma unroll
+                    for (int c = C - 1; c >= 0; --c) {
+                        d = bD[c] + h.m8 * d;
+                        bD[c] = d;
+                    }
+                } else {
+                    const int nc = min(C, Wu - t * C);
+#pragma unroll
+                    for (int c = C - 1; c >= 0; --c) {
+                        const double x = (c < nc) ? bD[c] : 0.0; /* D of a column that does not exist stays 0 */
+                        d = x + h.m8 * d;
+                        bD[c] = d;
+                    }
+                }
+                carryD = d;
+            }
+            if (t > 0) carryD = shfl_down1<G>(carryD);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) bD[c] = 0.0;
+    }
+    /* parallel phase B: M += m2*D(i,k+1); scale */
+    double hD = shfl_down1<G>(bD[0]);
+    if (g == G - 1 || g >= tlast) hD = 0.0; /* the slot above the band has D = 0 */
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double dn = (c + 1 < C) ? bD[c + 1] : hD; /* slots beyond the band hold D = 0 (see below) */
+        bM[c] = (bM[c] + h.m2 * dn) * inv;
+        bI[c] = bI[c] * inv;
+    }
+}
+
+#ifndef SPX_WAVES
+#define SPX_WAVES 2
+#endif
 template <int G, int C>
-__global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
+__global__ __launch_bounds__(64, SPX_WAVES) void baq_kernel(spx_dev_batch B)
 {
     constexpr int PPW = 64 / G; /* problems per wave */
     constexpr int SLOTS = G * C;
@@ -114,25 +272,36 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
 
     int L = 0, R = 0, bw = 0;
     int64_t ref0 = 0, qry0 = 0;
-    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m6 = 0, m8 = 0, e_match = 0, e_mis = 0;
+    HmmC h = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int hasN = 0;
     if (act) {
         L = B.L[pid]; R = B.R[pid]; bw = B.bw[pid];
         ref0 = B.ref_nib[pid]; qry0 = B.qry_nib[pid];
-        const double *h = B.hmm + (int64_t)pid * SPX_H_N;
-        m0 = h[SPX_H_M0]; m1 = h[SPX_H_M1]; m2 = h[SPX_H_M2]; m3 = h[SPX_H_M3]; m4 = h[SPX_H_M4];
-        m6 = h[SPX_H_M6]; m8 = h[SPX_H_M8]; e_match = h[SPX_H_EMATCH]; e_mis = h[SPX_H_EMIS];
+        const double *hp = B.hmm + (int64_t)pid * SPX_H_N;
+        h.m0 = hp[SPX_H_M0]; h.m1 = hp[SPX_H_M1]; h.m2 = hp[SPX_H_M2]; h.m3 = hp[SPX_H_M3]; h.m4 = hp[SPX_H_M4];
+        h.m6 = hp[SPX_H_M6]; h.m8 = hp[SPX_H_M8]; h.e_match = hp[SPX_H_EMATCH]; h.e_mis = hp[SPX_H_EMIS];
+        hasN = hp[SPX_H_PAD0] != 0.0; /* host flag: window or query holds an ambiguous base */
     }
-    /* wave-uniform quantities: band width (host guarantees one W per wave) and the longest query */
-    int Wu = 0, Lw = 0;
+    /* wave-uniform quantities: band width (host guarantees one W per wave), the longest query, the last
+     * row every problem of the wave treats as interior, and whether any problem holds an N */
+    int Wu = 0, Lw = 0, fwd_fast_end, bwd_fast_end;
     {
         int w = act ? 2 * bw + 1 : 0, l = L;
+        int ff = act ? R - bw : 0x7fffffff;      /* forward row i is interior iff i + bw <= R       */
+        int bf = act ? R - bw - 1 : 0x7fffffff;  /* backward row i is interior iff i + bw <  R       */
+        int anyN = hasN;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             w = max(w, __shfl_xor(w, o));
             l = max(l, __shfl_xor(l, o));
+            ff = min(ff, __shfl_xor(ff, o));
+            bf = min(bf, __shfl_xor(bf, o));
+            anyN |= __shfl_xor(anyN, o);
         }
         Wu = __builtin_amdgcn_readfirstlane(w);
         Lw = __builtin_amdgcn_readfirstlane(l);
+        fwd_fast_end = __builtin_amdgcn_readfirstlane(anyN ? 0 : ff);
+        bwd_fast_end = __builtin_amdgcn_readfirstlane(anyN ? 0 : bf);
     }
     if (Lw == 0) return;
     const int tlast = (Wu - 1) / C; /* last lane of a group that owns band slots */
@@ -157,9 +326,7 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
         const uint32_t qy = act ? fetch_code(B.qry4, qry0, 0, L) : 0;
         /* window for row 1: slot j <-> ref idx r = 1 - bw + j - 1 */
 #pragma unroll
-        for (int k = 0; k < CodeWin<C>::NW; ++k) cw.w[k] = 0;
-#pragma unroll
-        for (int k = 0; k < CodeWin<C>::NW; ++k) padw.w[k] = 0;
+        for (int k = 0; k < CodeWin<C>::NW; ++k) { cw.w[k] = 0; padw.w[k] = 0; }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             int j = jbase + c;
@@ -175,7 +342,7 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
         for (int c = 0; c < C; ++c) {
             uint32_t code = ew.get(c);
             bool valid = !(code & SPX_CODE_OUT);
-            double e = emission(code, qy, e_match, e_mis);
+            double e = emission<false>(code, qy, h.e_match, h.e_mis);
             fM[c] = valid ? e * bM : 0.0;
             fI[c] = valid ? SPX_EI * bI : 0.0;
             fD[c] = 0.0;
@@ -227,63 +394,9 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
             /* prefetch next row's query base and incoming ref code */
             qy_n = fetch_code(B.qry4, qry0, i, L);
             rc_n = fetch_code(B.ref4, ref0, (i + 1) - bw + (jbase + C - 1) - 1, R);
-
-            double nM = shfl_down1<G>(fM[0]), nI = shfl_down1<G>(fI[0]);
-            if (g == G - 1) { nM = 0.0; nI = 0.0; }
-            /* parallel phase, in place: fM<-M(i,.), fI<-I(i,.), fD<-m2*M(i,k-1) */
-            double prevM; /* new M of slot c-1 */
-            {
-                double S0 = (m0 * fM[0] + m3 * fI[0]) + m6 * fD[0];
-                double e0 = emission(ew.get(0), qy, e_match, e_mis);
-                double pMn = C > 1 ? fM[1] : nM, pIn = C > 1 ? fI[1] : nI;
-                double newM = e0 * S0;
-                double newI = SPX_EI * (m1 * pMn + m4 * pIn);
-                fM[0] = newM; fI[0] = newI;
-                prevM = newM;
-            }
-#pragma unroll
-            for (int c = 1; c < C; ++c) {
-                double S = (m0 * fM[c] + m3 * fI[c]) + m6 * fD[c];
-                double e = emission(ew.get(c), qy, e_match, e_mis);
-                double pMn = (c + 1 < C) ? fM[c + 1] : nM, pIn = (c + 1 < C) ? fI[c + 1] : nI;
-                double newM = e * S;
-                double newI = SPX_EI * (m1 * pMn + m4 * pIn);
-                fD[c] = m2 * prevM;
-                fM[c] = newM; fI[c] = newI;
-                prevM = newM;
-            }
-            {
-                double pl = shfl_up1<G>(prevM);
-                if (g == 0) pl = 0.0;
-                fD[0] = m2 * pl;
-            }
-            /* serial phase: D chain and row sum in column order */
-            double carryD = 0.0, carryS = 0.0, mysum = 0.0;
-            for (int t = 0; t <= tlast; ++t) {
-                const int nc = min(C, Wu - t * C);
-                if (g == t) {
-                    double d = carryD, s = carryS;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        if (c < nc) {
-                            bool valid = !(ew.get(c) & SPX_CODE_OUT);
-                            double dn = fD[c] + m8 * d;
-                            d = valid ? dn : 0.0;
-                            fD[c] = d;
-                            double tt = (fM[c] + fI[c]) + d;
-                            s = valid ? s + tt : s;
-                        }
-                    }
-                    carryD = d; carryS = s; mysum = s;
-                }
-                carryD = shfl_up1<G>(carryD);
-                carryS = shfl_up1<G>(carryS);
-            }
-            const double tot = __shfl(mysum, tlast, G);
-            const double inv = 1.0 / tot;
-            s_cur = tot;
-#pragma unroll
-            for (int c = 0; c < C; ++c) { fM[c] *= inv; fI[c] *= inv; fD[c] *= inv; }
+            double inv;
+            if (i <= fwd_fast_end) s_cur = fwd_row<G, C, true>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
+            else s_cur = fwd_row<G, C, false>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
             if (g == 0) sinv[i] = inv;
             if (i == next_row) {
                 double *dst = fsave + (int64_t)wnext * fstride + jbase;
@@ -296,7 +409,6 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
     }
     /* ------------------------------------------------------------------ */
     /* terminal: s[L+1] = sum_k f(L,k).M*sM + f(L,k).I*sI in column order */
-    double bMr[C], bIr[C], bDr[C];
     {
         const double sM = act ? B.hmm[(int64_t)pid * SPX_H_N + SPX_H_SM] : 0.0;
         const double sI = act ? B.hmm[(int64_t)pid * SPX_H_N + SPX_H_SI] : 0.0;
@@ -307,12 +419,10 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
                 double s = carry;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    if (c < nc) {
-                        int k = L - bw + jbase + c;
-                        bool valid = k >= 1 && k <= R;
-                        double tt = fM[c] * sM + fI[c] * sI;
-                        s = valid ? s + tt : s;
-                    }
+                    int k = L - bw + jbase + c;
+                    bool valid = c < nc && k >= 1 && k <= R;
+                    double tt = fM[c] * sM + fI[c] * sI;
+                    s = valid ? s + tt : s;
                 }
                 carry = s; mysum = s;
             }
@@ -325,29 +435,26 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
         for (int c = 0; c < C; ++c) {
             int j = jbase + c, k = L - bw + j;
             bool valid = act && j < Wu && k >= 1 && k <= R;
-            bMr[c] = valid ? vM : 0.0;
-            bIr[c] = valid ? vI : 0.0;
-            bDr[c] = 0.0;
+            fM[c] = valid ? vM : 0.0;
+            fI[c] = valid ? vI : 0.0;
+            fD[c] = 0.0;
         }
     }
     __threadfence_block(); /* sinv[] written by lane g==0 is read by the whole group below */
-    /* MAP of one row: f from fsave, b in registers */
+    /* MAP of one row: f from fsave, b in registers.  "First strictly greater" in column order:
+     * within a lane the scan is in column order, across lanes the lower lane wins ties. */
     auto do_map = [&](int i, int w) {
         const double *src = fsave + (int64_t)w * fstride + jbase;
-        double zM[C], zI[C];
         double best = 0.0;
         int best_k = -1;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             int j = jbase + c, k = i - bw + j;
             bool valid = j < Wu && k >= 1 && k <= R;
-            double a = src[c] * bMr[c], b = src[SLOTS + c] * bIr[c];
-            zM[c] = valid ? a : -1.0;
-            zI[c] = valid ? b : -1.0;
+            double a = src[c] * fM[c], b = src[SLOTS + c] * fI[c];
             if (valid && a > best) { best = a; best_k = ((k - 1) << 2) | 0; }
             if (valid && b > best) { best = b; best_k = ((k - 1) << 2) | 1; }
         }
-        /* first-greatest over the group's lanes (lower lane wins ties) */
 #pragma unroll
         for (int o = 1; o < G; o <<= 1) {
             double ob = __shfl_up(best, o, G);
@@ -356,18 +463,22 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
         }
         best = __shfl(best, G - 1, G);
         best_k = __shfl(best_k, G - 1, G);
-        /* sequential sum */
+        /* sequential sum in column order (products recomputed: this runs on a few rows only) */
         double carry = 0.0, mysum = 0.0;
         for (int t = 0; t <= tlast; ++t) {
             if (g == t) {
                 double s = carry;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    if (zM[c] >= 0.0) { s += zM[c]; s += zI[c]; }
+                    int j = jbase + c, k = i - bw + j;
+                    if (j < Wu && k >= 1 && k <= R) {
+                        s += src[c] * fM[c];
+                        s += src[SLOTS + c] * fI[c];
+                    }
                 }
                 carry = s; mysum = s;
             }
-            carry = shfl_up1<G>(carry);
+            carry = __shfl_up(carry, 1, G);
         }
         const double sum = __shfl(mysum, tlast, G);
         if (g == 0) {
@@ -384,8 +495,6 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
             }
         }
     };
-    /* the argmax scan above must honour "first strictly greater": within a lane the loop is in
-     * column order; across lanes an earlier lane wins ties (ob >= best keeps the earlier one). */
 
     int wprev = nrows - 1;
     int prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
@@ -420,50 +529,13 @@ __global__ __launch_bounds__(64) void baq_kernel(spx_dev_batch B)
                 rc_p = fetch_code(B.ref4, ref0, (i - 1) - bw + jbase, R);
                 inv_p = sinv[i - 1];
             }
-            double lI = shfl_up1<G>(bIr[C - 1]);
-            if (g == 0) lI = 0.0;
-            const double em1 = SPX_EI * m1, em4 = SPX_EI * m4;
-            /* parallel phase A (descending, in place): bM<-e*m0+EI*m1*bI', bI<-e*m3+EI*m4*bI', bD<-e*m6 */
-#pragma unroll
-            for (int c = C - 1; c >= 0; --c) {
-                double e = emission(ew.get(c), qy, e_match, e_mis) * bMr[c];
-                double bin = c > 0 ? bIr[c - 1] : lI;
-                double u = e * m0 + em1 * bin;
-                double v = e * m3 + em4 * bin;
-                bDr[c] = e * m6;
-                bMr[c] = u;
-                bIr[c] = v;
-            }
-            /* serial phase: D chain, descending columns; y = (i > 1) */
-            if (i > 1) {
-                double carryD = 0.0;
-                for (int t = tlast; t >= 0; --t) {
-                    const int nc = min(C, Wu - t * C);
-                    if (g == t) {
-                        double d = carryD;
-#pragma unroll
-                        for (int c = C - 1; c >= 0; --c) {
-                            if (c < nc) {
-                                d = bDr[c] + m8 * d;
-                                bDr[c] = d;
-                            }
-                        }
-                        carryD = d;
-                    }
-                    carryD = shfl_down1<G>(carryD);
-                }
+            /* pad slots (j >= W): in the general path their emission is 0, so their D stays 0; the fast path
+             * ignores the pad code, hence D of pad slots is forced to 0 by never running the recurrence there
+             * and by zeroing e*m6 below */
+            if (i <= bwd_fast_end) {
+                bwd_row<G, C, true>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv, i == 1);
             } else {
-#pragma unroll
-                for (int c = 0; c < C; ++c) bDr[c] = 0.0;
-            }
-            /* parallel phase B: M += m2*D(i,k+1); scale */
-            double hD = shfl_down1<G>(bDr[0]);
-            if (g == G - 1) hD = 0.0;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                double dn = (c + 1 < C) ? bDr[c + 1] : hD; /* slots beyond the band hold D = 0 (e = 0 there) */
-                bMr[c] = (bMr[c] + m2 * dn) * inv;
-                bIr[c] = bIr[c] * inv;
+                bwd_row<G, C, false>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv, i == 1);
             }
             if (i == prev_row) {
                 do_map(i, wprev);

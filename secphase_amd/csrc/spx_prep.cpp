@@ -27,6 +27,19 @@ namespace spx {
 
 static const unsigned char kNt16Int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};
 
+void RefIndex::index_ambiguous(const spx_ref *ref)
+{
+    npos.assign(ref->n_contigs, std::vector<int32_t>());
+    for (int i = 0; i < ref->n_contigs; ++i) {
+        const char *s = ref->bases + ref->seq_off[i];
+        const int64_t n = ref->seq_off[i + 1] - ref->seq_off[i];
+        for (int64_t k = 0; k < n; ++k) {
+            const char c = s[k] & ~0x20;
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') npos[i].push_back((int32_t)k);
+        }
+    }
+}
+
 void HostBatch::clear()
 {
     ref_nib.clear(); qry_nib.clear(); ref_tid.clear(); ref_rfs.clear(); L.clear(); R.clear(); bw.clear(); row_off.clear(); n_rows.clear();
@@ -617,13 +630,16 @@ static int plan_baq(const Aln &a, int ai, const std::vector<Mk> &mkc, std::vecto
             hmm_constants(R, L, d, e, par->set_q, &out.hmm[out.hmm.size() - SPX_H_N]);
             {
                 const size_t nb = (size_t)(L + 1) / 2, at = out.qry4.size();
+                bool has_n = ref.window_has_n(a.tid, b.rfs, R);
                 out.qry4.resize(at + nb, 0);
                 for (int k = 0; k < L; ++k) {
                     const int p = b.sqs + k;
                     const unsigned code = kNt16Int[(a.seq4[p >> 1] >> ((~p & 1) << 2)) & 0xf];
+                    has_n |= code > 3;
                     out.qry4[at + (k >> 1)] |= (uint8_t)(code << ((k & 1) << 2));
                 }
                 out.qry_nibbles += (int64_t)nb * 2;
+                out.hmm[out.hmm.size() - SPX_H_N + SPX_H_PAD0] = has_n ? 1.0 : 0.0;
             }
             ++n_prob;
             cells += band_cells(L, R, bw);

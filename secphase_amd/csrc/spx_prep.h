@@ -45,6 +45,18 @@ struct HostBatch {
 struct RefIndex {
     std::vector<int64_t> nib_off; /* [n_contigs] first nibble of each contig (byte aligned) */
     std::vector<int64_t> len;     /* [n_contigs] bases */
+    /* positions of ambiguous (non-ACGT) bases per contig, ascending: lets prep flag windows that need
+     * the general emission path */
+    std::vector<std::vector<int32_t>> npos;
+    bool window_has_n(int tid, int64_t start, int64_t n) const
+    {
+        if ((size_t)tid >= npos.size()) return false;
+        const std::vector<int32_t> &v = npos[tid];
+        size_t lo = 0, hi = v.size();
+        while (lo < hi) { size_t m = (lo + hi) / 2; if (v[m] < start) lo = m + 1; else hi = m; }
+        return lo < v.size() && v[lo] < start + n;
+    }
+    void index_ambiguous(const spx_ref *ref);
 };
 
 /* prepares groups [g0,g1) of bt */

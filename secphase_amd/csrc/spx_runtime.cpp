@@ -64,6 +64,10 @@ struct spx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
+     * (or in front of) the bulk class */
+    hipStream_t cls_stream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t cls_done[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_ref4 = nullptr;
     int64_t ref_bytes = 0;
     spx::RefIndex ref;
@@ -130,6 +134,10 @@ extern "C" int spx_create(int device, spx_ctx **out)
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    for (int i = 1; i < 7; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&c->cls_stream[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->cls_done[i], hipEventDisableTiming));
+    }
     {
         std::vector<double> t(102 + 512);
         spx::phred_thresholds(t.data());
@@ -144,12 +152,16 @@ extern "C" int spx_create(int device, spx_ctx **out)
 extern "C" void spx_destroy(spx_ctx *c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->d_ref4) hipFree(c->d_ref4);
-    if (c->d_tables) hipFree(c->d_tables);
+    (void)hipSetDevice(c->device);
+    if (c->d_ref4) (void)hipFree(c->d_ref4);
+    if (c->d_tables) (void)hipFree(c->d_tables);
     for (int i = 0; i < 4; ++i)
-        if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 1; i < 7; ++i) {
+        if (c->cls_done[i]) (void)hipEventDestroy(c->cls_done[i]);
+        if (c->cls_stream[i]) (void)hipStreamDestroy(c->cls_stream[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -182,7 +194,8 @@ extern "C" int spx_set_reference(spx_ctx *c, const spx_ref *ref)
     };
     for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work, t);
     for (auto &t : th) t.join();
-    if (c->d_ref4) { hipFree(c->d_ref4); c->d_ref4 = nullptr; }
+    c->ref.index_ambiguous(ref);
+    if (c->d_ref4) { (void)hipFree(c->d_ref4); c->d_ref4 = nullptr; }
     c->ref_bytes = (int64_t)packed.size();
     HIPCHK(hipMalloc((void **)&c->d_ref4, packed.size()));
     HIPCHK(hipMemcpy(c->d_ref4, packed.data(), packed.size(), hipMemcpyHostToDevice));
@@ -387,8 +400,16 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    for (int cls = 0; cls < 7; ++cls)
-        if (w->cls_used[cls]) HIPCHK(spx_launch_baq(cls, &w->cls_batch[cls], c->stream));
+    /* wide classes first on their own streams (few, long waves), the bulk class on the main stream */
+    for (int cls = 6; cls >= 1; --cls) {
+        if (!w->cls_used[cls]) continue;
+        HIPCHK(hipStreamWaitEvent(c->cls_stream[cls], c->ev[0], 0));
+        HIPCHK(spx_launch_baq(cls, &w->cls_batch[cls], c->cls_stream[cls]));
+        HIPCHK(hipEventRecord(c->cls_done[cls], c->cls_stream[cls]));
+    }
+    if (w->cls_used[0]) HIPCHK(spx_launch_baq(0, &w->cls_batch[0], c->stream));
+    for (int cls = 1; cls < 7; ++cls)
+        if (w->cls_used[cls]) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, c->stream));
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
@@ -470,8 +491,8 @@ extern "C" int spx_work_stats(const spx_work *w, spx_stats *st)
 extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
 {
     if (!w) return;
-    if (c) hipSetDevice(c->device);
-    if (w->arena) hipFree(w->arena);
+    if (c) (void)hipSetDevice(c->device);
+    if (w->arena) (void)hipFree(w->arena);
     delete w;
 }
 
@@ -594,6 +615,12 @@ extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, cons
         for (int i = 1; i <= L; ++i) { hb.rows.push_back(i); hb.row_expect.push_back(i - 1); hb.row_rawq.push_back(93); }
         hb.hmm.resize(hb.hmm.size() + SPX_H_N);
         spx::hmm_constants(R, L, pars[p].d, pars[p].e, set_q[p], &hb.hmm[hb.hmm.size() - SPX_H_N]);
+        {
+            bool has_n = false;
+            for (int k = 0; k < R; ++k) has_n |= ref[ref_off[p] + k] > 3;
+            for (int k = 0; k < L; ++k) has_n |= query[qry_off[p] + k] > 3;
+            hb.hmm[hb.hmm.size() - SPX_H_N + SPX_H_PAD0] = has_n ? 1.0 : 0.0;
+        }
         hb.dp_cells += spx::band_cells(L, R, bw);
     }
     ref4.resize(ref4.size() + 16, 0);
@@ -607,14 +634,14 @@ extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, cons
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(SPX_EHIP, "kernel execution failed");
     if (!rc) {
         float ms = 0;
-        hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
         if (kernel_ms) *kernel_ms = ms;
         const size_t nr = hb.rows.size();
         if (hipMemcpy(state, w->d_state, nr * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(q, w->d_q, nr, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(SPX_EHIP, "copy back failed");
     }
-    hipFree(d_ref);
+    (void)hipFree(d_ref);
     spx_work_free(c, w);
     return rc;
 }
@@ -661,6 +688,7 @@ extern "C" int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const sp
         ri.len.push_back(ref->seq_off[i + 1] - ref->seq_off[i]);
         nib += (ri.len[i] + 1) & ~(int64_t)1;
     }
+    ri.index_ambiguous(ref);
     spx_plan *p = new spx_plan();
     spx::prepare_groups(bt, ri, par, 0, bt->n_groups, p->hb);
     for (const spx_dev_marker &m : p->hb.markers) {
