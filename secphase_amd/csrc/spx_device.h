@@ -60,6 +60,9 @@ typedef struct spx_dev_batch {
     /* scratch */
     double *sinv;  /* 1/s[i] per row */
     double *fsave; /* scaled forward M,I rows at wanted rows: [row][2][slots] */
+    double *bsave; /* scaled backward M,I rows at wanted rows, same layout */
+    const int32_t *row_prob;   /* per wanted row: its problem */
+    const int32_t *prob_slots; /* per problem: band slots of its class */
     int64_t fsave_stride; /* doubles per wanted row = 2*slots of the class */
     const int64_t *fsave_off; /* per problem: offset (in doubles) of its first saved row */
     /* outputs per wanted row */

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "spx_device.h"
 
 #define SPX_EI 0.25
@@ -255,105 +257,134 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double
     }
 }
 
-#ifndef SPX_WAVES
-#define SPX_WAVES 2
-#endif
-template <int G, int C>
-__global__ __launch_bounds__(64, SPX_WAVES) void baq_kernel(spx_dev_batch B)
-{
-    constexpr int PPW = 64 / G; /* problems per wave */
-    constexpr int SLOTS = G * C;
-    const int lane = threadIdx.x & 63;
-    const int g = lane % G;
-    const int grp = lane / G;
-    const int oslot = blockIdx.x * PPW + grp;
-    const int pid = oslot < B.n_order ? B.order[oslot] : -1;
-    const bool act = pid >= 0;
+/* per-lane view of one problem */
+struct Prob {
+    int pid, L, R, bw, nrows, row0;
+    int64_t ref0, qry0;
+    bool act;
+};
 
-    int L = 0, R = 0, bw = 0;
-    int64_t ref0 = 0, qry0 = 0;
-    HmmC h = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int hasN = 0;
-    if (act) {
-        L = B.L[pid]; R = B.R[pid]; bw = B.bw[pid];
-        ref0 = B.ref_nib[pid]; qry0 = B.qry_nib[pid];
+template <int G>
+__device__ __forceinline__ Prob load_problem(const spx_dev_batch &B, int lane, HmmC &h, int &hasN)
+{
+    constexpr int PPW = 64 / G;
+    Prob P;
+    const int oslot = blockIdx.x * PPW + lane / G;
+    P.pid = oslot < B.n_order ? B.order[oslot] : -1;
+    P.L = P.R = P.bw = P.nrows = P.row0 = 0;
+    P.ref0 = P.qry0 = 0;
+    hasN = 0;
+    h = HmmC{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (P.pid >= 0) {
+        P.nrows = B.n_rows[P.pid];
+        if (P.nrows <= 0) P.pid = -1; /* no marker row wants a value: nothing observable to compute */
+    }
+    P.act = P.pid >= 0;
+    if (P.act) {
+        const int pid = P.pid;
+        P.L = B.L[pid]; P.R = B.R[pid]; P.bw = B.bw[pid];
+        P.ref0 = B.ref_nib[pid]; P.qry0 = B.qry_nib[pid];
+        P.row0 = B.row_off[pid];
         const double *hp = B.hmm + (int64_t)pid * SPX_H_N;
         h.m0 = hp[SPX_H_M0]; h.m1 = hp[SPX_H_M1]; h.m2 = hp[SPX_H_M2]; h.m3 = hp[SPX_H_M3]; h.m4 = hp[SPX_H_M4];
         h.m6 = hp[SPX_H_M6]; h.m8 = hp[SPX_H_M8]; h.e_match = hp[SPX_H_EMATCH]; h.e_mis = hp[SPX_H_EMIS];
         hasN = hp[SPX_H_PAD0] != 0.0; /* host flag: window or query holds an ambiguous base */
     }
-    /* wave-uniform quantities: band width (host guarantees one W per wave), the longest query, the last
-     * row every problem of the wave treats as interior, and whether any problem holds an N */
-    int Wu = 0, Lw = 0, fwd_fast_end, bwd_fast_end;
-    {
-        int w = act ? 2 * bw + 1 : 0, l = L;
-        int ff = act ? R - bw : 0x7fffffff;      /* forward row i is interior iff i + bw <= R       */
-        int bf = act ? R - bw - 1 : 0x7fffffff;  /* backward row i is interior iff i + bw <  R       */
-        int anyN = hasN;
+    return P;
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            w = max(w, __shfl_xor(w, o));
-            l = max(l, __shfl_xor(l, o));
-            ff = min(ff, __shfl_xor(ff, o));
-            bf = min(bf, __shfl_xor(bf, o));
-            anyN |= __shfl_xor(anyN, o);
-        }
-        Wu = __builtin_amdgcn_readfirstlane(w);
-        Lw = __builtin_amdgcn_readfirstlane(l);
-        fwd_fast_end = __builtin_amdgcn_readfirstlane(anyN ? 0 : ff);
-        bwd_fast_end = __builtin_amdgcn_readfirstlane(anyN ? 0 : bf);
-    }
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+#ifndef SPX_WAVES_F
+#define SPX_WAVES_F 2
+#endif
+#ifndef SPX_WAVES_B
+#define SPX_WAVES_B 2
+#endif
+
+/* ====================================================================== */
+/* forward pass: rows 1..L, saves 1/s[i] (i < L), s[L], s[L+1] and the scaled M,I rows at the wanted rows */
+template <int G, int C>
+__global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch B)
+{
+    constexpr int SLOTS = G * C;
+    const int lane = threadIdx.x & 63;
+    const int g = lane % G;
+    HmmC h;
+    int hasN;
+    const Prob P = load_problem<G>(B, lane, h, hasN);
+    const bool act = P.act;
+    const int L = P.L, R = P.R, bw = P.bw;
+    const int Wu = wave_max(act ? 2 * bw + 1 : 0);
+    const int Lw = wave_max(L);
     if (Lw == 0) return;
-    const int tlast = (Wu - 1) / C; /* last lane of a group that owns band slots */
+    /* forward row i is interior iff i + bw <= R, for every problem of the wave, and no N anywhere */
+    const int anyN = wave_max(hasN);
+    const int fast_end = anyN ? 1 : min(wave_min(act ? R - bw : 0x7fffffff), Lw);
+    const int tlast = (Wu - 1) / C;
     const int jbase = g * C;
 
     double fM[C], fI[C], fD[C];
     CodeWin<C> cw, padw; /* padw: SPX_CODE_OUT in the slots beyond the band (j >= W), fixed per problem */
-    double *sinv = B.sinv + (act ? B.s_off[pid] : 0);
-    const int nrows = act ? B.n_rows[pid] : 0;
-    const int row0 = act ? B.row_off[pid] : 0;
-    double *fsave = B.fsave + (act ? B.fsave_off[pid] : 0);
+    double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
+    double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
     const int64_t fstride = B.fsave_stride;
+    const int nrows = P.nrows, row0 = P.row0;
 
-    /* ------------------------------------------------------------------ */
-    /* forward row 1: f(1,k) = e*bM, EI*bI for k in [1, min(R, bw+1)], divided by the row sum */
     double s_cur = 1.0;
     int wnext = 0;
     int next_row = nrows > 0 ? B.rows[row0] : 0x7fffffff;
+    auto save_row = [&]() {
+        double *dst = fsave + (int64_t)wnext * fstride + jbase;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dst[c] = fM[c]; dst[SLOTS + c] = fI[c]; }
+        wnext++;
+        next_row = wnext < nrows ? B.rows[row0 + wnext] : 0x7fffffff;
+    };
+    /* row 1: f(1,k) = e*bM, EI*bI for k in [1, min(R, bw+1)], divided by the row sum */
     {
-        const double bM = act ? B.hmm[(int64_t)pid * SPX_H_N + SPX_H_BM] : 0.0;
-        const double bI = act ? B.hmm[(int64_t)pid * SPX_H_N + SPX_H_BI] : 0.0;
-        const uint32_t qy = act ? fetch_code(B.qry4, qry0, 0, L) : 0;
-        /* window for row 1: slot j <-> ref idx r = 1 - bw + j - 1 */
+        const double bM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_BM] : 0.0;
+        const double bI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_BI] : 0.0;
+        const uint32_t qy = act ? fetch_code(B.qry4, P.qry0, 0, L) : 0;
 #pragma unroll
         for (int k = 0; k < CodeWin<C>::NW; ++k) { cw.w[k] = 0; padw.w[k] = 0; }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            int j = jbase + c;
-            uint32_t code = act ? fetch_code(B.ref4, ref0, j - bw, R) : SPX_CODE_OUT;
-            cw.set(c, code);
+            const int j = jbase + c; /* slot j <-> ref idx 1 - bw + j - 1 */
+            cw.set(c, act ? fetch_code(B.ref4, P.ref0, j - bw, R) : SPX_CODE_OUT);
             padw.set(c, j < Wu ? 0u : (uint32_t)SPX_CODE_OUT);
         }
-        double carry = 0.0, mysum = 0.0;
         CodeWin<C> ew;
 #pragma unroll
         for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            uint32_t code = ew.get(c);
-            bool valid = !(code & SPX_CODE_OUT);
-            double e = emission<false>(code, qy, h.e_match, h.e_mis);
+            const uint32_t code = ew.get(c);
+            const bool valid = !(code & SPX_CODE_OUT);
+            const double e = emission<false>(code, qy, h.e_match, h.e_mis);
             fM[c] = valid ? e * bM : 0.0;
             fI[c] = valid ? SPX_EI * bI : 0.0;
             fD[c] = 0.0;
         }
+        double carry = 0.0, mysum = 0.0;
         for (int t = 0; t <= tlast; ++t) {
             if (g == t) {
                 double s = carry;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    bool valid = !(ew.get(c) & SPX_CODE_OUT);
-                    double tt = fM[c] + fI[c];
+                    const bool valid = !(ew.get(c) & SPX_CODE_OUT);
+                    const double tt = fM[c] + fI[c];
                     s = valid ? s + tt : s;
                 }
                 mysum = s;
@@ -361,7 +392,7 @@ __global__ __launch_bounds__(64, SPX_WAVES) void baq_kernel(spx_dev_batch B)
             }
             carry = shfl_up1<G>(carry);
         }
-        double tot = __shfl(mysum, tlast, G);
+        const double tot = __shfl(mysum, tlast, G);
         s_cur = tot;
         if (act) {
 #pragma unroll
@@ -370,48 +401,35 @@ __global__ __launch_bounds__(64, SPX_WAVES) void baq_kernel(spx_dev_batch B)
                 fI[c] = fI[c] / tot;
             }
             if (g == 0) sinv[1] = 1.0 / tot;
-        }
-        if (act && next_row == 1) {
-            double *dst = fsave + (int64_t)wnext * fstride + jbase;
-#pragma unroll
-            for (int c = 0; c < C; ++c) { dst[c] = fM[c]; dst[SLOTS + c] = fI[c]; }
-            wnext++;
-            next_row = wnext < nrows ? B.rows[row0 + wnext] : 0x7fffffff;
+            if (next_row == 1) save_row();
         }
     }
-    /* ------------------------------------------------------------------ */
-    /* forward rows 2..L */
-    uint32_t qy_n = (act && L >= 2) ? fetch_code(B.qry4, qry0, 1, L) : 0;
-    uint32_t rc_n = (act && L >= 2) ? fetch_code(B.ref4, ref0, 2 - bw + (jbase + C - 1) - 1, R) : SPX_CODE_OUT;
-    for (int i = 2; i <= Lw; ++i) {
-        const bool on = act && i <= L;
-        if (on) {
+    /* rows 2..L: an interior stretch without masks, then the rows whose band touches column R */
+    uint32_t qy_n = (act && L >= 2) ? fetch_code(B.qry4, P.qry0, 1, L) : 0;
+    uint32_t rc_n = (act && L >= 2) ? fetch_code(B.ref4, P.ref0, 2 - bw + (jbase + C - 1) - 1, R) : SPX_CODE_OUT;
+    auto row = [&](int i, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        if (act && i <= L) {
             const uint32_t qy = qy_n;
             cw.shift_down(rc_n);
             CodeWin<C> ew;
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
-            /* prefetch next row's query base and incoming ref code */
-            qy_n = fetch_code(B.qry4, qry0, i, L);
-            rc_n = fetch_code(B.ref4, ref0, (i + 1) - bw + (jbase + C - 1) - 1, R);
+            qy_n = fetch_code(B.qry4, P.qry0, i, L); /* prefetch for row i+1 */
+            rc_n = fetch_code(B.ref4, P.ref0, (i + 1) - bw + (jbase + C - 1) - 1, R);
             double inv;
-            if (i <= fwd_fast_end) s_cur = fwd_row<G, C, true>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
-            else s_cur = fwd_row<G, C, false>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
+            s_cur = fwd_row<G, C, FAST>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
             if (g == 0) sinv[i] = inv;
-            if (i == next_row) {
-                double *dst = fsave + (int64_t)wnext * fstride + jbase;
-#pragma unroll
-                for (int c = 0; c < C; ++c) { dst[c] = fM[c]; dst[SLOTS + c] = fI[c]; }
-                wnext++;
-                next_row = wnext < nrows ? B.rows[row0 + wnext] : 0x7fffffff;
-            }
+            if (i == next_row) save_row();
         }
-    }
-    /* ------------------------------------------------------------------ */
+    };
+    int i = 2;
+    for (; i <= fast_end; ++i) row(i, std::true_type{});
+    for (; i <= Lw; ++i) row(i, std::false_type{});
     /* terminal: s[L+1] = sum_k f(L,k).M*sM + f(L,k).I*sI in column order */
     {
-        const double sM = act ? B.hmm[(int64_t)pid * SPX_H_N + SPX_H_SM] : 0.0;
-        const double sI = act ? B.hmm[(int64_t)pid * SPX_H_N + SPX_H_SI] : 0.0;
+        const double sM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SM] : 0.0;
+        const double sI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SI] : 0.0;
         double carry = 0.0, mysum = 0.0;
         for (int t = 0; t <= tlast; ++t) {
             const int nc = min(C, Wu - t * C);
@@ -419,9 +437,9 @@ __global__ __launch_bounds__(64, SPX_WAVES) void baq_kernel(spx_dev_batch B)
                 double s = carry;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    int k = L - bw + jbase + c;
-                    bool valid = c < nc && k >= 1 && k <= R;
-                    double tt = fM[c] * sM + fI[c] * sI;
+                    const int k = L - bw + jbase + c;
+                    const bool valid = c < nc && k >= 1 && k <= R;
+                    const double tt = fM[c] * sM + fI[c] * sI;
                     s = valid ? s + tt : s;
                 }
                 carry = s; mysum = s;
@@ -429,121 +447,141 @@ __global__ __launch_bounds__(64, SPX_WAVES) void baq_kernel(spx_dev_batch B)
             carry = shfl_up1<G>(carry);
         }
         const double sL1 = __shfl(mysum, tlast, G);
-        /* backward row L */
-        const double vM = (sM / s_cur) / sL1, vI = (sI / s_cur) / sL1;
+        if (act && g == 0) { sinv[L] = s_cur; sinv[L + 1] = sL1; } /* raw s[L], s[L+1] for the backward start */
+    }
+}
+
+/* ====================================================================== */
+/* backward pass: rows L..(first wanted row), MAP + phred + write-back rule at the wanted rows.
+ * Rows below the first wanted row have no observable effect and are not computed. */
+template <int G, int C>
+__global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch B)
+{
+    constexpr int SLOTS = G * C;
+    const int lane = threadIdx.x & 63;
+    const int g = lane % G;
+    HmmC h;
+    int hasN;
+    const Prob P = load_problem<G>(B, lane, h, hasN);
+    const bool act = P.act;
+    const int L = P.L, R = P.R, bw = P.bw;
+    const int Wu = wave_max(act ? 2 * bw + 1 : 0);
+    const int Lw = wave_max(L);
+    if (Lw == 0) return;
+    const int nrows = P.nrows, row0 = P.row0;
+    const int stop = act ? B.rows[row0] : 0x7fffffff; /* first (smallest) wanted row */
+    const int stop_w = wave_min(stop);
+    const int anyN = wave_max(hasN);
+    /* backward row i is interior iff i + bw < R */
+    const int fast_end = anyN ? 0 : wave_min(act ? R - bw - 1 : 0x7fffffff);
+    const int tlast = (Wu - 1) / C;
+    const int jbase = g * C;
+
+    double bM[C], bI[C], bD[C];
+    CodeWin<C> cw, padw;
+    const double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
+    const int64_t fstride = B.fsave_stride;
+    /* row L */
+    {
+        const double sM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SM] : 0.0;
+        const double sI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SI] : 0.0;
+        const double sL = act ? sinv[L] : 1.0, sL1 = act ? sinv[L + 1] : 1.0;
+        const double vM = (sM / sL) / sL1, vI = (sI / sL) / sL1;
+#pragma unroll
+        for (int k = 0; k < CodeWin<C>::NW; ++k) { cw.w[k] = 0; padw.w[k] = 0; }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            int j = jbase + c, k = L - bw + j;
-            bool valid = act && j < Wu && k >= 1 && k <= R;
-            fM[c] = valid ? vM : 0.0;
-            fI[c] = valid ? vI : 0.0;
-            fD[c] = 0.0;
+            const int j = jbase + c, k = L - bw + j;
+            const bool valid = act && j < Wu && k >= 1 && k <= R;
+            bM[c] = valid ? vM : 0.0;
+            bI[c] = valid ? vI : 0.0;
+            bD[c] = 0.0;
+            padw.set(c, j < Wu ? 0u : (uint32_t)SPX_CODE_OUT);
+            /* window for row L-1: code of ref idx (L-1) - bw + j (= column k+1 of that row) */
+            cw.set(c, (act && L >= 2) ? fetch_code(B.ref4, P.ref0, (L - 1) - bw + j, R) : SPX_CODE_OUT);
         }
     }
-    __threadfence_block(); /* sinv[] written by lane g==0 is read by the whole group below */
-    /* MAP of one row: f from fsave, b in registers.  "First strictly greater" in column order:
-     * within a lane the scan is in column order, across lanes the lower lane wins ties. */
-    auto do_map = [&](int i, int w) {
-        const double *src = fsave + (int64_t)w * fstride + jbase;
-        double best = 0.0;
-        int best_k = -1;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            int j = jbase + c, k = i - bw + j;
-            bool valid = j < Wu && k >= 1 && k <= R;
-            double a = src[c] * fM[c], b = src[SLOTS + c] * fI[c];
-            if (valid && a > best) { best = a; best_k = ((k - 1) << 2) | 0; }
-            if (valid && b > best) { best = b; best_k = ((k - 1) << 2) | 1; }
-        }
-#pragma unroll
-        for (int o = 1; o < G; o <<= 1) {
-            double ob = __shfl_up(best, o, G);
-            int ok = __shfl_up(best_k, o, G);
-            if (g >= o && ob >= best && ok >= 0) { best = ob; best_k = ok; }
-        }
-        best = __shfl(best, G - 1, G);
-        best_k = __shfl(best_k, G - 1, G);
-        /* sequential sum in column order (products recomputed: this runs on a few rows only) */
-        double carry = 0.0, mysum = 0.0;
-        for (int t = 0; t <= tlast; ++t) {
-            if (g == t) {
-                double s = carry;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    int j = jbase + c, k = i - bw + j;
-                    if (j < Wu && k >= 1 && k <= R) {
-                        s += src[c] * fM[c];
-                        s += src[SLOTS + c] * fI[c];
-                    }
-                }
-                carry = s; mysum = s;
-            }
-            carry = __shfl_up(carry, 1, G);
-        }
-        const double sum = __shfl(mysum, tlast, G);
-        if (g == 0) {
-            double mx = best / sum;
-            uint32_t q = phred_from_x(1.0 - mx, B.qthr);
-            int ridx = row0 + w;
-            if (B.out_state) B.out_state[ridx] = best_k;
-            if (B.out_q) B.out_q[ridx] = (uint8_t)q;
-            if (B.out_bq) {
-                int expect = B.row_expect[ridx];
-                uint32_t raw = B.row_rawq[ridx];
-                uint32_t bq = ((best_k & 3) != 0 || (best_k >> 2) != expect) ? 0u : (raw < q ? raw : q);
-                B.out_bq[ridx] = (uint8_t)(bq < 94 ? bq : 93);
-            }
-        }
-    };
-
+    /* the scaled b row of every wanted row is parked next to the forward row; map_kernel finishes the job */
+    double *bsave = B.bsave + (act ? B.fsave_off[P.pid] : 0);
     int wprev = nrows - 1;
     int prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
-    if (act && prev_row == L) {
-        do_map(L, wprev);
+    auto save_row = [&]() {
+        double *dst = bsave + (int64_t)wprev * fstride + jbase;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dst[c] = bM[c]; dst[SLOTS + c] = bI[c]; }
         wprev--;
         prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
-    }
-    /* ------------------------------------------------------------------ */
-    /* backward rows L-1..1.  Window for row i holds the code of ref idx i - bw + j (= column k+1). */
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int j = jbase + c;
-        uint32_t code = (act && L >= 2) ? fetch_code(B.ref4, ref0, (L - 1) - bw + j, R) : SPX_CODE_OUT;
-        cw.set(c, code);
-    }
-    uint32_t qy_p = (act && L >= 2) ? fetch_code(B.qry4, qry0, L - 1, L) : 0;
+    };
+    if (act && prev_row == L) save_row();
+    uint32_t qy_p = (act && L >= 2) ? fetch_code(B.qry4, P.qry0, L - 1, L) : 0;
     uint32_t rc_p = SPX_CODE_OUT;
     double inv_p = (act && L >= 2) ? sinv[L - 1] : 0.0;
-    for (int i = Lw - 1; i >= 1; --i) {
-        const bool on = act && i <= L - 1;
-        if (on) {
+    auto row = [&](int i, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        if (act && i <= L - 1 && i >= stop) {
             const uint32_t qy = qy_p;
             const double inv = inv_p;
             if (i != L - 1) cw.shift_up(rc_p);
             CodeWin<C> ew;
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
-            /* prefetch for row i-1 */
-            if (i >= 2) {
-                qy_p = fetch_code(B.qry4, qry0, i - 1, L);
-                rc_p = fetch_code(B.ref4, ref0, (i - 1) - bw + jbase, R);
+            if (i >= 2) { /* prefetch for row i-1 */
+                qy_p = fetch_code(B.qry4, P.qry0, i - 1, L);
+                rc_p = fetch_code(B.ref4, P.ref0, (i - 1) - bw + jbase, R);
                 inv_p = sinv[i - 1];
             }
-            /* pad slots (j >= W): in the general path their emission is 0, so their D stays 0; the fast path
-             * ignores the pad code, hence D of pad slots is forced to 0 by never running the recurrence there
-             * and by zeroing e*m6 below */
-            if (i <= bwd_fast_end) {
-                bwd_row<G, C, true>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv, i == 1);
-            } else {
-                bwd_row<G, C, false>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv, i == 1);
-            }
-            if (i == prev_row) {
-                do_map(i, wprev);
-                wprev--;
-                prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
-            }
+            bwd_row<G, C, FAST>(bM, bI, bD, ew, qy, h, g, Wu, tlast, inv, i == 1);
+            if (i == prev_row) save_row();
         }
+    };
+    int i = Lw - 1;
+    const int lo = max(stop_w, 1);
+    for (; i > fast_end && i >= lo; --i) row(i, std::false_type{});
+    for (; i >= lo; --i) row(i, std::true_type{});
+}
+
+/* ====================================================================== */
+/* MAP + phred + write-back rule, one lane per wanted row.  z = f*b over the M and I states of the
+ * row in column order: first strictly greatest wins, the sum is sequential (probaln_glocal's MAP loop);
+ * then min(raw, q) with the CIGAR/MAP consistency check (ptMarker.c:778-779,786). */
+__global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_rows_total)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows_total) return;
+    const int p = B.row_prob[r];
+    const int i = B.rows[r], bw = B.bw[p], R = B.R[p];
+    const int W = 2 * bw + 1, slots = B.prob_slots[p];
+    const int64_t off = B.fsave_off[p] + (int64_t)(r - B.row_off[p]) * 2 * slots;
+    const double *fM = B.fsave + off, *fI = fM + slots, *bM = B.bsave + off, *bI = bM + slots;
+    const int j0 = max(0, bw + 1 - i), j1 = min(W - 1, R - i + bw); /* 1 <= k = i - bw + j <= R */
+    double best = 0.0, sum = 0.0;
+    int best_k = -1;
+    for (int j = j0; j <= j1; ++j) {
+        const int k = i - bw + j;
+        double z = fM[j] * bM[j];
+        if (z > best) { best = z; best_k = ((k - 1) << 2) | 0; }
+        sum += z;
+        z = fI[j] * bI[j];
+        if (z > best) { best = z; best_k = ((k - 1) << 2) | 1; }
+        sum += z;
     }
+    const double mx = best / sum;
+    const uint32_t q = phred_from_x(1.0 - mx, B.qthr);
+    if (B.out_state) B.out_state[r] = best_k;
+    if (B.out_q) B.out_q[r] = (uint8_t)q;
+    if (B.out_bq) {
+        const int expect = B.row_expect[r];
+        const uint32_t raw = B.row_rawq[r];
+        const uint32_t bq = ((best_k & 3) != 0 || (best_k >> 2) != expect) ? 0u : (raw < q ? raw : q);
+        B.out_bq[r] = (uint8_t)(bq < 94 ? bq : 93);
+    }
+}
+
+extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st)
+{
+    if (n_rows_total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(map_kernel, dim3((n_rows_total + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    return hipGetLastError();
 }
 
 /* ---------------------------------------------------------------------- */
@@ -613,14 +651,16 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 }
 
 /* ---------------------------------------------------------------------- */
+/* phase 0 = forward kernel, 1 = backward kernel (same grid; the backward launch follows on the same stream) */
 extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st)
 {
     if (B->n_order <= 0) return hipSuccess;
-#define SPX_LAUNCH(G_, C_)                                                                    \
-    {                                                                                         \
-        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw;                             \
-        hipLaunchKernelGGL((baq_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);          \
-    }                                                                                         \
+#define SPX_LAUNCH(G_, C_)                                                                        \
+    {                                                                                             \
+        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw;                                 \
+        hipLaunchKernelGGL((baq_fwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);          \
+        hipLaunchKernelGGL((baq_bwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);          \
+    }                                                                                             \
     break;
     switch (cls) {
     case 0: SPX_LAUNCH(4, 12)

@@ -27,6 +27,7 @@
 
 extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st);
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, hipStream_t st);
+extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
                                       unsigned long long *out, hipStream_t st);
 
@@ -247,12 +248,15 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     }
     /* scratch offsets */
     std::vector<int64_t> s_off(np), fsave_off(np);
+    std::vector<int32_t> prob_slots(np), row_prob(nr);
     int64_t s_tot = 0, f_tot = 0;
     for (size_t p = 0; p < np; ++p) {
         s_off[p] = s_tot;
         s_tot += hb.L[p] + 2;
         fsave_off[p] = f_tot;
-        f_tot += (int64_t)hb.n_rows[p] * 2 * spx::class_slots(spx::band_class(2 * hb.bw[p] + 1));
+        prob_slots[p] = spx::class_slots(spx::band_class(2 * hb.bw[p] + 1));
+        f_tot += (int64_t)hb.n_rows[p] * 2 * prob_slots[p];
+        for (int32_t w2 = 0; w2 < hb.n_rows[p]; ++w2) row_prob[hb.row_off[p] + w2] = (int32_t)p;
     }
     /* arena layout */
     Carver cv;
@@ -260,13 +264,15 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
            o_R = cv.take<int32_t>(np), o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N),
            o_row_off = cv.take<int32_t>(np), o_n_rows = cv.take<int32_t>(np), o_s_off = cv.take<int64_t>(np),
            o_fs_off = cv.take<int64_t>(np), o_qry4 = cv.take<uint8_t>(hb.qry4.size() + 16),
-           o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr), o_rawq = cv.take<uint8_t>(nr);
+           o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr), o_rawq = cv.take<uint8_t>(nr),
+           o_row_prob = cv.take<int32_t>(nr), o_prob_slots = cv.take<int32_t>(np);
     size_t o_order[7];
     for (int cls = 0; cls < 7; ++cls) o_order[cls] = cv.take<int32_t>(order[cls].size());
     size_t o_mk_first = cv.take<int32_t>(ng + 1), o_markers = cv.take<spx_dev_marker>(nm), o_naln = cv.take<uint8_t>(ng),
            o_sec = cv.take<uint16_t>(ng), o_gidx = cv.take<int32_t>(ng);
     const size_t in_bytes = cv.off;
     size_t o_sinv = cv.take<double>((size_t)s_tot), o_fsave = cv.take<double>((size_t)f_tot),
+           o_bsave = cv.take<double>((size_t)f_tot),
            o_bq = cv.take<uint8_t>(nr + 16), o_state = want_state_q ? cv.take<int32_t>(nr) : 0,
            o_q = want_state_q ? cv.take<uint8_t>(nr + 16) : 0, o_score = cv.take<double>(ng * 10),
            o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
@@ -282,6 +288,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     UP(o_ref_nib, hb.ref_nib); UP(o_qry_nib, hb.qry_nib); UP(o_L, hb.L); UP(o_R, hb.R); UP(o_bw, hb.bw);
     UP(o_hmm, hb.hmm); UP(o_row_off, hb.row_off); UP(o_n_rows, hb.n_rows); UP(o_s_off, s_off); UP(o_fs_off, fsave_off);
     UP(o_qry4, hb.qry4); UP(o_rows, hb.rows); UP(o_expect, hb.row_expect); UP(o_rawq, hb.row_rawq);
+    UP(o_row_prob, row_prob); UP(o_prob_slots, prob_slots);
     for (int cls = 0; cls < 7; ++cls) UP(o_order[cls], order[cls]);
     UP(o_mk_first, hb.mk_first); UP(o_markers, hb.markers); UP(o_naln, hb.n_aln); UP(o_sec, hb.sec_mask);
     UP(o_gidx, hb.grp_index);
@@ -320,6 +327,9 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
         B.row_rawq = (const uint8_t *)(base + o_rawq);
         B.sinv = (double *)(base + o_sinv);
         B.fsave = (double *)(base + o_fsave);
+        B.bsave = (double *)(base + o_bsave);
+        B.row_prob = (const int32_t *)(base + o_row_prob);
+        B.prob_slots = (const int32_t *)(base + o_prob_slots);
         B.fsave_stride = 2 * spx::class_slots(cls);
         B.fsave_off = (const int64_t *)(base + o_fs_off);
         B.out_bq = w->d_bq;
@@ -410,6 +420,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (w->cls_used[0]) HIPCHK(spx_launch_baq(0, &w->cls_batch[0], c->stream));
     for (int cls = 1; cls < 7; ++cls)
         if (w->cls_used[cls]) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
+    HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, c->stream));
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
