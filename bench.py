@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--platform", default="hifi", choices=["hifi", "ont"])
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
-    ap.add_argument("--chunk", type=int, default=2048, help="groups per prepared work list")
+    ap.add_argument("--chunk", type=int, default=0, help="groups per prepared work list (0: one list per step)")
+    ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=256, help="groups checked against the oracle before timing")
@@ -102,10 +103,13 @@ def main():
     gen_threads = max(1, min(64, ncpu // max(1, world)))
     first = rank * gps  # every rank scores its own shard of the read groups (weak scaling)
     t0 = time.time()
-    chunks = gen_parallel(genome, first, gps, args.chunk, gen_threads)
+    chunk = args.chunk or gps
+    chunks = gen_parallel(genome, first, gps, args.gen_chunk, gen_threads)
     t_gen = time.time() - t0
     t0 = time.time()
-    works = [ctx.prepare(ch.batch, params, host_threads=gen_threads) for ch in chunks]
+    per = max(1, chunk // args.gen_chunk)
+    works = [ctx.prepare([ch.batch for ch in chunks[k:k + per]], params, host_threads=gen_threads)
+             for k in range(0, len(chunks), per)]
     t_prep = time.time() - t0
     stats = [w.stats() for w in works]
     n_disp = sum(s.n_dispatched for s in stats)
@@ -140,7 +144,7 @@ def main():
         off = 0
         for k, w in enumerate(works):
             w.launch()
-            off += w.pack_decisions(first + k * args.chunk, dec.data_ptr() + 8 * off, dec.numel() - off)
+            off += w.pack_decisions(first + k * chunk, dec.data_ptr() + 8 * off, dec.numel() - off)
         if world > 1:
             ctx_sync()
             dist.gather(dec, gathered, dst=0)

@@ -100,6 +100,10 @@ int spx_score_batch(spx_ctx *ctx, const spx_batch *bt, const spx_params *par, sp
 
 /* split phase (what bench.py times; also lets a caller overlap host parsing of the next batch) */
 int spx_prepare(spx_ctx *ctx, const spx_batch *bt, const spx_params *par, int host_threads, spx_work **work);
+/* same, over several record batches that become ONE work list; group g of batch b is reported at
+ * out[(groups of batches < b) + g] */
+int spx_prepare_many(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_batches, const spx_params *par,
+                     int host_threads, spx_work **work);
 int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */
 int spx_sync(spx_ctx *ctx);
 /* multi-GPU: write one 8-byte decision record per dispatched group of `work` into a caller-owned

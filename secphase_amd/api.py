@@ -68,7 +68,7 @@ class PlanView(C.Structure):
 
 EXPORTS = [
     "spx_strerror", "spx_last_error", "spx_device_count", "spx_create", "spx_destroy", "spx_set_reference",
-    "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_launch", "spx_sync", "spx_collect",
+    "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_prepare_many", "spx_launch", "spx_sync", "spx_collect",
     "spx_work_stats", "spx_work_free", "spx_finalize", "spx_write_relabel_log", "spx_probaln_glocal",
     "spx_probaln_batch", "spx_pack_decisions", "spx_plan_create", "spx_plan_get", "spx_plan_free", "spx_host_tables",
 ]
@@ -100,6 +100,8 @@ def lib():
     L.spx_group_is_dispatched.argtypes = [C.POINTER(SpxBatch), C.c_int32]
     L.spx_score_batch.argtypes = [vp, C.POINTER(SpxBatch), C.POINTER(SpxParams), C.POINTER(GroupOut), C.POINTER(Stats)]
     L.spx_prepare.argtypes = [vp, C.POINTER(SpxBatch), C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
+    L.spx_prepare_many.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int,
+                                   C.POINTER(vp)]
     L.spx_launch.argtypes = [vp, vp]
     L.spx_sync.argtypes = [vp]
     L.spx_pack_decisions.argtypes = [vp, vp, C.c_int32, vp, C.c_int64]
@@ -148,6 +150,7 @@ class Context:
         return out, st
 
     def prepare(self, batch, params, host_threads=0):
+        """batch: one POINTER(SpxBatch) or a list of them (merged into one work list)"""
         return Work(self, batch, params, host_threads)
 
     def probaln_batch(self, refs, queries, set_q, pars):
@@ -186,10 +189,16 @@ class Context:
 class Work:
     def __init__(self, ctx, batch, params, host_threads):
         self.ctx = ctx
-        self.n = batch.contents.n_groups
         self.params = params
         self.h = C.c_void_p()
-        _chk(lib().spx_prepare(ctx.h, batch, C.byref(params), host_threads, C.byref(self.h)), "spx_prepare")
+        if isinstance(batch, (list, tuple)):
+            self.n = sum(b.contents.n_groups for b in batch)
+            arr = (C.POINTER(SpxBatch) * len(batch))(*batch)
+            _chk(lib().spx_prepare_many(ctx.h, arr, len(batch), C.byref(params), host_threads, C.byref(self.h)),
+                 "spx_prepare_many")
+        else:
+            self.n = batch.contents.n_groups
+            _chk(lib().spx_prepare(ctx.h, batch, C.byref(params), host_threads, C.byref(self.h)), "spx_prepare")
 
     def launch(self):
         _chk(lib().spx_launch(self.ctx.h, self.h), "spx_launch")

@@ -546,41 +546,64 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
  * then min(raw, q) with the CIGAR/MAP consistency check (ptMarker.c:778-779,786). */
 __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_rows_total)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows_total) return;
-    const int p = B.row_prob[r];
-    const int i = B.rows[r], bw = B.bw[p], R = B.R[p];
-    const int W = 2 * bw + 1, slots = B.prob_slots[p];
-    const int64_t off = B.fsave_off[p] + (int64_t)(r - B.row_off[p]) * 2 * slots;
+    /* 4 adjacent lanes per wanted row, each owning a contiguous quarter of the slots (coalesced reads of the
+     * 2 x slots doubles a row holds); products and the running argmax are lane-local, the sum is passed from
+     * lane to lane in column order */
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = tid >> 2, g = tid & 3;
+    const bool on = r < n_rows_total;
+    const int rr = on ? r : 0;
+    const int p = B.row_prob[rr];
+    const int i = B.rows[rr], bw = B.bw[p], R = B.R[p];
+    const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = slots >> 2;
+    const int64_t off = B.fsave_off[p] + (int64_t)(rr - B.row_off[p]) * 2 * slots;
     const double *fM = B.fsave + off, *fI = fM + slots, *bM = B.bsave + off, *bI = bM + slots;
     const int j0 = max(0, bw + 1 - i), j1 = min(W - 1, R - i + bw); /* 1 <= k = i - bw + j <= R */
-    double best = 0.0, sum = 0.0;
+    const int ja = max(j0, g * Cq), jb = min(j1, g * Cq + Cq - 1);
+    double best = 0.0, carry = 0.0, mysum = 0.0;
     int best_k = -1;
-    for (int j = j0; j <= j1; ++j) {
-        const int k = i - bw + j;
-        double z = fM[j] * bM[j];
-        if (z > best) { best = z; best_k = ((k - 1) << 2) | 0; }
-        sum += z;
-        z = fI[j] * bI[j];
-        if (z > best) { best = z; best_k = ((k - 1) << 2) | 1; }
-        sum += z;
+    for (int t = 0; t < 4; ++t) {
+        if (g == t && on) {
+            double s = carry;
+            for (int j = ja; j <= jb; ++j) {
+                const int k = i - bw + j;
+                double z = fM[j] * bM[j];
+                if (z > best) { best = z; best_k = ((k - 1) << 2) | 0; }
+                s += z;
+                z = fI[j] * bI[j];
+                if (z > best) { best = z; best_k = ((k - 1) << 2) | 1; }
+                s += z;
+            }
+            mysum = s;
+        }
+        carry = __shfl_up(mysum, 1, 4); /* lane t+1 continues from lane t's partial sum */
     }
-    const double mx = best / sum;
-    const uint32_t q = phred_from_x(1.0 - mx, B.qthr);
-    if (B.out_state) B.out_state[r] = best_k;
-    if (B.out_q) B.out_q[r] = (uint8_t)q;
-    if (B.out_bq) {
-        const int expect = B.row_expect[r];
-        const uint32_t raw = B.row_rawq[r];
-        const uint32_t bq = ((best_k & 3) != 0 || (best_k >> 2) != expect) ? 0u : (raw < q ? raw : q);
-        B.out_bq[r] = (uint8_t)(bq < 94 ? bq : 93);
+    const double sum = __shfl(mysum, 3, 4);
+    /* first strictly greatest in column order: the lower lane wins ties */
+#pragma unroll
+    for (int o = 1; o < 4; o <<= 1) {
+        const double ob = __shfl_up(best, o, 4);
+        const int ok = __shfl_up(best_k, o, 4);
+        if (g >= o && ob >= best && ok >= 0) { best = ob; best_k = ok; }
+    }
+    if (g == 3 && on) {
+        const double mx = best / sum;
+        const uint32_t q = phred_from_x(1.0 - mx, B.qthr);
+        if (B.out_state) B.out_state[r] = best_k;
+        if (B.out_q) B.out_q[r] = (uint8_t)q;
+        if (B.out_bq) {
+            const int expect = B.row_expect[r];
+            const uint32_t raw = B.row_rawq[r];
+            const uint32_t bq = ((best_k & 3) != 0 || (best_k >> 2) != expect) ? 0u : (raw < q ? raw : q);
+            B.out_bq[r] = (uint8_t)(bq < 94 ? bq : 93);
+        }
     }
 }
 
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st)
 {
     if (n_rows_total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(map_kernel, dim3((n_rows_total + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    hipLaunchKernelGGL(map_kernel, dim3((n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
     return hipGetLastError();
 }
 
@@ -663,7 +686,11 @@ extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_
     }                                                                                             \
     break;
     switch (cls) {
-    case 0: SPX_LAUNCH(4, 12)
+#ifndef SPX_CLS0_G
+#define SPX_CLS0_G 4
+#define SPX_CLS0_C 12
+#endif
+    case 0: SPX_LAUNCH(SPX_CLS0_G, SPX_CLS0_C)
     case 1: SPX_LAUNCH(4, 16)
     case 2: SPX_LAUNCH(8, 16)
     case 3: SPX_LAUNCH(16, 16)

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -221,7 +222,10 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     spx::HostBatch &hb = w->hb;
     const size_t np = hb.L.size(), nr = hb.rows.size(), ng = hb.grp_index.size(), nm = hb.markers.size();
     /* per-class launch order: (W, L desc), each W padded to whole waves */
-    static const int kG[7] = {4, 4, 8, 16, 32, 64, 64};
+#ifndef SPX_CLS0_G
+#define SPX_CLS0_G 4
+#endif
+    static const int kG[7] = {SPX_CLS0_G, 4, 8, 16, 32, 64, 64};
     std::vector<int32_t> order[7];
     std::vector<int32_t> ids[7];
     for (size_t p = 0; p < np; ++p) {
@@ -359,41 +363,60 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     return SPX_OK;
 }
 
-extern "C" int spx_prepare(spx_ctx *c, const spx_batch *bt, const spx_params *par, int host_threads, spx_work **out)
+/* several record batches (e.g. the blocks a reader thread hands over) become ONE work list; group g of
+ * batch b is reported at index (groups of batches < b) + g */
+extern "C" int spx_prepare_many(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par,
+                                int host_threads, spx_work **out)
 {
-    if (!c || !bt || !par || !out) return fail(SPX_EINVAL, "NULL argument");
+    if (!c || !bts || n_batches <= 0 || !par || !out) return fail(SPX_EINVAL, "NULL argument");
     if (!c->d_ref4) return fail(SPX_ENOREF, "spx_set_reference has not been called");
     HIPCHK(hipSetDevice(c->device));
     *out = nullptr;
     spx_work *w = new spx_work();
     memset(&w->st, 0, sizeof w->st);
     w->par = *par;
-    w->n_groups_in = bt->n_groups;
     double t0 = now_s();
+    /* tasks of <= 256 groups, pulled by the worker threads, merged in file order */
+    struct Task { int b; int32_t g0, g1, base; };
+    std::vector<Task> tasks;
+    int32_t base = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        if (!bts[b]) { delete w; return fail(SPX_EINVAL, "NULL batch"); }
+        for (int32_t g = 0; g < bts[b]->n_groups; g += 256)
+            tasks.push_back({b, g, std::min(bts[b]->n_groups, g + 256), base});
+        base += bts[b]->n_groups;
+    }
+    w->n_groups_in = base;
     int nthr = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
-    nthr = std::max(1, std::min(nthr, 64));
-    if (bt->n_groups < nthr * 8) nthr = 1;
+    nthr = std::max(1, std::min(nthr, 128));
+    nthr = std::min<int>(nthr, (int)std::max<size_t>(tasks.size(), 1));
     const spx::RefIndex &ri = c->ref;
-    std::vector<spx::HostBatch> parts(nthr);
-    std::vector<std::thread> th;
-    const int32_t ng = bt->n_groups;
-    auto run = [&](int t) {
-        int32_t g0 = (int32_t)((int64_t)ng * t / nthr), g1 = (int32_t)((int64_t)ng * (t + 1) / nthr);
-        spx::prepare_groups(bt, ri, par, g0, g1, parts[t]);
+    std::vector<spx::HostBatch> parts(tasks.size());
+    std::atomic<size_t> next(0);
+    auto run = [&]() {
+        for (;;) {
+            size_t t = next.fetch_add(1);
+            if (t >= tasks.size()) break;
+            const Task &k = tasks[t];
+            spx::prepare_groups(bts[k.b], ri, par, k.g0, k.g1, parts[t]);
+            for (int32_t &gi : parts[t].grp_index) gi += k.base;
+        }
     };
-    if (nthr == 1) run(0);
+    if (nthr == 1) run();
     else {
-        for (int t = 0; t < nthr; ++t) th.emplace_back(run, t);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t) th.emplace_back(run);
         for (auto &t : th) t.join();
     }
     w->hb.clear();
     w->hb.mk_first.push_back(0);
-    for (int t = 0; t < nthr; ++t) {
+    for (size_t t = 0; t < tasks.size(); ++t) {
         w->hb.append(parts[t]);
         w->hb.grp_error.insert(w->hb.grp_error.end(), parts[t].grp_error.begin(), parts[t].grp_error.end());
+        parts[t] = spx::HostBatch();
     }
     w->st.prep_seconds = now_s() - t0;
-    w->st.n_groups = ng;
+    w->st.n_groups = w->n_groups_in;
     w->st.n_dispatched = (int64_t)w->hb.grp_index.size();
     w->st.n_problems = (int64_t)w->hb.L.size();
     w->st.n_rows = (int64_t)w->hb.rows.size();
@@ -403,6 +426,12 @@ extern "C" int spx_prepare(spx_ctx *c, const spx_batch *bt, const spx_params *pa
     if (rc) { spx_work_free(c, w); return rc; }
     *out = w;
     return SPX_OK;
+}
+
+extern "C" int spx_prepare(spx_ctx *c, const spx_batch *bt, const spx_params *par, int host_threads, spx_work **out)
+{
+    if (!bt) return fail(SPX_EINVAL, "NULL argument");
+    return spx_prepare_many(c, &bt, 1, par, host_threads, out);
 }
 
 extern "C" int spx_launch(spx_ctx *c, spx_work *w)
