@@ -59,8 +59,7 @@ typedef struct spx_dev_batch {
     const uint8_t *row_rawq;   /* raw base quality */
     /* scratch */
     double *sinv;  /* 1/s[i] per row */
-    double *fsave; /* scaled forward M,I rows at wanted rows: [row][2][slots] */
-    double *bsave; /* scaled backward M,I rows at wanted rows, same layout */
+    double *fsave; /* wanted rows: scaled forward M,I ([row][2][slots]), replaced by f*b in the backward pass */
     const int32_t *row_prob;   /* per wanted row: its problem */
     const int32_t *prob_slots; /* per problem: band slots of its class */
     int64_t fsave_stride; /* doubles per wanted row = 2*slots of the class */

@@ -62,6 +62,20 @@ __device__ __forceinline__ uint32_t fetch_code(const uint8_t *__restrict__ pool,
     return (a & 1) ? (b >> 4) : (b & 0xfu);
 }
 
+/* 8 consecutive 4-bit codes starting at nibble address a (any alignment), as one dword */
+__device__ __forceinline__ uint32_t fetch8(const uint8_t *__restrict__ pool, int64_t a)
+{
+    a = a < 0 ? 0 : a; /* codes of columns < 1 are never used; keep the address inside the pool */
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
+    const uint32_t lo = p32[0], hi = p32[1];
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(a & 7) * 4u);
+}
+/* same for an address that is a multiple of 8 nibbles */
+__device__ __forceinline__ uint32_t fetch8_aligned(const uint8_t *__restrict__ pool, int64_t a)
+{
+    return reinterpret_cast<const uint32_t *>(pool)[a >> 3];
+}
+
 /* byte-packed window of C codes */
 template <int C>
 struct CodeWin {
@@ -405,18 +419,30 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
         }
     }
     /* rows 2..L: an interior stretch without masks, then the rows whose band touches column R */
-    uint32_t qy_n = (act && L >= 2) ? fetch_code(B.qry4, P.qry0, 1, L) : 0;
-    uint32_t rc_n = (act && L >= 2) ? fetch_code(B.ref4, P.ref0, 2 - bw + (jbase + C - 1) - 1, R) : SPX_CODE_OUT;
+    /* codes arrive 8 rows at a time (one dword of query codes, one funnel-shifted dword of reference codes
+     * for the slot entering the band at the top), fetched one chunk ahead */
+    const int top = jbase + C - 1; /* the slot that receives a new column each row */
+    auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + top - 1)); };   /* rows ib..ib+7 */
+    auto qry_chunk = [&](int ib) { return fetch8_aligned(B.qry4, P.qry0 + (ib - 1)); };
+    uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
+    uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
     auto row = [&](int i, auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         if (act && i <= L) {
-            const uint32_t qy = qy_n;
-            cw.shift_down(rc_n);
+            const uint32_t t4 = (uint32_t)((i - 1) & 7) * 4u;
+            if (t4 == 0) {
+                qwin = qwin_n; rwin = rwin_n;
+                qwin_n = qry_chunk(i + 8); rwin_n = ref_chunk(i + 8);
+            }
+            const uint32_t qy = (qwin >> t4) & 0xfu;
+            uint32_t rc = (rwin >> t4) & 0xfu;
+            if (!FAST) {
+                if ((unsigned)(i - bw + top - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
+            }
+            cw.shift_down(rc);
             CodeWin<C> ew;
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
-            qy_n = fetch_code(B.qry4, P.qry0, i, L); /* prefetch for row i+1 */
-            rc_n = fetch_code(B.ref4, P.ref0, (i + 1) - bw + (jbase + C - 1) - 1, R);
             double inv;
             s_cur = fwd_row<G, C, FAST>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
             if (g == 0) sinv[i] = inv;
@@ -501,35 +527,50 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
             cw.set(c, (act && L >= 2) ? fetch_code(B.ref4, P.ref0, (L - 1) - bw + j, R) : SPX_CODE_OUT);
         }
     }
-    /* the scaled b row of every wanted row is parked next to the forward row; map_kernel finishes the job */
-    double *bsave = B.bsave + (act ? B.fsave_off[P.pid] : 0);
+    /* at a wanted row the saved forward row is replaced in place by z = f*b (M and I states); map_kernel
+     * finishes the job (arg-max, ordered sum, phred, write-back rule) */
+    double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
     int wprev = nrows - 1;
     int prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
     auto save_row = [&]() {
-        double *dst = bsave + (int64_t)wprev * fstride + jbase;
+        double *dst = fsave + (int64_t)wprev * fstride + jbase;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { dst[c] = bM[c]; dst[SLOTS + c] = bI[c]; }
+        for (int c = 0; c < C; ++c) { dst[c] = dst[c] * bM[c]; dst[SLOTS + c] = dst[SLOTS + c] * bI[c]; }
         wprev--;
         prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
     };
     if (act && prev_row == L) save_row();
-    uint32_t qy_p = (act && L >= 2) ? fetch_code(B.qry4, P.qry0, L - 1, L) : 0;
-    uint32_t rc_p = SPX_CODE_OUT;
+    /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0; codes come 8 rows at a time
+     * (rows ib+7..ib with ib a multiple of 8), one chunk ahead */
+    auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + jbase)); };
+    auto qry_chunk = [&](int ib) { return ib >= 0 ? fetch8_aligned(B.qry4, P.qry0 + ib) : 0u; };
+    const int ib0 = (L - 1) & ~7;
+    uint32_t qwin = (act && L >= 2) ? qry_chunk(ib0) : 0, rwin = (act && L >= 2) ? ref_chunk(ib0) : 0;
+    uint32_t qwin_n = (act && L >= 2) ? qry_chunk(ib0 - 8) : 0, rwin_n = (act && L >= 2 && ib0 >= 8) ? ref_chunk(ib0 - 8) : 0;
     double inv_p = (act && L >= 2) ? sinv[L - 1] : 0.0;
     auto row = [&](int i, auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         if (act && i <= L - 1 && i >= stop) {
-            const uint32_t qy = qy_p;
+            const uint32_t t4 = (uint32_t)(i & 7) * 4u;
+            if (t4 == 28 && i != L - 1) {
+                qwin = qwin_n; rwin = rwin_n;
+                const int ibn = (i & ~7) - 8;
+                qwin_n = qry_chunk(ibn);
+                rwin_n = ibn >= 0 ? ref_chunk(ibn) : 0u;
+            }
+            const uint32_t qy = (qwin >> t4) & 0xfu;
             const double inv = inv_p;
-            if (i != L - 1) cw.shift_up(rc_p);
+            if (i != L - 1) {
+                uint32_t rc = (rwin >> t4) & 0xfu;
+                if (!FAST) {
+                    if ((unsigned)(i - bw + jbase) >= (unsigned)R) rc = SPX_CODE_OUT;
+                }
+                cw.shift_up(rc);
+            }
             CodeWin<C> ew;
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
-            if (i >= 2) { /* prefetch for row i-1 */
-                qy_p = fetch_code(B.qry4, P.qry0, i - 1, L);
-                rc_p = fetch_code(B.ref4, P.ref0, (i - 1) - bw + jbase, R);
-                inv_p = sinv[i - 1];
-            }
+            if (i >= 2) inv_p = sinv[i - 1]; /* prefetch for row i-1 */
             bwd_row<G, C, FAST>(bM, bI, bD, ew, qy, h, g, Wu, tlast, inv, i == 1);
             if (i == prev_row) save_row();
         }
@@ -557,7 +598,7 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
     const int i = B.rows[rr], bw = B.bw[p], R = B.R[p];
     const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = slots >> 2;
     const int64_t off = B.fsave_off[p] + (int64_t)(rr - B.row_off[p]) * 2 * slots;
-    const double *fM = B.fsave + off, *fI = fM + slots, *bM = B.bsave + off, *bI = bM + slots;
+    const double *zM = B.fsave + off, *zI = zM + slots; /* z = f*b, written by the backward kernel */
     const int j0 = max(0, bw + 1 - i), j1 = min(W - 1, R - i + bw); /* 1 <= k = i - bw + j <= R */
     const int ja = max(j0, g * Cq), jb = min(j1, g * Cq + Cq - 1);
     double best = 0.0, carry = 0.0, mysum = 0.0;
@@ -567,10 +608,10 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
             double s = carry;
             for (int j = ja; j <= jb; ++j) {
                 const int k = i - bw + j;
-                double z = fM[j] * bM[j];
+                double z = zM[j];
                 if (z > best) { best = z; best_k = ((k - 1) << 2) | 0; }
                 s += z;
-                z = fI[j] * bI[j];
+                z = zI[j];
                 if (z > best) { best = z; best_k = ((k - 1) << 2) | 1; }
                 s += z;
             }

@@ -629,7 +629,7 @@ static int plan_baq(const Aln &a, int ai, const std::vector<Mk> &mkc, std::vecto
             out.hmm.resize(out.hmm.size() + SPX_H_N);
             hmm_constants(R, L, d, e, par->set_q, &out.hmm[out.hmm.size() - SPX_H_N]);
             {
-                const size_t nb = (size_t)(L + 1) / 2, at = out.qry4.size();
+                const size_t nb = ((size_t)(L + 7) / 8) * 4, at = out.qry4.size(); /* whole dwords: the device reads 8 codes at a time */
                 bool has_n = ref.window_has_n(a.tid, b.rfs, R);
                 out.qry4.resize(at + nb, 0);
                 for (int k = 0; k < L; ++k) {

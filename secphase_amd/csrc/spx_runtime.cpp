@@ -174,13 +174,13 @@ extern "C" int spx_set_reference(spx_ctx *c, const spx_ref *ref)
     const int nc = ref->n_contigs;
     c->ref.nib_off.assign(nc, 0);
     c->ref.len.assign(nc, 0);
-    int64_t nib = 0;
+    int64_t nib = 256; /* leading pad: the kernels fetch whole dwords a few columns before a window */
     for (int i = 0; i < nc; ++i) {
         c->ref.nib_off[i] = nib;
         c->ref.len[i] = ref->seq_off[i + 1] - ref->seq_off[i];
         nib += (c->ref.len[i] + 1) & ~(int64_t)1; /* every contig starts on a byte boundary */
     }
-    std::vector<uint8_t> packed((size_t)(nib / 2) + 16, 0);
+    std::vector<uint8_t> packed((size_t)(nib / 2) + 128, 0); /* slack: the kernels fetch whole dwords past a window */
     unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::thread> th;
     auto work = [&](unsigned tid) {
@@ -267,7 +267,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     size_t o_ref_nib = cv.take<int64_t>(np), o_qry_nib = cv.take<int64_t>(np), o_L = cv.take<int32_t>(np),
            o_R = cv.take<int32_t>(np), o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N),
            o_row_off = cv.take<int32_t>(np), o_n_rows = cv.take<int32_t>(np), o_s_off = cv.take<int64_t>(np),
-           o_fs_off = cv.take<int64_t>(np), o_qry4 = cv.take<uint8_t>(hb.qry4.size() + 16),
+           o_fs_off = cv.take<int64_t>(np), o_qry4 = cv.take<uint8_t>(hb.qry4.size() + 128),
            o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr), o_rawq = cv.take<uint8_t>(nr),
            o_row_prob = cv.take<int32_t>(nr), o_prob_slots = cv.take<int32_t>(np);
     size_t o_order[7];
@@ -276,7 +276,6 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
            o_sec = cv.take<uint16_t>(ng), o_gidx = cv.take<int32_t>(ng);
     const size_t in_bytes = cv.off;
     size_t o_sinv = cv.take<double>((size_t)s_tot), o_fsave = cv.take<double>((size_t)f_tot),
-           o_bsave = cv.take<double>((size_t)f_tot),
            o_bq = cv.take<uint8_t>(nr + 16), o_state = want_state_q ? cv.take<int32_t>(nr) : 0,
            o_q = want_state_q ? cv.take<uint8_t>(nr + 16) : 0, o_score = cv.take<double>(ng * 10),
            o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
@@ -331,7 +330,6 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
         B.row_rawq = (const uint8_t *)(base + o_rawq);
         B.sinv = (double *)(base + o_sinv);
         B.fsave = (double *)(base + o_fsave);
-        B.bsave = (double *)(base + o_bsave);
         B.row_prob = (const int32_t *)(base + o_row_prob);
         B.prob_slots = (const int32_t *)(base + o_prob_slots);
         B.fsave_stride = 2 * spx::class_slots(cls);
@@ -628,7 +626,7 @@ extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, cons
     hb.mk_first.push_back(0);
     /* private reference pool: the problems' own ref windows */
     std::vector<uint8_t> ref4;
-    int64_t rn = 0;
+    int64_t rn = 256; /* leading pad, as in spx_set_reference */
     for (int32_t p = 0; p < n; ++p) {
         const int R = (int)(ref_off[p + 1] - ref_off[p]), L = (int)(qry_off[p + 1] - qry_off[p]);
         if (R <= 0 || L <= 0) { delete w; return fail(SPX_EINVAL, "empty problem"); }
@@ -642,7 +640,7 @@ extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, cons
         }
         rn += ((R + 1) / 2) * 2;
         hb.qry_nib.push_back(hb.qry_nibbles);
-        const size_t at = hb.qry4.size(), nb = (size_t)(L + 1) / 2;
+        const size_t at = hb.qry4.size(), nb = ((size_t)(L + 7) / 8) * 4;
         hb.qry4.resize(at + nb, 0);
         for (int k = 0; k < L; ++k) {
             unsigned code = query[qry_off[p] + k] > 3 ? 4u : query[qry_off[p] + k];
@@ -663,7 +661,7 @@ extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, cons
         }
         hb.dp_cells += spx::band_cells(L, R, bw);
     }
-    ref4.resize(ref4.size() + 16, 0);
+    ref4.resize(ref4.size() + 128, 0);
     uint8_t *d_ref = nullptr, *saved = c->d_ref4;
     HIPCHK(hipMalloc((void **)&d_ref, ref4.size()));
     HIPCHK(hipMemcpy(d_ref, ref4.data(), ref4.size(), hipMemcpyHostToDevice));
@@ -722,7 +720,7 @@ extern "C" int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const sp
 {
     if (!ref || !bt || !par || !out) return fail(SPX_EINVAL, "NULL argument");
     spx::RefIndex ri;
-    int64_t nib = 0;
+    int64_t nib = 256;
     for (int i = 0; i < ref->n_contigs; ++i) {
         ri.nib_off.push_back(nib);
         ri.len.push_back(ref->seq_off[i + 1] - ref->seq_off[i]);
