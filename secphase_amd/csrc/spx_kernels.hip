@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
     const int rr = on ? r : 0;
     const int p = B.row_prob[rr];
     const int i = B.rows[rr], bw = B.bw[p], R = B.R[p];
-    const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = slots >> 2;
+    const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = (slots + 3) >> 2;
     const int64_t off = B.fsave_off[p] + (int64_t)(rr - B.row_off[p]) * 2 * slots;
     const double *zM = B.fsave + off, *zI = zM + slots; /* z = f*b, written by the backward kernel */
     const int j0 = max(0, bw + 1 - i), j1 = min(W - 1, R - i + bw); /* 1 <= k = i - bw + j <= R */
@@ -726,18 +726,16 @@ extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_
         hipLaunchKernelGGL((baq_bwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);          \
     }                                                                                             \
     break;
-    switch (cls) {
-#ifndef SPX_CLS0_G
-#define SPX_CLS0_G 4
-#define SPX_CLS0_C 12
-#endif
-    case 0: SPX_LAUNCH(SPX_CLS0_G, SPX_CLS0_C)
-    case 1: SPX_LAUNCH(4, 16)
-    case 2: SPX_LAUNCH(8, 16)
-    case 3: SPX_LAUNCH(16, 16)
-    case 4: SPX_LAUNCH(32, 16)
-    case 5: SPX_LAUNCH(64, 16)
-    case 6: SPX_LAUNCH(64, 32)
+    switch (cls) { /* (lanes per problem, band slots per lane): keep in step with spx_prep.cpp kClass* */
+    case 0: SPX_LAUNCH(2, 21)
+    case 1: SPX_LAUNCH(2, 24)
+    case 2: SPX_LAUNCH(4, 16)
+    case 3: SPX_LAUNCH(4, 26)
+    case 4: SPX_LAUNCH(8, 16)
+    case 5: SPX_LAUNCH(16, 16)
+    case 6: SPX_LAUNCH(32, 16)
+    case 7: SPX_LAUNCH(64, 16)
+    case 8: SPX_LAUNCH(64, 32)
     default: return hipErrorInvalidValue;
     }
 #undef SPX_LAUNCH

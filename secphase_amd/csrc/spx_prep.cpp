@@ -117,13 +117,15 @@ int64_t band_cells(int L, int R, int bw)
     return c;
 }
 
-static const int kClassSlots[7] = {48, 64, 128, 256, 512, 1024, 2048};
+static const int kClassSlots[SPX_N_CLASSES] = {42, 48, 64, 104, 128, 256, 512, 1024, 2048};
+static const int kClassLanes[SPX_N_CLASSES] = {2, 2, 4, 4, 8, 16, 32, 64, 64};
 int band_class(int W)
 {
-    for (int c = 0; c < 7; ++c)
+    for (int c = 0; c < SPX_N_CLASSES; ++c)
         if (W <= kClassSlots[c]) return c;
     return -1;
 }
+int class_lanes(int cls) { return kClassLanes[cls]; }
 int class_slots(int cls) { return kClassSlots[cls]; }
 
 /* largest x in (0,1] with (int)(-4.343*log(x)+.499) >= k, by bisection on the

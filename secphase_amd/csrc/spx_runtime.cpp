@@ -68,8 +68,8 @@ struct spx_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
      * (or in front of) the bulk class */
-    hipStream_t cls_stream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t cls_done[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cls_stream[SPX_N_CLASSES] = {};
+    hipEvent_t cls_done[SPX_N_CLASSES] = {};
     uint8_t *d_ref4 = nullptr;
     int64_t ref_bytes = 0;
     spx::RefIndex ref;
@@ -82,8 +82,8 @@ struct spx_work {
     int32_t n_groups_in = 0;
     void *arena = nullptr;
     size_t arena_bytes = 0;
-    spx_dev_batch cls_batch[7];
-    int cls_used[7] = {0, 0, 0, 0, 0, 0, 0};
+    spx_dev_batch cls_batch[SPX_N_CLASSES];
+    int cls_used[SPX_N_CLASSES] = {};
     spx_dev_groups dg;
     bool have_groups = false;
     /* device output mirrors */
@@ -136,7 +136,7 @@ extern "C" int spx_create(int device, spx_ctx **out)
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-    for (int i = 1; i < 7; ++i) {
+    for (int i = 1; i < SPX_N_CLASSES; ++i) {
         HIPCHK(hipStreamCreateWithFlags(&c->cls_stream[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->cls_done[i], hipEventDisableTiming));
     }
@@ -159,7 +159,7 @@ extern "C" void spx_destroy(spx_ctx *c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 1; i < 7; ++i) {
+    for (int i = 1; i < SPX_N_CLASSES; ++i) {
         if (c->cls_done[i]) (void)hipEventDestroy(c->cls_done[i]);
         if (c->cls_stream[i]) (void)hipStreamDestroy(c->cls_stream[i]);
     }
@@ -222,17 +222,13 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     spx::HostBatch &hb = w->hb;
     const size_t np = hb.L.size(), nr = hb.rows.size(), ng = hb.grp_index.size(), nm = hb.markers.size();
     /* per-class launch order: (W, L desc), each W padded to whole waves */
-#ifndef SPX_CLS0_G
-#define SPX_CLS0_G 4
-#endif
-    static const int kG[7] = {SPX_CLS0_G, 4, 8, 16, 32, 64, 64};
-    std::vector<int32_t> order[7];
-    std::vector<int32_t> ids[7];
+    std::vector<int32_t> order[SPX_N_CLASSES];
+    std::vector<int32_t> ids[SPX_N_CLASSES];
     for (size_t p = 0; p < np; ++p) {
         int cls = spx::band_class(2 * hb.bw[p] + 1);
         ids[cls].push_back((int32_t)p);
     }
-    for (int cls = 0; cls < 7; ++cls) {
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
         auto &v = ids[cls];
         w->st.problems_per_class[cls] = (int64_t)v.size();
         if (v.empty()) continue;
@@ -241,7 +237,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
             if (hb.L[a] != hb.L[b]) return hb.L[a] > hb.L[b];
             return a < b;
         });
-        const int ppw = 64 / kG[cls];
+        const int ppw = 64 / spx::class_lanes(cls);
         for (size_t i = 0; i < v.size();) {
             size_t j = i;
             while (j < v.size() && hb.bw[v[j]] == hb.bw[v[i]]) ++j;
@@ -270,8 +266,8 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
            o_fs_off = cv.take<int64_t>(np), o_qry4 = cv.take<uint8_t>(hb.qry4.size() + 128),
            o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr), o_rawq = cv.take<uint8_t>(nr),
            o_row_prob = cv.take<int32_t>(nr), o_prob_slots = cv.take<int32_t>(np);
-    size_t o_order[7];
-    for (int cls = 0; cls < 7; ++cls) o_order[cls] = cv.take<int32_t>(order[cls].size());
+    size_t o_order[SPX_N_CLASSES];
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) o_order[cls] = cv.take<int32_t>(order[cls].size());
     size_t o_mk_first = cv.take<int32_t>(ng + 1), o_markers = cv.take<spx_dev_marker>(nm), o_naln = cv.take<uint8_t>(ng),
            o_sec = cv.take<uint16_t>(ng), o_gidx = cv.take<int32_t>(ng);
     const size_t in_bytes = cv.off;
@@ -292,7 +288,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     UP(o_hmm, hb.hmm); UP(o_row_off, hb.row_off); UP(o_n_rows, hb.n_rows); UP(o_s_off, s_off); UP(o_fs_off, fsave_off);
     UP(o_qry4, hb.qry4); UP(o_rows, hb.rows); UP(o_expect, hb.row_expect); UP(o_rawq, hb.row_rawq);
     UP(o_row_prob, row_prob); UP(o_prob_slots, prob_slots);
-    for (int cls = 0; cls < 7; ++cls) UP(o_order[cls], order[cls]);
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) UP(o_order[cls], order[cls]);
     UP(o_mk_first, hb.mk_first); UP(o_markers, hb.markers); UP(o_naln, hb.n_aln); UP(o_sec, hb.sec_mask);
     UP(o_gidx, hb.grp_index);
 #undef UP
@@ -308,7 +304,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     w->d_pass = (uint8_t *)(base + o_pass);
     w->d_tie = (uint16_t *)(base + o_tie);
     w->d_grp_index = (int32_t *)(base + o_gidx);
-    for (int cls = 0; cls < 7; ++cls) {
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
         spx_dev_batch &B = w->cls_batch[cls];
         memset(&B, 0, sizeof B);
         w->cls_used[cls] = !order[cls].empty();
@@ -438,14 +434,14 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     /* wide classes first on their own streams (few, long waves), the bulk class on the main stream */
-    for (int cls = 6; cls >= 1; --cls) {
+    for (int cls = SPX_N_CLASSES - 1; cls >= 1; --cls) {
         if (!w->cls_used[cls]) continue;
         HIPCHK(hipStreamWaitEvent(c->cls_stream[cls], c->ev[0], 0));
         HIPCHK(spx_launch_baq(cls, &w->cls_batch[cls], c->cls_stream[cls]));
         HIPCHK(hipEventRecord(c->cls_done[cls], c->cls_stream[cls]));
     }
     if (w->cls_used[0]) HIPCHK(spx_launch_baq(0, &w->cls_batch[0], c->stream));
-    for (int cls = 1; cls < 7; ++cls)
+    for (int cls = 1; cls < SPX_N_CLASSES; ++cls)
         if (w->cls_used[cls]) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
     HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
