@@ -80,7 +80,7 @@ typedef struct spx_dev_marker {
     uint8_t qfix;    /* quality when row < 0 (raw, or 0 at block edges) */
     uint8_t is_match;
     uint8_t aln;
-    uint8_t first_of_pos; /* 1 on the first marker of a read position */
+    uint8_t first_of_pos; /* on the first marker of a read position: how many markers it has (= alignments), else 0 */
 } spx_dev_marker;
 
 typedef struct spx_dev_groups {

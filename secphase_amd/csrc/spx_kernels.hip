@@ -649,41 +649,57 @@ extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_tota
 }
 
 /* ---------------------------------------------------------------------- */
-/* marker filter + score + deterministic part of the decision, one thread per group */
-__global__ __launch_bounds__(256) void score_kernel(spx_dev_groups Gd)
+/* marker filter + score + deterministic part of the decision
+ * (ptMarker.c:110-153 filter_lowq_markers, :307-325 calc_alignment_score; ptAlignment.c:137-177), three
+ * small kernels: per read position the minimum quality over its n markers; per (group, alignment) the
+ * score accumulated in position order (the order the reference adds them in); per group the decision. */
+__global__ __launch_bounds__(256) void posmin_kernel(spx_dev_groups Gd, int32_t n_markers, uint8_t *__restrict__ posmin)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_markers) return;
+    const int n = Gd.markers[m].first_of_pos; /* number of markers of this position, 0 if not the first */
+    if (n == 0) return;
+    int minq = 100;
+    for (int k = 0; k < n; ++k) {
+        const spx_dev_marker mk = Gd.markers[m + k];
+        const int q = mk.row >= 0 ? Gd.out_bq[mk.row] : mk.qfix;
+        minq = q < minq ? q : minq;
+    }
+    posmin[m] = (uint8_t)minq;
+}
+
+__global__ __launch_bounds__(256) void score_kernel(spx_dev_groups Gd, const uint8_t *__restrict__ posmin)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gi = t / 10, a = t - gi * 10;
+    if (gi >= Gd.n_groups) return;
+    const int n = Gd.n_aln[gi];
+    if (a >= n) return;
+    const int m0 = Gd.mk_first[gi], m1 = Gd.mk_first[gi + 1];
+    double sc = 0.0;
+    for (int m = m0; m < m1; m += n) {
+        const int minq = posmin[m];
+        if (minq > Gd.min_q) sc += Gd.markers[m + a].is_match ? Gd.match_tbl[minq] : Gd.mis_tbl[minq];
+    }
+    Gd.score[(int64_t)gi * 10 + a] = sc;
+}
+
+__global__ __launch_bounds__(256) void decide_kernel(spx_dev_groups Gd)
 {
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= Gd.n_groups) return;
-    const int m0 = Gd.mk_first[gi], m1 = Gd.mk_first[gi + 1];
     const int n = Gd.n_aln[gi];
     const uint32_t sec = Gd.sec_mask[gi];
-    double *out = Gd.score + (int64_t)gi * 10;
+    const double *sc = Gd.score + (int64_t)gi * 10;
     double max_score = -1.7976931348623157e308, prim_score = -1.7976931348623157e308;
     int max_idx = -1, prim_idx = -1;
     for (int a = 0; a < n; ++a) {
-        double sc = 0.0;
-        int p = m0;
-        while (p < m1) {
-            /* one read position: min quality over its markers (filter_lowq_markers) */
-            int e = p, mine = -1, is_match = 0;
-            int minq = 100;
-            do {
-                const spx_dev_marker mk = Gd.markers[e];
-                int q = mk.row >= 0 ? Gd.out_bq[mk.row] : mk.qfix;
-                if (q < minq) minq = q;
-                if (mk.aln == a) { mine = e; is_match = mk.is_match; }
-                ++e;
-            } while (e < m1 && !Gd.markers[e].first_of_pos);
-            if (minq > Gd.min_q && mine >= 0) sc += is_match ? Gd.match_tbl[minq] : Gd.mis_tbl[minq];
-            p = e;
-        }
-        out[a] = sc;
-        if (!((sec >> a) & 1)) { prim_idx = a; prim_score = sc; }
-        else if (max_score < sc) { max_idx = a; max_score = sc; }
+        if (!((sec >> a) & 1)) { prim_idx = a; prim_score = sc[a]; }
+        else if (max_score < sc[a]) { max_idx = a; max_score = sc[a]; }
     }
     uint32_t tie = 0;
     for (int a = 0; a < n; ++a)
-        if (((sec >> a) & 1) && max_score <= out[a]) tie |= 1u << a;
+        if (((sec >> a) & 1) && max_score <= sc[a]) tie |= 1u << a;
     Gd.prim_idx[gi] = (uint8_t)prim_idx;
     Gd.max_idx[gi] = (uint8_t)max_idx;
     Gd.tie_mask[gi] = (uint16_t)tie;
@@ -742,10 +758,12 @@ extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_
     return hipGetLastError();
 }
 
-extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, hipStream_t st)
+extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st)
 {
     if (Gd->n_groups <= 0) return hipSuccess;
-    int blocks = (Gd->n_groups + 255) / 256;
-    hipLaunchKernelGGL(score_kernel, dim3(blocks), dim3(256), 0, st, *Gd);
+    if (n_markers > 0)
+        hipLaunchKernelGGL(posmin_kernel, dim3((n_markers + 255) / 256), dim3(256), 0, st, *Gd, n_markers, posmin);
+    hipLaunchKernelGGL(score_kernel, dim3((Gd->n_groups * 10 + 255) / 256), dim3(256), 0, st, *Gd, posmin);
+    hipLaunchKernelGGL(decide_kernel, dim3((Gd->n_groups + 255) / 256), dim3(256), 0, st, *Gd);
     return hipGetLastError();
 }

@@ -748,7 +748,7 @@ static int prepare_one(const spx_batch *bt, const RefIndex &ref, const spx_param
             dm.qfix = (uint8_t)m.q;
             dm.is_match = (uint8_t)m.is_match;
             dm.aln = (uint8_t)m.aln;
-            dm.first_of_pos = (k == 0 || S.mk[k - 1].pos != m.pos) ? 1 : 0;
+            dm.first_of_pos = (k == 0 || S.mk[k - 1].pos != m.pos) ? (uint8_t)n : 0;
             out.markers.push_back(dm);
         }
     }

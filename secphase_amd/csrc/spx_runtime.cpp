@@ -27,7 +27,7 @@
 #include "spx_prep.h"
 
 extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st);
-extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, hipStream_t st);
+extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
                                       unsigned long long *out, hipStream_t st);
@@ -91,7 +91,7 @@ struct spx_work {
     uint8_t *d_prim = nullptr, *d_max = nullptr, *d_pass = nullptr;
     uint16_t *d_tie = nullptr;
     int32_t *d_grp_index = nullptr;
-    uint8_t *d_bq = nullptr, *d_q = nullptr;
+    uint8_t *d_bq = nullptr, *d_q = nullptr, *d_posmin = nullptr;
     int32_t *d_state = nullptr;
     spx_stats st;
     spx_params par;
@@ -272,7 +272,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
            o_sec = cv.take<uint16_t>(ng), o_gidx = cv.take<int32_t>(ng);
     const size_t in_bytes = cv.off;
     size_t o_sinv = cv.take<double>((size_t)s_tot), o_fsave = cv.take<double>((size_t)f_tot),
-           o_bq = cv.take<uint8_t>(nr + 16), o_state = want_state_q ? cv.take<int32_t>(nr) : 0,
+           o_bq = cv.take<uint8_t>(nr + 16), o_posmin = cv.take<uint8_t>(nm + 16), o_state = want_state_q ? cv.take<int32_t>(nr) : 0,
            o_q = want_state_q ? cv.take<uint8_t>(nr + 16) : 0, o_score = cv.take<double>(ng * 10),
            o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
            o_tie = cv.take<uint16_t>(ng);
@@ -296,6 +296,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     w->st.h2d_seconds = now_s() - t0;
     w->st.bytes_h2d = (int64_t)in_bytes;
     w->d_bq = (uint8_t *)(base + o_bq);
+    w->d_posmin = (uint8_t *)(base + o_posmin);
     w->d_state = want_state_q ? (int32_t *)(base + o_state) : nullptr;
     w->d_q = want_state_q ? (uint8_t *)(base + o_q) : nullptr;
     w->d_score = (double *)(base + o_score);
@@ -445,7 +446,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         if (w->cls_used[cls]) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
     HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, c->stream));
+    if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, (int32_t)w->hb.markers.size(), w->d_posmin, c->stream));
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     w->launched = true;
     return SPX_OK;
