@@ -44,6 +44,9 @@ class Stats(C.Structure):
         ("problems_per_class", C.c_int64 * 12),
         ("prep_seconds", C.c_double), ("h2d_seconds", C.c_double), ("kernel_seconds", C.c_double),
         ("d2h_seconds", C.c_double), ("baq_kernel_ms", C.c_double), ("score_kernel_ms", C.c_double),
+        ("main_fwd_ms", C.c_double), ("main_bwd_ms", C.c_double), ("main_class_cells", C.c_int64),
+        ("main_class", C.c_int32), ("main_class_lanes", C.c_int32), ("main_class_slots", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -731,16 +731,16 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 }
 
 /* ---------------------------------------------------------------------- */
-/* phase 0 = forward kernel, 1 = backward kernel (same grid; the backward launch follows on the same stream) */
-extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st)
+/* phase 0 = forward kernel, 1 = backward kernel, 2 = both (back to back on the same stream) */
+extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st)
 {
     if (B->n_order <= 0) return hipSuccess;
-#define SPX_LAUNCH(G_, C_)                                                                        \
-    {                                                                                             \
-        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw;                                 \
-        hipLaunchKernelGGL((baq_fwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);          \
-        hipLaunchKernelGGL((baq_bwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);          \
-    }                                                                                             \
+#define SPX_LAUNCH(G_, C_)                                                                                       \
+    {                                                                                                            \
+        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw;                                                \
+        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);         \
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);         \
+    }                                                                                                            \
     break;
     switch (cls) { /* (lanes per problem, band slots per lane): keep in step with spx_prep.cpp kClass* */
     case 0: SPX_LAUNCH(2, 21)

@@ -26,7 +26,7 @@
 #include "spx_device.h"
 #include "spx_prep.h"
 
-extern "C" hipError_t spx_launch_baq(int cls, const spx_dev_batch *B, hipStream_t st);
+extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st);
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
@@ -65,7 +65,7 @@ static const unsigned char kNt16Int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4
 struct spx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
      * (or in front of) the bulk class */
     hipStream_t cls_stream[SPX_N_CLASSES] = {};
@@ -84,6 +84,8 @@ struct spx_work {
     size_t arena_bytes = 0;
     spx_dev_batch cls_batch[SPX_N_CLASSES];
     int cls_used[SPX_N_CLASSES] = {};
+    int main_cls = -1;
+    int64_t cls_cells[SPX_N_CLASSES] = {};
     spx_dev_groups dg;
     bool have_groups = false;
     /* device output mirrors */
@@ -135,8 +137,8 @@ extern "C" int spx_create(int device, spx_ctx **out)
     spx_ctx *c = new spx_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-    for (int i = 1; i < SPX_N_CLASSES; ++i) {
+    for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    for (int i = 0; i < SPX_N_CLASSES; ++i) {
         HIPCHK(hipStreamCreateWithFlags(&c->cls_stream[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->cls_done[i], hipEventDisableTiming));
     }
@@ -157,9 +159,9 @@ extern "C" void spx_destroy(spx_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->d_ref4) (void)hipFree(c->d_ref4);
     if (c->d_tables) (void)hipFree(c->d_tables);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 1; i < SPX_N_CLASSES; ++i) {
+    for (int i = 0; i < SPX_N_CLASSES; ++i) {
         if (c->cls_done[i]) (void)hipEventDestroy(c->cls_done[i]);
         if (c->cls_stream[i]) (void)hipStreamDestroy(c->cls_stream[i]);
     }
@@ -227,6 +229,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     for (size_t p = 0; p < np; ++p) {
         int cls = spx::band_class(2 * hb.bw[p] + 1);
         ids[cls].push_back((int32_t)p);
+        w->cls_cells[cls] += spx::band_cells(hb.L[p], hb.R[p], hb.bw[p]);
     }
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
         auto &v = ids[cls];
@@ -309,6 +312,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
         spx_dev_batch &B = w->cls_batch[cls];
         memset(&B, 0, sizeof B);
         w->cls_used[cls] = !order[cls].empty();
+        if (w->cls_used[cls] && (w->main_cls < 0 || w->cls_cells[cls] > w->cls_cells[w->main_cls])) w->main_cls = cls;
         B.order = (const int32_t *)(base + o_order[cls]);
         B.n_order = (int32_t)order[cls].size();
         B.ref_nib = (const int64_t *)(base + o_ref_nib);
@@ -434,16 +438,24 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    /* wide classes first on their own streams (few, long waves), the bulk class on the main stream */
-    for (int cls = SPX_N_CLASSES - 1; cls >= 1; --cls) {
-        if (!w->cls_used[cls]) continue;
+    /* the class holding most of the band cells runs on the main stream (its forward and backward kernels are
+     * bracketed by events); the others run beside it on their own streams */
+    const int mc = w->main_cls;
+    for (int cls = SPX_N_CLASSES - 1; cls >= 0; --cls) {
+        if (!w->cls_used[cls] || cls == mc) continue;
         HIPCHK(hipStreamWaitEvent(c->cls_stream[cls], c->ev[0], 0));
-        HIPCHK(spx_launch_baq(cls, &w->cls_batch[cls], c->cls_stream[cls]));
+        HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->cls_stream[cls]));
         HIPCHK(hipEventRecord(c->cls_done[cls], c->cls_stream[cls]));
     }
-    if (w->cls_used[0]) HIPCHK(spx_launch_baq(0, &w->cls_batch[0], c->stream));
-    for (int cls = 1; cls < SPX_N_CLASSES; ++cls)
-        if (w->cls_used[cls]) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
+    if (mc >= 0) {
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(spx_launch_baq(mc, 0, &w->cls_batch[mc], c->stream));
+        HIPCHK(hipEventRecord(c->ev[4], c->stream));
+        HIPCHK(spx_launch_baq(mc, 1, &w->cls_batch[mc], c->stream));
+        HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    }
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
+        if (w->cls_used[cls] && cls != mc) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
     HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, (int32_t)w->hb.markers.size(), w->d_posmin, c->stream));
@@ -479,6 +491,16 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         w->st.baq_kernel_ms = ms;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
         w->st.score_kernel_ms = ms;
+        if (w->main_cls >= 0) {
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+            w->st.main_fwd_ms = ms;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+            w->st.main_bwd_ms = ms;
+            w->st.main_class = w->main_cls;
+            w->st.main_class_cells = w->cls_cells[w->main_cls];
+            w->st.main_class_lanes = spx::class_lanes(w->main_cls);
+            w->st.main_class_slots = spx::class_slots(w->main_cls);
+        }
         w->st.kernel_seconds = (w->st.baq_kernel_ms + w->st.score_kernel_ms) * 1e-3;
     }
     const size_t ng = w->hb.grp_index.size();
