@@ -58,6 +58,8 @@ def lib():
                                          C.POINTER(C.c_int), u8p]
         L.orc_phred_from_posterior.restype = C.c_int
         L.orc_phred_from_posterior.argtypes = [C.c_double]
+        L.orc_set_scratch_reuse.argtypes = [C.c_int]
+        L.orc_set_scratch_reuse.restype = None
         L.orc_probaln_consts.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(HmmConsts)]
         L.orc_srand.argtypes = [C.POINTER(Rand), C.c_uint]
         L.orc_rand_next.restype = C.c_int
@@ -77,7 +79,8 @@ def lib():
     return _lib
 
 
-def run_batch(batch, ref, params, threads=1, seed=1, log_path=None):
+def run_batch(batch, ref, params, threads=1, seed=1, log_path=None, reuse_scratch=False):
+    lib().orc_set_scratch_reuse(1 if reuse_scratch else 0)
     n = batch.contents.n_groups if hasattr(batch, "contents") else batch.n_groups
     res = (GroupResult * n)()
     nre = lib().orc_run_batch(batch, ref, C.byref(params), threads, seed, res,

@@ -88,6 +88,26 @@ void orc_probaln_consts(int l_ref, int l_query, float d, float e, int set_q, orc
     c->e_mis = (double)qf * ORC_EM;
 }
 
+/* The reference calloc()s two (L+1) x (3*bw2+6) double matrices per call and frees them again; with many
+ * worker threads that turns into mmap/munmap + page-fault contention.  For the CPU BASELINE the worker
+ * threads may keep one zeroed-on-demand scratch block each (same values, same arithmetic; only the
+ * allocator traffic goes away).  Off by default = the reference's allocation pattern. */
+static int g_reuse_scratch = 0;
+void orc_set_scratch_reuse(int on) { g_reuse_scratch = on; }
+static __thread double *t_buf = NULL;
+static __thread size_t t_cap = 0;
+static double *scratch_zeroed(size_t n_doubles)
+{
+    if (n_doubles > t_cap) {
+        free(t_buf);
+        t_cap = n_doubles + n_doubles / 4;
+        t_buf = malloc(t_cap * sizeof(double));
+        if (!t_buf) { t_cap = 0; return NULL; }
+    }
+    memset(t_buf, 0, n_doubles * sizeof(double));
+    return t_buf;
+}
+
 int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query,
                        const uint8_t *iqual, const orc_probaln_par *c, int *state, uint8_t *q)
 {
@@ -105,13 +125,24 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
     bw2 = bw * 2 + 1;
     i_dim = bw2 < l_ref ? (size_t)bw2 * 3 + 6 : (size_t)l_ref * 3 + 6;
 
-    f = calloc((size_t)(l_query + 1) * i_dim, sizeof(double));
-    if (is_backward) b = calloc((size_t)(l_query + 1) * i_dim, sizeof(double));
-    s = calloc((size_t)l_query + 2, sizeof(double));
-    qual = calloc((size_t)l_query, sizeof(float));
-    if (!f || (is_backward && !b) || !s || !qual) {
-        free(f); free(b); free(s); free(qual);
-        return INT_MIN;
+    const int reuse = g_reuse_scratch;
+    if (reuse) {
+        size_t nm = (size_t)(l_query + 1) * i_dim;
+        double *blk = scratch_zeroed(nm * (is_backward ? 2 : 1) + (size_t)l_query + 2 + ((size_t)l_query + 1) / 2 + 1);
+        if (!blk) return INT_MIN;
+        f = blk;
+        if (is_backward) b = blk + nm;
+        s = blk + nm * (is_backward ? 2 : 1);
+        qual = (float *)(s + l_query + 2);
+    } else {
+        f = calloc((size_t)(l_query + 1) * i_dim, sizeof(double));
+        if (is_backward) b = calloc((size_t)(l_query + 1) * i_dim, sizeof(double));
+        s = calloc((size_t)l_query + 2, sizeof(double));
+        qual = calloc((size_t)l_query, sizeof(float));
+        if (!f || (is_backward && !b) || !s || !qual) {
+            free(f); free(b); free(s); free(qual);
+            return INT_MIN;
+        }
     }
     for (i = 0; i < l_query; ++i) qual[i] = (float)pow(10, -(iqual ? iqual[i] : 30) / 10.);
 
@@ -185,7 +216,7 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
         Pr1 += -4.343 * log(p * l_ref * l_query);
         Pr = (int)(Pr1 + .499);
         if (!is_backward) {
-            free(f); free(s); free(qual);
+            if (!reuse) { free(f); free(s); free(qual); }
             return Pr;
         }
     }
@@ -240,6 +271,6 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
         state[i - 1] = max_k;
         q[i - 1] = (uint8_t)orc_phred_from_posterior(max);
     }
-    free(f); free(b); free(s); free(qual);
+    if (!reuse) { free(f); free(b); free(s); free(qual); }
     return Pr;
 }

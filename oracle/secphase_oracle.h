@@ -38,6 +38,7 @@ typedef struct orc_hmm_consts {
 int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query,
                        const uint8_t *iqual, const orc_probaln_par *c, int *state, uint8_t *q);
 int orc_phred_from_posterior(double max_over_sum);
+void orc_set_scratch_reuse(int on); /* CPU-baseline runs: per-thread scratch instead of calloc/free per call */
 void orc_probaln_consts(int l_ref, int l_query, float d, float e, int set_q, orc_hmm_consts *c);
 
 /* glibc rand() (TYPE_3 additive feedback) replay, so that the tie-breaking
