@@ -28,6 +28,22 @@ FLOPS_PER_CELL = 45             # forward 19 + backward 
 FWD_FLOPS_PER_CELL = 19
 
 
+def pmc_traffic(kernel, gps):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_counters.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very command, KB units).  FETCH_SIZE is
+    reported as read on gfx950 (the guide's x2 correction applies to wide 16 B/lane streams; these kernels read
+    bytes and dwords), so the figure is a lower bound on the read side.  None when the profile does not match."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_counters.json")))
+        meta = prof.get("_meta", {})
+        if meta.get("groups_per_step") != gps:
+            return None
+        k = prof.get("void " + kernel) or prof.get(kernel)
+        return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
+    except Exception:
+        return None
+
+
 def gen_parallel(genome, first, n, chunk, threads):
     """generate n groups starting at `first` in `chunk`-sized batches on `threads` threads"""
     from secphase_amd import synth  # noqa: F401
@@ -213,7 +229,7 @@ def main():
             "peak": PEAK_FP64_VECTOR_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved_tf / PEAK_FP64_VECTOR_TFLOPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(kname, gps),
             "kernel": kname,
             "avg_launch_ms": round(fwd_ms, 4),
             "cells_per_launch": int(cls_cells),
@@ -236,15 +252,23 @@ def main():
             ns = args.cpu_sample or max(256 if ont else 1024, (4 if ont else 16) * ncpu)
             ns = min(ns, gps)
             sample = genome.reads(first, ns)
-            cores = ncpu
-            t0 = time.perf_counter()
-            nre, res = orc.run_batch(sample.batch, genome.ref, params, threads=cores, seed=1, reuse_scratch=True)
-            dt = time.perf_counter() - t0
-            ndis = sum(1 for r in res if r.n_aln > 0)
-            cpu = {"value": round(ndis / dt, 2), "unit": "groups/s", "cores": cores, "kind": "port",
-                   "sample": f"first {ns} groups of the same workload, oracle (C restatement, -O2 -ffp-contract=off, pthread pool over "
-                             f"groups, per-thread DP scratch instead of calloc/free per call), {dt:.2f} s wall",
-                   "cells_per_s": round(sum(r.dp_cells for r in res) / dt, 1)}
+            # the oracle keeps the reference's memory pattern (two ~0.8 MB matrices zeroed per BAQ call), which
+            # saturates the host memory system well before all hardware threads are busy: time it at all
+            # threads and at 32, report the better one with the thread count actually used
+            best = None
+            for cores in sorted({ncpu, min(ncpu, 32)}, reverse=True):
+                t0 = time.perf_counter()
+                nre, res = orc.run_batch(sample.batch, genome.ref, params, threads=cores, seed=1, reuse_scratch=True)
+                dt = time.perf_counter() - t0
+                ndis = sum(1 for r in res if r.n_aln > 0)
+                cand = {"value": round(ndis / dt, 2), "unit": "groups/s", "cores": cores, "kind": "port",
+                        "sample": f"first {ns} groups of the same workload, oracle (C restatement, -O2 -ffp-contract=off, "
+                                  f"pthread pool over groups, per-thread DP scratch instead of calloc/free per call), "
+                                  f"{dt:.2f} s wall; host has {ncpu} hardware threads",
+                        "cells_per_s": round(sum(r.dp_cells for r in res) / dt, 1)}
+                if best is None or cand["value"] > best["value"]:
+                    best = cand
+            cpu = best
         line = {
             "metric": "reads/sec (primary+secondary groups scored)",
             "value": round(value, 2),
