@@ -138,7 +138,7 @@ struct HmmC {
 
 /* one forward row (i >= 2), in place: on entry fM,fI,fD = scaled row i-1; on exit scaled row i.
  * Returns the row sum s[i]. */
-template <int G, int C, bool FAST>
+template <int G, int C, bool FAST, int W0>
 __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], double (&fD)[C], const CodeWin<C> &ew,
                                           uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double &inv_out)
 {
@@ -184,7 +184,8 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
                     s = s + ((fM[c] + fI[c]) + d);
                 }
             } else {
-                const int nc = min(C, Wu - t * C);
+                /* W0 != 0: the band width is a compile-time constant of this instantiation */
+                const int nc = W0 ? (t < (W0 - 1) / C ? C : W0 - ((W0 - 1) / C) * C) : min(C, Wu - t * C);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     /* slots beyond the band (c >= nc) keep D = 0: it feeds M of that slot in the next row */
@@ -213,7 +214,7 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
 
 /* one backward row (1 <= i <= L-1), in place: on entry bM,bI = scaled row i+1; on exit scaled row i.
  * ew holds the code of column k+1 (ref index i - bw + j) per slot. */
-template <int G, int C, bool FAST>
+template <int G, int C, bool FAST, int W0>
 __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double (&bD)[C], const CodeWin<C> &ew,
                                         uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double inv, bool first_row)
 {
@@ -244,7 +245,7 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double
                         bD[c] = d;
                     }
                 } else {
-                    const int nc = min(C, Wu - t * C);
+                    const int nc = W0 ? (W0 - ((W0 - 1) / C) * C) : min(C, Wu - t * C);
 #pragma unroll
                     for (int c = C - 1; c >= 0; --c) {
                         const double x = (c < nc) ? bD[c] : 0.0; /* D of a column that does not exist stays 0 */
@@ -329,7 +330,7 @@ __device__ __forceinline__ int wave_min(int v)
 
 /* ====================================================================== */
 /* forward pass: rows 1..L, saves 1/s[i] (i < L), s[L], s[L+1] and the scaled M,I rows at the wanted rows */
-template <int G, int C>
+template <int G, int C, int W0>
 __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch B)
 {
     constexpr int SLOTS = G * C;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
     const Prob P = load_problem<G>(B, lane, h, hasN);
     const bool act = P.act;
     const int L = P.L, R = P.R, bw = P.bw;
-    const int Wu = wave_max(act ? 2 * bw + 1 : 0);
+    const int Wu = W0 ? W0 : wave_max(act ? 2 * bw + 1 : 0);
     const int Lw = wave_max(L);
     if (Lw == 0) return;
     /* forward row i is interior iff i + bw <= R, for every problem of the wave, and no N anywhere */
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
             double inv;
-            s_cur = fwd_row<G, C, FAST>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
+            s_cur = fwd_row<G, C, FAST, W0>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
             if (g == 0) sinv[i] = inv;
             if (i == next_row) save_row();
         }
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
 /* ====================================================================== */
 /* backward pass: rows L..(first wanted row), MAP + phred + write-back rule at the wanted rows.
  * Rows below the first wanted row have no observable effect and are not computed. */
-template <int G, int C>
+template <int G, int C, int W0>
 __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch B)
 {
     constexpr int SLOTS = G * C;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
     const Prob P = load_problem<G>(B, lane, h, hasN);
     const bool act = P.act;
     const int L = P.L, R = P.R, bw = P.bw;
-    const int Wu = wave_max(act ? 2 * bw + 1 : 0);
+    const int Wu = W0 ? W0 : wave_max(act ? 2 * bw + 1 : 0);
     const int Lw = wave_max(L);
     if (Lw == 0) return;
     const int nrows = P.nrows, row0 = P.row0;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
             if (i >= 2) inv_p = sinv[i - 1]; /* prefetch for row i-1 */
-            bwd_row<G, C, FAST>(bM, bI, bD, ew, qy, h, g, Wu, tlast, inv, i == 1);
+            bwd_row<G, C, FAST, W0>(bM, bI, bD, ew, qy, h, g, Wu, tlast, inv, i == 1);
             if (i == prev_row) save_row();
         }
     };
@@ -735,23 +736,23 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st)
 {
     if (B->n_order <= 0) return hipSuccess;
-#define SPX_LAUNCH(G_, C_)                                                                                       \
+#define SPX_LAUNCH(G_, C_, W0_)                                                                                  \
     {                                                                                                            \
         int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw;                                                \
-        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);         \
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_>), dim3(blocks), dim3(64), 0, st, *B);         \
+        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<G_, C_, W0_>), dim3(blocks), dim3(64), 0, st, *B);    \
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_>), dim3(blocks), dim3(64), 0, st, *B);    \
     }                                                                                                            \
     break;
     switch (cls) { /* (lanes per problem, band slots per lane): keep in step with spx_prep.cpp kClass* */
-    case 0: SPX_LAUNCH(2, 21)
-    case 1: SPX_LAUNCH(2, 24)
-    case 2: SPX_LAUNCH(4, 16)
-    case 3: SPX_LAUNCH(4, 26)
-    case 4: SPX_LAUNCH(8, 16)
-    case 5: SPX_LAUNCH(16, 16)
-    case 6: SPX_LAUNCH(32, 16)
-    case 7: SPX_LAUNCH(64, 16)
-    case 8: SPX_LAUNCH(64, 32)
+    case 0: SPX_LAUNCH(2, 21, 41) /* exactly W = 41: bw = 20, the HiFi preset on windows with R == L */
+    case 1: SPX_LAUNCH(2, 24, 0)
+    case 2: SPX_LAUNCH(4, 16, 0)
+    case 3: SPX_LAUNCH(4, 26, 0)
+    case 4: SPX_LAUNCH(8, 16, 0)
+    case 5: SPX_LAUNCH(16, 16, 0)
+    case 6: SPX_LAUNCH(32, 16, 0)
+    case 7: SPX_LAUNCH(64, 16, 0)
+    case 8: SPX_LAUNCH(64, 32, 0)
     default: return hipErrorInvalidValue;
     }
 #undef SPX_LAUNCH

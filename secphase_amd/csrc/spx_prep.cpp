@@ -121,7 +121,10 @@ static const int kClassSlots[SPX_N_CLASSES] = {42, 48, 64, 104, 128, 256, 512, 1
 static const int kClassLanes[SPX_N_CLASSES] = {2, 2, 4, 4, 8, 16, 32, 64, 64};
 int band_class(int W)
 {
-    for (int c = 0; c < SPX_N_CLASSES; ++c)
+    /* class 0 is specialised for exactly W = 41 (its instantiation has the band width as a constant);
+     * narrower bands (short windows, small -b) go to class 1 */
+    if (W == 41) return 0;
+    for (int c = 1; c < SPX_N_CLASSES; ++c)
         if (W <= kClassSlots[c]) return c;
     return -1;
 }
