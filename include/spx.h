@@ -122,6 +122,12 @@ void spx_work_free(spx_ctx *ctx, spx_work *work);
 /* rand() replay + decision, in file order */
 int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups);
 
+/* the same with ONE draw stream kept across batches (a whole run = the reference at -@1) */
+typedef struct spx_finalizer spx_finalizer;
+int spx_finalizer_create(unsigned rand_seed, spx_finalizer **out);
+int spx_finalizer_apply(spx_finalizer *f, const spx_params *par, spx_group_out *out, int32_t n_groups);
+void spx_finalizer_free(spx_finalizer *f);
+
 /* append the relabel records of a finalized batch to `path` (mode "w" or "a") */
 int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *bt, const spx_ref *ref,
                           const spx_group_out *out);
@@ -137,6 +143,41 @@ int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
 int spx_probaln_batch(spx_ctx *ctx, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
                       const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t *state,
                       uint8_t *q, double *kernel_ms);
+
+/* ---- BED side outputs (src/secphase.c:59-72,201-212,713-732; ptBlock.c:228-428,573-602) ------------ */
+typedef struct spx_bedset spx_bedset;
+int spx_bedset_create(spx_bedset **out);
+void spx_bedset_free(spx_bedset *b);
+int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, int32_t end /* inclusive */, int32_t count);
+int64_t spx_bedset_size(const spx_bedset *b);
+/* sort + ptBlock_merge_blocks_v2 per contig + ptBlock_save_in_bed; the file is created even when empty */
+int spx_bedset_save(const spx_bedset *b, const char *path, int print_count);
+/* the merge alone: disjoint pieces cut at every start and every end+1, each with the summed count of the
+ * blocks covering it (c == NULL: no counts).  Returns the number of pieces (<= cap) or SPX_EINVAL. */
+int spx_merge_blocks_count(int32_t n, const int32_t *s, const int32_t *e, const int32_t *c, int32_t *os, int32_t *oe,
+                           int32_t *oc, int32_t cap);
+/* after spx_collect + finalize: add the blocks of every relabelled group of `work` to the two sets
+ * (either may be NULL).  Returns the number of relabelled groups. */
+int spx_relabel_blocks(const spx_work *work, const spx_ref *ref, const spx_group_out *out, spx_bedset *modified_blocks,
+                       spx_bedset *marker_blocks);
+
+/* ---- input side: name-grouped BAM and FASTA readers (zlib only; the reference reads through htslib:
+ * sam_open/sam_read1 src/secphase.c:236-268, fai_load/fai_fetch src/secphase.c:101, ptMarker.c:739-744) ---- */
+typedef struct spx_bam_reader spx_bam_reader;
+typedef struct spx_fasta spx_fasta;
+const char *spx_io_last_error(void);
+int spx_bam_open(const char *path, int threads, spx_bam_reader **out);
+int32_t spx_bam_n_targets(const spx_bam_reader *r);
+const char *spx_bam_target_name(const spx_bam_reader *r, int32_t i);
+/* map BAM target ids to the contig indices of `ref` by name; returns the number of targets the FASTA lacks */
+int spx_bam_bind_reference(spx_bam_reader *r, const spx_ref *ref);
+/* up to max_groups complete name groups (consecutive records with one read name, src/secphase.c:273-279);
+ * the batch is owned by the reader and valid until the next call; returns groups read, 0 at EOF, <0 on error */
+int spx_bam_next_batch(spx_bam_reader *r, int32_t max_groups, const spx_batch **out);
+void spx_bam_close(spx_bam_reader *r);
+int spx_fasta_load(const char *path, spx_fasta **out);
+const spx_ref *spx_fasta_ref(const spx_fasta *f);
+void spx_fasta_free(spx_fasta *f);
 
 /* ---- host-only view of the work list (no device needed) ------------------
  * What spx_prepare would upload: the banded DP problems and the marker table.

@@ -35,6 +35,7 @@ class GroupResult(C.Structure):
         ("score", C.c_double * 16), ("rfe", C.c_int * 16),
         ("n_markers_initial", C.c_int), ("n_markers_final", C.c_int), ("n_blocks", C.c_int),
         ("n_baq_calls", C.c_int), ("dp_cells", C.c_longlong),
+        ("rfs", C.c_int * 16), ("final_markers", C.c_void_p), ("n_final", C.c_int),
     ]
 
 
@@ -73,16 +74,26 @@ def lib():
         L.orc_run_batch.restype = C.c_int
         L.orc_run_batch.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
                                     C.c_uint, C.POINTER(GroupResult), C.c_char_p]
+        L.orc_run_batch_bed.restype = C.c_int
+        L.orc_run_batch_bed.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
+                                        C.c_uint, C.POINTER(GroupResult), C.c_char_p, C.c_char_p, C.c_char_p]
+        ip = C.POINTER(C.c_int)
+        L.orc_blocks_sort.argtypes = [C.c_int, ip, ip, ip]
+        L.orc_blocks_sort.restype = None
+        L.orc_blocks_merge.argtypes = [C.c_int, ip, ip, ip, ip, ip, ip]
+        L.orc_blocks_merge_v2.argtypes = [C.c_int, ip, ip, ip, ip, ip, ip]
         L.orc_walk_cigar.restype = C.c_int
         L.orc_walk_cigar.argtypes = [C.POINTER(SpxBatch), C.c_int, C.POINTER(C.POINTER(Op))]
         _lib = L
     return _lib
 
 
-def run_batch(batch, ref, params, threads=1, seed=1, log_path=None, reuse_scratch=False):
+def run_batch(batch, ref, params, threads=1, seed=1, log_path=None, reuse_scratch=False, bed_modified=None,
+              bed_markers=None):
     lib().orc_set_scratch_reuse(1 if reuse_scratch else 0)
     n = batch.contents.n_groups if hasattr(batch, "contents") else batch.n_groups
     res = (GroupResult * n)()
-    nre = lib().orc_run_batch(batch, ref, C.byref(params), threads, seed, res,
-                              log_path.encode() if log_path else None)
+    enc = lambda p: p.encode() if p else None
+    nre = lib().orc_run_batch_bed(batch, ref, C.byref(params), threads, seed, res, enc(log_path), enc(bed_modified),
+                                  enc(bed_markers))
     return nre, res

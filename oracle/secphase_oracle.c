@@ -819,6 +819,8 @@ static int group_alns(const spx_batch *bt, int g, int *amap)
     return n;
 }
 
+static int g_keep_markers = 0; /* set by orc_run_batch_bed while it runs */
+
 /* marker branch of runOneThread up to (not including) get_best_record_index */
 static int score_group(const spx_batch *bt, const spx_ref *ref, int g, const spx_params *par, orc_group_result *out,
                        orc_baq_call *calls, int max_calls)
@@ -880,8 +882,10 @@ static int score_group(const spx_batch *bt, const spx_ref *ref, int g, const spx
     for (i = 0; i < n; ++i) {
         out->score[i] = al[i].score;
         out->rfe[i] = al[i].rfe;
+        out->rfs[i] = al[i].rfs;
         if (out->prim_idx < 0 && (al[i].flag & SPX_FSECONDARY) == 0) out->prim_idx = i;
     }
+    if (g_keep_markers) { out->final_markers = mk.v; out->n_final = mk.n; mk.v = NULL; }
     free(mk.v);
     free_alns(al, n);
     return 0;
@@ -934,8 +938,51 @@ static void *pool_worker(void *p_)
     return NULL;
 }
 
-int orc_run_batch(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads, unsigned rand_seed,
-                  orc_group_result *results, const char *log_path)
+typedef struct { int *s, *e, *c; int n, cap; } blkacc;
+static void acc_push(blkacc *a, int s, int e, int c)
+{
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 64;
+        a->s = realloc(a->s, sizeof(int) * a->cap); a->e = realloc(a->e, sizeof(int) * a->cap);
+        a->c = realloc(a->c, sizeof(int) * a->cap);
+    }
+    a->s[a->n] = s; a->e[a->n] = e; a->c[a->n] = c; a->n++;
+}
+static const spx_ref *g_sort_ref;
+static int cmp_contig(const void *a, const void *b)
+{
+    return strcmp(g_sort_ref->names + g_sort_ref->name_off[*(const int *)a], g_sort_ref->names + g_sort_ref->name_off[*(const int *)b]);
+}
+/* merge_and_save_blocks (secphase.c:59-72): sort by start, ptBlock_merge_blocks_v2, ptBlock_save_in_bed */
+static void save_bed(const spx_ref *ref, blkacc *acc, const char *path, int with_count)
+{
+    FILE *fp = fopen(path, "w");
+    int nc = ref->n_contigs, i, k, *order = malloc(sizeof(int) * (nc ? nc : 1));
+    if (!fp) { free(order); return; }
+    for (i = 0; i < nc; ++i) order[i] = i;
+    g_sort_ref = ref;
+    qsort(order, nc, sizeof(int), cmp_contig);
+    for (k = 0; k < nc; ++k) {
+        blkacc *a = &acc[order[k]];
+        int m, *os, *oe, *oc;
+        if (a->n == 0) continue;
+        orc_blocks_sort(a->n, a->s, a->e, a->c);
+        os = malloc(sizeof(int) * (2 * a->n + 1)); oe = malloc(sizeof(int) * (2 * a->n + 1)); oc = malloc(sizeof(int) * (2 * a->n + 1));
+        m = orc_blocks_merge_v2(a->n, a->s, a->e, with_count ? a->c : NULL, os, oe, with_count ? oc : NULL);
+        for (i = 0; i < m; ++i) {
+            if (oe[i] < os[i]) continue;
+            if (with_count) fprintf(fp, "%s\t%d\t%d\t%d\n", ref->names + ref->name_off[order[k]], os[i], oe[i] + 1, oc[i]);
+            else fprintf(fp, "%s\t%d\t%d\n", ref->names + ref->name_off[order[k]], os[i], oe[i] + 1);
+        }
+        free(os); free(oe); free(oc);
+    }
+    fclose(fp);
+    free(order);
+}
+
+int orc_run_batch_bed(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads, unsigned rand_seed,
+                      orc_group_result *results, const char *log_path, const char *bed_modified_path,
+                      const char *bed_marker_path)
 {
     pthread_t th[256];
     pool_arg pa;
@@ -943,28 +990,58 @@ int orc_run_batch(const spx_batch *bt, const spx_ref *ref, const spx_params *par
     int i, g, relabelled = 0, *rc = calloc(bt->n_groups > 0 ? bt->n_groups : 1, sizeof(int));
     orc_rand rng;
     FILE *log = log_path ? fopen(log_path, "w") : NULL;
+    const int want_bed = bed_modified_path || bed_marker_path;
+    blkacc *acc_mod = calloc(ref->n_contigs > 0 ? ref->n_contigs : 1, sizeof(blkacc));
+    blkacc *acc_mk = calloc(ref->n_contigs > 0 ? ref->n_contigs : 1, sizeof(blkacc));
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
+    g_keep_markers = want_bed;
     pa.bt = bt; pa.ref = ref; pa.par = par; pa.res = results; pa.rc = rc; pa.next = &next;
     if (threads == 1) pool_worker(&pa);
     else {
         for (i = 0; i < threads; ++i) pthread_create(&th[i], NULL, pool_worker, &pa);
         for (i = 0; i < threads; ++i) pthread_join(th[i], NULL);
     }
+    g_keep_markers = 0;
     orc_srand(&rng, rand_seed);
     for (g = 0; g < bt->n_groups; ++g) {
         if (rc[g] != 0) { results[g].best_idx = -1; results[g].relabel = 0; if (rc[g] < 0) results[g].n_aln = rc[g]; continue; }
         decide_group(bt, g, par, &rng, &results[g]);
         if (results[g].relabel) {
+            int amap[16];
+            group_alns(bt, g, amap);
             relabelled++;
-            if (log) {
-                int amap[16];
-                group_alns(bt, g, amap);
-                write_record(log, bt, ref, g, amap, &results[g]);
+            if (log) write_record(log, bt, ref, g, amap, &results[g]);
+            if (want_bed) { /* secphase.c:201-212 */
+                int pair[2], t, k;
+                pair[0] = results[g].prim_idx; pair[1] = results[g].best_idx;
+                for (t = 0; t < 2; ++t) {
+                    int a = pair[t], tid = bt->tid[amap[a]];
+                    acc_push(&acc_mod[tid], results[g].rfs[a], results[g].rfe[a], 1);
+                    for (k = 0; k < results[g].n_final; ++k)
+                        if (results[g].final_markers[k].alignment_idx == a)
+                            acc_push(&acc_mk[tid], results[g].final_markers[k].ref_pos, results[g].final_markers[k].ref_pos, 0);
+                }
             }
         }
+        free(results[g].final_markers);
+        results[g].final_markers = NULL;
+        results[g].n_final = 0;
     }
     if (log) fclose(log);
+    if (bed_modified_path) save_bed(ref, acc_mod, bed_modified_path, 1);
+    if (bed_marker_path) save_bed(ref, acc_mk, bed_marker_path, 0);
+    for (i = 0; i < ref->n_contigs; ++i) {
+        free(acc_mod[i].s); free(acc_mod[i].e); free(acc_mod[i].c);
+        free(acc_mk[i].s); free(acc_mk[i].e); free(acc_mk[i].c);
+    }
+    free(acc_mod); free(acc_mk);
     free(rc);
     return relabelled;
+}
+
+int orc_run_batch(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads, unsigned rand_seed,
+                  orc_group_result *results, const char *log_path)
+{
+    return orc_run_batch_bed(bt, ref, par, threads, rand_seed, results, log_path, NULL, NULL);
 }

@@ -88,6 +88,9 @@ typedef struct orc_group_result {
     int n_markers_initial, n_markers_final, n_blocks;
     int n_baq_calls;
     long long dp_cells;
+    int rfs[16];       /* ptAlignment.rfs */
+    orc_marker *final_markers; /* markers after filter_lowq_markers (only kept on request; owned) */
+    int n_final;
 } orc_group_result;
 
 /* Run the marker branch of runOneThread (secphase.c:156-219) for group g of
@@ -110,6 +113,18 @@ int orc_group_is_dispatched(const spx_batch *bt, int g);
  * groups. */
 int orc_run_batch(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads,
                   unsigned rand_seed, orc_group_result *results, const char *log_path);
+
+/* orc_run_batch + the two marker-mode BED side outputs (src/secphase.c:201-212,719-732): blocks of the old
+ * primary and of the promoted secondary of every relabelled read, merged with counts; reference positions of
+ * their surviving markers, merged without counts.  Paths may be NULL. */
+int orc_run_batch_bed(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads, unsigned rand_seed,
+                      orc_group_result *results, const char *log_path, const char *bed_modified_path,
+                      const char *bed_marker_path);
+
+/* ptBlock sort / merge (blocks_oracle.c) */
+void orc_blocks_sort(int n, int *s, int *e, int *c);
+int orc_blocks_merge(int n, const int *s, const int *e, const int *c, int *os, int *oe, int *oc);
+int orc_blocks_merge_v2(int n, const int *s, const int *e, const int *c, int *os, int *oe, int *oc);
 
 /* helpers exposed for unit tests */
 int orc_walk_cigar(const spx_batch *bt, int a, orc_op **ops_out); /* returns n states incl. state 0 */

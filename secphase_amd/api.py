@@ -74,6 +74,11 @@ EXPORTS = [
     "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_prepare_many", "spx_launch", "spx_sync", "spx_collect",
     "spx_work_stats", "spx_work_free", "spx_finalize", "spx_write_relabel_log", "spx_probaln_glocal",
     "spx_probaln_batch", "spx_pack_decisions", "spx_plan_create", "spx_plan_get", "spx_plan_free", "spx_host_tables",
+    "spx_finalizer_create", "spx_finalizer_apply", "spx_finalizer_free",
+    "spx_bedset_create", "spx_bedset_free", "spx_bedset_add", "spx_bedset_size", "spx_bedset_save",
+    "spx_merge_blocks_count", "spx_relabel_blocks",
+    "spx_io_last_error", "spx_bam_open", "spx_bam_n_targets", "spx_bam_target_name", "spx_bam_bind_reference",
+    "spx_bam_next_batch", "spx_bam_close", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
 ]
 
 _lib = None
@@ -124,6 +129,33 @@ def lib():
     L.spx_plan_free.restype = None
     L.spx_host_tables.argtypes = [_f64p, _f64p, _f64p]
     L.spx_host_tables.restype = None
+    L.spx_finalizer_create.argtypes = [C.c_uint, C.POINTER(vp)]
+    L.spx_finalizer_apply.argtypes = [vp, C.POINTER(SpxParams), C.POINTER(GroupOut), C.c_int32]
+    L.spx_finalizer_free.argtypes = [vp]
+    L.spx_finalizer_free.restype = None
+    L.spx_bedset_create.argtypes = [C.POINTER(vp)]
+    L.spx_bedset_free.argtypes = [vp]
+    L.spx_bedset_free.restype = None
+    L.spx_bedset_add.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
+    L.spx_bedset_size.argtypes = [vp]
+    L.spx_bedset_size.restype = C.c_int64
+    L.spx_bedset_save.argtypes = [vp, C.c_char_p, C.c_int]
+    L.spx_merge_blocks_count.argtypes = [C.c_int32] + [_i32p] * 6 + [C.c_int32]
+    L.spx_relabel_blocks.argtypes = [vp, C.POINTER(SpxRef), C.POINTER(GroupOut), vp, vp]
+    L.spx_io_last_error.restype = C.c_char_p
+    L.spx_bam_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.spx_bam_n_targets.argtypes = [vp]
+    L.spx_bam_target_name.argtypes = [vp, C.c_int32]
+    L.spx_bam_target_name.restype = C.c_char_p
+    L.spx_bam_bind_reference.argtypes = [vp, C.POINTER(SpxRef)]
+    L.spx_bam_next_batch.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(SpxBatch))]
+    L.spx_bam_close.argtypes = [vp]
+    L.spx_bam_close.restype = None
+    L.spx_fasta_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.spx_fasta_ref.argtypes = [vp]
+    L.spx_fasta_ref.restype = C.POINTER(SpxRef)
+    L.spx_fasta_free.argtypes = [vp]
+    L.spx_fasta_free.restype = None
     _lib = L
     return L
 

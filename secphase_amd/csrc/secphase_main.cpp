@@ -1,0 +1,218 @@
+/*
+ * secphase_main.cpp -- `secphase` command line on top of libspx (MI355X scoring path).
+ *
+ * Same options, presets, defaults and output files as the reference's main()
+ * (/root/reference/programs/src/secphase.c:387-743): -i/--inputBam, -f/--inputFasta, -o/--outDir,
+ * -P/--prefix, -x/--hifi, -y/--ont, -q -c -d -e -b -t -s -m -p -r -n, -@/--threads, --flankMargin.
+ * Marker mode only: -v/--inputVcf, -B, -g, -G (variant mode) and -w/--writeBam are refused with a message;
+ * -M (disable marker mode) leaves nothing to do.  All six output files the WDLs glob for
+ * (wdls/workflows/secphase.wdl:100-107) are created; the three variant-mode BEDs stay empty, as they do in
+ * the reference when no VCF is given.
+ *
+ * Pipeline: the reader inflates BGZF blocks in parallel and cuts the name-grouped BAM into blocks of
+ * --groupsPerBatch groups; each block is prepared on -@ host threads, scored on the GPU, finalised in file
+ * order with one rand() stream (= the reference at -@1) and appended to <prefix>.out.log.
+ */
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/spx.h"
+
+static const char *timestamp()
+{
+    static char buf[64];
+    time_t t = time(NULL);
+    struct tm *tm = localtime(&t);
+    snprintf(buf, sizeof buf, "%04d-%02d-%02d %02d:%02d:%02d", tm->tm_year + 1900, tm->tm_mon + 1, tm->tm_mday, tm->tm_hour,
+             tm->tm_min, tm->tm_sec);
+    return buf;
+}
+
+static struct option long_options[] = {{"inputBam", required_argument, NULL, 'i'},
+                                       {"inputFasta", required_argument, NULL, 'f'},
+                                       {"inputVcf", required_argument, NULL, 'v'},
+                                       {"disableMarkerMode", no_argument, NULL, 'M'},
+                                       {"baq", no_argument, NULL, 'q'},
+                                       {"gapOpen", required_argument, NULL, 'd'},
+                                       {"gapExt", required_argument, NULL, 'e'},
+                                       {"bandwidth", required_argument, NULL, 'b'},
+                                       {"consensus", no_argument, NULL, 'c'},
+                                       {"indelThreshold", required_argument, NULL, 't'},
+                                       {"initQ", required_argument, NULL, 's'},
+                                       {"minQ", required_argument, NULL, 'm'},
+                                       {"primMarginScore", required_argument, NULL, 'p'},
+                                       {"primMarginRandom", required_argument, NULL, 'r'},
+                                       {"minScore", required_argument, NULL, 'n'},
+                                       {"hifi", no_argument, NULL, 'x'},
+                                       {"ont", no_argument, NULL, 'y'},
+                                       {"minVariantMargin", required_argument, NULL, 'g'},
+                                       {"prefix", required_argument, NULL, 'P'},
+                                       {"outDir", required_argument, NULL, 'o'},
+                                       {"variantBed", required_argument, NULL, 'B'},
+                                       {"minGQ", required_argument, NULL, 'G'},
+                                       {"threads", required_argument, NULL, '@'},
+                                       {"writeBam", no_argument, NULL, 'w'},
+                                       {"flankMargin", required_argument, NULL, 'F'},
+                                       {"groupsPerBatch", required_argument, NULL, 1001},
+                                       {"device", required_argument, NULL, 1002},
+                                       {NULL, 0, NULL, 0}};
+
+static void usage(const char *prog)
+{
+    fprintf(stderr, "\nUsage: %s  -i <INPUT_BAM> -f <FASTA> \n", prog);
+    fprintf(stderr,
+            "Options (as in secphase; marker mode only):\n"
+            "         --inputBam, -i         Input BAM file (grouped by read name, cs tag present)\n"
+            "         --inputFasta, -f       Input FASTA file\n"
+            "         --outDir, -o           Output dir [secphase_out_dir]\n"
+            "         --prefix, -P           Prefix of the output files [secphase]\n"
+            "         --hifi, -x             [-q -c -t10 -d 1e-4 -e 0.1 -b20 -m10 -s40 -p40 -r0 -n -10]\n"
+            "         --ont, -y              [-q -c -t20 -d 1e-3 -e 0.1 -b20 -m10 -s20 -p20 -r0 -n -10]\n"
+            "         --baq -q, --gapOpen -d, --gapExt -e, --bandwidth -b, --consensus -c, --indelThreshold -t,\n"
+            "         --initQ -s, --minQ -m, --primMarginScore -p, --primMarginRandom -r, --minScore -n, --flankMargin\n"
+            "         --threads, -@          host threads for BGZF inflation and group preparation [4]\n"
+            "         --groupsPerBatch       read groups per GPU work list [16384]\n"
+            "         --device               GPU index [0]\n"
+            "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode), --writeBam/-w\n");
+}
+
+int main(int argc, char *argv[])
+{
+    /* defaults: src/secphase.c:420-449 */
+    spx_params par;
+    memset(&par, 0, sizeof par);
+    par.baq_flag = 0; par.consensus = 0; par.indel_threshold = 10; par.min_q = 10; par.min_score = -10;
+    par.prim_margin_score = 40; par.prim_margin_random = 0; par.set_q = 40; par.conf_d = 1e-4; par.conf_e = 0.1;
+    par.conf_b = 20; par.flank_margin = 500;
+    std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
+    bool preset_ont = false, preset_hifi = false, marker_mode = true;
+    int threads = 4, groups_per_batch = 16384, device = 0, c;
+    const char *prog = strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0];
+    while (~(c = getopt_long(argc, argv, "i:p:P:G:o:f:v:qd:e:b:n:r:m:ct:s:B:g:@:wxyMh", long_options, NULL))) {
+        switch (c) {
+        case 'i': inputPath = optarg; break;
+        case 'f': fastaPath = optarg; break;
+        case '@': threads = atoi(optarg); break;
+        case 'P': prefix = optarg; break;
+        case 'o': dirPath = optarg; break;
+        case 'x': /* src/secphase.c:477-490 */
+            preset_hifi = true;
+            par.baq_flag = 1; par.consensus = 1; par.indel_threshold = 10; par.conf_d = 1e-4; par.conf_e = 0.1; par.conf_b = 20;
+            par.min_q = 10; par.set_q = 40; par.prim_margin_score = 40; par.prim_margin_random = 0; par.min_score = -10;
+            break;
+        case 'y': /* src/secphase.c:491-504 */
+            preset_ont = true;
+            par.baq_flag = 1; par.consensus = 1; par.indel_threshold = 20; par.conf_d = 1e-3; par.conf_e = 0.1; par.conf_b = 20;
+            par.min_q = 10; par.set_q = 20; par.prim_margin_score = 20; par.prim_margin_random = 0; par.min_score = -10;
+            break;
+        case 'q': par.baq_flag = 1; break;
+        case 'd': par.conf_d = atof(optarg); break;
+        case 'e': par.conf_e = atof(optarg); break;
+        case 'b': par.conf_b = atof(optarg); break;
+        case 'c': par.consensus = 1; break;
+        case 't': par.indel_threshold = atoi(optarg); break;
+        case 's': par.set_q = atoi(optarg); break;
+        case 'm': par.min_q = atoi(optarg); break;
+        case 'p': par.prim_margin_score = atof(optarg); break;
+        case 'r': par.prim_margin_random = atof(optarg); break;
+        case 'n': par.min_score = atoi(optarg); break;
+        case 'F': par.flank_margin = atoi(optarg); break;
+        case 'M': marker_mode = false; break;
+        case 1001: groups_per_batch = atoi(optarg); break;
+        case 1002: device = atoi(optarg); break;
+        case 'v': case 'B': case 'g': case 'G':
+            fprintf(stderr, "[%s] variant mode (-v/-B/-g/-G) is not part of this build: marker mode only\n", timestamp());
+            return 2;
+        case 'w':
+            fprintf(stderr, "[%s] --writeBam is not part of this build\n", timestamp());
+            return 2;
+        default:
+            if (c != 'h') fprintf(stderr, "[E::%s] undefined option %c\n", __func__, c);
+            usage(prog);
+            return 1;
+        }
+    }
+    if (inputPath.empty() || fastaPath.empty()) { usage(prog); return 1; }
+    if (preset_ont && preset_hifi) {
+        fprintf(stderr, "[%s] Presets --hifi and --ont cannot be enabled at the same time. Select only one of them!\n", timestamp());
+        return EXIT_FAILURE;
+    }
+    if (groups_per_batch < 1) groups_per_batch = 1;
+    struct stat st;
+    if (stat(dirPath.c_str(), &st) == -1) mkdir(dirPath.c_str(), 0777);
+    auto out_path = [&](const char *suffix) { return dirPath + "/" + prefix + suffix; };
+
+    /* files that only variant mode fills: created empty (src/secphase.c:619-630,715-727) */
+    for (const char *sfx : {".initial_variant_blocks.bed", ".modified_read_blocks.variants.bed", ".variant_blocks.bed"}) {
+        FILE *f = fopen(out_path(sfx).c_str(), "w");
+        if (f) fclose(f);
+    }
+    const std::string log_path = out_path(".out.log");
+    { FILE *f = fopen(log_path.c_str(), "w"); if (!f) { fprintf(stderr, "cannot write %s\n", log_path.c_str()); return 1; } fclose(f); }
+
+    spx_fasta *fa = nullptr;
+    if (spx_fasta_load(fastaPath.c_str(), &fa) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); return 1; }
+    const spx_ref *ref = spx_fasta_ref(fa);
+    spx_bam_reader *bam = nullptr;
+    if (spx_bam_open(inputPath.c_str(), threads, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); return 1; }
+    int missing = spx_bam_bind_reference(bam, ref);
+    if (missing > 0) fprintf(stderr, "[%s] warning: %d BAM target(s) are not in the FASTA; reads on them are skipped\n", timestamp(), missing);
+
+    spx_ctx *ctx = nullptr;
+    int rc = spx_create(device, &ctx);
+    if (rc != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
+    if ((rc = spx_set_reference(ctx, ref)) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
+
+    spx_finalizer *fin = nullptr;
+    spx_finalizer_create(1, &fin); /* unseeded rand() == srand(1) */
+    spx_bedset *bed_mod = nullptr, *bed_mk = nullptr;
+    spx_bedset_create(&bed_mod);
+    spx_bedset_create(&bed_mk);
+
+    fprintf(stderr, "[%s] Started parsing alignments\n", timestamp());
+    long long n_alns = 0, n_reads = 0, n_modified = 0, n_rejected = 0;
+    std::vector<spx_group_out> out;
+    for (;;) {
+        const spx_batch *bt = nullptr;
+        int ng = spx_bam_next_batch(bam, groups_per_batch, &bt);
+        if (ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), spx_io_last_error()); return 1; }
+        if (ng == 0) break;
+        n_alns += bt->n_alns;
+        n_reads += ng;
+        if (marker_mode) {
+            spx_work *w = nullptr;
+            if ((rc = spx_prepare(ctx, bt, &par, threads, &w)) != SPX_OK || (rc = spx_launch(ctx, w)) != SPX_OK) {
+                fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
+                return 1;
+            }
+            out.resize(ng);
+            if ((rc = spx_collect(ctx, w, out.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
+            spx_finalizer_apply(fin, &par, out.data(), ng);
+            spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
+            n_modified += spx_relabel_blocks(w, ref, out.data(), bed_mod, bed_mk);
+            for (int g = 0; g < ng; ++g) if (out[g].n_aln < 0) ++n_rejected;
+            spx_work_free(ctx, w);
+        }
+        fprintf(stderr, "[%s] #parsed alignments = %lld, #parsed reads = %lld, #modifed by phased variants = 0, #modifed by markers = %lld\n",
+                timestamp(), n_alns, n_reads, n_modified);
+    }
+    if (n_rejected) fprintf(stderr, "[%s] %lld read group(s) use constructs the reference leaves undefined and were skipped\n", timestamp(), n_rejected);
+    fprintf(stderr, "[%s] Number of reads modified by phased variants = 0\n", timestamp());
+    fprintf(stderr, "[%s] Number of reads modified by marker score = %lld\n", timestamp(), n_modified);
+    spx_bedset_save(bed_mod, out_path(".modified_read_blocks.markers.bed").c_str(), 1);
+    spx_bedset_save(bed_mk, out_path(".marker_blocks.bed").c_str(), 0);
+    spx_bedset_free(bed_mod);
+    spx_bedset_free(bed_mk);
+    spx_finalizer_free(fin);
+    spx_bam_close(bam);
+    spx_destroy(ctx);
+    spx_fasta_free(fa);
+    return 0;
+}

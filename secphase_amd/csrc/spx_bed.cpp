@@ -1,0 +1,117 @@
+/*
+ * spx_bed.cpp -- BED side outputs of secphase.
+ *
+ *   <prefix>.modified_read_blocks.markers.bed   reference extents of the old primary and of the promoted
+ *        secondary of every relabelled read, merged per contig into disjoint segments carrying the number
+ *        of alignments covering them (src/secphase.c:201-203 ptBlock_add_alignment(..., true);
+ *        :719-721 merge_and_save_blocks(..., true))
+ *   <prefix>.marker_blocks.bed                  reference positions of the surviving markers of those two
+ *        alignments (src/secphase.c:205-212, submodules/ptMarker/ptMarker.c:844-865), merged without counts
+ *
+ * merge = ptBlock_merge_blocks_v2 (submodules/ptBlock/ptBlock.c:274-428) on blocks sorted by start
+ * (:228-236): the union of the blocks cut at every block start and at every (block end + 1), each piece
+ * carrying the summed count of the blocks covering it; pieces are NOT re-joined.  Here as a sweep over the
+ * sorted break points instead of the reference's list rewriting; tests/test_blocks.py checks it against the
+ * oracle's restatement and against the reference's own known-answer vectors.
+ * Writer = ptBlock_save_in_bed (:573-602): contigs in strcmp order, "ctg\tstart\tend+1[\tcount]".
+ */
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/spx.h"
+
+struct Blk3 { int32_t s, e, c; };
+
+/* coverage segmentation of blocks (any order); has_count=0: c ignored, output c = 0 */
+static void merge_count(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &out)
+{
+    out.clear();
+    if (v.empty()) return;
+    std::sort(v.begin(), v.end(), [](const Blk3 &a, const Blk3 &b) { return a.s != b.s ? a.s < b.s : a.e < b.e; });
+    /* break points: every start, every end+1 */
+    std::vector<int64_t> bp;
+    bp.reserve(v.size() * 2);
+    for (const Blk3 &b : v) {
+        if (b.e < b.s) continue; /* empty blocks take no part in the reference's loop either way */
+        bp.push_back(b.s);
+        bp.push_back((int64_t)b.e + 1);
+    }
+    std::sort(bp.begin(), bp.end());
+    bp.erase(std::unique(bp.begin(), bp.end()), bp.end());
+    /* coverage difference array over the break points */
+    std::vector<int64_t> dc(bp.size() + 1, 0), dn(bp.size() + 1, 0);
+    for (const Blk3 &b : v) {
+        if (b.e < b.s) continue;
+        size_t i0 = std::lower_bound(bp.begin(), bp.end(), (int64_t)b.s) - bp.begin();
+        size_t i1 = std::lower_bound(bp.begin(), bp.end(), (int64_t)b.e + 1) - bp.begin();
+        dc[i0] += b.c; dc[i1] -= b.c;
+        dn[i0] += 1; dn[i1] -= 1;
+    }
+    int64_t cov = 0, cnt = 0;
+    for (size_t i = 0; i + 1 < bp.size(); ++i) {
+        cov += dn[i];
+        cnt += dc[i];
+        if (cov > 0) out.push_back({(int32_t)bp[i], (int32_t)(bp[i + 1] - 1), has_count ? (int32_t)cnt : 0});
+    }
+}
+
+extern "C" int spx_merge_blocks_count(int32_t n, const int32_t *s, const int32_t *e, const int32_t *c, int32_t *os,
+                                      int32_t *oe, int32_t *oc, int32_t cap)
+{
+    if (n < 0 || !s || !e || !os || !oe) return SPX_EINVAL;
+    std::vector<Blk3> v(n), out;
+    for (int32_t i = 0; i < n; ++i) v[i] = {s[i], e[i], c ? c[i] : 0};
+    merge_count(v, c != nullptr, out);
+    if ((int32_t)out.size() > cap) return SPX_EINVAL;
+    for (size_t i = 0; i < out.size(); ++i) { os[i] = out[i].s; oe[i] = out[i].e; if (oc) oc[i] = out[i].c; }
+    return (int32_t)out.size();
+}
+
+struct spx_bedset {
+    std::map<std::string, std::vector<Blk3>> per_contig; /* std::map iterates in strcmp order for plain ASCII names */
+};
+
+extern "C" int spx_bedset_create(spx_bedset **out)
+{
+    if (!out) return SPX_EINVAL;
+    *out = new spx_bedset();
+    return SPX_OK;
+}
+extern "C" void spx_bedset_free(spx_bedset *b) { delete b; }
+extern "C" int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, int32_t end, int32_t count)
+{
+    if (!b || !contig) return SPX_EINVAL;
+    b->per_contig[contig].push_back({start, end, count});
+    return SPX_OK;
+}
+extern "C" int64_t spx_bedset_size(const spx_bedset *b)
+{
+    int64_t n = 0;
+    if (b) for (const auto &kv : b->per_contig) n += (int64_t)kv.second.size();
+    return n;
+}
+
+/* merge_and_save_blocks (src/secphase.c:59-72): merge per contig, write the BED.  The file is created even
+ * when there is nothing to write (the WDLs glob for it, wdls/workflows/secphase.wdl:100-107). */
+extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_count)
+{
+    if (!b || !path) return SPX_EINVAL;
+    FILE *fp = fopen(path, "w");
+    if (!fp) return SPX_EINVAL;
+    std::vector<Blk3> merged;
+    for (const auto &kv : b->per_contig) {
+        merge_count(kv.second, print_count != 0, merged);
+        for (const Blk3 &m : merged) {
+            if (m.e < m.s) continue;
+            if (print_count) fprintf(fp, "%s\t%d\t%d\t%d\n", kv.first.c_str(), m.s, m.e + 1, m.c);
+            else fprintf(fp, "%s\t%d\t%d\n", kv.first.c_str(), m.s, m.e + 1);
+        }
+    }
+    fclose(fp);
+    return SPX_OK;
+}

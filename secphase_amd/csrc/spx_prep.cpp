@@ -46,6 +46,7 @@ void HostBatch::clear()
     hmm.clear(); rows.clear(); row_expect.clear(); row_rawq.clear(); qry4.clear(); qry_nibbles = 0;
     grp_index.clear(); mk_first.clear(); markers.clear(); n_aln.clear(); sec_mask.clear(); rfe.clear();
     grp_problems.clear(); grp_cells.clear(); grp_error.clear(); dp_cells = 0;
+    rfs.clear(); atid.clear(); mk_ref_pos.clear();
 }
 
 template <class T>
@@ -72,6 +73,7 @@ void HostBatch::append(const HostBatch &o)
         markers.push_back(m);
     }
     cat(n_aln, o.n_aln); cat(sec_mask, o.sec_mask); cat(rfe, o.rfe); cat(grp_problems, o.grp_problems);
+    cat(rfs, o.rfs); cat(atid, o.atid); cat(mk_ref_pos, o.mk_ref_pos);
     cat(grp_cells, o.grp_cells);
     dp_cells += o.dp_cells;
 }
@@ -185,6 +187,7 @@ struct Mk {
     int32_t q;
     int32_t is_match;
     int32_t row;  /* wanted-row index (batch global) or -1 */
+    int32_t ref_pos; /* ptMarker.ref_pos: set for mismatches at creation, for matches inside an '=' op */
 };
 
 struct Aln {
@@ -337,7 +340,7 @@ static inline bool mk_less(const Mk &x, const Mk &y) { return x.pos != y.pos ? x
 static Mk match_marker(const Aln &a, int ai, int pos)
 {
     Mk m;
-    m.pos = pos; m.aln = ai; m.is_match = 1; m.row = -1;
+    m.pos = pos; m.aln = ai; m.is_match = 1; m.row = -1; m.ref_pos = -1;
     m.base_idx = a.rev ? a.l_qseq + a.rclip - pos - 1 : pos - a.lclip;
     m.q = (m.base_idx >= 0 && m.base_idx < a.l_qseq) ? a.qual[m.base_idx] : 0;
     return m;
@@ -358,7 +361,7 @@ static void collect_markers(std::vector<Aln> &al, int min_q, std::vector<Mk> &mk
                 if (q < min_q) continue;
                 Mk m;
                 m.aln = i; m.base_idx = o.sqs + j; m.pos = a.rev ? o.rde - j : o.rds + j;
-                m.q = q; m.is_match = 0; m.row = -1;
+                m.q = q; m.is_match = 0; m.row = -1; m.ref_pos = o.rfs + j;
                 mk.push_back(m);
             }
         }
@@ -393,6 +396,8 @@ static void collect_markers(std::vector<Aln> &al, int min_q, std::vector<Mk> &mk
                 const int p = mk[(size_t)col * n].pos;
                 if (!(o.rds <= p && p <= o.rde)) break;
                 if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) keep[col] = 0;
+                if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
+                    mk[(size_t)col * n + i].ref_pos = a.rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
                 col += step;
             }
         }
@@ -753,12 +758,17 @@ static int prepare_one(const spx_batch *bt, const RefIndex &ref, const spx_param
             dm.aln = (uint8_t)m.aln;
             dm.first_of_pos = (k == 0 || S.mk[k - 1].pos != m.pos) ? (uint8_t)n : 0;
             out.markers.push_back(dm);
+            out.mk_ref_pos.push_back(m.ref_pos);
         }
     }
     out.mk_first.push_back((int32_t)out.markers.size());
     out.n_aln.push_back((uint8_t)n);
     out.sec_mask.push_back(sec);
-    for (int i = 0; i < 10; ++i) out.rfe.push_back(i < n ? S.al[i].rfe : 0);
+    for (int i = 0; i < 10; ++i) {
+        out.rfe.push_back(i < n ? S.al[i].rfe : 0);
+        out.rfs.push_back(i < n ? S.al[i].rfs : 0);
+        out.atid.push_back(i < n ? S.al[i].tid : -1);
+    }
     out.grp_problems.push_back(n_prob);
     out.grp_cells.push_back(cells);
     out.dp_cells += cells;

@@ -32,6 +32,8 @@ struct HostBatch {
     std::vector<uint8_t> n_aln;
     std::vector<uint16_t> sec_mask;
     std::vector<int32_t> rfe;       /* 10 per dispatched group */
+    std::vector<int32_t> rfs, atid; /* 10 per dispatched group: ptAlignment.rfs, contig index */
+    std::vector<int32_t> mk_ref_pos; /* per marker: reference position (BED side outputs) */
     std::vector<int32_t> grp_problems;
     std::vector<int64_t> grp_cells;
     std::vector<int32_t> grp_error; /* per input group: 0 or SPX_E* */

@@ -26,6 +26,8 @@
 #include "spx_device.h"
 #include "spx_prep.h"
 
+struct spx_bedset;
+
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st);
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st);
@@ -98,6 +100,7 @@ struct spx_work {
     spx_stats st;
     spx_params par;
     bool launched = false;
+    std::vector<uint8_t> posmin_host; /* filled by spx_collect: per first-of-position marker, min quality */
 };
 
 extern "C" const char *spx_strerror(int code)
@@ -514,6 +517,9 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         HIPCHK(hipMemcpy(mx.data(), w->d_max, ng, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(pass.data(), w->d_pass, ng, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tie.data(), w->d_tie, ng * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        w->posmin_host.resize(w->hb.markers.size());
+        if (!w->posmin_host.empty())
+            HIPCHK(hipMemcpy(w->posmin_host.data(), w->d_posmin, w->posmin_host.size(), hipMemcpyDeviceToHost));
     }
     w->st.d2h_seconds = now_s() - t0;
     w->st.bytes_d2h = (int64_t)(ng * (80 + 5));
@@ -568,14 +574,28 @@ extern "C" int spx_score_batch(spx_ctx *c, const spx_batch *bt, const spx_params
 
 /* ------------------------------------------------------------------ */
 /* get_best_record_index's rand()-dependent tail (ptAlignment.c:163-176), replayed in file order.
- * random_r with a private state is glibc's rand() algorithm without the process-global state. */
-extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups)
-{
-    if (!par || !out) return fail(SPX_EINVAL, "NULL argument");
+ * random_r with a private state is glibc's rand() algorithm without the process-global state; a finalizer
+ * keeps that state across batches so that a whole run consumes ONE stream, like the reference at -@1. */
+struct spx_finalizer {
     struct random_data rd;
     char statebuf[128];
-    memset(&rd, 0, sizeof rd);
-    initstate_r(rand_seed, statebuf, sizeof statebuf, &rd);
+};
+
+extern "C" int spx_finalizer_create(unsigned rand_seed, spx_finalizer **out)
+{
+    if (!out) return fail(SPX_EINVAL, "NULL argument");
+    spx_finalizer *f = new spx_finalizer();
+    memset(&f->rd, 0, sizeof f->rd);
+    memset(f->statebuf, 0, sizeof f->statebuf);
+    initstate_r(rand_seed, f->statebuf, sizeof f->statebuf, &f->rd);
+    *out = f;
+    return SPX_OK;
+}
+extern "C" void spx_finalizer_free(spx_finalizer *f) { delete f; }
+
+extern "C" int spx_finalizer_apply(spx_finalizer *f, const spx_params *par, spx_group_out *out, int32_t n_groups)
+{
+    if (!f || !par || !out) return fail(SPX_EINVAL, "NULL argument");
     for (int32_t g = 0; g < n_groups; ++g) {
         spx_group_out &o = out[g];
         o.best_idx = -1;
@@ -585,8 +605,8 @@ extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group
         for (int a = 0; a < o.n_aln; ++a)
             if ((o.tie_mask >> a) & 1) tied[cnt++] = a;
         int32_t r;
-        if (cnt > 1) { random_r(&rd, &r); max_idx = tied[r % cnt]; }
-        random_r(&rd, &r);
+        if (cnt > 1) { random_r(&f->rd, &r); max_idx = tied[r % cnt]; }
+        random_r(&f->rd, &r);
         const int rnd = r % 2;
         const double max_score = o.max_idx >= 0 ? o.score[o.max_idx] : -DBL_MAX;
         const double prim_score = o.prim_idx >= 0 ? o.score[o.prim_idx] : -DBL_MAX;
@@ -600,6 +620,48 @@ extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group
         o.relabel = (best >= 0 && best != o.prim_idx) ? 1 : 0;
     }
     return SPX_OK;
+}
+
+extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups)
+{
+    spx_finalizer *f = nullptr;
+    int rc = spx_finalizer_create(rand_seed, &f);
+    if (rc) return rc;
+    rc = spx_finalizer_apply(f, par, out, n_groups);
+    spx_finalizer_free(f);
+    return rc;
+}
+
+/* BED bookkeeping of relabelled reads (src/secphase.c:201-212): extents of the old primary and of the promoted
+ * secondary (count 1 each), and the reference positions of their surviving markers */
+extern "C" int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, int32_t end, int32_t count);
+extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const spx_group_out *out,
+                                  spx_bedset *modified_blocks, spx_bedset *marker_blocks)
+{
+    if (!w || !ref || !out) return fail(SPX_EINVAL, "NULL argument");
+    const spx::HostBatch &hb = w->hb;
+    if (marker_blocks && w->posmin_host.size() != hb.markers.size()) return fail(SPX_EINVAL, "spx_collect has not run");
+    int n = 0;
+    for (size_t k = 0; k < hb.grp_index.size(); ++k) {
+        const spx_group_out &o = out[hb.grp_index[k]];
+        if (!o.relabel) continue;
+        ++n;
+        const int pair[2] = {o.prim_idx, o.best_idx};
+        for (int t = 0; t < 2; ++t) {
+            const int a = pair[t];
+            const int32_t tid = hb.atid[k * 10 + a];
+            const char *contig = ref->names + ref->name_off[tid];
+            if (modified_blocks) spx_bedset_add(modified_blocks, contig, hb.rfs[k * 10 + a], hb.rfe[k * 10 + a], 1);
+            if (!marker_blocks) continue;
+            const int na = hb.n_aln[k];
+            for (int32_t m = hb.mk_first[k]; m < hb.mk_first[k + 1]; m += na) {
+                if (w->posmin_host[m] <= w->par.min_q) continue; /* position removed by filter_lowq_markers */
+                const int32_t rp = hb.mk_ref_pos[m + a];
+                spx_bedset_add(marker_blocks, contig, rp, rp, 0);
+            }
+        }
+    }
+    return n;
 }
 
 extern "C" int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *bt, const spx_ref *ref,

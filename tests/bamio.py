@@ -1,0 +1,78 @@
+"""Test-side BAM / FASTA writers (pure Python + zlib): turn a flat record batch into the files the
+command-line program reads.  BGZF blocks of <= 60 KB, standard EOF marker."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_block(data):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+    return hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def write_bgzf(path, payload, block=60000):
+    with open(path, "wb") as f:
+        for o in range(0, len(payload), block):
+            f.write(_bgzf_block(payload[o:o + block]))
+        f.write(_EOF)
+
+
+def _cstr(base, off):
+    return C.string_at(base + off)
+
+
+def contigs_of(ref):
+    r = ref.contents
+    out = []
+    for i in range(r.n_contigs):
+        name = _cstr(r.names, r.name_off[i]).decode()
+        seq = C.string_at(r.bases + r.seq_off[i], r.seq_off[i + 1] - r.seq_off[i]).decode()
+        out.append((name, seq))
+    return out
+
+
+def write_fasta(path, ref, width=80):
+    with open(path, "w") as f:
+        for name, seq in contigs_of(ref):
+            f.write(f">{name} synthetic\n")
+            for o in range(0, len(seq), width):
+                f.write(seq[o:o + width] + "\n")
+
+
+def write_bam(path, batch, ref, contig_order=None, extra_tags=True):
+    """contig_order: permutation of contig indices for the BAM header (default identity)"""
+    b = batch.contents
+    r = ref.contents
+    names = [(_cstr(r.names, r.name_off[i]), r.seq_off[i + 1] - r.seq_off[i]) for i in range(r.n_contigs)]
+    order = list(contig_order) if contig_order is not None else list(range(r.n_contigs))
+    tid_of = {c: i for i, c in enumerate(order)}
+    text = b"@HD\tVN:1.6\tSO:queryname\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (names[c][0], names[c][1]) for c in order)
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(order)))
+    for c in order:
+        nm = names[c][0] + b"\0"
+        out += struct.pack("<i", len(nm)) + nm + struct.pack("<i", names[c][1])
+    for g in range(b.n_groups):
+        qn = _cstr(b.qnames, b.qname_off[g]) + b"\0"
+        for a in range(b.grp_first[g], b.grp_first[g + 1]):
+            lq, nc = b.l_qseq[a], b.n_cigar[a]
+            cig = bytes(np.ctypeslib.as_array(b.cigar, shape=(b.cigar_off[a] + nc,))[b.cigar_off[a]:].astype("<u4").tobytes())
+            seq = C.string_at(C.addressof(b.seq4.contents) + b.seq_off[a], (lq + 1) // 2)
+            qual = C.string_at(C.addressof(b.qual.contents) + b.qual_off[a], lq)
+            aux = b""
+            if extra_tags:
+                aux += b"NMi" + struct.pack("<i", 3) + b"tpAP"
+            if b.cs_off[a] >= 0:
+                aux += b"csZ" + _cstr(b.cs, b.cs_off[a]) + b"\0"
+            if extra_tags:
+                aux += b"zzBs" + struct.pack("<ihh", 2, -1, 7)
+            core = struct.pack("<iiBBHHHiiii", tid_of[b.tid[a]], b.pos[a], len(qn), 60, 4680, nc, b.flag[a], lq, -1, -1, 0)
+            rec = core + qn + cig + seq + qual + aux
+            out += struct.pack("<i", len(rec)) + rec
+    write_bgzf(path, bytes(out))

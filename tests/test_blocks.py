@@ -1,0 +1,83 @@
+"""CPU: ptBlock sort/merge (BED side outputs).  The reference's own known-answer vectors
+(tests/golden/ptblock_kats.json, from programs/src/secphase_test.c:30-231) pin BOTH the oracle's literal
+restatement and the product's sweep-line implementation; random inputs cross-check the two."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from oracle import orc
+from secphase_amd import api
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ptblock_kats.json")))
+
+
+def _arr(x):
+    return (C.c_int * max(len(x), 1))(*x)
+
+
+def oracle_merge_v2(blocks, counts):
+    L = orc.lib()
+    n = len(blocks)
+    s, e = _arr([b[0] for b in blocks]), _arr([b[1] for b in blocks])
+    c = _arr(counts) if counts is not None else None
+    L.orc_blocks_sort(n, s, e, c)
+    os_, oe, oc = (C.c_int * (2 * n + 2))(), (C.c_int * (2 * n + 2))(), (C.c_int * (2 * n + 2))()
+    m = L.orc_blocks_merge_v2(n, s, e, c, os_, oe, oc if counts is not None else None)
+    return [[os_[i], oe[i], oc[i] if counts is not None else 0] for i in range(m)]
+
+
+def product_merge(blocks, counts):
+    n = len(blocks)
+    i32 = lambda x: np.ascontiguousarray(np.array(x, np.int32))
+    s, e = i32([b[0] for b in blocks]), i32([b[1] for b in blocks])
+    c = i32(counts) if counts is not None else None
+    cap = 2 * n + 2
+    os_, oe, oc = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+    L = api.lib()
+    L.spx_merge_blocks_count.argtypes = [C.c_int32] + [C.POINTER(C.c_int32)] * 6 + [C.c_int32]
+    m = L.spx_merge_blocks_count(n, p(s), p(e), p(c), p(os_), p(oe), p(oc), cap)
+    assert m >= 0
+    return [[int(os_[i]), int(oe[i]), int(oc[i])] for i in range(m)]
+
+
+def test_reference_kats_sort(built):
+    L = orc.lib()
+    for v in KATS["sort_by_rfs"]:
+        b = v["blocks"]
+        s, e = _arr([x[0] for x in b]), _arr([x[1] for x in b])
+        L.orc_blocks_sort(len(b), s, e, None)
+        assert list(s)[:len(b)] == v["sorted_starts"]
+
+
+def test_reference_kats_merge_v1(built):
+    L = orc.lib()
+    for v in KATS["merge_v1"]:
+        b = v["blocks"]
+        n = len(b)
+        s, e = _arr([x[0] for x in b]), _arr([x[1] for x in b])
+        L.orc_blocks_sort(n, s, e, None)
+        os_, oe = (C.c_int * (n + 1))(), (C.c_int * (n + 1))()
+        m = L.orc_blocks_merge(n, s, e, None, os_, oe, None)
+        assert [[os_[i], oe[i]] for i in range(m)] == v["merged"]
+
+
+def test_reference_kats_merge_v2_with_count(built):
+    for v in KATS["merge_v2_count"]:
+        ones = [1] * len(v["blocks"])
+        assert oracle_merge_v2(v["blocks"], ones) == v["merged"]
+        assert product_merge(v["blocks"], ones) == v["merged"]
+
+
+def test_product_merge_equals_oracle_on_random_blocks(built):
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        n = int(rng.integers(1, 40))
+        starts = rng.integers(0, 200, n)
+        lens = rng.integers(0, 60, n)
+        blocks = [[int(s), int(s + l)] for s, l in zip(starts, lens)]
+        counts = [int(c) for c in rng.integers(1, 4, n)]
+        assert product_merge(blocks, counts) == oracle_merge_v2(blocks, counts), blocks
+        assert product_merge(blocks, None) == oracle_merge_v2(blocks, None), blocks

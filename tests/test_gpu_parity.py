@@ -146,3 +146,29 @@ def test_batch_edge_cases(ctx, tmp_path):
 
 def test_no_cpu_fallback():
     assert api.lib().spx_device_count() >= 1
+
+
+def test_command_line_drop_in(ctx, tmp_path):
+    """secphase --hifi -i X.bam -f asm.fa -o DIR -P P : relabel list and both marker-mode BEDs byte-identical to
+    the oracle's, all six output files present, several GPU batches sharing one rand() stream."""
+    import subprocess
+    from bamio import write_bam, write_fasta
+    g = small_genome(synth.HIFI, max_secondaries=4, n_paralogs=3, hardclip_frac=0.2, softclip_frac=0.3)
+    r = g.reads(0, 150)
+    fa, bam, outd = str(tmp_path / "asm.fa"), str(tmp_path / "reads.bam"), str(tmp_path / "out")
+    write_fasta(fa, g.ref)
+    write_bam(bam, r.batch, g.ref)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "secphase_amd", "bin", "secphase")
+    p = subprocess.run([exe, "--hifi", "-@", "4", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t",
+                        "--groupsPerBatch", "64"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    log_o, bm_o, bk_o = (str(tmp_path / n) for n in ("o.log", "o.mod.bed", "o.mk.bed"))
+    nre, res = orc.run_batch(r.batch, g.ref, records.preset("hifi"), threads=2, seed=1, log_path=log_o,
+                             bed_modified=bm_o, bed_markers=bk_o)
+    assert nre > 5
+    assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False)
+    assert filecmp.cmp(bm_o, os.path.join(outd, "t.modified_read_blocks.markers.bed"), shallow=False)
+    assert filecmp.cmp(bk_o, os.path.join(outd, "t.marker_blocks.bed"), shallow=False)
+    for sfx in ("initial_variant_blocks.bed", "modified_read_blocks.variants.bed", "variant_blocks.bed"):
+        assert os.path.getsize(os.path.join(outd, "t." + sfx)) == 0
+    assert f"Number of reads modified by marker score = {nre}" in p.stderr
