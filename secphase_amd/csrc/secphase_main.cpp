@@ -20,10 +20,16 @@
 #include <sys/stat.h>
 #include <time.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
 #include "../../include/spx.h"
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static const char *timestamp()
 {
@@ -178,31 +184,43 @@ int main(int argc, char *argv[])
 
     fprintf(stderr, "[%s] Started parsing alignments\n", timestamp());
     long long n_alns = 0, n_reads = 0, n_modified = 0, n_rejected = 0;
+    double t_read = 0, t_prep = 0, t_gpu = 0, t_out = 0, t_start = now_s(), t_hostprep = 0, t_h2d = 0, t_kernel = 0;
     std::vector<spx_group_out> out;
     for (;;) {
         const spx_batch *bt = nullptr;
+        double t0 = now_s();
         int ng = spx_bam_next_batch(bam, groups_per_batch, &bt);
+        t_read += now_s() - t0;
         if (ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), spx_io_last_error()); return 1; }
         if (ng == 0) break;
         n_alns += bt->n_alns;
         n_reads += ng;
         if (marker_mode) {
             spx_work *w = nullptr;
+            t0 = now_s();
             if ((rc = spx_prepare(ctx, bt, &par, threads, &w)) != SPX_OK || (rc = spx_launch(ctx, w)) != SPX_OK) {
                 fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
                 return 1;
             }
+            t_prep += now_s() - t0;
+            t0 = now_s();
             out.resize(ng);
             if ((rc = spx_collect(ctx, w, out.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
+            t_gpu += now_s() - t0;
+            { spx_stats st; spx_work_stats(w, &st); t_hostprep += st.prep_seconds; t_h2d += st.h2d_seconds; t_kernel += st.kernel_seconds; }
+            t0 = now_s();
             spx_finalizer_apply(fin, &par, out.data(), ng);
             spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
             n_modified += spx_relabel_blocks(w, ref, out.data(), bed_mod, bed_mk);
             for (int g = 0; g < ng; ++g) if (out[g].n_aln < 0) ++n_rejected;
             spx_work_free(ctx, w);
+            t_out += now_s() - t0;
         }
         fprintf(stderr, "[%s] #parsed alignments = %lld, #parsed reads = %lld, #modifed by phased variants = 0, #modifed by markers = %lld\n",
                 timestamp(), n_alns, n_reads, n_modified);
     }
+    fprintf(stderr, "[%s] time in the scoring loop: %.3f s (BAM read+inflate %.3f, prepare+upload %.3f, wait for GPU+download %.3f, "
+                    "finalise+write %.3f); inside prepare: host logic %.3f, upload %.3f; GPU kernels %.3f\n", timestamp(), now_s() - t_start, t_read, t_prep, t_gpu, t_out, t_hostprep, t_h2d, t_kernel);
     if (n_rejected) fprintf(stderr, "[%s] %lld read group(s) use constructs the reference leaves undefined and were skipped\n", timestamp(), n_rejected);
     fprintf(stderr, "[%s] Number of reads modified by phased variants = 0\n", timestamp());
     fprintf(stderr, "[%s] Number of reads modified by marker score = %lld\n", timestamp(), n_modified);

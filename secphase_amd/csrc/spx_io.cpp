@@ -13,6 +13,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <future>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,41 +26,52 @@ thread_local std::string g_io_err;
 
 struct Block { size_t coff, clen, uoff, ulen; };
 
+/* one batch under construction / handed out: SEQ, QUAL and cs are NOT copied, they are offsets into the
+ * inflated byte stream `ubuf` (only CIGAR is copied, it needs 4-byte alignment) */
+struct Slot {
+    std::vector<uint8_t> ubuf;
+    std::vector<int32_t> grp_first, tid, pos, l_qseq, n_cigar;
+    std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off;
+    std::vector<uint16_t> flag;
+    std::vector<uint32_t> cigar;
+    std::vector<char> qnames;
+    spx_batch view;
+    int ng = 0;
+    int rc = 0;
+    void clear()
+    {
+        grp_first.clear(); tid.clear(); pos.clear(); l_qseq.clear(); n_cigar.clear(); qname_off.clear(); cigar_off.clear();
+        seq_off.clear(); qual_off.clear(); cs_off.clear(); flag.clear(); cigar.clear(); qnames.clear(); ng = 0; rc = 0;
+    }
+};
+
 struct Reader {
     FILE *fp = nullptr;
-    std::vector<uint8_t> cbuf;  /* compressed blocks of the current chunk */
-    std::vector<uint8_t> ubuf;  /* inflated bytes not yet consumed + current chunk */
-    size_t upos = 0;
+    std::vector<uint8_t> cbuf;     /* compressed blocks of the current chunk */
+    std::vector<uint8_t> leftover; /* inflated bytes after the last complete group of the previous batch */
     bool eof = false;
     int threads = 4;
     /* header */
     std::vector<std::string> tname;
     std::vector<int64_t> tlen;
     std::vector<int32_t> tmap; /* BAM tid -> contig index of the reference handed to the scorer (-1 unknown) */
-    /* batch storage */
-    std::vector<int32_t> grp_first, tid, pos, l_qseq, n_cigar;
-    std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off;
-    std::vector<uint16_t> flag;
-    std::vector<uint32_t> cigar;
-    std::vector<uint8_t> seq4, qual;
-    std::vector<char> qnames, cs;
-    spx_batch view;
+    Slot slot[2];
+    int cur = 0;
+    std::future<void> pending; /* the NEXT batch is read while the caller works on the current one */
+    bool have_pending = false;
+    int32_t pending_max = 0;
     std::string last_name;
     bool have_last = false;
     int64_t n_records = 0, n_groups_total = 0;
 };
 
-bool read_chunk(Reader *r)
+/* read up to 256 BGZF blocks, inflate them in parallel, append to `ubuf`; false at EOF / error */
+bool read_chunk(Reader *r, std::vector<uint8_t> &ubuf)
 {
-    /* read up to 256 BGZF blocks, inflate them in parallel, append to ubuf */
     if (r->eof) return false;
-    if (r->upos > 0) {
-        r->ubuf.erase(r->ubuf.begin(), r->ubuf.begin() + (long)r->upos);
-        r->upos = 0;
-    }
     r->cbuf.clear();
     std::vector<Block> blocks;
-    size_t utot = r->ubuf.size();
+    size_t utot = ubuf.size();
     for (int n = 0; n < 256; ++n) {
         uint8_t hdr[18];
         size_t got = fread(hdr, 1, 18, r->fp);
@@ -87,7 +99,7 @@ bool read_chunk(Reader *r)
         utot += isize;
     }
     if (blocks.empty()) return false;
-    r->ubuf.resize(utot);
+    ubuf.resize(utot);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
     auto work = [&]() {
@@ -100,7 +112,7 @@ bool read_chunk(Reader *r)
             memset(&zs, 0, sizeof zs);
             if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
             zs.next_in = r->cbuf.data() + b.coff; zs.avail_in = (uInt)b.clen;
-            zs.next_out = r->ubuf.data() + b.uoff; zs.avail_out = (uInt)b.ulen;
+            zs.next_out = ubuf.data() + b.uoff; zs.avail_out = (uInt)b.ulen;
             int rc = inflate(&zs, Z_FINISH);
             if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
             inflateEnd(&zs);
@@ -117,22 +129,15 @@ bool read_chunk(Reader *r)
     return true;
 }
 
-/* make sure n bytes are available at upos; false at clean EOF / error */
-bool need(Reader *r, size_t n)
+/* make sure n bytes are available at `at` in ubuf; false at clean EOF / error */
+bool need(Reader *r, std::vector<uint8_t> &ubuf, size_t at, size_t n)
 {
-    while (r->ubuf.size() - r->upos < n)
-        if (!read_chunk(r)) return r->ubuf.size() - r->upos >= n;
+    while (ubuf.size() < at + n)
+        if (!read_chunk(r, ubuf)) return ubuf.size() >= at + n;
     return true;
 }
 
 inline int32_t le32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
-
-void clear_batch(Reader *r)
-{
-    r->grp_first.clear(); r->tid.clear(); r->pos.clear(); r->l_qseq.clear(); r->n_cigar.clear(); r->qname_off.clear();
-    r->cigar_off.clear(); r->seq_off.clear(); r->qual_off.clear(); r->cs_off.clear(); r->flag.clear(); r->cigar.clear();
-    r->seq4.clear(); r->qual.clear(); r->qnames.clear(); r->cs.clear();
-}
 
 /* find the cs:Z tag in the aux block */
 const char *find_cs(const uint8_t *aux, const uint8_t *end)
@@ -188,23 +193,27 @@ extern "C" int spx_bam_open(const char *path, int threads, spx_bam_reader **out)
     Reader *r = &h->r;
     r->fp = fp;
     r->threads = threads > 0 ? threads : 4;
-    if (!need(r, 12) || memcmp(r->ubuf.data() + r->upos, "BAM\1", 4) != 0) { g_io_err = "not a BAM file"; fclose(fp); delete h; return SPX_EINVAL; }
-    const int32_t l_text = le32(r->ubuf.data() + r->upos + 4);
-    r->upos += 8;
-    if (!need(r, (size_t)l_text + 4)) { g_io_err = "truncated BAM header"; fclose(fp); delete h; return SPX_EINVAL; }
-    r->upos += (size_t)l_text;
-    const int32_t n_ref = le32(r->ubuf.data() + r->upos);
-    r->upos += 4;
+    std::vector<uint8_t> &u = r->leftover;
+    size_t at = 0;
+    auto bail = [&](const char *msg) { g_io_err = msg; fclose(fp); delete h; return SPX_EINVAL; };
+    if (!need(r, u, at, 12) || memcmp(u.data(), "BAM\1", 4) != 0) return bail("not a BAM file");
+    const int32_t l_text = le32(u.data() + 4);
+    at = 8;
+    if (!need(r, u, at, (size_t)l_text + 4)) return bail("truncated BAM header");
+    at += (size_t)l_text;
+    const int32_t n_ref = le32(u.data() + at);
+    at += 4;
     for (int32_t i = 0; i < n_ref; ++i) {
-        if (!need(r, 4)) { g_io_err = "truncated BAM header"; fclose(fp); delete h; return SPX_EINVAL; }
-        const int32_t ln = le32(r->ubuf.data() + r->upos);
-        r->upos += 4;
-        if (!need(r, (size_t)ln + 4)) { g_io_err = "truncated BAM header"; fclose(fp); delete h; return SPX_EINVAL; }
-        r->tname.emplace_back((const char *)r->ubuf.data() + r->upos);
-        r->upos += (size_t)ln;
-        r->tlen.push_back(le32(r->ubuf.data() + r->upos));
-        r->upos += 4;
+        if (!need(r, u, at, 4)) return bail("truncated BAM header");
+        const int32_t ln = le32(u.data() + at);
+        at += 4;
+        if (!need(r, u, at, (size_t)ln + 4)) return bail("truncated BAM header");
+        r->tname.emplace_back((const char *)u.data() + at);
+        at += (size_t)ln;
+        r->tlen.push_back(le32(u.data() + at));
+        at += 4;
     }
+    u.erase(u.begin(), u.begin() + (long)at);
     r->tmap.assign(n_ref, -1);
     for (int32_t i = 0; i < n_ref; ++i) r->tmap[i] = i;
     *out = h;
@@ -233,20 +242,21 @@ extern "C" int spx_bam_bind_reference(spx_bam_reader *h, const spx_ref *ref)
     return missing;
 }
 
-/* up to max_groups complete name groups; the batch stays valid until the next call.  Returns the number of
- * groups (0 at end of file) or SPX_E*. */
-extern "C" int spx_bam_next_batch(spx_bam_reader *h, int32_t max_groups, const spx_batch **out)
+/* fill one slot with up to max_groups complete name groups */
+static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
 {
-    if (!h || !out || max_groups <= 0) return SPX_EINVAL;
-    Reader *r = &h->r;
-    clear_batch(r);
-    int32_t ng = 0;
+    S.clear();
+    S.ubuf.swap(r->leftover);
+    r->leftover.clear();
+    std::vector<uint8_t> &u = S.ubuf;
+    size_t at = 0;
     bool open_group = false;
     for (;;) {
-        if (!need(r, 4)) break;
-        const int32_t bs = le32(r->ubuf.data() + r->upos);
-        if (bs < 32 || !need(r, (size_t)bs + 4)) { if (bs >= 32) g_io_err = "truncated BAM record"; break; }
-        const uint8_t *p = r->ubuf.data() + r->upos + 4;
+        if (!need(r, u, at, 4)) break;
+        const int32_t bs = le32(u.data() + at);
+        if (bs < 32) { g_io_err = "corrupt BAM record"; S.rc = SPX_EINVAL; break; }
+        if (!need(r, u, at, (size_t)bs + 4)) { g_io_err = "truncated BAM record"; S.rc = SPX_EINVAL; break; }
+        const uint8_t *p = u.data() + at + 4;
         const int32_t refid = le32(p), posv = le32(p + 4);
         const uint32_t l_name = p[8];
         const uint32_t ncig = p[12] | (p[13] << 8), flg = p[14] | (p[15] << 8);
@@ -254,62 +264,80 @@ extern "C" int spx_bam_next_batch(spx_bam_reader *h, int32_t max_groups, const s
         const char *name = (const char *)p + 32;
         /* group boundary on a name change (src/secphase.c:273-279) */
         const bool same = r->have_last && r->last_name == name;
-        if (!same) {
-            if (open_group && ng == max_groups) break; /* leave this record for the next batch */
-            r->grp_first.push_back((int32_t)r->flag.size());
-            r->qname_off.push_back((int64_t)r->qnames.size());
-            r->qnames.insert(r->qnames.end(), name, name + strlen(name) + 1);
+        if (!same || !open_group) {
+            if (open_group && S.ng == max_groups) break; /* this record opens the next batch */
+            S.grp_first.push_back((int32_t)S.flag.size());
+            S.qname_off.push_back((int64_t)S.qnames.size());
+            S.qnames.insert(S.qnames.end(), name, name + strlen(name) + 1);
             r->last_name = name;
             r->have_last = true;
             open_group = true;
-            ++ng;
-        } else if (!open_group) {
-            /* cannot happen: a batch always ends on a group boundary */
-            r->grp_first.push_back((int32_t)r->flag.size());
-            r->qname_off.push_back((int64_t)r->qnames.size());
-            r->qnames.insert(r->qnames.end(), name, name + strlen(name) + 1);
-            open_group = true;
-            ++ng;
+            ++S.ng;
         }
         const uint8_t *cig = p + 32 + l_name, *sq = cig + 4 * (size_t)ncig, *ql = sq + ((size_t)lseq + 1) / 2, *aux = ql + lseq,
                       *end = p + bs;
-        r->flag.push_back((uint16_t)flg);
-        r->tid.push_back((refid >= 0 && (size_t)refid < r->tmap.size()) ? r->tmap[refid] : -1);
-        r->pos.push_back(posv);
-        r->l_qseq.push_back(lseq);
-        r->n_cigar.push_back((int32_t)ncig);
-        r->cigar_off.push_back((int64_t)r->cigar.size());
-        for (uint32_t k = 0; k < ncig; ++k) r->cigar.push_back((uint32_t)le32(cig + 4 * k));
-        r->seq_off.push_back((int64_t)r->seq4.size());
-        r->seq4.insert(r->seq4.end(), sq, sq + ((size_t)lseq + 1) / 2);
-        r->qual_off.push_back((int64_t)r->qual.size());
-        r->qual.insert(r->qual.end(), ql, ql + lseq);
+        S.flag.push_back((uint16_t)flg);
+        S.tid.push_back((refid >= 0 && (size_t)refid < r->tmap.size()) ? r->tmap[refid] : -1);
+        S.pos.push_back(posv);
+        S.l_qseq.push_back(lseq);
+        S.n_cigar.push_back((int32_t)ncig);
+        S.cigar_off.push_back((int64_t)S.cigar.size());
+        for (uint32_t k = 0; k < ncig; ++k) S.cigar.push_back((uint32_t)le32(cig + 4 * k));
+        S.seq_off.push_back((int64_t)(sq - u.data()));
+        S.qual_off.push_back((int64_t)(ql - u.data()));
         const char *csz = aux <= end ? find_cs(aux, end) : nullptr;
-        if (csz) {
-            r->cs_off.push_back((int64_t)r->cs.size());
-            r->cs.insert(r->cs.end(), csz, csz + strlen(csz) + 1);
-        } else r->cs_off.push_back(-1);
-        r->upos += (size_t)bs + 4;
+        S.cs_off.push_back(csz ? (int64_t)((const uint8_t *)csz - u.data()) : -1);
+        at += (size_t)bs + 4;
         r->n_records++;
     }
-    r->grp_first.push_back((int32_t)r->flag.size());
-    r->seq4.push_back(0); r->qual.push_back(0); r->cs.push_back(0); r->qnames.push_back(0); r->cigar.push_back(0);
-    spx_batch &b = r->view;
-    b.n_groups = ng;
-    b.n_alns = (int32_t)r->flag.size();
-    b.grp_first = r->grp_first.data(); b.qname_off = r->qname_off.data(); b.qnames = r->qnames.data();
-    b.flag = r->flag.data(); b.tid = r->tid.data(); b.pos = r->pos.data(); b.l_qseq = r->l_qseq.data();
-    b.n_cigar = r->n_cigar.data(); b.cigar_off = r->cigar_off.data(); b.seq_off = r->seq_off.data();
-    b.qual_off = r->qual_off.data(); b.cs_off = r->cs_off.data(); b.cigar = r->cigar.data(); b.seq4 = r->seq4.data();
-    b.qual = r->qual.data(); b.cs = r->cs.data();
-    *out = &r->view;
-    r->n_groups_total += ng;
-    return ng;
+    /* bytes of the records that belong to the next batch */
+    r->leftover.assign(u.begin() + (long)at, u.end());
+    S.grp_first.push_back((int32_t)S.flag.size());
+    S.qnames.push_back(0);
+    S.cigar.push_back(0);
+    u.resize(at + 8, 0); /* keep the consumed part (+ slack), drop the tail that was copied out */
+    spx_batch &b = S.view;
+    b.n_groups = S.ng;
+    b.n_alns = (int32_t)S.flag.size();
+    b.grp_first = S.grp_first.data(); b.qname_off = S.qname_off.data(); b.qnames = S.qnames.data();
+    b.flag = S.flag.data(); b.tid = S.tid.data(); b.pos = S.pos.data(); b.l_qseq = S.l_qseq.data();
+    b.n_cigar = S.n_cigar.data(); b.cigar_off = S.cigar_off.data(); b.seq_off = S.seq_off.data();
+    b.qual_off = S.qual_off.data(); b.cs_off = S.cs_off.data(); b.cigar = S.cigar.data();
+    b.seq4 = u.data(); b.qual = u.data(); b.cs = (const char *)u.data();
+    r->n_groups_total += S.ng;
+}
+
+/* up to max_groups complete name groups; the batch stays valid until the next call.  The following batch is
+ * read and inflated in the background while the caller works on this one.  Returns the number of groups
+ * (0 at end of file) or SPX_E*. */
+extern "C" int spx_bam_next_batch(spx_bam_reader *h, int32_t max_groups, const spx_batch **out)
+{
+    if (!h || !out || max_groups <= 0) return SPX_EINVAL;
+    Reader *r = &h->r;
+    if (r->have_pending && r->pending_max == max_groups) {
+        r->pending.get();
+        r->cur ^= 1; /* the slot the background task filled */
+    } else {
+        if (r->have_pending) r->pending.get(); /* different batch size requested: cannot happen in the CLI */
+        fill_slot(r, r->slot[r->cur], max_groups);
+    }
+    r->have_pending = false;
+    Slot &S = r->slot[r->cur];
+    *out = &S.view;
+    if (S.rc < 0) return S.rc;
+    if (S.ng > 0) {
+        Slot *nxt = &r->slot[r->cur ^ 1];
+        r->pending_max = max_groups;
+        r->pending = std::async(std::launch::async, [r, nxt, max_groups]() { fill_slot(r, *nxt, max_groups); });
+        r->have_pending = true;
+    }
+    return S.ng;
 }
 
 extern "C" void spx_bam_close(spx_bam_reader *h)
 {
     if (!h) return;
+    if (h->r.have_pending) h->r.pending.get();
     if (h->r.fp) fclose(h->r.fp);
     delete h;
 }

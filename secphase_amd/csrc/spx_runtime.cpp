@@ -76,6 +76,9 @@ struct spx_ctx {
     int64_t ref_bytes = 0;
     spx::RefIndex ref;
     double *d_tables = nullptr; /* qthr[102] | match[256] | mis[256] */
+    /* device arenas of finished work lists are kept for the next one (hipMalloc of several GB costs ~0.2 s) */
+    std::vector<std::pair<void *, size_t>> arena_cache;
+    std::mutex arena_mu;
     /* a tiny private reference pool for spx_probaln_batch */
 };
 
@@ -83,7 +86,7 @@ struct spx_work {
     spx::HostBatch hb;
     int32_t n_groups_in = 0;
     void *arena = nullptr;
-    size_t arena_bytes = 0;
+    size_t arena_bytes = 0, arena_cap = 0;
     spx_dev_batch cls_batch[SPX_N_CLASSES];
     int cls_used[SPX_N_CLASSES] = {};
     int main_cls = -1;
@@ -162,6 +165,7 @@ extern "C" void spx_destroy(spx_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->d_ref4) (void)hipFree(c->d_ref4);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    for (auto &a : c->arena_cache) (void)hipFree(a.first);
     for (int i = 0; i < 6; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < SPX_N_CLASSES; ++i) {
@@ -283,7 +287,22 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
            o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
            o_tie = cv.take<uint16_t>(ng);
     w->arena_bytes = cv.off + 256;
-    HIPCHK(hipMalloc(&w->arena, w->arena_bytes));
+    {
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        int best = -1;
+        for (size_t i = 0; i < c->arena_cache.size(); ++i)
+            if (c->arena_cache[i].second >= w->arena_bytes && (best < 0 || c->arena_cache[i].second < c->arena_cache[best].second))
+                best = (int)i;
+        if (best >= 0) {
+            w->arena = c->arena_cache[best].first;
+            w->arena_cap = c->arena_cache[best].second;
+            c->arena_cache.erase(c->arena_cache.begin() + best);
+        }
+    }
+    if (!w->arena) {
+        w->arena_cap = w->arena_bytes + w->arena_bytes / 8; /* head room so that the next, slightly larger list fits */
+        HIPCHK(hipMalloc(&w->arena, w->arena_cap));
+    }
     char *base = (char *)w->arena;
     double t0 = now_s();
 #define UP(off, vec)                                                                                         \
@@ -555,7 +574,15 @@ extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
 {
     if (!w) return;
     if (c) (void)hipSetDevice(c->device);
-    if (w->arena) (void)hipFree(w->arena);
+    if (w->arena) {
+        bool kept = false;
+        if (c) {
+            (void)hipStreamSynchronize(c->stream); /* nothing of this work list may still be running */
+            std::lock_guard<std::mutex> lk(c->arena_mu);
+            if (c->arena_cache.size() < 3) { c->arena_cache.emplace_back(w->arena, w->arena_cap); kept = true; }
+        }
+        if (!kept) (void)hipFree(w->arena);
+    }
     delete w;
 }
 
