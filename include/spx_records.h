@@ -65,6 +65,9 @@ typedef struct spx_batch {
     const uint8_t *seq4;      /* nt16 codes, two bases per byte, high nibble first */
     const uint8_t *qual;      /* phred, one byte per base                       */
     const char *cs;           /* short-form cs strings (without the leading 'Z'), NUL-terminated */
+    /* MD tag, used only for records without cs (cigar_it.c:46-63); both may be NULL when no record has one */
+    const int64_t *md_off;    /* BYTE offset into md[] ; -1 when the tag is absent */
+    const char *md;           /* MD strings, NUL-terminated */
 } spx_batch;
 
 /* The reference assembly, resident in RAM.  bases[] holds the raw FASTA

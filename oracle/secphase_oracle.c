@@ -86,6 +86,7 @@ typedef struct {
     const uint8_t *seq4;
     uint8_t *qual; /* private, mutable */
     const char *cs;
+    const char *md; /* used only when cs is absent (cigar_it.c:46-63) */
     orc_op *ops; /* ops[0] = start state */
     int n_ops;
     int lclip, rclip;
@@ -132,6 +133,59 @@ static int cs_next_token(const char *s, int *so, int *eo)
     return 0;
 }
 
+/* MD tokenizer: what regexec(MD_PATTERN) finds (cigar_it.h:10): un-anchored leftmost-longest search for
+ *   [A-Z]([0][A-Z])*  |  [0-9]+  |  \^[A-Z]+                                                       */
+static int is_upper(char c) { return c >= 'A' && c <= 'Z'; }
+static int md_next_token(const char *s, int *so, int *eo)
+{
+    int p;
+    for (p = 0; s[p]; ++p) {
+        char c = s[p];
+        if (is_upper(c)) {
+            int e = p + 1;
+            while (s[e] == '0' && is_upper(s[e + 1])) e += 2;
+            *so = p; *eo = e;
+            return 1;
+        }
+        if (is_digit(c)) {
+            int e = p + 1;
+            while (is_digit(s[e])) ++e;
+            *so = p; *eo = e;
+            return 1;
+        }
+        if (c == '^' && is_upper(s[p + 1])) {
+            int e = p + 1;
+            while (is_upper(s[e])) ++e;
+            *so = p; *eo = e;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* ptCigarIt_next_md (cigar_it.c:72-141), including its recursion on zero-length tokens */
+static int next_md(const char *md, int *off, orc_op *cur)
+{
+    const char *s = md + *off;
+    int so, eo;
+    char c, buf[24];
+    if (!md_next_token(s, &so, &eo)) return 0;
+    c = s[so];
+    if (c == '0') { cur->op = SPX_CDIFF; cur->len = 0; }
+    else if (c <= '9') {
+        int n = eo - so; /* the reference copies (eo-so) bytes from the START of the shifted string */
+        if (n > 19) n = 19;
+        memcpy(buf, s, n);
+        buf[n] = 0;
+        cur->op = SPX_CEQUAL;
+        cur->len = atoi(buf);
+    } else if (c < 90) { cur->op = SPX_CDIFF; cur->len = 1 + (eo - so - 1) / 2; }
+    else if (c == 94) { cur->op = SPX_CDEL; cur->len = eo - so - 1; }
+    *off += eo;
+    if (cur->len == 0) next_md(md, off, cur);
+    return cur->len;
+}
+
 /* ptCigarIt_construct + repeated ptCigarIt_next (cigar_it.c:14-69,213-308),
  * materialised once: the reference re-creates the iterator >=7 times per
  * alignment and always sees the same sequence of states. */
@@ -153,14 +207,16 @@ static int walk_cigar(waln *a)
     cur.rds_f = a->is_rev ? a->rclip + a->lclip + a->l_qseq : 0;
     cur.rde_f = a->is_rev ? a->rclip + a->lclip + a->l_qseq - 1 : -1;
     ops[n++] = cur;
-    if (!a->cs) { free(ops); return -3; } /* MD-only input: not restated yet */
+    const int use_cs = a->cs != NULL, use_md = !use_cs && a->md != NULL;
+    int md_off = 0;
+    if (!use_cs && !use_md) { free(ops); return -3; } /* the reference exit(1)s: neither tag present */
     while (idx != a->n_cigar - 1) {
         int op, len, rd_step, sq_step, rf_step, so, eo, have;
         idx += 1;
         op = a->cigar[idx] & 0xf;
         len = a->cigar[idx] >> 4;
         have = 0;
-        if (op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF || op == SPX_CINS || op == SPX_CDEL) {
+        if (use_cs && (op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF || op == SPX_CINS || op == SPX_CDEL)) {
             /* ptCigarIt_next_cs */
             const char *s = a->cs + cs_off;
             have = cs_next_token(s, &so, &eo);
@@ -179,8 +235,22 @@ static int walk_cigar(waln *a)
         case SPX_CEQUAL:
         case SPX_CDIFF:
             if (match_remain == 0) match_remain = len;
-            match_remain -= cur.len;
-            if (0 < match_remain) idx -= 1;
+            if (use_cs) {
+                match_remain -= cur.len;
+                if (0 < match_remain) idx -= 1;
+            } else { /* MD tokens do not see insertions, so they may span several CIGAR M ops (cigar_it.c:237-256) */
+                if (0 <= match_remain) next_md(a->md, &md_off, &cur);
+                if (match_remain < 0) {
+                    cur.op = SPX_CEQUAL;
+                    cur.len = imin(len, -1 * match_remain);
+                    match_remain += len;
+                } else {
+                    int md_len = cur.len;
+                    cur.len = imin(cur.len, match_remain);
+                    match_remain -= md_len;
+                }
+                if (0 < match_remain) idx -= 1;
+            }
             rd_step = sq_step = rf_step = cur.len;
             break;
         case SPX_CINS:
@@ -188,6 +258,7 @@ static int walk_cigar(waln *a)
             rd_step = sq_step = len; rf_step = 0;
             break;
         case SPX_CDEL:
+            if (use_md) next_md(a->md, &md_off, &cur);
             rd_step = sq_step = 0; rf_step = len;
             break;
         case SPX_CSOFT_CLIP:
@@ -243,6 +314,7 @@ int orc_walk_cigar(const spx_batch *bt, int ai, orc_op **ops_out)
     a.is_rev = (a.flag & SPX_FREVERSE) != 0;
     a.cigar = bt->cigar + bt->cigar_off[ai];
     a.cs = bt->cs_off[ai] >= 0 ? bt->cs + bt->cs_off[ai] : NULL;
+    a.md = (bt->md_off && bt->md && bt->md_off[ai] >= 0) ? bt->md + bt->md_off[ai] : NULL;
     rc = walk_cigar(&a);
     if (rc < 0) return rc;
     *ops_out = a.ops;
@@ -844,6 +916,7 @@ static int score_group(const spx_batch *bt, const spx_ref *ref, int g, const spx
         w->qual = malloc(w->l_qseq > 0 ? w->l_qseq : 1);
         memcpy(w->qual, bt->qual + bt->qual_off[a], w->l_qseq);
         w->cs = bt->cs_off[a] >= 0 ? bt->cs + bt->cs_off[a] : NULL;
+        w->md = (bt->md_off && bt->md && bt->md_off[a] >= 0) ? bt->md + bt->md_off[a] : NULL;
         rc = walk_cigar(w);
         if (rc < 0) { free_alns(al, n); return rc; }
         init_coordinates(w);

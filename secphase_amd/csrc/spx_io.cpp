@@ -31,7 +31,7 @@ struct Block { size_t coff, clen, uoff, ulen; };
 struct Slot {
     std::vector<uint8_t> ubuf;
     std::vector<int32_t> grp_first, tid, pos, l_qseq, n_cigar;
-    std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off;
+    std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off, md_off;
     std::vector<uint16_t> flag;
     std::vector<uint32_t> cigar;
     std::vector<char> qnames;
@@ -41,7 +41,7 @@ struct Slot {
     void clear()
     {
         grp_first.clear(); tid.clear(); pos.clear(); l_qseq.clear(); n_cigar.clear(); qname_off.clear(); cigar_off.clear();
-        seq_off.clear(); qual_off.clear(); cs_off.clear(); flag.clear(); cigar.clear(); qnames.clear(); ng = 0; rc = 0;
+        seq_off.clear(); qual_off.clear(); cs_off.clear(); md_off.clear(); flag.clear(); cigar.clear(); qnames.clear(); ng = 0; rc = 0;
     }
 };
 
@@ -139,8 +139,8 @@ bool need(Reader *r, std::vector<uint8_t> &ubuf, size_t at, size_t n)
 
 inline int32_t le32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
 
-/* find the cs:Z tag in the aux block */
-const char *find_cs(const uint8_t *aux, const uint8_t *end)
+/* find a Z tag (cs or MD) in the aux block */
+const char *find_tag(const uint8_t *aux, const uint8_t *end, char k0, char k1)
 {
     while (aux + 3 <= end) {
         const char t0 = (char)aux[0], t1 = (char)aux[1], ty = (char)aux[2];
@@ -153,7 +153,7 @@ const char *find_cs(const uint8_t *aux, const uint8_t *end)
         case 'Z': case 'H': {
             const uint8_t *z = v;
             while (z < end && *z) ++z;
-            if (t0 == 'c' && t1 == 's' && ty == 'Z') return (const char *)v;
+            if (t0 == k0 && t1 == k1 && ty == 'Z') return (const char *)v;
             len = (size_t)(z - v) + 1;
             break;
         }
@@ -285,8 +285,10 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
         for (uint32_t k = 0; k < ncig; ++k) S.cigar.push_back((uint32_t)le32(cig + 4 * k));
         S.seq_off.push_back((int64_t)(sq - u.data()));
         S.qual_off.push_back((int64_t)(ql - u.data()));
-        const char *csz = aux <= end ? find_cs(aux, end) : nullptr;
+        const char *csz = aux <= end ? find_tag(aux, end, 'c', 's') : nullptr;
         S.cs_off.push_back(csz ? (int64_t)((const uint8_t *)csz - u.data()) : -1);
+        const char *mdz = (!csz && aux <= end) ? find_tag(aux, end, 'M', 'D') : nullptr; /* only looked at without cs */
+        S.md_off.push_back(mdz ? (int64_t)((const uint8_t *)mdz - u.data()) : -1);
         at += (size_t)bs + 4;
         r->n_records++;
     }
@@ -304,6 +306,7 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
     b.n_cigar = S.n_cigar.data(); b.cigar_off = S.cigar_off.data(); b.seq_off = S.seq_off.data();
     b.qual_off = S.qual_off.data(); b.cs_off = S.cs_off.data(); b.cigar = S.cigar.data();
     b.seq4 = u.data(); b.qual = u.data(); b.cs = (const char *)u.data();
+    b.md_off = S.md_off.data(); b.md = (const char *)u.data();
     r->n_groups_total += S.ng;
 }
 

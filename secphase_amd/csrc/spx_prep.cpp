@@ -198,6 +198,7 @@ struct Aln {
     const uint32_t *cigar;
     const uint8_t *seq4, *qual;
     const char *cs;
+    const char *md;      /* consulted only when the record has no cs tag */
     std::vector<Op> ops; /* ops[0] = state before the first step */
     int32_t n_visit;     /* states a while(next) loop visits: ops[1..n_visit-1] */
     int32_t rest;        /* state the iterator rests on afterwards */
@@ -244,12 +245,67 @@ static inline bool next_cs_token(const char *s, int &so, int &eo)
     return false;
 }
 
+static inline bool upper_c(char c) { return c >= 'A' && c <= 'Z'; }
+
+/* first MD token at or after s: a mismatch run X(0X)*, a match count, or a deletion ^XXX
+ * (the un-anchored POSIX search of cigar_it.h:10) */
+static inline bool next_md_token(const char *s, int &so, int &eo)
+{
+    for (int p = 0; s[p]; ++p) {
+        const char c = s[p];
+        if (upper_c(c)) {
+            int e = p + 1;
+            while (s[e] == '0' && upper_c(s[e + 1])) e += 2;
+            so = p; eo = e;
+            return true;
+        }
+        if (digit_c(c)) {
+            int e = p + 1;
+            while (digit_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+        if (c == '^' && upper_c(s[p + 1])) {
+            int e = p + 1;
+            while (upper_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+    }
+    return false;
+}
+
+/* one MD step (cigar_it.c:72-141): a lone "0" separates two mismatches and is skipped */
+static int md_step(const char *md, int &at, Op &cur)
+{
+    for (;;) {
+        const char *s = md + at;
+        int so, eo;
+        if (!next_md_token(s, so, eo)) return 0;
+        const char c = s[so];
+        if (c == '0') { cur.op = SPX_CDIFF; cur.len = 0; }
+        else if (c <= '9') {
+            char buf[24];
+            int n = std::min(eo - so, 19);
+            memcpy(buf, s, n); /* sic: from the start of the shifted string, like the reference */
+            buf[n] = 0;
+            cur.op = SPX_CEQUAL;
+            cur.len = atoi(buf);
+        } else if (c < 90) { cur.op = SPX_CDIFF; cur.len = 1 + (eo - so - 1) / 2; }
+        else if (c == '^') { cur.op = SPX_CDEL; cur.len = eo - so - 1; }
+        at += eo;
+        if (cur.len != 0) return cur.len;
+    }
+}
+
 static int build_ops(Aln &a)
 {
     a.ops.clear();
     a.lclip = ((a.cigar[0] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(a.cigar[0] >> 4) : 0;
     a.rclip = ((a.cigar[a.n_cigar - 1] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(a.cigar[a.n_cigar - 1] >> 4) : 0;
-    if (!a.cs) return SPX_EUNSUPPORTED; /* MD-only records: not supported yet */
+    const bool use_cs = a.cs != nullptr, use_md = !use_cs && a.md != nullptr;
+    if (!use_cs && !use_md) return SPX_EINVAL; /* neither cs nor MD: the reference exits */
+    int md_at = 0;
     Op cur;
     cur.op = 255; cur.len = 0; cur.ret = 0;
     cur.sqs = 0; cur.sqe = -1;
@@ -264,7 +320,7 @@ static int build_ops(Aln &a)
         const int op = a.cigar[idx] & 0xf, len = (int)(a.cigar[idx] >> 4);
         int rd, sq, rf;
         const bool mtype = op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF;
-        if (mtype || op == SPX_CINS || op == SPX_CDEL) {
+        if (use_cs && (mtype || op == SPX_CINS || op == SPX_CDEL)) {
             int so, eo;
             const char *s = a.cs + cs_at;
             if (next_cs_token(s, so, eo)) {
@@ -278,13 +334,29 @@ static int build_ops(Aln &a)
         }
         if (mtype) {
             if (remain == 0) remain = len;
-            remain -= cur.len;
-            if (remain > 0) --idx; /* stay on this CIGAR op until cs has covered it */
+            if (use_cs) {
+                remain -= cur.len;
+                if (remain > 0) --idx; /* stay on this CIGAR op until cs has covered it */
+            } else {
+                /* MD knows nothing about insertions: a match run may reach into the following M ops (remain < 0) */
+                if (remain >= 0) md_step(a.md, md_at, cur);
+                if (remain < 0) {
+                    cur.op = SPX_CEQUAL;
+                    cur.len = std::min(len, -remain);
+                    remain += len;
+                } else {
+                    const int md_len = cur.len;
+                    cur.len = std::min(cur.len, remain);
+                    remain -= md_len;
+                }
+                if (remain > 0) --idx;
+            }
             rd = sq = rf = cur.len;
         } else if (op == SPX_CINS) {
             cur.len = len; cur.op = op;
             rd = sq = len; rf = 0;
         } else if (op == SPX_CDEL) {
+            if (use_md) md_step(a.md, md_at, cur);
             rd = sq = 0; rf = len;
         } else if (op == SPX_CSOFT_CLIP) {
             cur.len = len; cur.op = op;
@@ -702,6 +774,7 @@ static int prepare_one(const spx_batch *bt, const RefIndex &ref, const spx_param
         a.seq4 = bt->seq4 + bt->seq_off[r];
         a.qual = bt->qual + bt->qual_off[r];
         a.cs = bt->cs_off[r] >= 0 ? bt->cs + bt->cs_off[r] : nullptr;
+        a.md = (bt->md_off && bt->md && bt->md_off[r] >= 0) ? bt->md + bt->md_off[r] : nullptr;
         a.conf.clear(); a.flank.clear(); a.have_conf = false;
         if (a.n_cigar <= 0) return SPX_EINVAL;
         if (a.tid < 0 || (size_t)a.tid >= ref.len.size()) return SPX_EINVAL;

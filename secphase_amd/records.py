@@ -21,6 +21,7 @@ class SpxBatch(C.Structure):
         ("flag", c_u16p), ("tid", c_i32p), ("pos", c_i32p), ("l_qseq", c_i32p), ("n_cigar", c_i32p),
         ("cigar_off", c_i64p), ("seq_off", c_i64p), ("qual_off", c_i64p), ("cs_off", c_i64p),
         ("cigar", c_u32p), ("seq4", c_u8p), ("qual", c_u8p), ("cs", C.c_void_p),
+        ("md_off", c_i64p), ("md", C.c_void_p),
     ]
 
 

@@ -17,7 +17,7 @@ class SynthCfg(C.Structure):
         ("softclip_frac", C.c_double), ("hardclip_frac", C.c_double),
         ("shuffle_records", C.c_int32), ("inverted_paralogs", C.c_int32),
         ("n_base_frac", C.c_double), ("snv_rate", C.c_double), ("indel_rate", C.c_double),
-        ("paralog_snv_rate", C.c_double),
+        ("paralog_snv_rate", C.c_double), ("tag_mode", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

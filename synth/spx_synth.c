@@ -238,7 +238,7 @@ static void *vec_grow(vec *v, size_t add)
 struct spx_synth_reads {
     spx_batch bt;
     vec grp_first, qname_off, qnames, flag, tid, pos, l_qseq, n_cigar, cigar_off, seq_off, qual_off, cs_off, cigar, seq4,
-        qual, cs;
+        qual, cs, md_off, md;
 };
 
 typedef struct { /* one source base */
@@ -292,7 +292,7 @@ spx_synth_reads *spx_synth_reads_create(const spx_synth_genome *g, const spx_syn
         tmp = {0, 0, 0, 1};
     R->grp_first.esz = 4; R->qname_off.esz = 8; R->qnames.esz = 1; R->flag.esz = 2; R->tid.esz = 4; R->pos.esz = 4;
     R->l_qseq.esz = 4; R->n_cigar.esz = 4; R->cigar_off.esz = 8; R->seq_off.esz = 8; R->qual_off.esz = 8;
-    R->cs_off.esz = 8; R->cigar.esz = 4; R->seq4.esz = 1; R->qual.esz = 1; R->cs.esz = 1;
+    R->cs_off.esz = 8; R->cigar.esz = 4; R->seq4.esz = 1; R->qual.esz = 1; R->cs.esz = 1; R->md_off.esz = 8; R->md.esz = 1;
 
     for (gi = first; gi < first + n; ++gi) {
         rng_t r;
@@ -508,10 +508,13 @@ spx_synth_reads *spx_synth_reads_create(const spx_synth_genome *g, const spx_syn
                 VPUSH(R->cigar_off, int64_t, (int64_t)R->cigar.n);
                 VPUSH(R->seq_off, int64_t, (int64_t)R->seq4.n);
                 VPUSH(R->qual_off, int64_t, (int64_t)R->qual.n);
-                VPUSH(R->cs_off, int64_t, (int64_t)R->cs.n);
+                VPUSH(R->cs_off, int64_t, cfg->tag_mode == 1 ? (int64_t)-1 : (int64_t)R->cs.n);
+                VPUSH(R->md_off, int64_t, cfg->tag_mode == 0 ? (int64_t)-1 : (int64_t)R->md.n);
                 {
-                    int ncig = 0, lq = 0, eqrun = 0;
+                    int ncig = 0, lq = 0, eqrun = 0, mdrun = 0, md_after_del = 0;
                     char buf[32];
+                    const int want_cs = cfg->tag_mode != 1, want_md = cfg->tag_mode != 0;
+                    const size_t cs_mark = R->cs.n;
                     tmp.n = 0; /* unpacked SEQ */
                     for (e = 0; e < nev;) {
                         char ty = E[e].type;
@@ -528,10 +531,24 @@ spx_synth_reads *spx_synth_reads_create(const spx_synth_genome *g, const spx_syn
                                  : ty == 'S' ? SPX_CSOFT_CLIP : SPX_CHARD_CLIP;
                             VPUSH(R->cigar, uint32_t, (uint32_t)len << 4 | (uint32_t)op);
                             ncig++;
+                            if (ty != 'D' && ty != 'M') md_after_del = 0; /* a separate CIGAR D op gets its own MD token */
                             if (ty == 'I') VPUSH(R->cs, char, '+');
                             if (ty == 'D') VPUSH(R->cs, char, '-');
                             for (k = e; k < e2; ++k) {
                                 if (E[k].type != ty) continue;
+                                if (ty == 'M' && want_md) { /* MD: match counts, mismatched / deleted reference bases */
+                                    if (E[k].r == E[k].t) { mdrun++; md_after_del = 0; }
+                                    else {
+                                        int l2 = sprintf(buf, "%d%c", mdrun, E[k].t);
+                                        memcpy(vec_grow(&R->md, l2), buf, l2);
+                                        mdrun = 0; md_after_del = 0;
+                                    }
+                                }
+                                if (ty == 'D' && want_md) {
+                                    if (!md_after_del) { int l2 = sprintf(buf, "%d^", mdrun); memcpy(vec_grow(&R->md, l2), buf, l2); mdrun = 0; }
+                                    VPUSH(R->md, char, E[k].t);
+                                    md_after_del = 1;
+                                }
                                 if (ty == 'M') {
                                     if (E[k].r == E[k].t) eqrun++;
                                     else {
@@ -553,6 +570,8 @@ spx_synth_reads *spx_synth_reads_create(const spx_synth_genome *g, const spx_syn
                         e = e2;
                     }
                     VPUSH(R->cs, char, 0);
+                    if (!want_cs) R->cs.n = cs_mark; /* MD-only records carry no cs */
+                    if (want_md) { int l2 = sprintf(buf, "%d", mdrun); memcpy(vec_grow(&R->md, l2 + 1), buf, l2 + 1); }
                     VPUSH(R->n_cigar, int32_t, ncig);
                     VPUSH(R->l_qseq, int32_t, lq);
                     {
@@ -575,6 +594,7 @@ spx_synth_reads *spx_synth_reads_create(const spx_synth_genome *g, const spx_syn
     R->bt.n_cigar = R->n_cigar.p; R->bt.cigar_off = R->cigar_off.p; R->bt.seq_off = R->seq_off.p;
     R->bt.qual_off = R->qual_off.p; R->bt.cs_off = R->cs_off.p; R->bt.cigar = R->cigar.p; R->bt.seq4 = R->seq4.p;
     R->bt.qual = R->qual.p; R->bt.cs = R->cs.p;
+    R->bt.md_off = R->md_off.p; R->bt.md = R->md.p;
     return R;
 }
 
@@ -585,6 +605,6 @@ void spx_synth_reads_free(spx_synth_reads *R)
     if (!R) return;
     free(R->grp_first.p); free(R->qname_off.p); free(R->qnames.p); free(R->flag.p); free(R->tid.p); free(R->pos.p);
     free(R->l_qseq.p); free(R->n_cigar.p); free(R->cigar_off.p); free(R->seq_off.p); free(R->qual_off.p);
-    free(R->cs_off.p); free(R->cigar.p); free(R->seq4.p); free(R->qual.p); free(R->cs.p);
+    free(R->cs_off.p); free(R->cigar.p); free(R->seq4.p); free(R->qual.p); free(R->cs.p); free(R->md_off.p); free(R->md.p);
     free(R);
 }

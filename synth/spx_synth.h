@@ -33,6 +33,8 @@ typedef struct spx_synth_cfg {
     int32_t inverted_paralogs; /* 1: odd paralog sets are stored reverse-complemented */
     double n_base_frac;   /* fraction of assembly bases replaced by N (edge-case tests) */
     double snv_rate, indel_rate, paralog_snv_rate; /* 1/5000, 1/50000, 0.01 */
+    int32_t tag_mode;     /* 0: cs only, 1: MD only, 2: both */
+    int32_t reserved;
 } spx_synth_cfg;
 
 typedef struct spx_synth_genome spx_synth_genome;

@@ -70,6 +70,8 @@ def write_bam(path, batch, ref, contig_order=None, extra_tags=True):
                 aux += b"NMi" + struct.pack("<i", 3) + b"tpAP"
             if b.cs_off[a] >= 0:
                 aux += b"csZ" + _cstr(b.cs, b.cs_off[a]) + b"\0"
+            if b.md_off and b.md_off[a] >= 0:
+                aux += b"MDZ" + _cstr(b.md, b.md_off[a]) + b"\0"
             if extra_tags:
                 aux += b"zzBs" + struct.pack("<ihh", 2, -1, 7)
             core = struct.pack("<iiBBHHHiiii", tid_of[b.tid[a]], b.pos[a], len(qn), 60, 4680, nc, b.flag[a], lq, -1, -1, 0)

@@ -121,12 +121,13 @@ class HandBatch:
         import re
         self.keep = []
         grp_first, qname_off, qnames = [0], [], b""
-        flag, tid, pos, lq, ncig, cig_off, seq_off, qual_off, cs_off = [], [], [], [], [], [], [], [], []
-        cig, seq4, qual, cs = [], bytearray(), bytearray(), bytearray()
+        flag, tid, pos, lq, ncig, cig_off, seq_off, qual_off, cs_off, md_off = [], [], [], [], [], [], [], [], [], []
+        cig, seq4, qual, cs, md = [], bytearray(), bytearray(), bytearray(), bytearray()
         for name, recs in groups:
             qname_off.append(len(qnames))
             qnames += name.encode() + b"\0"
-            for (f, t, p, cg, sq, ql, c) in recs:
+            for rec in recs:
+                (f, t, p, cg, sq, ql, c), m = rec[:7], (rec[7] if len(rec) > 7 else None)
                 flag.append(f); tid.append(t); pos.append(p); lq.append(len(sq))
                 ops = re.findall(r"(\d+)([MIDNSHP=X])", cg)
                 ncig.append(len(ops)); cig_off.append(len(cig))
@@ -142,15 +143,20 @@ class HandBatch:
                     cs_off.append(-1)
                 else:
                     cs_off.append(len(cs)); cs += c.encode() + b"\0"
+                if m is None:
+                    md_off.append(-1)
+                else:
+                    md_off.append(len(md)); md += m.encode() + b"\0"
             grp_first.append(len(flag))
         A = lambda x, dt: np.ascontiguousarray(np.array(x, dt))
         self.arr = dict(grp_first=A(grp_first, np.int32), qname_off=A(qname_off, np.int64), flag=A(flag, np.uint16),
                         tid=A(tid, np.int32), pos=A(pos, np.int32), l_qseq=A(lq, np.int32), n_cigar=A(ncig, np.int32),
                         cigar_off=A(cig_off, np.int64), seq_off=A(seq_off, np.int64), qual_off=A(qual_off, np.int64),
-                        cs_off=A(cs_off, np.int64), cigar=A(cig if cig else [0], np.uint32),
+                        cs_off=A(cs_off, np.int64), md_off=A(md_off, np.int64), cigar=A(cig if cig else [0], np.uint32),
                         seq4=A(list(seq4) + [0], np.uint8), qual=A(list(qual) + [0], np.uint8))
         self.qnames = C.create_string_buffer(bytes(qnames) + b"\0")
         self.cs = C.create_string_buffer(bytes(cs) + b"\0")
+        self.md = C.create_string_buffer(bytes(md) + b"\0")
         b = records.SpxBatch()
         b.n_groups = len(groups)
         b.n_alns = len(flag)
@@ -158,6 +164,7 @@ class HandBatch:
             setattr(b, k, v.ctypes.data_as(dict(records.SpxBatch._fields_)[k]))
         b.qnames = C.cast(self.qnames, C.c_void_p)
         b.cs = C.cast(self.cs, C.c_void_p)
+        b.md = C.cast(self.md, C.c_void_p)
         self.struct = b
         self.batch = C.pointer(b)
 

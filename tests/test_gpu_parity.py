@@ -144,6 +144,13 @@ def test_batch_edge_cases(ctx, tmp_path):
     _batch_parity(ctx, g, r, records.preset("hifi"), tmp_path, "edge")
 
 
+def test_batch_md_only_records(ctx, tmp_path):
+    g = small_genome(synth.HIFI, tag_mode=1, read_len=6000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.3,
+                     softclip_frac=0.3)
+    r = g.reads(0, 48)
+    _batch_parity(ctx, g, r, records.preset("hifi"), tmp_path, "md")
+
+
 def test_no_cpu_fallback():
     assert api.lib().spx_device_count() >= 1
 

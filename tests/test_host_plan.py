@@ -56,6 +56,14 @@ def test_plan_edge_cases(built):
     _compare(g.ref, r.batch, records.preset("hifi"))
 
 
+def test_plan_md_only_records(built):
+    g = small_genome(synth.HIFI, tag_mode=1, read_len=5000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.3,
+                     softclip_frac=0.3)
+    r = g.reads(0, 30)
+    assert all(r.batch.contents.cs_off[a] < 0 for a in range(r.batch.contents.n_alns))
+    _compare(g.ref, r.batch, records.preset("hifi"))
+
+
 def test_plan_mixed_lengths(built):
     g = small_genome(synth.MIXED, n_paralogs=7, contig_len=250000, max_read_len=40000)
     r = g.reads(7, 12)

@@ -35,7 +35,8 @@ def _records(bp):
                          tuple(b.cigar[b.cigar_off[a] + k] for k in range(nc)),
                          C.string_at(C.addressof(b.seq4.contents) + b.seq_off[a], (lq + 1) // 2),
                          C.string_at(C.addressof(b.qual.contents) + b.qual_off[a], lq),
-                         C.string_at(b.cs + b.cs_off[a]) if b.cs_off[a] >= 0 else None))
+                         C.string_at(b.cs + b.cs_off[a]) if b.cs_off[a] >= 0 else None,
+                         C.string_at(b.md + b.md_off[a]) if (b.md_off and b.cs_off[a] < 0 and b.md_off[a] >= 0) else None))
         out.append((name, recs))
     return out
 
@@ -43,7 +44,17 @@ def _records(bp):
 def test_fasta_and_bam_round_trip(built, tmp_path):
     L = api.lib()
     _declare(L)
-    g = small_genome(synth.HIFI, read_len=3000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.3, softclip_frac=0.4)
+    _round_trip(tmp_path, 0)
+
+
+def test_bam_round_trip_md_only(built, tmp_path):
+    _round_trip(tmp_path, 1)
+
+
+def _round_trip(tmp_path, tag_mode):
+    L = api.lib()
+    g = small_genome(synth.HIFI, read_len=3000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.3, softclip_frac=0.4,
+                     tag_mode=tag_mode)
     r = g.reads(0, 37)
     fa, bam = str(tmp_path / "asm.fa"), str(tmp_path / "reads.bam")
     write_fasta(fa, g.ref)
