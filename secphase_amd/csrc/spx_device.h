@@ -41,8 +41,10 @@ enum {
 typedef struct spx_dev_batch {
     /* launch list of one band class: problem ids ordered by (W, L desc), padded
      * with -1 so that every wave holds problems of one W */
-    const int32_t *order;
+    const int32_t *order;     /* forward kernels: by (W, L descending) */
+    const int32_t *order_bwd; /* backward kernels: by (W, rows actually walked = L - first wanted row, descending) */
     int32_t n_order;
+    int32_t n_order_bwd;
     /* per problem */
     const int64_t *ref_nib; /* nibble index of ref window start in ref4   */
     const int64_t *qry_nib; /* nibble index of query window start in qry4 */

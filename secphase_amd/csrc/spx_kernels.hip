@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t fetch_code(const uint8_t *__restrict__ pool,
 /* 8 consecutive 4-bit codes starting at nibble address a (any alignment), as one dword */
 __device__ __forceinline__ uint32_t fetch8(const uint8_t *__restrict__ pool, int64_t a)
 {
-    a = a < 0 ? 0 : a; /* codes of columns < 1 are never used; keep the address inside the pool */
+    /* a may point a few codes in front of a window: both pools carry a lead pad (codes there are never used) */
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
     const uint32_t lo = p32[0], hi = p32[1];
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(a & 7) * 4u);
@@ -216,7 +216,7 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
  * ew holds the code of column k+1 (ref index i - bw + j) per slot. */
 template <int G, int C, bool FAST, int W0>
 __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double (&bD)[C], const CodeWin<C> &ew,
-                                        uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double inv, bool first_row)
+                                        uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double inv, bool first_row, bool any_first)
 {
     double lI = shfl_up1<G>(bI[C - 1]);
     if (g == 0) lI = 0.0;
@@ -232,8 +232,8 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double
         bM[c] = u;
         bI[c] = v;
     }
-    /* serial phase: D recurrence over descending columns; row 1 has y = 0 */
-    if (!first_row) {
+    /* serial phase: D recurrence over descending columns; row 1 has y = 0 (its D row is all zero) */
+    {
         double carryD = 0.0;
         for (int t = tlast; t >= 0; --t) {
             if (g == t) {
@@ -257,9 +257,10 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double
             }
             if (t > 0) carryD = shfl_down1<G>(carryD);
         }
-    } else {
+        if (any_first) { /* wave-uniform: some problem of the wave is on its row 1 */
 #pragma unroll
-        for (int c = 0; c < C; ++c) bD[c] = 0.0;
+            for (int c = 0; c < C; ++c) bD[c] = first_row ? 0.0 : bD[c];
+        }
     }
     /* parallel phase B: M += m2*D(i,k+1); scale */
     double hD = shfl_down1<G>(bD[0]);
@@ -280,12 +281,12 @@ struct Prob {
 };
 
 template <int G>
-__device__ __forceinline__ Prob load_problem(const spx_dev_batch &B, int lane, HmmC &h, int &hasN)
+__device__ __forceinline__ Prob load_problem(const spx_dev_batch &B, int lane, HmmC &h, int &hasN, bool bwd = false)
 {
     constexpr int PPW = 64 / G;
     Prob P;
     const int oslot = blockIdx.x * PPW + lane / G;
-    P.pid = oslot < B.n_order ? B.order[oslot] : -1;
+    P.pid = bwd ? (oslot < B.n_order_bwd ? B.order_bwd[oslot] : -1) : (oslot < B.n_order ? B.order[oslot] : -1);
     P.L = P.R = P.bw = P.nrows = P.row0 = 0;
     P.ref0 = P.qry0 = 0;
     hasN = 0;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
     const int g = lane % G;
     HmmC h;
     int hasN;
-    const Prob P = load_problem<G>(B, lane, h, hasN);
+    const Prob P = load_problem<G>(B, lane, h, hasN, true);
     const bool act = P.act;
     const int L = P.L, R = P.R, bw = P.bw;
     const int Wu = W0 ? W0 : wave_max(act ? 2 * bw + 1 : 0);
@@ -497,10 +498,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
     if (Lw == 0) return;
     const int nrows = P.nrows, row0 = P.row0;
     const int stop = act ? B.rows[row0] : 0x7fffffff; /* first (smallest) wanted row */
-    const int stop_w = wave_min(stop);
     const int anyN = wave_max(hasN);
-    /* backward row i is interior iff i + bw < R */
-    const int fast_end = anyN ? 0 : wave_min(act ? R - bw - 1 : 0x7fffffff);
     const int tlast = (Wu - 1) / C;
     const int jbase = g * C;
 
@@ -541,27 +539,36 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
         prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
     };
     if (act && prev_row == L) save_row();
-    /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0; codes come 8 rows at a time
-     * (rows ib+7..ib with ib a multiple of 8), one chunk ahead */
-    auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + jbase)); };
-    auto qry_chunk = [&](int ib) { return ib >= 0 ? fetch8_aligned(B.qry4, P.qry0 + ib) : 0u; };
-    const int ib0 = (L - 1) & ~7;
-    uint32_t qwin = (act && L >= 2) ? qry_chunk(ib0) : 0, rwin = (act && L >= 2) ? ref_chunk(ib0) : 0;
-    uint32_t qwin_n = (act && L >= 2) ? qry_chunk(ib0 - 8) : 0, rwin_n = (act && L >= 2 && ib0 >= 8) ? ref_chunk(ib0 - 8) : 0;
+    /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0.  Codes come 8 STEPS at a time
+     * (step t = row L-1-t, so the chunk phase is the same for every problem of the wave), one chunk ahead:
+     * the chunk of steps t0..t0+7 holds rows i0-7..i0 (i0 = L-1-t0) in ascending nibble order */
+    auto ref_chunk = [&](int i0) { return fetch8(B.ref4, P.ref0 + ((i0 - 7) - bw + jbase)); };
+    auto qry_chunk = [&](int i0) { return fetch8(B.qry4, P.qry0 + (i0 - 7)); };
+    uint32_t qwin = 0, rwin = 0;
+    uint32_t qwin_n = (act && L >= 2) ? qry_chunk(L - 1) : 0, rwin_n = (act && L >= 2) ? ref_chunk(L - 1) : 0;
     double inv_p = (act && L >= 2) ? sinv[L - 1] : 0.0;
-    auto row = [&](int i, auto fast_tag) {
+    /* every problem walks its own rows L-1, L-2, ... down to its first wanted row: step t of the wave is row
+     * L-1-t of each problem, so problems of different length stay busy together (the launch order groups
+     * problems by the number of rows they walk) and the masked general path is needed only for the first
+     * steps, where the band still touches column R */
+    const int nb = act ? max(L - stop, 0) : 0;
+    const int nbw = wave_max(nb);
+    const int n_slow = anyN ? nbw : min(nbw, wave_max(act ? min(nb, max(0, (L - 1) - (R - bw - 1))) : 0));
+    auto row = [&](int t, auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        if (act && i <= L - 1 && i >= stop) {
-            const uint32_t t4 = (uint32_t)(i & 7) * 4u;
-            if (t4 == 28 && i != L - 1) {
+        const int i = L - 1 - t;
+        const bool on = act && t < nb;
+        const bool any_first = __any(on && i == 1);
+        if (on) {
+            const uint32_t t4 = (uint32_t)(7 - (t & 7)) * 4u; /* wave-uniform */
+            if ((t & 7) == 0) {
                 qwin = qwin_n; rwin = rwin_n;
-                const int ibn = (i & ~7) - 8;
-                qwin_n = qry_chunk(ibn);
-                rwin_n = ibn >= 0 ? ref_chunk(ibn) : 0u;
+                qwin_n = qry_chunk(i - 8); /* rows below 1 read the lead pad: never used */
+                rwin_n = ref_chunk(i - 8);
             }
             const uint32_t qy = (qwin >> t4) & 0xfu;
             const double inv = inv_p;
-            if (i != L - 1) {
+            if (t != 0) {
                 uint32_t rc = (rwin >> t4) & 0xfu;
                 if (!FAST) {
                     if ((unsigned)(i - bw + jbase) >= (unsigned)R) rc = SPX_CODE_OUT;
@@ -572,14 +579,270 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
             if (i >= 2) inv_p = sinv[i - 1]; /* prefetch for row i-1 */
-            bwd_row<G, C, FAST, W0>(bM, bI, bD, ew, qy, h, g, Wu, tlast, inv, i == 1);
+            bwd_row<G, C, FAST, W0>(bM, bI, bD, ew, qy, h, g, Wu, tlast, inv, i == 1, any_first);
             if (i == prev_row) save_row();
         }
     };
-    int i = Lw - 1;
-    const int lo = max(stop_w, 1);
-    for (; i > fast_end && i >= lo; --i) row(i, std::false_type{});
-    for (; i >= lo; --i) row(i, std::true_type{});
+    int t = 0;
+    for (; t < n_slow; ++t) row(t, std::false_type{});
+    for (; t < nbw; ++t) row(t, std::true_type{});
+}
+
+/* ====================================================================== */
+/* One lane per problem (G = 1) for the exact band width W = C: no serial passes with idle lanes.
+ * Forward: M and I of the previous row stay in VGPRs UNSCALED (the scale factor is applied when a value is
+ * read, which is the same multiplication the reference does when it rescales the row); the D row lives in
+ * LDS ([slot][lane], conflict free).  Backward: D(i,k+1) is simply the value of the previous loop iteration,
+ * so nothing but the M and I rows is kept. */
+template <int C>
+struct NibWin { /* C 4-bit codes */
+    static constexpr int NW = (C + 7) / 8;
+    uint32_t w[NW];
+    __device__ __forceinline__ uint32_t get(int c) const { return (w[c >> 3] >> (4 * (c & 7))) & 0xfu; }
+    __device__ __forceinline__ void set(int c, uint32_t v)
+    {
+        w[c >> 3] = (w[c >> 3] & ~(0xfu << (4 * (c & 7)))) | (v << (4 * (c & 7)));
+    }
+    __device__ __forceinline__ void shift_down(uint32_t v) /* slot c <- slot c+1, slot C-1 <- v */
+    {
+#pragma unroll
+        for (int k = 0; k < NW - 1; ++k) w[k] = (w[k] >> 4) | (w[k + 1] << 28);
+        w[NW - 1] >>= 4;
+        set(C - 1, v);
+    }
+    __device__ __forceinline__ void shift_up(uint32_t v) /* slot c <- slot c-1, slot 0 <- v */
+    {
+#pragma unroll
+        for (int k = NW - 1; k > 0; --k) w[k] = (w[k] << 4) | (w[k - 1] >> 28);
+        w[0] = (w[0] << 4) | v;
+    }
+};
+
+template <int C>
+__global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
+{
+    __shared__ double sD[C][64];
+    const int lane = threadIdx.x & 63;
+    HmmC h;
+    int hasN;
+    const Prob P = load_problem<1>(B, lane, h, hasN);
+    const bool act = P.act;
+    const int L = P.L, R = P.R, bw = P.bw;
+    const int Lw = wave_max(L);
+    if (Lw == 0) return;
+    const int anyN = wave_max(hasN);
+    const int fast_end = anyN ? 1 : min(wave_min(act ? R - bw : 0x7fffffff), Lw);
+    double fM[C], fI[C];
+    NibWin<C> cw;
+    double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
+    double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
+    const int64_t fstride = B.fsave_stride;
+    const int SLOTS = (int)(fstride >> 1);
+    const int nrows = P.nrows, row0 = P.row0;
+    int wnext = 0;
+    int next_row = nrows > 0 ? B.rows[row0] : 0x7fffffff;
+    double inv_prev = 1.0, s_cur = 1.0;
+    auto save_row = [&](double inv) {
+        double *dst = fsave + (int64_t)wnext * fstride;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dst[c] = fM[c] * inv; dst[SLOTS + c] = fI[c] * inv; }
+        wnext++;
+        next_row = wnext < nrows ? B.rows[row0 + wnext] : 0x7fffffff;
+    };
+    /* row 1 */
+    {
+        const double bM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_BM] : 0.0;
+        const double bI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_BI] : 0.0;
+        const uint32_t qy = act ? fetch_code(B.qry4, P.qry0, 0, L) : 0;
+#pragma unroll
+        for (int k = 0; k < NibWin<C>::NW; ++k) cw.w[k] = 0;
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const uint32_t code = act ? fetch_code(B.ref4, P.ref0, c - bw, R) : SPX_CODE_OUT;
+            cw.set(c, code);
+            const bool valid = !(code & SPX_CODE_OUT);
+            const double e = emission<false>(code, qy, h.e_match, h.e_mis);
+            fM[c] = valid ? e * bM : 0.0;
+            fI[c] = valid ? SPX_EI * bI : 0.0;
+            sD[c][lane] = 0.0;
+            const double tt = fM[c] + fI[c];
+            s = valid ? s + tt : s;
+        }
+        s_cur = s;
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { fM[c] = fM[c] / s; fI[c] = fI[c] / s; }
+            sinv[1] = 1.0 / s;
+            inv_prev = 1.0; /* row 1 is stored already divided, as the reference does */
+            if (next_row == 1) save_row(1.0);
+        }
+    }
+    auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };
+    auto qry_chunk = [&](int ib) { return fetch8_aligned(B.qry4, P.qry0 + (ib - 1)); };
+    uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
+    uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
+    auto row = [&](int i, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        if (act && i <= L) {
+            const uint32_t t4 = (uint32_t)((i - 1) & 7) * 4u;
+            if (t4 == 0) {
+                qwin = qwin_n; rwin = rwin_n;
+                qwin_n = qry_chunk(i + 8); rwin_n = ref_chunk(i + 8);
+            }
+            const uint32_t qy = (qwin >> t4) & 0xfu;
+            uint32_t rc = (rwin >> t4) & 0xfu;
+            if (!FAST) {
+                if ((unsigned)(i - bw + (C - 1) - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
+            }
+            cw.shift_down(rc);
+            const double ip = inv_prev;
+            double pM = fM[0] * ip, pI = fI[0] * ip; /* scaled row i-1 at the current slot */
+            double d = 0.0, s = 0.0, prevM = 0.0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double pD = sD[c][lane] * ip;
+                const double S = (h.m0 * pM + h.m3 * pI) + h.m6 * pD;
+                const uint32_t code = cw.get(c);
+                const double e = emission<FAST>(code, qy, h.e_match, h.e_mis);
+                const double newM = e * S;
+                double nM = 0.0, nI = 0.0; /* scaled row i-1 at slot c+1 (the slot above the band is empty) */
+                if (c + 1 < C) { nM = fM[c + 1] * ip; nI = fI[c + 1] * ip; }
+                const double newI = SPX_EI * (h.m1 * nM + h.m4 * nI);
+                const double dn = h.m2 * prevM + h.m8 * d;
+                const bool valid = FAST || !(code & SPX_CODE_OUT);
+                d = valid ? dn : 0.0;
+                sD[c][lane] = d;
+                const double tt = (newM + newI) + d;
+                s = valid ? s + tt : s;
+                fM[c] = newM; fI[c] = newI;
+                prevM = newM;
+                pM = nM; pI = nI;
+            }
+            const double inv = 1.0 / s;
+            s_cur = s;
+            inv_prev = inv;
+            sinv[i] = inv;
+            if (i == next_row) save_row(inv);
+        }
+    };
+    int i = 2;
+    for (; i <= fast_end; ++i) row(i, std::true_type{});
+    for (; i <= Lw; ++i) row(i, std::false_type{});
+    /* terminal: s[L+1] over the scaled row L */
+    if (act) {
+        const double sM = B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SM], sI = B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SI];
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int k = L - bw + c;
+            const double tt = (fM[c] * inv_prev) * sM + (fI[c] * inv_prev) * sI;
+            s = (k >= 1 && k <= R) ? s + tt : s;
+        }
+        sinv[L] = s_cur;
+        sinv[L + 1] = s;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(64, 2) void baq_bwd1_kernel(spx_dev_batch B)
+{
+    const int lane = threadIdx.x & 63;
+    HmmC h;
+    int hasN;
+    const Prob P = load_problem<1>(B, lane, h, hasN, true);
+    const bool act = P.act;
+    const int L = P.L, R = P.R, bw = P.bw;
+    const int Lw = wave_max(L);
+    if (Lw == 0) return;
+    const int nrows = P.nrows, row0 = P.row0;
+    const int stop = act ? B.rows[row0] : 0x7fffffff;
+    const int anyN = wave_max(hasN);
+    double bM[C], bI[C];
+    NibWin<C> cw;
+    const double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
+    double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
+    const int64_t fstride = B.fsave_stride;
+    const int SLOTS = (int)(fstride >> 1);
+    double inv_next = 1.0; /* scale factor still to be applied to bM,bI (1/s[i+1]); row L is stored final */
+    {
+        const double sM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SM] : 0.0;
+        const double sI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SI] : 0.0;
+        const double sL = act ? sinv[L] : 1.0, sL1 = act ? sinv[L + 1] : 1.0;
+        const double vM = (sM / sL) / sL1, vI = (sI / sL) / sL1;
+#pragma unroll
+        for (int k = 0; k < NibWin<C>::NW; ++k) cw.w[k] = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int k = L - bw + c;
+            const bool valid = act && k >= 1 && k <= R;
+            bM[c] = valid ? vM : 0.0;
+            bI[c] = valid ? vI : 0.0;
+            cw.set(c, (act && L >= 2) ? fetch_code(B.ref4, P.ref0, (L - 1) - bw + c, R) : SPX_CODE_OUT);
+        }
+    }
+    int wprev = nrows - 1;
+    int prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
+    auto save_row = [&](double inv) { /* z = f * b(scaled) replaces the forward row */
+        double *dst = fsave + (int64_t)wprev * fstride;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dst[c] = dst[c] * (bM[c] * inv); dst[SLOTS + c] = dst[SLOTS + c] * (bI[c] * inv); }
+        wprev--;
+        prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
+    };
+    if (act && prev_row == L) save_row(1.0);
+    auto ref_chunk = [&](int i0) { return fetch8(B.ref4, P.ref0 + ((i0 - 7) - bw)); };
+    auto qry_chunk = [&](int i0) { return fetch8(B.qry4, P.qry0 + (i0 - 7)); };
+    uint32_t qwin = 0, rwin = 0;
+    uint32_t qwin_n = (act && L >= 2) ? qry_chunk(L - 1) : 0, rwin_n = (act && L >= 2) ? ref_chunk(L - 1) : 0;
+    double inv_p = (act && L >= 2) ? sinv[L - 1] : 0.0;
+    const double em1 = SPX_EI * h.m1, em4 = SPX_EI * h.m4;
+    /* step t of the wave = row L-1-t of each problem (see baq_bwd_kernel) */
+    const int nb = act ? max(L - stop, 0) : 0;
+    const int nbw = wave_max(nb);
+    const int n_slow = anyN ? nbw : min(nbw, wave_max(act ? min(nb, max(0, (L - 1) - (R - bw - 1))) : 0));
+    auto row = [&](int t, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const int i = L - 1 - t;
+        const bool on = act && t < nb;
+        const bool any_first = __any(on && i == 1);
+        if (on) {
+            const uint32_t t4 = (uint32_t)(7 - (t & 7)) * 4u; /* wave-uniform */
+            if ((t & 7) == 0) {
+                qwin = qwin_n; rwin = rwin_n;
+                qwin_n = qry_chunk(i - 8);
+                rwin_n = ref_chunk(i - 8);
+            }
+            const uint32_t qy = (qwin >> t4) & 0xfu;
+            const double inv = inv_p;
+            if (t != 0) {
+                uint32_t rc = (rwin >> t4) & 0xfu;
+                if (!FAST) {
+                    if ((unsigned)(i - bw) >= (unsigned)R) rc = SPX_CODE_OUT;
+                }
+                cw.shift_up(rc);
+            }
+            if (i >= 2) inv_p = sinv[i - 1];
+            const double in = inv_next;
+            /* y = (i > 1): on row 1 every D is 0.  m8y = m8 * y keeps the recurrence at 0 there (0 + 0*0). */
+            const double ym6 = (any_first && i == 1) ? 0.0 : h.m6, ym8 = (any_first && i == 1) ? 0.0 : h.m8;
+            double d = 0.0;
+#pragma unroll
+            for (int c = C - 1; c >= 0; --c) {
+                const double e = emission<FAST>(cw.get(c), qy, h.e_match, h.e_mis) * (bM[c] * in);
+                const double bin = c > 0 ? bI[c - 1] * in : 0.0;
+                const double newM = (e * h.m0 + em1 * bin) + h.m2 * d;
+                const double newI = e * h.m3 + em4 * bin;
+                d = e * ym6 + ym8 * d;
+                bM[c] = newM; bI[c] = newI;
+            }
+            inv_next = inv;
+            if (i == prev_row) save_row(inv);
+        }
+    };
+    int t = 0;
+    for (; t < n_slow; ++t) row(t, std::false_type{});
+    for (; t < nbw; ++t) row(t, std::true_type{});
 }
 
 /* ====================================================================== */
@@ -735,16 +998,28 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 /* phase 0 = forward kernel, 1 = backward kernel, 2 = both (back to back on the same stream) */
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st)
 {
-    if (B->n_order <= 0) return hipSuccess;
+    if (B->n_order <= 0 && B->n_order_bwd <= 0) return hipSuccess;
 #define SPX_LAUNCH(G_, C_, W0_)                                                                                  \
     {                                                                                                            \
-        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw;                                                \
+        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw, blocks_b = (B->n_order_bwd + ppw - 1) / ppw;   \
         if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<G_, C_, W0_>), dim3(blocks), dim3(64), 0, st, *B);    \
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_>), dim3(blocks), dim3(64), 0, st, *B);    \
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_>), dim3(blocks_b), dim3(64), 0, st, *B);  \
     }                                                                                                            \
     break;
     switch (cls) { /* (lanes per problem, band slots per lane): keep in step with spx_prep.cpp kClass* */
-    case 0: SPX_LAUNCH(2, 21, 41) /* exactly W = 41: bw = 20, the HiFi preset on windows with R == L */
+    case 0: /* exactly W = 41 (bw = 20, the HiFi preset on windows with R == L): one lane per problem */
+    {
+        /* forward: one lane per problem (no half-idle serial passes); backward: two lanes per problem -- with 64
+         * problems per wave the divergent row saves at the wanted rows cost more than the serial passes do */
+        int blocks = (B->n_order + 63) / 64;
+        if (phase != 1) hipLaunchKernelGGL((baq_fwd1_kernel<41>), dim3(blocks), dim3(64), 0, st, *B);
+#ifdef SPX_BWD0_G1
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd1_kernel<41>), dim3((B->n_order_bwd + 63) / 64), dim3(64), 0, st, *B);
+#else
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<2, 21, 41>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, *B);
+#endif
+    }
+    break;
     case 1: SPX_LAUNCH(2, 24, 0)
     case 2: SPX_LAUNCH(4, 16, 0)
     case 3: SPX_LAUNCH(4, 26, 0)

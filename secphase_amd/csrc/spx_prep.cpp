@@ -120,7 +120,7 @@ int64_t band_cells(int L, int R, int bw)
 }
 
 static const int kClassSlots[SPX_N_CLASSES] = {42, 48, 64, 104, 128, 256, 512, 1024, 2048};
-static const int kClassLanes[SPX_N_CLASSES] = {2, 2, 4, 4, 8, 16, 32, 64, 64};
+static const int kClassLanes[SPX_N_CLASSES] = {1, 2, 4, 4, 8, 16, 32, 64, 64};
 int band_class(int W)
 {
     /* class 0 is specialised for exactly W = 41 (its instantiation has the band width as a constant);
@@ -131,6 +131,12 @@ int band_class(int W)
     return -1;
 }
 int class_lanes(int cls) { return kClassLanes[cls]; }
+/* the backward kernel of class 0 keeps two lanes per problem */
+#ifdef SPX_BWD0_G1
+int class_lanes_bwd(int cls) { return kClassLanes[cls]; }
+#else
+int class_lanes_bwd(int cls) { return cls == 0 ? 2 : kClassLanes[cls]; }
+#endif
 int class_slots(int cls) { return kClassSlots[cls]; }
 
 /* largest x in (0,1] with (int)(-4.343*log(x)+.499) >= k, by bisection on the

@@ -70,7 +70,8 @@ int effective_bw(int l_ref, int l_query, int bw_in);
 int64_t band_cells(int L, int R, int bw_eff);
 int band_class(int W); /* index into the (G,C) table, -1 if too wide */
 int class_slots(int cls);
-int class_lanes(int cls); /* lanes of a wavefront that share one problem */
+int class_lanes(int cls); /* lanes of a wavefront that share one problem (forward kernel) */
+int class_lanes_bwd(int cls);
 void phred_thresholds(double *thr /* 102 */);
 void score_tables(double *match_tbl /*256*/, double *mis_tbl /*256*/);
 

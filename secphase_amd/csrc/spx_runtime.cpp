@@ -231,29 +231,35 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     spx::HostBatch &hb = w->hb;
     const size_t np = hb.L.size(), nr = hb.rows.size(), ng = hb.grp_index.size(), nm = hb.markers.size();
     /* per-class launch order: (W, L desc), each W padded to whole waves */
-    std::vector<int32_t> order[SPX_N_CLASSES];
+    std::vector<int32_t> order[SPX_N_CLASSES], order_b[SPX_N_CLASSES];
     std::vector<int32_t> ids[SPX_N_CLASSES];
     for (size_t p = 0; p < np; ++p) {
         int cls = spx::band_class(2 * hb.bw[p] + 1);
         ids[cls].push_back((int32_t)p);
         w->cls_cells[cls] += spx::band_cells(hb.L[p], hb.R[p], hb.bw[p]);
     }
+    /* rows the backward kernel walks: L down to the first wanted row */
+    auto brows = [&](int32_t p) { return hb.n_rows[p] > 0 ? hb.L[p] - hb.rows[hb.row_off[p]] + 1 : 0; };
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
         auto &v = ids[cls];
         w->st.problems_per_class[cls] = (int64_t)v.size();
         if (v.empty()) continue;
-        std::sort(v.begin(), v.end(), [&](int32_t a, int32_t b) {
-            if (hb.bw[a] != hb.bw[b]) return hb.bw[a] < hb.bw[b];
-            if (hb.L[a] != hb.L[b]) return hb.L[a] > hb.L[b];
-            return a < b;
-        });
-        const int ppw = 64 / spx::class_lanes(cls);
-        for (size_t i = 0; i < v.size();) {
-            size_t j = i;
-            while (j < v.size() && hb.bw[v[j]] == hb.bw[v[i]]) ++j;
-            for (size_t k = i; k < j; ++k) order[cls].push_back(v[k]);
-            while (order[cls].size() % ppw) order[cls].push_back(-1);
-            i = j;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int ppw = 64 / (pass ? spx::class_lanes_bwd(cls) : spx::class_lanes(cls));
+            std::sort(v.begin(), v.end(), [&](int32_t a, int32_t b) {
+                if (hb.bw[a] != hb.bw[b]) return hb.bw[a] < hb.bw[b];
+                const int ka = pass ? brows(a) : hb.L[a], kb = pass ? brows(b) : hb.L[b];
+                if (ka != kb) return ka > kb;
+                return a < b;
+            });
+            std::vector<int32_t> &dst = pass ? order_b[cls] : order[cls];
+            for (size_t i = 0; i < v.size();) {
+                size_t j = i;
+                while (j < v.size() && hb.bw[v[j]] == hb.bw[v[i]]) ++j;
+                for (size_t k = i; k < j; ++k) dst.push_back(v[k]);
+                while (dst.size() % ppw) dst.push_back(-1);
+                i = j;
+            }
         }
     }
     /* scratch offsets */
@@ -273,11 +279,14 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     size_t o_ref_nib = cv.take<int64_t>(np), o_qry_nib = cv.take<int64_t>(np), o_L = cv.take<int32_t>(np),
            o_R = cv.take<int32_t>(np), o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N),
            o_row_off = cv.take<int32_t>(np), o_n_rows = cv.take<int32_t>(np), o_s_off = cv.take<int64_t>(np),
-           o_fs_off = cv.take<int64_t>(np), o_qry4 = cv.take<uint8_t>(hb.qry4.size() + 128),
+           o_fs_off = cv.take<int64_t>(np), o_qry4 = cv.take<uint8_t>(hb.qry4.size() + 256), /* 128-byte lead pad + slack: chunked fetches reach a few codes outside a window */
            o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr), o_rawq = cv.take<uint8_t>(nr),
            o_row_prob = cv.take<int32_t>(nr), o_prob_slots = cv.take<int32_t>(np);
-    size_t o_order[SPX_N_CLASSES];
-    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) o_order[cls] = cv.take<int32_t>(order[cls].size());
+    size_t o_order[SPX_N_CLASSES], o_order_b[SPX_N_CLASSES];
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+        o_order[cls] = cv.take<int32_t>(order[cls].size());
+        o_order_b[cls] = cv.take<int32_t>(order_b[cls].size());
+    }
     size_t o_mk_first = cv.take<int32_t>(ng + 1), o_markers = cv.take<spx_dev_marker>(nm), o_naln = cv.take<uint8_t>(ng),
            o_sec = cv.take<uint16_t>(ng), o_gidx = cv.take<int32_t>(ng);
     const size_t in_bytes = cv.off;
@@ -311,9 +320,9 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
                           c->stream))
     UP(o_ref_nib, hb.ref_nib); UP(o_qry_nib, hb.qry_nib); UP(o_L, hb.L); UP(o_R, hb.R); UP(o_bw, hb.bw);
     UP(o_hmm, hb.hmm); UP(o_row_off, hb.row_off); UP(o_n_rows, hb.n_rows); UP(o_s_off, s_off); UP(o_fs_off, fsave_off);
-    UP(o_qry4, hb.qry4); UP(o_rows, hb.rows); UP(o_expect, hb.row_expect); UP(o_rawq, hb.row_rawq);
+    UP(o_qry4 + 128, hb.qry4); UP(o_rows, hb.rows); UP(o_expect, hb.row_expect); UP(o_rawq, hb.row_rawq);
     UP(o_row_prob, row_prob); UP(o_prob_slots, prob_slots);
-    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) UP(o_order[cls], order[cls]);
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) { UP(o_order[cls], order[cls]); UP(o_order_b[cls], order_b[cls]); }
     UP(o_mk_first, hb.mk_first); UP(o_markers, hb.markers); UP(o_naln, hb.n_aln); UP(o_sec, hb.sec_mask);
     UP(o_gidx, hb.grp_index);
 #undef UP
@@ -336,7 +345,9 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
         w->cls_used[cls] = !order[cls].empty();
         if (w->cls_used[cls] && (w->main_cls < 0 || w->cls_cells[cls] > w->cls_cells[w->main_cls])) w->main_cls = cls;
         B.order = (const int32_t *)(base + o_order[cls]);
+        B.order_bwd = (const int32_t *)(base + o_order_b[cls]);
         B.n_order = (int32_t)order[cls].size();
+        B.n_order_bwd = (int32_t)order_b[cls].size();
         B.ref_nib = (const int64_t *)(base + o_ref_nib);
         B.qry_nib = (const int64_t *)(base + o_qry_nib);
         B.L = (const int32_t *)(base + o_L);
@@ -347,7 +358,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
         B.n_rows = (const int32_t *)(base + o_n_rows);
         B.s_off = (const int64_t *)(base + o_s_off);
         B.ref4 = c->d_ref4;
-        B.qry4 = (const uint8_t *)(base + o_qry4);
+        B.qry4 = (const uint8_t *)(base + o_qry4 + 128);
         B.rows = (const int32_t *)(base + o_rows);
         B.row_expect = (const int32_t *)(base + o_expect);
         B.row_rawq = (const uint8_t *)(base + o_rawq);
@@ -463,8 +474,10 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     /* the class holding most of the band cells runs on the main stream (its forward and backward kernels are
      * bracketed by events); the others run beside it on their own streams */
     const int mc = w->main_cls;
+    static const bool serial = getenv("SPX_SERIAL") != nullptr; /* diagnostics: one class after the other */
     for (int cls = SPX_N_CLASSES - 1; cls >= 0; --cls) {
         if (!w->cls_used[cls] || cls == mc) continue;
+        if (serial) { HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->stream)); continue; }
         HIPCHK(hipStreamWaitEvent(c->cls_stream[cls], c->ev[0], 0));
         HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->cls_stream[cls]));
         HIPCHK(hipEventRecord(c->cls_done[cls], c->cls_stream[cls]));
@@ -477,7 +490,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         HIPCHK(hipEventRecord(c->ev[5], c->stream));
     }
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
-        if (w->cls_used[cls] && cls != mc) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
+        if (w->cls_used[cls] && cls != mc && !serial) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
     HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, (int32_t)w->hb.markers.size(), w->d_posmin, c->stream));
