@@ -132,14 +132,33 @@ __device__ __forceinline__ uint32_t phred_from_x(double x, const double *__restr
     return lo > 100 ? 99u : (uint32_t)lo;
 }
 
+/* where the D row of a problem lives: in VGPRs (scaled together with M and I), or in LDS ([slot][lane],
+ * bank-conflict free, left UNSCALED: the factor is applied when the value is read back in the next row,
+ * which is the very multiplication the reference performs when it rescales the row).  LDS storage frees
+ * 2*C VGPRs per lane, which is what lets wide (ONT) bands use 4 lanes per problem instead of 8. */
+template <int C>
+struct DRegs {
+    static constexpr bool lds = false;
+    double v[C];
+    __device__ __forceinline__ double get(int c) const { return v[c]; }
+    __device__ __forceinline__ void set(int c, double x) { v[c] = x; }
+};
+template <int C>
+struct DLds {
+    static constexpr bool lds = true;
+    double *base; /* &sD[0][lane] */
+    __device__ __forceinline__ double get(int c) const { return base[c * 64]; }
+    __device__ __forceinline__ void set(int c, double x) { base[c * 64] = x; }
+};
+
 struct HmmC {
     double m0, m1, m2, m3, m4, m6, m8, e_match, e_mis;
 };
 
 /* one forward row (i >= 2), in place: on entry fM,fI,fD = scaled row i-1; on exit scaled row i.
  * Returns the row sum s[i]. */
-template <int G, int C, bool FAST, int W0>
-__device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], double (&fD)[C], const CodeWin<C> &ew,
+template <int G, int C, bool FAST, int W0, class DS>
+__device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &D, double dinv, const CodeWin<C> &ew,
                                           uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double &inv_out)
 {
     double nM = shfl_down1<G>(fM[0]), nI = shfl_down1<G>(fI[0]);
@@ -147,7 +166,8 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
     /* parallel phase: fM<-M(i,.), fI<-I(i,.), fD<-m2*M(i,k-1) */
     double prevM;
     {
-        const double S0 = (h.m0 * fM[0] + h.m3 * fI[0]) + h.m6 * fD[0];
+        const double pD0 = DS::lds ? D.get(0) * dinv : D.get(0);
+        const double S0 = (h.m0 * fM[0] + h.m3 * fI[0]) + h.m6 * pD0;
         const double e0 = emission<FAST>(ew.get(0), qy, h.e_match, h.e_mis);
         const double pMn = C > 1 ? fM[1] : nM, pIn = C > 1 ? fI[1] : nI;
         prevM = e0 * S0;
@@ -156,19 +176,20 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
     }
 #pragma unroll
     for (int c = 1; c < C; ++c) {
-        const double S = (h.m0 * fM[c] + h.m3 * fI[c]) + h.m6 * fD[c];
+        const double pD = DS::lds ? D.get(c) * dinv : D.get(c);
+        const double S = (h.m0 * fM[c] + h.m3 * fI[c]) + h.m6 * pD;
         const double e = emission<FAST>(ew.get(c), qy, h.e_match, h.e_mis);
         const double pMn = (c + 1 < C) ? fM[c + 1] : nM, pIn = (c + 1 < C) ? fI[c + 1] : nI;
         const double newM = e * S;
         fI[c] = SPX_EI * (h.m1 * pMn + h.m4 * pIn);
-        fD[c] = h.m2 * prevM;
+        D.set(c, h.m2 * prevM);
         fM[c] = newM;
         prevM = newM;
     }
     {
         double pl = shfl_up1<G>(prevM);
         if (g == 0 || g > tlast) pl = 0.0; /* lanes beyond the band keep exact zeros */
-        fD[0] = h.m2 * pl;
+        D.set(0, h.m2 * pl);
     }
     /* serial phase: D recurrence and row sum in column order, one lane of the group at a time.
      * Straight-line code only (uniform selects, no branches inside the unrolled register arrays). */
@@ -176,11 +197,19 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
     for (int t = 0; t <= tlast; ++t) {
         if (g == t) {
             double d = carryD, s = carryS;
+            /* LDS mode: fetch the whole m2*M(i,k-1) row of this lane first (independent reads, pipelined),
+             * so that the recurrence below never waits on the LDS */
+            double av[DS::lds ? C : 1];
+            if constexpr (DS::lds) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) av[c] = D.get(c);
+            }
+            auto Aget = [&](int c) { if constexpr (DS::lds) return av[c]; else return D.get(c); };
             if (FAST && t < tlast) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    d = fD[c] + h.m8 * d;
-                    fD[c] = d;
+                    d = Aget(c) + h.m8 * d;
+                    D.set(c, d);
                     s = s + ((fM[c] + fI[c]) + d);
                 }
             } else {
@@ -190,9 +219,9 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
                 for (int c = 0; c < C; ++c) {
                     /* slots beyond the band (c >= nc) keep D = 0: it feeds M of that slot in the next row */
                     const bool valid = (c < nc) && (FAST || !(ew.get(c) & SPX_CODE_OUT));
-                    const double dn = fD[c] + h.m8 * d;
+                    const double dn = Aget(c) + h.m8 * d;
                     d = valid ? dn : 0.0;
-                    fD[c] = d;
+                    D.set(c, d);
                     const double tt = (fM[c] + fI[c]) + d;
                     s = (FAST || valid) ? s + tt : s; /* FAST: pad slots hold exact zeros */
                 }
@@ -207,15 +236,18 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], doub
     const double tot = __shfl(mysum, tlast, G);
     const double inv = 1.0 / tot;
 #pragma unroll
-    for (int c = 0; c < C; ++c) { fM[c] *= inv; fI[c] *= inv; fD[c] *= inv; }
+    for (int c = 0; c < C; ++c) {
+        fM[c] *= inv; fI[c] *= inv;
+        if constexpr (!DS::lds) D.v[c] *= inv;
+    }
     inv_out = inv;
     return tot;
 }
 
 /* one backward row (1 <= i <= L-1), in place: on entry bM,bI = scaled row i+1; on exit scaled row i.
  * ew holds the code of column k+1 (ref index i - bw + j) per slot. */
-template <int G, int C, bool FAST, int W0>
-__device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double (&bD)[C], const CodeWin<C> &ew,
+template <int G, int C, bool FAST, int W0, class DS>
+__device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], DS &D, const CodeWin<C> &ew,
                                         uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double inv, bool first_row, bool any_first)
 {
     double lI = shfl_up1<G>(bI[C - 1]);
@@ -228,7 +260,7 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double
         const double bin = c > 0 ? bI[c - 1] : lI;
         const double u = e * h.m0 + em1 * bin;
         const double v = e * h.m3 + em4 * bin;
-        bD[c] = e * h.m6;
+        D.set(c, e * h.m6);
         bM[c] = u;
         bI[c] = v;
     }
@@ -238,19 +270,25 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double
         for (int t = tlast; t >= 0; --t) {
             if (g == t) {
                 double d = carryD;
+                double xv[DS::lds ? C : 1];
+                if constexpr (DS::lds) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) xv[c] = D.get(c);
+                }
+                auto Xget = [&](int c) { if constexpr (DS::lds) return xv[c]; else return D.get(c); };
                 if (t < tlast) {
 #pragma unroll
                     for (int c = C - 1; c >= 0; --c) {
-                        d = bD[c] + h.m8 * d;
-                        bD[c] = d;
+                        d = Xget(c) + h.m8 * d;
+                        D.set(c, d);
                     }
                 } else {
                     const int nc = W0 ? (W0 - ((W0 - 1) / C) * C) : min(C, Wu - t * C);
 #pragma unroll
                     for (int c = C - 1; c >= 0; --c) {
-                        const double x = (c < nc) ? bD[c] : 0.0; /* D of a column that does not exist stays 0 */
+                        const double x = (c < nc) ? Xget(c) : 0.0; /* D of a column that does not exist stays 0 */
                         d = x + h.m8 * d;
-                        bD[c] = d;
+                        D.set(c, d);
                     }
                 }
                 carryD = d;
@@ -259,15 +297,15 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], double
         }
         if (any_first) { /* wave-uniform: some problem of the wave is on its row 1 */
 #pragma unroll
-            for (int c = 0; c < C; ++c) bD[c] = first_row ? 0.0 : bD[c];
+            for (int c = 0; c < C; ++c) D.set(c, first_row ? 0.0 : D.get(c));
         }
     }
     /* parallel phase B: M += m2*D(i,k+1); scale */
-    double hD = shfl_down1<G>(bD[0]);
+    double hD = shfl_down1<G>(D.get(0));
     if (g == G - 1 || g >= tlast) hD = 0.0; /* the slot above the band has D = 0 */
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const double dn = (c + 1 < C) ? bD[c + 1] : hD; /* slots beyond the band hold D = 0 (see below) */
+        const double dn = (c + 1 < C) ? D.get(c + 1) : hD; /* slots beyond the band hold D = 0 (see below) */
         bM[c] = (bM[c] + h.m2 * dn) * inv;
         bI[c] = bI[c] * inv;
     }
@@ -331,9 +369,10 @@ __device__ __forceinline__ int wave_min(int v)
 
 /* ====================================================================== */
 /* forward pass: rows 1..L, saves 1/s[i] (i < L), s[L], s[L+1] and the scaled M,I rows at the wanted rows */
-template <int G, int C, int W0>
+template <int G, int C, int W0, bool LDSD>
 __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch B)
 {
+    __shared__ double sD[LDSD ? C : 1][64];
     constexpr int SLOTS = G * C;
     const int lane = threadIdx.x & 63;
     const int g = lane % G;
@@ -351,7 +390,10 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
     const int tlast = (Wu - 1) / C;
     const int jbase = g * C;
 
-    double fM[C], fI[C], fD[C];
+    double fM[C], fI[C];
+    typename std::conditional<LDSD, DLds<C>, DRegs<C>>::type D;
+    if constexpr (LDSD) D.base = &sD[0][lane];
+    double dinv = 1.0; /* LDS mode: factor still to be applied to the stored D row */
     CodeWin<C> cw, padw; /* padw: SPX_CODE_OUT in the slots beyond the band (j >= W), fixed per problem */
     double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
     double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
@@ -391,7 +433,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
             const double e = emission<false>(code, qy, h.e_match, h.e_mis);
             fM[c] = valid ? e * bM : 0.0;
             fI[c] = valid ? SPX_EI * bI : 0.0;
-            fD[c] = 0.0;
+            D.set(c, 0.0);
         }
         double carry = 0.0, mysum = 0.0;
         for (int t = 0; t <= tlast; ++t) {
@@ -446,7 +488,8 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
             double inv;
-            s_cur = fwd_row<G, C, FAST, W0>(fM, fI, fD, ew, qy, h, g, Wu, tlast, inv);
+            s_cur = fwd_row<G, C, FAST, W0>(fM, fI, D, dinv, ew, qy, h, g, Wu, tlast, inv);
+            dinv = inv;
             if (g == 0) sinv[i] = inv;
             if (i == next_row) save_row();
         }
@@ -482,9 +525,10 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
 /* ====================================================================== */
 /* backward pass: rows L..(first wanted row), MAP + phred + write-back rule at the wanted rows.
  * Rows below the first wanted row have no observable effect and are not computed. */
-template <int G, int C, int W0>
+template <int G, int C, int W0, bool LDSD>
 __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch B)
 {
+    __shared__ double sD[LDSD ? C : 1][64];
     constexpr int SLOTS = G * C;
     const int lane = threadIdx.x & 63;
     const int g = lane % G;
@@ -502,7 +546,9 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
     const int tlast = (Wu - 1) / C;
     const int jbase = g * C;
 
-    double bM[C], bI[C], bD[C];
+    double bM[C], bI[C];
+    typename std::conditional<LDSD, DLds<C>, DRegs<C>>::type D;
+    if constexpr (LDSD) D.base = &sD[0][lane];
     CodeWin<C> cw, padw;
     const double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
     const int64_t fstride = B.fsave_stride;
@@ -520,7 +566,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
             const bool valid = act && j < Wu && k >= 1 && k <= R;
             bM[c] = valid ? vM : 0.0;
             bI[c] = valid ? vI : 0.0;
-            bD[c] = 0.0;
+            D.set(c, 0.0);
             padw.set(c, j < Wu ? 0u : (uint32_t)SPX_CODE_OUT);
             /* window for row L-1: code of ref idx (L-1) - bw + j (= column k+1 of that row) */
             cw.set(c, (act && L >= 2) ? fetch_code(B.ref4, P.ref0, (L - 1) - bw + j, R) : SPX_CODE_OUT);
@@ -579,7 +625,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
             if (i >= 2) inv_p = sinv[i - 1]; /* prefetch for row i-1 */
-            bwd_row<G, C, FAST, W0>(bM, bI, bD, ew, qy, h, g, Wu, tlast, inv, i == 1, any_first);
+            bwd_row<G, C, FAST, W0>(bM, bI, D, ew, qy, h, g, Wu, tlast, inv, i == 1, any_first);
             if (i == prev_row) save_row();
         }
     };
@@ -999,12 +1045,12 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st)
 {
     if (B->n_order <= 0 && B->n_order_bwd <= 0) return hipSuccess;
-#define SPX_LAUNCH(G_, C_, W0_)                                                                                  \
-    {                                                                                                            \
-        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw, blocks_b = (B->n_order_bwd + ppw - 1) / ppw;   \
-        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<G_, C_, W0_>), dim3(blocks), dim3(64), 0, st, *B);    \
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_>), dim3(blocks_b), dim3(64), 0, st, *B);  \
-    }                                                                                                            \
+#define SPX_LAUNCH(G_, C_, W0_, LDS_)                                                                                  \
+    {                                                                                                                  \
+        int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw, blocks_b = (B->n_order_bwd + ppw - 1) / ppw;         \
+        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<G_, C_, W0_, LDS_>), dim3(blocks), dim3(64), 0, st, *B);    \
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_, LDS_>), dim3(blocks_b), dim3(64), 0, st, *B);  \
+    }                                                                                                                  \
     break;
     switch (cls) { /* (lanes per problem, band slots per lane): keep in step with spx_prep.cpp kClass* */
     case 0: /* exactly W = 41 (bw = 20, the HiFi preset on windows with R == L): one lane per problem */
@@ -1016,18 +1062,20 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
 #ifdef SPX_BWD0_G1
         if (phase != 0) hipLaunchKernelGGL((baq_bwd1_kernel<41>), dim3((B->n_order_bwd + 63) / 64), dim3(64), 0, st, *B);
 #else
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<2, 21, 41>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, *B);
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<2, 21, 41, false>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, *B);
 #endif
     }
     break;
-    case 1: SPX_LAUNCH(2, 24, 0)
-    case 2: SPX_LAUNCH(4, 16, 0)
-    case 3: SPX_LAUNCH(4, 26, 0)
-    case 4: SPX_LAUNCH(8, 16, 0)
-    case 5: SPX_LAUNCH(16, 16, 0)
-    case 6: SPX_LAUNCH(32, 16, 0)
-    case 7: SPX_LAUNCH(64, 16, 0)
-    case 8: SPX_LAUNCH(64, 32, 0)
+    case 1: SPX_LAUNCH(2, 24, 0, false)
+    case 2: SPX_LAUNCH(4, 16, 0, false)
+    /* (4,28)/(4,32) with the D row in LDS (DLds) were measured for the ONT bands: parity-clean but slower than
+     * these -- four SIMDs share one LDS pipe and the row traffic saturates it */
+    case 3: SPX_LAUNCH(4, 26, 0, false)
+    case 4: SPX_LAUNCH(8, 16, 0, false)
+    case 5: SPX_LAUNCH(16, 16, 0, false)
+    case 6: SPX_LAUNCH(32, 16, 0, false)
+    case 7: SPX_LAUNCH(64, 16, 0, false)
+    case 8: SPX_LAUNCH(64, 32, 0, false)
     default: return hipErrorInvalidValue;
     }
 #undef SPX_LAUNCH
