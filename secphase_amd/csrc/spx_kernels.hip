@@ -1052,32 +1052,34 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
         if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_, LDS_>), dim3(blocks_b), dim3(64), 0, st, *B);  \
     }                                                                                                                  \
     break;
-    switch (cls) { /* (lanes per problem, band slots per lane): keep in step with spx_prep.cpp kClass* */
-    case 0: /* exactly W = 41 (bw = 20, the HiFi preset on windows with R == L): one lane per problem */
-    {
-        /* forward: one lane per problem (no half-idle serial passes); backward: two lanes per problem -- with 64
-         * problems per wave the divergent row saves at the wanted rows cost more than the serial passes do */
-        int blocks = (B->n_order + 63) / 64;
-        if (phase != 1) hipLaunchKernelGGL((baq_fwd1_kernel<41>), dim3(blocks), dim3(64), 0, st, *B);
-#ifdef SPX_BWD0_G1
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd1_kernel<41>), dim3((B->n_order_bwd + 63) / 64), dim3(64), 0, st, *B);
-#else
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<2, 21, 41, false>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, *B);
-#endif
-    }
+    /* exact-width classes (the HiFi preset: bw = 20 + |R-L|): forward with one lane per problem (no half-idle serial
+     * passes), backward with two lanes per problem -- with 64 problems per wave the divergent row saves at the
+     * wanted rows cost more than the serial passes do */
+#define SPX_LAUNCH_EXACT(W_, CB_)                                                                                      \
+    {                                                                                                                  \
+        if (phase != 1) hipLaunchKernelGGL((baq_fwd1_kernel<W_>), dim3((B->n_order + 63) / 64), dim3(64), 0, st, *B);  \
+        if (phase != 0)                                                                                                \
+            hipLaunchKernelGGL((baq_bwd_kernel<2, CB_, W_, false>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, *B); \
+    }                                                                                                                  \
     break;
-    case 1: SPX_LAUNCH(2, 24, 0, false)
-    case 2: SPX_LAUNCH(4, 16, 0, false)
+    switch (cls) { /* keep in step with spx_prep.cpp kClass* */
+    case 0: SPX_LAUNCH_EXACT(41, 21)
+    case 1: SPX_LAUNCH_EXACT(43, 22)
+    case 2: SPX_LAUNCH_EXACT(45, 23)
+    case 3: SPX_LAUNCH_EXACT(47, 24)
+    case 4: SPX_LAUNCH(2, 24, 0, false)
+    case 5: SPX_LAUNCH(4, 16, 0, false)
     /* (4,28)/(4,32) with the D row in LDS (DLds) were measured for the ONT bands: parity-clean but slower than
      * these -- four SIMDs share one LDS pipe and the row traffic saturates it */
-    case 3: SPX_LAUNCH(4, 26, 0, false)
-    case 4: SPX_LAUNCH(8, 16, 0, false)
-    case 5: SPX_LAUNCH(16, 16, 0, false)
-    case 6: SPX_LAUNCH(32, 16, 0, false)
-    case 7: SPX_LAUNCH(64, 16, 0, false)
-    case 8: SPX_LAUNCH(64, 32, 0, false)
+    case 6: SPX_LAUNCH(4, 26, 0, false)
+    case 7: SPX_LAUNCH(8, 16, 0, false)
+    case 8: SPX_LAUNCH(16, 16, 0, false)
+    case 9: SPX_LAUNCH(32, 16, 0, false)
+    case 10: SPX_LAUNCH(64, 16, 0, false)
+    case 11: SPX_LAUNCH(64, 32, 0, false)
     default: return hipErrorInvalidValue;
     }
+#undef SPX_LAUNCH_EXACT
 #undef SPX_LAUNCH
     return hipGetLastError();
 }

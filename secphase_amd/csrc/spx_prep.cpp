@@ -119,24 +119,22 @@ int64_t band_cells(int L, int R, int bw)
     return c;
 }
 
-static const int kClassSlots[SPX_N_CLASSES] = {42, 48, 64, 104, 128, 256, 512, 1024, 2048};
-static const int kClassLanes[SPX_N_CLASSES] = {1, 2, 4, 4, 8, 16, 32, 64, 64};
+/* band classes = kernel instantiations (spx_launch_baq): four exact widths, then generic ones by capacity */
+static const int kClassSlots[SPX_N_CLASSES] = {42, 44, 46, 48, 48, 64, 104, 128, 256, 512, 1024, 2048};
+static const int kClassLanes[SPX_N_CLASSES] = {1, 1, 1, 1, 2, 4, 4, 8, 16, 32, 64, 64};
+static const int kClassLanesBwd[SPX_N_CLASSES] = {2, 2, 2, 2, 2, 4, 4, 8, 16, 32, 64, 64};
 int band_class(int W)
 {
-    /* class 0 is specialised for exactly W = 41 (its instantiation has the band width as a constant);
-     * narrower bands (short windows, small -b) go to class 1 */
     if (W == 41) return 0;
-    for (int c = 1; c < SPX_N_CLASSES; ++c)
+    if (W == 43) return 1;
+    if (W == 45) return 2;
+    if (W == 47) return 3;
+    for (int c = 4; c < SPX_N_CLASSES; ++c)
         if (W <= kClassSlots[c]) return c;
     return -1;
 }
 int class_lanes(int cls) { return kClassLanes[cls]; }
-/* the backward kernel of class 0 keeps two lanes per problem */
-#ifdef SPX_BWD0_G1
-int class_lanes_bwd(int cls) { return kClassLanes[cls]; }
-#else
-int class_lanes_bwd(int cls) { return cls == 0 ? 2 : kClassLanes[cls]; }
-#endif
+int class_lanes_bwd(int cls) { return kClassLanesBwd[cls]; }
 int class_slots(int cls) { return kClassSlots[cls]; }
 
 /* largest x in (0,1] with (int)(-4.343*log(x)+.499) >= k, by bisection on the
