@@ -215,7 +215,7 @@ def main():
         # FP64 vector-ALU bound (not HBM, not MFMA): 19 of the 45 flops per band cell are forward flops.
         st0 = per_launch[0]
         G, slots = st0.main_class_lanes, st0.main_class_slots
-        kname = f"baq_fwd_kernel<{G}, {slots // G}>"
+        kname = f"baq_fwd1_kernel<{slots - 1}>" if G == 1 else f"baq_fwd_kernel<{G}, {slots // G}, 0, false>"
         fwd_ms = sum(p.main_fwd_ms for p in per_launch) / len(per_launch)
         bwd_ms = sum(p.main_bwd_ms for p in per_launch) / len(per_launch)
         cls_cells = sum(p.main_class_cells for p in per_launch) / len(per_launch)
