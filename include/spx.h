@@ -116,6 +116,10 @@ int spx_sync(spx_ctx *ctx);
  * 63 pass.  Asynchronous on the ctx stream; returns the number of records (>= 0) or SPX_E*. */
 int spx_pack_decisions(spx_ctx *ctx, spx_work *work, int32_t group_base, void *device_out, int64_t capacity);
 int spx_collect(spx_ctx *ctx, spx_work *work, spx_group_out *out);
+/* Quality arrays as the reference leaves them in the records after calc_local_baq (ptMarker.c:706,759,763),
+ * for a work list prepared with params.flags & SPX_PAR_ALL_ROWS and already launched.  `qual` must hold a copy
+ * of bt->qual (same qual_off layout) for batch number batch_index of spx_prepare_many; it is edited in place. */
+int spx_apply_quals(spx_ctx *ctx, spx_work *w, int32_t batch_index, const spx_batch *bt, uint8_t *qual);
 int spx_work_stats(const spx_work *work, spx_stats *stats);
 void spx_work_free(spx_ctx *ctx, spx_work *work);
 
@@ -175,6 +179,15 @@ int spx_bam_bind_reference(spx_bam_reader *r, const spx_ref *ref);
  * the batch is owned by the reader and valid until the next call; returns groups read, 0 at EOF, <0 on error */
 int spx_bam_next_batch(spx_bam_reader *r, int32_t max_groups, const spx_batch **out);
 void spx_bam_close(spx_bam_reader *r);
+/* -w/--writeBam (src/secphase.c:182-189,643-657): the reference opens the output with sam_open(path, "w"), i.e.
+ * SAM text despite the .bam name, writes the input header (sam_hdr_write) and then sam_write1()s every stored
+ * alignment of every dispatched group with the qualities calc_local_baq left in the record.
+ * spx_sam_write_group formats group g of the reader's CURRENT batch; qual is laid out like that batch's qual[]
+ * (what spx_apply_quals produced) or NULL for the record's own qualities.  Returns records written. */
+typedef struct spx_sam_writer spx_sam_writer;
+int spx_sam_open(const char *path, const spx_bam_reader *src, spx_sam_writer **out);
+int spx_sam_write_group(spx_sam_writer *w, const spx_bam_reader *src, int32_t g, const uint8_t *qual);
+int spx_sam_close(spx_sam_writer *w);
 int spx_fasta_load(const char *path, spx_fasta **out);
 const spx_ref *spx_fasta_ref(const spx_fasta *f);
 void spx_fasta_free(spx_fasta *f);
@@ -202,6 +215,10 @@ typedef struct spx_plan_view {
     const uint16_t *sec_mask;
     const int32_t *rfe;                  /* 10 per group */
     const int32_t *grp_error;            /* per INPUT group: 0 ok, 1 not dispatched, <0 SPX_E* */
+    /* SPX_PAR_ALL_ROWS only: calc_local_baq's writes to the record qualities, in order.  len 0: qual[rec][pos]=0;
+     * len>0: qual[rec][pos..pos+len) = BAQ value of wanted rows row0.. (row_expect<0: min(set_q,93)) */
+    int32_t n_qedits, pad_;
+    const int32_t *qe_rec, *qe_pos, *qe_len, *qe_row0;
 } spx_plan_view;
 int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const spx_params *par, spx_plan **out);
 int spx_plan_get(const spx_plan *plan, spx_plan_view *view);

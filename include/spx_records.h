@@ -83,6 +83,10 @@ typedef struct spx_ref {
 
 /* Scoring parameters = the subset of work_arg_t (tpool.h:26-55) the marker
  * path reads; defaults and presets are secphase.c:420-449,477-504. */
+/* spx_params.flags: every base of every realigned window gets its BAQ value (the quality-modified output
+ * of -w/--writeBam, secphase.c:182-189), not only the marker bases the scores need */
+#define SPX_PAR_ALL_ROWS 1
+
 typedef struct spx_params {
     int32_t baq_flag;
     int32_t consensus;
@@ -91,7 +95,7 @@ typedef struct spx_params {
     int32_t min_score;
     int32_t set_q;
     int32_t flank_margin;
-    int32_t reserved;
+    int32_t flags;     /* SPX_PAR_*; 0 on the scoring path */
     double prim_margin_score;
     double prim_margin_random;
     double conf_d;

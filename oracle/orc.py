@@ -77,6 +77,9 @@ def lib():
         L.orc_run_batch_bed.restype = C.c_int
         L.orc_run_batch_bed.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
                                         C.c_uint, C.POINTER(GroupResult), C.c_char_p, C.c_char_p, C.c_char_p]
+        L.orc_run_batch_quals.restype = C.c_int
+        L.orc_run_batch_quals.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
+                                          C.POINTER(GroupResult), C.POINTER(C.c_uint8)]
         ip = C.POINTER(C.c_int)
         L.orc_blocks_sort.argtypes = [C.c_int, ip, ip, ip]
         L.orc_blocks_sort.restype = None
@@ -86,6 +89,14 @@ def lib():
         L.orc_walk_cigar.argtypes = [C.POINTER(SpxBatch), C.c_int, C.POINTER(C.POINTER(Op))]
         _lib = L
     return _lib
+
+
+def run_batch_quals(batch, ref, params, qual, threads=1):
+    """qual: writable uint8 numpy copy of the batch's qual[]; edited in place as calc_local_baq would"""
+    n = batch.contents.n_groups if hasattr(batch, "contents") else batch.n_groups
+    res = (GroupResult * n)()
+    lib().orc_run_batch_quals(batch, ref, C.byref(params), threads, res, qual.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return qual, res
 
 
 def run_batch(batch, ref, params, threads=1, seed=1, log_path=None, reuse_scratch=False, bed_modified=None,

@@ -892,6 +892,7 @@ static int group_alns(const spx_batch *bt, int g, int *amap)
 }
 
 static int g_keep_markers = 0; /* set by orc_run_batch_bed while it runs */
+static uint8_t *g_qual_sink = NULL; /* set by orc_run_batch_quals while it runs: laid out like bt->qual */
 
 /* marker branch of runOneThread up to (not including) get_best_record_index */
 static int score_group(const spx_batch *bt, const spx_ref *ref, int g, const spx_params *par, orc_group_result *out,
@@ -959,6 +960,9 @@ static int score_group(const spx_batch *bt, const spx_ref *ref, int g, const spx
         if (out->prim_idx < 0 && (al[i].flag & SPX_FSECONDARY) == 0) out->prim_idx = i;
     }
     if (g_keep_markers) { out->final_markers = mk.v; out->n_final = mk.n; mk.v = NULL; }
+    /* what sam_write1 would see at secphase.c:182-189: the record qualities after calc_local_baq */
+    if (g_qual_sink)
+        for (i = 0; i < n; ++i) memcpy(g_qual_sink + bt->qual_off[amap[i]], al[i].qual, al[i].l_qseq > 0 ? al[i].l_qseq : 0);
     free(mk.v);
     free_alns(al, n);
     return 0;
@@ -1111,6 +1115,16 @@ int orc_run_batch_bed(const spx_batch *bt, const spx_ref *ref, const spx_params 
     free(acc_mod); free(acc_mk);
     free(rc);
     return relabelled;
+}
+
+int orc_run_batch_quals(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads,
+                        orc_group_result *results, uint8_t *qual_out)
+{
+    int rc;
+    g_qual_sink = qual_out;
+    rc = orc_run_batch_bed(bt, ref, par, threads, 1, results, NULL, NULL, NULL);
+    g_qual_sink = NULL;
+    return rc;
 }
 
 int orc_run_batch(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads, unsigned rand_seed,

@@ -121,6 +121,12 @@ int orc_run_batch_bed(const spx_batch *bt, const spx_ref *ref, const spx_params 
                       orc_group_result *results, const char *log_path, const char *bed_modified_path,
                       const char *bed_marker_path);
 
+/* orc_run_batch that also returns the record qualities as calc_local_baq leaves them (ptMarker.c:706,759,763),
+ * i.e. what -w/--writeBam hands to sam_write1 (src/secphase.c:182-189).  qual_out is laid out like bt->qual and
+ * must be pre-filled with a copy of it; records of groups that are not dispatched keep their bytes. */
+int orc_run_batch_quals(const spx_batch *bt, const spx_ref *ref, const spx_params *par, int threads,
+                        orc_group_result *results, uint8_t *qual_out);
+
 /* ptBlock sort / merge (blocks_oracle.c) */
 void orc_blocks_sort(int n, int *s, int *e, int *c);
 int orc_blocks_merge(int n, const int *s, const int *e, const int *c, int *os, int *oe, int *oc);

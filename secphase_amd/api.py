@@ -66,6 +66,8 @@ class PlanView(C.Structure):
         ("grp_index", _i32p), ("mk_first", _i32p), ("mk_row", _i32p),
         ("mk_qfix", _u8p), ("mk_is_match", _u8p), ("mk_aln", _u8p), ("mk_first_of_pos", _u8p),
         ("n_aln", _u8p), ("sec_mask", _u16p), ("rfe", _i32p), ("grp_error", _i32p),
+        ("n_qedits", C.c_int32), ("pad_", C.c_int32), ("qe_rec", _i32p), ("qe_pos", _i32p), ("qe_len", _i32p),
+        ("qe_row0", _i32p),
     ]
 
 
@@ -79,6 +81,7 @@ EXPORTS = [
     "spx_merge_blocks_count", "spx_relabel_blocks",
     "spx_io_last_error", "spx_bam_open", "spx_bam_n_targets", "spx_bam_target_name", "spx_bam_bind_reference",
     "spx_bam_next_batch", "spx_bam_close", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
+    "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
 ]
 
 _lib = None
@@ -156,6 +159,10 @@ def lib():
     L.spx_fasta_ref.restype = C.POINTER(SpxRef)
     L.spx_fasta_free.argtypes = [vp]
     L.spx_fasta_free.restype = None
+    L.spx_apply_quals.argtypes = [vp, vp, C.c_int32, C.POINTER(SpxBatch), _u8p]
+    L.spx_sam_open.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
+    L.spx_sam_write_group.argtypes = [vp, vp, C.c_int32, _u8p]
+    L.spx_sam_close.argtypes = [vp]
     _lib = L
     return L
 
@@ -253,6 +260,12 @@ class Work:
         if finalize_seed is not None:
             _chk(lib().spx_finalize(C.byref(self.params), finalize_seed, out, self.n), "spx_finalize")
         return out
+
+    def apply_quals(self, batch, qual, batch_index=0):
+        """qual: writable uint8 numpy copy of the batch's qual[] (edited in place); needs params.flags & 1"""
+        _chk(lib().spx_apply_quals(self.ctx.h, self.h, batch_index, batch, qual.ctypes.data_as(_u8p)),
+             "spx_apply_quals")
+        return qual
 
     def stats(self):
         st = Stats()

@@ -4,8 +4,10 @@
  * Same options, presets, defaults and output files as the reference's main()
  * (/root/reference/programs/src/secphase.c:387-743): -i/--inputBam, -f/--inputFasta, -o/--outDir,
  * -P/--prefix, -x/--hifi, -y/--ont, -q -c -d -e -b -t -s -m -p -r -n, -@/--threads, --flankMargin.
- * Marker mode only: -v/--inputVcf, -B, -g, -G (variant mode) and -w/--writeBam are refused with a message;
- * -M (disable marker mode) leaves nothing to do.  All six output files the WDLs glob for
+ * Marker mode only: -v/--inputVcf, -B, -g, -G (variant mode) are refused with a message; -M (disable marker
+ * mode) leaves nothing to do.  -w/--writeBam writes <prefix>.quality_modified.out.bam exactly as the reference
+ * does: SAM text (sam_open(path, "w"), src/secphase.c:643-652) holding the records of every dispatched group with
+ * the qualities calc_local_baq left in them (src/secphase.c:182-189).  All six output files the WDLs glob for
  * (wdls/workflows/secphase.wdl:100-107) are created; the three variant-mode BEDs stay empty, as they do in
  * the reference when no VCF is given.
  *
@@ -20,6 +22,7 @@
 #include <sys/stat.h>
 #include <time.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -86,7 +89,9 @@ static void usage(const char *prog)
             "         --threads, -@          host threads for BGZF inflation and group preparation [4]\n"
             "         --groupsPerBatch       read groups per GPU work list [16384]\n"
             "         --device               GPU index [0]\n"
-            "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode), --writeBam/-w\n");
+            "         --writeBam, -w         Write <prefix>.quality_modified.out.bam (SAM text, as the reference does) with\n"
+            "                                the base qualities modified by BAQ\n"
+            "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode)\n");
 }
 
 int main(int argc, char *argv[])
@@ -98,7 +103,7 @@ int main(int argc, char *argv[])
     par.prim_margin_score = 40; par.prim_margin_random = 0; par.set_q = 40; par.conf_d = 1e-4; par.conf_e = 0.1;
     par.conf_b = 20; par.flank_margin = 500;
     std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
-    bool preset_ont = false, preset_hifi = false, marker_mode = true;
+    bool preset_ont = false, preset_hifi = false, marker_mode = true, write_bam = false, batch_given = false;
     int threads = 4, groups_per_batch = 16384, device = 0, c;
     const char *prog = strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0];
     while (~(c = getopt_long(argc, argv, "i:p:P:G:o:f:v:qd:e:b:n:r:m:ct:s:B:g:@:wxyMh", long_options, NULL))) {
@@ -131,14 +136,12 @@ int main(int argc, char *argv[])
         case 'n': par.min_score = atoi(optarg); break;
         case 'F': par.flank_margin = atoi(optarg); break;
         case 'M': marker_mode = false; break;
-        case 1001: groups_per_batch = atoi(optarg); break;
+        case 1001: groups_per_batch = atoi(optarg); batch_given = true; break;
         case 1002: device = atoi(optarg); break;
         case 'v': case 'B': case 'g': case 'G':
             fprintf(stderr, "[%s] variant mode (-v/-B/-g/-G) is not part of this build: marker mode only\n", timestamp());
             return 2;
-        case 'w':
-            fprintf(stderr, "[%s] --writeBam is not part of this build\n", timestamp());
-            return 2;
+        case 'w': write_bam = true; break;
         default:
             if (c != 'h') fprintf(stderr, "[E::%s] undefined option %c\n", __func__, c);
             usage(prog);
@@ -151,6 +154,10 @@ int main(int argc, char *argv[])
         return EXIT_FAILURE;
     }
     if (groups_per_batch < 1) groups_per_batch = 1;
+    /* with -w every base of every realigned window keeps its forward row in HBM until the MAP kernel has run
+     * (~0.7 KB per base): smaller work lists */
+    if (write_bam && !batch_given) groups_per_batch = 1024;
+    if (write_bam) par.flags |= SPX_PAR_ALL_ROWS;
     struct stat st;
     if (stat(dirPath.c_str(), &st) == -1) mkdir(dirPath.c_str(), 0777);
     auto out_path = [&](const char *suffix) { return dirPath + "/" + prefix + suffix; };
@@ -170,6 +177,13 @@ int main(int argc, char *argv[])
     if (spx_bam_open(inputPath.c_str(), threads, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); return 1; }
     int missing = spx_bam_bind_reference(bam, ref);
     if (missing > 0) fprintf(stderr, "[%s] warning: %d BAM target(s) are not in the FASTA; reads on them are skipped\n", timestamp(), missing);
+
+    spx_sam_writer *sam = nullptr;
+    if (write_bam && spx_sam_open(out_path(".quality_modified.out.bam").c_str(), bam, &sam) != SPX_OK) {
+        fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error());
+        return 1;
+    }
+    std::vector<uint8_t> qbuf;
 
     spx_ctx *ctx = nullptr;
     int rc = spx_create(device, &ctx);
@@ -209,6 +223,17 @@ int main(int argc, char *argv[])
             t_gpu += now_s() - t0;
             { spx_stats st; spx_work_stats(w, &st); t_hostprep += st.prep_seconds; t_h2d += st.h2d_seconds; t_kernel += st.kernel_seconds; }
             t0 = now_s();
+            if (sam) { /* src/secphase.c:182-189: written before the decision, file order = the reference at -@1 */
+                int64_t qend = 0;
+                for (int32_t a = 0; a < bt->n_alns; ++a) qend = std::max<int64_t>(qend, bt->qual_off[a] + bt->l_qseq[a]);
+                qbuf.assign(bt->qual, bt->qual + qend);
+                if ((rc = spx_apply_quals(ctx, w, 0, bt, qbuf.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
+                for (int g = 0; g < ng; ++g)
+                    if (spx_group_is_dispatched(bt, g) && spx_sam_write_group(sam, bam, g, qbuf.data()) < 0) {
+                        fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error());
+                        return 1;
+                    }
+            }
             spx_finalizer_apply(fin, &par, out.data(), ng);
             spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
             n_modified += spx_relabel_blocks(w, ref, out.data(), bed_mod, bed_mk);
@@ -229,6 +254,7 @@ int main(int argc, char *argv[])
     spx_bedset_free(bed_mod);
     spx_bedset_free(bed_mk);
     spx_finalizer_free(fin);
+    if (sam && spx_sam_close(sam) != SPX_OK) { fprintf(stderr, "[%s] could not finish the quality-modified output\n", timestamp()); return 1; }
     spx_bam_close(bam);
     spx_destroy(ctx);
     spx_fasta_free(fa);

@@ -32,6 +32,7 @@ struct Slot {
     std::vector<uint8_t> ubuf;
     std::vector<int32_t> grp_first, tid, pos, l_qseq, n_cigar;
     std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off, md_off;
+    std::vector<int64_t> rec_off; /* first byte (after block_size) of each raw BAM record in ubuf */
     std::vector<uint16_t> flag;
     std::vector<uint32_t> cigar;
     std::vector<char> qnames;
@@ -42,6 +43,7 @@ struct Slot {
     {
         grp_first.clear(); tid.clear(); pos.clear(); l_qseq.clear(); n_cigar.clear(); qname_off.clear(); cigar_off.clear();
         seq_off.clear(); qual_off.clear(); cs_off.clear(); md_off.clear(); flag.clear(); cigar.clear(); qnames.clear(); ng = 0; rc = 0;
+        rec_off.clear();
     }
 };
 
@@ -55,6 +57,7 @@ struct Reader {
     std::vector<std::string> tname;
     std::vector<int64_t> tlen;
     std::vector<int32_t> tmap; /* BAM tid -> contig index of the reference handed to the scorer (-1 unknown) */
+    std::string header_text;
     Slot slot[2];
     int cur = 0;
     std::future<void> pending; /* the NEXT batch is read while the caller works on the current one */
@@ -200,6 +203,7 @@ extern "C" int spx_bam_open(const char *path, int threads, spx_bam_reader **out)
     const int32_t l_text = le32(u.data() + 4);
     at = 8;
     if (!need(r, u, at, (size_t)l_text + 4)) return bail("truncated BAM header");
+    r->header_text.assign((const char *)u.data() + at, strnlen((const char *)u.data() + at, (size_t)l_text));
     at += (size_t)l_text;
     const int32_t n_ref = le32(u.data() + at);
     at += 4;
@@ -285,6 +289,7 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
         for (uint32_t k = 0; k < ncig; ++k) S.cigar.push_back((uint32_t)le32(cig + 4 * k));
         S.seq_off.push_back((int64_t)(sq - u.data()));
         S.qual_off.push_back((int64_t)(ql - u.data()));
+        S.rec_off.push_back((int64_t)(p - u.data()));
         const char *csz = aux <= end ? find_tag(aux, end, 'c', 's') : nullptr;
         S.cs_off.push_back(csz ? (int64_t)((const uint8_t *)csz - u.data()) : -1);
         const char *mdz = (!csz && aux <= end) ? find_tag(aux, end, 'M', 'D') : nullptr; /* only looked at without cs */
@@ -343,6 +348,164 @@ extern "C" void spx_bam_close(spx_bam_reader *h)
     if (h->r.have_pending) h->r.pending.get();
     if (h->r.fp) fclose(h->r.fp);
     delete h;
+}
+
+/* ---- -w/--writeBam: the reference opens `<prefix>.quality_modified.out.bam` with sam_open(path, "w")
+ * (src/secphase.c:643-652), which in htslib means SAM TEXT, writes the input header and then, per dispatched
+ * group, every alignment with its BAQ-modified qualities through sam_write1 (src/secphase.c:182-189).  This is
+ * the same text: header, then one SAM line per record formatted from the raw BAM record. ---- */
+struct spx_sam_writer { FILE *fp = nullptr; std::string line; };
+
+extern "C" int spx_sam_open(const char *path, const spx_bam_reader *src, spx_sam_writer **out)
+{
+    if (!path || !src || !out) return SPX_EINVAL;
+    *out = nullptr;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) { g_io_err = std::string("cannot create ") + path; return SPX_EINVAL; }
+    const Reader &r = src->r;
+    const std::string &t = r.header_text;
+    if (!t.empty()) {
+        fwrite(t.data(), 1, t.size(), fp);
+        if (t.back() != '\n') fputc('\n', fp);
+    }
+    /* a header without @SQ lines gets them from the target list, as sam_hdr_write does */
+    bool has_sq = t.compare(0, 4, "@SQ\t") == 0 || t.find("\n@SQ\t") != std::string::npos;
+    if (!has_sq)
+        for (size_t i = 0; i < r.tname.size(); ++i) fprintf(fp, "@SQ\tSN:%s\tLN:%lld\n", r.tname[i].c_str(), (long long)r.tlen[i]);
+    spx_sam_writer *w = new spx_sam_writer();
+    w->fp = fp;
+    *out = w;
+    return SPX_OK;
+}
+
+static void put_int(std::string &s, long long v)
+{
+    char b[24];
+    s.append(b, (size_t)snprintf(b, sizeof b, "%lld", v));
+}
+static void put_g(std::string &s, double v)
+{
+    char b[40];
+    s.append(b, (size_t)snprintf(b, sizeof b, "%g", v));
+}
+
+/* one SAM line (sam_format1): the eleven mandatory fields, then the aux block */
+static bool format_sam(const Reader &r, const uint8_t *p, int32_t bs, const uint8_t *qual, std::string &s)
+{
+    const int32_t refid = le32(p), posv = le32(p + 4);
+    const uint32_t l_name = p[8], mapq = p[9];
+    const uint32_t ncig = p[12] | (p[13] << 8), flg = p[14] | (p[15] << 8);
+    const int32_t lseq = le32(p + 16), mtid = le32(p + 20), mpos = le32(p + 24), tlen = le32(p + 28);
+    const uint8_t *cig = p + 32 + l_name, *sq = cig + 4 * (size_t)ncig, *ql = sq + ((size_t)lseq + 1) / 2, *aux = ql + lseq,
+                  *end = p + bs;
+    if (aux > end) return false;
+    auto tname = [&](int32_t t) -> const char * { return (t >= 0 && (size_t)t < r.tname.size()) ? r.tname[t].c_str() : "*"; };
+    s.clear();
+    s += (const char *)p + 32; s += '\t';
+    put_int(s, flg); s += '\t';
+    s += tname(refid); s += '\t';
+    put_int(s, (long long)posv + 1); s += '\t';
+    put_int(s, mapq); s += '\t';
+    if (ncig == 0) s += '*';
+    for (uint32_t k = 0; k < ncig; ++k) {
+        const uint32_t c = (uint32_t)le32(cig + 4 * k);
+        put_int(s, c >> 4);
+        s += "MIDNSHP=XB??????"[c & 15];
+    }
+    s += '\t';
+    if (mtid < 0) s += '*';
+    else if (mtid == refid) s += '=';
+    else s += tname(mtid);
+    s += '\t';
+    put_int(s, (long long)mpos + 1); s += '\t';
+    put_int(s, tlen); s += '\t';
+    if (lseq == 0) s += "*\t*";
+    else {
+        for (int32_t k = 0; k < lseq; ++k) s += "=ACMGRSVTWYHKDBN"[(sq[k >> 1] >> ((~k & 1) << 2)) & 15];
+        s += '\t';
+        const uint8_t *q = qual ? qual : ql;
+        if (q[0] == 0xff) s += '*';
+        else for (int32_t k = 0; k < lseq; ++k) s += (char)(q[k] + 33);
+    }
+    while (aux + 3 <= end) {
+        const char ty = (char)aux[2];
+        s += '\t'; s += (char)aux[0]; s += (char)aux[1]; s += ':';
+        const uint8_t *v = aux + 3;
+        auto rd16 = [](const uint8_t *x) { return (uint32_t)(x[0] | (x[1] << 8)); };
+        switch (ty) {
+        case 'A': if (v + 1 > end) return false; s += "A:"; s += (char)v[0]; aux = v + 1; break;
+        case 'c': if (v + 1 > end) return false; s += "i:"; put_int(s, (int8_t)v[0]); aux = v + 1; break;
+        case 'C': if (v + 1 > end) return false; s += "i:"; put_int(s, v[0]); aux = v + 1; break;
+        case 's': if (v + 2 > end) return false; s += "i:"; put_int(s, (int16_t)rd16(v)); aux = v + 2; break;
+        case 'S': if (v + 2 > end) return false; s += "i:"; put_int(s, rd16(v)); aux = v + 2; break;
+        case 'i': if (v + 4 > end) return false; s += "i:"; put_int(s, le32(v)); aux = v + 4; break;
+        case 'I': if (v + 4 > end) return false; s += "i:"; put_int(s, (uint32_t)le32(v)); aux = v + 4; break;
+        case 'f': { if (v + 4 > end) return false; float f; memcpy(&f, v, 4); s += "f:"; put_g(s, f); aux = v + 4; break; }
+        case 'd': { if (v + 8 > end) return false; double d; memcpy(&d, v, 8); s += "d:"; put_g(s, d); aux = v + 8; break; }
+        case 'Z': case 'H': {
+            s += ty; s += ':';
+            while (v < end && *v) s += (char)*v++;
+            aux = v + 1;
+            break;
+        }
+        case 'B': {
+            if (v + 5 > end) return false;
+            const char sub = (char)v[0];
+            const uint32_t cnt = (uint32_t)le32(v + 1);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (v + 5 + es * (size_t)cnt > end) return false;
+            s += "B:"; s += sub;
+            const uint8_t *e = v + 5;
+            for (uint32_t k = 0; k < cnt; ++k, e += es) {
+                s += ',';
+                switch (sub) {
+                case 'c': put_int(s, (int8_t)e[0]); break;
+                case 'C': put_int(s, e[0]); break;
+                case 's': put_int(s, (int16_t)rd16(e)); break;
+                case 'S': put_int(s, rd16(e)); break;
+                case 'i': put_int(s, le32(e)); break;
+                case 'I': put_int(s, (uint32_t)le32(e)); break;
+                case 'f': { float f; memcpy(&f, e, 4); put_g(s, f); break; }
+                default: return false;
+                }
+            }
+            aux = e;
+            break;
+        }
+        default: return false;
+        }
+    }
+    s += '\n';
+    return true;
+}
+
+/* group g of the reader's CURRENT batch; `qual` is laid out like that batch's qual[] (NULL: the record's own
+ * qualities).  Unmapped records are skipped, as the reference never stores them (src/secphase.c:340). */
+extern "C" int spx_sam_write_group(spx_sam_writer *w, const spx_bam_reader *src, int32_t g, const uint8_t *qual)
+{
+    if (!w || !src) return SPX_EINVAL;
+    const Reader &r = src->r;
+    const Slot &S = r.slot[r.cur];
+    if (g < 0 || g >= S.ng) return SPX_EINVAL;
+    int n = 0;
+    for (int32_t a = S.grp_first[g]; a < S.grp_first[g + 1]; ++a) {
+        if (S.flag[a] & SPX_FUNMAP) continue;
+        if (n > 10) continue;
+        ++n;
+        const uint8_t *p = S.ubuf.data() + S.rec_off[a];
+        const int32_t bs = le32(p - 4);
+        if (!format_sam(r, p, bs, qual ? qual + S.qual_off[a] : nullptr, w->line)) { g_io_err = "corrupt aux block"; return SPX_EINVAL; }
+        if (fwrite(w->line.data(), 1, w->line.size(), w->fp) != w->line.size()) { g_io_err = "write failed"; return SPX_EINVAL; }
+    }
+    return n;
+}
+
+extern "C" int spx_sam_close(spx_sam_writer *w)
+{
+    if (!w) return SPX_OK;
+    int rc = fclose(w->fp) == 0 ? SPX_OK : SPX_EINVAL;
+    delete w;
+    return rc;
 }
 
 /* whole FASTA into RAM (the scorer keeps its own 4-bit copy in HBM; this one feeds spx_set_reference and

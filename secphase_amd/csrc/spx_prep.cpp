@@ -47,6 +47,7 @@ void HostBatch::clear()
     grp_index.clear(); mk_first.clear(); markers.clear(); n_aln.clear(); sec_mask.clear(); rfe.clear();
     grp_problems.clear(); grp_cells.clear(); grp_error.clear(); dp_cells = 0;
     rfs.clear(); atid.clear(); mk_ref_pos.clear();
+    qe_rec.clear(); qe_pos.clear(); qe_len.clear(); qe_row0.clear(); qe_batch.clear();
 }
 
 template <class T>
@@ -76,6 +77,8 @@ void HostBatch::append(const HostBatch &o)
     cat(rfs, o.rfs); cat(atid, o.atid); cat(mk_ref_pos, o.mk_ref_pos);
     cat(grp_cells, o.grp_cells);
     dp_cells += o.dp_cells;
+    cat(qe_rec, o.qe_rec); cat(qe_pos, o.qe_pos); cat(qe_len, o.qe_len); cat(qe_batch, o.qe_batch);
+    for (size_t i = 0; i < o.qe_row0.size(); ++i) qe_row0.push_back(o.qe_len[i] > 0 ? o.qe_row0[i] + row_base : 0);
 }
 
 /* ---------------- HMM set-up (host, once per problem) ---------------- */
@@ -652,13 +655,19 @@ static int plan_baq(const Aln &a, int ai, const std::vector<Mk> &mkc, std::vecto
     const int last = (int)a.ops.size() - 1;
     auto adv = [&]() -> int { if (ci < last) { ++ci; return a.ops[ci].ret; } return 0; };
     const float d = (float)par->conf_d, e = (float)par->conf_e;
+    const bool all_rows = (par->flags & SPX_PAR_ALL_ROWS) != 0;
+    auto zero_edit = [&](int base) {
+        if (!all_rows) return;
+        out.qe_rec.push_back(a.rec); out.qe_pos.push_back(base); out.qe_len.push_back(0); out.qe_row0.push_back(0);
+        out.qe_batch.push_back(0);
+    };
     for (size_t bi = 0; bi < a.conf.size(); ++bi) {
         const Blk &b = a.conf[bi];
         while (a.ops[ci].sqe < b.sqs || a.ops[ci].rfe < b.rfs)
             if (adv() == 0) break;
         /* markers of this alignment in the leading margin lose their quality */
         while (j >= 0 && j < nm && (mk[j].base_idx < b.sqs + margin || mk[j].aln != ai)) {
-            if (mk[j].aln == ai && b.sqs <= mk[j].base_idx) { mk[j].q = 0; mk[j].row = -1; }
+            if (mk[j].aln == ai && b.sqs <= mk[j].base_idx) { mk[j].q = 0; mk[j].row = -1; zero_edit(mk[j].base_idx); }
             j += step;
         }
         if (j >= 0 && j < nm && mk[j].base_idx <= b.sqe - margin && b.sqs + margin <= mk[j].base_idx) {
@@ -668,13 +677,19 @@ static int plan_baq(const Aln &a, int ai, const std::vector<Mk> &mkc, std::vecto
             const int bw_in = (int)(abs(R - L) + par->conf_b);
             const int bw = effective_bw(R, L, bw_in);
             if (band_class(2 * bw + 1) < 0) return SPX_EUNSUPPORTED;
-            /* wanted rows: this alignment's markers in [sqs+margin, sqe-margin) keep a BAQ value */
+            /* wanted rows: this alignment's markers in [sqs+margin, sqe-margin) keep a BAQ value; with
+             * SPX_PAR_ALL_ROWS every base of that range is wanted (the write-back at ptMarker.c:802) */
             S.rows_t.clear(); S.rows_mk.clear();
+            if (all_rows)
+                for (int t = margin; t < L - margin; ++t) { S.rows_t.push_back(t); S.rows_mk.push_back(-1); }
             for (int k = j; k >= 0 && k < nm; k += step) {
                 if (mk[k].aln != ai) continue;
                 if (mk[k].base_idx > b.sqe) break;
                 const int t = mk[k].base_idx - b.sqs;
-                if (t >= margin && t < L - margin) { S.rows_t.push_back(t); S.rows_mk.push_back(k); }
+                if (t >= margin && t < L - margin) {
+                    if (all_rows) S.rows_mk[t - margin] = k;
+                    else { S.rows_t.push_back(t); S.rows_mk.push_back(k); }
+                }
             }
             const int32_t row0 = (int32_t)out.rows.size();
             for (size_t w = 0; w < S.rows_t.size(); ++w) {
@@ -699,7 +714,12 @@ static int plan_baq(const Aln &a, int ai, const std::vector<Mk> &mkc, std::vecto
                 if (o.sqe <= b.sqe || o.rfe <= b.rfe) { if (adv() == 0) break; }
                 else break;
             }
+            if (all_rows) {
+                out.qe_rec.push_back(a.rec); out.qe_pos.push_back(b.sqs + margin); out.qe_len.push_back((int32_t)S.rows_t.size());
+                out.qe_row0.push_back(row0); out.qe_batch.push_back(0);
+            }
             for (size_t w = 0; w < S.rows_t.size(); ++w) {
+                if (S.rows_mk[w] < 0) continue;
                 Mk &m = mk[S.rows_mk[w]];
                 if (covered[w]) m.row = row0 + (int32_t)w;
                 else { m.row = -1; m.q = par->set_q < 94 ? par->set_q : 93; } /* base not under an M op: keeps set_q */
@@ -732,7 +752,7 @@ static int plan_baq(const Aln &a, int ai, const std::vector<Mk> &mkc, std::vecto
         }
         /* markers in the trailing margin lose their quality */
         while (j >= 0 && j < nm && ((mk[j].base_idx <= b.sqe && mk[j].aln == ai) || mk[j].aln != ai)) {
-            if (b.sqe - margin <= mk[j].base_idx && mk[j].aln == ai) { mk[j].q = 0; mk[j].row = -1; }
+            if (b.sqe - margin <= mk[j].base_idx && mk[j].aln == ai) { mk[j].q = 0; mk[j].row = -1; zero_edit(mk[j].base_idx); }
             j += step;
         }
     }

@@ -37,6 +37,10 @@ struct HostBatch {
     std::vector<int32_t> grp_problems;
     std::vector<int64_t> grp_cells;
     std::vector<int32_t> grp_error; /* per input group: 0 or SPX_E* */
+    /* SPX_PAR_ALL_ROWS only: the writes calc_local_baq makes to the record's quality array, in the order it
+     * makes them (ptMarker.c:706,759,763).  len == 0: qual[rec][pos] = 0; len > 0: rows row0.. hold the values of
+     * qual[rec][pos .. pos+len) (row_expect < 0: base not under an M/=/X op, keeps set_q) */
+    std::vector<int32_t> qe_rec, qe_pos, qe_len, qe_row0, qe_batch;
     int64_t dp_cells = 0;
 
     void clear();

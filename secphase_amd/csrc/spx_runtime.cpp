@@ -104,6 +104,7 @@ struct spx_work {
     spx_params par;
     bool launched = false;
     std::vector<uint8_t> posmin_host; /* filled by spx_collect: per first-of-position marker, min quality */
+    std::vector<uint8_t> bq_host;     /* filled by spx_apply_quals: BAQ value of every wanted row */
 };
 
 extern "C" const char *spx_strerror(int code)
@@ -432,6 +433,7 @@ extern "C" int spx_prepare_many(spx_ctx *c, const spx_batch *const *bts, int32_t
             const Task &k = tasks[t];
             spx::prepare_groups(bts[k.b], ri, par, k.g0, k.g1, parts[t]);
             for (int32_t &gi : parts[t].grp_index) gi += k.base;
+            for (int32_t &qb : parts[t].qe_batch) qb = k.b;
         }
     };
     if (nthr == 1) run();
@@ -572,6 +574,35 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         o.n_problems = w->hb.grp_problems[k];
         o.n_markers = w->hb.mk_first[k + 1] - w->hb.mk_first[k];
         o.dp_cells = w->hb.grp_cells[k];
+    }
+    return SPX_OK;
+}
+
+/* the quality array the reference would hand to sam_write1 (secphase.c:182-189): replays calc_local_baq's
+ * writes (ptMarker.c:706,759,763) with the BAQ values the kernels produced */
+extern "C" int spx_apply_quals(spx_ctx *c, spx_work *w, int32_t batch_index, const spx_batch *bt, uint8_t *qual)
+{
+    if (!c || !w || !bt || !qual) return fail(SPX_EINVAL, "NULL argument");
+    if (!(w->par.flags & SPX_PAR_ALL_ROWS)) return fail(SPX_EINVAL, "work list was not prepared with SPX_PAR_ALL_ROWS");
+    if (!w->launched) return fail(SPX_EINVAL, "work list has not been launched");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const spx::HostBatch &hb = w->hb;
+    if (w->bq_host.size() != hb.rows.size()) {
+        w->bq_host.resize(hb.rows.size());
+        if (!hb.rows.empty()) HIPCHK(hipMemcpy(w->bq_host.data(), w->d_bq, hb.rows.size(), hipMemcpyDeviceToHost));
+    }
+    const uint8_t keep = (uint8_t)(w->par.set_q < 94 ? w->par.set_q : 93);
+    for (size_t k = 0; k < hb.qe_rec.size(); ++k) {
+        if (hb.qe_batch[k] != batch_index) continue;
+        const int32_t r = hb.qe_rec[k];
+        if (r < 0 || r >= bt->n_alns) return fail(SPX_EINVAL, "batch does not match the work list");
+        uint8_t *q = qual + bt->qual_off[r] + hb.qe_pos[k];
+        if (hb.qe_len[k] == 0) { *q = 0; continue; }
+        for (int32_t t = 0; t < hb.qe_len[k]; ++t) {
+            const int32_t row = hb.qe_row0[k] + t;
+            q[t] = hb.row_expect[row] >= 0 ? w->bq_host[row] : keep;
+        }
     }
     return SPX_OK;
 }
@@ -879,6 +910,8 @@ extern "C" int spx_plan_get(const spx_plan *p, spx_plan_view *v)
     v->mk_aln = p->mk_aln.data(); v->mk_first_of_pos = p->mk_fop.data();
     v->n_aln = h.n_aln.data(); v->sec_mask = h.sec_mask.data(); v->rfe = h.rfe.data();
     v->grp_error = h.grp_error.data();
+    v->n_qedits = (int32_t)h.qe_rec.size(); v->pad_ = 0;
+    v->qe_rec = h.qe_rec.data(); v->qe_pos = h.qe_pos.data(); v->qe_len = h.qe_len.data(); v->qe_row0 = h.qe_row0.data();
     return SPX_OK;
 }
 

@@ -35,7 +35,7 @@ class SpxRef(C.Structure):
 class SpxParams(C.Structure):
     _fields_ = [
         ("baq_flag", C.c_int32), ("consensus", C.c_int32), ("indel_threshold", C.c_int32), ("min_q", C.c_int32),
-        ("min_score", C.c_int32), ("set_q", C.c_int32), ("flank_margin", C.c_int32), ("reserved", C.c_int32),
+        ("min_score", C.c_int32), ("set_q", C.c_int32), ("flank_margin", C.c_int32), ("flags", C.c_int32),
         ("prim_margin_score", C.c_double), ("prim_margin_random", C.c_double),
         ("conf_d", C.c_double), ("conf_e", C.c_double), ("conf_b", C.c_double),
     ]

@@ -78,3 +78,45 @@ def write_bam(path, batch, ref, contig_order=None, extra_tags=True):
             rec = core + qn + cig + seq + qual + aux
             out += struct.pack("<i", len(rec)) + rec
     write_bgzf(path, bytes(out))
+
+
+def _fmt_g(x):
+    return "%g" % x
+
+
+def sam_text(batch, ref, qual=None, contig_order=None, extra_tags=True, groups=None):
+    """The SAM text (header + records) of the BAM write_bam() produces, written independently of the product's
+    formatter from the SAM specification: 11 mandatory fields, then the aux fields in file order.
+    qual: optional replacement for the batch's qual[] (same layout); groups: indices to include (default all);
+    unmapped records are skipped like the reference's reader does (src/secphase.c:340)."""
+    b = batch.contents
+    r = ref.contents
+    names = [(_cstr(r.names, r.name_off[i]).decode(), r.seq_off[i + 1] - r.seq_off[i]) for i in range(r.n_contigs)]
+    order = list(contig_order) if contig_order is not None else list(range(r.n_contigs))
+    out = ["@HD\tVN:1.6\tSO:queryname\n"] + ["@SQ\tSN:%s\tLN:%d\n" % names[c] for c in order]
+    for g in (range(b.n_groups) if groups is None else groups):
+        qn = _cstr(b.qnames, b.qname_off[g]).decode()
+        for a in range(b.grp_first[g], b.grp_first[g + 1]):
+            if b.flag[a] & 4:
+                continue
+            lq, nc = b.l_qseq[a], b.n_cigar[a]
+            cig = "".join("%d%s" % (b.cigar[b.cigar_off[a] + k] >> 4, "MIDNSHP=XB"[b.cigar[b.cigar_off[a] + k] & 15])
+                          for k in range(nc)) or "*"
+            sq = C.string_at(C.addressof(b.seq4.contents) + b.seq_off[a], (lq + 1) // 2)
+            seq = "".join("=ACMGRSVTWYHKDBN"[(sq[k >> 1] >> (4 if k % 2 == 0 else 0)) & 15] for k in range(lq)) or "*"
+            if qual is None:
+                ql = C.string_at(C.addressof(b.qual.contents) + b.qual_off[a], lq)
+            else:
+                ql = bytes(qual[b.qual_off[a]:b.qual_off[a] + lq])
+            qs = "".join(chr(x + 33) for x in ql) if lq else "*"
+            f = [qn, str(b.flag[a]), names[b.tid[a]][0], str(b.pos[a] + 1), "60", cig, "*", "0", "0", seq, qs]
+            if extra_tags:
+                f += ["NM:i:3", "tp:A:P"]
+            if b.cs_off[a] >= 0:
+                f.append("cs:Z:" + _cstr(b.cs, b.cs_off[a]).decode())
+            if b.md_off and b.md_off[a] >= 0:
+                f.append("MD:Z:" + _cstr(b.md, b.md_off[a]).decode())
+            if extra_tags:
+                f.append("zz:B:s,-1,7")
+            out.append("\t".join(f) + "\n")
+    return "".join(out)

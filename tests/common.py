@@ -56,9 +56,8 @@ def oracle_probaln(ref, qry, set_q, d, e, bw):
     return pr, st, q
 
 
-def emulate_plan(plan, ref, params):
-    """Run the oracle DP on every problem of a host plan and apply the device-side
-    write-back + scoring rules in numpy: returns {input group index: (scores, prim, max, tie, pass)}."""
+def emulate_rows(plan, ref, params):
+    """The oracle DP on every problem of a host plan + the device-side write-back rule: BAQ value per wanted row."""
     v = plan.view
     bq = np.zeros(max(v.n_rows, 1), np.int64)
     for p in range(v.n_problems):
@@ -74,6 +73,37 @@ def emulate_plan(plan, ref, params):
             else:
                 b = min(int(v.row_rawq[ri]), int(qq[t]))
             bq[ri] = min(b, 93)
+    return bq
+
+
+def batch_qual_copy(batch):
+    """writable copy of a batch's qual[] (its extent is not stored: derived from the offsets)"""
+    b = batch.contents
+    end = max((b.qual_off[a] + b.l_qseq[a] for a in range(b.n_alns)), default=0)
+    return np.frombuffer(C.string_at(C.addressof(b.qual.contents), end), np.uint8).copy()
+
+
+def replay_qual_edits(plan, bq, batch, params):
+    """what spx_apply_quals does, from the host plan view (SPX_PAR_ALL_ROWS)"""
+    v, b = plan.view, batch.contents
+    qual = batch_qual_copy(batch)
+    keep = min(params.set_q, 93)
+    for k in range(v.n_qedits):
+        at = b.qual_off[v.qe_rec[k]] + v.qe_pos[k]
+        if v.qe_len[k] == 0:
+            qual[at] = 0
+            continue
+        for t in range(v.qe_len[k]):
+            row = v.qe_row0[k] + t
+            qual[at + t] = bq[row] if v.row_expect[row] >= 0 else keep
+    return qual
+
+
+def emulate_plan(plan, ref, params):
+    """Run the oracle DP on every problem of a host plan and apply the device-side
+    write-back + scoring rules in numpy: returns {input group index: (scores, prim, max, tie, pass)}."""
+    v = plan.view
+    bq = emulate_rows(plan, ref, params)
     match_tbl = (C.c_double * 256)()
     mis_tbl = (C.c_double * 256)()
     thr = (C.c_double * 102)()

@@ -179,3 +179,63 @@ def test_command_line_drop_in(ctx, tmp_path):
     for sfx in ("initial_variant_blocks.bed", "modified_read_blocks.variants.bed", "variant_blocks.bed"):
         assert os.path.getsize(os.path.join(outd, "t." + sfx)) == 0
     assert f"Number of reads modified by marker score = {nre}" in p.stderr
+
+
+def _quals_parity(ctx, genome, reads, params):
+    """all-rows work list (-w/--writeBam): record qualities after BAQ equal the oracle's, scores unchanged"""
+    import copy
+    from common import batch_qual_copy
+    ctx.set_reference(genome.ref)
+    p_all = copy.copy(params)
+    p_all.flags = 1
+    want, res = orc.run_batch_quals(reads.batch, genome.ref, params, batch_qual_copy(reads.batch), threads=2)
+    w = ctx.prepare(reads.batch, p_all)
+    w.launch()
+    out = w.collect(finalize_seed=1)
+    got = w.apply_quals(reads.batch, batch_qual_copy(reads.batch))
+    st = w.stats()
+    w.free()
+    assert np.array_equal(got, want)
+    assert not np.array_equal(want, batch_qual_copy(reads.batch))
+    for i in range(reads.batch.contents.n_groups):
+        for a in range(max(res[i].n_aln, 0)):
+            assert out[i].score[a] == res[i].score[a], (i, a)
+    return st
+
+
+def test_quality_modified_records_hifi(ctx):
+    g = small_genome(synth.HIFI, hardclip_frac=0.3, softclip_frac=0.4, max_secondaries=3, n_paralogs=2, n_base_frac=0.001)
+    st = _quals_parity(ctx, g, g.reads(0, 48), records.preset("hifi"))
+    assert st.n_rows > 20 * st.n_problems  # every base of the windows, not only markers
+
+
+def test_quality_modified_records_ont(ctx):
+    g = small_genome(synth.ONT, n_paralogs=3)
+    _quals_parity(ctx, g, g.reads(0, 12), records.preset("ont", bandwidth=50))
+
+
+def test_command_line_write_bam(ctx, tmp_path):
+    """secphase --hifi -w: <prefix>.quality_modified.out.bam is what the reference writes -- SAM text (sam_open "w",
+    src/secphase.c:643-652) with the header and, for every dispatched group in file order (= -@1), all records with
+    the qualities calc_local_baq left (src/secphase.c:182-189); the other outputs do not change."""
+    import subprocess
+    from bamio import sam_text, write_bam, write_fasta
+    from common import batch_qual_copy
+    g = small_genome(synth.HIFI, max_secondaries=4, n_paralogs=3, hardclip_frac=0.2, softclip_frac=0.3, read_len=6000)
+    r = g.reads(0, 90)
+    fa, bam, outd = str(tmp_path / "asm.fa"), str(tmp_path / "reads.bam"), str(tmp_path / "out")
+    write_fasta(fa, g.ref)
+    write_bam(bam, r.batch, g.ref)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "secphase_amd", "bin", "secphase")
+    p = subprocess.run([exe, "--hifi", "-w", "-@", "4", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t",
+                        "--groupsPerBatch", "32"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    par = records.preset("hifi")
+    log_o = str(tmp_path / "o.log")
+    nre, _ = orc.run_batch(r.batch, g.ref, par, threads=2, seed=1, log_path=log_o)
+    assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False)
+    want_q, _ = orc.run_batch_quals(r.batch, g.ref, par, batch_qual_copy(r.batch), threads=2)
+    disp = [k for k in range(r.batch.contents.n_groups) if orc.lib().orc_group_is_dispatched(r.batch, k)]
+    assert 0 < len(disp) < r.batch.contents.n_groups or len(disp) == r.batch.contents.n_groups
+    want = sam_text(r.batch, g.ref, qual=want_q, groups=disp)
+    assert open(os.path.join(outd, "t.quality_modified.out.bam")).read() == want

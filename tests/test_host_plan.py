@@ -6,7 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import HandBatch, HandRef, emulate_plan, small_genome
+from common import (HandBatch, HandRef, batch_qual_copy, emulate_plan, emulate_rows, replay_qual_edits,
+                    small_genome)
 from oracle import orc
 from secphase_amd import api, records, synth
 
@@ -68,6 +69,34 @@ def test_plan_mixed_lengths(built):
     g = small_genome(synth.MIXED, n_paralogs=7, contig_len=250000, max_read_len=40000)
     r = g.reads(7, 12)
     _compare(g.ref, r.batch, records.preset("hifi"))
+
+
+def _compare_quals(ref, batch, params):
+    """-w/--writeBam: the record qualities after calc_local_baq (all-rows work list) against the oracle's"""
+    import copy
+    p_all = copy.copy(params)
+    p_all.flags = 1
+    want, res = orc.run_batch_quals(batch, ref, params, batch_qual_copy(batch), threads=2)
+    plan = api.Plan(ref, batch, p_all)
+    got = replay_qual_edits(plan, emulate_rows(plan, ref, p_all), batch, p_all)
+    assert plan.view.n_qedits > 0
+    assert np.array_equal(got, want)
+    assert not np.array_equal(want, batch_qual_copy(batch))  # BAQ did change something
+    # the scores do not depend on the mode
+    base = emulate_plan(api.Plan(ref, batch, params), ref, params)
+    assert emulate_plan(plan, ref, p_all) == base
+
+
+def test_plan_all_rows_quals_hifi(built):
+    g = small_genome(synth.HIFI, read_len=4000, hardclip_frac=0.3, softclip_frac=0.4, max_secondaries=3, n_paralogs=2)
+    r = g.reads(0, 12)
+    _compare_quals(g.ref, r.batch, records.preset("hifi"))
+
+
+def test_plan_all_rows_quals_ont(built):
+    g = small_genome(synth.ONT, n_paralogs=3, read_len=3000)
+    r = g.reads(3, 4)
+    _compare_quals(g.ref, r.batch, records.preset("ont"))
 
 
 def test_plan_no_baq_no_consensus(built):

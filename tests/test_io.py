@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from bamio import contigs_of, write_bam, write_fasta
+from bamio import _bgzf_block, contigs_of, sam_text, write_bam, write_bgzf, write_fasta
 from common import small_genome
 from secphase_amd import api, records, synth
 
@@ -80,3 +80,90 @@ def _round_trip(tmp_path, tag_mode):
     L.spx_bam_close(rd)
     L.spx_fasta_free(fh)
     assert got == _records(r.batch)
+
+
+def _sam_decl(L):
+    vp = C.c_void_p
+    L.spx_sam_open.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
+    L.spx_sam_write_group.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_uint8)]
+    L.spx_sam_close.argtypes = [vp]
+
+
+def test_sam_writer_matches_spec_formatter(built, tmp_path):
+    """-w/--writeBam output format: sam_open(path, "w") = SAM text (src/secphase.c:643-652); every group, own qualities"""
+    L = api.lib()
+    _declare(L)
+    _sam_decl(L)
+    g = small_genome(synth.HIFI, read_len=2000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.3, softclip_frac=0.4,
+                     tag_mode=2)
+    r = g.reads(0, 23)
+    bam, sam = str(tmp_path / "reads.bam"), str(tmp_path / "out.sam")
+    order = list(range(g.ref.contents.n_contigs))[::-1]
+    write_bam(bam, r.batch, g.ref, contig_order=order)
+    rd, wr = C.c_void_p(), C.c_void_p()
+    assert L.spx_bam_open(bam.encode(), 2, C.byref(rd)) == 0, L.spx_io_last_error()
+    assert L.spx_sam_open(sam.encode(), rd, C.byref(wr)) == 0, L.spx_io_last_error()
+    while True:
+        bp = C.POINTER(records.SpxBatch)()
+        n = L.spx_bam_next_batch(rd, 7, C.byref(bp))
+        assert n >= 0
+        if n == 0:
+            break
+        for k in range(n):
+            assert L.spx_sam_write_group(wr, rd, k, None) == bp.contents.grp_first[k + 1] - bp.contents.grp_first[k]
+    assert L.spx_sam_close(wr) == 0
+    L.spx_bam_close(rd)
+    assert open(sam).read() == sam_text(r.batch, g.ref, contig_order=order)
+
+
+def test_sam_writer_aux_types_and_missing_fields(built, tmp_path):
+    """every aux type of the SAM specification, mate fields, a record without SEQ, a header without @SQ lines"""
+    import struct
+    L = api.lib()
+    _declare(L)
+    _sam_decl(L)
+    text = b"@HD\tVN:1.6\n@PG\tID:x"           # no @SQ line, no trailing newline
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 2)
+    for nm, ln in ((b"c1", 1000), (b"c2", 2000)):
+        hdr += struct.pack("<i", len(nm) + 1) + nm + b"\0" + struct.pack("<i", ln)
+
+    def rec(name, flag, tid, pos, mapq, cig, seq, qual, mtid, mpos, tlen, aux):
+        nt = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+        sq = bytearray((len(seq) + 1) // 2)
+        for k, c in enumerate(seq):
+            sq[k >> 1] |= nt[c] << (4 if k % 2 == 0 else 0)
+        cg = b"".join(struct.pack("<I", (n << 4) | "MIDNSHP=X".index(o)) for n, o in cig)
+        qn = name + b"\0"
+        core = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), mapq, 0, len(cig), flag, len(seq), mtid, mpos, tlen)
+        body = core + qn + cg + bytes(sq) + bytes(qual) + aux
+        return struct.pack("<i", len(body)) + body
+
+    aux = (b"XAAq" + b"Xcc" + struct.pack("<b", -5) + b"XCC" + struct.pack("<B", 200) + b"Xss" + struct.pack("<h", -300) +
+           b"XSS" + struct.pack("<H", 60000) + b"Xii" + struct.pack("<i", -70000) + b"XII" + struct.pack("<I", 4000000000) +
+           b"Xff" + struct.pack("<f", 0.5) + b"Xgf" + struct.pack("<f", 1e-7) + b"XZZhello world\0" + b"XHH1AE3\0" +
+           b"B1Bc" + struct.pack("<ibb", 2, -1, 2) + b"B2BC" + struct.pack("<iB", 1, 255) + b"B3BS" + struct.pack("<iH", 1, 65535) +
+           b"B4Bi" + struct.pack("<ii", 1, -9) + b"B5BI" + struct.pack("<iI", 1, 9) + b"B6Bf" + struct.pack("<iff", 2, 1.5, -2.25) +
+           b"B7Bs" + struct.pack("<i", 0))
+    body = (rec(b"r1", 0, 0, 99, 37, [(3, "S"), (4, "M"), (1, "I"), (2, "D"), (2, "=")], "ACGTNACGTA", [10, 20, 30, 40, 0, 1, 2, 3, 93, 50],
+                1, 499, -321, aux) +
+            rec(b"r1", 256, 1, 0, 0, [(5, "M")], "ACGTA", [0xff] * 5, 1, 7, 0, b"") +
+            rec(b"r2", 16, 1, 5, 255, [(2, "H"), (3, "X")], "", [], -1, -1, 0, b"NMC" + struct.pack("<B", 0)))
+    bam, sam = str(tmp_path / "x.bam"), str(tmp_path / "x.sam")
+    write_bgzf(bam, hdr + body)
+    rd, wr = C.c_void_p(), C.c_void_p()
+    assert L.spx_bam_open(bam.encode(), 1, C.byref(rd)) == 0, L.spx_io_last_error()
+    assert L.spx_sam_open(sam.encode(), rd, C.byref(wr)) == 0
+    bp = C.POINTER(records.SpxBatch)()
+    assert L.spx_bam_next_batch(rd, 10, C.byref(bp)) == 2
+    assert L.spx_sam_write_group(wr, rd, 0, None) == 2
+    assert L.spx_sam_write_group(wr, rd, 1, None) == 1
+    assert L.spx_sam_write_group(wr, rd, 2, None) < 0
+    assert L.spx_sam_close(wr) == 0
+    L.spx_bam_close(rd)
+    want = ("@HD\tVN:1.6\n@PG\tID:x\n@SQ\tSN:c1\tLN:1000\n@SQ\tSN:c2\tLN:2000\n"
+            "r1\t0\tc1\t100\t37\t3S4M1I2D2=\tc2\t500\t-321\tACGTNACGTA\t+5?I!\"#$~S\t"
+            "XA:A:q\tXc:i:-5\tXC:i:200\tXs:i:-300\tXS:i:60000\tXi:i:-70000\tXI:i:4000000000\tXf:f:0.5\tXg:f:1e-07\t"
+            "XZ:Z:hello world\tXH:H:1AE3\tB1:B:c,-1,2\tB2:B:C,255\tB3:B:S,65535\tB4:B:i,-9\tB5:B:I,9\tB6:B:f,1.5,-2.25\tB7:B:s\n"
+            "r1\t256\tc2\t1\t0\t5M\t=\t8\t0\tACGTA\t*\n"
+            "r2\t16\tc2\t6\t255\t2H3X\t*\t0\t0\t*\t*\tNM:i:0\n")
+    assert open(sam).read() == want
