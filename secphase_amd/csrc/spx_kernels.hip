@@ -117,6 +117,16 @@ __device__ __forceinline__ double emission(uint32_t code, uint32_t qy, double e_
     return e;
 }
 
+/* m all ones: a, m zero: b */
+__device__ __forceinline__ double select_bits(int32_t m, double a, double b)
+{
+    uint32_t um = (uint32_t)m;
+    asm("" : "+v"(um)); /* keep it a bit mask: otherwise the compiler turns this back into compare + 2 v_cndmask */
+    const uint32_t lo = ((uint32_t)__double2loint(a) & um) | ((uint32_t)__double2loint(b) & ~um);
+    const uint32_t hi = ((uint32_t)__double2hiint(a) & um) | ((uint32_t)__double2hiint(b) & ~um);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 /* phred of the posterior: (int)(-4.343*log(x)+.499) with x = 1 - max/sum,
  * evaluated through thresholds computed on the host with the host libm so
  * that the result is identical to the CPU path bit for bit. */
@@ -667,7 +677,10 @@ struct NibWin { /* C 4-bit codes */
 template <int C>
 __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
 {
-    __shared__ double sD[C][64];
+    /* D row of the previous/current row, [slot][lane].  Slot 0 is the leftmost band cell: its D is
+     * m2*M(k-1) + m8*D(k-1) with both neighbours outside the band, i.e. always +0 -- it is not stored, which
+     * brings W = 41 to 40 x 512 B = 20 KB per wave: 8 waves per CU fit the 160 KB of LDS instead of 7 */
+    __shared__ double sD[C - 1][64];
     const int lane = threadIdx.x & 63;
     HmmC h;
     int hasN;
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             const double e = emission<false>(code, qy, h.e_match, h.e_mis);
             fM[c] = valid ? e * bM : 0.0;
             fI[c] = valid ? SPX_EI * bI : 0.0;
-            sD[c][lane] = 0.0;
+            if (c > 0) sD[c - 1][lane] = 0.0;
             const double tt = fM[c] + fI[c];
             s = valid ? s + tt : s;
         }
@@ -742,24 +755,42 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
                 if ((unsigned)(i - bw + (C - 1) - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
             }
             cw.shift_down(rc);
+            /* interior rows: "reference base == query base" for the eight codes of a window word at once (exact
+             * zero-nibble test), then a bitwise select of the emission: 1.5 ops per cell instead of 5 */
+            uint32_t eq[NibWin<C>::NW];
+            if constexpr (FAST) {
+                const uint32_t qrep = qy * 0x11111111u;
+#pragma unroll
+                for (int k = 0; k < NibWin<C>::NW; ++k) {
+                    const uint32_t x = cw.w[k] ^ qrep;
+                    eq[k] = ~(((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u;
+                }
+            }
             const double ip = inv_prev;
             double pM = fM[0] * ip, pI = fI[0] * ip; /* scaled row i-1 at the current slot */
             double d = 0.0, s = 0.0, prevM = 0.0;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const double pD = sD[c][lane] * ip;
-                const double S = (h.m0 * pM + h.m3 * pI) + h.m6 * pD;
+                double S = h.m0 * pM + h.m3 * pI;
+                if (c > 0) S = S + h.m6 * (sD[c - 1][lane] * ip); /* slot 0: + m6 * 0 */
                 const uint32_t code = cw.get(c);
-                const double e = emission<FAST>(code, qy, h.e_match, h.e_mis);
+                double e;
+                if constexpr (FAST) {
+                    const int32_t m = (int32_t)(eq[c >> 3] << (28 - 4 * (c & 7))) >> 31; /* all ones on a match */
+                    e = select_bits(m, h.e_match, h.e_mis);
+                } else
+                    e = emission<false>(code, qy, h.e_match, h.e_mis);
                 const double newM = e * S;
                 double nM = 0.0, nI = 0.0; /* scaled row i-1 at slot c+1 (the slot above the band is empty) */
                 if (c + 1 < C) { nM = fM[c + 1] * ip; nI = fI[c + 1] * ip; }
                 const double newI = SPX_EI * (h.m1 * nM + h.m4 * nI);
-                const double dn = h.m2 * prevM + h.m8 * d;
                 const bool valid = FAST || !(code & SPX_CODE_OUT);
-                d = valid ? dn : 0.0;
-                sD[c][lane] = d;
-                const double tt = (newM + newI) + d;
+                if (c > 0) {
+                    const double dn = h.m2 * prevM + h.m8 * d;
+                    d = valid ? dn : 0.0;
+                    sD[c - 1][lane] = d;
+                }
+                const double tt = c > 0 ? (newM + newI) + d : newM + newI; /* slot 0: + 0 */
                 s = valid ? s + tt : s;
                 fM[c] = newM; fI[c] = newI;
                 prevM = newM;
@@ -913,6 +944,32 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
     const int ja = max(j0, g * Cq), jb = min(j1, g * Cq + Cq - 1);
     double best = 0.0, carry = 0.0, mysum = 0.0;
     int best_k = -1;
+    if (__builtin_amdgcn_ballot_w64(on && Cq > 12) == 0) {
+        /* narrow bands (every HiFi class): all loads are issued before the first add, so a wave pays one
+         * memory round trip instead of one per slot; slots outside [ja,jb] read as +0.0, which changes neither
+         * the sequential sum nor the strict arg-max */
+        double zm[12], zi[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const int j = g * Cq + c;
+            const bool in = on && c < Cq && j >= ja && j <= jb;
+            zm[c] = in ? zM[j] : 0.0;
+            zi[c] = in ? zI[j] : 0.0;
+        }
+        const int kbase = i - bw + g * Cq;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            if (zm[c] > best) { best = zm[c]; best_k = ((kbase + c - 1) << 2) | 0; }
+            if (zi[c] > best) { best = zi[c]; best_k = ((kbase + c - 1) << 2) | 1; }
+        }
+        for (int t = 0; t < 4; ++t) {
+            double sacc = carry;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) { sacc += zm[c]; sacc += zi[c]; }
+            if (g == t) mysum = sacc;
+            carry = __shfl_up(mysum, 1, 4);
+        }
+    } else
     for (int t = 0; t < 4; ++t) {
         if (g == t && on) {
             double s = carry;

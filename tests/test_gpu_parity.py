@@ -151,6 +151,27 @@ def test_batch_md_only_records(ctx, tmp_path):
     _batch_parity(ctx, g, r, records.preset("hifi"), tmp_path, "md")
 
 
+def test_batch_option_combinations(ctx, tmp_path):
+    """-q without -c (BAQ over whole confident blocks: thousands of rows per problem), -c without -q, neither, and
+    non-preset gap / band / quality parameters (src/secphase.c:420-449)"""
+    g = small_genome(synth.HIFI, read_len=6000, max_secondaries=2, hardclip_frac=0.2, softclip_frac=0.2)
+    r = g.reads(0, 24)
+    p = records.preset("hifi")
+    p.consensus = 0
+    st = _batch_parity(ctx, g, r, p, tmp_path, "noc")
+    assert st.n_rows > 0 and st.dp_cells // max(st.n_problems, 1) > 41 * 1500
+    p = records.preset("hifi")
+    p.baq_flag = 0
+    st = _batch_parity(ctx, g, r, p, tmp_path, "noq")
+    assert st.n_problems == 0
+    p.consensus = 0
+    _batch_parity(ctx, g, r, p, tmp_path, "none")
+    p = records.preset("hifi")
+    p.conf_d, p.conf_e, p.conf_b, p.set_q, p.min_q, p.indel_threshold = 3e-3, 0.25, 33.0, 27, 5, 4
+    p.prim_margin_score, p.prim_margin_random, p.min_score, p.flank_margin = 5.0, 3.0, -40, 300
+    _batch_parity(ctx, g, r, p, tmp_path, "odd")
+
+
 def test_no_cpu_fallback():
     assert api.lib().spx_device_count() >= 1
 
