@@ -147,6 +147,15 @@ int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
 int spx_probaln_batch(spx_ctx *ctx, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
                       const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t *state,
                       uint8_t *q, double *kernel_ms);
+/* Diagnostics for parity tests: runs the same batch as spx_probaln_batch and returns, for problem `which`, the
+ * kernels' own intermediate results, so that a test can compare them with a CPU implementation bit for bit
+ * instead of through the quantised state[]/q[] only.  With L = its query length, R = its reference length:
+ * scale[0] = 1, scale[i] = 1/s[i] for 1 <= i < L, scale[L] = s[L], scale[L+1] = s[L+1] (s = kprobaln's per-row
+ * scaling factors); zM, zI [L][R] row major: f*b of the M and I states of cell (i,k), 0 outside the band -- the
+ * products probaln_glocal's MAP loop maximises and sums. */
+int spx_probaln_posteriors(spx_ctx *ctx, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
+                           const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t which,
+                           double *scale, double *zM, double *zI);
 
 /* ---- BED side outputs (src/secphase.c:59-72,201-212,713-732; ptBlock.c:228-428,573-602) ------------ */
 typedef struct spx_bedset spx_bedset;

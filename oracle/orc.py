@@ -77,6 +77,10 @@ def lib():
         L.orc_run_batch_bed.restype = C.c_int
         L.orc_run_batch_bed.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
                                         C.c_uint, C.POINTER(GroupResult), C.c_char_p, C.c_char_p, C.c_char_p]
+        L.orc_probaln_posteriors.restype = C.c_int
+        L.orc_probaln_posteriors.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int,
+                                             C.POINTER(C.c_uint8), C.POINTER(ProbalnPar), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_run_batch_quals.restype = C.c_int
         L.orc_run_batch_quals.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
                                           C.POINTER(GroupResult), C.POINTER(C.c_uint8)]
@@ -89,6 +93,23 @@ def lib():
         L.orc_walk_cigar.argtypes = [C.POINTER(SpxBatch), C.c_int, C.POINTER(C.POINTER(Op))]
         _lib = L
     return _lib
+
+
+def probaln_posteriors(ref, query, set_q, d, e, bw):
+    """(s[L+2], zM[L,R], zI[L,R]) of the oracle's probaln_glocal for one problem"""
+    import numpy as np
+    ref = np.ascontiguousarray(ref, np.uint8)
+    query = np.ascontiguousarray(query, np.uint8)
+    L_, R_ = len(query), len(ref)
+    iq = np.full(L_, set_q, np.uint8)
+    s = np.zeros(L_ + 2)
+    zM = np.zeros((L_, R_))
+    zI = np.zeros((L_, R_))
+    u8 = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint8))
+    f64 = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    par = ProbalnPar(d, e, bw)
+    lib().orc_probaln_posteriors(u8(ref), R_, u8(query), L_, u8(iq), C.byref(par), f64(s), f64(zM), f64(zI))
+    return s, zM, zI
 
 
 def run_batch_quals(batch, ref, params, qual, threads=1):

@@ -108,6 +108,8 @@ static double *scratch_zeroed(size_t n_doubles)
     return t_buf;
 }
 
+static double *g_cap_s = NULL, *g_cap_zM = NULL, *g_cap_zI = NULL; /* set by orc_probaln_posteriors (single-threaded tests) */
+
 int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query,
                        const uint8_t *iqual, const orc_probaln_par *c, int *state, uint8_t *q)
 {
@@ -251,6 +253,21 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
         y = 1. / s[i];
         for (k = lo; k <= hi; ++k) bi[k] *= y;
     }
+    if (g_cap_s) { /* orc_probaln_posteriors: s[], and z = f*b (M, I) of every in-band cell */
+        memcpy(g_cap_s, s, sizeof(double) * ((size_t)l_query + 2));
+        for (i = 1; i <= l_query; ++i) {
+            int lo2 = i - bw > 1 ? i - bw : 1, hi2 = i + bw < l_ref ? i + bw : l_ref;
+            for (k = 1; k <= l_ref; ++k) {
+                size_t at = (size_t)(i - 1) * l_ref + (k - 1);
+                g_cap_zM[at] = g_cap_zI[at] = 0.;
+                if (k >= lo2 && k <= hi2) {
+                    int u = slot3(bw, i, k);
+                    g_cap_zM[at] = f[(size_t)i * i_dim + u] * b[(size_t)i * i_dim + u];
+                    g_cap_zI[at] = f[(size_t)i * i_dim + u + 1] * b[(size_t)i * i_dim + u + 1];
+                }
+            }
+        }
+    }
     /*** MAP ***/
     for (i = 1; i <= l_query; ++i) {
         double sum = 0., *fi = f + (size_t)i * i_dim, *bi = b + (size_t)i * i_dim, max = 0.;
@@ -273,4 +290,18 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
     }
     if (!reuse) { free(f); free(b); free(s); free(qual); }
     return Pr;
+}
+
+/* test diagnostics: the scaling factors s[0..l_query+1] and the posterior products z = f*b of the M and I states,
+ * row major [l_query][l_ref] (0 outside the band), with which the product's kernels are compared bit for bit */
+int orc_probaln_posteriors(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+                           const orc_probaln_par *c, double *s, double *zM, double *zI)
+{
+    int *state = malloc(sizeof(int) * (size_t)(l_query > 0 ? l_query : 1)), rc;
+    uint8_t *q = malloc((size_t)(l_query > 0 ? l_query : 1));
+    g_cap_s = s; g_cap_zM = zM; g_cap_zI = zI;
+    rc = orc_probaln_glocal(ref, l_ref, query, l_query, iqual, c, state, q);
+    g_cap_s = g_cap_zM = g_cap_zI = NULL;
+    free(state); free(q);
+    return rc;
 }

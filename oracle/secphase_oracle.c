@@ -189,6 +189,8 @@ static int next_md(const char *md, int *off, orc_op *cur)
 /* ptCigarIt_construct + repeated ptCigarIt_next (cigar_it.c:14-69,213-308),
  * materialised once: the reference re-creates the iterator >=7 times per
  * alignment and always sees the same sequence of states. */
+static int is_mx(int op);
+
 static int walk_cigar(waln *a)
 {
     int cap = a->n_cigar * 2 + 16, n = 0, idx = -1, match_remain = 0, cs_off = 0;
@@ -288,6 +290,12 @@ static int walk_cigar(waln *a)
         if (n == cap) { cap *= 2; ops = realloc(ops, sizeof(orc_op) * cap); }
         ops[n++] = cur;
         if (n > 50000000) { free(ops); return -4; }
+    }
+    { /* U6: an alignment without a single aligned base (all clips / insertions): the reference would index an
+       * empty SEQ/QUAL; no aligner writes such a record -- the group is rejected, like U3 */
+        int t, aligned = 0;
+        for (t = 1; t < n; ++t) aligned |= is_mx(ops[t].op) && ops[t].ret > 0;
+        if (!aligned || a->l_qseq <= 0) { free(ops); return -2; }
     }
     a->ops = ops;
     a->n_ops = n;

@@ -37,6 +37,10 @@ typedef struct orc_hmm_consts {
 
 int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query,
                        const uint8_t *iqual, const orc_probaln_par *c, int *state, uint8_t *q);
+/* test diagnostics: s[0..l_query+1] and z = f*b of the M and I states, row major [l_query][l_ref] (0 outside the
+ * band) -- the quantities the product's kernels are compared with bit for bit */
+int orc_probaln_posteriors(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+                           const orc_probaln_par *c, double *s, double *zM, double *zI);
 int orc_phred_from_posterior(double max_over_sum);
 void orc_set_scratch_reuse(int on); /* CPU-baseline runs: per-thread scratch instead of calloc/free per call */
 void orc_probaln_consts(int l_ref, int l_query, float d, float e, int set_q, orc_hmm_consts *c);

@@ -81,7 +81,7 @@ EXPORTS = [
     "spx_merge_blocks_count", "spx_relabel_blocks",
     "spx_io_last_error", "spx_bam_open", "spx_bam_n_targets", "spx_bam_target_name", "spx_bam_bind_reference",
     "spx_bam_next_batch", "spx_bam_close", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
-    "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
+    "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
 ]
 
 _lib = None
@@ -126,6 +126,8 @@ def lib():
     L.spx_probaln_glocal.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _u8p, C.POINTER(ProbalnPar), C.POINTER(C.c_int), _u8p]
     L.spx_probaln_batch.argtypes = [vp, C.c_int32, _u8p, _i64p, _u8p, _i64p, _i32p, C.POINTER(ProbalnPar), _i32p, _u8p,
                                     _f64p]
+    L.spx_probaln_posteriors.argtypes = [vp, C.c_int32, _u8p, _i64p, _u8p, _i64p, _i32p, C.POINTER(ProbalnPar), C.c_int32,
+                                         _f64p, _f64p, _f64p]
     L.spx_plan_create.argtypes = [C.POINTER(SpxRef), C.POINTER(SpxBatch), C.POINTER(SpxParams), C.POINTER(vp)]
     L.spx_plan_get.argtypes = [vp, C.POINTER(PlanView)]
     L.spx_plan_free.argtypes = [vp]
@@ -215,6 +217,31 @@ class Context:
                                      state.ctypes.data_as(_i32p), q.ctypes.data_as(_u8p), C.byref(ms)),
              "spx_probaln_batch")
         return ([state[qo[i]:qo[i + 1]] for i in range(n)], [q[qo[i]:qo[i + 1]] for i in range(n)], ms.value)
+
+    def probaln_posteriors(self, refs, queries, set_q, pars, which=0):
+        """diagnostics: (scale[L+2], zM[L,R], zI[L,R]) of problem `which` of the batch -- see spx.h.
+        A single problem may be given as (ref, query, set_q, par)."""
+        import numpy as np
+        if not isinstance(refs, (list, tuple)):
+            refs, queries, set_q, pars = [refs], [queries], [set_q], [pars]
+        n = len(refs)
+        ro = np.zeros(n + 1, np.int64)
+        qo = np.zeros(n + 1, np.int64)
+        ro[1:] = np.cumsum([len(r) for r in refs])
+        qo[1:] = np.cumsum([len(q) for q in queries])
+        rcat = np.ascontiguousarray(np.concatenate(refs).astype(np.uint8))
+        qcat = np.ascontiguousarray(np.concatenate(queries).astype(np.uint8))
+        sq = np.ascontiguousarray(np.asarray(set_q, np.int32))
+        P = (ProbalnPar * n)(*[ProbalnPar(*p) for p in pars])
+        L_, R_ = len(queries[which]), len(refs[which])
+        scale = np.zeros(L_ + 2)
+        zM = np.zeros((L_, R_))
+        zI = np.zeros((L_, R_))
+        _chk(lib().spx_probaln_posteriors(self.h, n, rcat.ctypes.data_as(_u8p), ro.ctypes.data_as(_i64p),
+                                          qcat.ctypes.data_as(_u8p), qo.ctypes.data_as(_i64p), sq.ctypes.data_as(_i32p), P,
+                                          which, scale.ctypes.data_as(_f64p), zM.ctypes.data_as(_f64p),
+                                          zI.ctypes.data_as(_f64p)), "spx_probaln_posteriors")
+        return scale, zM, zI
 
     def close(self):
         if self.h:

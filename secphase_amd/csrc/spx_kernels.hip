@@ -490,9 +490,10 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
             }
             const uint32_t qy = (qwin >> t4) & 0xfu;
             uint32_t rc = (rwin >> t4) & 0xfu;
-            if (!FAST) {
-                if ((unsigned)(i - bw + top - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
-            }
+            /* also on interior rows: the last lane's top slot lies (slots - W) columns beyond the band, so the
+             * column it receives can be > R while i + bw <= R still holds; that code slides into a real band
+             * slot a few rows later, when validity is read off the code */
+            if ((unsigned)(i - bw + top - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
             cw.shift_down(rc);
             CodeWin<C> ew;
 #pragma unroll

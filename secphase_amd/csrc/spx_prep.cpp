@@ -383,6 +383,12 @@ static int build_ops(Aln &a)
         if (a.ops.size() > 40000000u) return SPX_EINVAL;
     }
     const int n = (int)a.ops.size();
+    { /* U6: no aligned base at all (e.g. a CIGAR of clips only): undefined in the reference, rejected like U3 */
+        bool aligned = false;
+        for (int t = 1; t < n; ++t)
+            aligned |= (a.ops[t].op == SPX_CMATCH || a.ops[t].op == SPX_CEQUAL || a.ops[t].op == SPX_CDIFF) && a.ops[t].ret > 0;
+        if (!aligned || a.l_qseq <= 0) return SPX_EUNSUPPORTED;
+    }
     a.n_visit = n;
     a.rest = n - 1;
     for (int t = 1; t < n; ++t)

@@ -763,9 +763,9 @@ extern "C" int spx_write_relabel_log(const char *path, const char *mode, const s
 
 /* ------------------------------------------------------------------ */
 /* raw banded-HMM problems, all rows wanted */
-extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
-                                 const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars,
-                                 int32_t *state, uint8_t *q, double *kernel_ms)
+static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
+                       const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t *state, uint8_t *q,
+                       double *kernel_ms, int32_t post_which, double *post_scale, double *post_zM, double *post_zI)
 {
     if (!c || n < 0 || !ref || !ref_off || !query || !qry_off || !set_q || !pars || !state || !q)
         return fail(SPX_EINVAL, "NULL argument");
@@ -827,6 +827,27 @@ extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, cons
         (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
         if (kernel_ms) *kernel_ms = ms;
         const size_t nr = hb.rows.size();
+        if (post_scale) { /* spx_probaln_posteriors: 1/s[] and z = f*b of every slot of every row of one problem */
+            int64_t s_at = 0, f_at = 0; /* same layout rule as build_device_batch */
+            for (int32_t p = 0; p < post_which; ++p) {
+                s_at += hb.L[p] + 2;
+                f_at += (int64_t)hb.n_rows[p] * 2 * spx::class_slots(spx::band_class(2 * hb.bw[p] + 1));
+            }
+            const int cls = spx::band_class(2 * hb.bw[post_which] + 1), slots = spx::class_slots(cls), L = hb.L[post_which],
+                      R = hb.R[post_which], bw = hb.bw[post_which];
+            std::vector<double> zv((size_t)L * 2 * slots);
+            if (hipMemcpy(post_scale, w->cls_batch[cls].sinv + s_at, ((size_t)L + 2) * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(zv.data(), w->cls_batch[cls].fsave + f_at, zv.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(SPX_EHIP, "copy back failed");
+            post_scale[0] = 1.0;
+            for (int i = 1; i <= L && !rc; ++i)
+                for (int k = 1; k <= R; ++k) {
+                    const int j = k - (i - bw);
+                    const bool in = k >= std::max(1, i - bw) && k <= std::min(R, i + bw);
+                    post_zM[(size_t)(i - 1) * R + (k - 1)] = in ? zv[((size_t)(i - 1) * 2 + 0) * slots + j] : 0.0;
+                    post_zI[(size_t)(i - 1) * R + (k - 1)] = in ? zv[((size_t)(i - 1) * 2 + 1) * slots + j] : 0.0;
+                }
+        }
         if (hipMemcpy(state, w->d_state, nr * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(q, w->d_q, nr, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(SPX_EHIP, "copy back failed");
@@ -834,6 +855,23 @@ extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, cons
     (void)hipFree(d_ref);
     spx_work_free(c, w);
     return rc;
+}
+
+extern "C" int spx_probaln_batch(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
+                                 const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars,
+                                 int32_t *state, uint8_t *q, double *kernel_ms)
+{
+    return probaln_run(c, n, ref, ref_off, query, qry_off, set_q, pars, state, q, kernel_ms, 0, nullptr, nullptr, nullptr);
+}
+
+extern "C" int spx_probaln_posteriors(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
+                                      const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t which,
+                                      double *scale, double *zM, double *zI)
+{
+    if (!scale || !zM || !zI || !qry_off || which < 0 || which >= n) return fail(SPX_EINVAL, "invalid argument");
+    std::vector<int32_t> state((size_t)qry_off[n]);
+    std::vector<uint8_t> q((size_t)qry_off[n]);
+    return probaln_run(c, n, ref, ref_off, query, qry_off, set_q, pars, state.data(), q.data(), nullptr, which, scale, zM, zI);
 }
 
 static std::mutex g_single_mu;

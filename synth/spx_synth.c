@@ -480,6 +480,9 @@ spx_synth_reads *spx_synth_reads_create(const spx_synth_genome *g, const spx_syn
                 /* --- optional clip of 50-500 read bases on one side --- */
                 if (do_clip) {
                     int cnt = 0;
+                    /* a clip never swallows the alignment: at least 100 read bases (or half of a short read) stay
+                     * aligned -- no aligner writes a record made of clips only */
+                    { int keep = rlen / 2 < 100 ? rlen / 2 : 100; if (clip_len > rlen - keep) clip_len = rlen - keep; }
                     if (clip_left) {
                         for (e = 0; e < nev && cnt < clip_len; ++e)
                             if (E[e].type == 'M' || E[e].type == 'I') { E[e].type = 'S'; cnt++; }

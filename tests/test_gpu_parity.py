@@ -103,6 +103,76 @@ def test_probaln_wide_bands(ctx):
     _check(ctx, probs, [20] * len(probs), pars)
 
 
+def _posteriors_equal(ctx, ref, qry, set_q, par):
+    """bit-exact comparison of the kernels' own numbers -- the per-row scaling factors and every posterior product
+    z = f*b -- with the oracle's; state[]/q[] alone are too coarse (a phred and an arg-max hide 1e-6 errors)"""
+    sc, zM, zI = ctx.probaln_posteriors(ref, qry, set_q, par)
+    s, oM, oI = orc.probaln_posteriors(ref, qry, set_q, *par)
+    L = len(qry)
+    what = f"L={L} R={len(ref)} set_q={set_q} d,e,bw={par}"
+    with np.errstate(divide="ignore"):
+        assert np.array_equal(sc[1:L], 1.0 / s[1:L]), "1/s differs: " + what
+    assert sc[L] == s[L] and sc[L + 1] == s[L + 1], "s[L], s[L+1] differ: " + what
+    assert np.array_equal(zM, oM), "z (M state) differs: " + what
+    assert np.array_equal(zI, oI), "z (I state) differs: " + what
+
+
+def test_probaln_posteriors_bit_exact(ctx):
+    """every band class, R != L, bands wider than the query, homopolymers (exact ties), ambiguous bases, odd
+    HMM parameters: scaling factors and posterior products identical to the oracle's, bit for bit"""
+    rng = np.random.default_rng(11)
+    shapes = [(40, 70, 60), (200, 230, 130), (300, 330, 130), (387, 507, 143), (100, 100, 20), (262, 260, 21),
+              (500, 497, 22), (481, 487, 23), (300, 300, 52), (150, 160, 55), (200, 190, 60), (120, 150, 130),
+              (64, 64, 30), (9, 12, 5), (1, 1, 1), (3, 40, 37), (40, 3, 37), (700, 690, 300), (260, 262, 600), (90, 95, 45)]
+    for (L, R, bw) in shapes:
+        for kind in ("homopolymer", "related", "unrelated"):
+            if kind == "homopolymer":
+                ref = np.full(R, 2, np.uint8)
+                qry = np.full(L, 2, np.uint8)
+                qry[L // 2] = 1
+            elif kind == "related":
+                ref = rng.integers(0, 4, R).astype(np.uint8)
+                qry = np.resize(ref, L).copy()
+                m = rng.random(L) < 0.02
+                qry[m] = (qry[m] + 1) % 4
+            else:
+                ref = rng.integers(0, 4, R).astype(np.uint8)
+                qry = rng.integers(0, 4, L).astype(np.uint8)
+            for (d, e, sq) in ((1e-4, 0.1, 40), (1e-3, 0.1, 20), (0.01, 0.3, 27)):
+                _posteriors_equal(ctx, ref, qry, sq, (d, e, abs(R - L) + bw if bw < 600 else bw))
+    ref = rng.integers(0, 4, 300).astype(np.uint8)
+    qry = ref[:290].copy()
+    ref[rng.random(300) < 0.03] = 4
+    qry[rng.random(290) < 0.03] = 4
+    for bw in (20, 52, 130):
+        _posteriors_equal(ctx, ref, qry, 40, (1e-4, 0.1, 10 + bw))
+
+
+def test_probaln_posteriors_in_mixed_waves(ctx):
+    """the same comparison for problems that share their wavefronts with others (sorted into waves by band width
+    and length: a wave's interior-row range is the minimum over its problems)"""
+    rng = np.random.default_rng(12)
+    probs, sq, pars = [], [], []
+    for _ in range(160):
+        L = int(rng.integers(30, 420))
+        R = max(1, L + int(rng.choice([0, 0, 1, -1, 2, -3, 5, 12, -20, 30])))
+        ref = rng.integers(0, 4, R).astype(np.uint8) if rng.random() < 0.7 else np.full(R, 1, np.uint8)
+        qry = np.resize(ref, L).copy()
+        m = rng.random(L) < 0.02
+        qry[m] = (qry[m] + 1) % 4
+        probs.append((ref, qry))
+        sq.append(40)
+        pars.append((1e-4, 0.1, abs(R - L) + int(rng.choice([20, 20, 20, 21, 22, 50, 52, 60, 100, 130]))))
+    refs, qrys = [p[0] for p in probs], [p[1] for p in probs]
+    for which in rng.choice(len(probs), size=40, replace=False):
+        sc, zM, zI = ctx.probaln_posteriors(refs, qrys, sq, pars, which=int(which))
+        s, oM, oI = orc.probaln_posteriors(refs[which], qrys[which], sq[which], *pars[which])
+        L = len(qrys[which])
+        what = f"problem {which}: L={L} R={len(refs[which])} par={pars[which]}"
+        assert np.array_equal(sc[1:L], 1.0 / s[1:L]) and sc[L] == s[L] and sc[L + 1] == s[L + 1], "s differs, " + what
+        assert np.array_equal(zM, oM) and np.array_equal(zI, oI), "z differs, " + what
+
+
 def _batch_parity(ctx, genome, reads, params, tmp_path, tag):
     ctx.set_reference(genome.ref)
     out, st = ctx.score_batch(reads.batch, params, finalize_seed=1)

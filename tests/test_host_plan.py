@@ -126,6 +126,18 @@ def test_plan_rejects_undefined_cigar_ops(built):
                                      None, 0) == -2
 
 
+def test_plan_rejects_alignment_without_aligned_bases(built):
+    """U6: a record made of clips only (no aligner writes one; the reference would index an empty SEQ)"""
+    seq = "ACGT" * 10
+    hr = HandRef([("c0", seq * 4)])
+    hb = HandBatch([("r", [(0, 0, 0, "40M", seq, 30, ":40"), (256, 0, 3, "40H", "", 30, "")]),
+                    ("s", [(0, 0, 0, "40M", seq, 30, ":40"), (256, 0, 3, "38M", seq[:38], 30, ":38")])])
+    plan = api.Plan(hr.ref, hb.batch, records.preset("hifi"))
+    assert plan.view.grp_error[0] == api.EUNSUPPORTED and plan.view.grp_error[1] == 0 and plan.view.n_groups == 1
+    _, res = orc.run_batch(hb.batch, hr.ref, records.preset("hifi"), threads=1, seed=1)
+    assert res[0].n_aln < 0 and res[1].n_aln == 2
+
+
 def test_host_tables_match_libm(built):
     import math
     thr = (C.c_double * 102)()
