@@ -10,10 +10,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <future>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,10 +29,40 @@ thread_local std::string g_io_err;
 
 struct Block { size_t coff, clen, uoff, ulen; };
 
+/* byte buffer that grows WITHOUT zero-filling (a batch inflates to ~1 GB: value-initialising that much memory
+ * on one thread costs more than inflating it on 64) */
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    void reserve(size_t c)
+    {
+        if (c <= cap) return;
+        uint8_t *q = (uint8_t *)realloc(p, c);
+        if (!q) throw std::bad_alloc();
+        p = q; cap = c;
+    }
+    void resize(size_t m) /* new bytes are NOT initialised */
+    {
+        if (m > cap) reserve(std::max(m, cap + cap / 2));
+        n = m;
+    }
+    void clear() { n = 0; }
+    void swap(RawBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+    void assign(const uint8_t *b, const uint8_t *e) { resize((size_t)(e - b)); if (e > b) memmove(p, b, (size_t)(e - b)); }
+    void erase_front(size_t k) { if (k >= n) { n = 0; return; } memmove(p, p + k, n - k); n -= k; }
+};
+
 /* one batch under construction / handed out: SEQ, QUAL and cs are NOT copied, they are offsets into the
  * inflated byte stream `ubuf` (only CIGAR is copied, it needs 4-byte alignment) */
 struct Slot {
-    std::vector<uint8_t> ubuf;
+    RawBuf ubuf;
     std::vector<int32_t> grp_first, tid, pos, l_qseq, n_cigar;
     std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off, md_off;
     std::vector<int64_t> rec_off; /* first byte (after block_size) of each raw BAM record in ubuf */
@@ -50,7 +83,7 @@ struct Slot {
 struct Reader {
     FILE *fp = nullptr;
     std::vector<uint8_t> cbuf;     /* compressed blocks of the current chunk */
-    std::vector<uint8_t> leftover; /* inflated bytes after the last complete group of the previous batch */
+    RawBuf leftover; /* inflated bytes after the last complete group of the previous batch */
     bool eof = false;
     int threads = 4;
     /* header */
@@ -66,16 +99,28 @@ struct Reader {
     std::string last_name;
     bool have_last = false;
     int64_t n_records = 0, n_groups_total = 0;
+    double t_inflate = 0;
+    size_t last_batch_bytes = 0;
 };
 
-/* read up to 256 BGZF blocks, inflate them in parallel, append to `ubuf`; false at EOF / error */
-bool read_chunk(Reader *r, std::vector<uint8_t> &ubuf)
+/* read up to 1024 BGZF blocks (~64 MB inflated), inflate them in parallel, append to `ubuf`; false at EOF / error */
+bool read_chunk_impl(Reader *r, RawBuf &ubuf);
+bool read_chunk(Reader *r, RawBuf &ubuf)
+{
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    const bool ok = read_chunk_impl(r, ubuf);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    r->t_inflate += (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
+    return ok;
+}
+bool read_chunk_impl(Reader *r, RawBuf &ubuf)
 {
     if (r->eof) return false;
     r->cbuf.clear();
     std::vector<Block> blocks;
     size_t utot = ubuf.size();
-    for (int n = 0; n < 256; ++n) {
+    for (int n = 0; n < 1024; ++n) {
         uint8_t hdr[18];
         size_t got = fread(hdr, 1, 18, r->fp);
         if (got == 0) { r->eof = true; break; }
@@ -133,7 +178,7 @@ bool read_chunk(Reader *r, std::vector<uint8_t> &ubuf)
 }
 
 /* make sure n bytes are available at `at` in ubuf; false at clean EOF / error */
-bool need(Reader *r, std::vector<uint8_t> &ubuf, size_t at, size_t n)
+bool need(Reader *r, RawBuf &ubuf, size_t at, size_t n)
 {
     while (ubuf.size() < at + n)
         if (!read_chunk(r, ubuf)) return ubuf.size() >= at + n;
@@ -196,7 +241,7 @@ extern "C" int spx_bam_open(const char *path, int threads, spx_bam_reader **out)
     Reader *r = &h->r;
     r->fp = fp;
     r->threads = threads > 0 ? threads : 4;
-    std::vector<uint8_t> &u = r->leftover;
+    RawBuf &u = r->leftover;
     size_t at = 0;
     auto bail = [&](const char *msg) { g_io_err = msg; fclose(fp); delete h; return SPX_EINVAL; };
     if (!need(r, u, at, 12) || memcmp(u.data(), "BAM\1", 4) != 0) return bail("not a BAM file");
@@ -217,7 +262,7 @@ extern "C" int spx_bam_open(const char *path, int threads, spx_bam_reader **out)
         r->tlen.push_back(le32(u.data() + at));
         at += 4;
     }
-    u.erase(u.begin(), u.begin() + (long)at);
+    u.erase_front(at);
     r->tmap.assign(n_ref, -1);
     for (int32_t i = 0; i < n_ref; ++i) r->tmap[i] = i;
     *out = h;
@@ -247,12 +292,21 @@ extern "C" int spx_bam_bind_reference(spx_bam_reader *h, const spx_ref *ref)
 }
 
 /* fill one slot with up to max_groups complete name groups */
+static double io_now()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
 static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
 {
+    const double t_fill0 = io_now();
     S.clear();
     S.ubuf.swap(r->leftover);
     r->leftover.clear();
-    std::vector<uint8_t> &u = S.ubuf;
+    RawBuf &u = S.ubuf;
+    u.reserve(r->last_batch_bytes + r->last_batch_bytes / 8 + (96u << 20)); /* one allocation per batch, not a doubling chain */
     size_t at = 0;
     bool open_group = false;
     for (;;) {
@@ -298,11 +352,13 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
         r->n_records++;
     }
     /* bytes of the records that belong to the next batch */
-    r->leftover.assign(u.begin() + (long)at, u.end());
+    r->leftover.assign(u.data() + at, u.data() + u.size());
+    r->last_batch_bytes = at;
     S.grp_first.push_back((int32_t)S.flag.size());
     S.qnames.push_back(0);
     S.cigar.push_back(0);
-    u.resize(at + 8, 0); /* keep the consumed part (+ slack), drop the tail that was copied out */
+    u.resize(at + 8); /* keep the consumed part (+ slack), drop the tail that was copied out */
+    memset(u.data() + at, 0, 8);
     spx_batch &b = S.view;
     b.n_groups = S.ng;
     b.n_alns = (int32_t)S.flag.size();
@@ -313,6 +369,10 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
     b.seq4 = u.data(); b.qual = u.data(); b.cs = (const char *)u.data();
     b.md_off = S.md_off.data(); b.md = (const char *)u.data();
     r->n_groups_total += S.ng;
+    if (getenv("SPX_TIMING"))
+        fprintf(stderr, "[spx timing] BAM batch: %d groups, %.1f MB inflated, %.3f s (of which read+inflate %.3f s)\n", S.ng,
+                u.size() / 1e6, io_now() - t_fill0, r->t_inflate);
+    r->t_inflate = 0;
 }
 
 /* up to max_groups complete name groups; the batch stays valid until the next call.  The following batch is

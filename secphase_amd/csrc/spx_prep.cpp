@@ -22,6 +22,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 namespace spx {
 
@@ -81,6 +83,77 @@ void HostBatch::append(const HostBatch &o)
     for (size_t i = 0; i < o.qe_row0.size(); ++i) qe_row0.push_back(o.qe_len[i] > 0 ? o.qe_row0[i] + row_base : 0);
 }
 
+void HostBatch::assign_merged(std::vector<HostBatch> &parts, int n_threads)
+{
+    clear();
+    const size_t P = parts.size();
+    /* element offsets of every part in the merged arrays */
+    std::vector<size_t> o_np(P + 1, 0), o_nr(P + 1, 0), o_q4(P + 1, 0), o_ng(P + 1, 0), o_nm(P + 1, 0), o_nq(P + 1, 0), o_ge(P + 1, 0);
+    for (size_t t = 0; t < P; ++t) {
+        const HostBatch &o = parts[t];
+        o_np[t + 1] = o_np[t] + o.L.size();
+        o_nr[t + 1] = o_nr[t] + o.rows.size();
+        o_q4[t + 1] = o_q4[t] + o.qry4.size();
+        o_ng[t + 1] = o_ng[t] + o.grp_index.size();
+        o_nm[t + 1] = o_nm[t] + o.markers.size();
+        o_nq[t + 1] = o_nq[t] + o.qe_rec.size();
+        o_ge[t + 1] = o_ge[t] + o.grp_error.size();
+        dp_cells += o.dp_cells;
+    }
+    const size_t np = o_np[P], nr = o_nr[P], ng = o_ng[P], nm = o_nm[P], nq = o_nq[P];
+    ref_nib.resize(np); qry_nib.resize(np); ref_tid.resize(np); ref_rfs.resize(np); L.resize(np); R.resize(np); bw.resize(np);
+    row_off.resize(np); n_rows.resize(np); hmm.resize(np * SPX_H_N);
+    rows.resize(nr); row_expect.resize(nr); row_rawq.resize(nr);
+    qry4.resize(o_q4[P]);
+    qry_nibbles = (int64_t)o_q4[P] * 2;
+    grp_index.resize(ng); mk_first.resize(ng + 1); n_aln.resize(ng); sec_mask.resize(ng); rfe.resize(ng * 10); rfs.resize(ng * 10);
+    atid.resize(ng * 10); grp_problems.resize(ng); grp_cells.resize(ng);
+    markers.resize(nm); mk_ref_pos.resize(nm);
+    qe_rec.resize(nq); qe_pos.resize(nq); qe_len.resize(nq); qe_row0.resize(nq); qe_batch.resize(nq);
+    grp_error.resize(o_ge[P]);
+    mk_first[0] = 0;
+    auto cp = [](auto &dst, size_t at, const auto &src) {
+        if (!src.empty()) memcpy(dst.data() + at, src.data(), src.size() * sizeof(src[0]));
+    };
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= P) break;
+            const HostBatch &o = parts[t];
+            const size_t a = o_np[t], r0 = o_nr[t], g0 = o_ng[t], m0 = o_nm[t], q0 = o_nq[t];
+            const int64_t nib_base = (int64_t)o_q4[t] * 2;
+            const int32_t row_base = (int32_t)r0, mk_base = (int32_t)m0;
+            cp(ref_nib, a, o.ref_nib); cp(ref_tid, a, o.ref_tid); cp(ref_rfs, a, o.ref_rfs); cp(L, a, o.L); cp(R, a, o.R);
+            cp(bw, a, o.bw); cp(n_rows, a, o.n_rows); cp(hmm, a * SPX_H_N, o.hmm);
+            for (size_t i = 0; i < o.qry_nib.size(); ++i) qry_nib[a + i] = o.qry_nib[i] + nib_base;
+            for (size_t i = 0; i < o.row_off.size(); ++i) row_off[a + i] = o.row_off[i] + row_base;
+            cp(rows, r0, o.rows); cp(row_expect, r0, o.row_expect); cp(row_rawq, r0, o.row_rawq);
+            cp(qry4, o_q4[t], o.qry4);
+            cp(grp_index, g0, o.grp_index); cp(n_aln, g0, o.n_aln); cp(sec_mask, g0, o.sec_mask); cp(rfe, g0 * 10, o.rfe);
+            cp(rfs, g0 * 10, o.rfs); cp(atid, g0 * 10, o.atid); cp(grp_problems, g0, o.grp_problems); cp(grp_cells, g0, o.grp_cells);
+            for (size_t i = 1; i < o.mk_first.size(); ++i) mk_first[g0 + i] = o.mk_first[i] + mk_base;
+            for (size_t i = 0; i < o.markers.size(); ++i) {
+                spx_dev_marker m = o.markers[i];
+                if (m.row >= 0) m.row += row_base;
+                markers[m0 + i] = m;
+            }
+            cp(mk_ref_pos, m0, o.mk_ref_pos);
+            cp(qe_rec, q0, o.qe_rec); cp(qe_pos, q0, o.qe_pos); cp(qe_len, q0, o.qe_len); cp(qe_batch, q0, o.qe_batch);
+            for (size_t i = 0; i < o.qe_row0.size(); ++i) qe_row0[q0 + i] = o.qe_len[i] > 0 ? o.qe_row0[i] + row_base : 0;
+            cp(grp_error, o_ge[t], o.grp_error);
+            parts[t] = HostBatch(); /* give the memory back early */
+        }
+    };
+    const int nt = std::max(1, std::min<int>(n_threads, (int)P));
+    if (nt == 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work);
+        for (auto &t : th) t.join();
+    }
+}
+
 /* ---------------- HMM set-up (host, once per problem) ---------------- */
 void hmm_constants(int l_ref, int l_query, float d, float e, int set_q, double *h)
 {
@@ -114,12 +187,14 @@ int effective_bw(int l_ref, int l_query, int bw_in)
 
 int64_t band_cells(int L, int R, int bw)
 {
-    int64_t c = 0;
-    for (int i = 1; i <= L; ++i) {
-        int beg = std::max(1, i - bw), end = std::min(R, i + bw);
-        if (end >= beg) c += end - beg + 1;
-    }
-    return c;
+    /* sum over rows i = 1..L of (min(R, i+bw) - max(1, i-bw) + 1), in closed form (called once per problem on the
+     * launch path).  effective_bw() guarantees bw >= |R - L|, so every row has at least one cell. */
+    const int64_t l = L, r = R, w = bw;
+    const int64_t a = std::max<int64_t>(0, std::min<int64_t>(l, r - w)); /* rows with i + bw <= R */
+    const int64_t hi = a * (a + 1) / 2 + a * w + (l - a) * r;
+    const int64_t b = std::min<int64_t>(l, w + 1);                       /* rows with i - bw <= 1 */
+    const int64_t lo = b + (l * (l + 1) / 2 - b * (b + 1) / 2) - (l - b) * w;
+    return hi - lo + l;
 }
 
 /* band classes = kernel instantiations (spx_launch_baq): four exact widths, then generic ones by capacity */

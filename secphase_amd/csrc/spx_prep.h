@@ -45,6 +45,8 @@ struct HostBatch {
 
     void clear();
     void append(const HostBatch &o);
+    /* *this = parts[0] + parts[1] + ... (same result as appending them one by one), copied on n_threads threads */
+    void assign_merged(std::vector<HostBatch> &parts, int n_threads);
 };
 
 /* nibble offset of every contig inside the device reference pool */

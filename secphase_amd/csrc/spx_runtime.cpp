@@ -46,6 +46,12 @@ static int fail(int code, const std::string &msg)
         if (e_ != hipSuccess) return fail(SPX_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+static bool timing_on()
+{
+    static const bool on = getenv("SPX_TIMING") != nullptr; /* diagnostics: phase times of the host side on stderr */
+    return on;
+}
+
 static double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -231,6 +237,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
 {
     spx::HostBatch &hb = w->hb;
     const size_t np = hb.L.size(), nr = hb.rows.size(), ng = hb.grp_index.size(), nm = hb.markers.size();
+    const double tb0 = now_s();
     /* per-class launch order: (W, L desc), each W padded to whole waves */
     std::vector<int32_t> order[SPX_N_CLASSES], order_b[SPX_N_CLASSES];
     std::vector<int32_t> ids[SPX_N_CLASSES];
@@ -241,28 +248,51 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     }
     /* rows the backward kernel walks: L down to the first wanted row */
     auto brows = [&](int32_t p) { return hb.n_rows[p] > 0 ? hb.L[p] - hb.rows[hb.row_off[p]] + 1 : 0; };
-    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
-        auto &v = ids[cls];
-        w->st.problems_per_class[cls] = (int64_t)v.size();
-        if (v.empty()) continue;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int ppw = 64 / (pass ? spx::class_lanes_bwd(cls) : spx::class_lanes(cls));
-            std::sort(v.begin(), v.end(), [&](int32_t a, int32_t b) {
-                if (hb.bw[a] != hb.bw[b]) return hb.bw[a] < hb.bw[b];
-                const int ka = pass ? brows(a) : hb.L[a], kb = pass ? brows(b) : hb.L[b];
-                if (ka != kb) return ka > kb;
-                return a < b;
-            });
-            std::vector<int32_t> &dst = pass ? order_b[cls] : order[cls];
-            for (size_t i = 0; i < v.size();) {
-                size_t j = i;
-                while (j < v.size() && hb.bw[v[j]] == hb.bw[v[i]]) ++j;
-                for (size_t k = i; k < j; ++k) dst.push_back(v[k]);
-                while (dst.size() % ppw) dst.push_back(-1);
-                i = j;
+    /* order = (band width ascending, length descending, index ascending).  Keys are built in index order, so a stable
+     * LSD radix sort of (bw, max - length) gives it in O(n); forward and backward orders of all classes are
+     * independent and sorted on their own threads */
+    auto sort_class = [&](int cls, int pass) {
+        const std::vector<int32_t> &v = ids[cls];
+        std::vector<int32_t> &dst = pass ? order_b[cls] : order[cls];
+        if (v.empty()) return;
+        const int ppw = 64 / (pass ? spx::class_lanes_bwd(cls) : spx::class_lanes(cls));
+        const size_t n = v.size();
+        std::vector<uint64_t> a(n), b(n);
+        for (size_t i = 0; i < n; ++i) {
+            const int32_t p = v[i];
+            const uint32_t len = (uint32_t)(pass ? brows(p) : hb.L[p]);
+            const uint32_t key = ((uint32_t)hb.bw[p] << 20) | (0xfffffu - (len > 0xfffffu ? 0xfffffu : len)); /* bw <= 1023 */
+            a[i] = ((uint64_t)key << 32) | (uint32_t)p;
+        }
+        for (int shift = 32; shift < 64; shift += 11) { /* three 11-bit digits cover the 30 key bits in use */
+            size_t cnt[2049] = {0};
+            for (size_t i = 0; i < n; ++i) cnt[((a[i] >> shift) & 2047) + 1]++;
+            for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+            for (size_t i = 0; i < n; ++i) b[cnt[(a[i] >> shift) & 2047]++] = a[i];
+            a.swap(b);
+        }
+        dst.reserve(n + 64);
+        for (size_t i = 0; i < n;) {
+            const uint64_t bwkey = a[i] >> 52;
+            size_t j = i;
+            while (j < n && (a[j] >> 52) == bwkey) { dst.push_back((int32_t)(uint32_t)a[j]); ++j; }
+            while (dst.size() % ppw) dst.push_back(-1);
+            i = j;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+            w->st.problems_per_class[cls] = (int64_t)ids[cls].size();
+            if (ids[cls].empty()) continue;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (ids[cls].size() < 20000) sort_class(cls, pass);
+                else th.emplace_back(sort_class, cls, pass);
             }
         }
+        for (auto &t : th) t.join();
     }
+    const double tb1 = now_s();
     /* scratch offsets */
     std::vector<int64_t> s_off(np), fsave_off(np);
     std::vector<int32_t> prob_slots(np), row_prob(nr);
@@ -315,6 +345,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     }
     char *base = (char *)w->arena;
     double t0 = now_s();
+    if (timing_on()) fprintf(stderr, "[spx timing] device batch: launch orders %.3f s, offsets+arena %.3f s (%.2f GB)\n", tb1 - tb0, t0 - tb1, w->arena_bytes / 1e9);
 #define UP(off, vec)                                                                                         \
     if (!(vec).empty())                                                                                      \
     HIPCHK(hipMemcpyAsync(base + (off), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, \
@@ -330,6 +361,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     HIPCHK(hipStreamSynchronize(c->stream));
     w->st.h2d_seconds = now_s() - t0;
     w->st.bytes_h2d = (int64_t)in_bytes;
+    if (timing_on()) fprintf(stderr, "[spx timing] device batch: upload %.3f s (%.1f MB)\n", w->st.h2d_seconds, in_bytes / 1e6);
     w->d_bq = (uint8_t *)(base + o_bq);
     w->d_posmin = (uint8_t *)(base + o_posmin);
     w->d_state = want_state_q ? (int32_t *)(base + o_state) : nullptr;
@@ -442,14 +474,10 @@ extern "C" int spx_prepare_many(spx_ctx *c, const spx_batch *const *bts, int32_t
         for (int t = 0; t < nthr; ++t) th.emplace_back(run);
         for (auto &t : th) t.join();
     }
-    w->hb.clear();
-    w->hb.mk_first.push_back(0);
-    for (size_t t = 0; t < tasks.size(); ++t) {
-        w->hb.append(parts[t]);
-        w->hb.grp_error.insert(w->hb.grp_error.end(), parts[t].grp_error.begin(), parts[t].grp_error.end());
-        parts[t] = spx::HostBatch();
-    }
+    const double t_par = now_s();
+    w->hb.assign_merged(parts, nthr);
     w->st.prep_seconds = now_s() - t0;
+    if (timing_on()) fprintf(stderr, "[spx timing] prepare: %d threads, group logic %.3f s, merge %.3f s\n", nthr, t_par - t0, now_s() - t_par);
     w->st.n_groups = w->n_groups_in;
     w->st.n_dispatched = (int64_t)w->hb.grp_index.size();
     w->st.n_problems = (int64_t)w->hb.L.size();
