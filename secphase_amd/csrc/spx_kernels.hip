@@ -702,6 +702,17 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
     int wnext = 0;
     int next_row = nrows > 0 ? B.rows[row0] : 0x7fffffff;
     double inv_prev = 1.0, s_cur = 1.0;
+    /* 1/s[i] is collected for eight rows and written as one aligned 64-byte line per problem: a lane-strided
+     * 8-byte store per row costs a partial-line write (and the read that fills the line) every time */
+    double ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0, ib4 = 0, ib5 = 0, ib6 = 0, ib7 = 0;
+    auto put_inv = [&](double v) { /* straight-line shift: ib7 is the newest row */
+        ib0 = ib1; ib1 = ib2; ib2 = ib3; ib3 = ib4; ib4 = ib5; ib5 = ib6; ib6 = ib7; ib7 = v;
+    };
+    auto flush_inv = [&](int i) { /* rows i-7 .. i (a lead pad of one line per problem takes rows < 0 of a short query) */
+        double2 *dst = reinterpret_cast<double2 *>(sinv + (i - 7));
+        dst[0] = make_double2(ib0, ib1); dst[1] = make_double2(ib2, ib3);
+        dst[2] = make_double2(ib4, ib5); dst[3] = make_double2(ib6, ib7);
+    };
     auto save_row = [&](double inv) {
         double *dst = fsave + (int64_t)wnext * fstride;
 #pragma unroll
@@ -733,7 +744,8 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
         if (act) {
 #pragma unroll
             for (int c = 0; c < C; ++c) { fM[c] = fM[c] / s; fI[c] = fI[c] / s; }
-            sinv[1] = 1.0 / s;
+            put_inv(1.0 / s);
+            if (L == 1) flush_inv(1);
             inv_prev = 1.0; /* row 1 is stored already divided, as the reference does */
             if (next_row == 1) save_row(1.0);
         }
@@ -800,7 +812,8 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             const double inv = 1.0 / s;
             s_cur = s;
             inv_prev = inv;
-            sinv[i] = inv;
+            put_inv(inv);
+            if ((i & 7) == 7 || i == L) flush_inv(i);
             if (i == next_row) save_row(inv);
         }
     };

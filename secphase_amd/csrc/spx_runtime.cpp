@@ -298,8 +298,9 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     std::vector<int32_t> prob_slots(np), row_prob(nr);
     int64_t s_tot = 0, f_tot = 0;
     for (size_t p = 0; p < np; ++p) {
-        s_off[p] = s_tot;
-        s_tot += hb.L[p] + 2;
+        /* whole 64-byte lines behind a lead pad of one line: the one-lane forward kernel writes 1/s[] eight rows at a time */
+        s_off[p] = s_tot + 8;
+        s_tot += 8 + ((hb.L[p] + 2 + 7) & ~7);
         fsave_off[p] = f_tot;
         prob_slots[p] = spx::class_slots(spx::band_class(2 * hb.bw[p] + 1));
         f_tot += (int64_t)hb.n_rows[p] * 2 * prob_slots[p];
@@ -857,8 +858,9 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
         const size_t nr = hb.rows.size();
         if (post_scale) { /* spx_probaln_posteriors: 1/s[] and z = f*b of every slot of every row of one problem */
             int64_t s_at = 0, f_at = 0; /* same layout rule as build_device_batch */
+            s_at = 8;
             for (int32_t p = 0; p < post_which; ++p) {
-                s_at += hb.L[p] + 2;
+                s_at += 8 + ((hb.L[p] + 2 + 7) & ~7);
                 f_at += (int64_t)hb.n_rows[p] * 2 * spx::class_slots(spx::band_class(2 * hb.bw[p] + 1));
             }
             const int cls = spx::band_class(2 * hb.bw[post_which] + 1), slots = spx::class_slots(cls), L = hb.L[post_which],
