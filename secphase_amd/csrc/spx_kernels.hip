@@ -411,6 +411,14 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
     const int nrows = P.nrows, row0 = P.row0;
 
     double s_cur = 1.0;
+    /* 1/s[i] of eight rows is written as one 64-byte line (see baq_fwd1_kernel) */
+    double ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0, ib4 = 0, ib5 = 0, ib6 = 0, ib7 = 0;
+    auto put_inv = [&](double v) { ib0 = ib1; ib1 = ib2; ib2 = ib3; ib3 = ib4; ib4 = ib5; ib5 = ib6; ib6 = ib7; ib7 = v; };
+    auto flush_inv = [&](int i) { /* rows i-7 .. i; rows < 0 of a short query land in the problem's lead pad */
+        double2 *dst = reinterpret_cast<double2 *>(sinv + (i - 7));
+        dst[0] = make_double2(ib0, ib1); dst[1] = make_double2(ib2, ib3);
+        dst[2] = make_double2(ib4, ib5); dst[3] = make_double2(ib6, ib7);
+    };
     int wnext = 0;
     int next_row = nrows > 0 ? B.rows[row0] : 0x7fffffff;
     auto save_row = [&]() {
@@ -468,7 +476,8 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
                 fM[c] = fM[c] / tot;
                 fI[c] = fI[c] / tot;
             }
-            if (g == 0) sinv[1] = 1.0 / tot;
+            put_inv(1.0 / tot);
+            if (g == 0 && L == 1) flush_inv(1);
             if (next_row == 1) save_row();
         }
     }
@@ -501,7 +510,8 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
             double inv;
             s_cur = fwd_row<G, C, FAST, W0>(fM, fI, D, dinv, ew, qy, h, g, Wu, tlast, inv);
             dinv = inv;
-            if (g == 0) sinv[i] = inv;
+            put_inv(inv);
+            if (g == 0 && ((i & 7) == 7 || i == L)) flush_inv(i);
             if (i == next_row) save_row();
         }
     };
