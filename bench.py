@@ -172,6 +172,8 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx_sync()
+    if args.warmup > 0:
+        works[0].collect(finalize_seed=None)  # closes the event window: the averages below cover the TIMED launches only
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,7 +205,7 @@ def main():
     for w in works:
         if len(works) > 1:
             w.launch()  # the events belong to the context: with several work lists per step re-run each alone
-        w.collect(finalize_seed=None)  # one list per step: these are the events of the last TIMED launch
+        w.collect(finalize_seed=None)  # one list per step: averages over the launches of the timed region
         per_launch.append(w.stats())
     baq_ms = sum(p.baq_kernel_ms for p in per_launch)
     score_ms = sum(p.score_kernel_ms for p in per_launch)
@@ -232,11 +234,14 @@ def main():
             "traffic": pmc_traffic(kname, gps),
             "kernel": kname,
             "avg_launch_ms": round(fwd_ms, 4),
+            "launches_averaged": int(st0.n_launches_averaged),
             "cells_per_launch": int(cls_cells),
             "flops_per_cell": FWD_FLOPS_PER_CELL,
-            "note": "rows live in VGPRs: FP64 vector-ALU bound (SQ_ACTIVE_INST_VALU ~90% of SIMD cycles), not HBM/MFMA. "
-                    "peak = vector FP64 with FMA counted as 2; the bit-exact path may not fuse mul+add, so 39.3 is the "
-                    "attainable ceiling. algorithmic flops: 19 (forward) of 45 per band cell, SURVEY 8(d)",
+            "note": "rows live in VGPRs/LDS: FP64 vector-ALU work under the package power limit (the big kernels run at "
+                    "1.8-2.0 GHz, ~85% of the VALU issue slots), not HBM/MFMA. peak = vector FP64 at 2.4 GHz with FMA counted "
+                    "as 2; the bit-exact path may not fuse mul+add, so 39.3 is the attainable ceiling. algorithmic flops: "
+                    "19 (forward) of 45 per band cell, SURVEY 8(d); avg_launch_ms = HIP events on the launch stream, "
+                    "averaged over the timed launches (the other band classes run beside it on their own streams)",
             "phase": {"what": "forward + backward + MAP kernels, all band classes, 45 flop per band cell",
                       "achieved": round(phase_tf, 3), "frac": round(phase_tf / PEAK_FP64_VECTOR_TFLOPS, 4),
                       "ms_per_launch": round(baq_ms / len(works), 4),

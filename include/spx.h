@@ -78,13 +78,15 @@ typedef struct spx_stats {
     int64_t bytes_h2d, bytes_d2h;
     int64_t problems_per_class[12];
     double prep_seconds, h2d_seconds, kernel_seconds, d2h_seconds;
-    /* dominant kernel, measured with HIP events on the launch stream */
+    /* dominant kernel, measured with HIP events on the launch stream, averaged (see n_launches_averaged) */
     double baq_kernel_ms;   /* all BAQ launches of the work list (forward, backward, MAP; every band class) */
     double score_kernel_ms;
     /* the band class holding most cells: its forward / backward kernel alone */
     double main_fwd_ms, main_bwd_ms;
     int64_t main_class_cells;
-    int32_t main_class, main_class_lanes, main_class_slots, reserved;
+    int32_t main_class, main_class_lanes, main_class_slots;
+    int32_t n_launches_averaged; /* the *_ms fields are averages over this many launches: those since the previous
+                                  * spx_collect on the context (at most the last 64) */
 } spx_stats;
 
 const char *spx_strerror(int code);

@@ -73,7 +73,11 @@ static const unsigned char kNt16Int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4
 struct spx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    /* HIP events around the kernels of the last SPX_EV_RING launches (0 start, 1 after MAP, 2 after scoring, 3..5 around
+     * the main class' forward and backward kernels): spx_collect averages over the launches since the previous collect */
+    static const int SPX_EV_RING = 64;
+    hipEvent_t evr[SPX_EV_RING][6] = {};
+    int64_t n_launch = 0, collect_mark = 0;
     /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
      * (or in front of) the bulk class */
     hipStream_t cls_stream[SPX_N_CLASSES] = {};
@@ -150,7 +154,8 @@ extern "C" int spx_create(int device, spx_ctx **out)
     spx_ctx *c = new spx_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
+        for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
     for (int i = 0; i < SPX_N_CLASSES; ++i) {
         HIPCHK(hipStreamCreateWithFlags(&c->cls_stream[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->cls_done[i], hipEventDisableTiming));
@@ -174,7 +179,8 @@ extern "C" void spx_destroy(spx_ctx *c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (auto &a : c->arena_cache) (void)hipFree(a.first);
     for (int i = 0; i < 6; ++i)
-        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+        for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
+            if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
     for (int i = 0; i < SPX_N_CLASSES; ++i) {
         if (c->cls_done[i]) (void)hipEventDestroy(c->cls_done[i]);
         if (c->cls_stream[i]) (void)hipStreamDestroy(c->cls_stream[i]);
@@ -501,7 +507,9 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
 {
     if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    hipEvent_t *ev = c->evr[c->n_launch % spx_ctx::SPX_EV_RING];
+    c->n_launch++;
+    HIPCHK(hipEventRecord(ev[0], c->stream));
     /* the class holding most of the band cells runs on the main stream (its forward and backward kernels are
      * bracketed by events); the others run beside it on their own streams */
     const int mc = w->main_cls;
@@ -509,23 +517,23 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     for (int cls = SPX_N_CLASSES - 1; cls >= 0; --cls) {
         if (!w->cls_used[cls] || cls == mc) continue;
         if (serial) { HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->stream)); continue; }
-        HIPCHK(hipStreamWaitEvent(c->cls_stream[cls], c->ev[0], 0));
+        HIPCHK(hipStreamWaitEvent(c->cls_stream[cls], ev[0], 0));
         HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->cls_stream[cls]));
         HIPCHK(hipEventRecord(c->cls_done[cls], c->cls_stream[cls]));
     }
     if (mc >= 0) {
-        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(hipEventRecord(ev[3], c->stream));
         HIPCHK(spx_launch_baq(mc, 0, &w->cls_batch[mc], c->stream));
-        HIPCHK(hipEventRecord(c->ev[4], c->stream));
+        HIPCHK(hipEventRecord(ev[4], c->stream));
         HIPCHK(spx_launch_baq(mc, 1, &w->cls_batch[mc], c->stream));
-        HIPCHK(hipEventRecord(c->ev[5], c->stream));
+        HIPCHK(hipEventRecord(ev[5], c->stream));
     }
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
         if (w->cls_used[cls] && cls != mc && !serial) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
     HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), c->stream));
-    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipEventRecord(ev[1], c->stream));
     if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, (int32_t)w->hb.markers.size(), w->d_posmin, c->stream));
-    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(hipEventRecord(ev[2], c->stream));
     w->launched = true;
     return SPX_OK;
 }
@@ -552,16 +560,32 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (w->launched) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        w->st.baq_kernel_ms = ms;
-        HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-        w->st.score_kernel_ms = ms;
+        /* averages over the launches since the previous collect (at most the last SPX_EV_RING) */
+        int64_t first = std::max(c->collect_mark, c->n_launch - spx_ctx::SPX_EV_RING);
+        if (first >= c->n_launch) first = c->n_launch - 1;
+        double baq = 0, sc = 0, fw = 0, bw = 0;
+        const int n = (int)(c->n_launch - first);
+        for (int64_t l = first; l < c->n_launch; ++l) {
+            hipEvent_t *ev = c->evr[l % spx_ctx::SPX_EV_RING];
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            baq += ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[1], ev[2]));
+            sc += ms;
+            if (w->main_cls >= 0) {
+                HIPCHK(hipEventElapsedTime(&ms, ev[3], ev[4]));
+                fw += ms;
+                HIPCHK(hipEventElapsedTime(&ms, ev[4], ev[5]));
+                bw += ms;
+            }
+        }
+        c->collect_mark = c->n_launch;
+        w->st.baq_kernel_ms = baq / n;
+        w->st.score_kernel_ms = sc / n;
+        w->st.n_launches_averaged = n;
         if (w->main_cls >= 0) {
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
-            w->st.main_fwd_ms = ms;
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
-            w->st.main_bwd_ms = ms;
+            w->st.main_fwd_ms = fw / n;
+            w->st.main_bwd_ms = bw / n;
             w->st.main_class = w->main_cls;
             w->st.main_class_cells = w->cls_cells[w->main_cls];
             w->st.main_class_lanes = spx::class_lanes(w->main_cls);
@@ -853,7 +877,8 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(SPX_EHIP, "kernel execution failed");
     if (!rc) {
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        hipEvent_t *ev = c->evr[(c->n_launch - 1) % spx_ctx::SPX_EV_RING];
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
         if (kernel_ms) *kernel_ms = ms;
         const size_t nr = hb.rows.size();
         if (post_scale) { /* spx_probaln_posteriors: 1/s[] and z = f*b of every slot of every row of one problem */
