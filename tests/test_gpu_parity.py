@@ -330,3 +330,62 @@ def test_command_line_write_bam(ctx, tmp_path):
     assert 0 < len(disp) < r.batch.contents.n_groups or len(disp) == r.batch.contents.n_groups
     want = sam_text(r.batch, g.ref, qual=want_q, groups=disp)
     assert open(os.path.join(outd, "t.quality_modified.out.bam")).read() == want
+
+
+def test_full_size_workload_properties(ctx):
+    """BASELINE config 2 at the size bench.py times (16 384 HiFi groups, 15 kb reads, the 100 Mbp assembly): the oracle
+    would need minutes for all of it, so the whole batch is checked through size-independent properties -- the same
+    groups scored as one work list, as four shards, in another order and twice in a row give bit-identical scores
+    and decisions -- and a random sample of groups is compared with the oracle."""
+    import threading
+    cfg = synth.default_cfg(synth.HIFI)
+    g = synth.Genome(cfg)
+    par = records.preset("hifi")
+    n, chunk = 16384, 1024
+    parts = [None] * (n // chunk)
+
+    def gen(k0):
+        for k in range(k0, len(parts), 8):
+            parts[k] = g.reads(k * chunk, chunk)
+    th = [threading.Thread(target=gen, args=(k,)) for k in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    ctx.set_reference(g.ref)
+
+    def score(batches, relaunch=False):
+        w = ctx.prepare(batches, par)
+        w.launch()
+        if relaunch:
+            w.launch()
+        out = w.collect(finalize_seed=None)
+        st = w.stats()
+        res = [(o.n_aln, tuple(o.score[a] for a in range(max(o.n_aln, 0))), o.prim_idx, o.max_idx, o.tie_mask, o.pass_)
+               for o in out]
+        w.free()
+        return res, st
+
+    whole, st = score([p.batch for p in parts])
+    assert st.n_dispatched == n and st.n_problems > 1000000 and st.dp_cells > 10 ** 10
+    # shards (what rank r of a multi-GPU run would score) -- union equals the whole
+    sharded = []
+    for r in range(4):
+        res, _ = score([p.batch for p in parts[4 * r:4 * r + 4]])
+        sharded += res
+    assert sharded == whole
+    # another order of the same groups: results follow the groups
+    perm = list(range(len(parts)))[::-1]
+    res, _ = score([parts[k].batch for k in perm])
+    back = [None] * len(parts)
+    for pos, k in enumerate(perm):
+        back[k] = res[pos * chunk:(pos + 1) * chunk]
+    assert [x for blk in back for x in blk] == whole
+    # idempotence: launching the same work list twice leaves the same results
+    again, _ = score([p.batch for p in parts], relaunch=True)
+    assert again == whole
+    # a sample against the oracle
+    rng = np.random.default_rng(3)
+    for k in rng.choice(n, size=48, replace=False):
+        sub = g.reads(int(k), 1)
+        _, ores = orc.run_batch(sub.batch, g.ref, par, threads=1, seed=1)
+        e, o = ores[0], whole[int(k)]
+        assert o[0] == e.n_aln and o[1] == tuple(e.score[a] for a in range(e.n_aln)) and o[2] == e.prim_idx, int(k)
