@@ -659,8 +659,8 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
 /* One lane per problem (G = 1) for the exact band width W = C: no serial passes with idle lanes.
  * Forward: M and I of the previous row stay in VGPRs UNSCALED (the scale factor is applied when a value is
  * read, which is the same multiplication the reference does when it rescales the row); the D row lives in
- * LDS ([slot][lane], conflict free).  Backward: D(i,k+1) is simply the value of the previous loop iteration,
- * so nothing but the M and I rows is kept. */
+ * LDS ([slot][lane], conflict free).  (A one-lane backward kernel was measured too: slower than two lanes per
+ * problem, because the wanted rows of 64 problems diverge; it is not kept.) */
 template <int C>
 struct NibWin { /* C 4-bit codes */
     static constexpr int NW = (C + 7) / 8;
@@ -676,12 +676,6 @@ struct NibWin { /* C 4-bit codes */
         for (int k = 0; k < NW - 1; ++k) w[k] = (w[k] >> 4) | (w[k + 1] << 28);
         w[NW - 1] >>= 4;
         set(C - 1, v);
-    }
-    __device__ __forceinline__ void shift_up(uint32_t v) /* slot c <- slot c-1, slot 0 <- v */
-    {
-#pragma unroll
-        for (int k = NW - 1; k > 0; --k) w[k] = (w[k] << 4) | (w[k - 1] >> 28);
-        w[0] = (w[0] << 4) | v;
     }
 };
 
@@ -843,107 +837,6 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
         sinv[L] = s_cur;
         sinv[L + 1] = s;
     }
-}
-
-template <int C>
-__global__ __launch_bounds__(64, 2) void baq_bwd1_kernel(spx_dev_batch B)
-{
-    const int lane = threadIdx.x & 63;
-    HmmC h;
-    int hasN;
-    const Prob P = load_problem<1>(B, lane, h, hasN, true);
-    const bool act = P.act;
-    const int L = P.L, R = P.R, bw = P.bw;
-    const int Lw = wave_max(L);
-    if (Lw == 0) return;
-    const int nrows = P.nrows, row0 = P.row0;
-    const int stop = act ? B.rows[row0] : 0x7fffffff;
-    const int anyN = wave_max(hasN);
-    double bM[C], bI[C];
-    NibWin<C> cw;
-    const double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
-    double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
-    const int64_t fstride = B.fsave_stride;
-    const int SLOTS = (int)(fstride >> 1);
-    double inv_next = 1.0; /* scale factor still to be applied to bM,bI (1/s[i+1]); row L is stored final */
-    {
-        const double sM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SM] : 0.0;
-        const double sI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SI] : 0.0;
-        const double sL = act ? sinv[L] : 1.0, sL1 = act ? sinv[L + 1] : 1.0;
-        const double vM = (sM / sL) / sL1, vI = (sI / sL) / sL1;
-#pragma unroll
-        for (int k = 0; k < NibWin<C>::NW; ++k) cw.w[k] = 0;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int k = L - bw + c;
-            const bool valid = act && k >= 1 && k <= R;
-            bM[c] = valid ? vM : 0.0;
-            bI[c] = valid ? vI : 0.0;
-            cw.set(c, (act && L >= 2) ? fetch_code(B.ref4, P.ref0, (L - 1) - bw + c, R) : SPX_CODE_OUT);
-        }
-    }
-    int wprev = nrows - 1;
-    int prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
-    auto save_row = [&](double inv) { /* z = f * b(scaled) replaces the forward row */
-        double *dst = fsave + (int64_t)wprev * fstride;
-#pragma unroll
-        for (int c = 0; c < C; ++c) { dst[c] = dst[c] * (bM[c] * inv); dst[SLOTS + c] = dst[SLOTS + c] * (bI[c] * inv); }
-        wprev--;
-        prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
-    };
-    if (act && prev_row == L) save_row(1.0);
-    auto ref_chunk = [&](int i0) { return fetch8(B.ref4, P.ref0 + ((i0 - 7) - bw)); };
-    auto qry_chunk = [&](int i0) { return fetch8(B.qry4, P.qry0 + (i0 - 7)); };
-    uint32_t qwin = 0, rwin = 0;
-    uint32_t qwin_n = (act && L >= 2) ? qry_chunk(L - 1) : 0, rwin_n = (act && L >= 2) ? ref_chunk(L - 1) : 0;
-    double inv_p = (act && L >= 2) ? sinv[L - 1] : 0.0;
-    const double em1 = SPX_EI * h.m1, em4 = SPX_EI * h.m4;
-    /* step t of the wave = row L-1-t of each problem (see baq_bwd_kernel) */
-    const int nb = act ? max(L - stop, 0) : 0;
-    const int nbw = wave_max(nb);
-    const int n_slow = anyN ? nbw : min(nbw, wave_max(act ? min(nb, max(0, (L - 1) - (R - bw - 1))) : 0));
-    auto row = [&](int t, auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        const int i = L - 1 - t;
-        const bool on = act && t < nb;
-        const bool any_first = __any(on && i == 1);
-        if (on) {
-            const uint32_t t4 = (uint32_t)(7 - (t & 7)) * 4u; /* wave-uniform */
-            if ((t & 7) == 0) {
-                qwin = qwin_n; rwin = rwin_n;
-                qwin_n = qry_chunk(i - 8);
-                rwin_n = ref_chunk(i - 8);
-            }
-            const uint32_t qy = (qwin >> t4) & 0xfu;
-            const double inv = inv_p;
-            if (t != 0) {
-                uint32_t rc = (rwin >> t4) & 0xfu;
-                if (!FAST) {
-                    if ((unsigned)(i - bw) >= (unsigned)R) rc = SPX_CODE_OUT;
-                }
-                cw.shift_up(rc);
-            }
-            if (i >= 2) inv_p = sinv[i - 1];
-            const double in = inv_next;
-            /* y = (i > 1): on row 1 every D is 0.  m8y = m8 * y keeps the recurrence at 0 there (0 + 0*0). */
-            const double ym6 = (any_first && i == 1) ? 0.0 : h.m6, ym8 = (any_first && i == 1) ? 0.0 : h.m8;
-            double d = 0.0;
-#pragma unroll
-            for (int c = C - 1; c >= 0; --c) {
-                const double e = emission<FAST>(cw.get(c), qy, h.e_match, h.e_mis) * (bM[c] * in);
-                const double bin = c > 0 ? bI[c - 1] * in : 0.0;
-                const double newM = (e * h.m0 + em1 * bin) + h.m2 * d;
-                const double newI = e * h.m3 + em4 * bin;
-                d = e * ym6 + ym8 * d;
-                bM[c] = newM; bI[c] = newI;
-            }
-            inv_next = inv;
-            if (i == prev_row) save_row(inv);
-        }
-    };
-    int t = 0;
-    for (; t < n_slow; ++t) row(t, std::false_type{});
-    for (; t < nbw; ++t) row(t, std::true_type{});
 }
 
 /* ====================================================================== */
