@@ -1046,7 +1046,13 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
     /* (4,28)/(4,32) with the D row in LDS (DLds) were measured for the ONT bands: parity-clean but slower than
      * these -- four SIMDs share one LDS pipe and the row traffic saturates it */
     case 6: SPX_LAUNCH(4, 26, 0, false)
-    case 7: SPX_LAUNCH(8, 16, 0, false)
+    case 7: /* forward (8,16); backward (4,32): half the serial passes, and unlike the forward kernel (134 spilled
+             * VGPRs at (4,32), 99 with the D row in LDS -- both slower) it fits the register file */
+    {
+        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<8, 16, 0, false>), dim3((B->n_order + 7) / 8), dim3(64), 0, st, *B);
+        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<4, 32, 0, false>), dim3((B->n_order_bwd + 15) / 16), dim3(64), 0, st, *B);
+    }
+    break;
     case 8: SPX_LAUNCH(16, 16, 0, false)
     case 9: SPX_LAUNCH(32, 16, 0, false)
     case 10: SPX_LAUNCH(64, 16, 0, false)

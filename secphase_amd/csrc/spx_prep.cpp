@@ -200,7 +200,7 @@ int64_t band_cells(int L, int R, int bw)
 /* band classes = kernel instantiations (spx_launch_baq): four exact widths, then generic ones by capacity */
 static const int kClassSlots[SPX_N_CLASSES] = {42, 44, 46, 48, 48, 64, 104, 128, 256, 512, 1024, 2048};
 static const int kClassLanes[SPX_N_CLASSES] = {1, 1, 1, 1, 2, 4, 4, 8, 16, 32, 64, 64};
-static const int kClassLanesBwd[SPX_N_CLASSES] = {2, 2, 2, 2, 2, 4, 4, 8, 16, 32, 64, 64};
+static const int kClassLanesBwd[SPX_N_CLASSES] = {2, 2, 2, 2, 2, 4, 4, 4, 16, 32, 64, 64};
 int band_class(int W)
 {
     if (W == 41) return 0;
