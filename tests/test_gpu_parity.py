@@ -305,6 +305,26 @@ def test_quality_modified_records_ont(ctx):
     _quals_parity(ctx, g, g.reads(0, 12), records.preset("ont", bandwidth=50))
 
 
+def test_quality_modified_records_in_a_merged_work_list(ctx):
+    """spx_prepare_many over two record blocks: each block's qualities come back through its own batch index"""
+    import copy
+    from common import batch_qual_copy
+    g = small_genome(synth.HIFI, hardclip_frac=0.3, softclip_frac=0.4, max_secondaries=3, n_paralogs=2)
+    ra, rb = g.reads(0, 20), g.reads(20, 33)
+    par = records.preset("hifi")
+    p_all = copy.copy(par)
+    p_all.flags = 1
+    ctx.set_reference(g.ref)
+    w = ctx.prepare([ra.batch, rb.batch], p_all)
+    w.launch()
+    w.collect(finalize_seed=None)
+    for k, r in enumerate((ra, rb)):
+        want, _ = orc.run_batch_quals(r.batch, g.ref, par, batch_qual_copy(r.batch), threads=2)
+        got = w.apply_quals(r.batch, batch_qual_copy(r.batch), batch_index=k)
+        assert np.array_equal(got, want), k
+    w.free()
+
+
 def test_command_line_write_bam(ctx, tmp_path):
     """secphase --hifi -w: <prefix>.quality_modified.out.bam is what the reference writes -- SAM text (sam_open "w",
     src/secphase.c:643-652) with the header and, for every dispatched group in file order (= -@1), all records with
