@@ -46,6 +46,8 @@ extern "C" {
 #define SPX_ENOMEM (-4)
 #define SPX_EUNSUPPORTED (-5) /* input uses a construct the reference leaves undefined  */
 #define SPX_ENOREF (-6)    /* spx_set_reference has not been called                   */
+#define SPX_ENOTAG (-7)    /* a record of a dispatched group has neither cs nor MD: the reference prints "At least
+                            * one of the MD or CS tags should be present!" and exits (cigar_it.c:64-67)   */
 
 typedef struct spx_ctx spx_ctx;
 typedef struct spx_work spx_work;

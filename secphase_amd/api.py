@@ -13,7 +13,7 @@ from .records import SpxBatch, SpxParams, SpxRef
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPX_LIB") or os.path.join(_DIR, "libspx.so")
 
-OK, ENODEVICE, EHIP, EINVAL, ENOMEM, EUNSUPPORTED, ENOREF = 0, -1, -2, -3, -4, -5, -6
+OK, ENODEVICE, EHIP, EINVAL, ENOMEM, EUNSUPPORTED, ENOREF, ENOTAG = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class SpxError(RuntimeError):

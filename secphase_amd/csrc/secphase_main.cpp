@@ -222,6 +222,11 @@ int main(int argc, char *argv[])
             if ((rc = spx_collect(ctx, w, out.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
             t_gpu += now_s() - t0;
             { spx_stats st; spx_work_stats(w, &st); t_hostprep += st.prep_seconds; t_h2d += st.h2d_seconds; t_kernel += st.kernel_seconds; }
+            for (int g = 0; g < ng; ++g)
+                if (out[g].n_aln == SPX_ENOTAG) { /* the reference stops here: cigar_it.c:64-67 */
+                    fprintf(stderr, "At least one of the MD or CS tags should be present!\n");
+                    return 1;
+                }
             t0 = now_s();
             if (sam) { /* src/secphase.c:182-189: written before the decision, file order = the reference at -@1 */
                 int64_t qend = 0;

@@ -386,7 +386,7 @@ static int build_ops(Aln &a)
     a.lclip = ((a.cigar[0] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(a.cigar[0] >> 4) : 0;
     a.rclip = ((a.cigar[a.n_cigar - 1] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(a.cigar[a.n_cigar - 1] >> 4) : 0;
     const bool use_cs = a.cs != nullptr, use_md = !use_cs && a.md != nullptr;
-    if (!use_cs && !use_md) return SPX_EINVAL; /* neither cs nor MD: the reference exits */
+    if (!use_cs && !use_md) return SPX_ENOTAG; /* neither cs nor MD: the reference exits (cigar_it.c:64-67) */
     int md_at = 0;
     Op cur;
     cur.op = 255; cur.len = 0; cur.ret = 0;

@@ -127,6 +127,7 @@ extern "C" const char *spx_strerror(int code)
     case SPX_ENOMEM: return "out of memory";
     case SPX_EUNSUPPORTED: return "construct left undefined by the reference / not supported";
     case SPX_ENOREF: return "reference not set";
+    case SPX_ENOTAG: return "At least one of the MD or CS tags should be present!";
     default: return "unknown error";
     }
 }

@@ -410,3 +410,20 @@ def test_full_size_workload_properties(ctx):
         _, ores = orc.run_batch(sub.batch, g.ref, par, threads=1, seed=1)
         e, o = ores[0], whole[int(k)]
         assert o[0] == e.n_aln and o[1] == tuple(e.score[a] for a in range(e.n_aln)) and o[2] == e.prim_idx, int(k)
+
+
+def test_command_line_stops_on_records_without_tags(ctx, tmp_path):
+    """a dispatched group whose records carry neither cs nor MD ends the run like the reference does (cigar_it.c:64-67)"""
+    import subprocess
+    from bamio import write_bam, write_fasta
+    from common import HandBatch, HandRef
+    seq = "ACGT" * 10
+    hr = HandRef([("c0", seq * 4)])
+    hb = HandBatch([("r", [(0, 0, 0, "40M", seq, 30, None), (256, 0, 3, "38M", seq[:38], 30, None)])])
+    fa, bam, outd = str(tmp_path / "asm.fa"), str(tmp_path / "reads.bam"), str(tmp_path / "out")
+    write_fasta(fa, hr.ref)
+    write_bam(bam, hb.batch, hr.ref, extra_tags=False)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "secphase_amd", "bin", "secphase")
+    p = subprocess.run([exe, "--hifi", "-i", bam, "-f", fa, "--outDir", outd], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1
+    assert "At least one of the MD or CS tags should be present!" in p.stderr

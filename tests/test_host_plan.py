@@ -138,6 +138,18 @@ def test_plan_rejects_alignment_without_aligned_bases(built):
     assert res[0].n_aln < 0 and res[1].n_aln == 2
 
 
+def test_plan_reports_records_without_cs_and_md(built):
+    """cigar_it.c:64-67: the reference prints "At least one of the MD or CS tags should be present!" and exits"""
+    seq = "ACGT" * 10
+    hr = HandRef([("c0", seq * 4)])
+    hb = HandBatch([("r", [(0, 0, 0, "40M", seq, 30, ":40"), (256, 0, 3, "38M", seq[:38], 30, None)])])
+    plan = api.Plan(hr.ref, hb.batch, records.preset("hifi"))
+    assert plan.view.grp_error[0] == api.ENOTAG and plan.view.n_groups == 0
+    assert b"MD or CS" in api.lib().spx_strerror(api.ENOTAG)
+    _, res = orc.run_batch(hb.batch, hr.ref, records.preset("hifi"), threads=1, seed=1)
+    assert res[0].n_aln < 0
+
+
 def test_host_tables_match_libm(built):
     import math
     thr = (C.c_double * 102)()
