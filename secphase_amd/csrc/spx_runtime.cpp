@@ -449,19 +449,25 @@ extern "C" int spx_prepare_many(spx_ctx *c, const spx_batch *const *bts, int32_t
     memset(&w->st, 0, sizeof w->st);
     w->par = *par;
     double t0 = now_s();
-    /* tasks of <= 256 groups, pulled by the worker threads, merged in file order */
+    /* tasks of 16..256 groups (about four per thread, so that long reads do not leave threads idle), pulled by the
+     * worker threads, merged in file order */
     struct Task { int b; int32_t g0, g1, base; };
     std::vector<Task> tasks;
-    int32_t base = 0;
+    int nthr = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
+    nthr = std::max(1, std::min(nthr, 128));
+    int64_t n_all = 0;
     for (int b = 0; b < n_batches; ++b) {
         if (!bts[b]) { delete w; return fail(SPX_EINVAL, "NULL batch"); }
-        for (int32_t g = 0; g < bts[b]->n_groups; g += 256)
-            tasks.push_back({b, g, std::min(bts[b]->n_groups, g + 256), base});
+        n_all += bts[b]->n_groups;
+    }
+    const int32_t tsize = (int32_t)std::max<int64_t>(16, std::min<int64_t>(256, n_all / (4 * (int64_t)nthr)));
+    int32_t base = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        for (int32_t g = 0; g < bts[b]->n_groups; g += tsize)
+            tasks.push_back({b, g, std::min(bts[b]->n_groups, g + tsize), base});
         base += bts[b]->n_groups;
     }
     w->n_groups_in = base;
-    int nthr = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
-    nthr = std::max(1, std::min(nthr, 128));
     nthr = std::min<int>(nthr, (int)std::max<size_t>(tasks.size(), 1));
     const spx::RefIndex &ri = c->ref;
     std::vector<spx::HostBatch> parts(tasks.size());
