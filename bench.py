@@ -252,7 +252,7 @@ def main():
                     "algorithmic_bytes_per_launch": int(compulsory)},
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only: the other ranks would sit in a barrier
             from oracle import orc
             ns = args.cpu_sample or max(256 if ont else 1024, (4 if ont else 16) * ncpu)
             ns = min(ns, gps)
