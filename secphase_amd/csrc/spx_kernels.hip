@@ -1,23 +1,23 @@
 /*
  * spx_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the secphase hot path.
  *
- *  baq_kernel<G,C>  banded profile-HMM forward/backward + MAP at the wanted
- *                   rows (= htslib-1.17 probaln_glocal as called from
- *                   /root/reference/programs/submodules/ptMarker/ptMarker.c:755-757)
- *                   fused with secphase's write-back rule (ptMarker.c:778-779,786).
- *  score_kernel     filter_lowq_markers + calc_alignment_score + the
- *                   deterministic part of get_best_record_index
- *                   (ptMarker.c:110-153,307-325; ptAlignment.c:137-177).
+ *  baq_fwd1_kernel<W>        banded profile-HMM forward pass, one lane per DP problem (the HiFi band widths)
+ *  baq_fwd_kernel<G,C,..>    the same with G lanes x C slots per problem (every other band width)
+ *  baq_bwd_kernel<G,C,..>    backward pass; z = f*b at the wanted rows
+ *  map_kernel                arg-max, ordered sum, phred and secphase's write-back rule per wanted row
+ *                            (= htslib-1.17 probaln_glocal as called from
+ *                            /root/reference/programs/submodules/ptMarker/ptMarker.c:755-757, with
+ *                            ptMarker.c:778-779,786)
+ *  posmin/score/decide       filter_lowq_markers + calc_alignment_score + the deterministic part of
+ *                            get_best_record_index (ptMarker.c:110-153,307-325; ptAlignment.c:137-177)
+ *  pack_kernel               8-byte decision records for the multi-GPU gather
  *
- * Mapping: FP64-VALU bound, not HBM bound.  One DP problem
- * is owned by G adjacent lanes of a wavefront (64/G problems per wave); the
- * band is stored on DIAGONALS (slot j <-> column k = i - bw + j) so that the
- * M recurrence is lane-local, and each lane keeps C consecutive slots of the
- * current row entirely in VGPRs (3*C doubles).  Bit-exactness with the CPU
- * order of operations is kept by construction: no FMA contraction
- * (-ffp-contract=off), IEEE division, the D-state recurrence and the row sum
- * are evaluated in the reference's sequential column order (G short masked
- * passes with a wave-shuffle carry), and the per-row scale factor is applied
+ * Mapping: FP64 vector-ALU work, not HBM- or MFMA-bound.  The band is stored on DIAGONALS
+ * (slot j <-> column k = i - bw + j) so that the M recurrence is slot-local; a problem is owned by G adjacent lanes
+ * of a wavefront, each holding C consecutive slots of the current row in VGPRs (the one-lane kernel parks its D row
+ * in LDS).  Bit-exactness with the CPU order of operations is kept by construction: no FMA contraction
+ * (-ffp-contract=off), IEEE division, the D-state recurrence and the row sum evaluated in the reference's
+ * sequential column order (G short masked passes with a lane-to-lane carry), and the per-row scale factor applied
  * exactly where the reference applies it.
  */
 #include <hip/hip_runtime.h>
