@@ -173,6 +173,12 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &
 {
     double nM = shfl_down1<G>(fM[0]), nI = shfl_down1<G>(fI[0]);
     if (g == G - 1) { nM = 0.0; nI = 0.0; }
+    /* masked rows, narrow lanes: the validity of a slot is folded into the two inputs of its D recurrence in the
+     * parallel phase (m2*M(i,k-1) -> 0, m8 -> 0), so the serial passes -- executed by the whole wave for one lane's
+     * benefit -- need no selects at all */
+    constexpr bool MASKC = !FAST && !DS::lds && C <= 16;
+    double m8v[MASKC ? C : 1];
+    const int nc_own = g < tlast ? C : (g == tlast ? (W0 ? W0 - ((W0 - 1) / C) * C : Wu - tlast * C) : 0);
     /* parallel phase: fM<-M(i,.), fI<-I(i,.), fD<-m2*M(i,k-1) */
     double prevM;
     {
@@ -192,14 +198,24 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &
         const double pMn = (c + 1 < C) ? fM[c + 1] : nM, pIn = (c + 1 < C) ? fI[c + 1] : nI;
         const double newM = e * S;
         fI[c] = SPX_EI * (h.m1 * pMn + h.m4 * pIn);
-        D.set(c, h.m2 * prevM);
+        if constexpr (MASKC) {
+            const bool vld = c < nc_own && !(ew.get(c) & SPX_CODE_OUT);
+            D.set(c, vld ? h.m2 * prevM : 0.0);
+            m8v[c] = vld ? h.m8 : 0.0;
+        } else
+            D.set(c, h.m2 * prevM);
         fM[c] = newM;
         prevM = newM;
     }
     {
         double pl = shfl_up1<G>(prevM);
         if (g == 0 || g > tlast) pl = 0.0; /* lanes beyond the band keep exact zeros */
-        D.set(0, h.m2 * pl);
+        if constexpr (MASKC) {
+            const bool vld = 0 < nc_own && !(ew.get(0) & SPX_CODE_OUT);
+            D.set(0, vld ? h.m2 * pl : 0.0);
+            m8v[0] = vld ? h.m8 : 0.0;
+        } else
+            D.set(0, h.m2 * pl);
     }
     /* serial phase: D recurrence and row sum in column order, one lane of the group at a time.
      * Straight-line code only (uniform selects, no branches inside the unrolled register arrays). */
@@ -215,7 +231,14 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &
                 for (int c = 0; c < C; ++c) av[c] = D.get(c);
             }
             auto Aget = [&](int c) { if constexpr (DS::lds) return av[c]; else return D.get(c); };
-            if (FAST && t < tlast) {
+            if constexpr (MASKC) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) { /* a slot that is not a band cell: 0 + 0*d = 0, and it adds (0+0)+0 to the sum */
+                    d = Aget(c) + m8v[c] * d;
+                    D.set(c, d);
+                    s = s + ((fM[c] + fI[c]) + d);
+                }
+            } else if (FAST && t < tlast) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     d = Aget(c) + h.m8 * d;
@@ -232,8 +255,9 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &
                     const double dn = Aget(c) + h.m8 * d;
                     d = valid ? dn : 0.0;
                     D.set(c, d);
-                    const double tt = (fM[c] + fI[c]) + d;
-                    s = (FAST || valid) ? s + tt : s; /* FAST: pad slots hold exact zeros */
+                    /* no select on the sum: a slot that is not a band cell holds M = I = 0 (emission 0 / zero inputs) and
+                     * its D was just forced to 0, so it adds exactly +0 */
+                    s = s + ((fM[c] + fI[c]) + d);
                 }
             }
             carryD = d; carryS = s; mysum = s;
