@@ -867,6 +867,8 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
 /* MAP + phred + write-back rule, one lane per wanted row.  z = f*b over the M and I states of the
  * row in column order: first strictly greatest wins, the sum is sequential (probaln_glocal's MAP loop);
  * then min(raw, q) with the CIGAR/MAP consistency check (ptMarker.c:778-779,786). */
+/* CQMAX: most slots per lane this instantiation keeps in registers (12: 61 VGPRs, 8 waves per SIMD; 32: 150 VGPRs) */
+template <int CQMAX>
 __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_rows_total)
 {
     /* 4 adjacent lanes per wanted row, each owning a contiguous quarter of the slots (coalesced reads of the
@@ -885,13 +887,14 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
     const int ja = max(j0, g * Cq), jb = min(j1, g * Cq + Cq - 1);
     double best = 0.0, carry = 0.0, mysum = 0.0;
     int best_k = -1;
-    if (__builtin_amdgcn_ballot_w64(on && Cq > 12) == 0) {
-        /* narrow bands (every HiFi class): all loads are issued before the first add, so a wave pays one
-         * memory round trip instead of one per slot; slots outside [ja,jb] read as +0.0, which changes neither
-         * the sequential sum nor the strict arg-max */
-        double zm[12], zi[12];
+    /* narrow and medium bands: all loads of a row are issued before the first add, so a wave pays one memory round
+     * trip instead of one per slot; slots outside [ja,jb] read as +0.0, which changes neither the sequential sum nor
+     * the strict arg-max.  CQ = slots per lane held in registers: 12 covers every HiFi class, 32 the ONT ones */
+    auto batched = [&](auto cq_tag) {
+        constexpr int CQ = decltype(cq_tag)::value;
+        double zm[CQ], zi[CQ];
 #pragma unroll
-        for (int c = 0; c < 12; ++c) {
+        for (int c = 0; c < CQ; ++c) {
             const int j = g * Cq + c;
             const bool in = on && c < Cq && j >= ja && j <= jb;
             zm[c] = in ? zM[j] : 0.0;
@@ -899,18 +902,22 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
         }
         const int kbase = i - bw + g * Cq;
 #pragma unroll
-        for (int c = 0; c < 12; ++c) {
+        for (int c = 0; c < CQ; ++c) {
             if (zm[c] > best) { best = zm[c]; best_k = ((kbase + c - 1) << 2) | 0; }
             if (zi[c] > best) { best = zi[c]; best_k = ((kbase + c - 1) << 2) | 1; }
         }
         for (int t = 0; t < 4; ++t) {
             double sacc = carry;
 #pragma unroll
-            for (int c = 0; c < 12; ++c) { sacc += zm[c]; sacc += zi[c]; }
+            for (int c = 0; c < CQ; ++c) { sacc += zm[c]; sacc += zi[c]; }
             if (g == t) mysum = sacc;
             carry = __shfl_up(mysum, 1, 4);
         }
-    } else
+    };
+    const int cq_wave = wave_max(on ? Cq : 0);
+    if (cq_wave <= 12) batched(std::integral_constant<int, 12>{});
+    else if (CQMAX >= 32 && cq_wave <= 32) batched(std::integral_constant<int, CQMAX >= 32 ? 32 : 12>{});
+    else
     for (int t = 0; t < 4; ++t) {
         if (g == t && on) {
             double s = carry;
@@ -949,10 +956,12 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
     }
 }
 
-extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st)
+extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st)
 {
     if (n_rows_total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(map_kernel, dim3((n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    /* wide: most rows belong to bands of more than 48 slots (ONT): the instantiation that batches up to 32 slots per lane */
+    if (wide) hipLaunchKernelGGL(map_kernel<32>, dim3((n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    else hipLaunchKernelGGL(map_kernel<12>, dim3((n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
     return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ struct spx_bedset;
 
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st);
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
-extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st);
+extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
                                       unsigned long long *out, hipStream_t st);
 
@@ -537,7 +537,11 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     }
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
         if (w->cls_used[cls] && cls != mc && !serial) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
-    HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), c->stream));
+    {
+        int64_t narrow = 0, wide = 0;
+        for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
+        HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), wide > narrow, c->stream));
+    }
     HIPCHK(hipEventRecord(ev[1], c->stream));
     if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, (int32_t)w->hb.markers.size(), w->d_posmin, c->stream));
     HIPCHK(hipEventRecord(ev[2], c->stream));
