@@ -169,7 +169,8 @@ struct HmmC {
  * Returns the row sum s[i]. */
 template <int G, int C, bool FAST, int W0, class DS>
 __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &D, double dinv, const CodeWin<C> &ew,
-                                          uint32_t qy, const HmmC &h, int g, int Wu, int tlast, double &inv_out)
+                                          uint32_t qy, const HmmC &h, int g, int Wu, int tlast, int t_first, int t_stop,
+                                          double &inv_out)
 {
     double nM = shfl_down1<G>(fM[0]), nI = shfl_down1<G>(fI[0]);
     if (g == G - 1) { nM = 0.0; nI = 0.0; }
@@ -219,8 +220,12 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &
     }
     /* serial phase: D recurrence and row sum in column order, one lane of the group at a time.
      * Straight-line code only (uniform selects, no branches inside the unrolled register arrays). */
+    /* Lanes whose slots all lie left of column 1 (first rows: t < t_first) hold exact zeros and are skipped; so are,
+     * on masked rows, the lanes right of column R for every problem of the wave (t > t_stop): their recurrence
+     * inputs were zeroed above.  Both bounds are wave-uniform. */
+    const int t_end = MASKC ? min(t_stop, tlast) : tlast;
     double carryD = 0.0, carryS = 0.0, mysum = 0.0;
-    for (int t = 0; t <= tlast; ++t) {
+    for (int t = t_first; t <= t_end; ++t) {
         if (g == t) {
             double d = carryD, s = carryS;
             /* LDS mode: fetch the whole m2*M(i,k-1) row of this lane first (independent reads, pipelined),
@@ -262,12 +267,12 @@ __device__ __forceinline__ double fwd_row(double (&fM)[C], double (&fI)[C], DS &
             }
             carryD = d; carryS = s; mysum = s;
         }
-        if (t < tlast) {
+        if (t < t_end) {
             carryD = shfl_up1<G>(carryD);
             carryS = shfl_up1<G>(carryS);
         }
     }
-    const double tot = __shfl(mysum, tlast, G);
+    const double tot = __shfl(mysum, t_end, G);
     const double inv = 1.0 / tot;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
     const int fast_end = anyN ? 1 : min(wave_min(act ? R - bw : 0x7fffffff), Lw);
     const int tlast = (Wu - 1) / C;
     const int jbase = g * C;
+    const int bwu = (Wu - 1) / 2, Rmax = wave_max(act ? R : 0);
 
     double fM[C], fI[C];
     typename std::conditional<LDSD, DLds<C>, DRegs<C>>::type D;
@@ -532,7 +538,9 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
 #pragma unroll
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
             double inv;
-            s_cur = fwd_row<G, C, FAST, W0>(fM, fI, D, dinv, ew, qy, h, g, Wu, tlast, inv);
+            /* wave-uniform lane range that can hold band cells on this row: columns 1 .. max R of the wave */
+            const int t_first = max(0, bwu + 1 - i) / C, t_stop = max(0, Rmax - i + bwu) / C;
+            s_cur = fwd_row<G, C, FAST, W0>(fM, fI, D, dinv, ew, qy, h, g, Wu, tlast, t_first, t_stop, inv);
             dinv = inv;
             put_inv(inv);
             if (g == 0 && ((i & 7) == 7 || i == L)) flush_inv(i);
