@@ -78,7 +78,7 @@ typedef struct spx_stats {
     int64_t n_groups, n_dispatched, n_problems, n_rows, dp_cells;
     int64_t n_markers;
     int64_t bytes_h2d, bytes_d2h;
-    int64_t problems_per_class[12];
+    int64_t problems_per_class[16];
     double prep_seconds, h2d_seconds, kernel_seconds, d2h_seconds;
     /* dominant kernel, measured with HIP events on the launch stream, averaged (see n_launches_averaged) */
     double baq_kernel_ms;   /* all BAQ launches of the work list (forward, backward, MAP; every band class) */

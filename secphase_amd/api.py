@@ -41,7 +41,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("n_groups", C.c_int64), ("n_dispatched", C.c_int64), ("n_problems", C.c_int64), ("n_rows", C.c_int64),
         ("dp_cells", C.c_int64), ("n_markers", C.c_int64), ("bytes_h2d", C.c_int64), ("bytes_d2h", C.c_int64),
-        ("problems_per_class", C.c_int64 * 12),
+        ("problems_per_class", C.c_int64 * 16),
         ("prep_seconds", C.c_double), ("h2d_seconds", C.c_double), ("kernel_seconds", C.c_double),
         ("d2h_seconds", C.c_double), ("baq_kernel_ms", C.c_double), ("score_kernel_ms", C.c_double),
         ("main_fwd_ms", C.c_double), ("main_bwd_ms", C.c_double), ("main_class_cells", C.c_int64),

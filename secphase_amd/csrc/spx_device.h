@@ -10,7 +10,7 @@
 /* ref/query base codes on the device: 0..3 = ACGT, 4 = N/ambiguous,
  * SPX_CODE_OUT = column outside [1,R] (no such DP cell) */
 /* band classes = kernel instantiations (lanes per problem x slots per lane), see spx_launch_baq */
-#define SPX_N_CLASSES 12
+#define SPX_N_CLASSES 14
 
 #define SPX_CODE_N 4
 #define SPX_CODE_OUT 8

@@ -441,7 +441,8 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
     const int nrows = P.nrows, row0 = P.row0;
 
     double s_cur = 1.0;
-    /* 1/s[i] of eight rows is written as one 64-byte line (see baq_fwd1_kernel) */
+    /* 1/s[i] of eight rows is written as one 64-byte line (see baq_fwd1_kernel) -- where 16 VGPRs can be spared */
+    constexpr bool STAGE = C <= 16;
     double ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0, ib4 = 0, ib5 = 0, ib6 = 0, ib7 = 0;
     auto put_inv = [&](double v) { ib0 = ib1; ib1 = ib2; ib2 = ib3; ib3 = ib4; ib4 = ib5; ib5 = ib6; ib6 = ib7; ib7 = v; };
     auto flush_inv = [&](int i) { /* rows i-7 .. i; rows < 0 of a short query land in the problem's lead pad */
@@ -506,8 +507,11 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
                 fM[c] = fM[c] / tot;
                 fI[c] = fI[c] / tot;
             }
-            put_inv(1.0 / tot);
-            if (g == 0 && L == 1) flush_inv(1);
+            if constexpr (STAGE) {
+                put_inv(1.0 / tot);
+                if (g == 0 && L == 1) flush_inv(1);
+            } else if (g == 0)
+                sinv[1] = 1.0 / tot;
             if (next_row == 1) save_row();
         }
     }
@@ -542,8 +546,11 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
             const int t_first = max(0, bwu + 1 - i) / C, t_stop = max(0, Rmax - i + bwu) / C;
             s_cur = fwd_row<G, C, FAST, W0>(fM, fI, D, dinv, ew, qy, h, g, Wu, tlast, t_first, t_stop, inv);
             dinv = inv;
-            put_inv(inv);
-            if (g == 0 && ((i & 7) == 7 || i == L)) flush_inv(i);
+            if constexpr (STAGE) {
+                put_inv(inv);
+                if (g == 0 && ((i & 7) == 7 || i == L)) flush_inv(i);
+            } else if (g == 0)
+                sinv[i] = inv;
             if (i == next_row) save_row();
         }
     };
@@ -1098,6 +1105,8 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
     case 9: SPX_LAUNCH(32, 16, 0, false)
     case 10: SPX_LAUNCH(64, 16, 0, false)
     case 11: SPX_LAUNCH(64, 32, 0, false)
+    case 12: SPX_LAUNCH(4, 28, 0, false)
+    case 13: SPX_LAUNCH(4, 30, 0, false)
     default: return hipErrorInvalidValue;
     }
 #undef SPX_LAUNCH_EXACT

@@ -197,17 +197,25 @@ int64_t band_cells(int L, int R, int bw)
     return hi - lo + l;
 }
 
-/* band classes = kernel instantiations (spx_launch_baq): four exact widths, then generic ones by capacity */
-static const int kClassSlots[SPX_N_CLASSES] = {42, 44, 46, 48, 48, 64, 104, 128, 256, 512, 1024, 2048};
-static const int kClassLanes[SPX_N_CLASSES] = {1, 1, 1, 1, 2, 4, 4, 8, 16, 32, 64, 64};
-static const int kClassLanesBwd[SPX_N_CLASSES] = {2, 2, 2, 2, 2, 4, 4, 4, 16, 32, 64, 64};
+/* band classes = kernel instantiations (spx_launch_baq): four exact widths (one-lane forward kernel), then generic
+ * ones by capacity.  Classes 12 and 13 were added for the ONT widths: four lanes per problem cost half the serial
+ * passes of the (8,16) class, and 28 / 30 slots per lane is what the register file still takes (38 / 64 spilled
+ * VGPRs in the forward kernel; (4,32) spills 134 and loses). */
+static const int kClassSlots[SPX_N_CLASSES] = {42, 44, 46, 48, 48, 64, 104, 128, 256, 512, 1024, 2048, 112, 120};
+static const int kClassLanes[SPX_N_CLASSES] = {1, 1, 1, 1, 2, 4, 4, 8, 16, 32, 64, 64, 4, 4};
+static const int kClassLanesBwd[SPX_N_CLASSES] = {2, 2, 2, 2, 2, 4, 4, 4, 16, 32, 64, 64, 4, 4};
 int band_class(int W)
 {
     if (W == 41) return 0;
     if (W == 43) return 1;
     if (W == 45) return 2;
     if (W == 47) return 3;
-    for (int c = 4; c < SPX_N_CLASSES; ++c)
+    if (W <= 48) return 4;
+    if (W <= 64) return 5;
+    if (W <= 104) return 6;
+    if (W <= 112) return 12;
+    if (W <= 120) return 13;
+    for (int c = 7; c < 12; ++c)
         if (W <= kClassSlots[c]) return c;
     return -1;
 }
