@@ -123,7 +123,8 @@ def test_probaln_posteriors_bit_exact(ctx):
     rng = np.random.default_rng(11)
     shapes = [(40, 70, 60), (200, 230, 130), (300, 330, 130), (387, 507, 143), (100, 100, 20), (262, 260, 21),
               (500, 497, 22), (481, 487, 23), (300, 300, 52), (150, 160, 55), (200, 190, 60), (120, 150, 130),
-              (64, 64, 30), (9, 12, 5), (1, 1, 1), (3, 40, 37), (40, 3, 37), (700, 690, 300), (260, 262, 600), (90, 95, 45)]
+              (64, 64, 30), (9, 12, 5), (1, 1, 1), (3, 40, 37), (40, 3, 37), (700, 690, 300), (260, 262, 600), (90, 95, 45),
+              (260, 262, 55), (240, 240, 58), (230, 233, 59), (250, 250, 62), (180, 170, 25)]  # W = 115, 117, 125, 125, 71
     for (L, R, bw) in shapes:
         for kind in ("homopolymer", "related", "unrelated"):
             if kind == "homopolymer":
