@@ -30,9 +30,10 @@ FWD_FLOPS_PER_CELL = 19
 
 def pmc_traffic(kernel, gps):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_counters.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very command, KB units).  FETCH_SIZE is
-    reported as read on gfx950 (the guide's x2 correction applies to wide 16 B/lane streams; these kernels read
-    bytes and dwords), so the figure is a lower bound on the read side.  None when the profile does not match."""
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very command, KB units).  The guide's x2
+    correction of FETCH_SIZE on gfx950 applies to 16 B/lane streaming reads; for the access pattern of these kernels
+    the counters were calibrated on the backward kernel's known read / write volume: factor 1.
+    None when the profile does not match."""
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01_counters.json")))
         meta = prof.get("_meta", {})
@@ -226,7 +227,8 @@ def main():
         phase_tf = FLOPS_PER_CELL * (cells / len(works)) / (baq_ms / len(works) * 1e-3) / 1e12
         compulsory = (bytes_in + n_rows * 13) / len(works)  # inputs + per-row outputs, per launch
         roofline = {
-            "bound": "valu_fp64",
+            "bound": "mfma",  # the compute roof of the two the contract names; see "compute_unit" and "note"
+            "compute_unit": "valu_fp64",
             "achieved": round(achieved_tf, 3),
             "peak": PEAK_FP64_VECTOR_TFLOPS,
             "unit": "TFLOP/s",
@@ -237,7 +239,10 @@ def main():
             "launches_averaged": int(st0.n_launches_averaged),
             "cells_per_launch": int(cls_cells),
             "flops_per_cell": FWD_FLOPS_PER_CELL,
-            "note": "rows live in VGPRs/LDS: FP64 vector-ALU work under the package power limit (the big kernels run at "
+            "note": "compute-bound, but on the FP64 VECTOR ALU, not on the matrix cores: the DP has sequential dependences "
+                    "inside every row and MFMA's fused rounding would break bit-exactness; MI355X's FP64 MFMA peak equals "
+                    "its FP64 vector peak (78.6 TFLOP/s), so the roof is the same number. "
+                    "rows live in VGPRs/LDS: FP64 vector-ALU work under the package power limit (the big kernels run at "
                     "1.8-2.0 GHz, ~85% of the VALU issue slots), not HBM/MFMA. peak = vector FP64 at 2.4 GHz with FMA counted "
                     "as 2; the bit-exact path may not fuse mul+add, so 39.3 is the attainable ceiling. algorithmic flops: "
                     "19 (forward) of 45 per band cell, SURVEY 8(d); avg_launch_ms = HIP events on the launch stream, "
