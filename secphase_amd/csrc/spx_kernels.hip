@@ -883,19 +883,19 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
  * row in column order: first strictly greatest wins, the sum is sequential (probaln_glocal's MAP loop);
  * then min(raw, q) with the CIGAR/MAP consistency check (ptMarker.c:778-779,786). */
 /* CQMAX: most slots per lane this instantiation keeps in registers (12: 61 VGPRs, 8 waves per SIMD; 32: 150 VGPRs) */
-template <int CQMAX>
+template <int CQMAX, int LPR>
 __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_rows_total)
 {
-    /* 4 adjacent lanes per wanted row, each owning a contiguous quarter of the slots (coalesced reads of the
-     * 2 x slots doubles a row holds); products and the running argmax are lane-local, the sum is passed from
-     * lane to lane in column order */
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = tid >> 2, g = tid & 3;
+    /* LPR adjacent lanes per wanted row (4 for the narrow bands, 8 for the wide ones), each owning a contiguous
+     * share of the slots (coalesced reads of the 2 x slots doubles a row holds); products and the running argmax
+     * are lane-local, the sum is passed from lane to lane in column order */
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(tid / LPR), g = (int)(tid & (LPR - 1));
     const bool on = r < n_rows_total;
     const int rr = on ? r : 0;
     const int p = B.row_prob[rr];
     const int i = B.rows[rr], bw = B.bw[p], R = B.R[p];
-    const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = (slots + 3) >> 2;
+    const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = (slots + LPR - 1) / LPR;
     const int64_t off = B.fsave_off[p] + (int64_t)(rr - B.row_off[p]) * 2 * slots;
     const double *zM = B.fsave + off, *zI = zM + slots; /* z = f*b, written by the backward kernel */
     const int j0 = max(0, bw + 1 - i), j1 = min(W - 1, R - i + bw); /* 1 <= k = i - bw + j <= R */
@@ -921,19 +921,19 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
             if (zm[c] > best) { best = zm[c]; best_k = ((kbase + c - 1) << 2) | 0; }
             if (zi[c] > best) { best = zi[c]; best_k = ((kbase + c - 1) << 2) | 1; }
         }
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < LPR; ++t) {
             double sacc = carry;
 #pragma unroll
             for (int c = 0; c < CQ; ++c) { sacc += zm[c]; sacc += zi[c]; }
             if (g == t) mysum = sacc;
-            carry = __shfl_up(mysum, 1, 4);
+            carry = __shfl_up(mysum, 1, LPR);
         }
     };
     const int cq_wave = wave_max(on ? Cq : 0);
     if (cq_wave <= 12) batched(std::integral_constant<int, 12>{});
-    else if (CQMAX >= 32 && cq_wave <= 32) batched(std::integral_constant<int, CQMAX >= 32 ? 32 : 12>{});
+    else if (CQMAX > 12 && cq_wave <= CQMAX) batched(std::integral_constant<int, CQMAX>{});
     else
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < LPR; ++t) {
         if (g == t && on) {
             double s = carry;
             for (int j = ja; j <= jb; ++j) {
@@ -947,17 +947,17 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
             }
             mysum = s;
         }
-        carry = __shfl_up(mysum, 1, 4); /* lane t+1 continues from lane t's partial sum */
+        carry = __shfl_up(mysum, 1, LPR); /* lane t+1 continues from lane t's partial sum */
     }
-    const double sum = __shfl(mysum, 3, 4);
+    const double sum = __shfl(mysum, LPR - 1, LPR);
     /* first strictly greatest in column order: the lower lane wins ties */
 #pragma unroll
-    for (int o = 1; o < 4; o <<= 1) {
-        const double ob = __shfl_up(best, o, 4);
-        const int ok = __shfl_up(best_k, o, 4);
+    for (int o = 1; o < LPR; o <<= 1) {
+        const double ob = __shfl_up(best, o, LPR);
+        const int ok = __shfl_up(best_k, o, LPR);
         if (g >= o && ob >= best && ok >= 0) { best = ob; best_k = ok; }
     }
-    if (g == 3 && on) {
+    if (g == LPR - 1 && on) {
         const double mx = best / sum;
         const uint32_t q = phred_from_x(1.0 - mx, B.qthr);
         if (B.out_state) B.out_state[r] = best_k;
@@ -974,9 +974,9 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st)
 {
     if (n_rows_total <= 0) return hipSuccess;
-    /* wide: most rows belong to bands of more than 48 slots (ONT): the instantiation that batches up to 32 slots per lane */
-    if (wide) hipLaunchKernelGGL(map_kernel<32>, dim3((n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
-    else hipLaunchKernelGGL(map_kernel<12>, dim3((n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    /* wide: most rows belong to bands of more than 48 slots (ONT): eight lanes per row, up to 16 slots per lane */
+    if (wide) hipLaunchKernelGGL((map_kernel<16, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    else hipLaunchKernelGGL((map_kernel<12, 4>), dim3(((int64_t)n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
     return hipGetLastError();
 }
 
