@@ -76,6 +76,21 @@ __device__ __forceinline__ uint32_t fetch8_aligned(const uint8_t *__restrict__ p
     return reinterpret_cast<const uint32_t *>(pool)[a >> 3];
 }
 
+/* 16 consecutive codes (any alignment / a multiple of 8 nibbles): the one-lane forward kernel fetches its codes 16
+ * rows at a time -- with dword chunks every lane re-fetched its 64-byte line 16 times, and at 16 K lanes per XCD those
+ * lines do not survive in L2 between two fetches */
+__device__ __forceinline__ uint64_t fetch16(const uint8_t *__restrict__ pool, int64_t a)
+{
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
+    const uint32_t lo = p32[0], mid = p32[1], hi = p32[2], sh = (uint32_t)(a & 7) * 4u;
+    return (uint64_t)__builtin_amdgcn_alignbit(mid, lo, sh) | ((uint64_t)__builtin_amdgcn_alignbit(hi, mid, sh) << 32);
+}
+__device__ __forceinline__ uint64_t fetch16_aligned(const uint8_t *__restrict__ pool, int64_t a)
+{
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
+    return (uint64_t)p32[0] | ((uint64_t)p32[1] << 32);
+}
+
 /* byte-packed window of C codes */
 template <int C>
 struct CodeWin {
@@ -645,13 +660,13 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
         prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
     };
     if (act && prev_row == L) save_row();
-    /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0.  Codes come 8 STEPS at a time
+    /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0.  Codes come 16 STEPS at a time
      * (step t = row L-1-t, so the chunk phase is the same for every problem of the wave), one chunk ahead:
-     * the chunk of steps t0..t0+7 holds rows i0-7..i0 (i0 = L-1-t0) in ascending nibble order */
-    auto ref_chunk = [&](int i0) { return fetch8(B.ref4, P.ref0 + ((i0 - 7) - bw + jbase)); };
-    auto qry_chunk = [&](int i0) { return fetch8(B.qry4, P.qry0 + (i0 - 7)); };
-    uint32_t qwin = 0, rwin = 0;
-    uint32_t qwin_n = (act && L >= 2) ? qry_chunk(L - 1) : 0, rwin_n = (act && L >= 2) ? ref_chunk(L - 1) : 0;
+     * the chunk of steps t0..t0+15 holds rows i0-15..i0 (i0 = L-1-t0) in ascending nibble order */
+    auto ref_chunk = [&](int i0) { return fetch16(B.ref4, P.ref0 + ((i0 - 15) - bw + jbase)); };
+    auto qry_chunk = [&](int i0) { return fetch16(B.qry4, P.qry0 + (i0 - 15)); };
+    uint64_t qwin = 0, rwin = 0;
+    uint64_t qwin_n = (act && L >= 2) ? qry_chunk(L - 1) : 0, rwin_n = (act && L >= 2) ? ref_chunk(L - 1) : 0;
     double inv_p = (act && L >= 2) ? sinv[L - 1] : 0.0;
     /* every problem walks its own rows L-1, L-2, ... down to its first wanted row: step t of the wave is row
      * L-1-t of each problem, so problems of different length stay busy together (the launch order groups
@@ -666,16 +681,16 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
         const bool on = act && t < nb;
         const bool any_first = __any(on && i == 1);
         if (on) {
-            const uint32_t t4 = (uint32_t)(7 - (t & 7)) * 4u; /* wave-uniform */
-            if ((t & 7) == 0) {
+            const uint32_t t4 = (uint32_t)(15 - (t & 15)) * 4u; /* wave-uniform */
+            if ((t & 15) == 0) {
                 qwin = qwin_n; rwin = rwin_n;
-                qwin_n = qry_chunk(i - 8); /* rows below 1 read the lead pad: never used */
-                rwin_n = ref_chunk(i - 8);
+                qwin_n = qry_chunk(i - 16); /* rows below 1 read the lead pad: never used */
+                rwin_n = ref_chunk(i - 16);
             }
-            const uint32_t qy = (qwin >> t4) & 0xfu;
+            const uint32_t qy = (uint32_t)(qwin >> t4) & 0xfu;
             const double inv = inv_p;
             if (t != 0) {
-                uint32_t rc = (rwin >> t4) & 0xfu;
+                uint32_t rc = (uint32_t)(rwin >> t4) & 0xfu;
                 if (!FAST) {
                     if ((unsigned)(i - bw + jbase) >= (unsigned)R) rc = SPX_CODE_OUT;
                 }
@@ -793,20 +808,20 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             if (next_row == 1) save_row(1.0);
         }
     }
-    auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };
-    auto qry_chunk = [&](int ib) { return fetch8_aligned(B.qry4, P.qry0 + (ib - 1)); };
-    uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
-    uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
+    auto ref_chunk = [&](int ib) { return fetch16(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };   /* rows ib..ib+15 */
+    auto qry_chunk = [&](int ib) { return fetch16_aligned(B.qry4, P.qry0 + (ib - 1)); };
+    uint64_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
+    uint64_t qwin_n = act ? qry_chunk(17) : 0, rwin_n = act ? ref_chunk(17) : 0;
     auto row = [&](int i, auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         if (act && i <= L) {
-            const uint32_t t4 = (uint32_t)((i - 1) & 7) * 4u;
+            const uint32_t t4 = (uint32_t)((i - 1) & 15) * 4u;
             if (t4 == 0) {
                 qwin = qwin_n; rwin = rwin_n;
-                qwin_n = qry_chunk(i + 8); rwin_n = ref_chunk(i + 8);
+                qwin_n = qry_chunk(i + 16); rwin_n = ref_chunk(i + 16);
             }
-            const uint32_t qy = (qwin >> t4) & 0xfu;
-            uint32_t rc = (rwin >> t4) & 0xfu;
+            const uint32_t qy = (uint32_t)(qwin >> t4) & 0xfu;
+            uint32_t rc = (uint32_t)(rwin >> t4) & 0xfu;
             if (!FAST) {
                 if ((unsigned)(i - bw + (C - 1) - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
             }

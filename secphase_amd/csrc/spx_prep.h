@@ -49,6 +49,12 @@ struct HostBatch {
     void assign_merged(std::vector<HostBatch> &parts, int n_threads);
 };
 
+/* Pads of the 4-bit reference pool.  The kernels fetch codes in chunks of 16 a whole band width before / after a
+ * window (columns < 1 and > R: never used, but read): up to bw + 16 <= 1039 nibbles in front of the first contig and
+ * slots + 32 behind the last one (slots <= 2048). */
+constexpr int64_t kRefLeadNibbles = 4096;
+constexpr size_t kRefTailBytes = 2048;
+
 /* nibble offset of every contig inside the device reference pool */
 struct RefIndex {
     std::vector<int64_t> nib_off; /* [n_contigs] first nibble of each contig (byte aligned) */

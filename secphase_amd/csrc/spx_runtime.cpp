@@ -197,13 +197,13 @@ extern "C" int spx_set_reference(spx_ctx *c, const spx_ref *ref)
     const int nc = ref->n_contigs;
     c->ref.nib_off.assign(nc, 0);
     c->ref.len.assign(nc, 0);
-    int64_t nib = 256; /* leading pad: the kernels fetch whole dwords a few columns before a window */
+    int64_t nib = spx::kRefLeadNibbles; /* leading pad: the kernels fetch codes up to a band width before a window */
     for (int i = 0; i < nc; ++i) {
         c->ref.nib_off[i] = nib;
         c->ref.len[i] = ref->seq_off[i + 1] - ref->seq_off[i];
         nib += (c->ref.len[i] + 1) & ~(int64_t)1; /* every contig starts on a byte boundary */
     }
-    std::vector<uint8_t> packed((size_t)(nib / 2) + 128, 0); /* slack: the kernels fetch whole dwords past a window */
+    std::vector<uint8_t> packed((size_t)(nib / 2) + spx::kRefTailBytes, 0); /* slack: ... and past a window */
     unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::thread> th;
     auto work = [&](unsigned tid) {
@@ -842,7 +842,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
     hb.mk_first.push_back(0);
     /* private reference pool: the problems' own ref windows */
     std::vector<uint8_t> ref4;
-    int64_t rn = 256; /* leading pad, as in spx_set_reference */
+    int64_t rn = spx::kRefLeadNibbles; /* leading pad, as in spx_set_reference */
     for (int32_t p = 0; p < n; ++p) {
         const int R = (int)(ref_off[p + 1] - ref_off[p]), L = (int)(qry_off[p + 1] - qry_off[p]);
         if (R <= 0 || L <= 0) { delete w; return fail(SPX_EINVAL, "empty problem"); }
@@ -877,7 +877,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
         }
         hb.dp_cells += spx::band_cells(L, R, bw);
     }
-    ref4.resize(ref4.size() + 128, 0);
+    ref4.resize(ref4.size() + spx::kRefTailBytes, 0);
     uint8_t *d_ref = nullptr, *saved = c->d_ref4;
     HIPCHK(hipMalloc((void **)&d_ref, ref4.size()));
     HIPCHK(hipMemcpy(d_ref, ref4.data(), ref4.size(), hipMemcpyHostToDevice));
@@ -976,7 +976,7 @@ extern "C" int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const sp
 {
     if (!ref || !bt || !par || !out) return fail(SPX_EINVAL, "NULL argument");
     spx::RefIndex ri;
-    int64_t nib = 256;
+    int64_t nib = spx::kRefLeadNibbles;
     for (int i = 0; i < ref->n_contigs; ++i) {
         ri.nib_off.push_back(nib);
         ri.len.push_back(ref->seq_off[i + 1] - ref->seq_off[i]);
