@@ -91,6 +91,31 @@ __device__ __forceinline__ uint64_t fetch16_aligned(const uint8_t *__restrict__ 
     return (uint64_t)p32[0] | ((uint64_t)p32[1] << 32);
 }
 
+struct Codes32 { uint32_t w[4]; };
+__device__ __forceinline__ Codes32 fetch32(const uint8_t *__restrict__ pool, int64_t a)
+{
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
+    const uint32_t x0 = p32[0], x1 = p32[1], x2 = p32[2], x3 = p32[3], x4 = p32[4], sh = (uint32_t)(a & 7) * 4u;
+    Codes32 r;
+    r.w[0] = __builtin_amdgcn_alignbit(x1, x0, sh); r.w[1] = __builtin_amdgcn_alignbit(x2, x1, sh);
+    r.w[2] = __builtin_amdgcn_alignbit(x3, x2, sh); r.w[3] = __builtin_amdgcn_alignbit(x4, x3, sh);
+    return r;
+}
+__device__ __forceinline__ Codes32 fetch32_aligned(const uint8_t *__restrict__ pool, int64_t a)
+{
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
+    Codes32 r;
+    r.w[0] = p32[0]; r.w[1] = p32[1]; r.w[2] = p32[2]; r.w[3] = p32[3];
+    return r;
+}
+/* code t (0..31, wave-uniform) of a 32-code chunk */
+__device__ __forceinline__ uint32_t code_of(const Codes32 &c, uint32_t t)
+{
+    const uint32_t lo = (t & 16) ? c.w[2] : c.w[0], hi = (t & 16) ? c.w[3] : c.w[1];
+    const uint32_t w = (t & 8) ? hi : lo;
+    return (w >> ((t & 7) * 4u)) & 0xfu;
+}
+
 /* byte-packed window of C codes */
 template <int C>
 struct CodeWin {
@@ -808,20 +833,20 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             if (next_row == 1) save_row(1.0);
         }
     }
-    auto ref_chunk = [&](int ib) { return fetch16(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };   /* rows ib..ib+15 */
-    auto qry_chunk = [&](int ib) { return fetch16_aligned(B.qry4, P.qry0 + (ib - 1)); };
-    uint64_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
-    uint64_t qwin_n = act ? qry_chunk(17) : 0, rwin_n = act ? ref_chunk(17) : 0;
+    auto ref_chunk = [&](int ib) { return fetch32(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };   /* rows ib..ib+31 */
+    auto qry_chunk = [&](int ib) { return fetch32_aligned(B.qry4, P.qry0 + (ib - 1)); };
+    Codes32 qwin = {}, rwin = {}, qwin_n = {}, rwin_n = {};
+    if (act) { qwin = qry_chunk(1); rwin = ref_chunk(1); qwin_n = qry_chunk(33); rwin_n = ref_chunk(33); }
     auto row = [&](int i, auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         if (act && i <= L) {
-            const uint32_t t4 = (uint32_t)((i - 1) & 15) * 4u;
-            if (t4 == 0) {
+            const uint32_t tc = (uint32_t)((i - 1) & 31);
+            if (tc == 0) {
                 qwin = qwin_n; rwin = rwin_n;
-                qwin_n = qry_chunk(i + 16); rwin_n = ref_chunk(i + 16);
+                qwin_n = qry_chunk(i + 32); rwin_n = ref_chunk(i + 32);
             }
-            const uint32_t qy = (uint32_t)(qwin >> t4) & 0xfu;
-            uint32_t rc = (uint32_t)(rwin >> t4) & 0xfu;
+            const uint32_t qy = code_of(qwin, tc);
+            uint32_t rc = code_of(rwin, tc);
             if (!FAST) {
                 if ((unsigned)(i - bw + (C - 1) - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
             }
