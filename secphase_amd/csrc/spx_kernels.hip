@@ -76,46 +76,6 @@ __device__ __forceinline__ uint32_t fetch8_aligned(const uint8_t *__restrict__ p
     return reinterpret_cast<const uint32_t *>(pool)[a >> 3];
 }
 
-/* 16 consecutive codes (any alignment / a multiple of 8 nibbles): the one-lane forward kernel fetches its codes 16
- * rows at a time -- with dword chunks every lane re-fetched its 64-byte line 16 times, and at 16 K lanes per XCD those
- * lines do not survive in L2 between two fetches */
-__device__ __forceinline__ uint64_t fetch16(const uint8_t *__restrict__ pool, int64_t a)
-{
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
-    const uint32_t lo = p32[0], mid = p32[1], hi = p32[2], sh = (uint32_t)(a & 7) * 4u;
-    return (uint64_t)__builtin_amdgcn_alignbit(mid, lo, sh) | ((uint64_t)__builtin_amdgcn_alignbit(hi, mid, sh) << 32);
-}
-__device__ __forceinline__ uint64_t fetch16_aligned(const uint8_t *__restrict__ pool, int64_t a)
-{
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
-    return (uint64_t)p32[0] | ((uint64_t)p32[1] << 32);
-}
-
-struct Codes32 { uint32_t w[4]; };
-__device__ __forceinline__ Codes32 fetch32(const uint8_t *__restrict__ pool, int64_t a)
-{
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
-    const uint32_t x0 = p32[0], x1 = p32[1], x2 = p32[2], x3 = p32[3], x4 = p32[4], sh = (uint32_t)(a & 7) * 4u;
-    Codes32 r;
-    r.w[0] = __builtin_amdgcn_alignbit(x1, x0, sh); r.w[1] = __builtin_amdgcn_alignbit(x2, x1, sh);
-    r.w[2] = __builtin_amdgcn_alignbit(x3, x2, sh); r.w[3] = __builtin_amdgcn_alignbit(x4, x3, sh);
-    return r;
-}
-__device__ __forceinline__ Codes32 fetch32_aligned(const uint8_t *__restrict__ pool, int64_t a)
-{
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pool) + (a >> 3);
-    Codes32 r;
-    r.w[0] = p32[0]; r.w[1] = p32[1]; r.w[2] = p32[2]; r.w[3] = p32[3];
-    return r;
-}
-/* code t (0..31, wave-uniform) of a 32-code chunk */
-__device__ __forceinline__ uint32_t code_of(const Codes32 &c, uint32_t t)
-{
-    const uint32_t lo = (t & 16) ? c.w[2] : c.w[0], hi = (t & 16) ? c.w[3] : c.w[1];
-    const uint32_t w = (t & 8) ? hi : lo;
-    return (w >> ((t & 7) * 4u)) & 0xfu;
-}
-
 /* byte-packed window of C codes */
 template <int C>
 struct CodeWin {
@@ -685,13 +645,13 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
         prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
     };
     if (act && prev_row == L) save_row();
-    /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0.  Codes come 16 STEPS at a time
+    /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0.  Codes come 8 STEPS at a time
      * (step t = row L-1-t, so the chunk phase is the same for every problem of the wave), one chunk ahead:
-     * the chunk of steps t0..t0+15 holds rows i0-15..i0 (i0 = L-1-t0) in ascending nibble order */
-    auto ref_chunk = [&](int i0) { return fetch16(B.ref4, P.ref0 + ((i0 - 15) - bw + jbase)); };
-    auto qry_chunk = [&](int i0) { return fetch16(B.qry4, P.qry0 + (i0 - 15)); };
-    uint64_t qwin = 0, rwin = 0;
-    uint64_t qwin_n = (act && L >= 2) ? qry_chunk(L - 1) : 0, rwin_n = (act && L >= 2) ? ref_chunk(L - 1) : 0;
+     * the chunk of steps t0..t0+7 holds rows i0-7..i0 (i0 = L-1-t0) in ascending nibble order */
+    auto ref_chunk = [&](int i0) { return fetch8(B.ref4, P.ref0 + ((i0 - 7) - bw + jbase)); };
+    auto qry_chunk = [&](int i0) { return fetch8(B.qry4, P.qry0 + (i0 - 7)); };
+    uint32_t qwin = 0, rwin = 0;
+    uint32_t qwin_n = (act && L >= 2) ? qry_chunk(L - 1) : 0, rwin_n = (act && L >= 2) ? ref_chunk(L - 1) : 0;
     double inv_p = (act && L >= 2) ? sinv[L - 1] : 0.0;
     /* every problem walks its own rows L-1, L-2, ... down to its first wanted row: step t of the wave is row
      * L-1-t of each problem, so problems of different length stay busy together (the launch order groups
@@ -706,16 +666,16 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
         const bool on = act && t < nb;
         const bool any_first = __any(on && i == 1);
         if (on) {
-            const uint32_t t4 = (uint32_t)(15 - (t & 15)) * 4u; /* wave-uniform */
-            if ((t & 15) == 0) {
+            const uint32_t t4 = (uint32_t)(7 - (t & 7)) * 4u; /* wave-uniform */
+            if ((t & 7) == 0) {
                 qwin = qwin_n; rwin = rwin_n;
-                qwin_n = qry_chunk(i - 16); /* rows below 1 read the lead pad: never used */
-                rwin_n = ref_chunk(i - 16);
+                qwin_n = qry_chunk(i - 8); /* rows below 1 read the lead pad: never used */
+                rwin_n = ref_chunk(i - 8);
             }
-            const uint32_t qy = (uint32_t)(qwin >> t4) & 0xfu;
+            const uint32_t qy = (qwin >> t4) & 0xfu;
             const double inv = inv_p;
             if (t != 0) {
-                uint32_t rc = (uint32_t)(rwin >> t4) & 0xfu;
+                uint32_t rc = (rwin >> t4) & 0xfu;
                 if (!FAST) {
                     if ((unsigned)(i - bw + jbase) >= (unsigned)R) rc = SPX_CODE_OUT;
                 }
@@ -833,20 +793,20 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             if (next_row == 1) save_row(1.0);
         }
     }
-    auto ref_chunk = [&](int ib) { return fetch32(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };   /* rows ib..ib+31 */
-    auto qry_chunk = [&](int ib) { return fetch32_aligned(B.qry4, P.qry0 + (ib - 1)); };
-    Codes32 qwin = {}, rwin = {}, qwin_n = {}, rwin_n = {};
-    if (act) { qwin = qry_chunk(1); rwin = ref_chunk(1); qwin_n = qry_chunk(33); rwin_n = ref_chunk(33); }
+    auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };
+    auto qry_chunk = [&](int ib) { return fetch8_aligned(B.qry4, P.qry0 + (ib - 1)); };
+    uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
+    uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
     auto row = [&](int i, auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         if (act && i <= L) {
-            const uint32_t tc = (uint32_t)((i - 1) & 31);
-            if (tc == 0) {
+            const uint32_t t4 = (uint32_t)((i - 1) & 7) * 4u;
+            if (t4 == 0) {
                 qwin = qwin_n; rwin = rwin_n;
-                qwin_n = qry_chunk(i + 32); rwin_n = ref_chunk(i + 32);
+                qwin_n = qry_chunk(i + 8); rwin_n = ref_chunk(i + 8);
             }
-            const uint32_t qy = code_of(qwin, tc);
-            uint32_t rc = code_of(rwin, tc);
+            const uint32_t qy = (qwin >> t4) & 0xfu;
+            uint32_t rc = (rwin >> t4) & 0xfu;
             if (!FAST) {
                 if ((unsigned)(i - bw + (C - 1) - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
             }
