@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
     int best_k = -1;
     /* narrow and medium bands: all loads of a row are issued before the first add, so a wave pays one memory round
      * trip instead of one per slot; slots outside [ja,jb] read as +0.0, which changes neither the sequential sum nor
-     * the strict arg-max.  CQ = slots per lane held in registers: 12 covers every HiFi class, 32 the ONT ones */
+     * the strict arg-max.  CQ = slots per lane held in registers; wider rows take the loop below */
     auto batched = [&](auto cq_tag) {
         constexpr int CQ = decltype(cq_tag)::value;
         double zm[CQ], zi[CQ];
@@ -930,8 +930,7 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
         }
     };
     const int cq_wave = wave_max(on ? Cq : 0);
-    if (cq_wave <= 12) batched(std::integral_constant<int, 12>{});
-    else if (CQMAX > 12 && cq_wave <= CQMAX) batched(std::integral_constant<int, CQMAX>{});
+    if (cq_wave <= CQMAX) batched(std::integral_constant<int, CQMAX>{});
     else
     for (int t = 0; t < LPR; ++t) {
         if (g == t && on) {
@@ -974,9 +973,9 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st)
 {
     if (n_rows_total <= 0) return hipSuccess;
-    /* wide: most rows belong to bands of more than 48 slots (ONT): eight lanes per row, up to 16 slots per lane */
+    /* eight lanes per row; wide: most rows belong to bands of more than 48 slots (ONT): up to 16 slots per lane */
     if (wide) hipLaunchKernelGGL((map_kernel<16, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
-    else hipLaunchKernelGGL((map_kernel<12, 4>), dim3(((int64_t)n_rows_total * 4 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    else hipLaunchKernelGGL((map_kernel<6, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
     return hipGetLastError();
 }
 

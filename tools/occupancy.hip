@@ -23,7 +23,7 @@ int main()
     show("baq_bwd_kernel<2,22,43,false>", baq_bwd_kernel<2, 22, 43, false>);
     show("baq_fwd_kernel<4,16,0,false>", baq_fwd_kernel<4, 16, 0, false>);
     show("baq_fwd_kernel<8,16,0,false>", baq_fwd_kernel<8, 16, 0, false>);
-    show("map_kernel<12,4>", map_kernel<12, 4>);
+    show("map_kernel<6,8>", map_kernel<6, 8>);
     show("map_kernel<16,8>", map_kernel<16, 8>);
     return 0;
 }
