@@ -722,9 +722,12 @@ template <int C>
 __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
 {
     /* D row of the previous/current row, [slot][lane].  Slot 0 is the leftmost band cell: its D is
-     * m2*M(k-1) + m8*D(k-1) with both neighbours outside the band, i.e. always +0 -- it is not stored, which
-     * brings W = 41 to 40 x 512 B = 20 KB per wave: 8 waves per CU fit the 160 KB of LDS instead of 7 */
-    __shared__ double sD[C - 1][64];
+     * m2*M(k-1) + m8*D(k-1) with both neighbours outside the band, i.e. always +0 -- it is not stored.  At most 40
+     * slots go to LDS (40 x 512 B = 20 KB per wave: 8 waves per CU fit the 160 KB instead of 7); the first CR slots
+     * of the wider classes stay in VGPRs (same-box A/B: +0.6 %) */
+    constexpr int CR = (C - 1 > 40) ? C - 1 - 40 : 0;
+    __shared__ double sD[C - 1 - CR][64];
+    double dR[CR > 0 ? CR : 1];
     const int lane = threadIdx.x & 63;
     HmmC h;
     int hasN;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             const double e = emission<false>(code, qy, h.e_match, h.e_mis);
             fM[c] = valid ? e * bM : 0.0;
             fI[c] = valid ? SPX_EI * bI : 0.0;
-            if (c > 0) sD[c - 1][lane] = 0.0;
+            if (c > 0) { if (c - 1 < CR) dR[c - 1 < CR ? c - 1 : 0] = 0.0; else sD[c - 1 - CR][lane] = 0.0; }
             const double tt = fM[c] + fI[c];
             s = valid ? s + tt : s;
         }
@@ -828,7 +831,8 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 double S = h.m0 * pM + h.m3 * pI;
-                if (c > 0) S = S + h.m6 * (sD[c - 1][lane] * ip); /* slot 0: + m6 * 0 */
+                if (c > 0) /* slot 0: + m6 * 0 */
+                    S = S + h.m6 * ((c - 1 < CR ? dR[c - 1 < CR ? c - 1 : 0] : sD[c - 1 < CR ? 0 : c - 1 - CR][lane]) * ip);
                 const uint32_t code = cw.get(c);
                 double e;
                 if constexpr (FAST) {
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
                 if (c > 0) {
                     const double dn = h.m2 * prevM + h.m8 * d;
                     d = valid ? dn : 0.0;
-                    sD[c - 1][lane] = d;
+                    if (c - 1 < CR) dR[c - 1 < CR ? c - 1 : 0] = d; else sD[c - 1 - CR][lane] = d;
                 }
                 const double tt = c > 0 ? (newM + newI) + d : newM + newI; /* slot 0: + 0 */
                 s = valid ? s + tt : s;
