@@ -637,14 +637,18 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
     double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
     int wprev = nrows - 1;
     int prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
-    auto save_row = [&]() {
+    /* exact classes (W0 != 0): the one-lane forward kernel saved row i >= 2 unscaled, so z = (f * 1/s[i]) * b */
+    auto save_row = [&](double fscale) {
         double *dst = fsave + (int64_t)wprev * fstride + jbase;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { dst[c] = dst[c] * bM[c]; dst[SLOTS + c] = dst[SLOTS + c] * bI[c]; }
+        for (int c = 0; c < C; ++c) {
+            if constexpr (W0 != 0) { dst[c] = (dst[c] * fscale) * bM[c]; dst[SLOTS + c] = (dst[SLOTS + c] * fscale) * bI[c]; }
+            else { dst[c] = dst[c] * bM[c]; dst[SLOTS + c] = dst[SLOTS + c] * bI[c]; }
+        }
         wprev--;
         prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
     };
-    if (act && prev_row == L) save_row();
+    if (act && prev_row == L) save_row(L == 1 ? 1.0 : 1.0 / sinv[L]); /* sinv[L] holds s[L] itself */
     /* row i uses query idx i and lets ref idx i - bw + jbase enter at slot 0.  Codes come 8 STEPS at a time
      * (step t = row L-1-t, so the chunk phase is the same for every problem of the wave), one chunk ahead:
      * the chunk of steps t0..t0+7 holds rows i0-7..i0 (i0 = L-1-t0) in ascending nibble order */
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
             for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
             if (i >= 2) inv_p = sinv[i - 1]; /* prefetch for row i-1 */
             bwd_row<G, C, FAST, W0>(bM, bI, D, ew, qy, h, g, Wu, tlast, inv, i == 1, any_first);
-            if (i == prev_row) save_row();
+            if (i == prev_row) save_row(i == 1 ? 1.0 : inv);
         }
     };
     int t = 0;
@@ -759,14 +763,17 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
         dst[0] = make_double2(ib0, ib1); dst[1] = make_double2(ib2, ib3);
         dst[2] = make_double2(ib4, ib5); dst[3] = make_double2(ib6, ib7);
     };
-    auto save_row = [&](double inv) {
+    /* rows >= 2 are saved UNSCALED (row 1 is stored already divided): the backward kernel of the exact classes applies
+     * 1/s[i] before it multiplies by b -- the same two multiplications, 82 of them moved out of this kernel, where
+     * every row pays them for the one or two lanes that save (same-box A/B: +0.6 %) */
+    auto save_row = [&]() {
         double *dst = fsave + (int64_t)wnext * fstride;
 #pragma unroll
         for (int c = 0; c + 1 < C; c += 2) { /* 16-byte stores (rows start on 16-byte boundaries, SLOTS is even): +1.2 % in a same-box A/B */
-            *reinterpret_cast<double2 *>(dst + c) = make_double2(fM[c] * inv, fM[c + 1] * inv);
-            *reinterpret_cast<double2 *>(dst + SLOTS + c) = make_double2(fI[c] * inv, fI[c + 1] * inv);
+            *reinterpret_cast<double2 *>(dst + c) = make_double2(fM[c], fM[c + 1]);
+            *reinterpret_cast<double2 *>(dst + SLOTS + c) = make_double2(fI[c], fI[c + 1]);
         }
-        if (C & 1) { dst[C - 1] = fM[C - 1] * inv; dst[SLOTS + C - 1] = fI[C - 1] * inv; }
+        if (C & 1) { dst[C - 1] = fM[C - 1]; dst[SLOTS + C - 1] = fI[C - 1]; }
         wnext++;
         next_row = wnext < nrows ? B.rows[row0 + wnext] : 0x7fffffff;
     };
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             put_inv(1.0 / s);
             if (L == 1) flush_inv(1);
             inv_prev = 1.0; /* row 1 is stored already divided, as the reference does */
-            if (next_row == 1) save_row(1.0);
+            if (next_row == 1) save_row();
         }
     }
     auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };
@@ -865,7 +872,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             inv_prev = inv;
             put_inv(inv);
             if ((i & 7) == 7 || i == L) flush_inv(i);
-            if (i == next_row) save_row(inv);
+            if (i == next_row) save_row();
         }
     };
     int i = 2;
