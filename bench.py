@@ -107,7 +107,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ont = args.platform == "ont"
-    gps = args.groups_per_step or (4096 if ont else 16384)
+    gps = args.groups_per_step or (4096 if ont else 32768)  # HiFi: 32 768 groups per launch amortise the tails of the rare wide classes (+2.4 % over 16 384)
     params = records.preset("ont", bandwidth=50) if ont else records.preset("hifi")
     cfg = synth.default_cfg(synth.ONT if ont else synth.HIFI)
     # SURVEY section 8(d) assembly: 2 haplotypes x 10 contigs x 5 Mbp (+ paralog copies); resident in HBM as 4-bit codes

@@ -354,7 +354,7 @@ def test_command_line_write_bam(ctx, tmp_path):
 
 
 def test_full_size_workload_properties(ctx):
-    """BASELINE config 2 at the size bench.py times (16 384 HiFi groups, 15 kb reads, the 100 Mbp assembly): the oracle
+    """BASELINE config 2 at the size bench.py times (32 768 HiFi groups, 15 kb reads, the 100 Mbp assembly): the oracle
     would need minutes for all of it, so the whole batch is checked through size-independent properties -- the same
     groups scored as one work list, as four shards, in another order and twice in a row give bit-identical scores
     and decisions -- and a random sample of groups is compared with the oracle."""
@@ -362,7 +362,7 @@ def test_full_size_workload_properties(ctx):
     cfg = synth.default_cfg(synth.HIFI)
     g = synth.Genome(cfg)
     par = records.preset("hifi")
-    n, chunk = 16384, 1024
+    n, chunk = 32768, 1024
     parts = [None] * (n // chunk)
 
     def gen(k0):
@@ -387,11 +387,11 @@ def test_full_size_workload_properties(ctx):
         return res, st
 
     whole, st = score([p.batch for p in parts])
-    assert st.n_dispatched == n and st.n_problems > 1000000 and st.dp_cells > 10 ** 10
+    assert st.n_dispatched == n and st.n_problems > 2000000 and st.dp_cells > 2 * 10 ** 10
     # shards (what rank r of a multi-GPU run would score) -- union equals the whole
     sharded = []
     for r in range(4):
-        res, _ = score([p.batch for p in parts[4 * r:4 * r + 4]])
+        res, _ = score([p.batch for p in parts[8 * r:8 * r + 8]])
         sharded += res
     assert sharded == whole
     # another order of the same groups: results follow the groups
