@@ -74,7 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--platform", default="hifi", choices=["hifi", "ont"])
+    ap.add_argument("--platform", default="hifi", choices=["hifi", "ont", "mixed"])
+    ap.add_argument("--kernel-only", action="store_true", help="(profiling runs) only the device-resident replay")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
     ap.add_argument("--chunk", type=int, default=0, help="groups per prepared work list (0: one list per step)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
@@ -86,10 +87,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the one-rank-per-GPU job as a CHILD process -- nothing has touched the
+        # GPU yet (torch is not even imported), and the launcher is never exec'd -- and relay its JSON line
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     import torch
     import torch.distributed as dist
@@ -107,9 +116,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ont = args.platform == "ont"
-    gps = args.groups_per_step or (4096 if ont else 32768)  # HiFi: 32 768 groups per launch amortise the tails of the rare wide classes (+2.4 % over 16 384)
+    mixed = args.platform == "mixed"
+    gps = args.groups_per_step or (4096 if ont else 8192 if mixed else 32768)  # HiFi: 32 768 groups per launch amortise the tails of the rare wide classes (+2.4 % over 16 384)
+    # config 5 (mixed HiFi+ONT, power-law lengths, <= 8 secondaries) is run as --hifi over the whole mix, SURVEY 8(d)
     params = records.preset("ont", bandwidth=50) if ont else records.preset("hifi")
-    cfg = synth.default_cfg(synth.ONT if ont else synth.HIFI)
+    cfg = synth.default_cfg(synth.ONT if ont else synth.MIXED if mixed else synth.HIFI)
     # SURVEY section 8(d) assembly: 2 haplotypes x 10 contigs x 5 Mbp (+ paralog copies); resident in HBM as 4-bit codes
     t0 = time.time()
     genome = synth.Genome(cfg)
@@ -155,7 +166,14 @@ def main():
         w.free()
 
     # decision records land in a torch tensor so that RCCL can gather them
-    dec = torch.zeros(max(n_disp, 1), dtype=torch.int64, device="cuda")
+    # (every rank sizes its buffer by the largest dispatched count of any rank: ranks whose dispatch filter drops a
+    # different number of groups would otherwise disagree about the gather's message size)
+    cap = n_disp
+    if world > 1:
+        t = torch.tensor([n_disp], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cap = int(t.item())
+    dec = torch.full((max(cap, 1),), -1, dtype=torch.int64, device="cuda")
     gathered = [torch.zeros_like(dec) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
@@ -294,6 +312,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("1M ONT reads, 30 kb, <=4 secondaries, band=50, ONT gap params" if ont else
+                             "Mixed HiFi+ONT reads, length 2-100 kb power-law, <=8 secondaries, run as --hifi" if mixed else
                              "1M HiFi reads, 15 kb, <=2 secondaries, band=20, BAQ window 500 bp") +
                             f" (streamed as batches of {gps} groups per GPU per step; inputs resident in HBM)",
                 "groups_per_step_per_gpu": gps,

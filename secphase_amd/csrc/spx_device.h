@@ -64,6 +64,7 @@ typedef struct spx_dev_batch {
     const uint8_t *row_rawq;   /* raw base quality */
     /* scratch */
     double *sinv;  /* 1/s[i] per row */
+    double *s_raw; /* diagnostics (spx_probaln_glocal's return value): s[i] itself for 1 <= i < L, same offsets as sinv; NULL on the scoring path */
     double *fsave; /* wanted rows: scaled forward M,I ([row][2][slots]), replaced by f*b in the backward pass */
     const int32_t *row_prob;   /* per wanted row: its problem */
     const int32_t *prob_slots; /* per problem: band slots of its class */

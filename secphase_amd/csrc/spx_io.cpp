@@ -188,6 +188,39 @@ bool need(Reader *r, RawBuf &ubuf, size_t at, size_t n)
 inline int32_t le32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
 
 /* find a Z tag (cs or MD) in the aux block */
+/* value of a B-array tag (sub-type byte, count, elements) or NULL */
+const uint8_t *find_tag_b(const uint8_t *aux, const uint8_t *end, char k0, char k1)
+{
+    while (aux + 3 <= end) {
+        const char t0 = (char)aux[0], t1 = (char)aux[1], ty = (char)aux[2];
+        const uint8_t *v = aux + 3;
+        size_t len;
+        switch (ty) {
+        case 'A': case 'c': case 'C': len = 1; break;
+        case 's': case 'S': len = 2; break;
+        case 'i': case 'I': case 'f': len = 4; break;
+        case 'Z': case 'H': {
+            const uint8_t *z = v;
+            while (z < end && *z) ++z;
+            len = (size_t)(z - v) + 1;
+            break;
+        }
+        case 'B': {
+            if (v + 5 > end) return nullptr;
+            const char sub = (char)v[0];
+            const uint32_t cnt = (uint32_t)le32(v + 1);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            len = 5 + es * (size_t)cnt;
+            if (t0 == k0 && t1 == k1) return v + len <= end ? v : nullptr;
+            break;
+        }
+        default: return nullptr;
+        }
+        aux = v + len;
+    }
+    return nullptr;
+}
+
 const char *find_tag(const uint8_t *aux, const uint8_t *end, char k0, char k1)
 {
     while (aux + 3 <= end) {
@@ -320,6 +353,14 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
         const uint32_t ncig = p[12] | (p[13] << 8), flg = p[14] | (p[15] << 8);
         const int32_t lseq = le32(p + 16);
         const char *name = (const char *)p + 32;
+        /* the fixed part announces the lengths of the variable part: none of them may reach past the record, and the
+         * name must be NUL-terminated inside it (strlen / the CIGAR copy below would walk off the buffer otherwise) */
+        if (lseq < 0 || l_name < 1 || 32 + (uint64_t)l_name + 4 * (uint64_t)ncig + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs ||
+            name[l_name - 1] != 0) {
+            g_io_err = "corrupt BAM record (field lengths exceed the record)";
+            S.rc = SPX_EINVAL;
+            break;
+        }
         /* group boundary on a name change (src/secphase.c:273-279) */
         const bool same = r->have_last && r->last_name == name;
         if (!same || !open_group) {
@@ -338,9 +379,22 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
         S.tid.push_back((refid >= 0 && (size_t)refid < r->tmap.size()) ? r->tmap[refid] : -1);
         S.pos.push_back(posv);
         S.l_qseq.push_back(lseq);
-        S.n_cigar.push_back((int32_t)ncig);
+        /* more than 65535 CIGAR operations: the record carries the placeholder <l_seq>S<ref_len>N and the real CIGAR
+         * in the CG:B,I tag; sam_read1 puts it back before secphase sees the record, so do we */
+        const uint8_t *cg = nullptr;
+        uint32_t cg_n = 0;
+        if (ncig == 2 && aux <= end && ((uint32_t)le32(cig) & 0xf) == SPX_CSOFT_CLIP && ((uint32_t)le32(cig) >> 4) == (uint32_t)lseq &&
+            ((uint32_t)le32(cig + 4) & 0xf) == SPX_CREF_SKIP) {
+            const uint8_t *b = find_tag_b(aux, end, 'C', 'G');
+            if (b && (b[0] == 'I' || b[0] == 'i')) {
+                cg_n = (uint32_t)le32(b + 1);
+                if (cg_n > 0 && b + 5 + 4 * (size_t)cg_n <= end) cg = b + 5; else cg_n = 0;
+            }
+        }
+        S.n_cigar.push_back((int32_t)(cg ? cg_n : ncig));
         S.cigar_off.push_back((int64_t)S.cigar.size());
-        for (uint32_t k = 0; k < ncig; ++k) S.cigar.push_back((uint32_t)le32(cig + 4 * k));
+        if (cg) for (uint32_t k = 0; k < cg_n; ++k) S.cigar.push_back((uint32_t)le32(cg + 4 * k));
+        else for (uint32_t k = 0; k < ncig; ++k) S.cigar.push_back((uint32_t)le32(cig + 4 * k));
         S.seq_off.push_back((int64_t)(sq - u.data()));
         S.qual_off.push_back((int64_t)(ql - u.data()));
         S.rec_off.push_back((int64_t)(p - u.data()));

@@ -512,6 +512,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
                 if (g == 0 && L == 1) flush_inv(1);
             } else if (g == 0)
                 sinv[1] = 1.0 / tot;
+            if (B.s_raw && g == 0) B.s_raw[(sinv - B.sinv) + 1] = tot;
             if (next_row == 1) save_row();
         }
     }
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
                 if (g == 0 && ((i & 7) == 7 || i == L)) flush_inv(i);
             } else if (g == 0)
                 sinv[i] = inv;
+            if (B.s_raw && g == 0) B.s_raw[(sinv - B.sinv) + i] = s_cur;
             if (i == next_row) save_row();
         }
     };
@@ -804,6 +806,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             put_inv(1.0 / s);
             if (L == 1) flush_inv(1);
             inv_prev = 1.0; /* row 1 is stored already divided, as the reference does */
+            if (B.s_raw) B.s_raw[(sinv - B.sinv) + 1] = s;
             if (next_row == 1) save_row();
         }
     }
@@ -872,6 +875,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
             inv_prev = inv;
             put_inv(inv);
             if ((i & 7) == 7 || i == L) flush_inv(i);
+            if (B.s_raw) B.s_raw[(sinv - B.sinv) + i] = s;
             if (i == next_row) save_row();
         }
     };

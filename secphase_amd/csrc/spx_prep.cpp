@@ -898,7 +898,8 @@ static int prepare_one(const spx_batch *bt, const RefIndex &ref, const spx_param
     }
     collect_markers(S.al, par->min_q, S.mk, S.mtmp);
     /* snapshot of the state this group appends to, so a failing group leaves nothing behind */
-    const size_t s_prob = out.L.size(), s_rows = out.rows.size(), s_q = out.qry4.size(), s_hmm = out.hmm.size();
+    const size_t s_prob = out.L.size(), s_rows = out.rows.size(), s_q = out.qry4.size(), s_hmm = out.hmm.size(),
+                 s_qe = out.qe_rec.size();
     const int64_t s_nib = out.qry_nibbles;
     int n_prob = 0;
     int64_t cells = 0;
@@ -925,6 +926,9 @@ static int prepare_one(const spx_batch *bt, const RefIndex &ref, const spx_param
                         out.n_rows.resize(s_prob); out.hmm.resize(s_hmm); out.rows.resize(s_rows);
                         out.row_expect.resize(s_rows); out.row_rawq.resize(s_rows); out.qry4.resize(s_q);
                         out.qry_nibbles = s_nib;
+                        /* the quality edits of the failing group go too: their row indices are about to be reused */
+                        out.qe_rec.resize(s_qe); out.qe_pos.resize(s_qe); out.qe_len.resize(s_qe);
+                        out.qe_row0.resize(s_qe); out.qe_batch.resize(s_qe);
                         return rc;
                     }
                 }

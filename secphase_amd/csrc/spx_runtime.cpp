@@ -77,7 +77,7 @@ struct spx_ctx {
      * the main class' forward and backward kernels): spx_collect averages over the launches since the previous collect */
     static const int SPX_EV_RING = 64;
     hipEvent_t evr[SPX_EV_RING][6] = {};
-    int64_t n_launch = 0, collect_mark = 0;
+    int64_t n_launch = 0;
     /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
      * (or in front of) the bulk class */
     hipStream_t cls_stream[SPX_N_CLASSES] = {};
@@ -113,6 +113,7 @@ struct spx_work {
     spx_stats st;
     spx_params par;
     bool launched = false;
+    std::vector<int64_t> launch_ids; /* this work list's launches since its last spx_collect (indices into the ctx event ring) */
     std::vector<uint8_t> posmin_host; /* filled by spx_collect: per first-of-position marker, min quality */
     std::vector<uint8_t> bq_host;     /* filled by spx_apply_quals: BAQ value of every wanted row */
 };
@@ -331,7 +332,8 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     const size_t in_bytes = cv.off;
     size_t o_sinv = cv.take<double>((size_t)s_tot), o_fsave = cv.take<double>((size_t)f_tot),
            o_bq = cv.take<uint8_t>(nr + 16), o_posmin = cv.take<uint8_t>(nm + 16), o_state = want_state_q ? cv.take<int32_t>(nr) : 0,
-           o_q = want_state_q ? cv.take<uint8_t>(nr + 16) : 0, o_score = cv.take<double>(ng * 10),
+           o_q = want_state_q ? cv.take<uint8_t>(nr + 16) : 0, o_sraw = want_state_q ? cv.take<double>((size_t)s_tot) : 0,
+           o_score = cv.take<double>(ng * 10),
            o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
            o_tie = cv.take<uint16_t>(ng);
     w->arena_bytes = cv.off + 256;
@@ -404,6 +406,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
         B.row_expect = (const int32_t *)(base + o_expect);
         B.row_rawq = (const uint8_t *)(base + o_rawq);
         B.sinv = (double *)(base + o_sinv);
+        B.s_raw = want_state_q ? (double *)(base + o_sraw) : nullptr;
         B.fsave = (double *)(base + o_fsave);
         B.row_prob = (const int32_t *)(base + o_row_prob);
         B.prob_slots = (const int32_t *)(base + o_prob_slots);
@@ -515,6 +518,8 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
     hipEvent_t *ev = c->evr[c->n_launch % spx_ctx::SPX_EV_RING];
+    w->launch_ids.push_back(c->n_launch);
+    if (w->launch_ids.size() > (size_t)spx_ctx::SPX_EV_RING) w->launch_ids.erase(w->launch_ids.begin());
     c->n_launch++;
     HIPCHK(hipEventRecord(ev[0], c->stream));
     /* the class holding most of the band cells runs on the main stream (its forward and backward kernels are
@@ -571,32 +576,38 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (w->launched) {
-        /* averages over the launches since the previous collect (at most the last SPX_EV_RING) */
-        int64_t first = std::max(c->collect_mark, c->n_launch - spx_ctx::SPX_EV_RING);
-        if (first >= c->n_launch) first = c->n_launch - 1;
+        /* averages over THIS work list's launches since its previous collect (those whose events are still in the ring);
+         * other work lists launched in between have their own slots.  Timing is diagnostics: a failing event query
+         * zeroes the figures instead of failing the collect */
         double baq = 0, sc = 0, fw = 0, bw = 0;
-        const int n = (int)(c->n_launch - first);
-        for (int64_t l = first; l < c->n_launch; ++l) {
+        int n = 0;
+        bool ok = true;
+        for (int64_t l : w->launch_ids) {
+            if (c->n_launch - l > spx_ctx::SPX_EV_RING) continue; /* slot reused since */
             hipEvent_t *ev = c->evr[l % spx_ctx::SPX_EV_RING];
             float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            ok = ok && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
             baq += ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[1], ev[2]));
+            ok = ok && hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess;
             sc += ms;
             if (w->main_cls >= 0) {
-                HIPCHK(hipEventElapsedTime(&ms, ev[3], ev[4]));
+                ok = ok && hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess;
                 fw += ms;
-                HIPCHK(hipEventElapsedTime(&ms, ev[4], ev[5]));
+                ok = ok && hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess;
                 bw += ms;
             }
+            ++n;
         }
-        c->collect_mark = c->n_launch;
-        w->st.baq_kernel_ms = baq / n;
-        w->st.score_kernel_ms = sc / n;
+        w->launch_ids.clear();
+        if (!ok) { (void)hipGetLastError(); n = 0; }
+        const double dn = n > 0 ? (double)n : 1.0;
+        if (n == 0) baq = sc = fw = bw = 0;
+        w->st.baq_kernel_ms = baq / dn;
+        w->st.score_kernel_ms = sc / dn;
         w->st.n_launches_averaged = n;
         if (w->main_cls >= 0) {
-            w->st.main_fwd_ms = fw / n;
-            w->st.main_bwd_ms = bw / n;
+            w->st.main_fwd_ms = fw / dn;
+            w->st.main_bwd_ms = bw / dn;
             w->st.main_class = w->main_cls;
             w->st.main_class_cells = w->cls_cells[w->main_cls];
             w->st.main_class_lanes = spx::class_lanes(w->main_cls);
@@ -829,7 +840,8 @@ extern "C" int spx_write_relabel_log(const char *path, const char *mode, const s
 /* raw banded-HMM problems, all rows wanted */
 static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t *ref_off, const uint8_t *query,
                        const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t *state, uint8_t *q,
-                       double *kernel_ms, int32_t post_which, double *post_scale, double *post_zM, double *post_zI)
+                       double *kernel_ms, int32_t post_which, double *post_scale, double *post_zM, double *post_zI,
+                       int32_t *pr_out = nullptr)
 {
     if (!c || n < 0 || !ref || !ref_off || !query || !qry_off || !set_q || !pars || !state || !q)
         return fail(SPX_EINVAL, "NULL argument");
@@ -914,6 +926,28 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
                     post_zI[(size_t)(i - 1) * R + (k - 1)] = in ? zv[((size_t)(i - 1) * 2 + 1) * slots + j] : 0.0;
                 }
         }
+        if (pr_out && !rc) { /* probaln_glocal's return value: phred-scaled likelihood from the scaling factors s[0..L+1] */
+            int64_t s_all = 0;
+            for (int32_t p = 0; p < n; ++p) s_all += 8 + ((hb.L[p] + 2 + 7) & ~7);
+            std::vector<double> sraw((size_t)s_all), sfin((size_t)s_all);
+            const int cls0 = spx::band_class(2 * hb.bw[0] + 1);
+            if (hipMemcpy(sraw.data(), w->cls_batch[cls0].s_raw, sraw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(sfin.data(), w->cls_batch[cls0].sinv, sfin.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(SPX_EHIP, "copy back failed");
+            int64_t s_at = 8;
+            for (int32_t p = 0; p < n && !rc; ++p) {
+                const int L = hb.L[p], R = hb.R[p];
+                double pp = 1., Pr1 = 0.; /* s[0] = 1 */
+                for (int i = 1; i <= L + 1; ++i) {
+                    pp *= i < L ? sraw[s_at + i] : sfin[s_at + i]; /* sinv[L], sinv[L+1] hold s[L], s[L+1] themselves */
+                    if (pp < 1e-100) { Pr1 += -4.343 * log(pp); pp = 1.; }
+                }
+                Pr1 += -4.343 * log(pp * R * L);
+                const double v = Pr1 + .499;
+                pr_out[p] = (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN;
+                s_at += 8 + ((L + 2 + 7) & ~7);
+            }
+        }
         if (hipMemcpy(state, w->d_state, nr * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(q, w->d_q, nr, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(SPX_EHIP, "copy back failed");
@@ -957,11 +991,12 @@ extern "C" int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *
     int64_t ro[2] = {0, l_ref}, qo[2] = {0, l_query};
     int32_t sq32 = sq;
     std::vector<int32_t> st32(l_query);
-    int rc = spx_probaln_batch(g_single, 1, ref, ro, query, qo, &sq32, cpar, st32.data(), q, nullptr);
+    int32_t pr = 0;
+    int rc = probaln_run(g_single, 1, ref, ro, query, qo, &sq32, cpar, st32.data(), q, nullptr, 0, nullptr, nullptr, nullptr, &pr);
     if (rc) return INT_MIN;
     for (int i = 0; i < l_query; ++i) state[i] = st32[i];
-    /* phred-scaled likelihood: not used by secphase (ptMarker.c:755-760 only tests for INT_MIN) */
-    return 0;
+    /* phred-scaled likelihood, like htslib (secphase itself only tests the return value for INT_MIN, ptMarker.c:755-760) */
+    return pr;
 }
 
 /* ------------------------------------------------------------------ */

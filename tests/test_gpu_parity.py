@@ -353,16 +353,14 @@ def test_command_line_write_bam(ctx, tmp_path):
     assert open(os.path.join(outd, "t.quality_modified.out.bam")).read() == want
 
 
-def test_full_size_workload_properties(ctx):
-    """BASELINE config 2 at the size bench.py times (32 768 HiFi groups, 15 kb reads, the 100 Mbp assembly): the oracle
-    would need minutes for all of it, so the whole batch is checked through size-independent properties -- the same
-    groups scored as one work list, as four shards, in another order and twice in a row give bit-identical scores
-    and decisions -- and a random sample of groups is compared with the oracle."""
+def _full_size_properties(ctx, platform, par, n, chunk, n_shards, min_problems, min_cells, sample):
+    """A workload at the size bench.py times: the oracle would need minutes for all of it, so the whole batch is checked
+    through size-independent properties -- the same groups scored as one work list, as shards, in another order and
+    several times in a row give bit-identical scores and decisions -- and a random sample of groups is compared with
+    the oracle."""
     import threading
-    cfg = synth.default_cfg(synth.HIFI)
+    cfg = synth.default_cfg(platform)
     g = synth.Genome(cfg)
-    par = records.preset("hifi")
-    n, chunk = 32768, 1024
     parts = [None] * (n // chunk)
 
     def gen(k0):
@@ -376,7 +374,7 @@ def test_full_size_workload_properties(ctx):
     def score(batches, relaunch=False):
         w = ctx.prepare(batches, par)
         w.launch()
-        if relaunch:  # consecutive launches of one list overlap on the device (two scratch sets)
+        if relaunch:
             for _ in range(4):
                 w.launch()
         out = w.collect(finalize_seed=None)
@@ -387,11 +385,12 @@ def test_full_size_workload_properties(ctx):
         return res, st
 
     whole, st = score([p.batch for p in parts])
-    assert st.n_dispatched == n and st.n_problems > 2000000 and st.dp_cells > 2 * 10 ** 10
+    assert st.n_dispatched == n and st.n_problems > min_problems and st.dp_cells > min_cells
     # shards (what rank r of a multi-GPU run would score) -- union equals the whole
+    per = len(parts) // n_shards
     sharded = []
-    for r in range(4):
-        res, _ = score([p.batch for p in parts[8 * r:8 * r + 8]])
+    for r in range(n_shards):
+        res, _ = score([p.batch for p in parts[per * r:per * r + per]])
         sharded += res
     assert sharded == whole
     # another order of the same groups: results follow the groups
@@ -406,11 +405,70 @@ def test_full_size_workload_properties(ctx):
     assert again == whole
     # a sample against the oracle
     rng = np.random.default_rng(3)
-    for k in rng.choice(n, size=48, replace=False):
+    for k in rng.choice(n, size=sample, replace=False):
         sub = g.reads(int(k), 1)
         _, ores = orc.run_batch(sub.batch, g.ref, par, threads=1, seed=1)
         e, o = ores[0], whole[int(k)]
         assert o[0] == e.n_aln and o[1] == tuple(e.score[a] for a in range(e.n_aln)) and o[2] == e.prim_idx, int(k)
+    return st
+
+
+def test_full_size_workload_properties(ctx):
+    """BASELINE config 2 at the size bench.py times: 32 768 HiFi groups, 15 kb reads, the 100 Mbp assembly"""
+    _full_size_properties(ctx, synth.HIFI, records.preset("hifi"), 32768, 1024, 4, 2000000, 2 * 10 ** 10, 48)
+
+
+def test_full_size_workload_properties_ont(ctx):
+    """BASELINE config 3 at the size bench.py --platform ont times: 4 096 ONT groups, 30 kb reads, <= 4 secondaries,
+    band 50 on the 100 Mbp assembly -- the band classes (4,26)/(4,28)/(4,30)/(8,16)+(4,32) on real work lists"""
+    st = _full_size_properties(ctx, synth.ONT, records.preset("ont", bandwidth=50), 4096, 256, 4, 1000000, 5 * 10 ** 10, 48)
+    wide = sum(st.problems_per_class[c] for c in (6, 7, 12, 13))
+    assert wide > 0.9 * st.n_problems  # the ONT widths W = 101..127
+
+
+def test_batch_mixed_config5(ctx, tmp_path):
+    """BASELINE config 5 (load-balance stress): mixed HiFi + ONT reads, power-law lengths 2..100 kb, up to 8
+    secondaries, run as --hifi over the whole mix: scores, decisions and out.log byte-identical to the
+    oracle's over 256 groups"""
+    cfg = synth.default_cfg(synth.MIXED)
+    assert cfg.max_secondaries == 8 and cfg.max_read_len == 100000
+    g = synth.Genome(cfg)
+    r = g.reads(0, 256)
+    b = r.batch.contents
+    lens = [b.l_qseq[b.grp_first[k]] for k in range(b.n_groups)]
+    assert min(lens) < 4000 and max(lens) > 30000
+    assert max(b.grp_first[k + 1] - b.grp_first[k] for k in range(b.n_groups)) >= 8
+    st = _batch_parity(ctx, g, r, records.preset("hifi"), tmp_path, "mixed")
+    assert sum(1 for c in range(16) if st.problems_per_class[c] > 0) >= 4  # HiFi-like and ONT-like band widths side by side
+
+
+def test_probaln_glocal_symbol_on_device(built):
+    """spx_probaln_glocal -- the htslib-signature entry point (ptMarker.c:755-757) -- called directly: state[], q[] AND
+    the returned phred-scaled likelihood equal the oracle's probaln_glocal"""
+    rng = np.random.default_rng(21)
+    L = api.lib()
+    u8 = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint8))
+    for (n, sub, ind, bw, d, sq) in ((801, 0.003, 0.002, 20, 1e-4, 40), (640, 0.02, 0.04, 50, 1e-3, 20), (57, 0.05, 0.05, 7, 1e-2, 30),
+                                     (1, 0.0, 0.0, 3, 1e-4, 40), (300, 0.3, 0.1, 130, 1e-3, 13)):
+        ref, qry = _rand_problem(rng, n, ind, sub)
+        par = api.ProbalnPar(d, 0.1, abs(len(ref) - len(qry)) + bw)
+        iq = np.full(len(qry), sq, np.uint8)
+        st = np.zeros(len(qry), np.int32)
+        q = np.zeros(len(qry), np.uint8)
+        pr = L.spx_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), u8(iq), C.byref(par),
+                                  st.ctypes.data_as(C.POINTER(C.c_int)), u8(q))
+        epr, est, eq = oracle_probaln(ref, qry, sq, d, 0.1, par.bw)
+        assert pr == epr and pr != -2 ** 31, (n, pr, epr)
+        assert np.array_equal(st, est) and np.array_equal(q, eq), n
+    # iqual == NULL means Q30 for every base
+    ref, qry = _rand_problem(rng, 200, 0.01, 0.01)
+    par = api.ProbalnPar(1e-4, 0.1, 25)
+    st = np.zeros(len(qry), np.int32)
+    q = np.zeros(len(qry), np.uint8)
+    pr = L.spx_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), None, C.byref(par), st.ctypes.data_as(C.POINTER(C.c_int)), u8(q))
+    epr, est, eq = oracle_probaln(ref, qry, 30, 1e-4, 0.1, 25)
+    assert pr == epr and np.array_equal(st, est) and np.array_equal(q, eq)
+    assert L.spx_probaln_glocal(u8(ref), 0, u8(qry), len(qry), None, C.byref(par), st.ctypes.data_as(C.POINTER(C.c_int)), u8(q)) == 0
 
 
 def test_command_line_stops_on_records_without_tags(ctx, tmp_path):

@@ -167,3 +167,65 @@ def test_sam_writer_aux_types_and_missing_fields(built, tmp_path):
             "r1\t256\tc2\t1\t0\t5M\t=\t8\t0\tACGTA\t*\n"
             "r2\t16\tc2\t6\t255\t2H3X\t*\t0\t0\t*\t*\tNM:i:0\n")
     assert open(sam).read() == want
+
+
+def _raw_bam(path, records_bytes, contigs=((b"c0", 1000),)):
+    import struct
+    text = b"@HD\tVN:1.6\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % c for c in contigs)
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(contigs)))
+    for nm, ln in contigs:
+        out += struct.pack("<i", len(nm) + 1) + nm + b"\0" + struct.pack("<i", ln)
+    for rec in records_bytes:
+        out += struct.pack("<i", len(rec)) + rec
+    write_bgzf(path, bytes(out))
+
+
+def _raw_record(name, flag, pos, cigar, seq_len, aux=b"", l_name=None, n_cigar=None, l_seq=None):
+    import struct
+    qn = name + b"\0"
+    cig = b"".join(struct.pack("<I", (ln << 4) | op) for ln, op in cigar)
+    core = struct.pack("<iiBBHHHiiii", 0, pos, len(qn) if l_name is None else l_name, 60, 4680,
+                       len(cigar) if n_cigar is None else n_cigar, flag, seq_len if l_seq is None else l_seq, -1, -1, 0)
+    return core + qn + cig + bytes((seq_len + 1) // 2) + bytes([30]) * seq_len + aux
+
+
+def test_bam_long_cigar_is_taken_from_the_cg_tag(built, tmp_path):
+    """> 65535 CIGAR operations: BAM stores <l_seq>S<ref_len>N and the real CIGAR in CG:B,I; htslib's sam_read1
+    restores it before secphase's loop (src/secphase.c:268) sees the record"""
+    import struct
+    L = api.lib()
+    _declare(L)
+    real = [(5, 4), (20, 0), (2, 1), (13, 0)]  # 5S20M2I13M
+    cg = b"CGBI" + struct.pack("<i", len(real)) + b"".join(struct.pack("<I", (ln << 4) | op) for ln, op in real)
+    rec = _raw_record(b"r1", 0, 7, [(40, 4), (33, 3)], 40, aux=b"NMi" + struct.pack("<i", 1) + cg + b"csZ:20+ac:13\0")
+    plain = _raw_record(b"r1", 256, 9, [(40, 0)], 40, aux=b"csZ:40\0")
+    bam = str(tmp_path / "cg.bam")
+    _raw_bam(bam, [rec, plain])
+    h = C.c_void_p()
+    assert L.spx_bam_open(bam.encode(), 1, C.byref(h)) == 0
+    bp = C.POINTER(records.SpxBatch)()
+    assert L.spx_bam_next_batch(h, 8, C.byref(bp)) == 1
+    got = _records(bp)
+    assert got[0][1][0][4] == tuple((ln << 4) | op for ln, op in real)
+    assert got[0][1][1][4] == ((40 << 4),)
+    assert got[0][1][0][7] == b":20+ac:13"
+    L.spx_bam_close(h)
+
+
+def test_bam_records_with_impossible_lengths_are_rejected(built, tmp_path):
+    """n_cigar / l_seq / l_read_name reaching past block_size, or a name without its NUL: SPX_EINVAL, no wild reads"""
+    L = api.lib()
+    _declare(L)
+    good = _raw_record(b"ok", 0, 1, [(10, 0)], 10, aux=b"csZ:10\0")
+    for k, bad in enumerate((_raw_record(b"a", 0, 1, [(10, 0)], 10, n_cigar=60000),
+                             _raw_record(b"b", 0, 1, [(10, 0)], 10, l_seq=1 << 20),
+                             _raw_record(b"c", 0, 1, [(10, 0)], 10, l_name=200),
+                             _raw_record(b"dddd", 0, 1, [(10, 0)], 10, l_name=3))):
+        bam = str(tmp_path / f"bad{k}.bam")
+        _raw_bam(bam, [good, bad])
+        h = C.c_void_p()
+        assert L.spx_bam_open(bam.encode(), 1, C.byref(h)) == 0
+        bp = C.POINTER(records.SpxBatch)()
+        assert L.spx_bam_next_batch(h, 8, C.byref(bp)) == api.EINVAL, k
+        assert b"corrupt" in L.spx_io_last_error()
+        L.spx_bam_close(h)
