@@ -112,6 +112,16 @@ int spx_prepare(spx_ctx *ctx, const spx_batch *bt, const spx_params *par, int ho
  * out[(groups of batches < b) + g] */
 int spx_prepare_many(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_batches, const spx_params *par,
                      int host_threads, spx_work **work);
+/* The two halves of spx_prepare_many.  spx_stage: dispatch filter (src/secphase.c:285-288) + the dispatched groups'
+ * records packed into pinned memory on host_threads threads + ONE asynchronous copy into HBM.  spx_prepare_staged:
+ * the work list itself -- CIGAR/cs walk, markers, consensus windows, banded DP problems and marker table
+ * (cigar_it.c, ptMarker.c:42-831, src/secphase.c:162-170) -- is built ON THE DEVICE from the staged records.  It may
+ * be called again on the same staged records (records resident in HBM; bench.py times exactly that), and is
+ * thread-safe: preparations of different work lists are serialised on the context's preparation stream, which runs
+ * beside the DP kernels of the list launched before. */
+int spx_stage(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_batches, const spx_params *par, int host_threads,
+              spx_work **work);
+int spx_prepare_staged(spx_ctx *ctx, spx_work *work);
 int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */
 int spx_sync(spx_ctx *ctx);
 /* multi-GPU: write one 8-byte decision record per dispatched group of `work` into a caller-owned
@@ -235,6 +245,9 @@ typedef struct spx_plan_view {
 } spx_plan_view;
 int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const spx_params *par, spx_plan **out);
 int spx_plan_get(const spx_plan *plan, spx_plan_view *view);
+/* diagnostics for parity tests: the work list the DEVICE built for `work`, copied back in the shape of a host plan
+ * (free it with spx_plan_free), so that it can be compared with spx_plan_create's field by field */
+int spx_work_export(spx_ctx *ctx, spx_work *work, spx_plan **out);
 void spx_plan_free(spx_plan *plan);
 /* the tables the kernels use: phred thresholds thr[102], match_tbl[256], mis_tbl[256] */
 void spx_host_tables(double *thr, double *match_tbl, double *mis_tbl);

@@ -82,6 +82,7 @@ EXPORTS = [
     "spx_io_last_error", "spx_bam_open", "spx_bam_n_targets", "spx_bam_target_name", "spx_bam_bind_reference",
     "spx_bam_next_batch", "spx_bam_close", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
+    "spx_stage", "spx_prepare_staged", "spx_work_export",
 ]
 
 _lib = None
@@ -113,6 +114,9 @@ def lib():
     L.spx_prepare.argtypes = [vp, C.POINTER(SpxBatch), C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
     L.spx_prepare_many.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int,
                                    C.POINTER(vp)]
+    L.spx_stage.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
+    L.spx_prepare_staged.argtypes = [vp, vp]
+    L.spx_work_export.argtypes = [vp, vp, C.POINTER(vp)]
     L.spx_launch.argtypes = [vp, vp]
     L.spx_sync.argtypes = [vp]
     L.spx_pack_decisions.argtypes = [vp, vp, C.c_int32, vp, C.c_int64]
@@ -197,6 +201,10 @@ class Context:
         """batch: one POINTER(SpxBatch) or a list of them (merged into one work list)"""
         return Work(self, batch, params, host_threads)
 
+    def stage(self, batch, params, host_threads=0):
+        """records into HBM only; Work.prepare_staged() then builds the work list on the device"""
+        return Work(self, batch, params, host_threads, stage_only=True)
+
     def probaln_batch(self, refs, queries, set_q, pars):
         """refs/queries: lists of uint8 numpy arrays of 0..4 codes; returns (states, qs, kernel_ms)."""
         import numpy as np
@@ -256,18 +264,27 @@ class Context:
 
 
 class Work:
-    def __init__(self, ctx, batch, params, host_threads):
+    def __init__(self, ctx, batch, params, host_threads, stage_only=False):
         self.ctx = ctx
         self.params = params
         self.h = C.c_void_p()
-        if isinstance(batch, (list, tuple)):
-            self.n = sum(b.contents.n_groups for b in batch)
-            arr = (C.POINTER(SpxBatch) * len(batch))(*batch)
+        if not isinstance(batch, (list, tuple)):
+            batch = [batch]
+        self.n = sum(b.contents.n_groups for b in batch)
+        arr = (C.POINTER(SpxBatch) * len(batch))(*batch)
+        if stage_only:
+            _chk(lib().spx_stage(ctx.h, arr, len(batch), C.byref(params), host_threads, C.byref(self.h)), "spx_stage")
+        else:
             _chk(lib().spx_prepare_many(ctx.h, arr, len(batch), C.byref(params), host_threads, C.byref(self.h)),
                  "spx_prepare_many")
-        else:
-            self.n = batch.contents.n_groups
-            _chk(lib().spx_prepare(ctx.h, batch, C.byref(params), host_threads, C.byref(self.h)), "spx_prepare")
+
+    def prepare_staged(self):
+        """(re)build the work list on the device from the staged records"""
+        _chk(lib().spx_prepare_staged(self.ctx.h, self.h), "spx_prepare_staged")
+
+    def export_plan(self):
+        """diagnostics: the device-built work list as a Plan-like object (view, close)"""
+        return ExportedPlan(self)
 
     def launch(self):
         _chk(lib().spx_launch(self.ctx.h, self.h), "spx_launch")
@@ -307,6 +324,25 @@ class Work:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class ExportedPlan:
+    def __init__(self, work):
+        self.h = C.c_void_p()
+        _chk(lib().spx_work_export(work.ctx.h, work.h, C.byref(self.h)), "spx_work_export")
+        self.view = PlanView()
+        _chk(lib().spx_plan_get(self.h, C.byref(self.view)), "spx_plan_get")
+
+    def close(self):
+        if self.h:
+            lib().spx_plan_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -25,7 +25,9 @@
 
 #include <type_traits>
 
+#include "../../include/spx.h"
 #include "spx_device.h"
+#include "spx_prep_dev.h"
 
 #define SPX_EI 0.25
 
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
      * for the slot entering the band at the top), fetched one chunk ahead */
     const int top = jbase + C - 1; /* the slot that receives a new column each row */
     auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + top - 1)); };   /* rows ib..ib+7 */
-    auto qry_chunk = [&](int ib) { return fetch8_aligned(B.qry4, P.qry0 + (ib - 1)); };
+    auto qry_chunk = [&](int ib) { return fetch8(B.qry4, P.qry0 + (ib - 1)); }; /* windows start anywhere inside a recoded read */
     uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
     uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
     auto row = [&](int i, auto fast_tag) {
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
         }
     }
     auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + (C - 1) - 1)); };
-    auto qry_chunk = [&](int ib) { return fetch8_aligned(B.qry4, P.qry0 + (ib - 1)); };
+    auto qry_chunk = [&](int ib) { return fetch8(B.qry4, P.qry0 + (ib - 1)); }; /* windows start anywhere inside a recoded read */
     uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
     uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
     auto row = [&](int i, auto fast_tag) {
@@ -1069,6 +1071,40 @@ __global__ __launch_bounds__(256) void pack_kernel(spx_dev_groups Gd, const int3
     r |= (unsigned long long)Gd.tie_mask[gi] << 48;
     r |= (unsigned long long)(Gd.pass[gi] ? 1 : 0) << 63;
     out[gi] = r;
+}
+
+/* one packed result record per dispatched group (what spx_collect copies back in one piece) */
+__global__ __launch_bounds__(256) void results_kernel(spx_dev_groups Gd, const spx_group_info *__restrict__ info,
+                                                      const int32_t *__restrict__ rfe, spx_group_out *__restrict__ out)
+{
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= Gd.n_groups) return;
+    const spx_group_info in = info[gi];
+    spx_group_out o;
+    const int n = in.err ? 0 : in.n_aln;
+    for (int a = 0; a < 10; ++a) {
+        o.score[a] = a < n ? Gd.score[(int64_t)gi * 10 + a] : 0.0;
+        o.rfe[a] = a < n ? rfe[(int64_t)gi * 10 + a] : 0;
+    }
+    o.n_aln = (int8_t)(in.err ? in.err : in.n_aln);
+    o.prim_idx = in.err ? (int8_t)-1 : (int8_t)Gd.prim_idx[gi];
+    o.max_idx = in.err ? (int8_t)-1 : (int8_t)Gd.max_idx[gi];
+    o.pass = in.err ? (int8_t)0 : (int8_t)Gd.pass[gi];
+    o.tie_mask = in.err ? (uint16_t)0 : Gd.tie_mask[gi];
+    o.best_idx = -1;
+    o.relabel = 0;
+    o.n_problems = in.n_prob;
+    o.n_markers = in.n_mk;
+    o.dp_cells = in.cells;
+    out[gi] = o;
+}
+
+extern "C" hipError_t spx_launch_results(const spx_dev_groups *Gd, const spx_group_info *info, const int32_t *rfe,
+                                         spx_group_out *out, hipStream_t st)
+{
+    if (Gd->n_groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(results_kernel, dim3((Gd->n_groups + 255) / 256), dim3(256), 0, st, *Gd, info, rfe, out);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,

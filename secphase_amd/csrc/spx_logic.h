@@ -1,0 +1,1078 @@
+/*
+ * spx_logic.h -- the integer part of the secphase marker path (SURVEY.md section 8 rows A1-A8 and the control flow of
+ * A10), written ONCE for both sides: hipcc compiles these functions for gfx950, where one thread owns one alignment
+ * (op table, extents, confident blocks, mismatch list) or one read group (marker columns, consensus windows, BAQ work
+ * list), and for the host, where the very same code produces the host-only plan view the CPU tests check against the
+ * oracle.  No std:: containers, no allocation: every function works on caller-provided arrays with stated capacities
+ * and reports SPX_ENOMEM when one would overflow (the runtime then grows its pools and repeats the batch).
+ *
+ * Behavioural contract, by reference line (/root/reference/programs):
+ *   op table            submodules/cigar_it/cigar_it.c:14-69,72-141,145-211,213-308
+ *   aligned extents     submodules/ptAlignment/ptAlignment.c:42-95
+ *   markers             submodules/ptMarker/ptMarker.c:42-107,156-295
+ *   blocks              submodules/ptMarker/ptMarker.c:328-667, src/secphase.c:162-170
+ *   BAQ windows / rows  submodules/ptMarker/ptMarker.c:670-831
+ *   HMM constants       htslib-1.17 probaln.c initialisation
+ */
+#ifndef SPX_LOGIC_H
+#define SPX_LOGIC_H
+
+#include <stdint.h>
+
+#include "../../include/spx.h"
+#include "spx_device.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SPX_HD __host__ __device__ inline
+#else
+#define SPX_HD inline
+#endif
+
+namespace spxl {
+
+/* ---- records as the device sees them: one Rec per alignment of a dispatched group, pools of packed payload ---- */
+struct Rec {
+    int32_t rec;      /* record index in its input batch */
+    int32_t batch;    /* input batch (spx_prepare_many) */
+    int32_t grp;      /* dispatched-group index inside the work list */
+    int32_t flag, tid, pos, l_qseq, n_cigar;
+    int32_t cs_len;   /* -1: no cs tag */
+    int32_t md_len;   /* -1: no MD tag (looked at only without cs) */
+    int64_t cigar_off; /* uint32 units into the cigar pool */
+    int64_t seq_off;   /* BYTE offset into the sequence pools (raw BAM nibbles / recoded 0..4 codes), multiple of 4 */
+    int64_t qual_off;  /* BYTE offset into the quality pool */
+    int64_t tag_off;   /* BYTE offset of the cs (or MD) string in the text pool, NUL-terminated */
+};
+
+struct Op {
+    int32_t op, len; /* len doubles as the iterator's return value (0 ends a while(next) loop) */
+    int32_t sqs, sqe, rfs, rfe, rds, rde;
+};
+struct Blk {
+    int32_t rfs, rfe, sqs, sqe, rds, rde;
+};
+struct MM { /* mismatch marker of one alignment, in op order */
+    int32_t pos, base_idx, q, ref_pos;
+};
+struct Mk { /* one cell of the marker table: (read position, alignment) */
+    int32_t base_idx, ref_pos, row;
+    uint8_t q, is_match, pad0, pad1;
+};
+
+struct AlnState {
+    int32_t lclip, rclip, rfs, rfe, rds, rde;
+    int32_t n_ops, n_visit, rest;
+    int32_t n_conf, n_mm;
+    int32_t err;
+    int32_t mm_cap, conf_cap; /* bounds from the counting pass */
+    int32_t has_n, pad;       /* SEQ holds a base other than ACGT */
+    int64_t ops_off, conf_off, mm_off;
+};
+
+struct Pools {
+    const uint32_t *cigar;
+    const uint8_t *qual;
+    const char *text;
+    const uint8_t *code4; /* SEQ recoded to 0..4, low nibble first, same byte offsets as the raw pool, behind a lead pad */
+    int64_t code_lead_bytes;
+    Op *ops;
+    Blk *conf;
+    MM *mm;
+};
+
+/* reference side: contig table of the 4-bit pool + ambiguous-base index */
+struct RefView {
+    int32_t n_contigs;
+    const int64_t *nib_off; /* first nibble of each contig in the device pool */
+    const int64_t *len;
+    const int64_t *npos_off; /* [n_contigs+1] into npos */
+    const int32_t *npos;     /* ascending positions of non-ACGT bases per contig */
+};
+
+struct Params {
+    int32_t baq_flag, consensus, indel_threshold, min_q, set_q, flank_margin, all_rows, pad;
+    double conf_b;
+    float d, e;
+    float qf; /* (float)pow(10, -set_q/10.), host libm */
+    float pad2;
+};
+
+/* ---------------- band classes = DP kernel instantiations (keep in step with spx_launch_baq) ---------------- */
+SPX_HD int class_slots(int cls)
+{
+    switch (cls) {
+    case 0: return 42; case 1: return 44; case 2: return 46; case 3: return 48; case 4: return 48; case 5: return 64;
+    case 6: return 104; case 7: return 128; case 8: return 256; case 9: return 512; case 10: return 1024; case 11: return 2048;
+    case 12: return 112; default: return 120;
+    }
+}
+SPX_HD int class_lanes(int cls)
+{
+    switch (cls) {
+    case 0: case 1: case 2: case 3: return 1;
+    case 4: return 2; case 5: case 6: case 12: case 13: return 4;
+    case 7: return 8; case 8: return 16; case 9: return 32; default: return 64;
+    }
+}
+SPX_HD int class_lanes_bwd(int cls)
+{
+    switch (cls) {
+    case 0: case 1: case 2: case 3: case 4: return 2;
+    case 5: case 6: case 7: case 12: case 13: return 4;
+    case 8: return 16; case 9: return 32; default: return 64;
+    }
+}
+SPX_HD int band_class(int W)
+{
+    if (W == 41) return 0;
+    if (W == 43) return 1;
+    if (W == 45) return 2;
+    if (W == 47) return 3;
+    if (W <= 48) return 4;
+    if (W <= 64) return 5;
+    if (W <= 104) return 6;
+    if (W <= 112) return 12;
+    if (W <= 120) return 13;
+    if (W <= 128) return 7;
+    if (W <= 256) return 8;
+    if (W <= 512) return 9;
+    if (W <= 1024) return 10;
+    if (W <= 2048) return 11;
+    return -1;
+}
+
+SPX_HD int effective_bw(int l_ref, int l_query, int bw_in)
+{
+    int bw = l_ref > l_query ? l_ref : l_query;
+    if (bw > bw_in) bw = bw_in;
+    const int diff = l_ref > l_query ? l_ref - l_query : l_query - l_ref;
+    if (bw < diff) bw = diff;
+    return bw;
+}
+
+SPX_HD int64_t band_cells(int L, int R, int bw)
+{
+    /* sum over rows i = 1..L of (min(R, i+bw) - max(1, i-bw) + 1), closed form; effective_bw() guarantees bw >= |R - L| */
+    const int64_t l = L, r = R, w = bw;
+    int64_t a = r - w < l ? r - w : l;
+    if (a < 0) a = 0;
+    const int64_t hi = a * (a + 1) / 2 + a * w + (l - a) * r;
+    const int64_t b = l < w + 1 ? l : w + 1;
+    const int64_t lo = b + (l * (l + 1) / 2 - b * (b + 1) / 2) - (l - b) * w;
+    return hi - lo + l;
+}
+
+/* the float/double mix below is the one of probaln_glocal's initialisation: probaln_par_t holds floats,
+ * 1 - c->d - c->d and (1 - c->d) / l_ref are float expressions.  qf = (float)pow(10, -set_q/10.) comes from the host. */
+SPX_HD void hmm_constants(int l_ref, int l_query, float d, float e, float qf, double *h)
+{
+    const double sM = 1. / (2 * l_query + 2), sI = sM;
+    h[SPX_H_M0] = (double)((1 - d) - d) * (1 - sM);
+    h[SPX_H_M1] = (double)d * (1 - sM);
+    h[SPX_H_M2] = h[SPX_H_M1];
+    h[SPX_H_M3] = (double)(1 - e) * (1 - sI);
+    h[SPX_H_M4] = (double)e * (1 - sI);
+    h[SPX_H_M6] = (double)(1 - e);
+    h[SPX_H_M8] = (double)e;
+    h[SPX_H_BM] = (double)((1 - d) / l_ref);
+    h[SPX_H_BI] = (double)(d / l_ref);
+    h[SPX_H_SM] = sM;
+    h[SPX_H_SI] = sI;
+    h[SPX_H_EMATCH] = 1. - (double)qf;
+    h[SPX_H_EMIS] = (double)qf * .33333333333;
+    h[SPX_H_PAD0] = h[SPX_H_PAD1] = h[SPX_H_PAD2] = 0.;
+}
+
+SPX_HD bool window_has_n(const RefView &rv, int tid, int64_t start, int64_t n)
+{
+    if (!rv.npos_off || tid < 0 || tid >= rv.n_contigs) return false;
+    int64_t lo = rv.npos_off[tid], hi = rv.npos_off[tid + 1];
+    const int64_t end = hi;
+    while (lo < hi) {
+        const int64_t m = (lo + hi) / 2;
+        if (rv.npos[m] < start) lo = m + 1; else hi = m;
+    }
+    return lo < end && rv.npos[lo] < start + n;
+}
+
+/* ---------------- tokenisers ---------------- */
+SPX_HD bool lower_c(char c) { return c >= 'a' && c <= 'z'; }
+SPX_HD bool upper_c(char c) { return c >= 'A' && c <= 'Z'; }
+SPX_HD bool digit_c(char c) { return c >= '0' && c <= '9'; }
+
+/* decimal prefix of s like atoi (no sign / blanks occur here); wraps like 32-bit arithmetic on absurd input */
+SPX_HD int atoi_c(const char *s)
+{
+    uint32_t v = 0;
+    while (digit_c(*s)) { v = v * 10u + (uint32_t)(*s - '0'); ++s; }
+    return (int)v;
+}
+
+/* first short-form cs token at or after s (what an un-anchored POSIX search of
+ * (:[0-9]+)|([+-][a-z]+)|((\*[a-z]+)+) returns); false if none */
+SPX_HD bool next_cs_token(const char *s, int &so, int &eo)
+{
+    for (int p = 0; s[p]; ++p) {
+        const char c = s[p];
+        if (c == ':') {
+            if (!digit_c(s[p + 1])) continue;
+            int e = p + 1;
+            while (digit_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+        if (c == '+' || c == '-') {
+            if (!lower_c(s[p + 1])) continue;
+            int e = p + 1;
+            while (lower_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+        if (c == '*') {
+            if (!lower_c(s[p + 1])) continue;
+            int e = p;
+            while (s[e] == '*' && lower_c(s[e + 1])) {
+                ++e;
+                while (lower_c(s[e])) ++e;
+            }
+            so = p; eo = e;
+            return true;
+        }
+    }
+    return false;
+}
+
+/* first MD token at or after s: a mismatch run X(0X)*, a match count, or a deletion ^XXX (cigar_it.h:10) */
+SPX_HD bool next_md_token(const char *s, int &so, int &eo)
+{
+    for (int p = 0; s[p]; ++p) {
+        const char c = s[p];
+        if (upper_c(c)) {
+            int e = p + 1;
+            while (s[e] == '0' && upper_c(s[e + 1])) e += 2;
+            so = p; eo = e;
+            return true;
+        }
+        if (digit_c(c)) {
+            int e = p + 1;
+            while (digit_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+        if (c == '^' && upper_c(s[p + 1])) {
+            int e = p + 1;
+            while (upper_c(s[e])) ++e;
+            so = p; eo = e;
+            return true;
+        }
+    }
+    return false;
+}
+
+/* one MD step (cigar_it.c:72-141): a lone "0" separates two mismatches and is skipped */
+SPX_HD int md_step(const char *md, int &at, Op &cur)
+{
+    for (;;) {
+        const char *s = md + at;
+        int so, eo;
+        if (!next_md_token(s, so, eo)) return 0;
+        const char c = s[so];
+        if (c == '0') { cur.op = SPX_CDIFF; cur.len = 0; }
+        else if (c <= '9') {
+            /* sic: the reference copies eo - so characters from the START of the shifted string (not from so) and
+             * atoi()s them; at most 19 digits reach its buffer */
+            int n = eo - so;
+            if (n > 19) n = 19;
+            uint32_t v = 0;
+            for (int k = 0; k < n && digit_c(s[k]); ++k) v = v * 10u + (uint32_t)(s[k] - '0');
+            cur.op = SPX_CEQUAL;
+            cur.len = (int)v;
+        } else if (c < 90) { cur.op = SPX_CDIFF; cur.len = 1 + (eo - so - 1) / 2; }
+        else if (c == '^') { cur.op = SPX_CDEL; cur.len = eo - so - 1; }
+        at += eo;
+        if (cur.len != 0) return cur.len;
+    }
+}
+
+SPX_HD bool mx(int op) { return op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF; }
+
+/* ---------------- per-alignment pass ----------------
+ * EMIT = false: counts the op table (st.n_ops) and bounds the mismatch list and the confident blocks (st.mm_cap,
+ * st.conf_cap); EMIT = true: writes ops[0..n_ops) (ops[0] = state before the first step).  Both fill lclip/rclip,
+ * n_visit, rest and return 0 or SPX_E*. */
+template <bool EMIT>
+SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, AlnState &st, Op *ops)
+{
+    if (r.n_cigar <= 0) return SPX_EINVAL;
+    const uint32_t *cigar = P.cigar + r.cigar_off;
+    const uint8_t *qual = P.qual + r.qual_off;
+    st.lclip = ((cigar[0] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(cigar[0] >> 4) : 0;
+    st.rclip = ((cigar[r.n_cigar - 1] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(cigar[r.n_cigar - 1] >> 4) : 0;
+    const bool use_cs = r.cs_len >= 0, use_md = !use_cs && r.md_len >= 0;
+    if (!use_cs && !use_md) return SPX_ENOTAG; /* neither cs nor MD: the reference exits (cigar_it.c:64-67) */
+    const char *tag = P.text + r.tag_off;
+    const bool rev = (r.flag & SPX_FREVERSE) != 0;
+    int md_at = 0;
+    Op cur;
+    cur.op = 255; cur.len = 0;
+    cur.sqs = 0; cur.sqe = -1;
+    cur.rfs = r.pos; cur.rfe = r.pos - 1;
+    const int32_t T = st.lclip + st.rclip + r.l_qseq;
+    cur.rds = rev ? T : 0;
+    cur.rde = rev ? T - 1 : -1;
+    int32_t n = 0;
+    if (EMIT) ops[0] = cur;
+    n = 1;
+    int idx = -1, remain = 0, cs_at = 0;
+    bool aligned = false, visiting = true;
+    int32_t n_visit = -1, mm = 0, cf = 0;
+    while (idx != r.n_cigar - 1) {
+        ++idx;
+        const int op = (int)(cigar[idx] & 0xf), len = (int)(cigar[idx] >> 4);
+        int rd, sq, rf;
+        const bool mtype = op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF;
+        if (use_cs && (mtype || op == SPX_CINS || op == SPX_CDEL)) {
+            int so, eo;
+            const char *s = tag + cs_at;
+            if (next_cs_token(s, so, eo)) {
+                const char c = s[so];
+                if (c == ':') { cur.op = SPX_CEQUAL; cur.len = atoi_c(s + so + 1); }
+                else if (c == '*') { cur.op = SPX_CDIFF; cur.len = (eo - so + 1) / 3; }
+                else if (c == '+') { cur.op = SPX_CINS; cur.len = eo - so - 1; }
+                else { cur.op = SPX_CDEL; cur.len = eo - so - 1; }
+                cs_at += eo;
+            }
+        }
+        if (mtype) {
+            if (remain == 0) remain = len;
+            if (use_cs) {
+                remain -= cur.len;
+                if (remain > 0) --idx; /* stay on this CIGAR op until cs has covered it */
+            } else {
+                /* MD knows nothing about insertions: a match run may reach into the following M ops (remain < 0) */
+                if (remain >= 0) md_step(tag, md_at, cur);
+                if (remain < 0) {
+                    cur.op = SPX_CEQUAL;
+                    cur.len = len < -remain ? len : -remain;
+                    remain += len;
+                } else {
+                    const int md_len = cur.len;
+                    cur.len = cur.len < remain ? cur.len : remain;
+                    remain -= md_len;
+                }
+                if (remain > 0) --idx;
+            }
+            rd = sq = rf = cur.len;
+        } else if (op == SPX_CINS) {
+            cur.len = len; cur.op = op;
+            rd = sq = len; rf = 0;
+        } else if (op == SPX_CDEL) {
+            if (use_md) md_step(tag, md_at, cur);
+            rd = sq = 0; rf = len;
+        } else if (op == SPX_CSOFT_CLIP) {
+            cur.len = len; cur.op = op;
+            rd = sq = len; rf = 0;
+        } else if (op == SPX_CHARD_CLIP) {
+            cur.len = len; cur.op = op;
+            rd = len; sq = 0; rf = 0;
+        } else {
+            return SPX_EUNSUPPORTED; /* N / P / B: undefined in the reference (cigar_it.c:225-291) */
+        }
+        if (rev) { cur.rde = cur.rds - 1; cur.rds -= rd; }
+        else { cur.rds = cur.rde + 1; cur.rde += rd; }
+        cur.sqs = cur.sqe + 1; cur.sqe += sq;
+        cur.rfs = cur.rfe + 1; cur.rfe += rf;
+        if (EMIT) ops[n] = cur;
+        aligned = aligned || (mx(cur.op) && cur.len > 0);
+        if (visiting && cur.len == 0) { visiting = false; n_visit = n; }
+        if (!EMIT && visiting) {
+            if (cur.op == SPX_CDIFF) {
+                for (int j = 0; j < cur.len; ++j) {
+                    const int b = cur.sqs + j;
+                    if (b >= 0 && b < r.l_qseq && (int)qual[b] >= min_q) ++mm;
+                }
+            }
+            const bool indel = cur.op == SPX_CINS || cur.op == SPX_CDEL, clip = cur.op == SPX_CSOFT_CLIP || cur.op == SPX_CHARD_CLIP;
+            if (clip || (indel && cur.len > indel_thr)) ++cf;
+        }
+        ++n;
+        if (n > 40000000) return SPX_EINVAL;
+    }
+    /* U6: no aligned base at all (e.g. a CIGAR of clips only): undefined in the reference, rejected like U3 */
+    if (!aligned || r.l_qseq <= 0) return SPX_EUNSUPPORTED;
+    st.n_ops = n;
+    if (n_visit < 0) { st.n_visit = n; st.rest = n - 1; }
+    else { st.n_visit = n_visit; st.rest = n_visit; }
+    if (!EMIT) { st.mm_cap = mm; st.conf_cap = cf + 1; }
+    return 0;
+}
+
+/* aligned extents (ptAlignment_init_coordinates), confident blocks (find_confident_blocks) and the mismatch
+ * markers with raw quality >= min_q (ptMarker_get_initial_markers), all from the op table */
+SPX_HD int finish_alignment(const Rec &r, const Pools &P, int min_q, int thr, AlnState &st, const Op *ops, Blk *conf, MM *mmv)
+{
+    const bool rev = (r.flag & SPX_FREVERSE) != 0;
+    const uint8_t *qual = P.qual + r.qual_off;
+    st.rfs = st.rfe = st.rds = st.rde = -1;
+    for (int t = 1; t < st.n_visit; ++t) {
+        const Op o = ops[t];
+        if (st.rfs == -1 && mx(o.op)) {
+            st.rfs = o.rfs;
+            if (rev) st.rde = o.rde; else st.rds = o.rds;
+        }
+        if (st.rfe == -1 && st.rfs != -1 && (o.op == SPX_CHARD_CLIP || o.op == SPX_CSOFT_CLIP)) {
+            st.rfe = o.rfe;
+            if (rev) st.rds = o.rde + 1; else st.rde = o.rds - 1;
+        }
+    }
+    {
+        const Op o = ops[st.rest];
+        if (st.rfe == -1 && mx(o.op)) {
+            st.rfe = o.rfe;
+            if (rev) st.rds = o.rds; else st.rde = o.rde;
+        }
+    }
+    /* confident blocks */
+    int nc = 0;
+    {
+        int c_sqs = 0, c_rfs = r.pos;
+        int c_rd = rev ? ops[0].rde : ops[0].rds;
+        for (int t = 1; t < st.n_visit; ++t) {
+            const Op o = ops[t];
+            const bool indel = o.op == SPX_CINS || o.op == SPX_CDEL;
+            const bool clip = o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP;
+            if (!(indel || clip)) continue;
+            if (indel && o.len <= thr) continue;
+            if (c_sqs < o.sqs && c_rfs < o.rfs) {
+                if (nc >= st.conf_cap) return SPX_ENOMEM;
+                Blk b;
+                b.rfs = c_rfs; b.rfe = o.rfs - 1; b.sqs = c_sqs; b.sqe = o.sqs - 1;
+                if (rev) { b.rds = o.rde + 1; b.rde = c_rd; } else { b.rds = c_rd; b.rde = o.rds - 1; }
+                conf[nc++] = b;
+            }
+            c_sqs = o.sqe + 1;
+            c_rfs = o.rfe + 1;
+            c_rd = rev ? o.rds - 1 : o.rde + 1;
+        }
+        const Op o = ops[st.rest];
+        if (c_sqs <= o.sqe) {
+            if (nc >= st.conf_cap) return SPX_ENOMEM;
+            Blk b;
+            b.rfs = c_rfs; b.rfe = o.rfe; b.sqs = c_sqs; b.sqe = o.sqe;
+            if (rev) { b.rds = o.rds; b.rde = c_rd; } else { b.rds = c_rd; b.rde = o.rde; }
+            conf[nc++] = b;
+        }
+    }
+    st.n_conf = nc;
+    /* mismatch bases with raw quality >= min_q, in op order (ascending read position on the forward strand,
+     * descending on the reverse strand) */
+    int nm = 0;
+    for (int t = 1; t < st.n_visit; ++t) {
+        const Op o = ops[t];
+        if (o.op != SPX_CDIFF) continue;
+        for (int j = 0; j < o.len; ++j) {
+            const int b = o.sqs + j;
+            if (b < 0 || b >= r.l_qseq) continue; /* cs longer than SEQ: the reference would read past the record */
+            const int q = qual[b];
+            if (q < min_q) continue;
+            if (nm >= st.mm_cap) return SPX_ENOMEM;
+            MM m;
+            m.base_idx = b; m.pos = rev ? o.rde - j : o.rds + j; m.q = q; m.ref_pos = o.rfs + j;
+            mmv[nm++] = m;
+        }
+    }
+    st.n_mm = nm;
+    return 0;
+}
+
+/* ---------------- per-group pass ---------------- */
+struct GroupView {
+    int32_t n;             /* alignments */
+    const Rec *rec;        /* [n] */
+    AlnState *st;          /* [n] */
+};
+
+/* what one group needs in its scratch arena (bytes), from the per-alignment counts */
+struct GroupArena {
+    int32_t P_cap, blk_cap, rows_cap;
+    int64_t o_pos, o_mk, o_keep, o_flank, o_cur, o_nxt, o_proj, o_nproj, o_rowsmk, bytes;
+};
+SPX_HD GroupArena group_arena_layout(const GroupView &G, bool all_rows, int slack)
+{
+    GroupArena A;
+    int64_t P = 0, C = 0, lq = 0;
+    for (int i = 0; i < G.n; ++i) {
+        P += G.st[i].n_mm;
+        C += G.st[i].n_conf;
+        if (G.rec[i].l_qseq > lq) lq = G.rec[i].l_qseq;
+    }
+    A.P_cap = (int32_t)P;
+    /* interval lists: the intersection of k sorted lists has at most the sum of their lengths; flanking windows are at
+     * most one per marker cell in the degenerate margin-0 case, normally about one per position.  `slack` multiplies
+     * the estimate after an overflow. */
+    int64_t bc = C + 2 * P + 16;
+    if (slack > 1) bc = C + (int64_t)slack * P * (G.n > 0 ? G.n : 1) + 16;
+    A.blk_cap = (int32_t)(bc > 0x3fffffff ? 0x3fffffff : bc);
+    A.rows_cap = (int32_t)(all_rows ? lq + 8 : P + 8);
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += (bytes + 15) & ~(int64_t)15; return at; };
+    A.o_pos = take(4 * (P + 1));
+    A.o_mk = take((int64_t)sizeof(Mk) * (P * G.n + 1));
+    A.o_keep = take(P + 1);
+    A.o_flank = take((int64_t)sizeof(Blk) * A.blk_cap);
+    A.o_cur = take((int64_t)sizeof(Blk) * A.blk_cap);
+    A.o_nxt = take((int64_t)sizeof(Blk) * A.blk_cap);
+    A.o_proj = take((int64_t)sizeof(Blk) * A.blk_cap * G.n);
+    A.o_nproj = take(4 * 16);
+    A.o_rowsmk = take(4 * (int64_t)A.rows_cap);
+    A.bytes = o;
+    return A;
+}
+
+struct GroupCount {
+    int32_t err;      /* 0 or SPX_E* (the group is then reported with that code and contributes nothing) */
+    int32_t scored;
+    int32_t n_cols;   /* marker columns kept (markers = n_cols * n) */
+    int32_t n_prob, n_rows, n_qe;
+    int64_t cells, s_need, f_need;
+    int32_t cls_prob[SPX_N_CLASSES];
+    int64_t cls_cells[SPX_N_CLASSES];
+};
+
+SPX_HD Mk match_marker(const Rec &r, const AlnState &st, const uint8_t *qual, int pos)
+{
+    Mk m;
+    const bool rev = (r.flag & SPX_FREVERSE) != 0;
+    m.is_match = 1; m.row = -1; m.ref_pos = -1; m.pad0 = m.pad1 = 0;
+    m.base_idx = rev ? r.l_qseq + st.rclip - pos - 1 : pos - st.lclip;
+    m.q = (m.base_idx >= 0 && m.base_idx < r.l_qseq) ? qual[m.base_idx] : 0;
+    return m;
+}
+
+/* marker columns of a group: k-way merge of the alignments' mismatch lists by read position, positions where every
+ * alignment mismatches dropped (remove_all_mismatch_markers), the others completed with match markers
+ * (sort_and_fill_markers), then columns inside an insertion / clip of any alignment dropped and the reference
+ * positions of match markers inside '=' ops filled in (filter_ins_markers).  Returns the number of columns kept. */
+SPX_HD int group_columns(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk, uint8_t *keep)
+{
+    const int n = G.n;
+    int head[10], left[10];
+    for (int i = 0; i < n; ++i) {
+        const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
+        left[i] = G.st[i].n_mm;
+        head[i] = rev ? G.st[i].n_mm - 1 : 0;
+    }
+    int ncol = 0;
+    for (;;) {
+        int best = 0x7fffffff;
+        for (int i = 0; i < n; ++i)
+            if (left[i] > 0) {
+                const int p = P.mm[G.st[i].mm_off + head[i]].pos;
+                if (p < best) best = p;
+            }
+        if (best == 0x7fffffff) break;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i)
+            if (left[i] > 0 && P.mm[G.st[i].mm_off + head[i]].pos == best) ++cnt;
+        for (int i = 0; i < n; ++i) {
+            const bool has = left[i] > 0 && P.mm[G.st[i].mm_off + head[i]].pos == best;
+            if (cnt != n) {
+                Mk m;
+                if (has) {
+                    const MM s = P.mm[G.st[i].mm_off + head[i]];
+                    m.base_idx = s.base_idx; m.ref_pos = s.ref_pos; m.row = -1; m.q = (uint8_t)s.q; m.is_match = 0;
+                    m.pad0 = m.pad1 = 0;
+                } else
+                    m = match_marker(G.rec[i], G.st[i], P.qual + G.rec[i].qual_off, best);
+                mk[(int64_t)ncol * n + i] = m;
+            }
+            if (has) {
+                const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
+                head[i] += rev ? -1 : 1;
+                left[i]--;
+            }
+        }
+        if (cnt != n) { pos[ncol] = best; keep[ncol] = 1; ++ncol; }
+    }
+    if (ncol == 0) return 0;
+    /* positions inside an insertion / clip of any alignment are not comparable: drop the column */
+    for (int i = 0; i < n; ++i) {
+        const Rec &r = G.rec[i];
+        const AlnState &st = G.st[i];
+        const bool rev = (r.flag & SPX_FREVERSE) != 0;
+        const Op *ops = P.ops + st.ops_off;
+        int col = rev ? ncol - 1 : 0;
+        const int step = rev ? -1 : 1;
+        for (int t = 1; t < st.n_visit && col >= 0 && col < ncol; ++t) {
+            const Op o = ops[t];
+            while (col >= 0 && col < ncol) {
+                const int p = pos[col];
+                if (!(o.rds <= p && p <= o.rde)) break;
+                if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) keep[col] = 0;
+                if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
+                    mk[(int64_t)col * n + i].ref_pos = rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
+                col += step;
+            }
+        }
+    }
+    int w = 0;
+    for (int c = 0; c < ncol; ++c) {
+        if (!keep[c]) continue;
+        if (w != c) {
+            pos[w] = pos[c];
+            for (int i = 0; i < n; ++i) mk[(int64_t)w * n + i] = mk[(int64_t)c * n + i];
+        }
+        ++w;
+    }
+    return w;
+}
+
+/* ascending by key; inputs are monotone (ascending, or descending on the reverse strand), so: reverse when
+ * descending, then an insertion pass that is linear on sorted data */
+template <int KEY> /* 0: rds, 1: sqs */
+SPX_HD void sort_blocks(Blk *b, int n)
+{
+    auto key = [](const Blk &x) { return KEY == 0 ? x.rds : x.sqs; };
+    if (n > 1 && key(b[0]) > key(b[n - 1]))
+        for (int i = 0, j = n - 1; i < j; ++i, --j) { const Blk t = b[i]; b[i] = b[j]; b[j] = t; }
+    for (int i = 1; i < n; ++i) {
+        const Blk t = b[i];
+        int j = i - 1;
+        while (j >= 0 && key(b[j]) > key(t)) { b[j + 1] = b[j]; --j; }
+        b[j + 1] = t;
+    }
+}
+
+/* flanking windows of one alignment around every marker cell (find_flanking_blocks) */
+SPX_HD int flank_blocks(const AlnState &st, const int32_t *pos, int ncol, int n, int margin, Blk *out, int cap)
+{
+    auto lo = [&](int p) { const int v = p - margin; return st.rds > v ? st.rds : v; };
+    auto hi = [&](int p) { const int v = p + margin; return st.rde < v ? st.rde : v; };
+    int cnt = 0;
+    int start = lo(pos[0]), end = hi(pos[0]);
+    const int64_t total = (int64_t)ncol * n;
+    for (int64_t i = 1; i < total; ++i) {
+        const int p = pos[i / n];
+        const int cs = lo(p), ce = hi(p);
+        if (cs < end) end = ce;
+        else {
+            if (cnt >= cap) return -1;
+            Blk b = {-1, -1, -1, -1, start, end};
+            out[cnt++] = b;
+            start = cs; end = ce;
+        }
+    }
+    if (cnt >= cap) return -1;
+    Blk b = {-1, -1, -1, -1, start, end};
+    out[cnt++] = b;
+    return cnt;
+}
+
+SPX_HD int intersect(const Blk *x, int nx, const Blk *y, int ny, Blk *out, int cap)
+{
+    if (nx == 0 || ny == 0) return 0;
+    int cnt = 0, j = 0;
+    for (int i = 0; i < nx; ++i) {
+        while (j < ny && y[j].rde < x[i].rds) ++j;
+        while (j < ny && y[j].rds < x[i].rde) {
+            if (cnt >= cap) return -1;
+            Blk b = {-1, -1, -1, -1, x[i].rds > y[j].rds ? x[i].rds : y[j].rds, x[i].rde < y[j].rde ? x[i].rde : y[j].rde};
+            out[cnt++] = b;
+            if (y[j].rde <= x[i].rde) ++j; else break;
+        }
+    }
+    return cnt;
+}
+
+/* project the consensus intervals cur[0..nb) (read coordinates) onto one alignment (correct_conf_blocks) */
+SPX_HD int project_blocks(const Rec &r, const AlnState &st, const Op *ops, const Blk *cur, int nb, int thr, Blk *out, int cap)
+{
+    const bool rev = (r.flag & SPX_FREVERSE) != 0;
+    int cnt = 0;
+    int j = rev ? nb - 1 : 0;
+    bool have = true, del_flag = false;
+    int bs = rev ? -cur[j].rde : cur[j].rds, be = rev ? -cur[j].rds : cur[j].rde;
+    int rfs = -1, rfe = -1, sqs = -1, sqe = -1;
+    for (int t = 1; t < st.n_visit; ++t) {
+        const Op o = ops[t];
+        const int cs = rev ? -o.rde : o.rds, ce = rev ? -o.rds : o.rde;
+        if (mx(o.op) || o.op == SPX_CINS) {
+            const bool ins = o.op == SPX_CINS;
+            while (have && be <= ce) {
+                if (cs <= bs && !(del_flag && cs == bs)) {
+                    rfs = ins ? o.rfs : o.rfs + (bs - cs);
+                    sqs = o.sqs + (bs - cs);
+                }
+                rfe = ins ? o.rfe : o.rfs + (be - cs);
+                sqe = o.sqs + (be - cs);
+                if (cnt >= cap) return -1;
+                Blk b = {rfs, rfe, sqs, sqe, cur[j].rds, cur[j].rde};
+                out[cnt++] = b;
+                if (rev && j > 0) { --j; bs = -cur[j].rde; be = -cur[j].rds; }
+                else if (!rev && j < nb - 1) { ++j; bs = cur[j].rds; be = cur[j].rde; }
+                else have = false;
+            }
+            if (!have) break;
+            if (cs <= bs && bs <= ce && !(del_flag && cs == bs)) {
+                rfs = ins ? o.rfs : o.rfs + (bs - cs);
+                sqs = o.sqs + (bs - cs);
+            }
+            del_flag = false;
+        } else if (o.op == SPX_CDEL) {
+            if (have && bs == cs && o.len <= thr) {
+                del_flag = true;
+                rfs = o.rfs;
+                sqs = o.sqs;
+            }
+        }
+    }
+    sort_blocks<1>(out, cnt);
+    return cnt;
+}
+
+/* the scratch arrays of one group */
+struct GroupScratch {
+    int32_t *pos;
+    Mk *mk;
+    uint8_t *keep;
+    Blk *flank, *cur, *nxt;
+    Blk *proj;       /* [n][blk_cap]: each alignment's current block list (confident blocks, then projected windows) */
+    int32_t *nproj;  /* [n] */
+    int32_t *rows_mk;
+    int32_t blk_cap, rows_cap;
+};
+SPX_HD GroupScratch group_scratch(const GroupArena &A, char *base)
+{
+    GroupScratch S;
+    S.pos = (int32_t *)(base + A.o_pos);
+    S.mk = (Mk *)(base + A.o_mk);
+    S.keep = (uint8_t *)(base + A.o_keep);
+    S.flank = (Blk *)(base + A.o_flank);
+    S.cur = (Blk *)(base + A.o_cur);
+    S.nxt = (Blk *)(base + A.o_nxt);
+    S.proj = (Blk *)(base + A.o_proj);
+    S.nproj = (int32_t *)(base + A.o_nproj);
+    S.rows_mk = (int32_t *)(base + A.o_rowsmk);
+    S.blk_cap = A.blk_cap;
+    S.rows_cap = A.rows_cap;
+    return S;
+}
+
+/* consensus windows (secphase.c:162-170 + ptMarker.c:398-667).  On return S.proj/S.nproj hold, per alignment, the
+ * blocks plan_baq walks.  Returns 1 if the group is scored, 0 if not, < 0 on SPX_E*. */
+SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, int ncol)
+{
+    const int n = G.n, cap = S.blk_cap;
+    for (int i = 0; i < n; ++i) {
+        const AlnState &st = G.st[i];
+        if (st.n_conf > cap) return SPX_ENOMEM;
+        Blk *dst = S.proj + (int64_t)i * cap;
+        for (int k = 0; k < st.n_conf; ++k) dst[k] = P.conf[st.conf_off + k];
+        S.nproj[i] = st.n_conf;
+    }
+    int margin = par.flank_margin, nblk = 1 /* DESIGN.md U1 */, iter = 0;
+    auto too_long = [&]() {
+        bool flag = false;
+        for (int i = 0; i < n; ++i) {
+            if (S.nproj[i] == 0) return true;
+            const Blk *b = S.proj + (int64_t)i * cap;
+            for (int k = 0; k < S.nproj[i]; ++k)
+                if ((b[k].sqe - b[k].sqs) > 1000 || (b[k].rfe - b[k].rfs) > 1000) flag = true;
+        }
+        return flag;
+    };
+    while (par.consensus && too_long()) {
+        margin = (int)(margin * 0.8);
+        /* intersect every alignment's blocks, then every alignment's flanking windows, in read coordinates */
+        sort_blocks<0>(S.proj, S.nproj[0]);
+        int nc = S.nproj[0];
+        for (int k = 0; k < nc; ++k) S.cur[k] = S.proj[k];
+        Blk *cur = S.cur, *nxt = S.nxt;
+        for (int i = 1; i < n; ++i) {
+            Blk *bi = S.proj + (int64_t)i * cap;
+            sort_blocks<0>(bi, S.nproj[i]);
+            const int m = intersect(cur, nc, bi, S.nproj[i], nxt, cap);
+            if (m < 0) return SPX_ENOMEM;
+            nc = m;
+            Blk *t = cur; cur = nxt; nxt = t;
+        }
+        for (int i = 0; i < n; ++i) {
+            const int nf = flank_blocks(G.st[i], S.pos, ncol, n, margin, S.flank, cap);
+            if (nf < 0) return SPX_ENOMEM;
+            sort_blocks<0>(S.flank, nf);
+            const int m = intersect(cur, nc, S.flank, nf, nxt, cap);
+            if (m < 0) return SPX_ENOMEM;
+            nc = m;
+            Blk *t = cur; cur = nxt; nxt = t;
+        }
+        if (nc == 0) {
+            for (int i = 0; i < n; ++i) S.nproj[i] = 0;
+            nblk = 0;
+            break;
+        }
+        for (int i = 0; i < n; ++i) {
+            const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, cur, nc, par.indel_threshold,
+                                         S.proj + (int64_t)i * cap, cap);
+            if (m < 0) return SPX_ENOMEM;
+            S.nproj[i] = m;
+        }
+        nblk = nc;
+        if (++iter >= 64) break;
+    }
+    return (nblk > 0 || !par.consensus) ? 1 : 0;
+}
+
+/* where the emitting pass writes */
+struct PlanOut {
+    /* per problem */
+    int64_t *ref_nib, *qry_nib;
+    int32_t *ref_tid, *ref_rfs; /* may be NULL */
+    int32_t *L, *R, *bw, *row_off, *n_rows, *prob_slots;
+    double *hmm;
+    int64_t *s_off, *fsave_off;
+    /* per wanted row */
+    int32_t *rows, *row_expect, *row_prob;
+    uint8_t *row_rawq;
+    /* quality edits (all_rows) */
+    int32_t *qe_rec, *qe_pos, *qe_len, *qe_row0, *qe_batch;
+};
+struct PlanBase { /* this group's first problem / row / edit and scratch offsets */
+    int64_t prob, row, qe, s_off, f_off;
+};
+
+/* BAQ windows of one alignment (calc_local_baq's control flow).  EMIT = false: counts into gc; EMIT = true: writes
+ * the problems, the wanted rows and the marker updates.  Columns are visited through this alignment's cell only:
+ * the reference's loops step over every marker and skip the other alignments' cells. */
+template <bool EMIT>
+SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S, int ncol,
+                    GroupCount &gc, PlanBase &at, const PlanOut &out)
+{
+    const int n = G.n;
+    const Rec &r = G.rec[ai];
+    const AlnState &st = G.st[ai];
+    const Op *ops = P.ops + st.ops_off;
+    const uint8_t *qual = P.qual + r.qual_off;
+    const bool rev = (r.flag & SPX_FREVERSE) != 0;
+    const int step = rev ? -1 : 1;
+    int c = rev ? ncol - 1 : 0;
+    int ci = 0;
+    const int margin = 10;
+    const int last = st.n_ops - 1;
+    auto adv = [&]() -> int { if (ci < last) { ++ci; return ops[ci].len; } return 0; };
+    auto own = [&](int col) -> Mk & { return S.mk[(int64_t)col * n + ai]; };
+    auto zero_edit = [&](int base) {
+        if (!par.all_rows) return;
+        if (EMIT) {
+            out.qe_rec[at.qe] = r.rec; out.qe_pos[at.qe] = base; out.qe_len[at.qe] = 0; out.qe_row0[at.qe] = 0;
+            out.qe_batch[at.qe] = r.batch;
+        }
+        at.qe++;
+        if (!EMIT) gc.n_qe++;
+    };
+    const Blk *blocks = S.proj + (int64_t)ai * S.blk_cap;
+    const int nblocks = S.nproj[ai];
+    for (int bi = 0; bi < nblocks; ++bi) {
+        const Blk b = blocks[bi];
+        while (ops[ci].sqe < b.sqs || ops[ci].rfe < b.rfs)
+            if (adv() == 0) break;
+        /* markers of this alignment in the leading margin lose their quality */
+        while (c >= 0 && c < ncol && own(c).base_idx < b.sqs + margin) {
+            if (b.sqs <= own(c).base_idx) {
+                if (EMIT) { own(c).q = 0; own(c).row = -1; }
+                zero_edit(own(c).base_idx);
+            }
+            c += step;
+        }
+        if (c >= 0 && c < ncol && own(c).base_idx <= b.sqe - margin && b.sqs + margin <= own(c).base_idx) {
+            const int L = b.sqe - b.sqs + 1, R = b.rfe - b.rfs + 1;
+            if (L <= 0 || R <= 0) return SPX_EINVAL;
+            if (r.tid < 0 || r.tid >= rv.n_contigs || b.rfs < 0 || b.rfe >= rv.len[r.tid]) return SPX_EINVAL;
+            if (b.sqs < 0 || b.sqe >= r.l_qseq) return SPX_EINVAL;
+            const int diff = R > L ? R - L : L - R;
+            const int bw_in = (int)(diff + par.conf_b);
+            const int bw = effective_bw(R, L, bw_in);
+            const int cls = band_class(2 * bw + 1);
+            if (cls < 0) return SPX_EUNSUPPORTED;
+            const int slots = class_slots(cls);
+            /* wanted rows: this alignment's markers in [sqs+margin, sqe-margin) keep a BAQ value; with all_rows every
+             * base of that range is wanted (the write-back at ptMarker.c:786) */
+            int nrows = 0;
+            if (par.all_rows) {
+                nrows = L - 2 * margin > 0 ? L - 2 * margin : 0;
+                if (nrows > S.rows_cap) return SPX_ENOMEM;
+                if (EMIT) for (int t = 0; t < nrows; ++t) S.rows_mk[t] = -1;
+            }
+            for (int k = c; k >= 0 && k < ncol; k += step) {
+                if (own(k).base_idx > b.sqe) break;
+                const int t = own(k).base_idx - b.sqs;
+                if (t >= margin && t < L - margin) {
+                    if (par.all_rows) { if (EMIT) S.rows_mk[t - margin] = k; }
+                    else {
+                        if (nrows >= S.rows_cap) return SPX_ENOMEM;
+                        if (EMIT) { S.rows_mk[nrows] = k; out.rows[at.row + nrows] = t + 1; }
+                        ++nrows;
+                    }
+                }
+            }
+            const int64_t row0 = at.row;
+            if (EMIT) {
+                for (int w = 0; w < nrows; ++w) {
+                    const int t = par.all_rows ? margin + w : out.rows[row0 + w] - 1;
+                    out.rows[row0 + w] = t + 1;
+                    out.row_expect[row0 + w] = -1;
+                    out.row_rawq[row0 + w] = qual[b.sqs + t];
+                    out.row_prob[row0 + w] = (int32_t)at.prob;
+                }
+            }
+            /* expected reference index of every wanted base, from the CIGAR walk of the write-back loop; the wanted
+             * rows ascend and the M/=/X pieces of a block are disjoint and ascending, so one cursor serves */
+            int w = 0;
+            while (ops[ci].sqs <= b.sqe || ops[ci].rfs <= b.rfe) {
+                const Op o = ops[ci];
+                int x = o.rfs - b.rfs, y = o.sqs - b.sqs;
+                if (x < 0) x = 0;
+                if (y < 0) y = 0;
+                if (EMIT && mx(o.op)) {
+                    const int e1 = o.sqe < b.sqe ? o.sqe : b.sqe, s1 = o.sqs > b.sqs ? o.sqs : b.sqs;
+                    int len = e1 - s1 + 1;
+                    if (o.len < len) len = o.len;
+                    while (w < nrows && out.rows[row0 + w] - 1 < y) ++w;
+                    while (w < nrows && out.rows[row0 + w] - 1 < y + len) {
+                        out.row_expect[row0 + w] = x + (out.rows[row0 + w] - 1 - y);
+                        ++w;
+                    }
+                }
+                if (o.sqe <= b.sqe || o.rfe <= b.rfe) { if (adv() == 0) break; }
+                else break;
+            }
+            if (par.all_rows) {
+                if (EMIT) {
+                    out.qe_rec[at.qe] = r.rec; out.qe_pos[at.qe] = b.sqs + margin; out.qe_len[at.qe] = nrows;
+                    out.qe_row0[at.qe] = (int32_t)row0; out.qe_batch[at.qe] = r.batch;
+                }
+                at.qe++;
+                if (!EMIT) gc.n_qe++;
+            }
+            if (EMIT) {
+                for (int w2 = 0; w2 < nrows; ++w2) {
+                    const int k = S.rows_mk[w2];
+                    if (k < 0) continue;
+                    Mk &m = own(k);
+                    if (out.row_expect[row0 + w2] >= 0) m.row = (int32_t)(row0 + w2);
+                    else { m.row = -1; m.q = (uint8_t)(par.set_q < 94 ? par.set_q : 93); } /* base not under an M op: keeps set_q */
+                }
+                const int64_t p = at.prob;
+                out.ref_nib[p] = rv.nib_off[r.tid] + b.rfs;
+                if (out.ref_tid) { out.ref_tid[p] = r.tid; out.ref_rfs[p] = b.rfs; }
+                out.qry_nib[p] = (P.code_lead_bytes + r.seq_off) * 2 + b.sqs;
+                out.L[p] = L; out.R[p] = R; out.bw[p] = bw;
+                out.row_off[p] = (int32_t)row0;
+                out.n_rows[p] = nrows;
+                out.prob_slots[p] = slots;
+                out.s_off[p] = at.s_off + 8;
+                out.fsave_off[p] = at.f_off;
+                double *h = out.hmm + p * SPX_H_N;
+                hmm_constants(R, L, par.d, par.e, par.qf, h);
+                bool has_n = window_has_n(rv, r.tid, b.rfs, R);
+                if (!has_n && st.has_n) {
+                    const uint8_t *code = P.code4 + P.code_lead_bytes + r.seq_off;
+                    for (int k = 0; k < L && !has_n; ++k) {
+                        const int q = b.sqs + k;
+                        has_n = ((code[q >> 1] >> ((q & 1) << 2)) & 0xf) > 3;
+                    }
+                }
+                h[SPX_H_PAD0] = has_n ? 1.0 : 0.0;
+            }
+            const int64_t cells = band_cells(L, R, bw);
+            if (!EMIT) {
+                gc.n_prob++;
+                gc.n_rows += nrows;
+                gc.cells += cells;
+                gc.cls_prob[cls]++;
+                gc.cls_cells[cls] += cells;
+                gc.s_need += 8 + ((L + 2 + 7) & ~7);
+                gc.f_need += (int64_t)nrows * 2 * slots;
+            }
+            at.prob++;
+            at.row += nrows;
+            /* whole 64-byte lines behind a lead pad of one line: the one-lane forward kernel writes 1/s[] eight rows at a time */
+            at.s_off += 8 + ((L + 2 + 7) & ~7);
+            at.f_off += (int64_t)nrows * 2 * slots;
+        }
+        /* markers in the trailing margin lose their quality */
+        while (c >= 0 && c < ncol && own(c).base_idx <= b.sqe) {
+            if (b.sqe - margin <= own(c).base_idx) {
+                if (EMIT) { own(c).q = 0; own(c).row = -1; }
+                zero_edit(own(c).base_idx);
+            }
+            c += step;
+        }
+    }
+    return 0;
+}
+
+/* pass 1 of a group: columns, consensus windows, work-list sizes.  The marker table and the block lists stay in the
+ * group's scratch for pass 2. */
+SPX_HD void group_count(const GroupView &G, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S, GroupCount &gc)
+{
+    gc.err = 0; gc.scored = 0; gc.n_cols = 0; gc.n_prob = 0; gc.n_rows = 0; gc.n_qe = 0;
+    gc.cells = 0; gc.s_need = 0; gc.f_need = 0;
+    for (int k = 0; k < SPX_N_CLASSES; ++k) { gc.cls_prob[k] = 0; gc.cls_cells[k] = 0; }
+    for (int i = 0; i < G.n; ++i)
+        if (G.st[i].err) { gc.err = G.st[i].err; return; }
+    for (int i = 0; i < G.n; ++i)
+        if (G.rec[i].tid < 0 || G.rec[i].tid >= rv.n_contigs) { gc.err = SPX_EINVAL; return; }
+    const int ncol = group_columns(G, P, S.pos, S.mk, S.keep);
+    gc.n_cols = ncol;
+    for (int i = 0; i < G.n; ++i) S.nproj[i] = 0;
+    if (ncol == 0) return;
+    const int sc = group_blocks(G, P, par, S, ncol);
+    if (sc < 0) { gc.err = sc; gc.n_cols = 0; return; }
+    gc.scored = sc;
+    if (!sc) { gc.n_cols = 0; return; }
+    if (par.baq_flag) {
+        PlanBase at = {0, 0, 0, 0, 0};
+        PlanOut none = {};
+        for (int i = 0; i < G.n; ++i) {
+            const int rc = plan_baq<false>(G, i, P, rv, par, S, ncol, gc, at, none);
+            if (rc) {
+                gc.err = rc; gc.scored = 0; gc.n_cols = 0; gc.n_prob = 0; gc.n_rows = 0; gc.n_qe = 0;
+                gc.cells = 0; gc.s_need = 0; gc.f_need = 0;
+                for (int k = 0; k < SPX_N_CLASSES; ++k) { gc.cls_prob[k] = 0; gc.cls_cells[k] = 0; }
+                return;
+            }
+        }
+    }
+}
+
+/* pass 2: writes the group's problems / rows / edits at `at`, then its marker table at mk_out (n_cols * n entries) */
+SPX_HD int group_emit(const GroupView &G, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S,
+                      const GroupCount &gc, PlanBase at, const PlanOut &out, spx_dev_marker *mk_out, int32_t *mk_ref_pos)
+{
+    if (gc.err || !gc.scored) return 0;
+    const int n = G.n, ncol = gc.n_cols;
+    if (par.baq_flag) {
+        GroupCount dummy = gc;
+        for (int i = 0; i < n; ++i) {
+            const int rc = plan_baq<true>(G, i, P, rv, par, S, ncol, dummy, at, out);
+            if (rc) return rc; /* cannot happen: the counting pass went through the same control flow */
+        }
+    }
+    for (int c = 0; c < ncol; ++c)
+        for (int i = 0; i < n; ++i) {
+            const Mk m = S.mk[(int64_t)c * n + i];
+            spx_dev_marker dm;
+            dm.row = m.row;
+            dm.qfix = m.q;
+            dm.is_match = m.is_match;
+            dm.aln = (uint8_t)i;
+            dm.first_of_pos = i == 0 ? (uint8_t)n : 0;
+            mk_out[(int64_t)c * n + i] = dm;
+            mk_ref_pos[(int64_t)c * n + i] = m.ref_pos;
+        }
+    return 0;
+}
+
+} // namespace spxl
+#endif

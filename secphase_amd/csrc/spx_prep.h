@@ -1,7 +1,7 @@
 /*
- * spx_prep.h -- host-side preparation of a batch of alignment groups for the
- * device: CIGAR/cs walk, markers, consensus blocks, and the list of banded
- * DP problems + the marker table the scoring kernel consumes.  Internal.
+ * spx_prep.h -- host side of the work-list preparation: staging of record batches into the packed pools the
+ * device reads (spx_logic.h Rec + payload), the host-only plan (the same spx_logic.h functions run on the CPU),
+ * and the tables the kernels need.  Internal.
  */
 #ifndef SPX_PREP_H
 #define SPX_PREP_H
@@ -12,9 +12,12 @@
 
 #include "../../include/spx.h"
 #include "spx_device.h"
+#include "spx_logic.h"
 
 namespace spx {
 
+/* a work list as the host sees it: filled completely by the host plan (spx_plan_create, spx_probaln_*), and for
+ * device-prepared work lists only with the per-group arrays spx_collect / spx_relabel_blocks / spx_apply_quals pull back */
 struct HostBatch {
     /* DP problems */
     std::vector<int64_t> ref_nib, qry_nib;
@@ -36,17 +39,12 @@ struct HostBatch {
     std::vector<int32_t> mk_ref_pos; /* per marker: reference position (BED side outputs) */
     std::vector<int32_t> grp_problems;
     std::vector<int64_t> grp_cells;
-    std::vector<int32_t> grp_error; /* per input group: 0 or SPX_E* */
+    std::vector<int32_t> grp_error; /* per input group: 0, 1 (not dispatched) or SPX_E* */
     /* SPX_PAR_ALL_ROWS only: the writes calc_local_baq makes to the record's quality array, in the order it
      * makes them (ptMarker.c:706,759,763).  len == 0: qual[rec][pos] = 0; len > 0: rows row0.. hold the values of
      * qual[rec][pos .. pos+len) (row_expect < 0: base not under an M/=/X op, keeps set_q) */
     std::vector<int32_t> qe_rec, qe_pos, qe_len, qe_row0, qe_batch;
     int64_t dp_cells = 0;
-
-    void clear();
-    void append(const HostBatch &o);
-    /* *this = parts[0] + parts[1] + ... (same result as appending them one by one), copied on n_threads threads */
-    void assign_merged(std::vector<HostBatch> &parts, int n_threads);
 };
 
 /* Pads of the 4-bit reference pool.  The kernels fetch codes in chunks of 16 a whole band width before / after a
@@ -54,38 +52,62 @@ struct HostBatch {
  * slots + 32 behind the last one (slots <= 2048). */
 constexpr int64_t kRefLeadNibbles = 4096;
 constexpr size_t kRefTailBytes = 2048;
+/* same for the pool of recoded read sequences the query windows point into */
+constexpr int64_t kCodeLeadBytes = 128;
+constexpr int64_t kCodeTailBytes = 256;
 
-/* nibble offset of every contig inside the device reference pool */
+/* nibble offset of every contig inside the device reference pool + the ambiguous-base index */
 struct RefIndex {
     std::vector<int64_t> nib_off; /* [n_contigs] first nibble of each contig (byte aligned) */
     std::vector<int64_t> len;     /* [n_contigs] bases */
-    /* positions of ambiguous (non-ACGT) bases per contig, ascending: lets prep flag windows that need
-     * the general emission path */
-    std::vector<std::vector<int32_t>> npos;
-    bool window_has_n(int tid, int64_t start, int64_t n) const
-    {
-        if ((size_t)tid >= npos.size()) return false;
-        const std::vector<int32_t> &v = npos[tid];
-        size_t lo = 0, hi = v.size();
-        while (lo < hi) { size_t m = (lo + hi) / 2; if (v[m] < start) lo = m + 1; else hi = m; }
-        return lo < v.size() && v[lo] < start + n;
-    }
-    void index_ambiguous(const spx_ref *ref);
+    std::vector<int64_t> npos_off; /* [n_contigs+1] */
+    std::vector<int32_t> npos;     /* positions of non-ACGT bases per contig, ascending */
+    void build(const spx_ref *ref);
+    spxl::RefView view() const;
 };
 
-/* prepares groups [g0,g1) of bt */
-int prepare_groups(const spx_batch *bt, const RefIndex &ref, const spx_params *par, int32_t g0, int32_t g1,
-                   HostBatch &out);
+/* ---- staging: record batches -> one packed buffer (host pinned memory in the runtime, plain memory for the plan) ---- */
+struct StageLayout {
+    int64_t n_groups_in = 0; /* input groups over all batches */
+    int64_t n_dgroups = 0;   /* groups passing the dispatch filter (src/secphase.c:285-288) */
+    int64_t n_slots = 0;     /* their alignments */
+    int64_t cigar_words = 0, seq_bytes = 0, qual_bytes = 0, text_bytes = 0;
+    /* byte offsets inside the staged buffer */
+    size_t o_recs = 0, o_slot0 = 0, o_gidx = 0, o_cigar = 0, o_seq = 0, o_qual = 0, o_text = 0, bytes = 0;
+};
+struct Stage {
+    StageLayout lay;
+    std::vector<spxl::Rec> recs;      /* offsets already final */
+    std::vector<int32_t> slot0;       /* [n_dgroups+1] */
+    std::vector<int32_t> grp_index;   /* [n_dgroups] input group (global over the batches) */
+    std::vector<int32_t> grp_error;   /* per input group: 0 dispatched / 1 not */
+    std::vector<const spx_batch *> batches;
+    std::vector<int32_t> batch_base;  /* first input group of every batch */
+};
+/* measure: dispatch filter, per-alignment payload sizes (strlen of the tags), layout */
+int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, Stage &st);
+/* copy the payload into dst (lay.bytes bytes) on `threads` threads */
+void stage_copy(const Stage &st, char *dst, int threads);
+
+/* what the work list needs from spx_params, in the shape spx_logic.h wants (qf through the host libm) */
+spxl::Params logic_params(const spx_params *par);
+
+/* host plan: the spx_logic.h passes run on the CPU; fills every array of hb */
+int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &ref, const spx_params *par, int threads,
+              HostBatch &hb);
 
 void hmm_constants(int l_ref, int l_query, float d, float e, int set_q, double *h /* SPX_H_N */);
-int effective_bw(int l_ref, int l_query, int bw_in);
-int64_t band_cells(int L, int R, int bw_eff);
-int band_class(int W); /* index into the (G,C) table, -1 if too wide */
-int class_slots(int cls);
-int class_lanes(int cls); /* lanes of a wavefront that share one problem (forward kernel) */
-int class_lanes_bwd(int cls);
+inline int effective_bw(int l_ref, int l_query, int bw_in) { return spxl::effective_bw(l_ref, l_query, bw_in); }
+inline int64_t band_cells(int L, int R, int bw_eff) { return spxl::band_cells(L, R, bw_eff); }
+inline int band_class(int W) { return spxl::band_class(W); } /* index into the (G,C) table, -1 if too wide */
+inline int class_slots(int cls) { return spxl::class_slots(cls); }
+inline int class_lanes(int cls) { return spxl::class_lanes(cls); } /* lanes of a wavefront that share one problem (forward kernel) */
+inline int class_lanes_bwd(int cls) { return spxl::class_lanes_bwd(cls); }
 void phred_thresholds(double *thr /* 102 */);
 void score_tables(double *match_tbl /*256*/, double *mis_tbl /*256*/);
+bool group_dispatched(const spx_batch *bt, int g);
+/* SEQ as BAM stores it (nt16, high nibble first) -> 0..4 codes, low nibble first; returns whether a code > 3 occurred */
+bool recode_seq(const uint8_t *src, uint8_t *dst, int64_t n_bytes);
 
 } // namespace spx
 #endif

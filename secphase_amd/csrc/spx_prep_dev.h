@@ -1,0 +1,75 @@
+/*
+ * spx_prep_dev.h -- argument blocks of the preparation kernels (spx_prep_kernels.hip), shared with the runtime.
+ * Internal.
+ */
+#ifndef SPX_PREP_DEV_H
+#define SPX_PREP_DEV_H
+
+#include <stdint.h>
+
+#include "spx_logic.h"
+
+/* sizes the host reads back once per work list (one small D2H copy) */
+struct spx_prep_totals {
+    int64_t n_ops, n_conf, n_mm;      /* pool needs of the per-alignment pass */
+    int64_t arena_bytes;              /* scratch need of the per-group pass */
+    int64_t n_prob, n_rows, n_qe, n_mk, s_tot, f_tot, cells;
+    int64_t n_ok;                     /* dispatched groups without an error */
+    int32_t overflow;                 /* 1: a pool was too small, 2: a group's interval lists outgrew their estimate */
+    int32_t pad;
+    int64_t cls_prob[SPX_N_CLASSES], cls_cells[SPX_N_CLASSES];
+};
+
+struct spx_group_info { /* per dispatched group, copied back with the results */
+    int32_t err, n_aln, n_prob, n_mk;
+    int64_t cells;
+};
+
+struct spx_prep_args {
+    int32_t n_slots, n_dgroups;
+    const spxl::Rec *recs;
+    const int32_t *slot0; /* [n_dgroups+1] */
+    spxl::AlnState *ast;
+    spxl::Pools P;
+    uint8_t *code4_w;     /* P.code4, writable */
+    int64_t ops_cap, conf_cap, mm_cap;
+    spxl::RefView rv;
+    spxl::Params par;
+    spxl::GroupCount *gc;
+    int64_t *ga_bytes, *ga_off;
+    char *arena;
+    int64_t arena_cap;
+    int32_t slack, pad;
+    spx_prep_totals *tot;
+};
+
+struct spx_emit_args {
+    const spxl::PlanBase *base;
+    const int64_t *mk_base;
+    spxl::PlanOut out;
+    spx_dev_marker *markers;
+    int32_t *mk_ref_pos;
+    int32_t *mk_first;
+    uint8_t *n_aln;
+    uint16_t *sec_mask;
+    int32_t *rfe, *rfs, *atid;
+    spx_group_info *info;
+};
+
+struct spx_order_segs { /* where each band class' launch order lives inside the order array */
+    int64_t off[SPX_N_CLASSES];
+    int64_t cap[SPX_N_CLASSES];
+};
+
+struct spx_order_args {
+    int32_t n_prob, pad;
+    const int32_t *bw, *L, *n_rows, *row_off, *rows;
+    uint64_t *key_f, *key_b, *key_sorted;
+    int32_t *val, *val_sorted;
+    int32_t *bin_start, *bin_end, *pad_base; /* SPX_N_CLASSES * 1024 each */
+    void *temp;
+    size_t temp_bytes;
+    int32_t *order_f, *order_b;
+};
+
+#endif

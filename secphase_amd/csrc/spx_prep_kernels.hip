@@ -1,0 +1,351 @@
+/*
+ * spx_prep_kernels.hip -- work-list preparation ON THE DEVICE (gfx950): the integer part of the secphase marker path
+ * (SURVEY.md section 8 rows A1-A8 and A10's control flow; /root/reference/programs/submodules/cigar_it/cigar_it.c,
+ * ptAlignment/ptAlignment.c:42-95, ptMarker/ptMarker.c:42-107,156-295,328-667,670-831, src/secphase.c:162-170).
+ * The functions are those of spx_logic.h -- the same source the host plan runs -- driven by these kernels:
+ *
+ *   recode_kernel        SEQ (BAM nt16, high nibble first) -> 0..4 codes the DP kernels read, coalesced
+ *   aln_count_kernel     one thread per alignment: size of its op table, bounds of its mismatch / block lists
+ *   aln_build_kernel     one thread per alignment: op table, aligned extents, confident blocks, mismatch list
+ *   group_count_kernel   one thread per read group: marker columns, consensus windows, work-list sizes
+ *   group_emit_kernel    one thread per read group: DP problems (with their HMM constants), wanted rows, marker table
+ *   scan kernels         exclusive prefix sums that turn the counts into offsets (single workgroup, LDS)
+ *   order kernels        launch orders of the band classes: radix sort by (class, band, length) + padding to whole waves
+ *
+ * This is integer, pointer-chasing, latency-bound work: one lane walks one alignment's ops.  It costs a few per cent of
+ * the DP kernels' time and needs no host cores, which is what lets 8 GPUs share one host.
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "spx_logic.h"
+#include "spx_prep_dev.h"
+
+using namespace spxl;
+
+/* ---------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void recode_kernel(const uint32_t *__restrict__ raw, uint32_t *__restrict__ code, int64_t n_words,
+                                                     const Rec *__restrict__ recs, int32_t n_slots, AlnState *__restrict__ ast)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t x = raw[w];
+    const uint64_t tbl = 0x4444444344424104ull; /* seq_nt16_int, one nibble per nt16 code */
+    uint32_t out = 0, nmask = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t byte = (x >> (8 * b)) & 0xffu;
+        const uint32_t hi = (uint32_t)(tbl >> (4 * (byte >> 4))) & 0xfu, lo = (uint32_t)(tbl >> (4 * (byte & 0xfu))) & 0xfu;
+        out |= (hi | (lo << 4)) << (8 * b);
+        if (hi > 3) nmask |= 1u << (2 * b);
+        if (lo > 3) nmask |= 1u << (2 * b + 1);
+    }
+    code[w] = out;
+    if (nmask) { /* rare: find the alignment this word belongs to and flag it if the base lies inside its SEQ */
+        const int64_t byte0 = w * 4;
+        int lo = 0, hi = n_slots - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (recs[mid].seq_off <= byte0) lo = mid; else hi = mid - 1;
+        }
+        const int64_t nib0 = (byte0 - recs[lo].seq_off) * 2;
+        for (int k = 0; k < 8; ++k)
+            if (((nmask >> k) & 1) && nib0 + k < recs[lo].l_qseq) { ast[lo].has_n = 1; break; }
+    }
+}
+
+__global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    AlnState st = A.ast[s];
+    const Rec r = A.recs[s];
+    st.n_ops = 0; st.mm_cap = 0; st.conf_cap = 0; st.n_conf = 0; st.n_mm = 0;
+    st.err = build_ops<false>(r, A.P, A.par.min_q, A.par.indel_threshold, st, nullptr);
+    if (st.err) { st.n_ops = 0; st.mm_cap = 0; st.conf_cap = 0; }
+    A.ast[s] = st;
+}
+
+__global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    AlnState st = A.ast[s];
+    if (st.err) return;
+    if (st.ops_off + st.n_ops > A.ops_cap || st.conf_off + st.conf_cap > A.conf_cap || st.mm_off + st.mm_cap > A.mm_cap) {
+        A.tot->overflow = 1;
+        return;
+    }
+    const Rec r = A.recs[s];
+    Op *ops = A.P.ops + st.ops_off;
+    st.err = build_ops<true>(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops);
+    if (!st.err) st.err = finish_alignment(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops, A.P.conf + st.conf_off, A.P.mm + st.mm_off);
+    A.ast[s] = st;
+}
+
+__global__ __launch_bounds__(64) void group_arena_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    const int s0 = A.slot0[k];
+    GroupView G = {A.slot0[k + 1] - s0, A.recs + s0, A.ast + s0};
+    A.ga_bytes[k] = group_arena_layout(G, A.par.all_rows != 0, A.slack).bytes;
+}
+
+__global__ __launch_bounds__(64) void group_count_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    const int s0 = A.slot0[k];
+    GroupView G = {A.slot0[k + 1] - s0, A.recs + s0, A.ast + s0};
+    const GroupArena ga = group_arena_layout(G, A.par.all_rows != 0, A.slack);
+    GroupCount gc;
+    if (A.ga_off[k] + ga.bytes > A.arena_cap) {
+        A.tot->overflow = 1;
+        gc.err = SPX_ENOMEM; gc.scored = 0; gc.n_cols = 0; gc.n_prob = 0; gc.n_rows = 0; gc.n_qe = 0; gc.cells = 0; gc.s_need = 0; gc.f_need = 0;
+        for (int c = 0; c < SPX_N_CLASSES; ++c) { gc.cls_prob[c] = 0; gc.cls_cells[c] = 0; }
+        A.gc[k] = gc;
+        return;
+    }
+    GroupScratch S = group_scratch(ga, A.arena + A.ga_off[k]);
+    group_count(G, A.P, A.rv, A.par, S, gc);
+    if (gc.err == SPX_ENOMEM) A.tot->overflow = 2; /* an interval list outgrew its estimate: repeat with more slack */
+    A.gc[k] = gc;
+    for (int c = 0; c < SPX_N_CLASSES; ++c)
+        if (gc.cls_prob[c]) {
+            atomicAdd((unsigned long long *)&A.tot->cls_prob[c], (unsigned long long)gc.cls_prob[c]);
+            atomicAdd((unsigned long long *)&A.tot->cls_cells[c], (unsigned long long)gc.cls_cells[c]);
+        }
+}
+
+__global__ __launch_bounds__(64) void group_emit_kernel(spx_prep_args A, spx_emit_args E)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    const int s0 = A.slot0[k];
+    const int n = A.slot0[k + 1] - s0;
+    GroupView G = {n, A.recs + s0, A.ast + s0};
+    const GroupCount gc = A.gc[k];
+    const GroupArena ga = group_arena_layout(G, A.par.all_rows != 0, A.slack);
+    GroupScratch S = group_scratch(ga, A.arena + A.ga_off[k]);
+    const PlanBase at = E.base[k];
+    const int64_t mk0 = E.mk_base[k];
+    group_emit(G, A.P, A.rv, A.par, S, gc, at, E.out, E.markers + mk0, E.mk_ref_pos + mk0);
+    const bool ok = gc.err == 0;
+    E.mk_first[k] = (int32_t)mk0;
+    if (k == A.n_dgroups - 1) E.mk_first[k + 1] = (int32_t)(mk0 + (ok ? (int64_t)gc.n_cols * n : 0));
+    E.n_aln[k] = ok ? (uint8_t)n : 0; /* a group with an error takes no part in scoring; its code travels in grp_err */
+    uint16_t sec = 0;
+    for (int i = 0; i < 10; ++i) {
+        const bool in = i < n;
+        if (in && (G.rec[i].flag & SPX_FSECONDARY)) sec |= (uint16_t)(1u << i);
+        E.rfe[k * 10 + i] = in ? G.st[i].rfe : 0;
+        E.rfs[k * 10 + i] = in ? G.st[i].rfs : 0;
+        E.atid[k * 10 + i] = in ? G.rec[i].tid : -1;
+    }
+    E.sec_mask[k] = sec;
+    spx_group_info gi;
+    gi.err = gc.err; gi.n_aln = n; gi.n_prob = ok ? gc.n_prob : 0; gi.n_mk = ok ? gc.n_cols * n : 0; gi.cells = ok ? gc.cells : 0;
+    E.info[k] = gi;
+}
+
+/* ---------------------------------------------------------------------- */
+/* exclusive prefix sums by ONE workgroup of 1024 lanes: the arrays have 10^4 .. 10^5 entries (alignments, groups),
+ * a single pass over them through LDS costs microseconds and needs no temporary storage protocol */
+__device__ __forceinline__ int64_t block_exscan(int64_t v, int64_t *lds, int64_t &total)
+{
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t a = t >= o ? lds[t - o] : 0;
+        __syncthreads();
+        lds[t] += a;
+        __syncthreads();
+    }
+    const int64_t incl = lds[t];
+    total = lds[1023];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(1024) void scan_slots_kernel(spx_prep_args A)
+{
+    __shared__ int64_t lds[1024];
+    int64_t run_ops = 0, run_conf = 0, run_mm = 0;
+    for (int base = 0; base < A.n_slots; base += 1024) {
+        const int s = base + threadIdx.x;
+        const bool in = s < A.n_slots;
+        const int64_t a = in ? A.ast[s].n_ops : 0, b = in ? A.ast[s].conf_cap : 0, c = in ? A.ast[s].mm_cap : 0;
+        int64_t ta, tb, tc;
+        const int64_t ea = block_exscan(a, lds, ta), eb = block_exscan(b, lds, tb), ec = block_exscan(c, lds, tc);
+        if (in) { A.ast[s].ops_off = run_ops + ea; A.ast[s].conf_off = run_conf + eb; A.ast[s].mm_off = run_mm + ec; }
+        run_ops += ta; run_conf += tb; run_mm += tc;
+    }
+    if (threadIdx.x == 0) { A.tot->n_ops = run_ops; A.tot->n_conf = run_conf; A.tot->n_mm = run_mm; }
+}
+
+__global__ __launch_bounds__(1024) void scan_arena_kernel(spx_prep_args A)
+{
+    __shared__ int64_t lds[1024];
+    int64_t run = 0;
+    for (int base = 0; base < A.n_dgroups; base += 1024) {
+        const int k = base + threadIdx.x;
+        const bool in = k < A.n_dgroups;
+        const int64_t a = in ? A.ga_bytes[k] : 0;
+        int64_t ta;
+        const int64_t ea = block_exscan(a, lds, ta);
+        if (in) A.ga_off[k] = run + ea;
+        run += ta;
+    }
+    if (threadIdx.x == 0) A.tot->arena_bytes = run;
+}
+
+__global__ __launch_bounds__(1024) void scan_groups_kernel(spx_prep_args A, PlanBase *__restrict__ base_out, int64_t *__restrict__ mk_base)
+{
+    __shared__ int64_t lds[1024];
+    int64_t r_prob = 0, r_row = 0, r_qe = 0, r_s = 0, r_f = 0, r_mk = 0, r_cells = 0, r_ok = 0;
+    for (int b0 = 0; b0 < A.n_dgroups; b0 += 1024) {
+        const int k = b0 + threadIdx.x;
+        const bool in = k < A.n_dgroups;
+        GroupCount gc;
+        int n = 0;
+        bool ok = false;
+        if (in) { gc = A.gc[k]; n = A.slot0[k + 1] - A.slot0[k]; ok = gc.err == 0; }
+        const int64_t v_prob = ok ? gc.n_prob : 0, v_row = ok ? gc.n_rows : 0, v_qe = ok ? gc.n_qe : 0, v_s = ok ? gc.s_need : 0,
+                      v_f = ok ? gc.f_need : 0, v_mk = ok ? (int64_t)gc.n_cols * n : 0, v_c = ok ? gc.cells : 0;
+        int64_t t1, t2, t3, t4, t5, t6, t7;
+        const int64_t e1 = block_exscan(v_prob, lds, t1), e2 = block_exscan(v_row, lds, t2), e3 = block_exscan(v_qe, lds, t3),
+                      e4 = block_exscan(v_s, lds, t4), e5 = block_exscan(v_f, lds, t5), e6 = block_exscan(v_mk, lds, t6);
+        block_exscan(v_c, lds, t7);
+        int64_t t8;
+        block_exscan(ok ? 1 : 0, lds, t8);
+        r_ok += t8;
+        if (in) {
+            PlanBase pb;
+            pb.prob = r_prob + e1; pb.row = r_row + e2; pb.qe = r_qe + e3; pb.s_off = r_s + e4; pb.f_off = r_f + e5;
+            base_out[k] = pb;
+            mk_base[k] = r_mk + e6;
+        }
+        r_prob += t1; r_row += t2; r_qe += t3; r_s += t4; r_f += t5; r_mk += t6; r_cells += t7;
+    }
+    if (threadIdx.x == 0) {
+        A.tot->n_prob = r_prob; A.tot->n_rows = r_row; A.tot->n_qe = r_qe; A.tot->s_tot = r_s; A.tot->f_tot = r_f;
+        A.tot->n_mk = r_mk; A.tot->cells = r_cells; A.tot->n_ok = r_ok;
+    }
+}
+
+/* ---------------------------------------------------------------------- */
+/* launch orders: per band class, problems by (band width ascending, length descending), every band width padded to
+ * whole waves (a wave must hold problems of ONE width: its band geometry is wave-uniform) */
+__global__ __launch_bounds__(256) void order_keys_kernel(spx_order_args O)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= O.n_prob) return;
+    const int bw = O.bw[p], L = O.L[p], nr = O.n_rows[p];
+    const int cls = band_class(2 * bw + 1);
+    const uint32_t lf = (uint32_t)L > 0xfffffu ? 0xfffffu : (uint32_t)L;
+    /* rows the backward kernel walks: L down to the first wanted row */
+    const int br = nr > 0 ? L - O.rows[O.row_off[p]] + 1 : 0;
+    const uint32_t lb = (uint32_t)br > 0xfffffu ? 0xfffffu : (uint32_t)br;
+    const uint64_t hi = ((uint64_t)cls << 30) | ((uint64_t)bw << 20);
+    O.key_f[p] = hi | (0xfffffu - lf);
+    O.key_b[p] = hi | (0xfffffu - lb);
+    O.val[p] = p;
+}
+
+__global__ __launch_bounds__(256) void order_bins_kernel(const uint64_t *__restrict__ keys, int32_t n, int32_t *__restrict__ bin_start,
+                                                         int32_t *__restrict__ bin_end)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = (uint32_t)(keys[i] >> 20);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 20) != b) bin_start[b] = i;
+    if (i == n - 1 || (uint32_t)(keys[i + 1] >> 20) != b) bin_end[b] = i + 1;
+}
+
+/* one workgroup: padded size of every (class, band) bin and its offset inside the class segment */
+__global__ __launch_bounds__(1024) void order_pad_kernel(const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end,
+                                                         int32_t *__restrict__ pad_base, int bwd)
+{
+    __shared__ int64_t lds[1024];
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) { /* the 1024 possible band widths of one class */
+        const int b = (cls << 10) + threadIdx.x;
+        const int ppw = 64 / (bwd ? class_lanes_bwd(cls) : class_lanes(cls));
+        const int cnt = bin_start[b] >= 0 ? bin_end[b] - bin_start[b] : 0;
+        const int64_t padded = (cnt + ppw - 1) / ppw * ppw;
+        int64_t tot;
+        pad_base[b] = (int32_t)block_exscan(padded, lds, tot);
+    }
+}
+
+__global__ __launch_bounds__(256) void order_scatter_kernel(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, int32_t n,
+                                                            const int32_t *__restrict__ bin_start, const int32_t *__restrict__ pad_base,
+                                                            spx_order_segs segs, int32_t *__restrict__ order)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = (uint32_t)(keys[i] >> 20);
+    const int cls = (int)(b >> 10);
+    const int64_t dst = segs.off[cls] + pad_base[b] + (i - bin_start[b]);
+    if (dst < segs.off[cls] + segs.cap[cls]) order[dst] = vals[i];
+}
+
+/* ---------------------------------------------------------------------- */
+extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *raw_seq, int64_t seq_words, hipStream_t st)
+{
+    if (A->n_slots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aln_count_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
+    if (seq_words > 0)
+        hipLaunchKernelGGL(recode_kernel, dim3((unsigned)((seq_words + 255) / 256)), dim3(256), 0, st, raw_seq,
+                           (uint32_t *)(A->code4_w + A->P.code_lead_bytes), seq_words, A->recs, A->n_slots, A->ast);
+    hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(1024), 0, st, *A);
+    hipLaunchKernelGGL(aln_build_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *base_out, int64_t *mk_base, hipStream_t st)
+{
+    if (A->n_dgroups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(group_arena_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A);
+    hipLaunchKernelGGL(scan_arena_kernel, dim3(1), dim3(1024), 0, st, *A);
+    hipLaunchKernelGGL(group_count_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A);
+    hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, st, *A, base_out, mk_base);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st)
+{
+    if (A->n_dgroups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(group_emit_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A, *E);
+    return hipGetLastError();
+}
+
+extern "C" size_t spx_order_temp_bytes(int32_t n_prob)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const int32_t *)nullptr,
+                                       (int32_t *)nullptr, n_prob > 0 ? n_prob : 1, 0, 34);
+    return bytes;
+}
+
+/* fills order_f / order_b (both pre-set to -1 by the caller's memset) */
+extern "C" hipError_t spx_prep_orders(const spx_order_args *O, const spx_order_segs *sf, const spx_order_segs *sb, hipStream_t st)
+{
+    const int32_t n = O->n_prob;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(order_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *O);
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t tb = O->temp_bytes;
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(O->temp, tb, pass ? O->key_b : O->key_f, O->key_sorted, O->val, O->val_sorted, n, 0, 34, st);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(O->bin_start, 0xff, sizeof(int32_t) * SPX_N_CLASSES * 1024, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(order_bins_kernel, dim3((n + 255) / 256), dim3(256), 0, st, O->key_sorted, n, O->bin_start, O->bin_end);
+        hipLaunchKernelGGL(order_pad_kernel, dim3(1), dim3(1024), 0, st, O->bin_start, O->bin_end, O->pad_base, pass);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, O->key_sorted, O->val_sorted, n, O->bin_start,
+                           O->pad_base, pass ? *sb : *sf, pass ? O->order_b : O->order_f);
+    }
+    return hipGetLastError();
+}

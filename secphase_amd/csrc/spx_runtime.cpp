@@ -25,6 +25,7 @@
 #include "../../include/spx.h"
 #include "spx_device.h"
 #include "spx_prep.h"
+#include "spx_prep_dev.h"
 
 struct spx_bedset;
 
@@ -33,6 +34,13 @@ extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_marke
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
                                       unsigned long long *out, hipStream_t st);
+extern "C" hipError_t spx_launch_results(const spx_dev_groups *Gd, const spx_group_info *info, const int32_t *rfe,
+                                         spx_group_out *out, hipStream_t st);
+extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *raw_seq, int64_t seq_words, hipStream_t st);
+extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *base_out, int64_t *mk_base, hipStream_t st);
+extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st);
+extern "C" size_t spx_order_temp_bytes(int32_t n_prob);
+extern "C" hipError_t spx_prep_orders(const spx_order_args *O, const spx_order_segs *sf, const spx_order_segs *sb, hipStream_t st);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
@@ -85,16 +93,67 @@ struct spx_ctx {
     uint8_t *d_ref4 = nullptr;
     int64_t ref_bytes = 0;
     spx::RefIndex ref;
+    void *d_refidx = nullptr;     /* device copy of the contig table + ambiguous-base index (spxl::RefView) */
+    spxl::RefView d_rv = {};
     double *d_tables = nullptr; /* qthr[102] | match[256] | mis[256] */
     /* device arenas of finished work lists are kept for the next one (hipMalloc of several GB costs ~0.2 s) */
     std::vector<std::pair<void *, size_t>> arena_cache;
+    std::vector<std::pair<void *, size_t>> pinned_cache; /* hipHostMalloc'ed staging buffers */
     std::mutex arena_mu;
-    /* a tiny private reference pool for spx_probaln_batch */
+    /* work-list preparation on the device: its own stream (it overlaps the DP kernels of the previous list), pools
+     * that only live during a preparation and are shared by all of them (prep_mu serialises preparations) */
+    hipStream_t prep_stream = nullptr;
+    std::mutex prep_mu;
+    struct DevBuf {
+        void *p = nullptr;
+        size_t cap = 0;
+    } pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort;
+    spx_prep_totals *d_tot = nullptr, *h_tot = nullptr; /* device / pinned host */
+    int32_t *d_bins = nullptr;                          /* 3 x SPX_N_CLASSES x 1024 */
 };
+
+/* grow-only device buffer; the caller holds prep_mu.  Kernels of an earlier preparation may still read the old
+ * allocation, so the stream is drained before it is released. */
+static int ensure_pool(spx_ctx *c, spx_ctx::DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return SPX_OK;
+    if (b.p) {
+        if (hipStreamSynchronize(c->prep_stream) != hipSuccess) return SPX_EHIP;
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 4 + (1u << 20);
+    if (hipMalloc(&b.p, want) != hipSuccess) { (void)hipGetLastError(); return SPX_ENOMEM; }
+    b.cap = want;
+    return SPX_OK;
+}
 
 struct spx_work {
     spx::HostBatch hb;
     int32_t n_groups_in = 0;
+    /* ---- device-prepared work lists: the staged records (part A, resident until the list is freed) ---- */
+    spx_ctx *owner = nullptr;
+    bool staged = false;        /* spx_stage has run: records are in HBM */
+    bool prepared = false;      /* spx_prepare_staged has run: the work list exists */
+    spx::Stage stage;
+    void *h_stage = nullptr;    /* pinned host copy of the staged buffer */
+    size_t h_stage_cap = 0;
+    void *in_arena = nullptr;   /* device: staged buffer | recoded SEQ | per-alignment / per-group state */
+    size_t in_cap = 0;
+    size_t o_code = 0, o_ast = 0, o_gc = 0, o_gab = 0, o_gao = 0, o_base = 0, o_mkb = 0;
+    spx_prep_args pa;
+    spx_prep_totals tot;
+    hipEvent_t ev_ready = nullptr; /* recorded on the preparation stream when the list may be launched */
+    int32_t n_dgroups = 0;      /* groups that passed the dispatch filter (device arrays have one entry each) */
+    std::vector<spx_group_info> info; /* pulled back by spx_collect */
+    spx_group_out *d_results = nullptr;
+    spx_group_info *d_info = nullptr;
+    int32_t *d_rfe = nullptr, *d_rfs = nullptr, *d_atid = nullptr, *d_mk_first = nullptr, *d_mk_ref_pos = nullptr;
+    int32_t *d_qe[5] = {};
+    int32_t *d_row_expect = nullptr;
+    int64_t n_rows_dev = 0, n_mk_dev = 0, n_prob_dev = 0;
+    bool mirrors_markers = false, mirrors_qe = false;
     void *arena = nullptr;
     size_t arena_bytes = 0, arena_cap = 0;
     spx_dev_batch cls_batch[SPX_N_CLASSES];
@@ -156,6 +215,10 @@ extern "C" int spx_create(int device, spx_ctx **out)
     spx_ctx *c = new spx_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&c->d_tot, sizeof(spx_prep_totals)));
+    HIPCHK(hipHostMalloc((void **)&c->h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&c->d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
     for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
     for (int i = 0; i < SPX_N_CLASSES; ++i) {
@@ -178,8 +241,16 @@ extern "C" void spx_destroy(spx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_ref4) (void)hipFree(c->d_ref4);
+    if (c->d_refidx) (void)hipFree(c->d_refidx);
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (auto &a : c->arena_cache) (void)hipFree(a.first);
+    for (auto &a : c->pinned_cache) (void)hipHostFree(a.first);
+    for (spx_ctx::DevBuf *b : {&c->pool_ops, &c->pool_conf, &c->pool_mm, &c->pool_garena, &c->pool_keys, &c->pool_sort})
+        if (b->p) (void)hipFree(b->p);
+    if (c->d_tot) (void)hipFree(c->d_tot);
+    if (c->h_tot) (void)hipHostFree(c->h_tot);
+    if (c->d_bins) (void)hipFree(c->d_bins);
+    if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
     for (int i = 0; i < 6; ++i)
         for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
             if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
@@ -196,14 +267,9 @@ extern "C" int spx_set_reference(spx_ctx *c, const spx_ref *ref)
     if (!c || !ref) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
     const int nc = ref->n_contigs;
-    c->ref.nib_off.assign(nc, 0);
-    c->ref.len.assign(nc, 0);
-    int64_t nib = spx::kRefLeadNibbles; /* leading pad: the kernels fetch codes up to a band width before a window */
-    for (int i = 0; i < nc; ++i) {
-        c->ref.nib_off[i] = nib;
-        c->ref.len[i] = ref->seq_off[i + 1] - ref->seq_off[i];
-        nib += (c->ref.len[i] + 1) & ~(int64_t)1; /* every contig starts on a byte boundary */
-    }
+    c->ref.build(ref);
+    int64_t nib = spx::kRefLeadNibbles;
+    for (int i = 0; i < nc; ++i) nib += (c->ref.len[i] + 1) & ~(int64_t)1;
     std::vector<uint8_t> packed((size_t)(nib / 2) + spx::kRefTailBytes, 0); /* slack: ... and past a window */
     unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::thread> th;
@@ -220,11 +286,27 @@ extern "C" int spx_set_reference(spx_ctx *c, const spx_ref *ref)
     };
     for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work, t);
     for (auto &t : th) t.join();
-    c->ref.index_ambiguous(ref);
     if (c->d_ref4) { (void)hipFree(c->d_ref4); c->d_ref4 = nullptr; }
     c->ref_bytes = (int64_t)packed.size();
     HIPCHK(hipMalloc((void **)&c->d_ref4, packed.size()));
     HIPCHK(hipMemcpy(c->d_ref4, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    { /* contig table + ambiguous-base index for the preparation kernels */
+        if (c->d_refidx) { (void)hipFree(c->d_refidx); c->d_refidx = nullptr; }
+        const size_t b0 = (size_t)nc * 8, b1 = (size_t)nc * 8, b2 = ((size_t)nc + 1) * 8, b3 = c->ref.npos.size() * 4 + 16;
+        HIPCHK(hipMalloc(&c->d_refidx, b0 + b1 + b2 + b3 + 64));
+        char *d = (char *)c->d_refidx;
+        if (nc) {
+            HIPCHK(hipMemcpy(d, c->ref.nib_off.data(), b0, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d + b0, c->ref.len.data(), b1, hipMemcpyHostToDevice));
+        }
+        HIPCHK(hipMemcpy(d + b0 + b1, c->ref.npos_off.data(), b2, hipMemcpyHostToDevice));
+        if (!c->ref.npos.empty()) HIPCHK(hipMemcpy(d + b0 + b1 + b2, c->ref.npos.data(), c->ref.npos.size() * 4, hipMemcpyHostToDevice));
+        c->d_rv.n_contigs = nc;
+        c->d_rv.nib_off = (const int64_t *)d;
+        c->d_rv.len = (const int64_t *)(d + b0);
+        c->d_rv.npos_off = (const int64_t *)(d + b0 + b1);
+        c->d_rv.npos = (const int32_t *)(d + b0 + b1 + b2);
+    }
     return SPX_OK;
 }
 
@@ -439,10 +521,79 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
     return SPX_OK;
 }
 
-/* several record batches (e.g. the blocks a reader thread hands over) become ONE work list; group g of
- * batch b is reported at index (groups of batches < b) + g */
-extern "C" int spx_prepare_many(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par,
-                                int host_threads, spx_work **out)
+/* ------------------------------------------------------------------ */
+/* device allocations of finished work lists are kept for the next one (hipMalloc of several GB costs ~0.2 s) */
+static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        int best = -1;
+        for (size_t i = 0; i < c->arena_cache.size(); ++i)
+            if (c->arena_cache[i].second >= bytes && (best < 0 || c->arena_cache[i].second < c->arena_cache[best].second))
+                best = (int)i;
+        if (best >= 0) {
+            void *p = c->arena_cache[best].first;
+            *cap = c->arena_cache[best].second;
+            c->arena_cache.erase(c->arena_cache.begin() + best);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    *cap = bytes + bytes / 8 + 4096; /* head room so that the next, slightly larger list fits */
+    if (hipMalloc(&p, *cap) != hipSuccess) {
+        (void)hipGetLastError();
+        /* give cached blocks back to the driver and try once more */
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        for (auto &a : c->arena_cache) (void)hipFree(a.first);
+        c->arena_cache.clear();
+        if (hipMalloc(&p, *cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    return p;
+}
+static void arena_put(spx_ctx *c, void *p, size_t cap)
+{
+    if (!p) return;
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        if (c->arena_cache.size() < 8) { c->arena_cache.emplace_back(p, cap); return; }
+    }
+    (void)hipFree(p);
+}
+static void *pinned_get(spx_ctx *c, size_t bytes, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        int best = -1;
+        for (size_t i = 0; i < c->pinned_cache.size(); ++i)
+            if (c->pinned_cache[i].second >= bytes && (best < 0 || c->pinned_cache[i].second < c->pinned_cache[best].second))
+                best = (int)i;
+        if (best >= 0) {
+            void *p = c->pinned_cache[best].first;
+            *cap = c->pinned_cache[best].second;
+            c->pinned_cache.erase(c->pinned_cache.begin() + best);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    *cap = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&p, *cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+static void pinned_put(spx_ctx *c, void *p, size_t cap)
+{
+    if (!p) return;
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        if (c->pinned_cache.size() < 4) { c->pinned_cache.emplace_back(p, cap); return; }
+    }
+    (void)hipHostFree(p);
+}
+
+/* Step 1 of a work list: dispatch filter + staging of the dispatched groups' records into pinned memory (host
+ * threads), one asynchronous copy into HBM.  Several record batches (e.g. the blocks a reader thread hands over) become
+ * ONE work list; group g of batch b is reported at index (groups of batches < b) + g. */
+extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par, int host_threads,
+                         spx_work **out)
 {
     if (!c || !bts || n_batches <= 0 || !par || !out) return fail(SPX_EINVAL, "NULL argument");
     if (!c->d_ref4) return fail(SPX_ENOREF, "spx_set_reference has not been called");
@@ -450,58 +601,303 @@ extern "C" int spx_prepare_many(spx_ctx *c, const spx_batch *const *bts, int32_t
     *out = nullptr;
     spx_work *w = new spx_work();
     memset(&w->st, 0, sizeof w->st);
+    memset(&w->pa, 0, sizeof w->pa);
+    memset(&w->tot, 0, sizeof w->tot);
     w->par = *par;
-    double t0 = now_s();
-    /* tasks of 16..256 groups (about four per thread, so that long reads do not leave threads idle), pulled by the
-     * worker threads, merged in file order */
-    struct Task { int b; int32_t g0, g1, base; };
-    std::vector<Task> tasks;
+    w->owner = c;
+    const double t0 = now_s();
     int nthr = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
-    nthr = std::max(1, std::min(nthr, 128));
-    int64_t n_all = 0;
-    for (int b = 0; b < n_batches; ++b) {
-        if (!bts[b]) { delete w; return fail(SPX_EINVAL, "NULL batch"); }
-        n_all += bts[b]->n_groups;
-    }
-    const int32_t tsize = (int32_t)std::max<int64_t>(16, std::min<int64_t>(256, n_all / (4 * (int64_t)nthr)));
-    int32_t base = 0;
-    for (int b = 0; b < n_batches; ++b) {
-        for (int32_t g = 0; g < bts[b]->n_groups; g += tsize)
-            tasks.push_back({b, g, std::min(bts[b]->n_groups, g + tsize), base});
-        base += bts[b]->n_groups;
-    }
-    w->n_groups_in = base;
-    nthr = std::min<int>(nthr, (int)std::max<size_t>(tasks.size(), 1));
-    const spx::RefIndex &ri = c->ref;
-    std::vector<spx::HostBatch> parts(tasks.size());
-    std::atomic<size_t> next(0);
-    auto run = [&]() {
-        for (;;) {
-            size_t t = next.fetch_add(1);
-            if (t >= tasks.size()) break;
-            const Task &k = tasks[t];
-            spx::prepare_groups(bts[k.b], ri, par, k.g0, k.g1, parts[t]);
-            for (int32_t &gi : parts[t].grp_index) gi += k.base;
-            for (int32_t &qb : parts[t].qe_batch) qb = k.b;
-        }
-    };
-    if (nthr == 1) run();
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthr; ++t) th.emplace_back(run);
-        for (auto &t : th) t.join();
-    }
-    const double t_par = now_s();
-    w->hb.assign_merged(parts, nthr);
-    w->st.prep_seconds = now_s() - t0;
-    if (timing_on()) fprintf(stderr, "[spx timing] prepare: %d threads, group logic %.3f s, merge %.3f s\n", nthr, t_par - t0, now_s() - t_par);
+    nthr = std::max(1, std::min(nthr, 64));
+    int rc = spx::stage_measure(bts, n_batches, nthr, w->stage);
+    if (rc) { delete w; return fail(rc, "invalid batch"); }
+    const spx::StageLayout &L = w->stage.lay;
+    w->n_groups_in = (int32_t)L.n_groups_in;
+    w->n_dgroups = (int32_t)L.n_dgroups;
+    w->hb.grp_error = w->stage.grp_error;
+    w->h_stage = pinned_get(c, L.bytes + 64, &w->h_stage_cap);
+    if (!w->h_stage) { delete w; return fail(SPX_ENOMEM, "pinned staging buffer"); }
+    spx::stage_copy(w->stage, (char *)w->h_stage, nthr);
+    const double t1 = now_s();
+    /* part A in HBM: staged records | recoded SEQ | per-alignment state | per-group counts and offsets */
+    Carver cv;
+    const size_t ns = (size_t)L.n_slots, ng = (size_t)L.n_dgroups;
+    const size_t o_in = cv.take<char>(L.bytes + 64);
+    w->o_code = cv.take<char>((size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes));
+    w->o_ast = cv.take<spxl::AlnState>(ns + 1);
+    w->o_gc = cv.take<spxl::GroupCount>(ng + 1);
+    w->o_gab = cv.take<int64_t>(ng + 1);
+    w->o_gao = cv.take<int64_t>(ng + 1);
+    w->o_base = cv.take<spxl::PlanBase>(ng + 1);
+    w->o_mkb = cv.take<int64_t>(ng + 2);
+    (void)o_in;
+    w->in_arena = arena_get(c, cv.off + 256, &w->in_cap);
+    if (!w->in_arena) { spx_work_free(c, w); return fail(SPX_ENOMEM, "device memory for the staged records"); }
+    char *base = (char *)w->in_arena;
+    HIPCHK(hipMemcpyAsync(base, w->h_stage, L.bytes, hipMemcpyHostToDevice, c->prep_stream));
+    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes), c->prep_stream));
+    w->st.prep_seconds = t1 - t0;
+    w->st.bytes_h2d = (int64_t)L.bytes;
     w->st.n_groups = w->n_groups_in;
-    w->st.n_dispatched = (int64_t)w->hb.grp_index.size();
-    w->st.n_problems = (int64_t)w->hb.L.size();
-    w->st.n_rows = (int64_t)w->hb.rows.size();
-    w->st.dp_cells = w->hb.dp_cells;
-    w->st.n_markers = (int64_t)w->hb.markers.size();
-    int rc = build_device_batch(c, w, false);
+    w->staged = true;
+    if (timing_on()) fprintf(stderr, "[spx timing] stage: %d threads, measure+copy %.3f s, %.1f MB\n", nthr, t1 - t0, L.bytes / 1e6);
+    *out = w;
+    return SPX_OK;
+}
+
+static void fill_prep_args(spx_ctx *c, spx_work *w)
+{
+    const spx::StageLayout &L = w->stage.lay;
+    char *base = (char *)w->in_arena;
+    spx_prep_args &A = w->pa;
+    memset(&A, 0, sizeof A);
+    A.n_slots = (int32_t)L.n_slots;
+    A.n_dgroups = (int32_t)L.n_dgroups;
+    A.recs = (const spxl::Rec *)(base + L.o_recs);
+    A.slot0 = (const int32_t *)(base + L.o_slot0);
+    A.ast = (spxl::AlnState *)(base + w->o_ast);
+    A.P.cigar = (const uint32_t *)(base + L.o_cigar);
+    A.P.qual = (const uint8_t *)(base + L.o_qual);
+    A.P.text = (const char *)(base + L.o_text);
+    A.P.code4 = (const uint8_t *)(base + w->o_code);
+    A.P.code_lead_bytes = spx::kCodeLeadBytes;
+    A.code4_w = (uint8_t *)(base + w->o_code);
+    A.P.ops = (spxl::Op *)c->pool_ops.p;
+    A.P.conf = (spxl::Blk *)c->pool_conf.p;
+    A.P.mm = (spxl::MM *)c->pool_mm.p;
+    A.rv = c->d_rv;
+    A.par = spx::logic_params(&w->par);
+    A.gc = (spxl::GroupCount *)(base + w->o_gc);
+    A.ga_bytes = (int64_t *)(base + w->o_gab);
+    A.ga_off = (int64_t *)(base + w->o_gao);
+    A.arena = (char *)c->pool_garena.p;
+    A.arena_cap = (int64_t)c->pool_garena.cap;
+    A.slack = 1;
+    A.tot = c->d_tot;
+}
+
+/* Step 2: the work list is built ON THE DEVICE from the staged records (spx_prep_kernels.hip).  One small copy of the
+ * sizes comes back in the middle (scratch and output arrays are carved to measure); everything else is asynchronous on
+ * the context's preparation stream.  May be called again on the same staged records (bench.py re-prepares resident
+ * batches: the timed step then covers the whole path, records -> decisions). */
+extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
+{
+    if (!c || !w || !w->staged) return fail(SPX_EINVAL, "work list has not been staged");
+    HIPCHK(hipSetDevice(c->device));
+    const spx::StageLayout &L = w->stage.lay;
+    const size_t ns = (size_t)L.n_slots, ng = (size_t)L.n_dgroups;
+    std::lock_guard<std::mutex> lk(c->prep_mu);
+    const double t0 = now_s();
+    if (w->arena) { /* re-preparation: the previous list of this work must have left the device */
+        HIPCHK(hipStreamSynchronize(c->stream));
+        arena_put(c, w->arena, w->arena_cap);
+        w->arena = nullptr;
+    }
+    w->prepared = false;
+    /* pools of the per-alignment pass, by bounds the host knows without touching the payload: an op per CIGAR op or
+     * per two tag characters; a confident block per CIGAR op; a mismatch per tag character */
+    const size_t ops_bound = (size_t)L.cigar_words + (size_t)L.text_bytes / 2 + 2 * ns + 16;
+    const size_t conf_bound = (size_t)L.cigar_words + 2 * ns + 16, mm_bound = (size_t)L.text_bytes + 16;
+    int rc;
+    if ((rc = ensure_pool(c, c->pool_ops, ops_bound * sizeof(spxl::Op))) || (rc = ensure_pool(c, c->pool_conf, conf_bound * sizeof(spxl::Blk))) ||
+        (rc = ensure_pool(c, c->pool_mm, mm_bound * sizeof(spxl::MM))))
+        return fail(rc, "device memory for the preparation pools");
+    if ((rc = ensure_pool(c, c->pool_garena, (size_t)(32u << 20) + ns * 4096))) return fail(rc, "device memory for the group scratch");
+    fill_prep_args(c, w);
+    spx_prep_args &A = w->pa;
+    A.ops_cap = (int64_t)ops_bound; A.conf_cap = (int64_t)conf_bound; A.mm_cap = (int64_t)mm_bound;
+    char *base = (char *)w->in_arena;
+    spxl::PlanBase *d_base = (spxl::PlanBase *)(base + w->o_base);
+    int64_t *d_mkb = (int64_t *)(base + w->o_mkb);
+    HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), c->prep_stream));
+    HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
+    HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, c->prep_stream));
+    for (int attempt = 0;; ++attempt) {
+        HIPCHK(spx_prep_phase2(&A, d_base, d_mkb, c->prep_stream));
+        HIPCHK(hipMemcpyAsync(c->h_tot, c->d_tot, sizeof(spx_prep_totals), hipMemcpyDeviceToHost, c->prep_stream));
+        HIPCHK(hipStreamSynchronize(c->prep_stream));
+        w->tot = *c->h_tot;
+        if (!w->tot.overflow) break;
+        if (attempt >= 6) return fail(SPX_ENOMEM, "group scratch keeps overflowing");
+        if (w->tot.overflow == 1) {
+            if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes + 4096))) return fail(rc, "device memory for the group scratch");
+            A.arena = (char *)c->pool_garena.p;
+            A.arena_cap = (int64_t)c->pool_garena.cap;
+        } else {
+            A.slack *= 4;
+            if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes * 4 + 4096))) return fail(rc, "device memory for the group scratch");
+            A.arena = (char *)c->pool_garena.p;
+            A.arena_cap = (int64_t)c->pool_garena.cap;
+        }
+        HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
+    }
+    const double t1 = now_s();
+    /* ---- part B: the work list, its scratch and its outputs, carved to measure ---- */
+    const spx_prep_totals &T = w->tot;
+    const size_t np = (size_t)T.n_prob, nr = (size_t)T.n_rows, nq = (size_t)T.n_qe, nm = (size_t)T.n_mk;
+    if (np > 0x7ffffff0u || nr > 0x7ffffff0u || nm > 0x7ffffff0u) return fail(SPX_EINVAL, "work list too large: stage fewer groups at a time");
+    spx_order_segs sf, sb;
+    size_t order_f_n = 0, order_b_n = 0;
+    w->main_cls = -1;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+        w->cls_cells[cls] = T.cls_cells[cls];
+        w->st.problems_per_class[cls] = T.cls_prob[cls];
+        w->cls_used[cls] = T.cls_prob[cls] > 0;
+        if (w->cls_used[cls] && (w->main_cls < 0 || w->cls_cells[cls] > w->cls_cells[w->main_cls])) w->main_cls = cls;
+        /* a class segment holds its problems plus, per band width that can occur in the class, less than one wave of padding */
+        const int ppw_f = 64 / spx::class_lanes(cls), ppw_b = 64 / spx::class_lanes_bwd(cls);
+        const int wmax = spx::class_slots(cls);
+        const size_t widths = (size_t)std::min(1024, wmax / 2 + 1);
+        sf.off[cls] = (int64_t)order_f_n;
+        sf.cap[cls] = T.cls_prob[cls] > 0 ? (int64_t)(((size_t)T.cls_prob[cls] + widths * ppw_f + 63) & ~(size_t)63) : 0;
+        order_f_n += (size_t)sf.cap[cls];
+        sb.off[cls] = (int64_t)order_b_n;
+        sb.cap[cls] = T.cls_prob[cls] > 0 ? (int64_t)(((size_t)T.cls_prob[cls] + widths * ppw_b + 63) & ~(size_t)63) : 0;
+        order_b_n += (size_t)sb.cap[cls];
+    }
+    Carver cv;
+    const size_t o_ref_nib = cv.take<int64_t>(np), o_qry_nib = cv.take<int64_t>(np), o_L = cv.take<int32_t>(np), o_R = cv.take<int32_t>(np),
+                 o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N), o_row_off = cv.take<int32_t>(np),
+                 o_n_rows = cv.take<int32_t>(np), o_s_off = cv.take<int64_t>(np), o_fs_off = cv.take<int64_t>(np),
+                 o_prob_slots = cv.take<int32_t>(np), o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr),
+                 o_rawq = cv.take<uint8_t>(nr + 16), o_row_prob = cv.take<int32_t>(nr), o_qe = cv.take<int32_t>(5 * nq + 4),
+                 o_order_f = cv.take<int32_t>(order_f_n + 64), o_order_b = cv.take<int32_t>(order_b_n + 64),
+                 o_mk_first = cv.take<int32_t>(ng + 2), o_markers = cv.take<spx_dev_marker>(nm + 1), o_mkref = cv.take<int32_t>(nm + 1),
+                 o_naln = cv.take<uint8_t>(ng + 16), o_sec = cv.take<uint16_t>(ng + 8), o_rfe = cv.take<int32_t>(ng * 10 + 10),
+                 o_rfs = cv.take<int32_t>(ng * 10 + 10), o_atid = cv.take<int32_t>(ng * 10 + 10), o_info = cv.take<spx_group_info>(ng + 1);
+    const size_t in_bytes = cv.off;
+    const size_t o_sinv = cv.take<double>((size_t)T.s_tot + 16), o_fsave = cv.take<double>((size_t)T.f_tot + 16), o_bq = cv.take<uint8_t>(nr + 16),
+                 o_posmin = cv.take<uint8_t>(nm + 16), o_score = cv.take<double>(ng * 10 + 10), o_prim = cv.take<uint8_t>(ng + 16),
+                 o_max = cv.take<uint8_t>(ng + 16), o_pass = cv.take<uint8_t>(ng + 16), o_tie = cv.take<uint16_t>(ng + 8),
+                 o_results = cv.take<spx_group_out>(ng + 1);
+    (void)in_bytes;
+    w->arena_bytes = cv.off + 256;
+    w->arena = arena_get(c, w->arena_bytes, &w->arena_cap);
+    if (!w->arena) return fail(SPX_ENOMEM, "device memory for the work list");
+    char *B0 = (char *)w->arena;
+    /* temporaries of the launch-order sort (context pools) */
+    const size_t sort_tmp = spx_order_temp_bytes((int32_t)np);
+    if ((rc = ensure_pool(c, c->pool_keys, (np + 16) * (3 * 8 + 2 * 4))) || (rc = ensure_pool(c, c->pool_sort, sort_tmp + 256)))
+        return fail(rc, "device memory for the launch-order sort");
+    spx_emit_args E;
+    memset(&E, 0, sizeof E);
+    E.base = d_base;
+    E.mk_base = d_mkb;
+    E.out.ref_nib = (int64_t *)(B0 + o_ref_nib); E.out.qry_nib = (int64_t *)(B0 + o_qry_nib);
+    E.out.L = (int32_t *)(B0 + o_L); E.out.R = (int32_t *)(B0 + o_R); E.out.bw = (int32_t *)(B0 + o_bw);
+    E.out.row_off = (int32_t *)(B0 + o_row_off); E.out.n_rows = (int32_t *)(B0 + o_n_rows); E.out.prob_slots = (int32_t *)(B0 + o_prob_slots);
+    E.out.hmm = (double *)(B0 + o_hmm); E.out.s_off = (int64_t *)(B0 + o_s_off); E.out.fsave_off = (int64_t *)(B0 + o_fs_off);
+    E.out.rows = (int32_t *)(B0 + o_rows); E.out.row_expect = (int32_t *)(B0 + o_expect); E.out.row_prob = (int32_t *)(B0 + o_row_prob);
+    E.out.row_rawq = (uint8_t *)(B0 + o_rawq);
+    int32_t *qe = (int32_t *)(B0 + o_qe);
+    E.out.qe_rec = qe; E.out.qe_pos = qe + nq; E.out.qe_len = qe + 2 * nq; E.out.qe_row0 = qe + 3 * nq; E.out.qe_batch = qe + 4 * nq;
+    for (int k = 0; k < 5; ++k) w->d_qe[k] = qe + (size_t)k * nq;
+    E.markers = (spx_dev_marker *)(B0 + o_markers);
+    E.mk_ref_pos = (int32_t *)(B0 + o_mkref);
+    E.mk_first = (int32_t *)(B0 + o_mk_first);
+    E.n_aln = (uint8_t *)(B0 + o_naln);
+    E.sec_mask = (uint16_t *)(B0 + o_sec);
+    E.rfe = (int32_t *)(B0 + o_rfe); E.rfs = (int32_t *)(B0 + o_rfs); E.atid = (int32_t *)(B0 + o_atid);
+    E.info = (spx_group_info *)(B0 + o_info);
+    HIPCHK(hipMemsetAsync(B0 + o_mk_first, 0, (ng + 2) * 4, c->prep_stream));
+    HIPCHK(spx_prep_emit(&A, &E, c->prep_stream));
+    /* launch orders */
+    HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (order_f_n + 64) * 4, c->prep_stream));
+    HIPCHK(hipMemsetAsync(B0 + o_order_b, 0xff, (order_b_n + 64) * 4, c->prep_stream));
+    if (np) {
+        spx_order_args O;
+        memset(&O, 0, sizeof O);
+        O.n_prob = (int32_t)np;
+        O.bw = E.out.bw; O.L = E.out.L; O.n_rows = E.out.n_rows; O.row_off = E.out.row_off; O.rows = E.out.rows;
+        char *kp = (char *)c->pool_keys.p;
+        O.key_f = (uint64_t *)kp; O.key_b = O.key_f + (np + 2); O.key_sorted = O.key_b + (np + 2);
+        O.val = (int32_t *)(O.key_sorted + (np + 2)); O.val_sorted = O.val + (np + 2);
+        O.bin_start = c->d_bins; O.bin_end = c->d_bins + SPX_N_CLASSES * 1024; O.pad_base = c->d_bins + 2 * SPX_N_CLASSES * 1024;
+        O.temp = c->pool_sort.p; O.temp_bytes = sort_tmp;
+        O.order_f = (int32_t *)(B0 + o_order_f); O.order_b = (int32_t *)(B0 + o_order_b);
+        HIPCHK(spx_prep_orders(&O, &sf, &sb, c->prep_stream));
+    }
+    if (!w->ev_ready) HIPCHK(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(w->ev_ready, c->prep_stream));
+    /* ---- kernel argument blocks ---- */
+    w->d_bq = (uint8_t *)(B0 + o_bq);
+    w->d_posmin = (uint8_t *)(B0 + o_posmin);
+    w->d_state = nullptr;
+    w->d_q = nullptr;
+    w->d_score = (double *)(B0 + o_score);
+    w->d_prim = (uint8_t *)(B0 + o_prim);
+    w->d_max = (uint8_t *)(B0 + o_max);
+    w->d_pass = (uint8_t *)(B0 + o_pass);
+    w->d_tie = (uint16_t *)(B0 + o_tie);
+    w->d_grp_index = (int32_t *)(base + L.o_gidx);
+    w->d_results = (spx_group_out *)(B0 + o_results);
+    w->d_info = E.info;
+    w->d_rfe = E.rfe; w->d_rfs = E.rfs; w->d_atid = E.atid; w->d_mk_first = E.mk_first; w->d_mk_ref_pos = E.mk_ref_pos;
+    w->d_row_expect = E.out.row_expect;
+    w->n_rows_dev = (int64_t)nr; w->n_mk_dev = (int64_t)nm; w->n_prob_dev = (int64_t)np;
+    w->mirrors_markers = w->mirrors_qe = false;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+        spx_dev_batch &B = w->cls_batch[cls];
+        memset(&B, 0, sizeof B);
+        B.order = (const int32_t *)(B0 + o_order_f) + sf.off[cls];
+        B.order_bwd = (const int32_t *)(B0 + o_order_b) + sb.off[cls];
+        B.n_order = (int32_t)sf.cap[cls];
+        B.n_order_bwd = (int32_t)sb.cap[cls];
+        B.ref_nib = E.out.ref_nib; B.qry_nib = E.out.qry_nib; B.L = E.out.L; B.R = E.out.R; B.bw = E.out.bw; B.hmm = E.out.hmm;
+        B.row_off = E.out.row_off; B.n_rows = E.out.n_rows; B.s_off = E.out.s_off;
+        B.ref4 = c->d_ref4;
+        B.qry4 = A.P.code4;
+        B.rows = E.out.rows; B.row_expect = E.out.row_expect; B.row_rawq = E.out.row_rawq;
+        B.sinv = (double *)(B0 + o_sinv);
+        B.s_raw = nullptr;
+        B.fsave = (double *)(B0 + o_fsave);
+        B.row_prob = E.out.row_prob; B.prob_slots = E.out.prob_slots;
+        B.fsave_stride = 2 * spx::class_slots(cls);
+        B.fsave_off = E.out.fsave_off;
+        B.out_bq = w->d_bq; B.out_state = nullptr; B.out_q = nullptr;
+        B.qthr = c->d_tables;
+    }
+    spx_dev_groups &G = w->dg;
+    memset(&G, 0, sizeof G);
+    G.n_groups = (int32_t)ng;
+    G.mk_first = E.mk_first;
+    G.markers = E.markers;
+    G.n_aln = E.n_aln;
+    G.sec_mask = E.sec_mask;
+    G.out_bq = w->d_bq;
+    G.match_tbl = c->d_tables + 102;
+    G.mis_tbl = c->d_tables + 102 + 256;
+    G.min_q = w->par.min_q;
+    G.prim_margin = w->par.prim_margin_score;
+    G.min_score = (double)w->par.min_score;
+    G.score = w->d_score;
+    G.prim_idx = w->d_prim;
+    G.max_idx = w->d_max;
+    G.tie_mask = w->d_tie;
+    G.pass = w->d_pass;
+    w->have_groups = ng > 0;
+    w->st.n_dispatched = (int64_t)T.n_ok;
+    w->st.n_problems = (int64_t)np;
+    w->st.n_rows = (int64_t)nr;
+    w->st.dp_cells = T.cells;
+    w->st.n_markers = (int64_t)nm;
+    w->st.h2d_seconds = 0;
+    w->prepared = true;
+    w->launched = false;
+    w->launch_ids.clear();
+    if (timing_on())
+        fprintf(stderr, "[spx timing] device prepare: counts %.3f s, carve+emit+orders enqueued %.3f s; %zu problems, %zu rows, list %.2f GB\n",
+                t1 - t0, now_s() - t1, np, nr, w->arena_bytes / 1e9);
+    return SPX_OK;
+}
+
+extern "C" int spx_prepare_many(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par,
+                                int host_threads, spx_work **out)
+{
+    if (!out) return fail(SPX_EINVAL, "NULL argument");
+    spx_work *w = nullptr;
+    int rc = spx_stage(c, bts, n_batches, par, host_threads, &w);
+    if (rc) return rc;
+    rc = spx_prepare_staged(c, w);
     if (rc) { spx_work_free(c, w); return rc; }
     *out = w;
     return SPX_OK;
@@ -517,6 +913,8 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
 {
     if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
+    if (w->staged && !w->prepared) return fail(SPX_EINVAL, "work list has been staged but not prepared");
+    if (w->ev_ready) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_ready, 0)); /* the list is built on the preparation stream */
     hipEvent_t *ev = c->evr[c->n_launch % spx_ctx::SPX_EV_RING];
     w->launch_ids.push_back(c->n_launch);
     if (w->launch_ids.size() > (size_t)spx_ctx::SPX_EV_RING) w->launch_ids.erase(w->launch_ids.begin());
@@ -545,10 +943,15 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     {
         int64_t narrow = 0, wide = 0;
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
-        HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)w->hb.rows.size(), wide > narrow, c->stream));
+        const int64_t nrows = w->staged ? w->n_rows_dev : (int64_t)w->hb.rows.size();
+        HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)nrows, wide > narrow, c->stream));
     }
     HIPCHK(hipEventRecord(ev[1], c->stream));
-    if (w->have_groups) HIPCHK(spx_launch_score(&w->dg, (int32_t)w->hb.markers.size(), w->d_posmin, c->stream));
+    if (w->have_groups) {
+        const int64_t nmk = w->staged ? w->n_mk_dev : (int64_t)w->hb.markers.size();
+        HIPCHK(spx_launch_score(&w->dg, (int32_t)nmk, w->d_posmin, c->stream));
+        if (w->staged) HIPCHK(spx_launch_results(&w->dg, w->d_info, w->d_rfe, w->d_results, c->stream));
+    }
     HIPCHK(hipEventRecord(ev[2], c->stream));
     w->launched = true;
     return SPX_OK;
@@ -557,10 +960,11 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
 extern "C" int spx_pack_decisions(spx_ctx *c, spx_work *w, int32_t group_base, void *device_out, int64_t capacity)
 {
     if (!c || !w || !device_out) return fail(SPX_EINVAL, "NULL argument");
-    if (capacity < (int64_t)w->hb.grp_index.size()) return fail(SPX_EINVAL, "decision buffer too small");
+    const int64_t ng = w->staged ? (int64_t)w->n_dgroups : (int64_t)w->hb.grp_index.size();
+    if (capacity < ng) return fail(SPX_EINVAL, "decision buffer too small");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(spx_launch_pack(&w->dg, w->d_grp_index, group_base, (unsigned long long *)device_out, c->stream));
-    return (int)w->hb.grp_index.size();
+    return (int)ng;
 }
 
 extern "C" int spx_sync(spx_ctx *c)
@@ -615,6 +1019,32 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         }
         w->st.kernel_seconds = (w->st.baq_kernel_ms + w->st.score_kernel_ms) * 1e-3;
     }
+    if (w->staged) {
+        /* device-prepared list: one packed record per dispatched group (results_kernel), one copy */
+        const size_t ng = (size_t)w->n_dgroups;
+        double t0 = now_s();
+        size_t cap = 0;
+        spx_group_out *h = ng ? (spx_group_out *)pinned_get(c, ng * sizeof(spx_group_out), &cap) : nullptr;
+        if (ng && !h) return fail(SPX_ENOMEM, "pinned result buffer");
+        if (ng) {
+            hipError_t e = hipMemcpyAsync(h, w->d_results, ng * sizeof(spx_group_out), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { pinned_put(c, h, cap); return fail(SPX_EHIP, std::string("result copy: ") + hipGetErrorString(e)); }
+        }
+        w->st.d2h_seconds = now_s() - t0;
+        w->st.bytes_d2h = (int64_t)(ng * sizeof(spx_group_out));
+        for (int32_t g = 0; g < w->n_groups_in; ++g) {
+            memset(&out[g], 0, sizeof out[g]);
+            out[g].prim_idx = out[g].max_idx = out[g].best_idx = -1;
+        }
+        for (size_t k = 0; k < ng; ++k) {
+            const int32_t g = w->stage.grp_index[k];
+            out[g] = h[k];
+            if (h[k].n_aln < 0) w->hb.grp_error[(size_t)g] = h[k].n_aln;
+        }
+        pinned_put(c, h, cap);
+        return SPX_OK;
+    }
     const size_t ng = w->hb.grp_index.size();
     std::vector<double> score(ng * 10);
     std::vector<uint8_t> prim(ng), mx(ng), pass(ng);
@@ -626,9 +1056,6 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         HIPCHK(hipMemcpy(mx.data(), w->d_max, ng, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(pass.data(), w->d_pass, ng, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tie.data(), w->d_tie, ng * sizeof(uint16_t), hipMemcpyDeviceToHost));
-        w->posmin_host.resize(w->hb.markers.size());
-        if (!w->posmin_host.empty())
-            HIPCHK(hipMemcpy(w->posmin_host.data(), w->d_posmin, w->posmin_host.size(), hipMemcpyDeviceToHost));
     }
     w->st.d2h_seconds = now_s() - t0;
     w->st.bytes_d2h = (int64_t)(ng * (80 + 5));
@@ -653,6 +1080,56 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
     return SPX_OK;
 }
 
+/* host mirrors of a device-prepared list, pulled on demand: the per-group / per-marker arrays the BED bookkeeping
+ * reads, and the quality edits of an all-rows list */
+static int pull_marker_mirrors(spx_ctx *c, spx_work *w)
+{
+    if (!w->staged || w->mirrors_markers) return SPX_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    spx::HostBatch &hb = w->hb;
+    const size_t ng = (size_t)w->n_dgroups, nm = (size_t)w->n_mk_dev;
+    hb.grp_index = w->stage.grp_index;
+    hb.rfe.assign(ng * 10, 0); hb.rfs.assign(ng * 10, 0); hb.atid.assign(ng * 10, -1);
+    hb.mk_first.assign(ng + 1, 0); hb.mk_ref_pos.assign(nm, 0); hb.n_aln.assign(ng, 0);
+    w->posmin_host.assign(nm, 0);
+    std::vector<spx_group_info> info(ng);
+    if (ng) {
+        HIPCHK(hipMemcpy(hb.rfe.data(), w->d_rfe, ng * 40, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.rfs.data(), w->d_rfs, ng * 40, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.atid.data(), w->d_atid, ng * 40, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.mk_first.data(), w->d_mk_first, (ng + 1) * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(info.data(), w->d_info, ng * sizeof(spx_group_info), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < ng; ++k) hb.n_aln[k] = (uint8_t)(info[k].err ? 0 : info[k].n_aln);
+    }
+    if (nm) {
+        HIPCHK(hipMemcpy(hb.mk_ref_pos.data(), w->d_mk_ref_pos, nm * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(w->posmin_host.data(), w->d_posmin, nm, hipMemcpyDeviceToHost));
+    }
+    w->mirrors_markers = true;
+    return SPX_OK;
+}
+
+static int pull_qe_mirrors(spx_ctx *c, spx_work *w)
+{
+    if (!w->staged || w->mirrors_qe) return SPX_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    spx::HostBatch &hb = w->hb;
+    const size_t nq = (size_t)w->tot.n_qe, nr = (size_t)w->n_rows_dev;
+    hb.qe_rec.assign(nq, 0); hb.qe_pos.assign(nq, 0); hb.qe_len.assign(nq, 0); hb.qe_row0.assign(nq, 0); hb.qe_batch.assign(nq, 0);
+    hb.row_expect.assign(nr, 0);
+    hb.rows.assign(nr, 0); /* only its size is consulted */
+    if (nq) {
+        HIPCHK(hipMemcpy(hb.qe_rec.data(), w->d_qe[0], nq * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.qe_pos.data(), w->d_qe[1], nq * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.qe_len.data(), w->d_qe[2], nq * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.qe_row0.data(), w->d_qe[3], nq * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.qe_batch.data(), w->d_qe[4], nq * 4, hipMemcpyDeviceToHost));
+    }
+    if (nr) HIPCHK(hipMemcpy(hb.row_expect.data(), w->d_row_expect, nr * 4, hipMemcpyDeviceToHost));
+    w->mirrors_qe = true;
+    return SPX_OK;
+}
+
 /* the quality array the reference would hand to sam_write1 (secphase.c:182-189): replays calc_local_baq's
  * writes (ptMarker.c:706,759,763) with the BAQ values the kernels produced */
 extern "C" int spx_apply_quals(spx_ctx *c, spx_work *w, int32_t batch_index, const spx_batch *bt, uint8_t *qual)
@@ -662,6 +1139,7 @@ extern "C" int spx_apply_quals(spx_ctx *c, spx_work *w, int32_t batch_index, con
     if (!w->launched) return fail(SPX_EINVAL, "work list has not been launched");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    { int rc = pull_qe_mirrors(c, w); if (rc) return rc; }
     const spx::HostBatch &hb = w->hb;
     if (w->bq_host.size() != hb.rows.size()) {
         w->bq_host.resize(hb.rows.size());
@@ -693,15 +1171,14 @@ extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
 {
     if (!w) return;
     if (c) (void)hipSetDevice(c->device);
-    if (w->arena) {
-        bool kept = false;
-        if (c) {
-            (void)hipStreamSynchronize(c->stream); /* nothing of this work list may still be running */
-            std::lock_guard<std::mutex> lk(c->arena_mu);
-            if (c->arena_cache.size() < 3) { c->arena_cache.emplace_back(w->arena, w->arena_cap); kept = true; }
-        }
-        if (!kept) (void)hipFree(w->arena);
+    if (c && (w->arena || w->in_arena)) {
+        (void)hipStreamSynchronize(c->prep_stream); /* nothing of this work list may still be running */
+        (void)hipStreamSynchronize(c->stream);
     }
+    if (w->arena) arena_put(c, w->arena, w->arena_cap);
+    if (w->in_arena) arena_put(c, w->in_arena, w->in_cap);
+    if (w->h_stage) pinned_put(c, w->h_stage, w->h_stage_cap);
+    if (w->ev_ready) (void)hipEventDestroy(w->ev_ready);
     delete w;
 }
 
@@ -785,8 +1262,13 @@ extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const s
                                   spx_bedset *modified_blocks, spx_bedset *marker_blocks)
 {
     if (!w || !ref || !out) return fail(SPX_EINVAL, "NULL argument");
+    if (w->staged) {
+        if (!w->owner) return fail(SPX_EINVAL, "work list has no context");
+        int rc = pull_marker_mirrors(w->owner, const_cast<spx_work *>(w));
+        if (rc) return rc;
+    }
     const spx::HostBatch &hb = w->hb;
-    if (marker_blocks && w->posmin_host.size() != hb.markers.size()) return fail(SPX_EINVAL, "spx_collect has not run");
+    if (marker_blocks && !w->staged && w->posmin_host.size() != hb.markers.size()) return fail(SPX_EINVAL, "spx_collect has not run");
     int n = 0;
     for (size_t k = 0; k < hb.grp_index.size(); ++k) {
         const spx_group_out &o = out[hb.grp_index[k]];
@@ -800,6 +1282,7 @@ extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const s
             if (modified_blocks) spx_bedset_add(modified_blocks, contig, hb.rfs[k * 10 + a], hb.rfe[k * 10 + a], 1);
             if (!marker_blocks) continue;
             const int na = hb.n_aln[k];
+            if (na <= 0) continue;
             for (int32_t m = hb.mk_first[k]; m < hb.mk_first[k + 1]; m += na) {
                 if (w->posmin_host[m] <= w->par.min_q) continue; /* position removed by filter_lowq_markers */
                 const int32_t rp = hb.mk_ref_pos[m + a];
@@ -850,7 +1333,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
     memset(&w->st, 0, sizeof w->st);
     memset(&w->par, 0, sizeof w->par);
     spx::HostBatch &hb = w->hb;
-    hb.clear();
+    hb = spx::HostBatch();
     hb.mk_first.push_back(0);
     /* private reference pool: the problems' own ref windows */
     std::vector<uint8_t> ref4;
@@ -1011,16 +1494,82 @@ extern "C" int spx_plan_create(const spx_ref *ref, const spx_batch *bt, const sp
 {
     if (!ref || !bt || !par || !out) return fail(SPX_EINVAL, "NULL argument");
     spx::RefIndex ri;
-    int64_t nib = spx::kRefLeadNibbles;
-    for (int i = 0; i < ref->n_contigs; ++i) {
-        ri.nib_off.push_back(nib);
-        ri.len.push_back(ref->seq_off[i + 1] - ref->seq_off[i]);
-        nib += (ri.len[i] + 1) & ~(int64_t)1;
-    }
-    ri.index_ambiguous(ref);
+    ri.build(ref);
     spx_plan *p = new spx_plan();
-    spx::prepare_groups(bt, ri, par, 0, bt->n_groups, p->hb);
+    int nthr = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int rc = spx::host_plan(&bt, 1, ri, par, nthr, p->hb);
+    if (rc) { delete p; return fail(rc, "host plan failed"); }
     for (const spx_dev_marker &m : p->hb.markers) {
+        p->mk_row.push_back(m.row);
+        p->mk_qfix.push_back(m.qfix);
+        p->mk_is_match.push_back(m.is_match);
+        p->mk_aln.push_back(m.aln);
+        p->mk_fop.push_back(m.first_of_pos);
+    }
+    *out = p;
+    return SPX_OK;
+}
+
+/* diagnostics: the work list the DEVICE built, copied back in the shape of a host plan, so that a test can compare
+ * the two field by field (groups with an error are left out, as in the host plan) */
+extern "C" int spx_work_export(spx_ctx *c, spx_work *w, spx_plan **out)
+{
+    if (!c || !w || !out) return fail(SPX_EINVAL, "NULL argument");
+    if (!w->staged || !w->prepared) return fail(SPX_EINVAL, "not a device-prepared work list");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->prep_stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    spx_plan *p = new spx_plan();
+    spx::HostBatch &hb = p->hb;
+    const size_t np = (size_t)w->n_prob_dev, nr = (size_t)w->n_rows_dev, nm = (size_t)w->n_mk_dev, ng = (size_t)w->n_dgroups,
+                 nq = (size_t)w->tot.n_qe;
+    const spx_dev_batch &B = w->cls_batch[0];
+    auto pull = [&](auto &vec, const void *src, size_t n) -> bool {
+        vec.resize(n);
+        return n == 0 || hipMemcpy(vec.data(), src, n * sizeof(vec[0]), hipMemcpyDeviceToHost) == hipSuccess;
+    };
+    bool ok = pull(hb.ref_nib, B.ref_nib, np) && pull(hb.qry_nib, B.qry_nib, np) && pull(hb.L, B.L, np) && pull(hb.R, B.R, np) &&
+              pull(hb.bw, B.bw, np) && pull(hb.row_off, B.row_off, np) && pull(hb.n_rows, B.n_rows, np) && pull(hb.hmm, B.hmm, np * SPX_H_N) &&
+              pull(hb.rows, B.rows, nr) && pull(hb.row_expect, B.row_expect, nr) && pull(hb.row_rawq, B.row_rawq, nr) &&
+              pull(hb.qe_rec, w->d_qe[0], nq) && pull(hb.qe_pos, w->d_qe[1], nq) && pull(hb.qe_len, w->d_qe[2], nq) &&
+              pull(hb.qe_row0, w->d_qe[3], nq) && pull(hb.qe_batch, w->d_qe[4], nq);
+    const spx::StageLayout &L = w->stage.lay;
+    ok = ok && pull(hb.qry4, (const char *)w->in_arena + w->o_code, (size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes));
+    hb.qry_nibbles = (int64_t)hb.qry4.size() * 2;
+    std::vector<spx_dev_marker> mk;
+    std::vector<int32_t> mkref, mkfirst, rfe, rfs, atid;
+    std::vector<uint8_t> naln;
+    std::vector<uint16_t> sec;
+    std::vector<spx_group_info> info;
+    ok = ok && pull(mk, w->dg.markers, nm) && pull(mkref, w->d_mk_ref_pos, nm) && pull(mkfirst, w->d_mk_first, ng + 1) &&
+         pull(rfe, w->d_rfe, ng * 10) && pull(rfs, w->d_rfs, ng * 10) && pull(atid, w->d_atid, ng * 10) && pull(naln, w->dg.n_aln, ng) &&
+         pull(sec, w->dg.sec_mask, ng) && pull(info, w->d_info, ng);
+    if (!ok) { delete p; return fail(SPX_EHIP, "copy back failed"); }
+    /* reference window of a problem from its nibble address */
+    hb.ref_tid.assign(np, -1);
+    hb.ref_rfs.assign(np, 0);
+    for (size_t q = 0; q < np; ++q)
+        for (size_t t = 0; t < c->ref.nib_off.size(); ++t)
+            if (hb.ref_nib[q] >= c->ref.nib_off[t] && hb.ref_nib[q] < c->ref.nib_off[t] + c->ref.len[t]) {
+                hb.ref_tid[q] = (int32_t)t;
+                hb.ref_rfs[q] = (int32_t)(hb.ref_nib[q] - c->ref.nib_off[t]);
+                break;
+            }
+    hb.grp_error = w->stage.grp_error;
+    hb.mk_first.assign(1, 0);
+    for (size_t k = 0; k < ng; ++k) {
+        if (info[k].err) { hb.grp_error[(size_t)w->stage.grp_index[k]] = info[k].err; continue; }
+        hb.grp_index.push_back(w->stage.grp_index[k]);
+        for (int32_t m = mkfirst[k]; m < mkfirst[k + 1]; ++m) { hb.markers.push_back(mk[(size_t)m]); hb.mk_ref_pos.push_back(mkref[(size_t)m]); }
+        hb.mk_first.push_back((int32_t)hb.markers.size());
+        hb.n_aln.push_back(naln[k]);
+        hb.sec_mask.push_back(sec[k]);
+        for (int i = 0; i < 10; ++i) { hb.rfe.push_back(rfe[k * 10 + i]); hb.rfs.push_back(rfs[k * 10 + i]); hb.atid.push_back(atid[k * 10 + i]); }
+        hb.grp_problems.push_back(info[k].n_prob);
+        hb.grp_cells.push_back(info[k].cells);
+        hb.dp_cells += info[k].cells;
+    }
+    for (const spx_dev_marker &m : hb.markers) {
         p->mk_row.push_back(m.row);
         p->mk_qfix.push_back(m.qfix);
         p->mk_is_match.push_back(m.is_match);

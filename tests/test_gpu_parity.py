@@ -174,6 +174,66 @@ def test_probaln_posteriors_in_mixed_waves(ctx):
         assert np.array_equal(zM, oM) and np.array_equal(zI, oI), "z differs, " + what
 
 
+def _plans_equal(dev, host, n_input_groups):
+    """every array of the work list the DEVICE built against the host plan (same spx_logic.h source run on the CPU,
+    itself checked against the oracle in tests/test_host_plan.py), bit for bit"""
+    a, b = dev.view, host.view
+    for f in ("n_problems", "n_rows", "n_groups", "n_markers", "n_qedits"):
+        assert getattr(a, f) == getattr(b, f), (f, getattr(a, f), getattr(b, f))
+
+    def arr(v, name, n, dt=None):
+        p = getattr(v, name)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0)
+
+    np_, nr, ng, nm, nq = a.n_problems, a.n_rows, a.n_groups, a.n_markers, a.n_qedits
+    for name, n in (("L", np_), ("R", np_), ("bw", np_), ("ref_tid", np_), ("ref_rfs", np_), ("qry_nib", np_), ("row_off", np_),
+                    ("n_rows_of", np_), ("rows", nr), ("row_expect", nr), ("row_rawq", nr), ("grp_index", ng),
+                    ("mk_first", ng + 1), ("mk_row", nm), ("mk_qfix", nm), ("mk_is_match", nm), ("mk_aln", nm),
+                    ("mk_first_of_pos", nm), ("n_aln", ng), ("sec_mask", ng), ("rfe", ng * 10), ("grp_error", n_input_groups),
+                    ("qe_rec", nq), ("qe_pos", nq), ("qe_len", nq), ("qe_row0", nq)):
+        x, y = arr(a, name, n), arr(b, name, n)
+        assert np.array_equal(x, y), (name, np.flatnonzero(x != y)[:5])
+    ha, hb_ = arr(a, "hmm", np_ * 16), arr(b, "hmm", np_ * 16)
+    assert np.array_equal(ha.view(np.uint64), hb_.view(np.uint64)), "HMM constants differ"
+    from common import nibbles
+    for p in range(0, np_, max(1, np_ // 200)):
+        assert np.array_equal(nibbles(a.qry4, a.qry_nib[p], a.L[p]), nibbles(b.qry4, b.qry_nib[p], b.L[p])), p
+
+
+def test_device_work_list_equals_host_plan(ctx):
+    """the preparation kernels (spx_prep_kernels.hip) against the host plan: HiFi, ONT, clips + shuffled records +
+    inverted paralogs + ambiguous bases, MD-only records, mixed lengths, all-rows lists, odd parameters"""
+    import copy
+    cases = [
+        (small_genome(synth.HIFI), 96, records.preset("hifi")),
+        (small_genome(synth.ONT, n_paralogs=3), 24, records.preset("ont", bandwidth=50)),
+        (small_genome(synth.HIFI, hardclip_frac=0.5, softclip_frac=0.5, shuffle_records=1, inverted_paralogs=1, n_paralogs=3,
+                      max_secondaries=4, n_base_frac=0.002, read_len=6000), 64, records.preset("hifi")),
+        (small_genome(synth.HIFI, tag_mode=1, read_len=6000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.3, softclip_frac=0.3),
+         48, records.preset("hifi")),
+        (small_genome(synth.MIXED, n_paralogs=7, contig_len=250000, max_read_len=40000), 24, records.preset("hifi")),
+    ]
+    odd = records.preset("hifi")
+    odd.conf_d, odd.conf_e, odd.conf_b, odd.set_q, odd.min_q, odd.indel_threshold = 3e-3, 0.25, 33.0, 27, 5, 4
+    odd.flank_margin = 300
+    cases.append((small_genome(synth.HIFI, read_len=6000, max_secondaries=2, hardclip_frac=0.2, softclip_frac=0.2), 24, odd))
+    noc = records.preset("hifi")
+    noc.consensus = 0
+    cases.append((small_genome(synth.HIFI, read_len=3000, max_secondaries=2), 12, noc))
+    for g, n, par in cases:
+        r = g.reads(0, n)
+        ctx.set_reference(g.ref)
+        for flags in (0, 1):
+            p2 = copy.copy(par)
+            p2.flags = flags
+            w = ctx.prepare(r.batch, p2)
+            dev = w.export_plan()
+            host = api.Plan(g.ref, r.batch, p2)
+            _plans_equal(dev, host, n)
+            dev.close()
+            w.free()
+
+
 def _batch_parity(ctx, genome, reads, params, tmp_path, tag):
     ctx.set_reference(genome.ref)
     out, st = ctx.score_batch(reads.batch, params, finalize_seed=1)
@@ -421,7 +481,7 @@ def test_full_size_workload_properties(ctx):
 def test_full_size_workload_properties_ont(ctx):
     """BASELINE config 3 at the size bench.py --platform ont times: 4 096 ONT groups, 30 kb reads, <= 4 secondaries,
     band 50 on the 100 Mbp assembly -- the band classes (4,26)/(4,28)/(4,30)/(8,16)+(4,32) on real work lists"""
-    st = _full_size_properties(ctx, synth.ONT, records.preset("ont", bandwidth=50), 4096, 256, 4, 1000000, 5 * 10 ** 10, 48)
+    st = _full_size_properties(ctx, synth.ONT, records.preset("ont", bandwidth=50), 4096, 256, 4, 1000000, 2 * 10 ** 10, 48)
     wide = sum(st.problems_per_class[c] for c in (6, 7, 12, 13))
     assert wide > 0.9 * st.n_problems  # the ONT widths W = 101..127
 
