@@ -88,6 +88,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per stream of the context (before HIP initialises)
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start the one-rank-per-GPU job as a CHILD process -- nothing has touched the
         # GPU yet (torch is not even imported), and the launcher is never exec'd -- and relay its JSON line

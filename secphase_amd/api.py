@@ -114,9 +114,10 @@ def lib():
     L.spx_prepare.argtypes = [vp, C.POINTER(SpxBatch), C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
     L.spx_prepare_many.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int,
                                    C.POINTER(vp)]
-    L.spx_stage.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
-    L.spx_prepare_staged.argtypes = [vp, vp]
-    L.spx_work_export.argtypes = [vp, vp, C.POINTER(vp)]
+    if hasattr(L, "spx_stage"):  # (tools/ab_bench.py may load an older build through SPX_LIB)
+        L.spx_stage.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
+        L.spx_prepare_staged.argtypes = [vp, vp]
+        L.spx_work_export.argtypes = [vp, vp, C.POINTER(vp)]
     L.spx_launch.argtypes = [vp, vp]
     L.spx_sync.argtypes = [vp]
     L.spx_pack_decisions.argtypes = [vp, vp, C.c_int32, vp, C.c_int64]

@@ -811,14 +811,32 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
             nblk = 0;
             break;
         }
-        for (int i = 0; i < n; ++i) {
-            const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, cur, nc, par.indel_threshold,
-                                         S.proj + (int64_t)i * cap, cap);
-            if (m < 0) return SPX_ENOMEM;
-            S.nproj[i] = m;
+        ++iter;
+        /* A window longer than 1000 bases in READ coordinates is longer than 1000 in SEQ coordinates on every
+         * alignment (inside an alignment SEQ index and read position move together), so the loop is certain to go
+         * round again and this round's projection onto the alignments -- a walk over all their ops -- would only
+         * feed the next round's intersection, which reads nothing but the read coordinates: every alignment gets
+         * every window (windows lie inside confident blocks of all alignments), so each list is the window list
+         * itself.  The last permitted round always projects for real. */
+        bool long_window = false;
+        for (int k = 0; k < nc; ++k)
+            if (cur[k].rde - cur[k].rds > 1000) long_window = true;
+        if (long_window && iter < 64) {
+            for (int i = 0; i < n; ++i) {
+                Blk *dst = S.proj + (int64_t)i * cap;
+                for (int k = 0; k < nc; ++k) { Blk b = {0, 0, cur[k].rds, cur[k].rde, cur[k].rds, cur[k].rde}; dst[k] = b; }
+                S.nproj[i] = nc;
+            }
+        } else {
+            for (int i = 0; i < n; ++i) {
+                const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, cur, nc, par.indel_threshold,
+                                             S.proj + (int64_t)i * cap, cap);
+                if (m < 0) return SPX_ENOMEM;
+                S.nproj[i] = m;
+            }
         }
         nblk = nc;
-        if (++iter >= 64) break;
+        if (iter >= 64) break;
     }
     return (nblk > 0 || !par.consensus) ? 1 : 0;
 }
@@ -829,7 +847,7 @@ struct PlanOut {
     int64_t *ref_nib, *qry_nib;
     int32_t *ref_tid, *ref_rfs; /* may be NULL */
     int32_t *L, *R, *bw, *row_off, *n_rows, *prob_slots;
-    double *hmm;
+    uint8_t *has_n; /* window or query holds a base other than ACGT (selects the general emission path) */
     int64_t *s_off, *fsave_off;
     /* per wanted row */
     int32_t *rows, *row_expect, *row_prob;
@@ -972,8 +990,6 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                 out.prob_slots[p] = slots;
                 out.s_off[p] = at.s_off + 8;
                 out.fsave_off[p] = at.f_off;
-                double *h = out.hmm + p * SPX_H_N;
-                hmm_constants(R, L, par.d, par.e, par.qf, h);
                 bool has_n = window_has_n(rv, r.tid, b.rfs, R);
                 if (!has_n && st.has_n) {
                     const uint8_t *code = P.code4 + P.code_lead_bytes + r.seq_off;
@@ -982,7 +998,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                         has_n = ((code[q >> 1] >> ((q & 1) << 2)) & 0xf) > 3;
                     }
                 }
-                h[SPX_H_PAD0] = has_n ? 1.0 : 0.0;
+                out.has_n[p] = has_n ? 1 : 0;
             }
             const int64_t cells = band_cells(L, R, bw);
             if (!EMIT) {
@@ -1010,6 +1026,13 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
         }
     }
     return 0;
+}
+
+/* the HMM constants of problem p (one thread per problem on the device: coalesced, unlike the group passes) */
+SPX_HD void problem_constants(const Params &par, int L, int R, uint8_t has_n, double *h)
+{
+    hmm_constants(R, L, par.d, par.e, par.qf, h);
+    h[SPX_H_PAD0] = has_n ? 1.0 : 0.0;
 }
 
 /* pass 1 of a group: columns, consensus windows, work-list sizes.  The marker table and the block lists stay in the

@@ -390,11 +390,12 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
     hb.grp_problems.resize((size_t)n_ok); hb.grp_cells.resize((size_t)n_ok);
     std::vector<int64_t> s_off(np), f_off(np);
     std::vector<int32_t> prob_slots(np), row_prob(nr);
+    std::vector<uint8_t> has_n(np);
     spxl::PlanOut out;
     memset(&out, 0, sizeof out);
     out.ref_nib = hb.ref_nib.data(); out.qry_nib = hb.qry_nib.data(); out.ref_tid = hb.ref_tid.data(); out.ref_rfs = hb.ref_rfs.data();
     out.L = hb.L.data(); out.R = hb.R.data(); out.bw = hb.bw.data(); out.row_off = hb.row_off.data(); out.n_rows = hb.n_rows.data();
-    out.prob_slots = prob_slots.data(); out.hmm = hb.hmm.data(); out.s_off = s_off.data(); out.fsave_off = f_off.data();
+    out.prob_slots = prob_slots.data(); out.has_n = has_n.data(); out.s_off = s_off.data(); out.fsave_off = f_off.data();
     out.rows = hb.rows.data(); out.row_expect = hb.row_expect.data(); out.row_prob = row_prob.data(); out.row_rawq = hb.row_rawq.data();
     out.qe_rec = hb.qe_rec.data(); out.qe_pos = hb.qe_pos.data(); out.qe_len = hb.qe_len.data(); out.qe_row0 = hb.qe_row0.data();
     out.qe_batch = hb.qe_batch.data();
@@ -423,6 +424,10 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
             hb.grp_problems[(size_t)kk] = c.n_prob;
             hb.grp_cells[(size_t)kk] = c.cells;
         }
+    });
+    parallel_for((int64_t)np, threads, [&](int64_t p0, int64_t p1) {
+        for (int64_t q = p0; q < p1; ++q)
+            spxl::problem_constants(lp, hb.L[(size_t)q], hb.R[(size_t)q], has_n[(size_t)q], hb.hmm.data() + (size_t)q * SPX_H_N);
     });
     hb.qry4.swap(code);
     hb.qry_nibbles = (int64_t)hb.qry4.size() * 2;

@@ -47,6 +47,8 @@ struct spx_emit_args {
     const spxl::PlanBase *base;
     const int64_t *mk_base;
     spxl::PlanOut out;
+    double *hmm;      /* [n_prob][SPX_H_N], filled by problem_constants_kernel */
+    int32_t n_prob, pad;
     spx_dev_marker *markers;
     int32_t *mk_ref_pos;
     int32_t *mk_first;

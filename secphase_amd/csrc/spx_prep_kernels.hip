@@ -150,6 +150,19 @@ __global__ __launch_bounds__(64) void group_emit_kernel(spx_prep_args A, spx_emi
     E.info[k] = gi;
 }
 
+__global__ __launch_bounds__(256) void problem_constants_kernel(Params par, int32_t n_prob, const int32_t *__restrict__ L,
+                                                                const int32_t *__restrict__ R, const uint8_t *__restrict__ has_n,
+                                                                double *__restrict__ hmm)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_prob) return;
+    double h[SPX_H_N];
+    problem_constants(par, L[p], R[p], has_n[p], h);
+    double2 *dst = reinterpret_cast<double2 *>(hmm + (int64_t)p * SPX_H_N);
+#pragma unroll
+    for (int k = 0; k < SPX_H_N / 2; ++k) dst[k] = make_double2(h[2 * k], h[2 * k + 1]);
+}
+
 /* ---------------------------------------------------------------------- */
 /* exclusive prefix sums by ONE workgroup of 1024 lanes: the arrays have 10^4 .. 10^5 entries (alignments, groups),
  * a single pass over them through LDS costs microseconds and needs no temporary storage protocol */
@@ -319,6 +332,9 @@ extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args 
 {
     if (A->n_dgroups <= 0) return hipSuccess;
     hipLaunchKernelGGL(group_emit_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A, *E);
+    if (E->n_prob > 0)
+        hipLaunchKernelGGL(problem_constants_kernel, dim3((E->n_prob + 255) / 256), dim3(256), 0, st, A->par, E->n_prob, E->out.L, E->out.R,
+                           E->out.has_n, E->hmm);
     return hipGetLastError();
 }
 

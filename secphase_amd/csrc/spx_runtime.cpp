@@ -88,8 +88,13 @@ struct spx_ctx {
     int64_t n_launch = 0;
     /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
      * (or in front of) the bulk class */
-    hipStream_t cls_stream[SPX_N_CLASSES] = {};
-    hipEvent_t cls_done[SPX_N_CLASSES] = {};
+    /* (three side streams, the classes spread over them by band cells: with the main, the preparation and the copy
+     * stream that is six -- one hardware queue each, see spx_create) */
+    static const int SPX_N_SIDE = 3;
+    hipStream_t side_stream[SPX_N_SIDE] = {};
+    hipEvent_t side_done[SPX_N_SIDE] = {};
+    hipStream_t copy_stream = nullptr; /* host -> HBM copies of staged records */
+    std::mutex launch_mu;              /* spx_launch may be called from several threads (pipelined callers) */
     uint8_t *d_ref4 = nullptr;
     int64_t ref_bytes = 0;
     spx::RefIndex ref;
@@ -145,6 +150,8 @@ struct spx_work {
     spx_prep_args pa;
     spx_prep_totals tot;
     hipEvent_t ev_ready = nullptr; /* recorded on the preparation stream when the list may be launched */
+    hipEvent_t ev_staged = nullptr; /* recorded on the copy stream when the records are in HBM */
+    hipEvent_t ev_done = nullptr;  /* recorded on the main stream behind the last kernel of the latest launch */
     int32_t n_dgroups = 0;      /* groups that passed the dispatch filter (device arrays have one entry each) */
     std::vector<spx_group_info> info; /* pulled back by spx_collect */
     spx_group_out *d_results = nullptr;
@@ -204,6 +211,10 @@ extern "C" int spx_create(int device, spx_ctx **out)
 {
     if (!out) return fail(SPX_EINVAL, "out is NULL");
     *out = nullptr;
+    /* HIP multiplexes streams onto hardware queues (4 by default): two streams that share one run their kernels one
+     * after the other.  Ask for 8 before the runtime initialises; a process that has initialised HIP already (e.g.
+     * after importing torch) must have set the variable itself -- bench.py and the command line do. */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SPX_ENODEVICE, "hipGetDeviceCount found no device");
     if (device < 0 || device >= n) return fail(SPX_ENODEVICE, "device index out of range");
@@ -221,10 +232,11 @@ extern "C" int spx_create(int device, spx_ctx **out)
     HIPCHK(hipMalloc((void **)&c->d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
     for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
-    for (int i = 0; i < SPX_N_CLASSES; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&c->cls_stream[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->cls_done[i], hipEventDisableTiming));
+    for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
     }
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     {
         std::vector<double> t(102 + 512);
         spx::phred_thresholds(t.data());
@@ -254,10 +266,11 @@ extern "C" void spx_destroy(spx_ctx *c)
     for (int i = 0; i < 6; ++i)
         for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
             if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
-    for (int i = 0; i < SPX_N_CLASSES; ++i) {
-        if (c->cls_done[i]) (void)hipEventDestroy(c->cls_done[i]);
-        if (c->cls_stream[i]) (void)hipStreamDestroy(c->cls_stream[i]);
+    for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
+        if (c->side_done[i]) (void)hipEventDestroy(c->side_done[i]);
+        if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
     }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -633,8 +646,10 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->in_arena = arena_get(c, cv.off + 256, &w->in_cap);
     if (!w->in_arena) { spx_work_free(c, w); return fail(SPX_ENOMEM, "device memory for the staged records"); }
     char *base = (char *)w->in_arena;
-    HIPCHK(hipMemcpyAsync(base, w->h_stage, L.bytes, hipMemcpyHostToDevice, c->prep_stream));
-    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes), c->prep_stream));
+    HIPCHK(hipMemcpyAsync(base, w->h_stage, L.bytes, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes), c->copy_stream));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_staged, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(w->ev_staged, c->copy_stream));
     w->st.prep_seconds = t1 - t0;
     w->st.bytes_h2d = (int64_t)L.bytes;
     w->st.n_groups = w->n_groups_in;
@@ -688,7 +703,8 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     std::lock_guard<std::mutex> lk(c->prep_mu);
     const double t0 = now_s();
     if (w->arena) { /* re-preparation: the previous list of this work must have left the device */
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done));
+        else HIPCHK(hipStreamSynchronize(c->stream));
         arena_put(c, w->arena, w->arena_cap);
         w->arena = nullptr;
     }
@@ -708,6 +724,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     char *base = (char *)w->in_arena;
     spxl::PlanBase *d_base = (spxl::PlanBase *)(base + w->o_base);
     int64_t *d_mkb = (int64_t *)(base + w->o_mkb);
+    if (w->ev_staged) HIPCHK(hipStreamWaitEvent(c->prep_stream, w->ev_staged, 0));
     HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), c->prep_stream));
     HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
     HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, c->prep_stream));
@@ -758,7 +775,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     const size_t o_ref_nib = cv.take<int64_t>(np), o_qry_nib = cv.take<int64_t>(np), o_L = cv.take<int32_t>(np), o_R = cv.take<int32_t>(np),
                  o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N), o_row_off = cv.take<int32_t>(np),
                  o_n_rows = cv.take<int32_t>(np), o_s_off = cv.take<int64_t>(np), o_fs_off = cv.take<int64_t>(np),
-                 o_prob_slots = cv.take<int32_t>(np), o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr),
+                 o_prob_slots = cv.take<int32_t>(np), o_hasn = cv.take<uint8_t>(np + 16), o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr),
                  o_rawq = cv.take<uint8_t>(nr + 16), o_row_prob = cv.take<int32_t>(nr), o_qe = cv.take<int32_t>(5 * nq + 4),
                  o_order_f = cv.take<int32_t>(order_f_n + 64), o_order_b = cv.take<int32_t>(order_b_n + 64),
                  o_mk_first = cv.take<int32_t>(ng + 2), o_markers = cv.take<spx_dev_marker>(nm + 1), o_mkref = cv.take<int32_t>(nm + 1),
@@ -785,7 +802,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     E.out.ref_nib = (int64_t *)(B0 + o_ref_nib); E.out.qry_nib = (int64_t *)(B0 + o_qry_nib);
     E.out.L = (int32_t *)(B0 + o_L); E.out.R = (int32_t *)(B0 + o_R); E.out.bw = (int32_t *)(B0 + o_bw);
     E.out.row_off = (int32_t *)(B0 + o_row_off); E.out.n_rows = (int32_t *)(B0 + o_n_rows); E.out.prob_slots = (int32_t *)(B0 + o_prob_slots);
-    E.out.hmm = (double *)(B0 + o_hmm); E.out.s_off = (int64_t *)(B0 + o_s_off); E.out.fsave_off = (int64_t *)(B0 + o_fs_off);
+    E.out.has_n = (uint8_t *)(B0 + o_hasn); E.hmm = (double *)(B0 + o_hmm); E.n_prob = (int32_t)np; E.out.s_off = (int64_t *)(B0 + o_s_off); E.out.fsave_off = (int64_t *)(B0 + o_fs_off);
     E.out.rows = (int32_t *)(B0 + o_rows); E.out.row_expect = (int32_t *)(B0 + o_expect); E.out.row_prob = (int32_t *)(B0 + o_row_prob);
     E.out.row_rawq = (uint8_t *)(B0 + o_rawq);
     int32_t *qe = (int32_t *)(B0 + o_qe);
@@ -842,7 +859,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         B.order_bwd = (const int32_t *)(B0 + o_order_b) + sb.off[cls];
         B.n_order = (int32_t)sf.cap[cls];
         B.n_order_bwd = (int32_t)sb.cap[cls];
-        B.ref_nib = E.out.ref_nib; B.qry_nib = E.out.qry_nib; B.L = E.out.L; B.R = E.out.R; B.bw = E.out.bw; B.hmm = E.out.hmm;
+        B.ref_nib = E.out.ref_nib; B.qry_nib = E.out.qry_nib; B.L = E.out.L; B.R = E.out.R; B.bw = E.out.bw; B.hmm = E.hmm;
         B.row_off = E.out.row_off; B.n_rows = E.out.n_rows; B.s_off = E.out.s_off;
         B.ref4 = c->d_ref4;
         B.qry4 = A.P.code4;
@@ -914,6 +931,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
     if (w->staged && !w->prepared) return fail(SPX_EINVAL, "work list has been staged but not prepared");
+    std::lock_guard<std::mutex> lk(c->launch_mu);
     if (w->ev_ready) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_ready, 0)); /* the list is built on the preparation stream */
     hipEvent_t *ev = c->evr[c->n_launch % spx_ctx::SPX_EV_RING];
     w->launch_ids.push_back(c->n_launch);
@@ -921,16 +939,27 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     c->n_launch++;
     HIPCHK(hipEventRecord(ev[0], c->stream));
     /* the class holding most of the band cells runs on the main stream (its forward and backward kernels are
-     * bracketed by events); the others run beside it on their own streams */
+     * bracketed by events); the others run beside it on the side streams, heaviest first, each on the stream that
+     * has the least work so far */
     const int mc = w->main_cls;
     static const bool serial = getenv("SPX_SERIAL") != nullptr; /* diagnostics: one class after the other */
-    for (int cls = SPX_N_CLASSES - 1; cls >= 0; --cls) {
-        if (!w->cls_used[cls] || cls == mc) continue;
+    int order[SPX_N_CLASSES], no = 0;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
+        if (w->cls_used[cls] && cls != mc) order[no++] = cls;
+    std::sort(order, order + no, [&](int a, int b) { return w->cls_cells[a] != w->cls_cells[b] ? w->cls_cells[a] > w->cls_cells[b] : a < b; });
+    int64_t load[spx_ctx::SPX_N_SIDE] = {};
+    bool used_side[spx_ctx::SPX_N_SIDE] = {};
+    for (int k = 0; k < no; ++k) {
+        const int cls = order[k];
         if (serial) { HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->stream)); continue; }
-        HIPCHK(hipStreamWaitEvent(c->cls_stream[cls], ev[0], 0));
-        HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->cls_stream[cls]));
-        HIPCHK(hipEventRecord(c->cls_done[cls], c->cls_stream[cls]));
+        int sidx = 0;
+        for (int t = 1; t < spx_ctx::SPX_N_SIDE; ++t) if (load[t] < load[sidx]) sidx = t;
+        if (!used_side[sidx]) { HIPCHK(hipStreamWaitEvent(c->side_stream[sidx], ev[0], 0)); used_side[sidx] = true; }
+        HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->side_stream[sidx]));
+        load[sidx] += w->cls_cells[cls] + 1;
     }
+    for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+        if (used_side[t]) HIPCHK(hipEventRecord(c->side_done[t], c->side_stream[t]));
     if (mc >= 0) {
         HIPCHK(hipEventRecord(ev[3], c->stream));
         HIPCHK(spx_launch_baq(mc, 0, &w->cls_batch[mc], c->stream));
@@ -938,8 +967,8 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         HIPCHK(spx_launch_baq(mc, 1, &w->cls_batch[mc], c->stream));
         HIPCHK(hipEventRecord(ev[5], c->stream));
     }
-    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
-        if (w->cls_used[cls] && cls != mc && !serial) HIPCHK(hipStreamWaitEvent(c->stream, c->cls_done[cls], 0));
+    for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+        if (used_side[t]) HIPCHK(hipStreamWaitEvent(c->stream, c->side_done[t], 0));
     {
         int64_t narrow = 0, wide = 0;
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
@@ -953,6 +982,8 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         if (w->staged) HIPCHK(spx_launch_results(&w->dg, w->d_info, w->d_rfe, w->d_results, c->stream));
     }
     HIPCHK(hipEventRecord(ev[2], c->stream));
+    if (!w->ev_done) HIPCHK(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(w->ev_done, c->stream));
     w->launched = true;
     return SPX_OK;
 }
@@ -978,7 +1009,9 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
 {
     if (!c || !w || !out) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    /* wait for THIS work list only: lists launched after it keep running (pipelined callers) */
+    if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done));
+    else HIPCHK(hipStreamSynchronize(c->stream));
     if (w->launched) {
         /* averages over THIS work list's launches since its previous collect (those whose events are still in the ring);
          * other work lists launched in between have their own slots.  Timing is diagnostics: a failing event query
@@ -1027,8 +1060,8 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         spx_group_out *h = ng ? (spx_group_out *)pinned_get(c, ng * sizeof(spx_group_out), &cap) : nullptr;
         if (ng && !h) return fail(SPX_ENOMEM, "pinned result buffer");
         if (ng) {
-            hipError_t e = hipMemcpyAsync(h, w->d_results, ng * sizeof(spx_group_out), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            hipError_t e = hipMemcpyAsync(h, w->d_results, ng * sizeof(spx_group_out), hipMemcpyDeviceToHost, c->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
             if (e != hipSuccess) { pinned_put(c, h, cap); return fail(SPX_EHIP, std::string("result copy: ") + hipGetErrorString(e)); }
         }
         w->st.d2h_seconds = now_s() - t0;
@@ -1171,14 +1204,19 @@ extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
 {
     if (!w) return;
     if (c) (void)hipSetDevice(c->device);
-    if (c && (w->arena || w->in_arena)) {
-        (void)hipStreamSynchronize(c->prep_stream); /* nothing of this work list may still be running */
-        (void)hipStreamSynchronize(c->stream);
+    if (c && (w->arena || w->in_arena)) { /* nothing of this work list may still be running */
+        if (w->ev_staged) (void)hipEventSynchronize(w->ev_staged);
+        if (w->ev_ready) (void)hipEventSynchronize(w->ev_ready);
+        else if (w->staged) (void)hipStreamSynchronize(c->prep_stream);
+        if (w->ev_done) (void)hipEventSynchronize(w->ev_done);
+        else (void)hipStreamSynchronize(c->stream);
     }
     if (w->arena) arena_put(c, w->arena, w->arena_cap);
     if (w->in_arena) arena_put(c, w->in_arena, w->in_cap);
     if (w->h_stage) pinned_put(c, w->h_stage, w->h_stage_cap);
     if (w->ev_ready) (void)hipEventDestroy(w->ev_ready);
+    if (w->ev_staged) (void)hipEventDestroy(w->ev_staged);
+    if (w->ev_done) (void)hipEventDestroy(w->ev_done);
     delete w;
 }
 
