@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- secphase hot path (marker -> banded-HMM BAQ -> marker-consistency score ->
-decision) on N MI355X GPUs of one node.
+"""bench.py -- secphase hot path (markers -> consensus windows -> banded-HMM BAQ -> marker-consistency score ->
+decision -> relabel list) on N MI355X GPUs of one node.
 
-A "step" is one pass of the device path over one batch of synthetic alignment groups whose
-work list (packed query windows, wanted rows, marker tables) and reference are ALREADY resident
-in HBM: every banded DP problem of the batch + the scoring/decision kernel + (N>1) one RCCL
-gather of the 8-byte decision records to rank 0.  `value` = groups/s over all ranks.
+A "step" is one pass of the WHOLE hot path over one batch of synthetic alignment groups whose RECORDS (flag / position /
+CIGAR / cs / SEQ / QUAL, the bytes a BAM reader produces) are already resident in HBM when the timed region starts:
+  device:  CIGAR+cs walk, markers, consensus windows, DP work list (spx_prep_kernels.hip)  ->  banded-HMM forward /
+           backward / MAP kernels  ->  marker filter, score, decision kernels  ->  one packed result record per group
+  host:    one D2H copy of those records, the rand() replay of the decision in file order, the relabel list appended
+           to out.log;  N>1: one RCCL gather of 16-byte decision records + one of the candidate records to rank 0,
+           which replays and writes for all ranks.
+Steps are pipelined (`--depth` batches in flight: the preparation of batch k+1 runs beside the DP kernels of batch k);
+every step works on its own batch of groups (`distinct_batches` in the output; they repeat only when steps + warmup
+exceeds it).  `value` = dispatched groups/s over all ranks.  Also reported: `pipelined_from_host` (the same steps fed
+from host memory: staging + PCIe copy inside the timed region) and, with --kernel-only, the DP + scoring kernels of ONE
+prepared work list replayed (the figure round 1 reported; kept for kernel A/B runs and profiles).
 
-Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run)
-prints ONE JSON line on rank 0.
+Contract: python bench.py --gpus N --steps K --warmup W prints ONE JSON line on rank 0.  N>1 without torchrun:
+bench.py starts `python -m torch.distributed.run` itself as a child process.
 """
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import tempfile
 import threading
 import time
 
@@ -28,26 +37,27 @@ FLOPS_PER_CELL = 45             # forward 19 + backward 
 FWD_FLOPS_PER_CELL = 19
 
 
-def pmc_traffic(kernel, gps):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_counters.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very command, KB units).  The guide's x2
-    correction of FETCH_SIZE on gfx950 applies to 16 B/lane streaming reads; for the access pattern of these kernels
-    the counters were calibrated on the backward kernel's known read / write volume: factor 1.
-    None when the profile does not match."""
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_counters.json")))
-        meta = prof.get("_meta", {})
-        if meta.get("groups_per_step") != gps:
-            return None
-        k = prof.get("void " + kernel) or prof.get(kernel)
-        return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
-    except Exception:
-        return None
+def pmc_traffic(kernel, gps, platform):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_counters_<platform>.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of `bench.py --kernel-only`, KB units; tools/pmc_collect.py).
+    The guide's x2 correction of FETCH_SIZE on gfx950 applies to 16 B/lane streaming reads; for the access pattern of
+    these kernels the counters were calibrated on the backward kernel's known read / write volume:
+    factor 1.  None when no profile matches this workload."""
+    for name in (f"r02_counters_{platform}.json", "r01_counters.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            meta = prof.get("_meta", {})
+            if meta.get("groups_per_step") != gps or meta.get("platform", "hifi") != platform:
+                continue
+            k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel) or prof.get(kernel)
+            return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
+        except Exception:
+            continue
+    return None
 
 
 def gen_parallel(genome, first, n, chunk, threads):
     """generate n groups starting at `first` in `chunk`-sized batches on `threads` threads"""
-    from secphase_amd import synth  # noqa: F401
     starts = list(range(first, first + n, chunk))
     out = [None] * len(starts)
     it = iter(range(len(starts)))
@@ -75,12 +85,15 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--platform", default="hifi", choices=["hifi", "ont", "mixed"])
-    ap.add_argument("--kernel-only", action="store_true", help="(profiling runs) only the device-resident replay")
+    ap.add_argument("--kernel-only", action="store_true", help="only the replay of one prepared work list (profiles, kernel A/B)")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
-    ap.add_argument("--chunk", type=int, default=0, help="groups per prepared work list (0: one list per step)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
+    ap.add_argument("--distinct", type=int, default=32, help="at most this many distinct batches per rank (HBM / host memory)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the pipelined-from-host measurement")
+    ap.add_argument("--cpu-bracket", action="store_true", help="also time the -O0 / calloc-per-call / 4-thread variants of the CPU baseline")
     ap.add_argument("--verify", type=int, default=256, help="groups checked against the oracle before timing")
     args = ap.parse_args()
 
@@ -101,11 +114,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     import __graft_entry__ as ge
-    from secphase_amd import api, records, synth
+    from secphase_amd import api, records, shard, synth
 
     if not os.path.exists(api.LIB_PATH):
         ge.build()
@@ -115,10 +129,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    L = api.lib()
 
     ont = args.platform == "ont"
     mixed = args.platform == "mixed"
-    gps = args.groups_per_step or (4096 if ont else 8192 if mixed else 32768)  # HiFi: 32 768 groups per launch amortise the tails of the rare wide classes (+2.4 % over 16 384)
+    gps = args.groups_per_step or (4096 if ont else 8192 if mixed else 32768)
     # config 5 (mixed HiFi+ONT, power-law lengths, <= 8 secondaries) is run as --hifi over the whole mix, SURVEY 8(d)
     params = records.preset("ont", bandwidth=50) if ont else records.preset("hifi")
     cfg = synth.default_cfg(synth.ONT if ont else synth.MIXED if mixed else synth.HIFI)
@@ -130,33 +145,24 @@ def main():
     ctx.set_reference(genome.ref)
 
     ncpu = os.cpu_count() or 1
-    gen_threads = max(1, min(64, ncpu // max(1, world)))
-    first = rank * gps  # every rank scores its own shard of the read groups (weak scaling)
+    host_threads = max(1, min(64, ncpu // max(1, world)))
+    n_total = args.steps + args.warmup
+    D = 1 if args.kernel_only else max(1, min(n_total, args.distinct))
+    first = rank * D * gps  # every rank scores its own shard of the read-group stream (weak scaling)
     t0 = time.time()
-    chunk = args.chunk or gps
-    chunks = gen_parallel(genome, first, gps, args.gen_chunk, gen_threads)
+    batches = []  # batches[i] = the record blocks (generator chunks) of distinct batch i
+    for i in range(D):
+        batches.append(gen_parallel(genome, first + i * gps, gps, args.gen_chunk, host_threads))
     t_gen = time.time() - t0
-    t0 = time.time()
-    per = max(1, chunk // args.gen_chunk)
-    works = [ctx.prepare([ch.batch for ch in chunks[k:k + per]], params, host_threads=gen_threads)
-             for k in range(0, len(chunks), per)]
-    t_prep = time.time() - t0
-    stats = [w.stats() for w in works]
-    n_disp = sum(s.n_dispatched for s in stats)
-    n_prob = sum(s.n_problems for s in stats)
-    n_rows = sum(s.n_rows for s in stats)
-    cells = sum(s.dp_cells for s in stats)
-    bytes_in = sum(s.bytes_h2d for s in stats)
+    ptrs = [[ch.batch for ch in b] for b in batches]
 
     # ---- parity gate on a sample of the very workload being timed (oracle = checker only) ----
     verified = 0
     if rank == 0 and args.verify > 0:
         from oracle import orc
-        nchk = min(args.verify, chunks[0].batch.contents.n_groups)
+        nchk = min(args.verify, gps)
         sub = genome.reads(first, nchk)
-        w = ctx.prepare(sub.batch, params, host_threads=gen_threads)
-        w.launch()
-        out = w.collect(finalize_seed=1)
+        out, _ = ctx.score_batch(sub.batch, params, finalize_seed=1)
         _, res = orc.run_batch(sub.batch, genome.ref, params, threads=min(ncpu, 64), seed=1)
         for i in range(nchk):
             o, e = out[i], res[i]
@@ -164,87 +170,157 @@ def main():
             if not ok:
                 sys.exit(f"parity check failed on group {i}: GPU result differs from the oracle")
         verified = nchk
-        w.free()
-
-    # decision records land in a torch tensor so that RCCL can gather them
-    # (every rank sizes its buffer by the largest dispatched count of any rank: ranks whose dispatch filter drops a
-    # different number of groups would otherwise disagree about the gather's message size)
-    cap = n_disp
-    if world > 1:
-        t = torch.tensor([n_disp], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cap = int(t.item())
-    dec = torch.full((max(cap, 1),), -1, dtype=torch.int64, device="cuda")
-    gathered = [torch.zeros_like(dec) for _ in range(world)] if (world > 1 and rank == 0) else None
-
-    def step():
-        off = 0
-        for k, w in enumerate(works):
-            w.launch()
-            off += w.pack_decisions(first + k * chunk, dec.data_ptr() + 8 * off, dec.numel() - off)
-        if world > 1:
-            ctx_sync()
-            dist.gather(dec, gathered, dst=0)
 
     def ctx_sync():
-        api._chk(api.lib().spx_sync(ctx.h), "spx_sync")
+        api._chk(L.spx_sync(ctx.h), "spx_sync")
 
-    for _ in range(args.warmup):
-        step()
-    ctx_sync()
-    if args.warmup > 0:
-        works[0].collect(finalize_seed=None)  # closes the event window: the averages below cover the TIMED launches only
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    baq_ms = 0.0
-    score_ms = 0.0
-    for _ in range(args.steps):
-        step()
-    ctx_sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def sync_all():
+        ctx_sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tmpdir = tempfile.mkdtemp(prefix="spx_bench_")
+    log_path = os.path.join(tmpdir, f"bench.{rank}.out.log")
+
+    # ------------------------------------------------------------------ kernel-only replay (round-1 figure)
+    def kernel_only(steps, warmup):
+        w = ctx.prepare(ptrs[0], params, host_threads=host_threads)
+        for _ in range(warmup):
+            w.launch()
+        ctx_sync()
+        w.collect(finalize_seed=None)  # closes the event window: the averages cover the timed launches only
+        sync_all()
+        t = time.perf_counter()
+        for _ in range(steps):
+            w.launch()
+        sync_all()
+        el = time.perf_counter() - t
+        w.collect(finalize_seed=None)
+        st = w.stats()
+        w.free()
+        return el, st
+
+    staged, pipe, fin = [], None, C.c_void_p()
+    t_stage = 0.0
+    relabelled = [0]
+    if not args.kernel_only:
+        t0 = time.time()
+        staged = [ctx.stage(p, params, host_threads=host_threads) for p in ptrs]  # records -> HBM, outside the timed region
+        ctx_sync()
+        t_stage = time.time() - t0
+        pipe = api.Pipe(ctx, params, depth=args.depth, host_threads=host_threads)
+        api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+    outbuf = (api.GroupOut * gps)()
+    dec_dev = torch.zeros(gps * shard.DECISION_BYTES, dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def out_at(base):
+        return C.cast(C.byref(outbuf, base * C.sizeof(api.GroupOut)), C.POINTER(api.GroupOut))
+
+    def finish_step(step_global, i, n, work):
+        """what follows the kernels: rand() replay in file order + relabel list (N=1), or the two gathers and rank 0's
+        replay for all ranks (N>1)"""
+        if world == 1:
+            api._chk(L.spx_finalizer_apply(fin, C.byref(params), outbuf, n), "spx_finalizer_apply")
+            base = 0
+            for bp in ptrs[i]:
+                api._chk(L.spx_write_relabel_log(log_path.encode(), b"a", bp, genome.ref, out_at(base)), "spx_write_relabel_log")
+                base += bp.contents.n_groups
+            relabelled[0] += sum(1 for g in range(0, n, 997) if outbuf[g].relabel)  # (sampled: keeps Python out of the timing)
+            return
+        gbase = (step_global * world + rank) * gps
+        nd = work.pack_decisions(gbase, dec_dev.data_ptr(), gps)  # device -> device, then RCCL
+        dparts = shard.gather_bytes(dec_dev[: nd * shard.DECISION_BYTES], dist, torch)
+        cands = []
+        base = 0
+        for bp in ptrs[i]:
+            nc = L.spx_relabel_candidates(bp, gbase + base, out_at(base), C.byref(params), None, 0)
+            if nc > 0:
+                arr = (api.RelabelRec * nc)()
+                L.spx_relabel_candidates(bp, gbase + base, out_at(base), C.byref(params), arr, nc)
+                cands.append(np.frombuffer(memoryview(arr), np.uint8).copy())
+            base += bp.contents.n_groups
+        cbytes = np.concatenate(cands) if cands else np.zeros(0, np.uint8)
+        cparts = shard.gather_bytes(torch.from_numpy(cbytes).to("cuda"), dist, torch)
+        if rank == 0:
+            _, nw = shard.merge_and_write(api, params, fin, genome.ref, dparts, cparts, log_path)
+            relabelled[0] += nw
+
+    def run(nsteps, offset, from_host):
+        submitted = received = 0
+        while received < nsteps:
+            while submitted < nsteps and pipe.pending() < args.depth + 1:
+                i = (offset + submitted) % D
+                if from_host:
+                    pipe.submit(batch=ptrs[i])
+                else:
+                    pipe.submit(staged=staged[i])
+                submitted += 1
+            i = (offset + received) % D
+            _, n = pipe.next(outbuf)
+            finish_step(offset + received, i, n, staged[i] if not from_host else None)
+            received += 1
+
+    host_leg = None
+    if args.kernel_only:
+        elapsed, st_k = kernel_only(args.steps, args.warmup)
+        per_step_stats = [st_k]
+    else:
+        open(log_path, "w").close()
+        run(args.warmup, 0, False)
+        sync_all()
+        t0 = time.perf_counter()
+        run(args.steps, args.warmup, False)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        per_step_stats = [staged[(args.warmup + k) % D].stats() for k in range(min(args.steps, D))]
+        if world == 1 and not args.no_host_leg:
+            # the same steps fed from HOST memory: staging (host threads) + PCIe copy inside the timed region
+            hs = max(2, min(args.steps, 8))
+            run(1, 0, True)
+            sync_all()
+            t1 = time.perf_counter()
+            run(hs, 1, True)
+            sync_all()
+            el_h = time.perf_counter() - t1
+            host_leg = (hs, el_h)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_disp, n_prob, cells], dtype=torch.int64, device="cuda")
+
+    nst = len(per_step_stats)
+    n_disp = sum(int(s.n_dispatched) for s in per_step_stats) / nst
+    n_prob = sum(int(s.n_problems) for s in per_step_stats) / nst
+    n_rows = sum(int(s.n_rows) for s in per_step_stats) / nst
+    cells = sum(int(s.dp_cells) for s in per_step_stats) / nst
+    bytes_in = sum(int(s.bytes_h2d) for s in per_step_stats) / nst
+    if world > 1:
+        tot = torch.tensor([n_disp, n_prob, cells], dtype=torch.float64, device="cuda")
         dist.all_reduce(tot)
-        n_disp_all, n_prob_all, cells_all = [int(x) for x in tot.tolist()]
+        n_disp_all, n_prob_all, cells_all = [float(x) for x in tot.tolist()]
     else:
         n_disp_all, n_prob_all, cells_all = n_disp, n_prob, cells
-
-    # dominant kernel: HIP events recorded by spx_launch on the launch stream around the BAQ kernels of the
-    # timed region (hipEventRecord on the ctx stream, not torch's current stream)
-    per_launch = []
-    for w in works:
-        if len(works) > 1:
-            w.launch()  # the events belong to the context: with several work lists per step re-run each alone
-        w.collect(finalize_seed=None)  # one list per step: averages over the launches of the timed region
-        per_launch.append(w.stats())
-    baq_ms = sum(p.baq_kernel_ms for p in per_launch)
-    score_ms = sum(p.score_kernel_ms for p in per_launch)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_disp_all * args.steps / elapsed
-        # ---- roofline of the dominant kernel: the forward kernel of the band class holding most cells.
+        # ---- roofline of the dominant kernel: the forward kernel of the band class holding most cells, timed with HIP
+        # events on the stream it is launched on (spx_launch), averaged over the timed steps.
         # FP64 vector-ALU bound (not HBM, not MFMA): 19 of the 45 flops per band cell are forward flops.
-        st0 = per_launch[0]
+        st0 = per_step_stats[0]
         G, slots = st0.main_class_lanes, st0.main_class_slots
         kname = f"baq_fwd1_kernel<{slots - 1}>" if G == 1 else f"baq_fwd_kernel<{G}, {slots // G}, 0, false>"
-        fwd_ms = sum(p.main_fwd_ms for p in per_launch) / len(per_launch)
-        bwd_ms = sum(p.main_bwd_ms for p in per_launch) / len(per_launch)
-        cls_cells = sum(p.main_class_cells for p in per_launch) / len(per_launch)
-        achieved_tf = FWD_FLOPS_PER_CELL * cls_cells / (fwd_ms * 1e-3) / 1e12
+        fwd_ms = sum(p.main_fwd_ms for p in per_step_stats) / nst
+        bwd_ms = sum(p.main_bwd_ms for p in per_step_stats) / nst
+        baq_ms = sum(p.baq_kernel_ms for p in per_step_stats) / nst
+        score_ms = sum(p.score_kernel_ms for p in per_step_stats) / nst
+        cls_cells = sum(p.main_class_cells for p in per_step_stats) / nst
+        achieved_tf = FWD_FLOPS_PER_CELL * cls_cells / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
         # whole BAQ phase (forward + backward + MAP, all classes) at the algorithm's 45 flop per cell
-        phase_tf = FLOPS_PER_CELL * (cells / len(works)) / (baq_ms / len(works) * 1e-3) / 1e12
-        compulsory = (bytes_in + n_rows * 13) / len(works)  # inputs + per-row outputs, per launch
+        phase_tf = FLOPS_PER_CELL * cells / (baq_ms * 1e-3) / 1e12 if baq_ms > 0 else 0.0
+        compulsory = n_prob * 1700  # SURVEY 8(d): ~1.7 KB of compulsory HBM bytes per DP problem
         roofline = {
             "bound": "mfma",  # the compute roof of the two the contract names; see "compute_unit" and "note"
             "compute_unit": "valu_fp64",
@@ -252,10 +328,10 @@ def main():
             "peak": PEAK_FP64_VECTOR_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved_tf / PEAK_FP64_VECTOR_TFLOPS, 4),
-            "traffic": pmc_traffic(kname, gps),
+            "traffic": pmc_traffic(kname, gps, args.platform),
             "kernel": kname,
             "avg_launch_ms": round(fwd_ms, 4),
-            "launches_averaged": int(st0.n_launches_averaged),
+            "launches_averaged": int(sum(p.n_launches_averaged for p in per_step_stats)),
             "cells_per_launch": int(cls_cells),
             "flops_per_cell": FWD_FLOPS_PER_CELL,
             "note": "compute-bound, but on the FP64 VECTOR ALU, not on the matrix cores: the DP has sequential dependences "
@@ -265,14 +341,14 @@ def main():
                     "1.8-2.0 GHz, ~85% of the VALU issue slots), not HBM/MFMA. peak = vector FP64 at 2.4 GHz with FMA counted "
                     "as 2; the bit-exact path may not fuse mul+add, so 39.3 is the attainable ceiling. algorithmic flops: "
                     "19 (forward) of 45 per band cell, SURVEY 8(d); avg_launch_ms = HIP events on the launch stream, "
-                    "averaged over the timed launches (the other band classes run beside it on their own streams)",
+                    "averaged over the timed steps (the other band classes, and the preparation kernels of the next batch, "
+                    "run beside it on their own streams)",
             "phase": {"what": "forward + backward + MAP kernels, all band classes, 45 flop per band cell",
                       "achieved": round(phase_tf, 3), "frac": round(phase_tf / PEAK_FP64_VECTOR_TFLOPS, 4),
-                      "ms_per_launch": round(baq_ms / len(works), 4),
-                      "backward_kernel_ms": round(bwd_ms, 4)},
-            "hbm": {"bound": "hbm", "achieved": round(compulsory / (baq_ms / len(works) * 1e-3) / 1e9, 2),
+                      "ms_per_launch": round(baq_ms, 4), "backward_kernel_ms": round(bwd_ms, 4)},
+            "hbm": {"bound": "hbm", "achieved": round(compulsory / (baq_ms * 1e-3) / 1e9, 2) if baq_ms > 0 else 0.0,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(compulsory / (baq_ms / len(works) * 1e-3) / 1e9 / PEAK_HBM_GBS, 6),
+                    "frac": round(compulsory / (baq_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6) if baq_ms > 0 else 0.0,
                     "algorithmic_bytes_per_launch": int(compulsory)},
         }
         cpu = None
@@ -284,20 +360,43 @@ def main():
             # the oracle keeps the reference's memory pattern (two ~0.8 MB matrices zeroed per BAQ call), which
             # saturates the host memory system well before all hardware threads are busy: time it at all
             # threads and at 32, report the better one with the thread count actually used
+
+            def time_oracle(cores, reuse, variant=None):
+                t_ = time.perf_counter()
+                _, res_ = orc.run_batch(sample.batch, genome.ref, params, threads=cores, seed=1, reuse_scratch=reuse, variant=variant)
+                dt_ = time.perf_counter() - t_
+                nd_ = sum(1 for r in res_ if r.n_aln > 0)
+                return nd_ / dt_, dt_, sum(r.dp_cells for r in res_) / dt_
+
             best = None
             for cores in sorted({ncpu, min(ncpu, 32)}, reverse=True):
-                t0 = time.perf_counter()
-                nre, res = orc.run_batch(sample.batch, genome.ref, params, threads=cores, seed=1, reuse_scratch=True)
-                dt = time.perf_counter() - t0
-                ndis = sum(1 for r in res if r.n_aln > 0)
-                cand = {"value": round(ndis / dt, 2), "unit": "groups/s", "cores": cores, "kind": "port",
+                v, dt, cps = time_oracle(cores, True)
+                cand = {"value": round(v, 2), "unit": "groups/s", "cores": cores, "kind": "port",
                         "sample": f"first {ns} groups of the same workload, oracle (C restatement, -O2 -ffp-contract=off, "
                                   f"pthread pool over groups, per-thread DP scratch instead of calloc/free per call), "
                                   f"{dt:.2f} s wall; host has {ncpu} hardware threads",
-                        "cells_per_s": round(sum(r.dp_cells for r in res) / dt, 1)}
+                        "cells_per_s": round(cps, 1)}
                 if best is None or cand["value"] > best["value"]:
                     best = cand
             cpu = best
+            if args.cpu_bracket:
+                # what separates the port from the real reference build
+                br = {}
+                cores = best["cores"]
+                v, dt, _ = time_oracle(cores, False)
+                br["calloc_per_call"] = {"value": round(v, 2), "cores": cores, "what": "two calloc'd FP64 matrices per BAQ call, like htslib"}
+                try:
+                    v, dt, _ = time_oracle(cores, False, variant="O0")
+                    br["O0_build"] = {"value": round(v, 2), "cores": cores,
+                                      "what": "gcc -O0 (the reference Makefile gives no -O flag), calloc per call"}
+                except Exception as e:  # noqa: BLE001
+                    br["O0_build"] = {"error": str(e)}
+                v1, dt1, _ = time_oracle(1, True)
+                br["one_thread"] = {"value": round(v1, 2), "cores": 1}
+                v4, dt4, _ = time_oracle(min(4, ncpu), False)
+                br["reference_default_threads"] = {"value": round(v4, 2), "cores": min(4, ncpu),
+                                                   "what": "-@ default of the reference (4), calloc per call"}
+                cpu["bracket"] = br
         line = {
             "metric": "reads/sec (primary+secondary groups scored)",
             "value": round(value, 2),
@@ -315,13 +414,18 @@ def main():
                 "workload": ("1M ONT reads, 30 kb, <=4 secondaries, band=50, ONT gap params" if ont else
                              "Mixed HiFi+ONT reads, length 2-100 kb power-law, <=8 secondaries, run as --hifi" if mixed else
                              "1M HiFi reads, 15 kb, <=2 secondaries, band=20, BAQ window 500 bp") +
-                            f" (streamed as batches of {gps} groups per GPU per step; inputs resident in HBM)",
+                            f" (streamed as batches of {gps} groups per GPU per step; " +
+                            ("ONE prepared work list replayed: kernels only)" if args.kernel_only else
+                             "records resident in HBM, whole path records -> relabel list inside the step)"),
                 "groups_per_step_per_gpu": gps,
-                "dp_problems_per_step": n_prob_all,
-                "dp_cells_per_step": cells_all,
-                "wanted_rows_per_step_rank0": n_rows,
-                "parallelism": f"reads sharded over {world} GPU(s); RCCL gather of 8-byte decision records" if world > 1
-                               else "single GPU",
+                "distinct_batches_per_gpu": D,
+                "pipeline_depth": args.depth,
+                "dp_problems_per_step": int(n_prob_all),
+                "dp_cells_per_step": int(cells_all),
+                "wanted_rows_per_step_rank0": int(n_rows),
+                "record_bytes_per_step_rank0": int(bytes_in),
+                "parallelism": (f"reads sharded over {world} GPUs; RCCL gather of 16-byte decision records + candidate records to "
+                                f"rank 0, which replays the draws and writes the list") if world > 1 else "single GPU",
                 "verified_groups_vs_oracle": verified,
             },
             "roofline": roofline,
@@ -329,9 +433,24 @@ def main():
             "kernel_ms_per_step": {"baq": round(baq_ms, 3), "score": round(score_ms, 3)},
             "dp_cells_per_s": round(cells_all * args.steps / elapsed, 1),
             "dp_problems_per_s": round(n_prob_all * args.steps / elapsed, 1),
-            "setup_s": {"genome": round(t_genome, 2), "generate": round(t_gen, 2), "host_prepare+h2d": round(t_prep, 2)},
+            "setup_s": {"genome": round(t_genome, 2), "generate": round(t_gen, 2), "stage_records_to_hbm": round(t_stage, 2)},
         }
+        if host_leg:
+            hs, el_h = host_leg
+            line["pipelined_from_host"] = {"value": round(n_disp * hs / el_h, 2), "unit": "groups/s", "steps": hs,
+                                           "ms_per_step": round(el_h / hs * 1e3, 3),
+                                           "what": "the same steps with the records in HOST memory: dispatch filter + staging into pinned "
+                                                   f"memory on {host_threads} host threads + PCIe copy inside the timed region",
+                                           "GB_per_s_over_pcie": round(bytes_in * hs / el_h / 1e9, 2)}
+        if not args.kernel_only:
+            line["relabelled_sampled"] = relabelled[0]
         print(json.dumps(line), flush=True)
+    if pipe is not None:
+        pipe.close()
+    if fin:
+        L.spx_finalizer_free(fin)
+    for w in staged:
+        w.free()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

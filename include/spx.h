@@ -124,11 +124,47 @@ int spx_stage(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_batches, 
 int spx_prepare_staged(spx_ctx *ctx, spx_work *work);
 int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */
 int spx_sync(spx_ctx *ctx);
-/* multi-GPU: write one 8-byte decision record per dispatched group of `work` into a caller-owned
- * DEVICE buffer (e.g. a torch tensor that is then handed to an RCCL gather): bits 0-31 global
- * group index (= index in the batch + group_base), 32-39 prim_idx, 40-47 max_idx, 48-62 tie_mask,
- * 63 pass.  Asynchronous on the ctx stream; returns the number of records (>= 0) or SPX_E*. */
+/* ---- multi-GPU: what crosses ranks (spx_gather.cpp).  Read groups shard over ranks; the relabel list is a property of
+ * the whole file -- records in file order, the tie-breaking rand() stream consumed in file order (src/secphase.c:194-217,
+ * ptAlignment.c:163-176 at -@1).  Every rank contributes (a) one spx_decision per dispatched group (ONE gather of
+ * fixed-size records: enough to replay the draws of every group in global order) and (b) one spx_relabel_rec per
+ * candidate group (those whose best alignment can be a secondary: what print_alignment_scores, src/secphase.c:32-57,
+ * needs to write the record). ---- */
+typedef struct spx_decision { /* 16 bytes */
+    uint32_t group;    /* global group index */
+    int8_t n_aln;      /* alignments scored; < 2: the group draws nothing */
+    int8_t prim_idx, max_idx;
+    uint8_t pass;      /* max > prim + prim_margin && max >= min_score */
+    uint16_t tie_mask; /* secondaries whose score >= max */
+    uint16_t reserved;
+    int32_t absdiff;   /* abs((int)(max_score - prim_score)), the operand of the prim_margin_random test (ptAlignment.c:172) */
+} spx_decision;
+typedef struct spx_relabel_rec {
+    uint32_t group;
+    int8_t n_aln, prim_idx;
+    int8_t pad_[2];
+    double score[10];
+    int32_t rfe[10], pos[10], tid[10];
+    uint16_t flag[10];
+    char qname[260];
+} spx_relabel_rec;
+/* One spx_decision per dispatched group of `work` into a caller-owned DEVICE buffer (e.g. a torch tensor that is then
+ * handed to an RCCL gather); group = index in the work list's input + group_base.  Waits for the work list's kernels
+ * and returns when the records are written.  Returns the number of records or SPX_E*. */
 int spx_pack_decisions(spx_ctx *ctx, spx_work *work, int32_t group_base, void *device_out, int64_t capacity);
+/* the same records from collected results (host side; groups that are not scored are left out) */
+int spx_decisions_from_results(const spx_group_out *out, int32_t n_groups, int32_t group_base, spx_decision *dst, int32_t capacity);
+/* candidate records of a collected batch (dst == NULL: only counts them) */
+int spx_relabel_candidates(const spx_batch *bt, int32_t group_base, const spx_group_out *out, const spx_params *par,
+                           spx_relabel_rec *dst, int32_t capacity);
+/* rank 0: the draws of all groups, records sorted by group (a finalizer keeps ONE stream over the whole run) */
+typedef struct spx_finalizer spx_finalizer;
+int spx_finalizer_apply_decisions(spx_finalizer *f, const spx_params *par, const spx_decision *dec, int32_t n, int8_t *best_idx,
+                                  int8_t *relabel);
+/* appends the relabel records of the candidates whose decision (best_idx[k], from the call above) is a secondary;
+ * returns how many were written */
+int spx_write_relabel_records(const char *path, const char *mode, const spx_ref *ref, const spx_relabel_rec *recs, int32_t n,
+                              const int8_t *best_idx);
 int spx_collect(spx_ctx *ctx, spx_work *work, spx_group_out *out);
 /* Quality arrays as the reference leaves them in the records after calc_local_baq (ptMarker.c:706,759,763),
  * for a work list prepared with params.flags & SPX_PAR_ALL_ROWS and already launched.  `qual` must hold a copy
@@ -137,11 +173,29 @@ int spx_apply_quals(spx_ctx *ctx, spx_work *w, int32_t batch_index, const spx_ba
 int spx_work_stats(const spx_work *work, spx_stats *stats);
 void spx_work_free(spx_ctx *ctx, spx_work *work);
 
+/* ---- in-order pipeline over one context: what replaces the reference's thread pool + output mutex
+ * (src/secphase.c:230-351, :74-228).  `depth` submissions are in flight at once, each on its own worker thread:
+ * staging (host threads) -> copy to HBM -> device preparation -> DP + scoring kernels -> packed results back; the copy
+ * of one batch, the preparation of the next and the kernels of a third overlap on the device.  Results are handed out
+ * in SUBMISSION order (the rand() replay and the relabel list need file order). ---- */
+typedef struct spx_pipe spx_pipe;
+int spx_pipe_create(spx_ctx *ctx, const spx_params *par, int depth, int host_threads, spx_pipe **out);
+/* Either record batches (valid until the matching spx_pipe_next has returned), or -- staged != NULL -- a work list the
+ * caller staged with spx_stage (records resident in HBM; it is prepared again, launched and collected; it stays the
+ * caller's) with the number of input groups it covers.  Blocks while depth + 1 submissions are in flight. */
+int spx_pipe_submit(spx_pipe *p, const spx_batch *const *batches, int32_t n_batches, spx_work *staged, int32_t n_groups_staged,
+                    void *tag);
+/* Results of the OLDEST submission: returns its number of input groups (out[0..n) filled like spx_collect does) or
+ * SPX_E*.  *work (may be NULL) receives the work list -- for spx_relabel_blocks / spx_apply_quals; the caller frees it
+ * with spx_work_free unless it is its own staged list; with work == NULL a list the pipe created is freed here. */
+int spx_pipe_next(spx_pipe *p, spx_group_out *out, int32_t capacity, spx_work **work, void **tag);
+int spx_pipe_pending(spx_pipe *p);
+void spx_pipe_destroy(spx_pipe *p);
+
 /* rand() replay + decision, in file order */
 int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups);
 
 /* the same with ONE draw stream kept across batches (a whole run = the reference at -@1) */
-typedef struct spx_finalizer spx_finalizer;
 int spx_finalizer_create(unsigned rand_seed, spx_finalizer **out);
 int spx_finalizer_apply(spx_finalizer *f, const spx_params *par, spx_group_out *out, int32_t n_groups);
 void spx_finalizer_free(spx_finalizer *f);

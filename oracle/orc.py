@@ -40,59 +40,72 @@ class GroupResult(C.Structure):
 
 
 _lib = None
+_variants = {}
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", _DIR])
 
 
-def lib():
+def lib(variant=None):
+    """variant "O0": the same sources compiled without optimisation (bench.py's CPU-baseline bracket)"""
     global _lib
+    if variant:
+        if variant not in _variants:
+            path = os.path.join(_DIR, f"liborc_{variant}.so")
+            if not os.path.exists(path):
+                build()
+            _variants[variant] = _load(path)
+        return _variants[variant]
     if _lib is None:
         path = os.path.join(_DIR, "liborc.so")
         if not os.path.exists(path):
             build()
-        L = C.CDLL(path)
-        u8p = C.POINTER(C.c_uint8)
-        L.orc_probaln_glocal.restype = C.c_int
-        L.orc_probaln_glocal.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.POINTER(ProbalnPar),
-                                         C.POINTER(C.c_int), u8p]
-        L.orc_phred_from_posterior.restype = C.c_int
-        L.orc_phred_from_posterior.argtypes = [C.c_double]
-        L.orc_set_scratch_reuse.argtypes = [C.c_int]
-        L.orc_set_scratch_reuse.restype = None
-        L.orc_probaln_consts.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(HmmConsts)]
-        L.orc_srand.argtypes = [C.POINTER(Rand), C.c_uint]
-        L.orc_rand_next.restype = C.c_int
-        L.orc_rand_next.argtypes = [C.POINTER(Rand)]
-        L.orc_score_group.restype = C.c_int
-        L.orc_score_group.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.c_int, C.POINTER(SpxParams),
-                                      C.POINTER(Rand), C.POINTER(GroupResult), C.c_void_p,
-                                      C.POINTER(BaqCall), C.c_int]
-        L.orc_group_is_dispatched.restype = C.c_int
-        L.orc_group_is_dispatched.argtypes = [C.POINTER(SpxBatch), C.c_int]
-        L.orc_run_batch.restype = C.c_int
-        L.orc_run_batch.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
-                                    C.c_uint, C.POINTER(GroupResult), C.c_char_p]
-        L.orc_run_batch_bed.restype = C.c_int
-        L.orc_run_batch_bed.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
-                                        C.c_uint, C.POINTER(GroupResult), C.c_char_p, C.c_char_p, C.c_char_p]
-        L.orc_probaln_posteriors.restype = C.c_int
-        L.orc_probaln_posteriors.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int,
-                                             C.POINTER(C.c_uint8), C.POINTER(ProbalnPar), C.POINTER(C.c_double),
-                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        L.orc_run_batch_quals.restype = C.c_int
-        L.orc_run_batch_quals.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
-                                          C.POINTER(GroupResult), C.POINTER(C.c_uint8)]
-        ip = C.POINTER(C.c_int)
-        L.orc_blocks_sort.argtypes = [C.c_int, ip, ip, ip]
-        L.orc_blocks_sort.restype = None
-        L.orc_blocks_merge.argtypes = [C.c_int, ip, ip, ip, ip, ip, ip]
-        L.orc_blocks_merge_v2.argtypes = [C.c_int, ip, ip, ip, ip, ip, ip]
-        L.orc_walk_cigar.restype = C.c_int
-        L.orc_walk_cigar.argtypes = [C.POINTER(SpxBatch), C.c_int, C.POINTER(C.POINTER(Op))]
-        _lib = L
+        _lib = _load(path)
     return _lib
+
+
+def _load(path):
+    L = C.CDLL(path)
+    u8p = C.POINTER(C.c_uint8)
+    L.orc_probaln_glocal.restype = C.c_int
+    L.orc_probaln_glocal.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.POINTER(ProbalnPar),
+                                     C.POINTER(C.c_int), u8p]
+    L.orc_phred_from_posterior.restype = C.c_int
+    L.orc_phred_from_posterior.argtypes = [C.c_double]
+    L.orc_set_scratch_reuse.argtypes = [C.c_int]
+    L.orc_set_scratch_reuse.restype = None
+    L.orc_probaln_consts.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(HmmConsts)]
+    L.orc_srand.argtypes = [C.POINTER(Rand), C.c_uint]
+    L.orc_rand_next.restype = C.c_int
+    L.orc_rand_next.argtypes = [C.POINTER(Rand)]
+    L.orc_score_group.restype = C.c_int
+    L.orc_score_group.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.c_int, C.POINTER(SpxParams),
+                                  C.POINTER(Rand), C.POINTER(GroupResult), C.c_void_p,
+                                  C.POINTER(BaqCall), C.c_int]
+    L.orc_group_is_dispatched.restype = C.c_int
+    L.orc_group_is_dispatched.argtypes = [C.POINTER(SpxBatch), C.c_int]
+    L.orc_run_batch.restype = C.c_int
+    L.orc_run_batch.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
+                                C.c_uint, C.POINTER(GroupResult), C.c_char_p]
+    L.orc_run_batch_bed.restype = C.c_int
+    L.orc_run_batch_bed.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
+                                    C.c_uint, C.POINTER(GroupResult), C.c_char_p, C.c_char_p, C.c_char_p]
+    L.orc_probaln_posteriors.restype = C.c_int
+    L.orc_probaln_posteriors.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int,
+                                         C.POINTER(C.c_uint8), C.POINTER(ProbalnPar), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_run_batch_quals.restype = C.c_int
+    L.orc_run_batch_quals.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(SpxParams), C.c_int,
+                                      C.POINTER(GroupResult), C.POINTER(C.c_uint8)]
+    ip = C.POINTER(C.c_int)
+    L.orc_blocks_sort.argtypes = [C.c_int, ip, ip, ip]
+    L.orc_blocks_sort.restype = None
+    L.orc_blocks_merge.argtypes = [C.c_int, ip, ip, ip, ip, ip, ip]
+    L.orc_blocks_merge_v2.argtypes = [C.c_int, ip, ip, ip, ip, ip, ip]
+    L.orc_walk_cigar.restype = C.c_int
+    L.orc_walk_cigar.argtypes = [C.POINTER(SpxBatch), C.c_int, C.POINTER(C.POINTER(Op))]
+    return L
 
 
 def probaln_posteriors(ref, query, set_q, d, e, bw):
@@ -121,11 +134,12 @@ def run_batch_quals(batch, ref, params, qual, threads=1):
 
 
 def run_batch(batch, ref, params, threads=1, seed=1, log_path=None, reuse_scratch=False, bed_modified=None,
-              bed_markers=None):
-    lib().orc_set_scratch_reuse(1 if reuse_scratch else 0)
+              bed_markers=None, variant=None):
+    L = lib(variant)
+    L.orc_set_scratch_reuse(1 if reuse_scratch else 0)
     n = batch.contents.n_groups if hasattr(batch, "contents") else batch.n_groups
     res = (GroupResult * n)()
     enc = lambda p: p.encode() if p else None
-    nre = lib().orc_run_batch_bed(batch, ref, C.byref(params), threads, seed, res, enc(log_path), enc(bed_modified),
-                                  enc(bed_markers))
+    nre = L.orc_run_batch_bed(batch, ref, C.byref(params), threads, seed, res, enc(log_path), enc(bed_modified),
+                              enc(bed_markers))
     return nre, res

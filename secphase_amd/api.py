@@ -37,6 +37,17 @@ class GroupOut(C.Structure):
     ]
 
 
+class Decision(C.Structure):
+    _fields_ = [("group", C.c_uint32), ("n_aln", C.c_int8), ("prim_idx", C.c_int8), ("max_idx", C.c_int8), ("pass_", C.c_uint8),
+                ("tie_mask", C.c_uint16), ("reserved", C.c_uint16), ("absdiff", C.c_int32)]
+
+
+class RelabelRec(C.Structure):
+    _fields_ = [("group", C.c_uint32), ("n_aln", C.c_int8), ("prim_idx", C.c_int8), ("pad_", C.c_int8 * 2),
+                ("score", C.c_double * 10), ("rfe", C.c_int32 * 10), ("pos", C.c_int32 * 10), ("tid", C.c_int32 * 10),
+                ("flag", C.c_uint16 * 10), ("qname", C.c_char * 260)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("n_groups", C.c_int64), ("n_dispatched", C.c_int64), ("n_problems", C.c_int64), ("n_rows", C.c_int64),
@@ -83,6 +94,8 @@ EXPORTS = [
     "spx_bam_next_batch", "spx_bam_close", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
     "spx_stage", "spx_prepare_staged", "spx_work_export",
+    "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
+    "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
 ]
 
 _lib = None
@@ -118,6 +131,21 @@ def lib():
         L.spx_stage.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
         L.spx_prepare_staged.argtypes = [vp, vp]
         L.spx_work_export.argtypes = [vp, vp, C.POINTER(vp)]
+    if hasattr(L, "spx_decisions_from_results"):
+        L.spx_decisions_from_results.argtypes = [C.POINTER(GroupOut), C.c_int32, C.c_int32, C.POINTER(Decision), C.c_int32]
+        L.spx_relabel_candidates.argtypes = [C.POINTER(SpxBatch), C.c_int32, C.POINTER(GroupOut), C.POINTER(SpxParams),
+                                             C.POINTER(RelabelRec), C.c_int32]
+        L.spx_finalizer_apply_decisions.argtypes = [vp, C.POINTER(SpxParams), C.POINTER(Decision), C.c_int32,
+                                                    C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
+        L.spx_write_relabel_records.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(SpxRef), C.POINTER(RelabelRec), C.c_int32,
+                                                C.POINTER(C.c_int8)]
+    if hasattr(L, "spx_pipe_create"):
+        L.spx_pipe_create.argtypes = [vp, C.POINTER(SpxParams), C.c_int, C.c_int, C.POINTER(vp)]
+        L.spx_pipe_submit.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, vp, C.c_int32, vp]
+        L.spx_pipe_next.argtypes = [vp, C.POINTER(GroupOut), C.c_int32, C.POINTER(vp), C.POINTER(vp)]
+        L.spx_pipe_pending.argtypes = [vp]
+        L.spx_pipe_destroy.argtypes = [vp]
+        L.spx_pipe_destroy.restype = None
     L.spx_launch.argtypes = [vp, vp]
     L.spx_sync.argtypes = [vp]
     L.spx_pack_decisions.argtypes = [vp, vp, C.c_int32, vp, C.c_int64]
@@ -325,6 +353,53 @@ class Work:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class Pipe:
+    """in-order scoring pipeline (spx_pipe_*): submit batches or staged works, take results in submission order"""
+
+    def __init__(self, ctx, params, depth=3, host_threads=0):
+        self.ctx = ctx
+        self.params = params
+        self.h = C.c_void_p()
+        _chk(lib().spx_pipe_create(ctx.h, C.byref(params), depth, host_threads, C.byref(self.h)), "spx_pipe_create")
+        self._keep = []
+
+    def submit(self, batch=None, staged=None):
+        if staged is not None:
+            _chk(lib().spx_pipe_submit(self.h, None, 0, staged.h, staged.n, None), "spx_pipe_submit")
+            self._keep.append((staged.n, None))
+            return
+        if not isinstance(batch, (list, tuple)):
+            batch = [batch]
+        arr = (C.POINTER(SpxBatch) * len(batch))(*batch)
+        n = sum(b.contents.n_groups for b in batch)
+        _chk(lib().spx_pipe_submit(self.h, arr, len(batch), None, 0, None), "spx_pipe_submit")
+        self._keep.append((n, arr))
+
+    def next(self, out=None):
+        """results of the oldest submission: (GroupOut array, n)"""
+        n, _ = self._keep.pop(0)
+        if out is None:
+            out = (GroupOut * max(n, 1))()
+        rc = lib().spx_pipe_next(self.h, out, n, None, None)
+        if rc < 0:
+            raise SpxError(rc, "spx_pipe_next")
+        return out, rc
+
+    def pending(self):
+        return lib().spx_pipe_pending(self.h)
+
+    def close(self):
+        if self.h:
+            lib().spx_pipe_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

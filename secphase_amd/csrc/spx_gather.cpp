@@ -1,0 +1,180 @@
+/*
+ * spx_gather.cpp -- what crosses ranks in a multi-GPU run, and what rank 0 does with it (host code, no HIP).
+ *
+ * Read groups shard over ranks; the relabel list is a property of the whole file: records in file order, the
+ * tie-breaking rand() stream consumed in file order (the reference at -@1,
+ * /root/reference/programs/src/secphase.c:194-217 + submodules/ptAlignment/ptAlignment.c:163-176).  So every rank sends
+ *   (a) one 16-byte spx_decision per dispatched group  -- enough to replay the draws of EVERY group in global order;
+ *   (b) one spx_relabel_rec per CANDIDATE group         -- the groups whose best alignment can be a secondary
+ *       (margin test passed, or a coin flip decides): read name, per-alignment flag / contig / position / score / end,
+ *       i.e. everything print_alignment_scores (src/secphase.c:32-57) writes;
+ * rank 0 merges (a) by group index, replays the draws, and writes the records of (b) whose decision is a relabel.
+ */
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/spx.h"
+
+extern "C" void spx_internal_set_error(const char *msg);
+
+static int popcount16(unsigned v)
+{
+    int n = 0;
+    for (; v; v &= v - 1) ++n;
+    return n;
+}
+
+/* abs((int)(max_score - prim_score)) with the x86 conversion the reference's build performs (ptAlignment.c:172) */
+static int32_t absdiff_of(const spx_group_out &o)
+{
+    const double max_score = o.max_idx >= 0 ? o.score[o.max_idx] : -1.7976931348623157e308;
+    const double prim_score = o.prim_idx >= 0 ? o.score[o.prim_idx] : -1.7976931348623157e308;
+    const double dd = max_score - prim_score;
+    int d = (dd > -2147483649.0 && dd < 2147483648.0) ? (int)dd : INT_MIN;
+    if (d < 0 && d != INT_MIN) d = -d;
+    return d;
+}
+
+extern "C" int spx_decisions_from_results(const spx_group_out *out, int32_t n_groups, int32_t group_base, spx_decision *dst, int32_t capacity)
+{
+    if (!out || !dst) return SPX_EINVAL;
+    int32_t n = 0;
+    for (int32_t g = 0; g < n_groups; ++g) {
+        const spx_group_out &o = out[g];
+        if (o.n_aln < 2) continue; /* not dispatched, or rejected: draws nothing */
+        if (n >= capacity) return SPX_EINVAL;
+        spx_decision d;
+        memset(&d, 0, sizeof d);
+        d.group = (uint32_t)(group_base + g);
+        d.n_aln = o.n_aln;
+        d.prim_idx = o.prim_idx;
+        d.max_idx = o.max_idx;
+        d.pass = (uint8_t)(o.pass ? 1 : 0);
+        d.tie_mask = o.tie_mask;
+        d.absdiff = absdiff_of(o);
+        dst[n++] = d;
+    }
+    return n;
+}
+
+/* the draws of one group (ptAlignment.c:163-176); r = two consecutive values of the stream are consumed as needed */
+struct spx_finalizer;
+extern "C" int spx_finalizer_draw(spx_finalizer *f, int32_t *out);
+
+static void decide(spx_finalizer *f, const spx_params *par, int n_aln, int prim_idx, int max_idx0, unsigned tie_mask, int pass,
+                   int32_t absdiff, int8_t *best_out, int8_t *relabel_out)
+{
+    *best_out = -1;
+    *relabel_out = 0;
+    if (n_aln < 2) return;
+    int tied[16], cnt = 0, max_idx = max_idx0;
+    for (int a = 0; a < n_aln && a < 16; ++a)
+        if ((tie_mask >> a) & 1) tied[cnt++] = a;
+    int32_t r;
+    if (cnt > 1) { spx_finalizer_draw(f, &r); max_idx = tied[r % cnt]; }
+    spx_finalizer_draw(f, &r);
+    const int rnd = r % 2;
+    int best;
+    if (absdiff < par->prim_margin_random) best = rnd == 0 ? prim_idx : max_idx;
+    else best = pass ? max_idx : prim_idx;
+    *best_out = (int8_t)best;
+    *relabel_out = (best >= 0 && best != prim_idx) ? 1 : 0;
+}
+
+extern "C" int spx_finalizer_apply(spx_finalizer *f, const spx_params *par, spx_group_out *out, int32_t n_groups)
+{
+    if (!f || !par || !out) return SPX_EINVAL;
+    for (int32_t g = 0; g < n_groups; ++g) {
+        spx_group_out &o = out[g];
+        decide(f, par, o.n_aln, o.prim_idx, o.max_idx, o.tie_mask, o.pass, o.n_aln >= 2 ? absdiff_of(o) : 0, &o.best_idx, &o.relabel);
+    }
+    return SPX_OK;
+}
+
+extern "C" int spx_finalizer_apply_decisions(spx_finalizer *f, const spx_params *par, const spx_decision *dec, int32_t n, int8_t *best_idx,
+                                             int8_t *relabel)
+{
+    if (!f || !par || !dec || !best_idx || !relabel) return SPX_EINVAL;
+    for (int32_t k = 0; k < n; ++k) {
+        if (k > 0 && dec[k].group < dec[k - 1].group) { spx_internal_set_error("decision records are not in group order"); return SPX_EINVAL; }
+        decide(f, par, dec[k].n_aln, dec[k].prim_idx, dec[k].max_idx, dec[k].tie_mask, dec[k].pass, dec[k].absdiff, &best_idx[k], &relabel[k]);
+    }
+    return SPX_OK;
+}
+
+extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups)
+{
+    spx_finalizer *f = nullptr;
+    int rc = spx_finalizer_create(rand_seed, &f);
+    if (rc) return rc;
+    rc = spx_finalizer_apply(f, par, out, n_groups);
+    spx_finalizer_free(f);
+    return rc;
+}
+
+extern "C" int spx_relabel_candidates(const spx_batch *bt, int32_t group_base, const spx_group_out *out, const spx_params *par,
+                                      spx_relabel_rec *dst, int32_t capacity)
+{
+    if (!bt || !out || !par) return SPX_EINVAL;
+    int32_t n = 0;
+    for (int32_t g = 0; g < bt->n_groups; ++g) {
+        const spx_group_out &o = out[g];
+        if (o.n_aln < 2) continue;
+        const bool cand = o.pass || popcount16(o.tie_mask) > 1 || absdiff_of(o) < par->prim_margin_random;
+        if (!cand) continue;
+        if (dst) {
+            if (n >= capacity) return SPX_EINVAL;
+            spx_relabel_rec &r = dst[n];
+            memset(&r, 0, sizeof r);
+            r.group = (uint32_t)(group_base + g);
+            r.n_aln = o.n_aln;
+            r.prim_idx = o.prim_idx;
+            int i = 0;
+            for (int a = bt->grp_first[g]; a < bt->grp_first[g + 1]; ++a) {
+                if (bt->flag[a] & SPX_FUNMAP) continue;
+                if (i >= o.n_aln || i >= 10) break;
+                r.score[i] = o.score[i];
+                r.rfe[i] = o.rfe[i];
+                r.pos[i] = bt->pos[a];
+                r.tid[i] = bt->tid[a];
+                r.flag[i] = bt->flag[a];
+                ++i;
+            }
+            const char *qn = bt->qnames + bt->qname_off[g];
+            strncpy(r.qname, qn, sizeof r.qname - 1);
+        }
+        ++n;
+    }
+    return n;
+}
+
+extern "C" int spx_write_relabel_records(const char *path, const char *mode, const spx_ref *ref, const spx_relabel_rec *recs, int32_t n,
+                                         const int8_t *best_idx)
+{
+    if (!path || !ref || (!recs && n > 0) || (!best_idx && n > 0)) return SPX_EINVAL;
+    FILE *f = fopen(path, mode && *mode ? mode : "w");
+    if (!f) { spx_internal_set_error((std::string("cannot open ") + path).c_str()); return SPX_EINVAL; }
+    int written = 0;
+    for (int32_t k = 0; k < n; ++k) {
+        const spx_relabel_rec &r = recs[k];
+        const int best = best_idx[k];
+        if (best < 0 || best == r.prim_idx) continue;
+        ++written;
+        fprintf(f, "#MARKER SCORE\n");
+        fprintf(f, "$\t%s\n", r.qname);
+        for (int i = 0; i < r.n_aln && i < 10; ++i) {
+            const char *tag = !(r.flag[i] & SPX_FSECONDARY) ? "*" : (i == best ? "@" : "!");
+            const char *contig = (r.tid[i] >= 0 && r.tid[i] < ref->n_contigs) ? ref->names + ref->name_off[r.tid[i]] : "*";
+            fprintf(f, "%s\t%.2f\t%s\t%ld\t%d\n", tag, r.score[i], contig, (long)r.pos[i], r.rfe[i]);
+        }
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    return written;
+}

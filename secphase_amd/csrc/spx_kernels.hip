@@ -10,7 +10,7 @@
  *                            ptMarker.c:778-779,786)
  *  posmin/score/decide       filter_lowq_markers + calc_alignment_score + the deterministic part of
  *                            get_best_record_index (ptMarker.c:110-153,307-325; ptAlignment.c:137-177)
- *  pack_kernel               8-byte decision records for the multi-GPU gather
+ *  pack_kernel               16-byte decision records for the multi-GPU gather
  *
  * Mapping: FP64 vector-ALU work, not HBM- or MFMA-bound.  The band is stored on DIAGONALS
  * (slot j <-> column k = i - bw + j) so that the M recurrence is slot-local; a problem is owned by G adjacent lanes
@@ -1058,19 +1058,31 @@ __global__ __launch_bounds__(256) void decide_kernel(spx_dev_groups Gd)
     Gd.pass[gi] = !(prim_idx == -1 || max_score <= (prim_score + Gd.prim_margin) || max_score < Gd.min_score);
 }
 
-/* fixed-size decision records for the cross-rank gather (one RCCL collective):
- * {group index u32 | prim i8 | max_idx i8 | tie_mask u16 low byte.. } packed in 8 bytes */
+/* fixed-size decision records for the cross-rank gather (one RCCL collective): everything the rand() replay of
+ * get_best_record_index needs (ptAlignment.c:163-176), 16 bytes per dispatched group.  Groups with an error
+ * (n_aln = 0 on the device) draw nothing and are marked n_aln = 0. */
 __global__ __launch_bounds__(256) void pack_kernel(spx_dev_groups Gd, const int32_t *__restrict__ grp_index,
-                                                   int32_t group_base, unsigned long long *__restrict__ out)
+                                                   int32_t group_base, spx_decision *__restrict__ out)
 {
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= Gd.n_groups) return;
-    unsigned long long r = (unsigned long long)(uint32_t)(grp_index[gi] + group_base);
-    r |= (unsigned long long)Gd.prim_idx[gi] << 32;
-    r |= (unsigned long long)Gd.max_idx[gi] << 40;
-    r |= (unsigned long long)Gd.tie_mask[gi] << 48;
-    r |= (unsigned long long)(Gd.pass[gi] ? 1 : 0) << 63;
-    out[gi] = r;
+    spx_decision d;
+    d.group = (uint32_t)(grp_index[gi] + group_base);
+    const int n = Gd.n_aln[gi];
+    d.n_aln = (int8_t)n;
+    const int prim = (int8_t)Gd.prim_idx[gi], mx = (int8_t)Gd.max_idx[gi];
+    d.prim_idx = (int8_t)prim;
+    d.max_idx = (int8_t)mx;
+    d.pass = Gd.pass[gi] ? 1 : 0;
+    d.tie_mask = Gd.tie_mask[gi];
+    d.reserved = 0;
+    const double *sc = Gd.score + (int64_t)gi * 10;
+    const double max_score = mx >= 0 ? sc[mx] : -1.7976931348623157e308, prim_score = prim >= 0 ? sc[prim] : -1.7976931348623157e308;
+    const double dd = max_score - prim_score;
+    int v = (dd > -2147483649.0 && dd < 2147483648.0) ? (int)dd : (int)0x80000000; /* cvttsd2si */
+    if (v < 0 && v != (int)0x80000000) v = -v;
+    d.absdiff = n >= 2 ? v : 0;
+    out[gi] = d;
 }
 
 /* one packed result record per dispatched group (what spx_collect copies back in one piece) */
@@ -1108,7 +1120,7 @@ extern "C" hipError_t spx_launch_results(const spx_dev_groups *Gd, const spx_gro
 }
 
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
-                                      unsigned long long *out, hipStream_t st)
+                                      spx_decision *out, hipStream_t st)
 {
     if (Gd->n_groups <= 0) return hipSuccess;
     int blocks = (Gd->n_groups + 255) / 256;

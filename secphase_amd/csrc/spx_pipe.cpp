@@ -1,0 +1,178 @@
+/*
+ * spx_pipe.cpp -- in-order scoring pipeline over one context (include/spx.h, spx_pipe_*).
+ *
+ * The reference hands every read group to a thread pool and serialises the output with a mutex
+ * (/root/reference/programs/src/secphase.c:230-351 dispatch, :74-228 worker).  Here a submission is a whole batch of
+ * groups; `depth` submissions are in flight at once, each driven by one worker thread through
+ *     stage (host threads pack the records, one copy to HBM)  ->  device preparation  ->  DP + scoring kernels  ->
+ *     one copy of the packed results back,
+ * so that the copy of batch k+2, the preparation of batch k+1 and the DP kernels of batch k overlap on the device (copy,
+ * preparation and main streams of the context).  Results come back in SUBMISSION order, which is what the rand()
+ * replay of the decision (spx_finalizer_apply) and the relabel list need: the output equals the reference at -@1.
+ */
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/spx.h"
+
+extern "C" void spx_internal_set_error(const char *msg);
+
+namespace {
+
+struct Job {
+    std::vector<const spx_batch *> batches;
+    spx_work *work = nullptr; /* staged by the caller (records resident in HBM) or created here */
+    bool own_work = false;
+    void *tag = nullptr;
+    int32_t n_groups = 0;
+    std::vector<spx_group_out> out;
+    int rc = 0;
+    std::string err;
+    bool done = false;
+};
+
+} // namespace
+
+struct spx_pipe {
+    spx_ctx *ctx = nullptr;
+    spx_params par;
+    int depth = 2, stage_threads = 1;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_room;
+    std::deque<Job *> todo;     /* submitted, not yet picked up */
+    std::deque<Job *> inflight; /* submission order, delivered from the front */
+    bool stop = false;
+    std::vector<std::thread> workers;
+};
+
+static void run_job(spx_pipe *p, Job *j)
+{
+    int rc = SPX_OK;
+    if (!j->work) {
+        rc = spx_stage(p->ctx, j->batches.data(), (int32_t)j->batches.size(), &p->par, p->stage_threads, &j->work);
+        j->own_work = rc == SPX_OK;
+    }
+    if (rc == SPX_OK) rc = spx_prepare_staged(p->ctx, j->work);
+    if (rc == SPX_OK) rc = spx_launch(p->ctx, j->work);
+    if (rc == SPX_OK) {
+        j->out.resize((size_t)(j->n_groups > 0 ? j->n_groups : 1));
+        rc = spx_collect(p->ctx, j->work, j->out.data());
+    }
+    if (rc != SPX_OK) j->err = spx_last_error();
+    j->rc = rc;
+}
+
+static void worker_main(spx_pipe *p)
+{
+    for (;;) {
+        Job *j = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_work.wait(lk, [&] { return p->stop || !p->todo.empty(); });
+            if (p->todo.empty()) return; /* stop requested and nothing left */
+            j = p->todo.front();
+            p->todo.pop_front();
+        }
+        run_job(p, j);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            j->done = true;
+        }
+        p->cv_done.notify_all();
+    }
+}
+
+extern "C" int spx_pipe_create(spx_ctx *ctx, const spx_params *par, int depth, int host_threads, spx_pipe **out)
+{
+    if (!ctx || !par || !out) return SPX_EINVAL;
+    spx_pipe *p = new spx_pipe();
+    p->ctx = ctx;
+    p->par = *par;
+    p->depth = depth < 1 ? 1 : (depth > 8 ? 8 : depth);
+    int ht = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
+    p->stage_threads = ht / p->depth > 0 ? ht / p->depth : 1;
+    for (int t = 0; t < p->depth; ++t) p->workers.emplace_back(worker_main, p);
+    *out = p;
+    return SPX_OK;
+}
+
+extern "C" int spx_pipe_submit(spx_pipe *p, const spx_batch *const *batches, int32_t n_batches, spx_work *staged, int32_t n_groups_staged,
+                               void *tag)
+{
+    if (!p || (!staged && (!batches || n_batches <= 0))) return SPX_EINVAL;
+    Job *j = new Job();
+    j->tag = tag;
+    if (staged) {
+        j->work = staged;
+        j->n_groups = n_groups_staged;
+    } else {
+        int64_t n = 0;
+        for (int32_t b = 0; b < n_batches; ++b) {
+            if (!batches[b]) { delete j; return SPX_EINVAL; }
+            j->batches.push_back(batches[b]);
+            n += batches[b]->n_groups;
+        }
+        j->n_groups = (int32_t)n;
+    }
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_room.wait(lk, [&] { return (int)p->inflight.size() < p->depth + 1; }); /* one waiting beside `depth` running */
+        p->todo.push_back(j);
+        p->inflight.push_back(j);
+    }
+    p->cv_work.notify_one();
+    return SPX_OK;
+}
+
+extern "C" int spx_pipe_pending(spx_pipe *p)
+{
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return (int)p->inflight.size();
+}
+
+extern "C" int spx_pipe_next(spx_pipe *p, spx_group_out *out, int32_t capacity, spx_work **work, void **tag)
+{
+    if (!p || !out) return SPX_EINVAL;
+    Job *j = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        if (p->inflight.empty()) return SPX_EINVAL;
+        j = p->inflight.front();
+        p->cv_done.wait(lk, [&] { return j->done; });
+        p->inflight.pop_front();
+    }
+    p->cv_room.notify_all();
+    int rc = j->rc;
+    if (rc != SPX_OK) spx_internal_set_error(j->err.c_str());
+    if (tag) *tag = j->tag;
+    if (rc == SPX_OK && capacity < j->n_groups) rc = SPX_EINVAL;
+    if (rc == SPX_OK) {
+        for (int32_t g = 0; g < j->n_groups; ++g) out[g] = j->out[(size_t)g];
+        rc = j->n_groups;
+    }
+    if (work) *work = j->work; /* the caller frees it (or keeps its own staged list) */
+    else if (j->own_work && j->work) spx_work_free(p->ctx, j->work);
+    delete j;
+    return rc;
+}
+
+extern "C" void spx_pipe_destroy(spx_pipe *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_work.notify_all();
+    for (auto &t : p->workers) t.join();
+    for (Job *j : p->inflight) {
+        if (j->own_work && j->work) spx_work_free(p->ctx, j->work);
+        delete j;
+    }
+    delete p;
+}

@@ -33,7 +33,7 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
-                                      unsigned long long *out, hipStream_t st);
+                                      spx_decision *out, hipStream_t st);
 extern "C" hipError_t spx_launch_results(const spx_dev_groups *Gd, const spx_group_info *info, const int32_t *rfe,
                                          spx_group_out *out, hipStream_t st);
 extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *raw_seq, int64_t seq_words, hipStream_t st);
@@ -199,6 +199,8 @@ extern "C" const char *spx_strerror(int code)
     }
 }
 extern "C" const char *spx_last_error(void) { return g_err.c_str(); }
+/* internal: lets the pipeline hand a worker thread's error text to the thread that asks for the results */
+extern "C" void spx_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 
 extern "C" int spx_device_count(void)
 {
@@ -994,7 +996,12 @@ extern "C" int spx_pack_decisions(spx_ctx *c, spx_work *w, int32_t group_base, v
     const int64_t ng = w->staged ? (int64_t)w->n_dgroups : (int64_t)w->hb.grp_index.size();
     if (capacity < ng) return fail(SPX_EINVAL, "decision buffer too small");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(spx_launch_pack(&w->dg, w->d_grp_index, group_base, (unsigned long long *)device_out, c->stream));
+    /* behind the work list's own kernels only (not behind lists launched later), on the copy stream; returns when the
+     * records are in the buffer, so the caller can hand it to a collective on any stream */
+    if (w->ev_done) HIPCHK(hipStreamWaitEvent(c->copy_stream, w->ev_done, 0));
+    else HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(spx_launch_pack(&w->dg, w->d_grp_index, group_base, (spx_decision *)device_out, c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
     return (int)ng;
 }
 
@@ -1254,43 +1261,12 @@ extern "C" int spx_finalizer_create(unsigned rand_seed, spx_finalizer **out)
 }
 extern "C" void spx_finalizer_free(spx_finalizer *f) { delete f; }
 
-extern "C" int spx_finalizer_apply(spx_finalizer *f, const spx_params *par, spx_group_out *out, int32_t n_groups)
+/* one value of the stream (spx_gather.cpp holds the decision rule that consumes them) */
+extern "C" int spx_finalizer_draw(spx_finalizer *f, int32_t *out)
 {
-    if (!f || !par || !out) return fail(SPX_EINVAL, "NULL argument");
-    for (int32_t g = 0; g < n_groups; ++g) {
-        spx_group_out &o = out[g];
-        o.best_idx = -1;
-        o.relabel = 0;
-        if (o.n_aln < 2) continue;
-        int tied[16], cnt = 0, max_idx = o.max_idx;
-        for (int a = 0; a < o.n_aln; ++a)
-            if ((o.tie_mask >> a) & 1) tied[cnt++] = a;
-        int32_t r;
-        if (cnt > 1) { random_r(&f->rd, &r); max_idx = tied[r % cnt]; }
-        random_r(&f->rd, &r);
-        const int rnd = r % 2;
-        const double max_score = o.max_idx >= 0 ? o.score[o.max_idx] : -DBL_MAX;
-        const double prim_score = o.prim_idx >= 0 ? o.score[o.prim_idx] : -DBL_MAX;
-        double dd = max_score - prim_score;
-        int d = (dd > -2147483649.0 && dd < 2147483648.0) ? (int)dd : INT_MIN;
-        if (d < 0 && d != INT_MIN) d = -d;
-        int best;
-        if (d < par->prim_margin_random) best = rnd == 0 ? o.prim_idx : max_idx;
-        else best = o.pass ? max_idx : o.prim_idx;
-        o.best_idx = (int8_t)best;
-        o.relabel = (best >= 0 && best != o.prim_idx) ? 1 : 0;
-    }
+    if (!f || !out) return SPX_EINVAL;
+    random_r(&f->rd, out);
     return SPX_OK;
-}
-
-extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups)
-{
-    spx_finalizer *f = nullptr;
-    int rc = spx_finalizer_create(rand_seed, &f);
-    if (rc) return rc;
-    rc = spx_finalizer_apply(f, par, out, n_groups);
-    spx_finalizer_free(f);
-    return rc;
 }
 
 /* BED bookkeeping of relabelled reads (src/secphase.c:201-212): extents of the old primary and of the promoted

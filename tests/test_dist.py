@@ -1,5 +1,11 @@
-"""CPU, world_size 2 over gloo: reads shard across ranks, one gather of the 8-byte decision
-records, rank 0 replays the tie-breaking draws in file order -> same relabel list as one process."""
+"""CPU, world_size 2 over gloo: the multi-GPU path that EMITS the relabel list.  Reads shard across ranks by cost
+(unequal shard sizes), every rank turns its results into spx_decision + spx_relabel_rec records through the C ABI, two
+gathers bring them to rank 0, which replays the tie-breaking draws in global file order and writes out.log -- byte for
+byte what one process writes, tie groups included (/root/reference/programs/src/secphase.c:194-217 at -@1).
+There is no GPU here: the oracle stands in for the device path (test infrastructure only), everything after the scores
+is the product's own code."""
+import ctypes as C
+import filecmp
 import os
 import sys
 
@@ -12,59 +18,137 @@ import torch.multiprocessing as mp
 from secphase_amd import shard
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_GROUPS = 60
 
 
-def _worker(rank, world, port, n_groups, tmp):
+def _setup():
+    from common import small_genome
+    from secphase_amd import records, synth
+    g = small_genome(synth.HIFI, max_secondaries=4, n_paralogs=3, read_len=4000, min_secondaries=0, paralog_snv_rate=0.0002)  # near-identical paralogs: tied secondaries
+    p = records.preset("hifi")
+    p.prim_margin_score = 5.0  # more relabelled reads
+    return g, p
+
+
+def _results_from_oracle(api, res, params):
+    """oracle GroupResult -> the spx_group_out array spx_collect would hand back (stand-in for the device path)"""
+    out = (api.GroupOut * max(len(res), 1))()
+    for i, e in enumerate(res):
+        o = out[i]
+        o.n_aln = e.n_aln if e.n_aln > 0 else (e.n_aln if e.n_aln < 0 else 0)
+        o.prim_idx = o.max_idx = o.best_idx = -1
+        if e.n_aln < 2:
+            continue
+        for a in range(e.n_aln):
+            o.score[a] = e.score[a]
+            o.rfe[a] = e.rfe[a]
+        o.prim_idx = e.prim_idx
+        sec = [a for a in range(e.n_aln) if a != e.prim_idx]
+        mxs = max(e.score[a] for a in sec)
+        o.max_idx = next(a for a in sec if e.score[a] == mxs)
+        o.tie_mask = sum(1 << a for a in sec if e.score[a] >= mxs)
+        o.pass_ = 0 if (mxs <= e.score[e.prim_idx] + params.prim_margin_score or mxs < params.min_score) else 1
+    return out
+
+
+def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from common import small_genome
     from oracle import orc
-    from secphase_amd import records, synth
-    g = small_genome(synth.HIFI, max_secondaries=3, n_paralogs=2, read_len=4000)
-    p = records.preset("hifi")
-    lo, hi = shard.shard_range(n_groups, rank, world)
-    r = g.reads(lo, hi - lo)          # this rank's shard only
-    _, res = orc.run_batch(r.batch, g.ref, p, threads=1, seed=1)   # stands in for the device path on CPU
-    recs = []
-    for i, e in enumerate(res):
-        if e.n_aln <= 0:
-            continue
-        sec = [a for a in range(e.n_aln) if a != e.prim_idx]
-        mxs = max(e.score[a] for a in sec)
-        mx = next(a for a in sec if e.score[a] == mxs)
-        tie = sum(1 << a for a in sec if e.score[a] >= mxs)
-        ok = not (mxs <= e.score[e.prim_idx] + p.prim_margin_score or mxs < p.min_score)
-        recs.append(shard.pack_record(lo + i, e.prim_idx, mx, tie, ok))
-    out = shard.gather_records(torch.tensor(recs, dtype=torch.int64), dist, dst=0)
+    from secphase_amd import api
+    g, p = _setup()
+    # shards by cost: every rank computes the same boundaries from the same cost vector (here: read length as a proxy)
+    whole = g.reads(0, N_GROUPS)
+    b = whole.batch.contents
+    cost = [sum(b.l_qseq[a] for a in range(b.grp_first[k], b.grp_first[k + 1])) ** 1.0 * (1 + 7 * (k < N_GROUPS // 3))
+            for k in range(N_GROUPS)]
+    bounds, imb = shard.shard_by_cost(cost, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    r = g.reads(lo, hi - lo)  # this rank's shard only
+    _, res = orc.run_batch(r.batch, g.ref, p, threads=1, seed=1)
+    out = _results_from_oracle(api, res, p)
+    n = hi - lo
+    L = api.lib()
+    dec = (api.Decision * max(n, 1))()
+    nd = L.spx_decisions_from_results(out, n, lo, dec, n)
+    assert nd >= 0
+    nc = L.spx_relabel_candidates(r.batch, lo, out, C.byref(p), None, 0)
+    cand = (api.RelabelRec * max(nc, 1))()
+    assert L.spx_relabel_candidates(r.batch, lo, out, C.byref(p), cand, nc) == nc
+    dev = torch.device("cpu")
+    dparts = shard.gather_bytes(torch.from_numpy(np.frombuffer(memoryview(dec), np.uint8)[: nd * 16].copy()), dist, torch)
+    cparts = shard.gather_bytes(torch.from_numpy(np.frombuffer(memoryview(cand), np.uint8)[: nc * C.sizeof(api.RelabelRec)].copy()),
+                                dist, torch)
     if rank == 0:
-        np.save(os.path.join(tmp, "gathered.npy"), out)
+        fin = C.c_void_p()
+        api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+        log = os.path.join(tmp, "dist.out.log")
+        open(log, "w").close()
+        ndec, nrec = shard.merge_and_write(api, p, fin, g.ref, dparts, cparts, log)
+        L.spx_finalizer_free(fin)
+        with open(os.path.join(tmp, "info.txt"), "w") as f:
+            f.write(f"{ndec} {nrec} {bounds[1]} {imb}\n")
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_process(built, tmp_path):
-    n_groups = 24
+def test_two_ranks_emit_the_same_relabel_list_as_one_process(built, tmp_path):
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, n_groups, str(tmp_path)), nprocs=2, join=True)
-    got = shard.unpack_records(np.load(str(tmp_path / "gathered.npy")))
-    from common import small_genome
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     from oracle import orc
-    from secphase_amd import records, synth
-    g = small_genome(synth.HIFI, max_secondaries=3, n_paralogs=2, read_len=4000)
-    p = records.preset("hifi")
-    r = g.reads(0, n_groups)
-    _, res = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1)
-    exp = [(i, e) for i, e in enumerate(res) if e.n_aln > 0]
-    assert got["group"].tolist() == [i for i, _ in exp]
-    assert got["prim_idx"].tolist() == [e.prim_idx for _, e in exp]
-    # decisions that do not depend on a draw must agree; (ties are replayed on rank 0 in file order)
-    for k, (i, e) in enumerate(exp):
-        if bin(int(got["tie_mask"][k])).count("1") == 1:
-            best = int(got["max_idx"][k]) if got["passed"][k] else int(got["prim_idx"][k])
-            assert best == e.best_idx, i
+    g, p = _setup()
+    r = g.reads(0, N_GROUPS)
+    log_o = str(tmp_path / "one.out.log")
+    nre, res = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1, log_path=log_o)
+    ndec, nrec, cut, imb = open(str(tmp_path / "info.txt")).read().split()
+    assert int(cut) != N_GROUPS // 2  # the two shards are NOT equally long
+    assert int(ndec) == sum(1 for e in res if e.n_aln >= 2)
+    assert nre > 3 and int(nrec) == nre
+    # tie groups are part of the comparison: at least one group draws twice
+    ties = 0
+    for e in res:
+        if e.n_aln >= 2:
+            sec = [a for a in range(e.n_aln) if a != e.prim_idx]
+            mxs = max(e.score[a] for a in sec)
+            ties += sum(1 for a in sec if e.score[a] >= mxs) > 1
+    assert ties > 0
+    assert filecmp.cmp(log_o, str(tmp_path / "dist.out.log"), shallow=False)
+
+
+def test_decisions_replay_equals_result_replay(built):
+    """spx_finalizer_apply_decisions over packed 16-byte records == spx_finalizer_apply over full results, also with a
+    non-zero prim_margin_random (coin flips) -- the two share one rule, this pins the record layout"""
+    from oracle import orc
+    from secphase_amd import api
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    g, p = _setup()
+    r = g.reads(0, 40)
+    L = api.lib()
+    for pmr in (0.0, 30.0):
+        p.prim_margin_random = pmr
+        _, res = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1)
+        out = _results_from_oracle(api, res, p)
+        dec = (api.Decision * 40)()
+        nd = L.spx_decisions_from_results(out, 40, 0, dec, 40)
+        f1, f2 = C.c_void_p(), C.c_void_p()
+        L.spx_finalizer_create(7, C.byref(f1))
+        L.spx_finalizer_create(7, C.byref(f2))
+        best = (C.c_int8 * 40)()
+        rel = (C.c_int8 * 40)()
+        api._chk(L.spx_finalizer_apply_decisions(f1, C.byref(p), dec, nd, best, rel), "decisions")
+        api._chk(L.spx_finalizer_apply(f2, C.byref(p), out, 40), "results")
+        k = 0
+        for i in range(40):
+            if out[i].n_aln >= 2:
+                assert dec[k].group == i and best[k] == out[i].best_idx and rel[k] == out[i].relabel, i
+                k += 1
+        assert k == nd
+        L.spx_finalizer_free(f1)
+        L.spx_finalizer_free(f2)
+    p.prim_margin_random = 0.0
 
 
 def test_shard_ranges_cover_everything():
@@ -73,3 +157,10 @@ def test_shard_ranges_cover_everything():
             spans = [shard.shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+    rng = np.random.default_rng(5)
+    cost = rng.pareto(1.2, 5000) + 1
+    for w in (2, 4, 8):
+        b, imb = shard.shard_by_cost(cost, w)
+        assert b[0] == 0 and b[-1] == 5000 and all(b[i] <= b[i + 1] for i in range(w))
+        assert imb < 1.25  # heaviest shard within 25 % of the mean on a heavy-tailed cost vector
+    assert shard.shard_by_cost([], 4)[0] == [0, 0, 0, 0, 0]

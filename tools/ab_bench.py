@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--platform", default="hifi")
+    ap.add_argument("--mode", default="kernel", choices=["kernel", "pipe"], help="kernel: --kernel-only replay; pipe: the whole pipelined step")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     res = {}
@@ -25,8 +26,9 @@ def main():
             env.pop("SPX_LIB", None)
             if path:
                 env["SPX_LIB"] = os.path.abspath(path)
+            extra = ["--kernel-only"] if a.mode == "kernel" else ["--no-host-leg"]
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--no-cpu-baseline",
-                                  "--verify", "0", "--platform", a.platform], env=env, capture_output=True, text=True).stdout
+                                  "--verify", "0", "--platform", a.platform] + extra, env=env, capture_output=True, text=True).stdout
             d = json.loads(out.strip().splitlines()[-1])
             res.setdefault(name, []).append(d["value"])
     for name, vals in res.items():
