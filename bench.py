@@ -260,6 +260,8 @@ def main():
             i = (offset + received) % D
             _, n = pipe.next(outbuf)
             finish_step(offset + received, i, n, staged[i] if not from_host else None)
+            if not from_host:
+                staged[i].release()  # the list's HBM goes back to the context for the next step's list
             received += 1
 
     host_leg = None
@@ -268,6 +270,7 @@ def main():
         per_step_stats = [st_k]
     else:
         open(log_path, "w").close()
+        run(args.depth + 1, 0, False)  # set-up, like the staging above: the context's HBM arenas of every pipeline slot exist
         run(args.warmup, 0, False)
         sync_all()
         t0 = time.perf_counter()
@@ -278,10 +281,10 @@ def main():
         if world == 1 and not args.no_host_leg:
             # the same steps fed from HOST memory: staging (host threads) + PCIe copy inside the timed region
             hs = max(2, min(args.steps, 8))
-            run(1, 0, True)
+            run(args.depth + 2, 0, True)  # warm-up: pinned staging buffers and device arenas of every slot exist
             sync_all()
             t1 = time.perf_counter()
-            run(hs, 1, True)
+            run(hs, args.depth + 2, True)
             sync_all()
             el_h = time.perf_counter() - t1
             host_leg = (hs, el_h)

@@ -122,6 +122,8 @@ int spx_prepare_many(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_ba
 int spx_stage(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_batches, const spx_params *par, int host_threads,
               spx_work **work);
 int spx_prepare_staged(spx_ctx *ctx, spx_work *work);
+/* drops the prepared list (its HBM goes back to the context's cache), keeps the staged records */
+int spx_work_release(spx_ctx *ctx, spx_work *work);
 int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */
 int spx_sync(spx_ctx *ctx);
 /* ---- multi-GPU: what crosses ranks (spx_gather.cpp).  Read groups shard over ranks; the relabel list is a property of

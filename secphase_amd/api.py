@@ -93,7 +93,7 @@ EXPORTS = [
     "spx_io_last_error", "spx_bam_open", "spx_bam_n_targets", "spx_bam_target_name", "spx_bam_bind_reference",
     "spx_bam_next_batch", "spx_bam_close", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
-    "spx_stage", "spx_prepare_staged", "spx_work_export",
+    "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
     "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
 ]
@@ -131,6 +131,7 @@ def lib():
         L.spx_stage.argtypes = [vp, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxParams), C.c_int, C.POINTER(vp)]
         L.spx_prepare_staged.argtypes = [vp, vp]
         L.spx_work_export.argtypes = [vp, vp, C.POINTER(vp)]
+        L.spx_work_release.argtypes = [vp, vp]
     if hasattr(L, "spx_decisions_from_results"):
         L.spx_decisions_from_results.argtypes = [C.POINTER(GroupOut), C.c_int32, C.c_int32, C.POINTER(Decision), C.c_int32]
         L.spx_relabel_candidates.argtypes = [C.POINTER(SpxBatch), C.c_int32, C.POINTER(GroupOut), C.POINTER(SpxParams),
@@ -310,6 +311,10 @@ class Work:
     def prepare_staged(self):
         """(re)build the work list on the device from the staged records"""
         _chk(lib().spx_prepare_staged(self.ctx.h, self.h), "spx_prepare_staged")
+
+    def release(self):
+        """drop the prepared list, keep the staged records"""
+        _chk(lib().spx_work_release(self.ctx.h, self.h), "spx_work_release")
 
     def export_plan(self):
         """diagnostics: the device-built work list as a Plan-like object (view, close)"""

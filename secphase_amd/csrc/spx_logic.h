@@ -557,26 +557,23 @@ SPX_HD Mk match_marker(const Rec &r, const AlnState &st, const uint8_t *qual, in
 SPX_HD int group_columns(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk, uint8_t *keep)
 {
     const int n = G.n;
-    int head[10], left[10];
+    int head[10], left[10], hpos[10]; /* hpos: read position of each list's head (0x7fffffff: exhausted) */
     for (int i = 0; i < n; ++i) {
         const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
         left[i] = G.st[i].n_mm;
         head[i] = rev ? G.st[i].n_mm - 1 : 0;
+        hpos[i] = left[i] > 0 ? P.mm[G.st[i].mm_off + head[i]].pos : 0x7fffffff;
     }
     int ncol = 0;
     for (;;) {
-        int best = 0x7fffffff;
+        int best = 0x7fffffff, cnt = 0;
         for (int i = 0; i < n; ++i)
-            if (left[i] > 0) {
-                const int p = P.mm[G.st[i].mm_off + head[i]].pos;
-                if (p < best) best = p;
-            }
+            if (hpos[i] < best) best = hpos[i];
         if (best == 0x7fffffff) break;
-        int cnt = 0;
         for (int i = 0; i < n; ++i)
-            if (left[i] > 0 && P.mm[G.st[i].mm_off + head[i]].pos == best) ++cnt;
+            if (hpos[i] == best) ++cnt;
         for (int i = 0; i < n; ++i) {
-            const bool has = left[i] > 0 && P.mm[G.st[i].mm_off + head[i]].pos == best;
+            const bool has = hpos[i] == best;
             if (cnt != n) {
                 Mk m;
                 if (has) {
@@ -591,6 +588,7 @@ SPX_HD int group_columns(const GroupView &G, const Pools &P, int32_t *pos, Mk *m
                 const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
                 head[i] += rev ? -1 : 1;
                 left[i]--;
+                hpos[i] = left[i] > 0 ? P.mm[G.st[i].mm_off + head[i]].pos : 0x7fffffff;
             }
         }
         if (cnt != n) { pos[ncol] = best; keep[ncol] = 1; ++ncol; }
@@ -877,8 +875,12 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
     int ci = 0;
     const int margin = 10;
     const int last = st.n_ops - 1;
-    auto adv = [&]() -> int { if (ci < last) { ++ci; return ops[ci].len; } return 0; };
+    /* the op and the marker under the two cursors live in registers: every re-read would be a dependent global load */
+    Op co = ops[0];
+    auto adv = [&]() -> int { if (ci < last) { ++ci; co = ops[ci]; return co.len; } return 0; };
     auto own = [&](int col) -> Mk & { return S.mk[(int64_t)col * n + ai]; };
+    int cb = (c >= 0 && c < ncol) ? own(c).base_idx : 0; /* base_idx of this alignment's marker in column c */
+    auto step_c = [&]() { c += step; if (c >= 0 && c < ncol) cb = own(c).base_idx; };
     auto zero_edit = [&](int base) {
         if (!par.all_rows) return;
         if (EMIT) {
@@ -892,17 +894,17 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
     const int nblocks = S.nproj[ai];
     for (int bi = 0; bi < nblocks; ++bi) {
         const Blk b = blocks[bi];
-        while (ops[ci].sqe < b.sqs || ops[ci].rfe < b.rfs)
+        while (co.sqe < b.sqs || co.rfe < b.rfs)
             if (adv() == 0) break;
         /* markers of this alignment in the leading margin lose their quality */
-        while (c >= 0 && c < ncol && own(c).base_idx < b.sqs + margin) {
-            if (b.sqs <= own(c).base_idx) {
+        while (c >= 0 && c < ncol && cb < b.sqs + margin) {
+            if (b.sqs <= cb) {
                 if (EMIT) { own(c).q = 0; own(c).row = -1; }
-                zero_edit(own(c).base_idx);
+                zero_edit(cb);
             }
-            c += step;
+            step_c();
         }
-        if (c >= 0 && c < ncol && own(c).base_idx <= b.sqe - margin && b.sqs + margin <= own(c).base_idx) {
+        if (c >= 0 && c < ncol && cb <= b.sqe - margin && b.sqs + margin <= cb) {
             const int L = b.sqe - b.sqs + 1, R = b.rfe - b.rfs + 1;
             if (L <= 0 || R <= 0) return SPX_EINVAL;
             if (r.tid < 0 || r.tid >= rv.n_contigs || b.rfs < 0 || b.rfe >= rv.len[r.tid]) return SPX_EINVAL;
@@ -921,16 +923,21 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                 if (nrows > S.rows_cap) return SPX_ENOMEM;
                 if (EMIT) for (int t = 0; t < nrows; ++t) S.rows_mk[t] = -1;
             }
-            for (int k = c; k >= 0 && k < ncol; k += step) {
-                if (own(k).base_idx > b.sqe) break;
-                const int t = own(k).base_idx - b.sqs;
-                if (t >= margin && t < L - margin) {
-                    if (par.all_rows) { if (EMIT) S.rows_mk[t - margin] = k; }
-                    else {
-                        if (nrows >= S.rows_cap) return SPX_ENOMEM;
-                        if (EMIT) { S.rows_mk[nrows] = k; out.rows[at.row + nrows] = t + 1; }
-                        ++nrows;
+            {
+                int kb = cb;
+                for (int k = c; k >= 0 && k < ncol;) {
+                    if (kb > b.sqe) break;
+                    const int t = kb - b.sqs;
+                    if (t >= margin && t < L - margin) {
+                        if (par.all_rows) { if (EMIT) S.rows_mk[t - margin] = k; }
+                        else {
+                            if (nrows >= S.rows_cap) return SPX_ENOMEM;
+                            if (EMIT) { S.rows_mk[nrows] = k; out.rows[at.row + nrows] = t + 1; }
+                            ++nrows;
+                        }
                     }
+                    k += step;
+                    if (k >= 0 && k < ncol) kb = own(k).base_idx;
                 }
             }
             const int64_t row0 = at.row;
@@ -946,8 +953,8 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
             /* expected reference index of every wanted base, from the CIGAR walk of the write-back loop; the wanted
              * rows ascend and the M/=/X pieces of a block are disjoint and ascending, so one cursor serves */
             int w = 0;
-            while (ops[ci].sqs <= b.sqe || ops[ci].rfs <= b.rfe) {
-                const Op o = ops[ci];
+            while (co.sqs <= b.sqe || co.rfs <= b.rfe) {
+                const Op o = co;
                 int x = o.rfs - b.rfs, y = o.sqs - b.sqs;
                 if (x < 0) x = 0;
                 if (y < 0) y = 0;
@@ -1017,12 +1024,12 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
             at.f_off += (int64_t)nrows * 2 * slots;
         }
         /* markers in the trailing margin lose their quality */
-        while (c >= 0 && c < ncol && own(c).base_idx <= b.sqe) {
-            if (b.sqe - margin <= own(c).base_idx) {
+        while (c >= 0 && c < ncol && cb <= b.sqe) {
+            if (b.sqe - margin <= cb) {
                 if (EMIT) { own(c).q = 0; own(c).row = -1; }
-                zero_edit(own(c).base_idx);
+                zero_edit(cb);
             }
-            c += step;
+            step_c();
         }
     }
     return 0;

@@ -228,7 +228,12 @@ extern "C" int spx_create(int device, spx_ctx **out)
     spx_ctx *c = new spx_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking));
+    { /* the preparation kernels are long dependent chains on few waves: with high priority they get wave slots as soon
+       * as DP workgroups retire instead of queueing behind a whole DP launch */
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, hi));
+    }
     HIPCHK(hipMalloc((void **)&c->d_tot, sizeof(spx_prep_totals)));
     HIPCHK(hipHostMalloc((void **)&c->h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
@@ -906,6 +911,22 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     if (timing_on())
         fprintf(stderr, "[spx timing] device prepare: counts %.3f s, carve+emit+orders enqueued %.3f s; %zu problems, %zu rows, list %.2f GB\n",
                 t1 - t0, now_s() - t1, np, nr, w->arena_bytes / 1e9);
+    return SPX_OK;
+}
+
+/* gives the prepared list (work list, scratch, outputs) back and keeps the staged records: the next
+ * spx_prepare_staged builds it anew.  Waits for the list's kernels. */
+extern "C" int spx_work_release(spx_ctx *c, spx_work *w)
+{
+    if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
+    if (!w->staged || !w->arena) return SPX_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (w->ev_ready) HIPCHK(hipEventSynchronize(w->ev_ready));
+    if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done));
+    arena_put(c, w->arena, w->arena_cap);
+    w->arena = nullptr;
+    w->prepared = false;
+    w->launched = false;
     return SPX_OK;
 }
 
