@@ -52,6 +52,9 @@ struct Op {
 struct Blk {
     int32_t rfs, rfe, sqs, sqe, rds, rde;
 };
+struct Iv { /* interval in forward-read coordinates, inclusive */
+    int32_t s, e;
+};
 struct MM { /* mismatch marker of one alignment, in op order */
     int32_t pos, base_idx, q, ref_pos;
 };
@@ -520,9 +523,9 @@ SPX_HD GroupArena group_arena_layout(const GroupView &G, bool all_rows, int slac
     A.o_pos = take(4 * (P + 1));
     A.o_mk = take((int64_t)sizeof(Mk) * (P * G.n + 1));
     A.o_keep = take(P + 1);
-    A.o_flank = take((int64_t)sizeof(Blk) * A.blk_cap);
-    A.o_cur = take((int64_t)sizeof(Blk) * A.blk_cap);
-    A.o_nxt = take((int64_t)sizeof(Blk) * A.blk_cap);
+    A.o_flank = take((int64_t)sizeof(Iv) * A.blk_cap);
+    A.o_cur = take((int64_t)sizeof(Iv) * A.blk_cap);
+    A.o_nxt = take((int64_t)sizeof(Iv) * A.blk_cap);
     A.o_proj = take((int64_t)sizeof(Blk) * A.blk_cap * G.n);
     A.o_nproj = take(4 * 16);
     A.o_rowsmk = take(4 * (int64_t)A.rows_cap);
@@ -642,55 +645,74 @@ SPX_HD void sort_blocks(Blk *b, int n)
     }
 }
 
-/* flanking windows of one alignment around every marker cell (find_flanking_blocks) */
-SPX_HD int flank_blocks(const AlnState &st, const int32_t *pos, int ncol, int n, int margin, Blk *out, int cap)
+/* flanking windows of one alignment around every marker cell (find_flanking_blocks).  The reference walks the
+ * marker LIST, which holds every position n times (one cell per alignment): the repeats are replayed from a register. */
+SPX_HD int flank_blocks(const AlnState &st, const int32_t *pos, int ncol, int n, int margin, Iv *out, int cap)
 {
-    auto lo = [&](int p) { const int v = p - margin; return st.rds > v ? st.rds : v; };
-    auto hi = [&](int p) { const int v = p + margin; return st.rde < v ? st.rde : v; };
     int cnt = 0;
-    int start = lo(pos[0]), end = hi(pos[0]);
-    const int64_t total = (int64_t)ncol * n;
-    for (int64_t i = 1; i < total; ++i) {
-        const int p = pos[i / n];
-        const int cs = lo(p), ce = hi(p);
-        if (cs < end) end = ce;
-        else {
-            if (cnt >= cap) return -1;
-            Blk b = {-1, -1, -1, -1, start, end};
-            out[cnt++] = b;
-            start = cs; end = ce;
+    int start = 0, end = 0;
+    for (int col = 0; col < ncol; ++col) {
+        const int p = pos[col];
+        const int v0 = p - margin, v1 = p + margin;
+        const int cs = st.rds > v0 ? st.rds : v0, ce = st.rde < v1 ? st.rde : v1;
+        for (int rep = 0; rep < n; ++rep) {
+            if (col == 0 && rep == 0) { start = cs; end = ce; continue; }
+            if (cs < end) end = ce;
+            else {
+                if (cnt >= cap) return -1;
+                Iv b = {start, end};
+                out[cnt++] = b;
+                start = cs; end = ce;
+            }
         }
     }
     if (cnt >= cap) return -1;
-    Blk b = {-1, -1, -1, -1, start, end};
+    Iv b = {start, end};
     out[cnt++] = b;
     return cnt;
 }
 
-SPX_HD int intersect(const Blk *x, int nx, const Blk *y, int ny, Blk *out, int cap)
+/* ascending by start; the lists are ascending already except in degenerate cases */
+SPX_HD void sort_intervals(Iv *b, int n)
+{
+    for (int i = 1; i < n; ++i) {
+        const Iv t = b[i];
+        int j = i - 1;
+        if (b[j].s <= t.s) continue;
+        while (j >= 0 && b[j].s > t.s) { b[j + 1] = b[j]; --j; }
+        b[j + 1] = t;
+    }
+}
+
+/* intersect_by_rd_f (ptMarker.c:398-435): strict '<' overlap test, windows that merely touch do not intersect.
+ * GetY(j) yields interval j of the second list (an Iv list, or the read coordinates of a block list). */
+template <class GetY>
+SPX_HD int intersect(const Iv *x, int nx, GetY gety, int ny, Iv *out, int cap)
 {
     if (nx == 0 || ny == 0) return 0;
     int cnt = 0, j = 0;
+    Iv y = gety(0);
     for (int i = 0; i < nx; ++i) {
-        while (j < ny && y[j].rde < x[i].rds) ++j;
-        while (j < ny && y[j].rds < x[i].rde) {
+        const Iv xi = x[i];
+        while (j < ny && y.e < xi.s) { ++j; if (j < ny) y = gety(j); }
+        while (j < ny && y.s < xi.e) {
             if (cnt >= cap) return -1;
-            Blk b = {-1, -1, -1, -1, x[i].rds > y[j].rds ? x[i].rds : y[j].rds, x[i].rde < y[j].rde ? x[i].rde : y[j].rde};
+            Iv b = {xi.s > y.s ? xi.s : y.s, xi.e < y.e ? xi.e : y.e};
             out[cnt++] = b;
-            if (y[j].rde <= x[i].rde) ++j; else break;
+            if (y.e <= xi.e) { ++j; if (j < ny) y = gety(j); } else break;
         }
     }
     return cnt;
 }
 
 /* project the consensus intervals cur[0..nb) (read coordinates) onto one alignment (correct_conf_blocks) */
-SPX_HD int project_blocks(const Rec &r, const AlnState &st, const Op *ops, const Blk *cur, int nb, int thr, Blk *out, int cap)
+SPX_HD int project_blocks(const Rec &r, const AlnState &st, const Op *ops, const Iv *cur, int nb, int thr, Blk *out, int cap)
 {
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
     int cnt = 0;
     int j = rev ? nb - 1 : 0;
     bool have = true, del_flag = false;
-    int bs = rev ? -cur[j].rde : cur[j].rds, be = rev ? -cur[j].rds : cur[j].rde;
+    int bs = rev ? -cur[j].e : cur[j].s, be = rev ? -cur[j].s : cur[j].e;
     int rfs = -1, rfe = -1, sqs = -1, sqe = -1;
     for (int t = 1; t < st.n_visit; ++t) {
         const Op o = ops[t];
@@ -705,10 +727,10 @@ SPX_HD int project_blocks(const Rec &r, const AlnState &st, const Op *ops, const
                 rfe = ins ? o.rfe : o.rfs + (be - cs);
                 sqe = o.sqs + (be - cs);
                 if (cnt >= cap) return -1;
-                Blk b = {rfs, rfe, sqs, sqe, cur[j].rds, cur[j].rde};
+                Blk b = {rfs, rfe, sqs, sqe, cur[j].s, cur[j].e};
                 out[cnt++] = b;
-                if (rev && j > 0) { --j; bs = -cur[j].rde; be = -cur[j].rds; }
-                else if (!rev && j < nb - 1) { ++j; bs = cur[j].rds; be = cur[j].rde; }
+                if (rev && j > 0) { --j; bs = -cur[j].e; be = -cur[j].s; }
+                else if (!rev && j < nb - 1) { ++j; bs = cur[j].s; be = cur[j].e; }
                 else have = false;
             }
             if (!have) break;
@@ -734,7 +756,7 @@ struct GroupScratch {
     int32_t *pos;
     Mk *mk;
     uint8_t *keep;
-    Blk *flank, *cur, *nxt;
+    Iv *flank, *cur, *nxt; /* interval lists of the consensus rounds: read coordinates only */
     Blk *proj;       /* [n][blk_cap]: each alignment's current block list (confident blocks, then projected windows) */
     int32_t *nproj;  /* [n] */
     int32_t *rows_mk;
@@ -746,9 +768,9 @@ SPX_HD GroupScratch group_scratch(const GroupArena &A, char *base)
     S.pos = (int32_t *)(base + A.o_pos);
     S.mk = (Mk *)(base + A.o_mk);
     S.keep = (uint8_t *)(base + A.o_keep);
-    S.flank = (Blk *)(base + A.o_flank);
-    S.cur = (Blk *)(base + A.o_cur);
-    S.nxt = (Blk *)(base + A.o_nxt);
+    S.flank = (Iv *)(base + A.o_flank);
+    S.cur = (Iv *)(base + A.o_cur);
+    S.nxt = (Iv *)(base + A.o_nxt);
     S.proj = (Blk *)(base + A.o_proj);
     S.nproj = (int32_t *)(base + A.o_nproj);
     S.rows_mk = (int32_t *)(base + A.o_rowsmk);
@@ -762,47 +784,90 @@ SPX_HD GroupScratch group_scratch(const GroupArena &A, char *base)
 SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, int ncol)
 {
     const int n = G.n, cap = S.blk_cap;
+    bool too_long = false; /* needs_to_find_blocks: a block longer than 1000 (SEQ or reference), or an alignment without blocks */
     for (int i = 0; i < n; ++i) {
         const AlnState &st = G.st[i];
         if (st.n_conf > cap) return SPX_ENOMEM;
         Blk *dst = S.proj + (int64_t)i * cap;
-        for (int k = 0; k < st.n_conf; ++k) dst[k] = P.conf[st.conf_off + k];
+        for (int k = 0; k < st.n_conf; ++k) {
+            const Blk b = P.conf[st.conf_off + k];
+            dst[k] = b;
+            if ((b.sqe - b.sqs) > 1000 || (b.rfe - b.rfs) > 1000) too_long = true;
+        }
         S.nproj[i] = st.n_conf;
+        if (st.n_conf == 0) too_long = true;
     }
     int margin = par.flank_margin, nblk = 1 /* DESIGN.md U1 */, iter = 0;
-    auto too_long = [&]() {
-        bool flag = false;
-        for (int i = 0; i < n; ++i) {
-            if (S.nproj[i] == 0) return true;
-            const Blk *b = S.proj + (int64_t)i * cap;
-            for (int k = 0; k < S.nproj[i]; ++k)
-                if ((b[k].sqe - b[k].sqs) > 1000 || (b[k].rfe - b[k].rfs) > 1000) flag = true;
-        }
-        return flag;
-    };
-    while (par.consensus && too_long()) {
+    /* `same`: every alignment's block list is, in read coordinates, the interval list prev[0..np) of the round before
+     * (see the long-window shortcut below); otherwise the lists are S.proj */
+    bool same = false;
+    Iv *prev = S.flank; /* three buffers rotate: prev / cur / nxt; flank windows are generated into the spare one */
+    int np = 0;
+    Iv *cur = S.cur, *nxt = S.nxt;
+    while (par.consensus && too_long) {
         margin = (int)(margin * 0.8);
         /* intersect every alignment's blocks, then every alignment's flanking windows, in read coordinates */
-        sort_blocks<0>(S.proj, S.nproj[0]);
-        int nc = S.nproj[0];
-        for (int k = 0; k < nc; ++k) S.cur[k] = S.proj[k];
-        Blk *cur = S.cur, *nxt = S.nxt;
-        for (int i = 1; i < n; ++i) {
-            Blk *bi = S.proj + (int64_t)i * cap;
-            sort_blocks<0>(bi, S.nproj[i]);
-            const int m = intersect(cur, nc, bi, S.nproj[i], nxt, cap);
-            if (m < 0) return SPX_ENOMEM;
-            nc = m;
-            Blk *t = cur; cur = nxt; nxt = t;
+        int nc;
+        if (same) {
+            nc = np;
+            for (int k = 0; k < np; ++k) cur[k] = prev[k];
+            for (int i = 1; i < n; ++i) {
+                const Iv *pv = prev;
+                const int m = intersect(cur, nc, [&](int j) { return pv[j]; }, np, nxt, cap);
+                if (m < 0) return SPX_ENOMEM;
+                nc = m;
+                Iv *t = cur; cur = nxt; nxt = t;
+            }
+        } else {
+            sort_blocks<0>(S.proj, S.nproj[0]);
+            nc = S.nproj[0];
+            for (int k = 0; k < nc; ++k) { Iv v = {S.proj[k].rds, S.proj[k].rde}; cur[k] = v; }
+            for (int i = 1; i < n; ++i) {
+                Blk *bi = S.proj + (int64_t)i * cap;
+                sort_blocks<0>(bi, S.nproj[i]);
+                const int m = intersect(cur, nc, [&](int j) { Iv v = {bi[j].rds, bi[j].rde}; return v; }, S.nproj[i], nxt, cap);
+                if (m < 0) return SPX_ENOMEM;
+                nc = m;
+                Iv *t = cur; cur = nxt; nxt = t;
+            }
+        }
+        /* prev is free now: it takes the flanking windows.  With a positive margin and every marker position inside
+         * the aligned extent [rds, rde] of every alignment, the merge decisions (cs < end) do not depend on the extent:
+         * clamping only moves the start of the first window and the end of the last one.  The windows are then built
+         * ONCE without clamping and every alignment reads them through its own clamp. */
+        Iv *fl = prev;
+        bool shared = margin > 0;
+        for (int i = 0; i < n && shared; ++i)
+            shared = G.st[i].rde > G.st[i].rds && S.pos[0] >= G.st[i].rds && S.pos[ncol - 1] <= G.st[i].rde;
+        int nu = 0;
+        if (shared) {
+            AlnState wide = G.st[0];
+            wide.rds = -0x3fffffff; wide.rde = 0x3fffffff;
+            nu = flank_blocks(wide, S.pos, ncol, n, margin, fl, cap);
+            if (nu < 0) return SPX_ENOMEM;
         }
         for (int i = 0; i < n; ++i) {
-            const int nf = flank_blocks(G.st[i], S.pos, ncol, n, margin, S.flank, cap);
-            if (nf < 0) return SPX_ENOMEM;
-            sort_blocks<0>(S.flank, nf);
-            const int m = intersect(cur, nc, S.flank, nf, nxt, cap);
+            int nf, m;
+            if (shared) {
+                nf = nu;
+                const Iv *fv = fl;
+                const int lo = G.st[i].rds, hi = G.st[i].rde, lastj = nu - 1;
+                m = intersect(cur, nc, [&](int j) {
+                    Iv v = fv[j];
+                    if (j == 0 && v.s < lo) v.s = lo;
+                    if (j == lastj && v.e > hi) v.e = hi;
+                    return v;
+                }, nf, nxt, cap);
+            } else {
+                nf = flank_blocks(G.st[i], S.pos, ncol, n, margin, fl, cap);
+                if (nf < 0) return SPX_ENOMEM;
+                sort_intervals(fl, nf);
+                const Iv *fv = fl;
+                m = intersect(cur, nc, [&](int j) { return fv[j]; }, nf, nxt, cap);
+            }
             if (m < 0) return SPX_ENOMEM;
             nc = m;
-            Blk *t = cur; cur = nxt; nxt = t;
+            Iv *t = cur; cur = nxt; nxt = t;
         }
         if (nc == 0) {
             for (int i = 0; i < n; ++i) S.nproj[i] = 0;
@@ -818,22 +883,26 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
          * itself.  The last permitted round always projects for real. */
         bool long_window = false;
         for (int k = 0; k < nc; ++k)
-            if (cur[k].rde - cur[k].rds > 1000) long_window = true;
+            if (cur[k].e - cur[k].s > 1000) long_window = true;
+        nblk = nc;
         if (long_window && iter < 64) {
+            same = true;
+            Iv *t = prev; prev = cur; cur = t; /* this round's windows become `prev` */
+            np = nc;
+            too_long = true;
+        } else {
+            same = false;
+            too_long = false;
             for (int i = 0; i < n; ++i) {
                 Blk *dst = S.proj + (int64_t)i * cap;
-                for (int k = 0; k < nc; ++k) { Blk b = {0, 0, cur[k].rds, cur[k].rde, cur[k].rds, cur[k].rde}; dst[k] = b; }
-                S.nproj[i] = nc;
-            }
-        } else {
-            for (int i = 0; i < n; ++i) {
-                const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, cur, nc, par.indel_threshold,
-                                             S.proj + (int64_t)i * cap, cap);
+                const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, cur, nc, par.indel_threshold, dst, cap);
                 if (m < 0) return SPX_ENOMEM;
                 S.nproj[i] = m;
+                if (m == 0) too_long = true;
+                for (int k = 0; k < m; ++k)
+                    if ((dst[k].sqe - dst[k].sqs) > 1000 || (dst[k].rfe - dst[k].rfs) > 1000) too_long = true;
             }
         }
-        nblk = nc;
         if (iter >= 64) break;
     }
     return (nblk > 0 || !par.consensus) ? 1 : 0;

@@ -19,6 +19,8 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "spx_logic.h"
 #include "spx_prep_dev.h"
 
@@ -28,30 +30,32 @@ using namespace spxl;
 __global__ __launch_bounds__(256) void recode_kernel(const uint32_t *__restrict__ raw, uint32_t *__restrict__ code, int64_t n_words,
                                                      const Rec *__restrict__ recs, int32_t n_slots, AlnState *__restrict__ ast)
 {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const uint32_t x = raw[w];
+    /* grid-stride: a few thousand fat waves instead of a block per KB -- this kernel runs beside the DP kernels of the
+     * previous batch, where every new workgroup waits for a wave slot */
     const uint64_t tbl = 0x4444444344424104ull; /* seq_nt16_int, one nibble per nt16 code */
-    uint32_t out = 0, nmask = 0;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = raw[w];
+        uint32_t out = 0, nmask = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const uint32_t byte = (x >> (8 * b)) & 0xffu;
-        const uint32_t hi = (uint32_t)(tbl >> (4 * (byte >> 4))) & 0xfu, lo = (uint32_t)(tbl >> (4 * (byte & 0xfu))) & 0xfu;
-        out |= (hi | (lo << 4)) << (8 * b);
-        if (hi > 3) nmask |= 1u << (2 * b);
-        if (lo > 3) nmask |= 1u << (2 * b + 1);
-    }
-    code[w] = out;
-    if (nmask) { /* rare: find the alignment this word belongs to and flag it if the base lies inside its SEQ */
-        const int64_t byte0 = w * 4;
-        int lo = 0, hi = n_slots - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (recs[mid].seq_off <= byte0) lo = mid; else hi = mid - 1;
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t byte = (x >> (8 * b)) & 0xffu;
+            const uint32_t hi = (uint32_t)(tbl >> (4 * (byte >> 4))) & 0xfu, lo = (uint32_t)(tbl >> (4 * (byte & 0xfu))) & 0xfu;
+            out |= (hi | (lo << 4)) << (8 * b);
+            if (hi > 3) nmask |= 1u << (2 * b);
+            if (lo > 3) nmask |= 1u << (2 * b + 1);
         }
-        const int64_t nib0 = (byte0 - recs[lo].seq_off) * 2;
-        for (int k = 0; k < 8; ++k)
-            if (((nmask >> k) & 1) && nib0 + k < recs[lo].l_qseq) { ast[lo].has_n = 1; break; }
+        code[w] = out;
+        if (nmask) { /* rare: find the alignment this word belongs to and flag it if the base lies inside its SEQ */
+            const int64_t byte0 = w * 4;
+            int lo = 0, hi = n_slots - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (recs[mid].seq_off <= byte0) lo = mid; else hi = mid - 1;
+            }
+            const int64_t nib0 = (byte0 - recs[lo].seq_off) * 2;
+            for (int k = 0; k < 8; ++k)
+                if (((nmask >> k) & 1) && nib0 + k < recs[lo].l_qseq) { ast[lo].has_n = 1; break; }
+        }
     }
 }
 
@@ -311,7 +315,7 @@ extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *ra
     if (A->n_slots <= 0) return hipSuccess;
     hipLaunchKernelGGL(aln_count_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
     if (seq_words > 0)
-        hipLaunchKernelGGL(recode_kernel, dim3((unsigned)((seq_words + 255) / 256)), dim3(256), 0, st, raw_seq,
+        hipLaunchKernelGGL(recode_kernel, dim3((unsigned)std::min<int64_t>((seq_words + 255) / 256, 2048)), dim3(256), 0, st, raw_seq,
                            (uint32_t *)(A->code4_w + A->P.code_lead_bytes), seq_words, A->recs, A->n_slots, A->ast);
     hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(1024), 0, st, *A);
     hipLaunchKernelGGL(aln_build_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);

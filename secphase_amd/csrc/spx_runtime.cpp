@@ -108,6 +108,7 @@ struct spx_ctx {
     /* work-list preparation on the device: its own stream (it overlaps the DP kernels of the previous list), pools
      * that only live during a preparation and are shared by all of them (prep_mu serialises preparations) */
     hipStream_t prep_stream = nullptr;
+    int prep_cus = 0; /* CUs reserved for the preparation stream (0: no CU masks) */
     std::mutex prep_mu;
     struct DevBuf {
         void *p = nullptr;
@@ -227,20 +228,42 @@ extern "C" int spx_create(int device, spx_ctx **out)
         return fail(SPX_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     spx_ctx *c = new spx_ctx();
     c->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    { /* the preparation kernels are long dependent chains on few waves: with high priority they get wave slots as soon
-       * as DP workgroups retire instead of queueing behind a whole DP launch */
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, hi));
+    /* Optional spatial partition of the chip (SPX_PREP_CUS=k, off by default): k CUs are reserved for the preparation
+     * stream and masked out of the DP streams.  Measured on MI355X (round 2): the DP kernels fill every SIMD's register
+     * file, so preparation waves launched beside them wait for the DP launch to drain -- but the preparation kernels
+     * are scattered-load bound and need far more than 16-32 CUs to finish within a DP step, so reserving CUs loses
+     * (127 / 82 ms per step with 16 / 32 CUs against 63 ms without masks).  Kept for experiments. */
+    int prep_cus = 0;
+    if (const char *e = getenv("SPX_PREP_CUS")) prep_cus = atoi(e);
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> m_prep((size_t)(ncu + 31) / 32, 0u), m_dp((size_t)(ncu + 31) / 32, 0u);
+    bool masked = prep_cus > 0 && prep_cus < ncu / 2;
+    if (masked) {
+        /* queue CU masks on a multi-XCD part: bit i names CU i / 8 of XCD i % 8 (the driver deals the bits round-robin
+         * over the XCDs), so a block of 8k consecutive bits takes k CUs from EVERY XCD -- anything else would leave one
+         * XCD short and the DP kernels, whose workgroups are dealt evenly over the XCDs, would wait for it */
+        prep_cus = (prep_cus + 7) / 8 * 8;
+        for (int i = 0; i < ncu; ++i) (i < prep_cus ? m_prep : m_dp)[(size_t)i / 32] |= 1u << (i % 32);
     }
+    auto mk_stream = [&](hipStream_t *st, const std::vector<uint32_t> &mask) -> hipError_t {
+        if (masked) {
+            hipError_t e = hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+            if (e == hipSuccess) return e;
+            (void)hipGetLastError();
+            masked = false; /* not supported here: plain streams for everything created from now on */
+        }
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    HIPCHK(mk_stream(&c->prep_stream, m_prep));
+    c->prep_cus = masked ? prep_cus : 0;
+    HIPCHK(mk_stream(&c->stream, m_dp));
     HIPCHK(hipMalloc((void **)&c->d_tot, sizeof(spx_prep_totals)));
     HIPCHK(hipHostMalloc((void **)&c->h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
     for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
     for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking));
+        HIPCHK(mk_stream(&c->side_stream[i], m_dp));
         HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
     }
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));

@@ -34,13 +34,14 @@ def main():
     ap.add_argument("--groups-per-step", type=int, default=0)
     ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "pmc_tmp"))
     ap.add_argument("--extra", nargs="*", default=[], help="more arguments for bench.py")
+    ap.add_argument("--full", action="store_true", help="the whole pipelined step (preparation kernels included) instead of --kernel-only")
     a = ap.parse_args()
     os.environ.setdefault("TMPDIR", "/tmp")
     res, meta = {}, {"platform": a.platform, "steps": a.steps, "warmup": a.warmup, "passes": PASSES,
                      "note": "each pass = rocprofv3 --pmc <counters> -- python3 bench.py ...; dispatches are serialised under "
                              "--pmc, so duration_ns_alone is the kernel alone on the chip; FETCH_SIZE/WRITE_SIZE in KB"}
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--platform", a.platform, "--steps", str(a.steps), "--warmup",
-             str(a.warmup), "--no-cpu-baseline", "--verify", "0", "--kernel-only"] + a.extra
+             str(a.warmup), "--no-cpu-baseline", "--verify", "0"] + (["--no-host-leg", "--depth", "1"] if a.full else ["--kernel-only"]) + a.extra
     if a.groups_per_step:
         bench += ["--groups-per-step", str(a.groups_per_step)]
     for k, ctrs in enumerate(PASSES):
