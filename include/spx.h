@@ -255,7 +255,9 @@ const char *spx_bam_target_name(const spx_bam_reader *r, int32_t i);
 /* map BAM target ids to the contig indices of `ref` by name; returns the number of targets the FASTA lacks */
 int spx_bam_bind_reference(spx_bam_reader *r, const spx_ref *ref);
 /* up to max_groups complete name groups (consecutive records with one read name, src/secphase.c:273-279);
- * the batch is owned by the reader and valid until the next call; returns groups read, 0 at EOF, <0 on error */
+ * the batch is owned by the reader and stays valid for the next SPX_BAM_KEEP calls (a pipelined caller has several
+ * batches in flight); returns groups read, 0 at EOF, <0 on error */
+#define SPX_BAM_KEEP 6
 int spx_bam_next_batch(spx_bam_reader *r, int32_t max_groups, const spx_batch **out);
 void spx_bam_close(spx_bam_reader *r);
 /* -w/--writeBam (src/secphase.c:182-189,643-657): the reference opens the output with sam_open(path, "w"), i.e.
@@ -266,6 +268,8 @@ void spx_bam_close(spx_bam_reader *r);
 typedef struct spx_sam_writer spx_sam_writer;
 int spx_sam_open(const char *path, const spx_bam_reader *src, spx_sam_writer **out);
 int spx_sam_write_group(spx_sam_writer *w, const spx_bam_reader *src, int32_t g, const uint8_t *qual);
+/* the same for group g of an EARLIER batch of the reader that is still alive (SPX_BAM_KEEP) */
+int spx_sam_write_group_of(spx_sam_writer *w, const spx_bam_reader *src, const spx_batch *bt, int32_t g, const uint8_t *qual);
 int spx_sam_close(spx_sam_writer *w);
 int spx_fasta_load(const char *path, spx_fasta **out);
 const spx_ref *spx_fasta_ref(const spx_fasta *f);

@@ -95,7 +95,7 @@ EXPORTS = [
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
-    "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
+    "spx_sam_write_group_of", "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
 ]
 
 _lib = None

@@ -199,59 +199,76 @@ int main(int argc, char *argv[])
 
     fprintf(stderr, "[%s] Started parsing alignments\n", timestamp());
     long long n_alns = 0, n_reads = 0, n_modified = 0, n_rejected = 0;
-    double t_read = 0, t_prep = 0, t_gpu = 0, t_out = 0, t_start = now_s(), t_hostprep = 0, t_h2d = 0, t_kernel = 0;
+    double t_read = 0, t_wait = 0, t_out = 0, t_start = now_s(), t_hostprep = 0, t_kernel = 0;
     std::vector<spx_group_out> out;
+    /* the reference hands every group to a pool thread and serialises the output with a mutex; here whole batches
+     * flow through an in-order pipeline: while batch k is on the GPU, batch k+1 is staged and copied, batch k+2 is
+     * inflated by the reader, and the results of batch k-1 are written -- in file order */
+    const int depth = 3;
+    spx_pipe *pipe = nullptr;
+    if (marker_mode && (rc = spx_pipe_create(ctx, &par, depth, threads, &pipe)) != SPX_OK) {
+        fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
+        return 1;
+    }
+    bool eof = false;
+    int inflight = 0;
     for (;;) {
-        const spx_batch *bt = nullptr;
-        double t0 = now_s();
-        int ng = spx_bam_next_batch(bam, groups_per_batch, &bt);
-        t_read += now_s() - t0;
-        if (ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), spx_io_last_error()); return 1; }
-        if (ng == 0) break;
-        n_alns += bt->n_alns;
-        n_reads += ng;
-        if (marker_mode) {
-            spx_work *w = nullptr;
-            t0 = now_s();
-            if ((rc = spx_prepare(ctx, bt, &par, threads, &w)) != SPX_OK || (rc = spx_launch(ctx, w)) != SPX_OK) {
+        while (!eof && inflight < depth + 1 && inflight < SPX_BAM_KEEP - 1) {
+            const spx_batch *bt = nullptr;
+            double t0 = now_s();
+            int ng = spx_bam_next_batch(bam, groups_per_batch, &bt);
+            t_read += now_s() - t0;
+            if (ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), spx_io_last_error()); return 1; }
+            if (ng == 0) { eof = true; break; }
+            n_alns += bt->n_alns;
+            n_reads += ng;
+            if (!marker_mode) continue;
+            if ((rc = spx_pipe_submit(pipe, &bt, 1, nullptr, 0, (void *)bt)) != SPX_OK) {
                 fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
                 return 1;
             }
-            t_prep += now_s() - t0;
-            t0 = now_s();
-            out.resize(ng);
-            if ((rc = spx_collect(ctx, w, out.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
-            t_gpu += now_s() - t0;
-            { spx_stats st; spx_work_stats(w, &st); t_hostprep += st.prep_seconds; t_h2d += st.h2d_seconds; t_kernel += st.kernel_seconds; }
+            ++inflight;
+        }
+        if (inflight == 0) break;
+        spx_work *w = nullptr;
+        void *tag = nullptr;
+        double t0 = now_s();
+        out.resize((size_t)groups_per_batch + 1);
+        const int ng = spx_pipe_next(pipe, out.data(), groups_per_batch, &w, &tag);
+        t_wait += now_s() - t0;
+        --inflight;
+        if (ng < 0) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(ng), spx_last_error()); return 1; }
+        const spx_batch *bt = (const spx_batch *)tag;
+        { spx_stats st; spx_work_stats(w, &st); t_hostprep += st.prep_seconds; t_kernel += st.kernel_seconds; }
+        for (int g = 0; g < ng; ++g)
+            if (out[g].n_aln == SPX_ENOTAG) { /* the reference stops here: cigar_it.c:64-67 */
+                fprintf(stderr, "At least one of the MD or CS tags should be present!\n");
+                return 1;
+            }
+        t0 = now_s();
+        if (sam) { /* src/secphase.c:182-189: written before the decision, file order = the reference at -@1 */
+            int64_t qend = 0;
+            for (int32_t a = 0; a < bt->n_alns; ++a) qend = std::max<int64_t>(qend, bt->qual_off[a] + bt->l_qseq[a]);
+            qbuf.assign(bt->qual, bt->qual + qend);
+            if ((rc = spx_apply_quals(ctx, w, 0, bt, qbuf.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
             for (int g = 0; g < ng; ++g)
-                if (out[g].n_aln == SPX_ENOTAG) { /* the reference stops here: cigar_it.c:64-67 */
-                    fprintf(stderr, "At least one of the MD or CS tags should be present!\n");
+                if (spx_group_is_dispatched(bt, g) && spx_sam_write_group_of(sam, bam, bt, g, qbuf.data()) < 0) {
+                    fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error());
                     return 1;
                 }
-            t0 = now_s();
-            if (sam) { /* src/secphase.c:182-189: written before the decision, file order = the reference at -@1 */
-                int64_t qend = 0;
-                for (int32_t a = 0; a < bt->n_alns; ++a) qend = std::max<int64_t>(qend, bt->qual_off[a] + bt->l_qseq[a]);
-                qbuf.assign(bt->qual, bt->qual + qend);
-                if ((rc = spx_apply_quals(ctx, w, 0, bt, qbuf.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
-                for (int g = 0; g < ng; ++g)
-                    if (spx_group_is_dispatched(bt, g) && spx_sam_write_group(sam, bam, g, qbuf.data()) < 0) {
-                        fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error());
-                        return 1;
-                    }
-            }
-            spx_finalizer_apply(fin, &par, out.data(), ng);
-            spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
-            n_modified += spx_relabel_blocks(w, ref, out.data(), bed_mod, bed_mk);
-            for (int g = 0; g < ng; ++g) if (out[g].n_aln < 0) ++n_rejected;
-            spx_work_free(ctx, w);
-            t_out += now_s() - t0;
         }
+        spx_finalizer_apply(fin, &par, out.data(), ng);
+        spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
+        n_modified += spx_relabel_blocks(w, ref, out.data(), bed_mod, bed_mk);
+        for (int g = 0; g < ng; ++g) if (out[g].n_aln < 0) ++n_rejected;
+        spx_work_free(ctx, w);
+        t_out += now_s() - t0;
         fprintf(stderr, "[%s] #parsed alignments = %lld, #parsed reads = %lld, #modifed by phased variants = 0, #modifed by markers = %lld\n",
                 timestamp(), n_alns, n_reads, n_modified);
     }
-    fprintf(stderr, "[%s] time in the scoring loop: %.3f s (BAM read+inflate %.3f, prepare+upload %.3f, wait for GPU+download %.3f, "
-                    "finalise+write %.3f); inside prepare: host logic %.3f, upload %.3f; GPU kernels %.3f\n", timestamp(), now_s() - t_start, t_read, t_prep, t_gpu, t_out, t_hostprep, t_h2d, t_kernel);
+    if (pipe) spx_pipe_destroy(pipe);
+    fprintf(stderr, "[%s] time in the scoring loop: %.3f s (BAM read+inflate not hidden by the read-ahead %.3f, waiting for results %.3f, "
+                    "finalise+write %.3f); on pipeline threads: staging %.3f; GPU kernels %.3f\n", timestamp(), now_s() - t_start, t_read, t_wait, t_out, t_hostprep, t_kernel);
     if (n_rejected) fprintf(stderr, "[%s] %lld read group(s) use constructs the reference leaves undefined and were skipped\n", timestamp(), n_rejected);
     fprintf(stderr, "[%s] Number of reads modified by phased variants = 0\n", timestamp());
     fprintf(stderr, "[%s] Number of reads modified by marker score = %lld\n", timestamp(), n_modified);

@@ -91,7 +91,10 @@ struct Reader {
     std::vector<int64_t> tlen;
     std::vector<int32_t> tmap; /* BAM tid -> contig index of the reference handed to the scorer (-1 unknown) */
     std::string header_text;
-    Slot slot[2];
+    /* ring of batches: the caller may keep the last SPX_BAM_SLOTS - 2 batches alive (a pipelined caller has several in
+     * flight), one more is being read ahead */
+    static const int NSLOT = 8;
+    Slot slot[NSLOT];
     int cur = 0;
     std::future<void> pending; /* the NEXT batch is read while the caller works on the current one */
     bool have_pending = false;
@@ -438,7 +441,7 @@ extern "C" int spx_bam_next_batch(spx_bam_reader *h, int32_t max_groups, const s
     Reader *r = &h->r;
     if (r->have_pending && r->pending_max == max_groups) {
         r->pending.get();
-        r->cur ^= 1; /* the slot the background task filled */
+        r->cur = (r->cur + 1) % Reader::NSLOT; /* the slot the background task filled */
     } else {
         if (r->have_pending) r->pending.get(); /* different batch size requested: cannot happen in the CLI */
         fill_slot(r, r->slot[r->cur], max_groups);
@@ -448,7 +451,7 @@ extern "C" int spx_bam_next_batch(spx_bam_reader *h, int32_t max_groups, const s
     *out = &S.view;
     if (S.rc < 0) return S.rc;
     if (S.ng > 0) {
-        Slot *nxt = &r->slot[r->cur ^ 1];
+        Slot *nxt = &r->slot[(r->cur + 1) % Reader::NSLOT];
         r->pending_max = max_groups;
         r->pending = std::async(std::launch::async, [r, nxt, max_groups]() { fill_slot(r, *nxt, max_groups); });
         r->have_pending = true;
@@ -595,11 +598,8 @@ static bool format_sam(const Reader &r, const uint8_t *p, int32_t bs, const uint
 
 /* group g of the reader's CURRENT batch; `qual` is laid out like that batch's qual[] (NULL: the record's own
  * qualities).  Unmapped records are skipped, as the reference never stores them (src/secphase.c:340). */
-extern "C" int spx_sam_write_group(spx_sam_writer *w, const spx_bam_reader *src, int32_t g, const uint8_t *qual)
+static int sam_write_group_of(spx_sam_writer *w, const Reader &r, const Slot &S, int32_t g, const uint8_t *qual)
 {
-    if (!w || !src) return SPX_EINVAL;
-    const Reader &r = src->r;
-    const Slot &S = r.slot[r.cur];
     if (g < 0 || g >= S.ng) return SPX_EINVAL;
     int n = 0;
     for (int32_t a = S.grp_first[g]; a < S.grp_first[g + 1]; ++a) {
@@ -612,6 +612,22 @@ extern "C" int spx_sam_write_group(spx_sam_writer *w, const spx_bam_reader *src,
         if (fwrite(w->line.data(), 1, w->line.size(), w->fp) != w->line.size()) { g_io_err = "write failed"; return SPX_EINVAL; }
     }
     return n;
+}
+
+extern "C" int spx_sam_write_group(spx_sam_writer *w, const spx_bam_reader *src, int32_t g, const uint8_t *qual)
+{
+    if (!w || !src) return SPX_EINVAL;
+    return sam_write_group_of(w, src->r, src->r.slot[src->r.cur], g, qual);
+}
+
+/* the same for a batch handed out earlier and still alive (pipelined callers) */
+extern "C" int spx_sam_write_group_of(spx_sam_writer *w, const spx_bam_reader *src, const spx_batch *bt, int32_t g, const uint8_t *qual)
+{
+    if (!w || !src || !bt) return SPX_EINVAL;
+    for (int k = 0; k < Reader::NSLOT; ++k)
+        if (&src->r.slot[k].view == bt) return sam_write_group_of(w, src->r, src->r.slot[k], g, qual);
+    g_io_err = "batch is no longer held by the reader";
+    return SPX_EINVAL;
 }
 
 extern "C" int spx_sam_close(spx_sam_writer *w)

@@ -546,3 +546,79 @@ def test_command_line_stops_on_records_without_tags(ctx, tmp_path):
     p = subprocess.run([exe, "--hifi", "-i", bam, "-f", fa, "--outDir", outd], capture_output=True, text=True, timeout=300)
     assert p.returncode == 1
     assert "At least one of the MD or CS tags should be present!" in p.stderr
+
+
+def test_pipeline_in_order_equals_one_shot_scoring(ctx):
+    """spx_pipe: batches submitted from host memory and staged work lists (records resident in HBM, prepared again for
+    every submission) come back in submission order with the very results spx_score_batch gives; device-packed
+    16-byte decision records equal the ones built from the collected results"""
+    g = small_genome(synth.HIFI, max_secondaries=3, n_paralogs=2, hardclip_frac=0.2, softclip_frac=0.3, read_len=5000)
+    par = records.preset("hifi")
+    ctx.set_reference(g.ref)
+    sizes = [17, 40, 3, 29, 64, 8, 31]
+    reads, first = [], 0
+    for n in sizes:
+        reads.append(g.reads(first, n))
+        first += n
+    want = []
+    for r in reads:
+        out, _ = ctx.score_batch(r.batch, par, finalize_seed=None)
+        want.append([(o.n_aln, tuple(o.score[a] for a in range(max(o.n_aln, 0))), o.prim_idx, o.max_idx, o.tie_mask, o.pass_,
+                      tuple(o.rfe[a] for a in range(max(o.n_aln, 0))), o.n_problems, o.n_markers, o.dp_cells) for o in out])
+
+    def sig(out, n):
+        return [(o.n_aln, tuple(o.score[a] for a in range(max(o.n_aln, 0))), o.prim_idx, o.max_idx, o.tie_mask, o.pass_,
+                 tuple(o.rfe[a] for a in range(max(o.n_aln, 0))), o.n_problems, o.n_markers, o.dp_cells) for o in out[:n]]
+
+    pipe = api.Pipe(ctx, par, depth=3, host_threads=8)
+    staged = [ctx.stage(r.batch, par) for r in reads]
+    for rnd in range(2):  # the second round re-prepares the same staged records
+        got = []
+        sub = 0
+        for k in range(len(reads)):
+            while sub < len(reads) and pipe.pending() < 4:
+                if (sub + rnd) % 2 == 0:
+                    pipe.submit(batch=reads[sub].batch)
+                else:
+                    pipe.submit(staged=staged[sub])
+                sub += 1
+            out, n = pipe.next()
+            assert n == sizes[k]
+            got.append(sig(out, n))
+        assert got == want, rnd
+    # decision records: device pack kernel vs host conversion of the collected results
+    import torch
+    w = staged[4]
+    w.prepare_staged()
+    w.launch()
+    out = w.collect(finalize_seed=None)
+    dev = torch.zeros(sizes[4] * 16, dtype=torch.uint8, device="cuda")
+    nd = w.pack_decisions(1000, dev.data_ptr(), sizes[4])
+    host = (api.Decision * sizes[4])()
+    nh = api.lib().spx_decisions_from_results(out, sizes[4], 1000, host, sizes[4])
+    raw = dev.cpu().numpy().tobytes()
+    drec = [api.Decision.from_buffer_copy(raw[16 * k:16 * k + 16]) for k in range(nd)]
+    drec = [d for d in drec if d.n_aln >= 2]
+    assert len(drec) == nh
+    for a, b in zip(drec, host):
+        assert (a.group, a.n_aln, a.prim_idx, a.max_idx, a.pass_, a.tie_mask, a.absdiff) == \
+               (b.group, b.n_aln, b.prim_idx, b.max_idx, b.pass_, b.tie_mask, b.absdiff)
+    pipe.close()
+    for s in staged:
+        s.free()
+
+
+def test_pipeline_reports_group_errors_in_place(ctx):
+    """a group the reference cannot score (N op in the CIGAR) keeps its slot and its error code inside a pipelined batch"""
+    from common import HandBatch, HandRef
+    seq = "ACGT" * 10
+    hr = HandRef([("c0", seq * 4)])
+    hb = HandBatch([("bad", [(0, 0, 0, "20M5N20M", seq, 30, ":20:20"), (256, 0, 3, "40M", seq, 30, ":40")]),
+                    ("ok", [(0, 0, 0, "40M", seq, 30, ":40"), (256, 0, 3, "38M", seq[:38], 30, ":38")]),
+                    ("notag", [(0, 0, 0, "40M", seq, 30, ":40"), (256, 0, 3, "38M", seq[:38], 30, None)])])
+    ctx.set_reference(hr.ref)
+    pipe = api.Pipe(ctx, records.preset("hifi"), depth=2, host_threads=2)
+    pipe.submit(batch=hb.batch)
+    out, n = pipe.next()
+    assert n == 3 and out[0].n_aln == api.EUNSUPPORTED and out[1].n_aln == 2 and out[2].n_aln == api.ENOTAG
+    pipe.close()
