@@ -80,9 +80,19 @@ struct Slot {
     }
 };
 
+struct CChunk { /* compressed blocks of one chunk */
+    std::vector<uint8_t> cbuf;
+    std::vector<Block> blocks;
+    bool eof = false;
+    std::string err;
+};
+
 struct Reader {
     FILE *fp = nullptr;
-    std::vector<uint8_t> cbuf;     /* compressed blocks of the current chunk */
+    CChunk cchunk[2];              /* the chunk being inflated and the one a helper thread reads ahead */
+    int ccur = 0;
+    std::future<void> ahead;
+    bool have_ahead = false;
     RawBuf leftover; /* inflated bytes after the last complete group of the previous batch */
     bool eof = false;
     int threads = 4;
@@ -117,59 +127,87 @@ bool read_chunk(Reader *r, RawBuf &ubuf)
     r->t_inflate += (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
     return ok;
 }
-bool read_chunk_impl(Reader *r, RawBuf &ubuf)
+/* compressed side of one chunk: up to kChunkBlocks BGZF blocks read from the file (serial freads).  It is fetched by a
+ * helper thread while the previous chunk is being inflated on the worker threads. */
+static const int kChunkBlocks = 4096; /* ~256 MB inflated */
+static void read_compressed(Reader *r, CChunk &c)
 {
-    if (r->eof) return false;
-    r->cbuf.clear();
-    std::vector<Block> blocks;
-    size_t utot = ubuf.size();
-    for (int n = 0; n < 1024; ++n) {
+    c.cbuf.clear();
+    c.blocks.clear();
+    c.eof = false;
+    c.err.clear();
+    size_t utot = 0;
+    for (int n = 0; n < kChunkBlocks; ++n) {
         uint8_t hdr[18];
         size_t got = fread(hdr, 1, 18, r->fp);
-        if (got == 0) { r->eof = true; break; }
-        if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { g_io_err = "not a BGZF block"; r->eof = true; return false; }
+        if (got == 0) { c.eof = true; break; }
+        if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { c.err = "not a BGZF block"; c.eof = true; return; }
         const unsigned xlen = hdr[10] | (hdr[11] << 8);
         /* the BC subfield is first in every BAM written by htslib/samtools; general case: scan the extra field */
         std::vector<uint8_t> extra(xlen);
         memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
-        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, r->fp) != xlen - 6) { g_io_err = "truncated BGZF header"; r->eof = true; return false; }
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, r->fp) != xlen - 6) { c.err = "truncated BGZF header"; c.eof = true; return; }
         int bsize = -1;
         for (size_t o = 0; o + 4 <= xlen;) {
             const unsigned slen = extra[o + 2] | (extra[o + 3] << 8);
             if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = extra[o + 4] | (extra[o + 5] << 8);
             o += 4 + slen;
         }
-        if (bsize < 0) { g_io_err = "BGZF block without BC field"; r->eof = true; return false; }
+        if (bsize < 0) { c.err = "BGZF block without BC field"; c.eof = true; return; }
         const size_t clen = (size_t)bsize + 1 - 12 - xlen; /* deflate data + crc32 + isize */
-        const size_t coff = r->cbuf.size();
-        r->cbuf.resize(coff + clen);
-        if (fread(r->cbuf.data() + coff, 1, clen, r->fp) != clen || clen < 8) { g_io_err = "truncated BGZF block"; r->eof = true; return false; }
-        const uint8_t *t = r->cbuf.data() + coff + clen - 4;
+        const size_t coff = c.cbuf.size();
+        c.cbuf.resize(coff + clen);
+        if (fread(c.cbuf.data() + coff, 1, clen, r->fp) != clen || clen < 8) { c.err = "truncated BGZF block"; c.eof = true; return; }
+        const uint8_t *t = c.cbuf.data() + coff + clen - 4;
         const size_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((size_t)t[3] << 24);
-        blocks.push_back({coff, clen - 8, utot, isize});
+        c.blocks.push_back({coff, clen - 8, utot, isize});
         utot += isize;
     }
+}
+
+bool read_chunk_impl(Reader *r, RawBuf &ubuf)
+{
+    if (r->eof && !r->have_ahead) return false;
+    CChunk *c = &r->cchunk[r->ccur];
+    if (r->have_ahead) {
+        r->ahead.get(); /* the helper thread has filled cchunk[ccur] */
+        r->have_ahead = false;
+    } else
+        read_compressed(r, *c);
+    if (!c->err.empty()) { g_io_err = c->err; r->eof = true; return false; }
+    if (c->eof) r->eof = true;
+    if (!r->eof) { /* fetch the next chunk's compressed bytes while this one is inflated */
+        r->ccur ^= 1;
+        CChunk *nx = &r->cchunk[r->ccur];
+        r->ahead = std::async(std::launch::async, [r, nx]() { read_compressed(r, *nx); });
+        r->have_ahead = true;
+    }
+    const std::vector<Block> &blocks = c->blocks;
     if (blocks.empty()) return false;
-    ubuf.resize(utot);
+    const size_t ubase = ubuf.size();
+    ubuf.resize(ubase + blocks.back().uoff + blocks.back().ulen);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
     auto work = [&]() {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
         for (;;) {
-            size_t k = next.fetch_add(1);
+            size_t k = next.fetch_add(4);
             if (k >= blocks.size()) break;
-            const Block &b = blocks[k];
-            if (b.ulen == 0) continue;
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; continue; }
-            zs.next_in = r->cbuf.data() + b.coff; zs.avail_in = (uInt)b.clen;
-            zs.next_out = ubuf.data() + b.uoff; zs.avail_out = (uInt)b.ulen;
-            int rc = inflate(&zs, Z_FINISH);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
-            inflateEnd(&zs);
+            for (size_t q = k; q < std::min(blocks.size(), k + 4); ++q) {
+                const Block &b = blocks[q];
+                if (b.ulen == 0) continue;
+                if (inflateReset(&zs) != Z_OK) { bad = 1; continue; }
+                zs.next_in = c->cbuf.data() + b.coff; zs.avail_in = (uInt)b.clen;
+                zs.next_out = ubuf.data() + ubase + b.uoff; zs.avail_out = (uInt)b.ulen;
+                int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
+            }
         }
+        inflateEnd(&zs);
     };
-    int nt = std::max(1, std::min<int>(r->threads, (int)blocks.size()));
+    int nt = std::max(1, std::min<int>(r->threads, (int)(blocks.size() + 3) / 4));
     if (nt == 1) work();
     else {
         std::vector<std::thread> th;
@@ -342,7 +380,7 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
     S.ubuf.swap(r->leftover);
     r->leftover.clear();
     RawBuf &u = S.ubuf;
-    u.reserve(r->last_batch_bytes + r->last_batch_bytes / 8 + (96u << 20)); /* one allocation per batch, not a doubling chain */
+    u.reserve(r->last_batch_bytes + r->last_batch_bytes / 8 + (320u << 20)); /* one allocation per batch, not a doubling chain */
     size_t at = 0;
     bool open_group = false;
     for (;;) {
@@ -463,6 +501,7 @@ extern "C" void spx_bam_close(spx_bam_reader *h)
 {
     if (!h) return;
     if (h->r.have_pending) h->r.pending.get();
+    if (h->r.have_ahead) h->r.ahead.get();
     if (h->r.fp) fclose(h->r.fp);
     delete h;
 }
