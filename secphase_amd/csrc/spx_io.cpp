@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -127,6 +128,30 @@ bool read_chunk(Reader *r, RawBuf &ubuf)
     r->t_inflate += (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
     return ok;
 }
+/* libdeflate inflates BGZF blocks 2-3x faster than zlib.  The image ships its runtime library without headers, so the
+ * three entry points are bound at run time (their C signatures are part of libdeflate's stable ABI); zlib is what
+ * runs when the library is not there. */
+struct Deflate {
+    void *(*alloc)(void) = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    Deflate()
+    {
+        if (getenv("SPX_NO_LIBDEFLATE")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        if (!alloc || !decompress || !release) alloc = nullptr;
+    }
+};
+static const Deflate &deflate_lib()
+{
+    static const Deflate d;
+    return d;
+}
+
 /* compressed side of one chunk: up to kChunkBlocks BGZF blocks read from the file (serial freads).  It is fetched by a
  * helper thread while the previous chunk is being inflated on the worker threads. */
 static const int kChunkBlocks = 4096; /* ~256 MB inflated */
@@ -188,7 +213,24 @@ bool read_chunk_impl(Reader *r, RawBuf &ubuf)
     ubuf.resize(ubase + blocks.back().uoff + blocks.back().ulen);
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);
+    const Deflate &DL = deflate_lib();
     auto work = [&]() {
+        if (DL.alloc) {
+            void *d = DL.alloc();
+            if (!d) { bad = 1; return; }
+            for (;;) {
+                size_t k = next.fetch_add(4);
+                if (k >= blocks.size()) break;
+                for (size_t q = k; q < std::min(blocks.size(), k + 4); ++q) {
+                    const Block &b = blocks[q];
+                    if (b.ulen == 0) continue;
+                    size_t got = 0;
+                    if (DL.decompress(d, c->cbuf.data() + b.coff, b.clen, ubuf.data() + ubase + b.uoff, b.ulen, &got) != 0 || got != b.ulen) bad = 1;
+                }
+            }
+            DL.release(d);
+            return;
+        }
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
