@@ -528,7 +528,7 @@ SPX_HD GroupArena group_arena_layout(const GroupView &G, bool all_rows, int slac
     A.o_nxt = take((int64_t)sizeof(Iv) * A.blk_cap);
     A.o_proj = take((int64_t)sizeof(Blk) * A.blk_cap * G.n);
     A.o_nproj = take(4 * 16);
-    A.o_rowsmk = take(4 * (int64_t)A.rows_cap);
+    A.o_rowsmk = take(4 * (int64_t)A.rows_cap * (G.n > 0 ? G.n : 1)); /* one list per alignment: their passes run side by side */
     A.bytes = o;
     return A;
 }
@@ -553,11 +553,14 @@ SPX_HD Mk match_marker(const Rec &r, const AlnState &st, const uint8_t *qual, in
     return m;
 }
 
-/* marker columns of a group: k-way merge of the alignments' mismatch lists by read position, positions where every
- * alignment mismatches dropped (remove_all_mismatch_markers), the others completed with match markers
- * (sort_and_fill_markers), then columns inside an insertion / clip of any alignment dropped and the reference
- * positions of match markers inside '=' ops filled in (filter_ins_markers).  Returns the number of columns kept. */
-SPX_HD int group_columns(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk, uint8_t *keep)
+/* Marker columns of a group, in three steps so that the middle one can run one alignment per thread:
+ * group_merge   k-way merge of the alignments' mismatch lists by read position, positions where every alignment
+ *               mismatches dropped (remove_all_mismatch_markers), the others completed with match markers
+ *               (sort_and_fill_markers); returns the number of columns
+ * aln_filter    one alignment's walk over its ops and the columns (filter_ins_markers): columns inside an insertion /
+ *               clip are marked for removal, the reference positions of its match markers inside '=' ops filled in
+ * group_compact removes the marked columns; returns the number kept */
+SPX_HD int group_merge(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk, uint8_t *keep)
 {
     const int n = G.n;
     int head[10], left[10], hpos[10]; /* hpos: read position of each list's head (0x7fffffff: exhausted) */
@@ -596,27 +599,37 @@ SPX_HD int group_columns(const GroupView &G, const Pools &P, int32_t *pos, Mk *m
         }
         if (cnt != n) { pos[ncol] = best; keep[ncol] = 1; ++ncol; }
     }
-    if (ncol == 0) return 0;
-    /* positions inside an insertion / clip of any alignment are not comparable: drop the column */
-    for (int i = 0; i < n; ++i) {
-        const Rec &r = G.rec[i];
-        const AlnState &st = G.st[i];
-        const bool rev = (r.flag & SPX_FREVERSE) != 0;
-        const Op *ops = P.ops + st.ops_off;
-        int col = rev ? ncol - 1 : 0;
-        const int step = rev ? -1 : 1;
-        for (int t = 1; t < st.n_visit && col >= 0 && col < ncol; ++t) {
-            const Op o = ops[t];
-            while (col >= 0 && col < ncol) {
-                const int p = pos[col];
-                if (!(o.rds <= p && p <= o.rde)) break;
-                if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) keep[col] = 0;
-                if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
-                    mk[(int64_t)col * n + i].ref_pos = rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
-                col += step;
-            }
+    return ncol;
+}
+
+SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, uint8_t *keep, int ncol)
+{
+    /* positions inside an insertion / clip of any alignment are not comparable: the column goes */
+    const int n = G.n;
+    const Rec &r = G.rec[i];
+    const AlnState &st = G.st[i];
+    const bool rev = (r.flag & SPX_FREVERSE) != 0;
+    const Op *ops = P.ops + st.ops_off;
+    int col = rev ? ncol - 1 : 0;
+    const int step = rev ? -1 : 1;
+    if (ncol <= 0) return;
+    int p = pos[col];
+    for (int t = 1; t < st.n_visit && col >= 0 && col < ncol; ++t) {
+        const Op o = ops[t];
+        while (col >= 0 && col < ncol) {
+            if (!(o.rds <= p && p <= o.rde)) break;
+            if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) keep[col] = 0; /* (every alignment writes the same 0) */
+            if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
+                mk[(int64_t)col * n + i].ref_pos = rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
+            col += step;
+            if (col >= 0 && col < ncol) p = pos[col];
         }
     }
+}
+
+SPX_HD int group_compact(const GroupView &G, int32_t *pos, Mk *mk, const uint8_t *keep, int ncol)
+{
+    const int n = G.n;
     int w = 0;
     for (int c = 0; c < ncol; ++c) {
         if (!keep[c]) continue;
@@ -961,6 +974,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
     };
     const Blk *blocks = S.proj + (int64_t)ai * S.blk_cap;
     const int nblocks = S.nproj[ai];
+    int32_t *rows_mk = S.rows_mk + (int64_t)ai * S.rows_cap;
     for (int bi = 0; bi < nblocks; ++bi) {
         const Blk b = blocks[bi];
         while (co.sqe < b.sqs || co.rfe < b.rfs)
@@ -990,7 +1004,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
             if (par.all_rows) {
                 nrows = L - 2 * margin > 0 ? L - 2 * margin : 0;
                 if (nrows > S.rows_cap) return SPX_ENOMEM;
-                if (EMIT) for (int t = 0; t < nrows; ++t) S.rows_mk[t] = -1;
+                if (EMIT) for (int t = 0; t < nrows; ++t) rows_mk[t] = -1;
             }
             {
                 int kb = cb;
@@ -998,10 +1012,10 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                     if (kb > b.sqe) break;
                     const int t = kb - b.sqs;
                     if (t >= margin && t < L - margin) {
-                        if (par.all_rows) { if (EMIT) S.rows_mk[t - margin] = k; }
+                        if (par.all_rows) { if (EMIT) rows_mk[t - margin] = k; }
                         else {
                             if (nrows >= S.rows_cap) return SPX_ENOMEM;
-                            if (EMIT) { S.rows_mk[nrows] = k; out.rows[at.row + nrows] = t + 1; }
+                            if (EMIT) { rows_mk[nrows] = k; out.rows[at.row + nrows] = t + 1; }
                             ++nrows;
                         }
                     }
@@ -1050,7 +1064,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
             }
             if (EMIT) {
                 for (int w2 = 0; w2 < nrows; ++w2) {
-                    const int k = S.rows_mk[w2];
+                    const int k = rows_mk[w2];
                     if (k < 0) continue;
                     Mk &m = own(k);
                     if (out.row_expect[row0 + w2] >= 0) m.row = (int32_t)(row0 + w2);
@@ -1111,53 +1125,94 @@ SPX_HD void problem_constants(const Params &par, int L, int R, uint8_t has_n, do
     h[SPX_H_PAD0] = has_n ? 1.0 : 0.0;
 }
 
-/* pass 1 of a group: columns, consensus windows, work-list sizes.  The marker table and the block lists stay in the
- * group's scratch for pass 2. */
-SPX_HD void group_count(const GroupView &G, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S, GroupCount &gc)
+/* ---- the passes of a read group.  G* run one group per thread, A* one alignment per thread (the walks over ops and
+ * markers are per alignment and make up most of the work); the marker table and the block lists stay in the group's
+ * scratch in between.  The host plan calls them in the same order. ---- */
+SPX_HD void count_clear(GroupCount &gc)
 {
     gc.err = 0; gc.scored = 0; gc.n_cols = 0; gc.n_prob = 0; gc.n_rows = 0; gc.n_qe = 0;
     gc.cells = 0; gc.s_need = 0; gc.f_need = 0;
     for (int k = 0; k < SPX_N_CLASSES; ++k) { gc.cls_prob[k] = 0; gc.cls_cells[k] = 0; }
+}
+
+/* G1: error checks + marker columns before the insertion / clip filter (gc.n_cols = their number) */
+SPX_HD void group_pass_merge(const GroupView &G, const Pools &P, const RefView &rv, GroupScratch &S, GroupCount &gc)
+{
+    count_clear(gc);
+    for (int i = 0; i < G.n; ++i) S.nproj[i] = 0;
     for (int i = 0; i < G.n; ++i)
         if (G.st[i].err) { gc.err = G.st[i].err; return; }
     for (int i = 0; i < G.n; ++i)
         if (G.rec[i].tid < 0 || G.rec[i].tid >= rv.n_contigs) { gc.err = SPX_EINVAL; return; }
-    const int ncol = group_columns(G, P, S.pos, S.mk, S.keep);
+    gc.n_cols = group_merge(G, P, S.pos, S.mk, S.keep);
+}
+
+/* A1 */
+SPX_HD void aln_pass_filter(const GroupView &G, int i, const Pools &P, GroupScratch &S, const GroupCount &gc)
+{
+    if (gc.err || gc.n_cols == 0) return;
+    aln_filter(G, i, P, S.pos, S.mk, S.keep, gc.n_cols);
+}
+
+/* G2: filtered columns, consensus windows */
+SPX_HD void group_pass_blocks(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, GroupCount &gc)
+{
+    if (gc.err || gc.n_cols == 0) return;
+    const int ncol = group_compact(G, S.pos, S.mk, S.keep, gc.n_cols);
     gc.n_cols = ncol;
-    for (int i = 0; i < G.n; ++i) S.nproj[i] = 0;
     if (ncol == 0) return;
     const int sc = group_blocks(G, P, par, S, ncol);
     if (sc < 0) { gc.err = sc; gc.n_cols = 0; return; }
     gc.scored = sc;
-    if (!sc) { gc.n_cols = 0; return; }
-    if (par.baq_flag) {
-        PlanBase at = {0, 0, 0, 0, 0};
-        PlanOut none = {};
-        for (int i = 0; i < G.n; ++i) {
-            const int rc = plan_baq<false>(G, i, P, rv, par, S, ncol, gc, at, none);
-            if (rc) {
-                gc.err = rc; gc.scored = 0; gc.n_cols = 0; gc.n_prob = 0; gc.n_rows = 0; gc.n_qe = 0;
-                gc.cells = 0; gc.s_need = 0; gc.f_need = 0;
-                for (int k = 0; k < SPX_N_CLASSES; ++k) { gc.cls_prob[k] = 0; gc.cls_cells[k] = 0; }
-                return;
-            }
+    if (!sc) gc.n_cols = 0;
+}
+
+/* A2: work-list sizes of one alignment (ac.err: SPX_E* of its BAQ plan) */
+SPX_HD void aln_pass_count(const GroupView &G, int i, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S,
+                           const GroupCount &gc, GroupCount &ac)
+{
+    count_clear(ac);
+    if (gc.err || !gc.scored || !par.baq_flag) return;
+    PlanBase at = {0, 0, 0, 0, 0};
+    PlanOut none = {};
+    const int rc = plan_baq<false>(G, i, P, rv, par, S, gc.n_cols, ac, at, none);
+    if (rc) { count_clear(ac); ac.err = rc; }
+}
+
+/* G3: sums of the group; an alignment's error (the first in alignment order) makes the whole group an error and
+ * clears every count */
+SPX_HD void group_pass_sum(const GroupView &G, GroupCount &gc, GroupCount *ac)
+{
+    if (gc.err) return;
+    for (int i = 0; i < G.n; ++i)
+        if (ac[i].err) {
+            const int e = ac[i].err;
+            count_clear(gc);
+            gc.err = e;
+            for (int k = 0; k < G.n; ++k) count_clear(ac[k]);
+            return;
         }
+    for (int i = 0; i < G.n; ++i) {
+        gc.n_prob += ac[i].n_prob; gc.n_rows += ac[i].n_rows; gc.n_qe += ac[i].n_qe;
+        gc.cells += ac[i].cells; gc.s_need += ac[i].s_need; gc.f_need += ac[i].f_need;
+        for (int k = 0; k < SPX_N_CLASSES; ++k) { gc.cls_prob[k] += ac[i].cls_prob[k]; gc.cls_cells[k] += ac[i].cls_cells[k]; }
     }
 }
 
-/* pass 2: writes the group's problems / rows / edits at `at`, then its marker table at mk_out (n_cols * n entries) */
-SPX_HD int group_emit(const GroupView &G, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S,
-                      const GroupCount &gc, PlanBase at, const PlanOut &out, spx_dev_marker *mk_out, int32_t *mk_ref_pos)
+/* A3: problems / rows / edits of one alignment at `at`, marker updates on its own cells */
+SPX_HD int aln_pass_emit(const GroupView &G, int i, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S,
+                         const GroupCount &gc, PlanBase at, const PlanOut &out)
 {
-    if (gc.err || !gc.scored) return 0;
+    if (gc.err || !gc.scored || !par.baq_flag) return 0;
+    GroupCount dummy;
+    return plan_baq<true>(G, i, P, rv, par, S, gc.n_cols, dummy, at, out); /* same control flow as the counting pass */
+}
+
+/* G4: the group's marker table (n_cols * n entries) */
+SPX_HD void group_pass_markers(const GroupView &G, GroupScratch &S, const GroupCount &gc, spx_dev_marker *mk_out, int32_t *mk_ref_pos)
+{
+    if (gc.err || !gc.scored) return;
     const int n = G.n, ncol = gc.n_cols;
-    if (par.baq_flag) {
-        GroupCount dummy = gc;
-        for (int i = 0; i < n; ++i) {
-            const int rc = plan_baq<true>(G, i, P, rv, par, S, ncol, dummy, at, out);
-            if (rc) return rc; /* cannot happen: the counting pass went through the same control flow */
-        }
-    }
     for (int c = 0; c < ncol; ++c)
         for (int i = 0; i < n; ++i) {
             const Mk m = S.mk[(int64_t)c * n + i];
@@ -1170,7 +1225,6 @@ SPX_HD int group_emit(const GroupView &G, const Pools &P, const RefView &rv, con
             mk_out[(int64_t)c * n + i] = dm;
             mk_ref_pos[(int64_t)c * n + i] = m.ref_pos;
         }
-    return 0;
 }
 
 } // namespace spxl

@@ -336,33 +336,60 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
                                                       conf.data() + a.conf_off, mm.data() + a.mm_off);
         }
     });
-    /* pass C: per group, columns + windows + counts (scratch kept for pass D) */
-    std::vector<spxl::GroupCount> gc((size_t)ng);
+    /* the group / alignment passes, in the order the device runs them (scratch kept between them) */
+    std::vector<spxl::GroupCount> gc((size_t)ng), ac((size_t)ns);
     std::vector<spxl::GroupArena> ga((size_t)ng);
     std::vector<int64_t> ga_off((size_t)ng + 1, 0);
+    std::vector<int32_t> slot_grp((size_t)ns);
+    for (int64_t k = 0; k < ng; ++k)
+        for (int32_t q = st.slot0[(size_t)k]; q < st.slot0[(size_t)k + 1]; ++q) slot_grp[(size_t)q] = (int32_t)k;
+    auto view = [&](int64_t k) {
+        spxl::GroupView G = {st.slot0[(size_t)k + 1] - st.slot0[(size_t)k], recs + st.slot0[(size_t)k], ast.data() + st.slot0[(size_t)k]};
+        return G;
+    };
     int slack = 1;
     std::vector<char> arena;
     for (;;) {
         for (int64_t k = 0; k < ng; ++k) {
-            spxl::GroupView G = {st.slot0[(size_t)k + 1] - st.slot0[(size_t)k], recs + st.slot0[(size_t)k], ast.data() + st.slot0[(size_t)k]};
-            ga[(size_t)k] = spxl::group_arena_layout(G, lp.all_rows != 0, slack);
+            ga[(size_t)k] = spxl::group_arena_layout(view(k), lp.all_rows != 0, slack);
             ga_off[(size_t)k + 1] = ga_off[(size_t)k] + ga[(size_t)k].bytes;
         }
         arena.assign((size_t)ga_off[(size_t)ng] + 64, 0);
+        auto scratch = [&](int64_t k) { return spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k]); };
         std::atomic<int> overflow(0);
-        parallel_for(ng, threads, [&](int64_t k0, int64_t k1) {
+        parallel_for(ng, threads, [&](int64_t k0, int64_t k1) { /* G1 */
+            for (int64_t k = k0; k < k1; ++k) { spxl::GroupScratch S = scratch(k); spxl::group_pass_merge(view(k), P, rv, S, gc[(size_t)k]); }
+        });
+        parallel_for(ns, threads, [&](int64_t q0, int64_t q1) { /* A1 */
+            for (int64_t q = q0; q < q1; ++q) {
+                const int64_t k = slot_grp[(size_t)q];
+                spxl::GroupScratch S = scratch(k);
+                spxl::aln_pass_filter(view(k), (int)(q - st.slot0[(size_t)k]), P, S, gc[(size_t)k]);
+            }
+        });
+        parallel_for(ng, threads, [&](int64_t k0, int64_t k1) { /* G2 */
             for (int64_t k = k0; k < k1; ++k) {
-                spxl::GroupView G = {st.slot0[(size_t)k + 1] - st.slot0[(size_t)k], recs + st.slot0[(size_t)k], ast.data() + st.slot0[(size_t)k]};
-                spxl::GroupScratch S = spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k]);
-                spxl::group_count(G, P, rv, lp, S, gc[(size_t)k]);
+                spxl::GroupScratch S = scratch(k);
+                spxl::group_pass_blocks(view(k), P, lp, S, gc[(size_t)k]);
                 if (gc[(size_t)k].err == SPX_ENOMEM) overflow = 1;
             }
         });
+        if (!overflow) {
+            parallel_for(ns, threads, [&](int64_t q0, int64_t q1) { /* A2 */
+                for (int64_t q = q0; q < q1; ++q) {
+                    const int64_t k = slot_grp[(size_t)q];
+                    spxl::GroupScratch S = scratch(k);
+                    spxl::aln_pass_count(view(k), (int)(q - st.slot0[(size_t)k]), P, rv, lp, S, gc[(size_t)k], ac[(size_t)q]);
+                    if (ac[(size_t)q].err == SPX_ENOMEM) overflow = 1;
+                }
+            });
+        }
         if (!overflow || slack >= 64) break;
         slack *= 4; /* an interval list outgrew its estimate: bigger scratch, same computation */
     }
+    for (int64_t k = 0; k < ng; ++k) spxl::group_pass_sum(view(k), gc[(size_t)k], ac.data() + st.slot0[(size_t)k]); /* G3 */
     /* offsets: errored groups are left out of the work list (their code goes to grp_error) */
-    std::vector<spxl::PlanBase> base((size_t)ng);
+    std::vector<spxl::PlanBase> base((size_t)ns + 1);
     std::vector<int64_t> mk_base((size_t)ng + 1, 0);
     std::vector<int32_t> okidx((size_t)ng, -1);
     spxl::PlanBase tot = {0, 0, 0, 0, 0};
@@ -370,12 +397,15 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
     hb.grp_error = st.grp_error;
     for (int64_t k = 0; k < ng; ++k) {
         const spxl::GroupCount &c = gc[(size_t)k];
-        base[(size_t)k] = tot;
         mk_base[(size_t)k + 1] = mk_base[(size_t)k];
+        for (int32_t q = st.slot0[(size_t)k]; q < st.slot0[(size_t)k + 1]; ++q) {
+            const spxl::GroupCount &a = ac[(size_t)q];
+            base[(size_t)q] = tot;
+            tot.prob += a.n_prob; tot.row += a.n_rows; tot.qe += a.n_qe; tot.s_off += a.s_need; tot.f_off += a.f_need;
+        }
         if (c.err) { hb.grp_error[(size_t)st.grp_index[(size_t)k]] = c.err; continue; }
         okidx[(size_t)k] = n_ok++;
         const int n = st.slot0[(size_t)k + 1] - st.slot0[(size_t)k];
-        tot.prob += c.n_prob; tot.row += c.n_rows; tot.qe += c.n_qe; tot.s_off += c.s_need; tot.f_off += c.f_need;
         mk_base[(size_t)k + 1] += (int64_t)c.n_cols * n;
         hb.dp_cells += c.cells;
     }
@@ -399,17 +429,23 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
     out.rows = hb.rows.data(); out.row_expect = hb.row_expect.data(); out.row_prob = row_prob.data(); out.row_rawq = hb.row_rawq.data();
     out.qe_rec = hb.qe_rec.data(); out.qe_pos = hb.qe_pos.data(); out.qe_len = hb.qe_len.data(); out.qe_row0 = hb.qe_row0.data();
     out.qe_batch = hb.qe_batch.data();
-    /* pass D: emit */
-    parallel_for(ng, threads, [&](int64_t k0, int64_t k1) {
+    auto scratch = [&](int64_t k) { return spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k]); };
+    parallel_for(ns, threads, [&](int64_t q0, int64_t q1) { /* A3 */
+        for (int64_t q = q0; q < q1; ++q) {
+            const int64_t k = slot_grp[(size_t)q];
+            spxl::GroupScratch S = scratch(k);
+            spxl::aln_pass_emit(view(k), (int)(q - st.slot0[(size_t)k]), P, rv, lp, S, gc[(size_t)k], base[(size_t)q], out);
+        }
+    });
+    parallel_for(ng, threads, [&](int64_t k0, int64_t k1) { /* G4 + the per-group arrays */
         for (int64_t k = k0; k < k1; ++k) {
             const spxl::GroupCount &c = gc[(size_t)k];
             if (c.err) continue;
             const int32_t kk = okidx[(size_t)k];
-            const int n = st.slot0[(size_t)k + 1] - st.slot0[(size_t)k];
-            spxl::GroupView G = {n, recs + st.slot0[(size_t)k], ast.data() + st.slot0[(size_t)k]};
-            spxl::GroupScratch S = spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k]);
-            spxl::group_emit(G, P, rv, lp, S, c, base[(size_t)k], out, hb.markers.data() + mk_base[(size_t)k],
-                             hb.mk_ref_pos.data() + mk_base[(size_t)k]);
+            spxl::GroupView G = view(k);
+            const int n = G.n;
+            spxl::GroupScratch S = scratch(k);
+            spxl::group_pass_markers(G, S, c, hb.markers.data() + mk_base[(size_t)k], hb.mk_ref_pos.data() + mk_base[(size_t)k]);
             hb.grp_index[(size_t)kk] = st.grp_index[(size_t)k];
             hb.mk_first[(size_t)kk + 1] = (int32_t)mk_base[(size_t)k + 1];
             hb.n_aln[(size_t)kk] = (uint8_t)n;

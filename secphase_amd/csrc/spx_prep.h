@@ -6,6 +6,7 @@
 #ifndef SPX_PREP_H
 #define SPX_PREP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include <vector>

@@ -35,7 +35,8 @@ struct spx_prep_args {
     int64_t ops_cap, conf_cap, mm_cap;
     spxl::RefView rv;
     spxl::Params par;
-    spxl::GroupCount *gc;
+    spxl::GroupCount *gc;  /* per dispatched group */
+    spxl::GroupCount *ac;  /* per alignment: its share of the work list */
     int64_t *ga_bytes, *ga_off;
     char *arena;
     int64_t arena_cap;
@@ -44,7 +45,7 @@ struct spx_prep_args {
 };
 
 struct spx_emit_args {
-    const spxl::PlanBase *base;
+    const spxl::PlanBase *base; /* per alignment */
     const int64_t *mk_base;
     spxl::PlanOut out;
     double *hmm;      /* [n_prob][SPX_H_N], filled by problem_constants_kernel */

@@ -7,8 +7,11 @@
  *   recode_kernel        SEQ (BAM nt16, high nibble first) -> 0..4 codes the DP kernels read, coalesced
  *   aln_count_kernel     one thread per alignment: size of its op table, bounds of its mismatch / block lists
  *   aln_build_kernel     one thread per alignment: op table, aligned extents, confident blocks, mismatch list
- *   group_count_kernel   one thread per read group: marker columns, consensus windows, work-list sizes
- *   group_emit_kernel    one thread per read group: DP problems (with their HMM constants), wanted rows, marker table
+ *   group_merge / aln_filter / group_blocks / aln_count_plan / group_sum kernels
+ *                        marker columns, consensus windows, work-list sizes: the passes over one group alternate with
+ *                        the passes over one alignment (the walks over ops and markers: most of the work)
+ *   aln_emit / group_finish / problem_constants kernels
+ *                        DP problems (with their HMM constants), wanted rows, marker table
  *   scan kernels         exclusive prefix sums that turn the counts into offsets (single workgroup, LDS)
  *   order kernels        launch orders of the band classes: radix sort by (class, band, length) + padding to whole waves
  *
@@ -97,24 +100,90 @@ __global__ __launch_bounds__(64) void group_arena_kernel(spx_prep_args A)
     A.ga_bytes[k] = group_arena_layout(G, A.par.all_rows != 0, A.slack).bytes;
 }
 
-__global__ __launch_bounds__(64) void group_count_kernel(spx_prep_args A)
+/* ---- the passes of spx_logic.h: G* one read group per thread, A* one alignment per thread ---- */
+struct GroupCtx {
+    GroupView G;
+    GroupScratch S;
+    bool ok;
+};
+__device__ __forceinline__ GroupCtx group_ctx(const spx_prep_args &A, int k)
+{
+    GroupCtx c;
+    const int s0 = A.slot0[k];
+    c.G.n = A.slot0[k + 1] - s0;
+    c.G.rec = A.recs + s0;
+    c.G.st = A.ast + s0;
+    const GroupArena ga = group_arena_layout(c.G, A.par.all_rows != 0, A.slack);
+    c.ok = A.ga_off[k] + ga.bytes <= A.arena_cap;
+    c.S = group_scratch(ga, A.arena + A.ga_off[k]);
+    return c;
+}
+
+__global__ __launch_bounds__(64) void group_merge_kernel(spx_prep_args A)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n_dgroups) return;
-    const int s0 = A.slot0[k];
-    GroupView G = {A.slot0[k + 1] - s0, A.recs + s0, A.ast + s0};
-    const GroupArena ga = group_arena_layout(G, A.par.all_rows != 0, A.slack);
+    GroupCtx c = group_ctx(A, k);
     GroupCount gc;
-    if (A.ga_off[k] + ga.bytes > A.arena_cap) {
+    if (!c.ok) {
         A.tot->overflow = 1;
-        gc.err = SPX_ENOMEM; gc.scored = 0; gc.n_cols = 0; gc.n_prob = 0; gc.n_rows = 0; gc.n_qe = 0; gc.cells = 0; gc.s_need = 0; gc.f_need = 0;
-        for (int c = 0; c < SPX_N_CLASSES; ++c) { gc.cls_prob[c] = 0; gc.cls_cells[c] = 0; }
+        count_clear(gc);
+        gc.err = SPX_ENOMEM;
         A.gc[k] = gc;
         return;
     }
-    GroupScratch S = group_scratch(ga, A.arena + A.ga_off[k]);
-    group_count(G, A.P, A.rv, A.par, S, gc);
+    group_pass_merge(c.G, A.P, A.rv, c.S, gc);
+    A.gc[k] = gc;
+}
+
+__global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    const int k = A.recs[s].grp;
+    const GroupCount gc = A.gc[k];
+    if (gc.err || gc.n_cols == 0) return;
+    GroupCtx c = group_ctx(A, k);
+    aln_pass_filter(c.G, s - A.slot0[k], A.P, c.S, gc);
+}
+
+__global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    GroupCount gc = A.gc[k];
+    if (gc.err || gc.n_cols == 0) return;
+    GroupCtx c = group_ctx(A, k);
+    group_pass_blocks(c.G, A.P, A.par, c.S, gc);
     if (gc.err == SPX_ENOMEM) A.tot->overflow = 2; /* an interval list outgrew its estimate: repeat with more slack */
+    A.gc[k] = gc;
+}
+
+__global__ __launch_bounds__(64) void aln_count_plan_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    const int k = A.recs[s].grp;
+    const GroupCount gc = A.gc[k];
+    GroupCount ac;
+    if (gc.err || !gc.scored) { count_clear(ac); A.ac[s] = ac; return; }
+    GroupCtx c = group_ctx(A, k);
+    aln_pass_count(c.G, s - A.slot0[k], A.P, A.rv, A.par, c.S, gc, ac);
+    if (ac.err == SPX_ENOMEM) A.tot->overflow = 2;
+    A.ac[s] = ac;
+}
+
+__global__ __launch_bounds__(64) void group_sum_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    GroupCount gc = A.gc[k];
+    GroupView G;
+    const int s0 = A.slot0[k];
+    G.n = A.slot0[k + 1] - s0;
+    G.rec = A.recs + s0;
+    G.st = A.ast + s0;
+    group_pass_sum(G, gc, A.ac + s0);
     A.gc[k] = gc;
     for (int c = 0; c < SPX_N_CLASSES; ++c)
         if (gc.cls_prob[c]) {
@@ -123,30 +192,37 @@ __global__ __launch_bounds__(64) void group_count_kernel(spx_prep_args A)
         }
 }
 
-__global__ __launch_bounds__(64) void group_emit_kernel(spx_prep_args A, spx_emit_args E)
+__global__ __launch_bounds__(64) void aln_emit_kernel(spx_prep_args A, spx_emit_args E)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    const int k = A.recs[s].grp;
+    const GroupCount gc = A.gc[k];
+    if (gc.err || !gc.scored) return;
+    GroupCtx c = group_ctx(A, k);
+    aln_pass_emit(c.G, s - A.slot0[k], A.P, A.rv, A.par, c.S, gc, E.base[s], E.out);
+}
+
+__global__ __launch_bounds__(64) void group_finish_kernel(spx_prep_args A, spx_emit_args E)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n_dgroups) return;
-    const int s0 = A.slot0[k];
-    const int n = A.slot0[k + 1] - s0;
-    GroupView G = {n, A.recs + s0, A.ast + s0};
     const GroupCount gc = A.gc[k];
-    const GroupArena ga = group_arena_layout(G, A.par.all_rows != 0, A.slack);
-    GroupScratch S = group_scratch(ga, A.arena + A.ga_off[k]);
-    const PlanBase at = E.base[k];
+    GroupCtx c = group_ctx(A, k);
+    const int n = c.G.n;
     const int64_t mk0 = E.mk_base[k];
-    group_emit(G, A.P, A.rv, A.par, S, gc, at, E.out, E.markers + mk0, E.mk_ref_pos + mk0);
+    group_pass_markers(c.G, c.S, gc, E.markers + mk0, E.mk_ref_pos + mk0);
     const bool ok = gc.err == 0;
     E.mk_first[k] = (int32_t)mk0;
     if (k == A.n_dgroups - 1) E.mk_first[k + 1] = (int32_t)(mk0 + (ok ? (int64_t)gc.n_cols * n : 0));
-    E.n_aln[k] = ok ? (uint8_t)n : 0; /* a group with an error takes no part in scoring; its code travels in grp_err */
+    E.n_aln[k] = ok ? (uint8_t)n : 0; /* a group with an error takes no part in scoring; its code travels in the info record */
     uint16_t sec = 0;
     for (int i = 0; i < 10; ++i) {
         const bool in = i < n;
-        if (in && (G.rec[i].flag & SPX_FSECONDARY)) sec |= (uint16_t)(1u << i);
-        E.rfe[k * 10 + i] = in ? G.st[i].rfe : 0;
-        E.rfs[k * 10 + i] = in ? G.st[i].rfs : 0;
-        E.atid[k * 10 + i] = in ? G.rec[i].tid : -1;
+        if (in && (c.G.rec[i].flag & SPX_FSECONDARY)) sec |= (uint16_t)(1u << i);
+        E.rfe[k * 10 + i] = in ? c.G.st[i].rfe : 0;
+        E.rfs[k * 10 + i] = in ? c.G.st[i].rfs : 0;
+        E.atid[k * 10 + i] = in ? c.G.rec[i].tid : -1;
     }
     E.sec_mask[k] = sec;
     spx_group_info gi;
@@ -219,33 +295,42 @@ __global__ __launch_bounds__(1024) void scan_arena_kernel(spx_prep_args A)
     if (threadIdx.x == 0) A.tot->arena_bytes = run;
 }
 
-__global__ __launch_bounds__(1024) void scan_groups_kernel(spx_prep_args A, PlanBase *__restrict__ base_out, int64_t *__restrict__ mk_base)
+__global__ __launch_bounds__(1024) void scan_plan_kernel(spx_prep_args A, PlanBase *__restrict__ base_out, int64_t *__restrict__ mk_base)
 {
     __shared__ int64_t lds[1024];
-    int64_t r_prob = 0, r_row = 0, r_qe = 0, r_s = 0, r_f = 0, r_mk = 0, r_cells = 0, r_ok = 0;
-    for (int b0 = 0; b0 < A.n_dgroups; b0 += 1024) {
-        const int k = b0 + threadIdx.x;
-        const bool in = k < A.n_dgroups;
-        GroupCount gc;
-        int n = 0;
-        bool ok = false;
-        if (in) { gc = A.gc[k]; n = A.slot0[k + 1] - A.slot0[k]; ok = gc.err == 0; }
-        const int64_t v_prob = ok ? gc.n_prob : 0, v_row = ok ? gc.n_rows : 0, v_qe = ok ? gc.n_qe : 0, v_s = ok ? gc.s_need : 0,
-                      v_f = ok ? gc.f_need : 0, v_mk = ok ? (int64_t)gc.n_cols * n : 0, v_c = ok ? gc.cells : 0;
-        int64_t t1, t2, t3, t4, t5, t6, t7;
+    /* per alignment: where its problems / rows / edits / scratch start */
+    int64_t r_prob = 0, r_row = 0, r_qe = 0, r_s = 0, r_f = 0;
+    for (int b0 = 0; b0 < A.n_slots; b0 += 1024) {
+        const int q = b0 + threadIdx.x;
+        const bool in = q < A.n_slots;
+        int64_t v_prob = 0, v_row = 0, v_qe = 0, v_s = 0, v_f = 0;
+        if (in) { const GroupCount ac = A.ac[q]; v_prob = ac.n_prob; v_row = ac.n_rows; v_qe = ac.n_qe; v_s = ac.s_need; v_f = ac.f_need; }
+        int64_t t1, t2, t3, t4, t5;
         const int64_t e1 = block_exscan(v_prob, lds, t1), e2 = block_exscan(v_row, lds, t2), e3 = block_exscan(v_qe, lds, t3),
-                      e4 = block_exscan(v_s, lds, t4), e5 = block_exscan(v_f, lds, t5), e6 = block_exscan(v_mk, lds, t6);
-        block_exscan(v_c, lds, t7);
-        int64_t t8;
-        block_exscan(ok ? 1 : 0, lds, t8);
-        r_ok += t8;
+                      e4 = block_exscan(v_s, lds, t4), e5 = block_exscan(v_f, lds, t5);
         if (in) {
             PlanBase pb;
             pb.prob = r_prob + e1; pb.row = r_row + e2; pb.qe = r_qe + e3; pb.s_off = r_s + e4; pb.f_off = r_f + e5;
-            base_out[k] = pb;
-            mk_base[k] = r_mk + e6;
+            base_out[q] = pb;
         }
-        r_prob += t1; r_row += t2; r_qe += t3; r_s += t4; r_f += t5; r_mk += t6; r_cells += t7;
+        r_prob += t1; r_row += t2; r_qe += t3; r_s += t4; r_f += t5;
+    }
+    /* per group: where its marker table starts */
+    int64_t r_mk = 0, r_cells = 0, r_ok = 0;
+    for (int b0 = 0; b0 < A.n_dgroups; b0 += 1024) {
+        const int k = b0 + threadIdx.x;
+        const bool in = k < A.n_dgroups;
+        int64_t v_mk = 0, v_c = 0, v_ok = 0;
+        if (in) {
+            const GroupCount gc = A.gc[k];
+            if (gc.err == 0) { v_mk = (int64_t)gc.n_cols * (A.slot0[k + 1] - A.slot0[k]); v_c = gc.cells; v_ok = 1; }
+        }
+        int64_t t6, t7, t8;
+        const int64_t e6 = block_exscan(v_mk, lds, t6);
+        block_exscan(v_c, lds, t7);
+        block_exscan(v_ok, lds, t8);
+        if (in) mk_base[k] = r_mk + e6;
+        r_mk += t6; r_cells += t7; r_ok += t8;
     }
     if (threadIdx.x == 0) {
         A.tot->n_prob = r_prob; A.tot->n_rows = r_row; A.tot->n_qe = r_qe; A.tot->s_tot = r_s; A.tot->f_tot = r_f;
@@ -325,17 +410,23 @@ extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *ra
 extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *base_out, int64_t *mk_base, hipStream_t st)
 {
     if (A->n_dgroups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(group_arena_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A);
+    const dim3 gg((A->n_dgroups + 63) / 64), ga((A->n_slots + 63) / 64), b64(64);
+    hipLaunchKernelGGL(group_arena_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(scan_arena_kernel, dim3(1), dim3(1024), 0, st, *A);
-    hipLaunchKernelGGL(group_count_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A);
-    hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, st, *A, base_out, mk_base);
+    hipLaunchKernelGGL(group_merge_kernel, gg, b64, 0, st, *A);
+    hipLaunchKernelGGL(aln_filter_kernel, ga, b64, 0, st, *A);
+    hipLaunchKernelGGL(group_blocks_kernel, gg, b64, 0, st, *A);
+    hipLaunchKernelGGL(aln_count_plan_kernel, ga, b64, 0, st, *A);
+    hipLaunchKernelGGL(group_sum_kernel, gg, b64, 0, st, *A);
+    hipLaunchKernelGGL(scan_plan_kernel, dim3(1), dim3(1024), 0, st, *A, base_out, mk_base);
     return hipGetLastError();
 }
 
 extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st)
 {
     if (A->n_dgroups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(group_emit_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(aln_emit_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(group_finish_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A, *E);
     if (E->n_prob > 0)
         hipLaunchKernelGGL(problem_constants_kernel, dim3((E->n_prob + 255) / 256), dim3(256), 0, st, A->par, E->n_prob, E->out.L, E->out.R,
                            E->out.has_n, E->hmm);

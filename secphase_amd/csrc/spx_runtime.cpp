@@ -147,7 +147,7 @@ struct spx_work {
     size_t h_stage_cap = 0;
     void *in_arena = nullptr;   /* device: staged buffer | recoded SEQ | per-alignment / per-group state */
     size_t in_cap = 0;
-    size_t o_code = 0, o_ast = 0, o_gc = 0, o_gab = 0, o_gao = 0, o_base = 0, o_mkb = 0;
+    size_t o_code = 0, o_ast = 0, o_gc = 0, o_ac = 0, o_gab = 0, o_gao = 0, o_base = 0, o_mkb = 0;
     spx_prep_args pa;
     spx_prep_totals tot;
     hipEvent_t ev_ready = nullptr; /* recorded on the preparation stream when the list may be launched */
@@ -668,9 +668,10 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->o_code = cv.take<char>((size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes));
     w->o_ast = cv.take<spxl::AlnState>(ns + 1);
     w->o_gc = cv.take<spxl::GroupCount>(ng + 1);
+    w->o_ac = cv.take<spxl::GroupCount>(ns + 1);
     w->o_gab = cv.take<int64_t>(ng + 1);
     w->o_gao = cv.take<int64_t>(ng + 1);
-    w->o_base = cv.take<spxl::PlanBase>(ng + 1);
+    w->o_base = cv.take<spxl::PlanBase>(ns + 1);
     w->o_mkb = cv.take<int64_t>(ng + 2);
     (void)o_in;
     w->in_arena = arena_get(c, cv.off + 256, &w->in_cap);
@@ -712,6 +713,7 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.rv = c->d_rv;
     A.par = spx::logic_params(&w->par);
     A.gc = (spxl::GroupCount *)(base + w->o_gc);
+    A.ac = (spxl::GroupCount *)(base + w->o_ac);
     A.ga_bytes = (int64_t *)(base + w->o_gab);
     A.ga_off = (int64_t *)(base + w->o_gao);
     A.arena = (char *)c->pool_garena.p;

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+    # torch brings its own copy of the HIP runtime: when libspx's runtime initialises first, torch later finds "no HIP
+    # GPUs" in the same process.  Tests that hand torch tensors to libspx (decision records for the RCCL gather) need
+    # both, so torch goes first -- as in bench.py.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 @pytest.fixture(scope="session")
