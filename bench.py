@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--platform", default="hifi", choices=["hifi", "ont", "mixed"])
     ap.add_argument("--kernel-only", action="store_true", help="only the replay of one prepared work list (profiles, kernel A/B)")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
-    ap.add_argument("--depth", type=int, default=0, help="batches in flight in the pipeline (0: 3, or 2 for the long-read presets)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
     ap.add_argument("--distinct", type=int, default=32, help="at most this many distinct batches per rank (HBM / host memory)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")
@@ -133,10 +133,7 @@ def main():
 
     ont = args.platform == "ont"
     mixed = args.platform == "mixed"
-    if args.depth <= 0:
-        args.depth = 2 if (ont or mixed) else 3  # an ONT work list of 16 384 groups holds ~60 GB of saved rows
-    gps = args.groups_per_step or (16384 if ont else 16384 if mixed else 32768)  # long reads: larger batches amortise the
-    # preparation's dependent chains (one lane walks one alignment's thousands of ops)
+    gps = args.groups_per_step or (4096 if ont else 8192 if mixed else 32768)
     # config 5 (mixed HiFi+ONT, power-law lengths, <= 8 secondaries) is run as --hifi over the whole mix, SURVEY 8(d)
     params = records.preset("ont", bandwidth=50) if ont else records.preset("hifi")
     cfg = synth.default_cfg(synth.ONT if ont else synth.MIXED if mixed else synth.HIFI)

@@ -73,18 +73,6 @@ struct AlnState {
     int64_t ops_off, conf_off, mm_off;
 };
 
-/* Strided pointer.  The per-alignment tables (ops, confident blocks, mismatches) and the per-group scratch lists are
- * lane-private arrays; on the device the arrays of the 64 alignments / groups that share a wavefront are INTERLEAVED
- * (element k of lane l at index k * 64 + l), so that a wave-level load of "element k of my list" is one coalesced
- * access instead of 64 cache lines.  On the host the stride is 1. */
-template <class T>
-struct Sp {
-    T *p;
-    int32_t stride;
-    SPX_HD T &operator[](int64_t k) const { return p[k * stride]; }
-    SPX_HD Sp operator+(int64_t k) const { Sp r = {p + k * stride, stride}; return r; }
-};
-
 struct Pools {
     const uint32_t *cigar;
     const uint8_t *qual;
@@ -94,12 +82,7 @@ struct Pools {
     Op *ops;
     Blk *conf;
     MM *mm;
-    int32_t lanes, pad; /* interleave factor of the three tables above: AlnState.*_off name element 0 of a lane */
 };
-
-SPX_HD Sp<Op> ops_of(const Pools &P, const AlnState &st) { Sp<Op> r = {P.ops + st.ops_off, P.lanes}; return r; }
-SPX_HD Sp<Blk> conf_of(const Pools &P, const AlnState &st) { Sp<Blk> r = {P.conf + st.conf_off, P.lanes}; return r; }
-SPX_HD Sp<MM> mm_of(const Pools &P, const AlnState &st) { Sp<MM> r = {P.mm + st.mm_off, P.lanes}; return r; }
 
 /* reference side: contig table of the 4-bit pool + ambiguous-base index */
 struct RefView {
@@ -317,38 +300,12 @@ SPX_HD int md_step(const char *md, int &at, Op &cur)
 
 SPX_HD bool mx(int op) { return op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF; }
 
-/* Forward walk over ops[t0..t1): f(t, op) is called in order and returns false to stop.  The table is read four ops
- * (one 128-byte line) at a time and the NEXT four are requested before the current four are processed: on the device
- * a walk is a chain of dependent, mostly cold loads (a long read has thousands of ops), and this keeps two lines in
- * flight instead of stalling on every op. */
-template <class F>
-SPX_HD void walk_ops(Sp<Op> ops, int t0, int t1, F f)
-{
-    if (t0 >= t1) return;
-    Op a0 = ops[t0], a1 = a0, a2 = a0, a3 = a0;
-    if (t0 + 1 < t1) a1 = ops[t0 + 1];
-    if (t0 + 2 < t1) a2 = ops[t0 + 2];
-    if (t0 + 3 < t1) a3 = ops[t0 + 3];
-    for (int t = t0; t < t1; t += 4) {
-        Op b0 = a0, b1 = a0, b2 = a0, b3 = a0;
-        if (t + 4 < t1) b0 = ops[t + 4];
-        if (t + 5 < t1) b1 = ops[t + 5];
-        if (t + 6 < t1) b2 = ops[t + 6];
-        if (t + 7 < t1) b3 = ops[t + 7];
-        if (!f(t, a0)) return;
-        if (t + 1 < t1 && !f(t + 1, a1)) return;
-        if (t + 2 < t1 && !f(t + 2, a2)) return;
-        if (t + 3 < t1 && !f(t + 3, a3)) return;
-        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-    }
-}
-
 /* ---------------- per-alignment pass ----------------
  * EMIT = false: counts the op table (st.n_ops) and bounds the mismatch list and the confident blocks (st.mm_cap,
  * st.conf_cap); EMIT = true: writes ops[0..n_ops) (ops[0] = state before the first step).  Both fill lclip/rclip,
  * n_visit, rest and return 0 or SPX_E*. */
 template <bool EMIT>
-SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, AlnState &st, Sp<Op> ops)
+SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, AlnState &st, Op *ops)
 {
     if (r.n_cigar <= 0) return SPX_EINVAL;
     const uint32_t *cigar = P.cigar + r.cigar_off;
@@ -456,7 +413,7 @@ SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, Aln
 
 /* aligned extents (ptAlignment_init_coordinates), confident blocks (find_confident_blocks) and the mismatch
  * markers with raw quality >= min_q (ptMarker_get_initial_markers), all from the op table */
-SPX_HD int finish_alignment(const Rec &r, const Pools &P, int min_q, int thr, AlnState &st, Sp<Op> ops, Sp<Blk> conf, Sp<MM> mmv)
+SPX_HD int finish_alignment(const Rec &r, const Pools &P, int min_q, int thr, AlnState &st, const Op *ops, Blk *conf, MM *mmv)
 {
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
     const uint8_t *qual = P.qual + r.qual_off;
@@ -540,15 +497,13 @@ struct GroupView {
 };
 
 /* what one group needs in its scratch arena (bytes), from the per-alignment counts */
-/* scratch of the group passes.  group_caps: element capacities one group needs; wave_arena_layout: the arena of
- * `lanes` consecutive groups (a wavefront on the device, one group on the host) -- every list gets the largest capacity
- * any of them needs and the lists are interleaved by lane (Sp). */
-struct GroupCaps {
-    int32_t P_cap, blk_cap, rows_cap, n;
+struct GroupArena {
+    int32_t P_cap, blk_cap, rows_cap;
+    int64_t o_pos, o_mk, o_keep, o_flank, o_cur, o_nxt, o_proj, o_nproj, o_rowsmk, bytes;
 };
-SPX_HD GroupCaps group_caps(const GroupView &G, bool all_rows, int slack)
+SPX_HD GroupArena group_arena_layout(const GroupView &G, bool all_rows, int slack)
 {
-    GroupCaps A;
+    GroupArena A;
     int64_t P = 0, C = 0, lq = 0;
     for (int i = 0; i < G.n; ++i) {
         P += G.st[i].n_mm;
@@ -563,35 +518,17 @@ SPX_HD GroupCaps group_caps(const GroupView &G, bool all_rows, int slack)
     if (slack > 1) bc = C + (int64_t)slack * P * (G.n > 0 ? G.n : 1) + 16;
     A.blk_cap = (int32_t)(bc > 0x3fffffff ? 0x3fffffff : bc);
     A.rows_cap = (int32_t)(all_rows ? lq + 8 : P + 8);
-    A.n = G.n > 0 ? G.n : 1;
-    return A;
-}
-struct GroupArena {
-    int32_t P_cap, blk_cap, rows_cap, n;
-    int64_t o_pos, o_mk, o_keep, o_flank, o_cur, o_nxt, o_proj, o_nproj, o_rowsmk, bytes;
-};
-SPX_HD GroupArena wave_arena_layout(const GroupCaps *caps, int cnt, int lanes)
-{
-    GroupArena A;
-    A.P_cap = 0; A.blk_cap = 0; A.rows_cap = 0; A.n = 1;
-    for (int k = 0; k < cnt; ++k) {
-        if (caps[k].P_cap > A.P_cap) A.P_cap = caps[k].P_cap;
-        if (caps[k].blk_cap > A.blk_cap) A.blk_cap = caps[k].blk_cap;
-        if (caps[k].rows_cap > A.rows_cap) A.rows_cap = caps[k].rows_cap;
-        if (caps[k].n > A.n) A.n = caps[k].n;
-    }
-    const int64_t P = A.P_cap, n = A.n, w = lanes;
     int64_t o = 0;
-    auto take = [&](int64_t bytes) { const int64_t at = o; o += (bytes * w + 255) & ~(int64_t)255; return at; };
+    auto take = [&](int64_t bytes) { const int64_t at = o; o += (bytes + 15) & ~(int64_t)15; return at; };
     A.o_pos = take(4 * (P + 1));
-    A.o_mk = take((int64_t)sizeof(Mk) * (P * n + 1));
+    A.o_mk = take((int64_t)sizeof(Mk) * (P * G.n + 1));
     A.o_keep = take(P + 1);
     A.o_flank = take((int64_t)sizeof(Iv) * A.blk_cap);
     A.o_cur = take((int64_t)sizeof(Iv) * A.blk_cap);
     A.o_nxt = take((int64_t)sizeof(Iv) * A.blk_cap);
-    A.o_proj = take((int64_t)sizeof(Blk) * A.blk_cap * n);
+    A.o_proj = take((int64_t)sizeof(Blk) * A.blk_cap * G.n);
     A.o_nproj = take(4 * 16);
-    A.o_rowsmk = take(4 * (int64_t)A.rows_cap * n); /* one list per alignment: their passes run side by side */
+    A.o_rowsmk = take(4 * (int64_t)A.rows_cap * (G.n > 0 ? G.n : 1)); /* one list per alignment: their passes run side by side */
     A.bytes = o;
     return A;
 }
@@ -623,7 +560,7 @@ SPX_HD Mk match_marker(const Rec &r, const AlnState &st, const uint8_t *qual, in
  * aln_filter    one alignment's walk over its ops and the columns (filter_ins_markers): columns inside an insertion /
  *               clip are marked for removal, the reference positions of its match markers inside '=' ops filled in
  * group_compact removes the marked columns; returns the number kept */
-SPX_HD int group_merge(const GroupView &G, const Pools &P, Sp<int32_t> pos, Sp<Mk> mk, Sp<uint8_t> keep)
+SPX_HD int group_merge(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk, uint8_t *keep)
 {
     const int n = G.n;
     int head[10], left[10], hpos[10]; /* hpos: read position of each list's head (0x7fffffff: exhausted) */
@@ -631,7 +568,7 @@ SPX_HD int group_merge(const GroupView &G, const Pools &P, Sp<int32_t> pos, Sp<M
         const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
         left[i] = G.st[i].n_mm;
         head[i] = rev ? G.st[i].n_mm - 1 : 0;
-        hpos[i] = left[i] > 0 ? mm_of(P, G.st[i])[head[i]].pos : 0x7fffffff;
+        hpos[i] = left[i] > 0 ? P.mm[G.st[i].mm_off + head[i]].pos : 0x7fffffff;
     }
     int ncol = 0;
     for (;;) {
@@ -646,7 +583,7 @@ SPX_HD int group_merge(const GroupView &G, const Pools &P, Sp<int32_t> pos, Sp<M
             if (cnt != n) {
                 Mk m;
                 if (has) {
-                    const MM s = mm_of(P, G.st[i])[head[i]];
+                    const MM s = P.mm[G.st[i].mm_off + head[i]];
                     m.base_idx = s.base_idx; m.ref_pos = s.ref_pos; m.row = -1; m.q = (uint8_t)s.q; m.is_match = 0;
                     m.pad0 = m.pad1 = 0;
                 } else
@@ -657,7 +594,7 @@ SPX_HD int group_merge(const GroupView &G, const Pools &P, Sp<int32_t> pos, Sp<M
                 const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
                 head[i] += rev ? -1 : 1;
                 left[i]--;
-                hpos[i] = left[i] > 0 ? mm_of(P, G.st[i])[head[i]].pos : 0x7fffffff;
+                hpos[i] = left[i] > 0 ? P.mm[G.st[i].mm_off + head[i]].pos : 0x7fffffff;
             }
         }
         if (cnt != n) { pos[ncol] = best; keep[ncol] = 1; ++ncol; }
@@ -665,19 +602,20 @@ SPX_HD int group_merge(const GroupView &G, const Pools &P, Sp<int32_t> pos, Sp<M
     return ncol;
 }
 
-SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, Sp<int32_t> pos, Sp<Mk> mk, Sp<uint8_t> keep, int ncol)
+SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, uint8_t *keep, int ncol)
 {
     /* positions inside an insertion / clip of any alignment are not comparable: the column goes */
     const int n = G.n;
     const Rec &r = G.rec[i];
     const AlnState &st = G.st[i];
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
-    const Sp<Op> ops = ops_of(P, st);
+    const Op *ops = P.ops + st.ops_off;
     int col = rev ? ncol - 1 : 0;
     const int step = rev ? -1 : 1;
     if (ncol <= 0) return;
     int p = pos[col];
-    walk_ops(ops, 1, st.n_visit, [&](int, const Op &o) {
+    for (int t = 1; t < st.n_visit && col >= 0 && col < ncol; ++t) {
+        const Op o = ops[t];
         while (col >= 0 && col < ncol) {
             if (!(o.rds <= p && p <= o.rde)) break;
             if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) keep[col] = 0; /* (every alignment writes the same 0) */
@@ -686,11 +624,10 @@ SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, Sp<int32_t> po
             col += step;
             if (col >= 0 && col < ncol) p = pos[col];
         }
-        return col >= 0 && col < ncol;
-    });
+    }
 }
 
-SPX_HD int group_compact(const GroupView &G, Sp<int32_t> pos, Sp<Mk> mk, Sp<uint8_t> keep, int ncol)
+SPX_HD int group_compact(const GroupView &G, int32_t *pos, Mk *mk, const uint8_t *keep, int ncol)
 {
     const int n = G.n;
     int w = 0;
@@ -708,7 +645,7 @@ SPX_HD int group_compact(const GroupView &G, Sp<int32_t> pos, Sp<Mk> mk, Sp<uint
 /* ascending by key; inputs are monotone (ascending, or descending on the reverse strand), so: reverse when
  * descending, then an insertion pass that is linear on sorted data */
 template <int KEY> /* 0: rds, 1: sqs */
-SPX_HD void sort_blocks(Sp<Blk> b, int n)
+SPX_HD void sort_blocks(Blk *b, int n)
 {
     auto key = [](const Blk &x) { return KEY == 0 ? x.rds : x.sqs; };
     if (n > 1 && key(b[0]) > key(b[n - 1]))
@@ -723,7 +660,7 @@ SPX_HD void sort_blocks(Sp<Blk> b, int n)
 
 /* flanking windows of one alignment around every marker cell (find_flanking_blocks).  The reference walks the
  * marker LIST, which holds every position n times (one cell per alignment): the repeats are replayed from a register. */
-SPX_HD int flank_blocks(const AlnState &st, Sp<int32_t> pos, int ncol, int n, int margin, Sp<Iv> out, int cap)
+SPX_HD int flank_blocks(const AlnState &st, const int32_t *pos, int ncol, int n, int margin, Iv *out, int cap)
 {
     int cnt = 0;
     int start = 0, end = 0;
@@ -749,7 +686,7 @@ SPX_HD int flank_blocks(const AlnState &st, Sp<int32_t> pos, int ncol, int n, in
 }
 
 /* ascending by start; the lists are ascending already except in degenerate cases */
-SPX_HD void sort_intervals(Sp<Iv> b, int n)
+SPX_HD void sort_intervals(Iv *b, int n)
 {
     for (int i = 1; i < n; ++i) {
         const Iv t = b[i];
@@ -763,7 +700,7 @@ SPX_HD void sort_intervals(Sp<Iv> b, int n)
 /* intersect_by_rd_f (ptMarker.c:398-435): strict '<' overlap test, windows that merely touch do not intersect.
  * GetY(j) yields interval j of the second list (an Iv list, or the read coordinates of a block list). */
 template <class GetY>
-SPX_HD int intersect(Sp<Iv> x, int nx, GetY gety, int ny, Sp<Iv> out, int cap)
+SPX_HD int intersect(const Iv *x, int nx, GetY gety, int ny, Iv *out, int cap)
 {
     if (nx == 0 || ny == 0) return 0;
     int cnt = 0, j = 0;
@@ -782,7 +719,7 @@ SPX_HD int intersect(Sp<Iv> x, int nx, GetY gety, int ny, Sp<Iv> out, int cap)
 }
 
 /* project the consensus intervals cur[0..nb) (read coordinates) onto one alignment (correct_conf_blocks) */
-SPX_HD int project_blocks(const Rec &r, const AlnState &st, Sp<Op> ops, Sp<Iv> cur, int nb, int thr, Sp<Blk> out, int cap)
+SPX_HD int project_blocks(const Rec &r, const AlnState &st, const Op *ops, const Iv *cur, int nb, int thr, Blk *out, int cap)
 {
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
     int cnt = 0;
@@ -790,8 +727,8 @@ SPX_HD int project_blocks(const Rec &r, const AlnState &st, Sp<Op> ops, Sp<Iv> c
     bool have = true, del_flag = false;
     int bs = rev ? -cur[j].e : cur[j].s, be = rev ? -cur[j].s : cur[j].e;
     int rfs = -1, rfe = -1, sqs = -1, sqe = -1;
-    bool overflow = false;
-    walk_ops(ops, 1, st.n_visit, [&](int, const Op &o) {
+    for (int t = 1; t < st.n_visit; ++t) {
+        const Op o = ops[t];
         const int cs = rev ? -o.rde : o.rds, ce = rev ? -o.rds : o.rde;
         if (mx(o.op) || o.op == SPX_CINS) {
             const bool ins = o.op == SPX_CINS;
@@ -802,14 +739,14 @@ SPX_HD int project_blocks(const Rec &r, const AlnState &st, Sp<Op> ops, Sp<Iv> c
                 }
                 rfe = ins ? o.rfe : o.rfs + (be - cs);
                 sqe = o.sqs + (be - cs);
-                if (cnt >= cap) { overflow = true; return false; }
+                if (cnt >= cap) return -1;
                 Blk b = {rfs, rfe, sqs, sqe, cur[j].s, cur[j].e};
                 out[cnt++] = b;
                 if (rev && j > 0) { --j; bs = -cur[j].e; be = -cur[j].s; }
                 else if (!rev && j < nb - 1) { ++j; bs = cur[j].s; be = cur[j].e; }
                 else have = false;
             }
-            if (!have) return false;
+            if (!have) break;
             if (cs <= bs && bs <= ce && !(del_flag && cs == bs)) {
                 rfs = ins ? o.rfs : o.rfs + (bs - cs);
                 sqs = o.sqs + (bs - cs);
@@ -822,37 +759,34 @@ SPX_HD int project_blocks(const Rec &r, const AlnState &st, Sp<Op> ops, Sp<Iv> c
                 sqs = o.sqs;
             }
         }
-        return true;
-    });
-    if (overflow) return -1;
+    }
     sort_blocks<1>(out, cnt);
     return cnt;
 }
 
 /* the scratch arrays of one group */
 struct GroupScratch {
-    Sp<int32_t> pos;
-    Sp<Mk> mk;
-    Sp<uint8_t> keep;
-    Sp<Iv> flank, cur, nxt; /* interval lists of the consensus rounds: read coordinates only */
-    Sp<Blk> proj;       /* [n][blk_cap]: each alignment's current block list (confident blocks, then projected windows) */
-    Sp<int32_t> nproj;  /* [n] */
-    Sp<int32_t> rows_mk;
+    int32_t *pos;
+    Mk *mk;
+    uint8_t *keep;
+    Iv *flank, *cur, *nxt; /* interval lists of the consensus rounds: read coordinates only */
+    Blk *proj;       /* [n][blk_cap]: each alignment's current block list (confident blocks, then projected windows) */
+    int32_t *nproj;  /* [n] */
+    int32_t *rows_mk;
     int32_t blk_cap, rows_cap;
 };
-/* the lists of lane `lane` inside the arena of its wave */
-SPX_HD GroupScratch group_scratch(const GroupArena &A, char *base, int lane, int lanes)
+SPX_HD GroupScratch group_scratch(const GroupArena &A, char *base)
 {
     GroupScratch S;
-    S.pos.p = (int32_t *)(base + A.o_pos) + lane; S.pos.stride = lanes;
-    S.mk.p = (Mk *)(base + A.o_mk) + lane; S.mk.stride = lanes;
-    S.keep.p = (uint8_t *)(base + A.o_keep) + lane; S.keep.stride = lanes;
-    S.flank.p = (Iv *)(base + A.o_flank) + lane; S.flank.stride = lanes;
-    S.cur.p = (Iv *)(base + A.o_cur) + lane; S.cur.stride = lanes;
-    S.nxt.p = (Iv *)(base + A.o_nxt) + lane; S.nxt.stride = lanes;
-    S.proj.p = (Blk *)(base + A.o_proj) + lane; S.proj.stride = lanes;
-    S.nproj.p = (int32_t *)(base + A.o_nproj) + lane; S.nproj.stride = lanes;
-    S.rows_mk.p = (int32_t *)(base + A.o_rowsmk) + lane; S.rows_mk.stride = lanes;
+    S.pos = (int32_t *)(base + A.o_pos);
+    S.mk = (Mk *)(base + A.o_mk);
+    S.keep = (uint8_t *)(base + A.o_keep);
+    S.flank = (Iv *)(base + A.o_flank);
+    S.cur = (Iv *)(base + A.o_cur);
+    S.nxt = (Iv *)(base + A.o_nxt);
+    S.proj = (Blk *)(base + A.o_proj);
+    S.nproj = (int32_t *)(base + A.o_nproj);
+    S.rows_mk = (int32_t *)(base + A.o_rowsmk);
     S.blk_cap = A.blk_cap;
     S.rows_cap = A.rows_cap;
     return S;
@@ -867,9 +801,9 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
     for (int i = 0; i < n; ++i) {
         const AlnState &st = G.st[i];
         if (st.n_conf > cap) return SPX_ENOMEM;
-        Sp<Blk> dst = S.proj + (int64_t)i * cap;
+        Blk *dst = S.proj + (int64_t)i * cap;
         for (int k = 0; k < st.n_conf; ++k) {
-            const Blk b = conf_of(P, st)[k];
+            const Blk b = P.conf[st.conf_off + k];
             dst[k] = b;
             if ((b.sqe - b.sqs) > 1000 || (b.rfe - b.rfs) > 1000) too_long = true;
         }
@@ -880,9 +814,9 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
     /* `same`: every alignment's block list is, in read coordinates, the interval list prev[0..np) of the round before
      * (see the long-window shortcut below); otherwise the lists are S.proj */
     bool same = false;
-    Sp<Iv> prev = S.flank; /* three buffers rotate: prev / cur / nxt; flank windows are generated into the spare one */
+    Iv *prev = S.flank; /* three buffers rotate: prev / cur / nxt; flank windows are generated into the spare one */
     int np = 0;
-    Sp<Iv> cur = S.cur, nxt = S.nxt;
+    Iv *cur = S.cur, *nxt = S.nxt;
     while (par.consensus && too_long) {
         margin = (int)(margin * 0.8);
         /* intersect every alignment's blocks, then every alignment's flanking windows, in read coordinates */
@@ -891,30 +825,30 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
             nc = np;
             for (int k = 0; k < np; ++k) cur[k] = prev[k];
             for (int i = 1; i < n; ++i) {
-                const Sp<Iv> pv = prev;
+                const Iv *pv = prev;
                 const int m = intersect(cur, nc, [&](int j) { return pv[j]; }, np, nxt, cap);
                 if (m < 0) return SPX_ENOMEM;
                 nc = m;
-                Sp<Iv> t = cur; cur = nxt; nxt = t;
+                Iv *t = cur; cur = nxt; nxt = t;
             }
         } else {
             sort_blocks<0>(S.proj, S.nproj[0]);
             nc = S.nproj[0];
             for (int k = 0; k < nc; ++k) { Iv v = {S.proj[k].rds, S.proj[k].rde}; cur[k] = v; }
             for (int i = 1; i < n; ++i) {
-                Sp<Blk> bi = S.proj + (int64_t)i * cap;
+                Blk *bi = S.proj + (int64_t)i * cap;
                 sort_blocks<0>(bi, S.nproj[i]);
                 const int m = intersect(cur, nc, [&](int j) { Iv v = {bi[j].rds, bi[j].rde}; return v; }, S.nproj[i], nxt, cap);
                 if (m < 0) return SPX_ENOMEM;
                 nc = m;
-                Sp<Iv> t = cur; cur = nxt; nxt = t;
+                Iv *t = cur; cur = nxt; nxt = t;
             }
         }
         /* prev is free now: it takes the flanking windows.  With a positive margin and every marker position inside
          * the aligned extent [rds, rde] of every alignment, the merge decisions (cs < end) do not depend on the extent:
          * clamping only moves the start of the first window and the end of the last one.  The windows are then built
          * ONCE without clamping and every alignment reads them through its own clamp. */
-        Sp<Iv> fl = prev;
+        Iv *fl = prev;
         bool shared = margin > 0;
         for (int i = 0; i < n && shared; ++i)
             shared = G.st[i].rde > G.st[i].rds && S.pos[0] >= G.st[i].rds && S.pos[ncol - 1] <= G.st[i].rde;
@@ -929,7 +863,7 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
             int nf, m;
             if (shared) {
                 nf = nu;
-                const Sp<Iv> fv = fl;
+                const Iv *fv = fl;
                 const int lo = G.st[i].rds, hi = G.st[i].rde, lastj = nu - 1;
                 m = intersect(cur, nc, [&](int j) {
                     Iv v = fv[j];
@@ -941,12 +875,12 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
                 nf = flank_blocks(G.st[i], S.pos, ncol, n, margin, fl, cap);
                 if (nf < 0) return SPX_ENOMEM;
                 sort_intervals(fl, nf);
-                const Sp<Iv> fv = fl;
+                const Iv *fv = fl;
                 m = intersect(cur, nc, [&](int j) { return fv[j]; }, nf, nxt, cap);
             }
             if (m < 0) return SPX_ENOMEM;
             nc = m;
-            Sp<Iv> t = cur; cur = nxt; nxt = t;
+            Iv *t = cur; cur = nxt; nxt = t;
         }
         if (nc == 0) {
             for (int i = 0; i < n; ++i) S.nproj[i] = 0;
@@ -966,15 +900,15 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
         nblk = nc;
         if (long_window && iter < 64) {
             same = true;
-            Sp<Iv> t = prev; prev = cur; cur = t; /* this round's windows become `prev` */
+            Iv *t = prev; prev = cur; cur = t; /* this round's windows become `prev` */
             np = nc;
             too_long = true;
         } else {
             same = false;
             too_long = false;
             for (int i = 0; i < n; ++i) {
-                Sp<Blk> dst = S.proj + (int64_t)i * cap;
-                const int m = project_blocks(G.rec[i], G.st[i], ops_of(P, G.st[i]), cur, nc, par.indel_threshold, dst, cap);
+                Blk *dst = S.proj + (int64_t)i * cap;
+                const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, cur, nc, par.indel_threshold, dst, cap);
                 if (m < 0) return SPX_ENOMEM;
                 S.nproj[i] = m;
                 if (m == 0) too_long = true;
@@ -1015,7 +949,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
     const int n = G.n;
     const Rec &r = G.rec[ai];
     const AlnState &st = G.st[ai];
-    const Sp<Op> ops = ops_of(P, st);
+    const Op *ops = P.ops + st.ops_off;
     const uint8_t *qual = P.qual + r.qual_off;
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
     const int step = rev ? -1 : 1;
@@ -1038,9 +972,9 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
         at.qe++;
         if (!EMIT) gc.n_qe++;
     };
-    const Sp<Blk> blocks = S.proj + (int64_t)ai * S.blk_cap;
+    const Blk *blocks = S.proj + (int64_t)ai * S.blk_cap;
     const int nblocks = S.nproj[ai];
-    const Sp<int32_t> rows_mk = S.rows_mk + (int64_t)ai * S.rows_cap;
+    int32_t *rows_mk = S.rows_mk + (int64_t)ai * S.rows_cap;
     for (int bi = 0; bi < nblocks; ++bi) {
         const Blk b = blocks[bi];
         while (co.sqe < b.sqs || co.rfe < b.rfs)

@@ -297,7 +297,6 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
     P.text = buf.data() + L.o_text;
     P.code4 = code.data();
     P.code_lead_bytes = kCodeLeadBytes;
-    P.lanes = 1; /* host: nothing is interleaved */
     const uint8_t *raw = (const uint8_t *)(buf.data() + L.o_seq);
     /* pass A: recode + count */
     parallel_for(ns, threads, [&](int64_t a0, int64_t a1) {
@@ -311,7 +310,7 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
             for (int64_t k = 0; k < lq && !hn; ++k)
                 hn = ((code[(size_t)(kCodeLeadBytes + r.seq_off + (k >> 1))] >> ((k & 1) << 2)) & 0xf) > 3;
             a.has_n = hn;
-            a.err = spxl::build_ops<false>(r, P, lp.min_q, lp.indel_threshold, a, spxl::Sp<spxl::Op>{nullptr, 1});
+            a.err = spxl::build_ops<false>(r, P, lp.min_q, lp.indel_threshold, a, nullptr);
             if (a.err) { a.n_ops = 0; a.mm_cap = 0; a.conf_cap = 0; }
         }
     });
@@ -332,9 +331,9 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
             const spxl::Rec &r = recs[s];
             spxl::AlnState &a = ast[(size_t)s];
             if (a.err) continue;
-            a.err = spxl::build_ops<true>(r, P, lp.min_q, lp.indel_threshold, a, spxl::ops_of(P, a));
-            if (!a.err) a.err = spxl::finish_alignment(r, P, lp.min_q, lp.indel_threshold, a, spxl::ops_of(P, a), spxl::conf_of(P, a),
-                                                      spxl::mm_of(P, a));
+            a.err = spxl::build_ops<true>(r, P, lp.min_q, lp.indel_threshold, a, ops.data() + a.ops_off);
+            if (!a.err) a.err = spxl::finish_alignment(r, P, lp.min_q, lp.indel_threshold, a, ops.data() + a.ops_off,
+                                                      conf.data() + a.conf_off, mm.data() + a.mm_off);
         }
     });
     /* the group / alignment passes, in the order the device runs them (scratch kept between them) */
@@ -352,12 +351,11 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
     std::vector<char> arena;
     for (;;) {
         for (int64_t k = 0; k < ng; ++k) {
-            const spxl::GroupCaps caps = spxl::group_caps(view(k), lp.all_rows != 0, slack);
-            ga[(size_t)k] = spxl::wave_arena_layout(&caps, 1, 1);
+            ga[(size_t)k] = spxl::group_arena_layout(view(k), lp.all_rows != 0, slack);
             ga_off[(size_t)k + 1] = ga_off[(size_t)k] + ga[(size_t)k].bytes;
         }
         arena.assign((size_t)ga_off[(size_t)ng] + 64, 0);
-        auto scratch = [&](int64_t k) { return spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k], 0, 1); };
+        auto scratch = [&](int64_t k) { return spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k]); };
         std::atomic<int> overflow(0);
         parallel_for(ng, threads, [&](int64_t k0, int64_t k1) { /* G1 */
             for (int64_t k = k0; k < k1; ++k) { spxl::GroupScratch S = scratch(k); spxl::group_pass_merge(view(k), P, rv, S, gc[(size_t)k]); }
@@ -431,7 +429,7 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
     out.rows = hb.rows.data(); out.row_expect = hb.row_expect.data(); out.row_prob = row_prob.data(); out.row_rawq = hb.row_rawq.data();
     out.qe_rec = hb.qe_rec.data(); out.qe_pos = hb.qe_pos.data(); out.qe_len = hb.qe_len.data(); out.qe_row0 = hb.qe_row0.data();
     out.qe_batch = hb.qe_batch.data();
-    auto scratch = [&](int64_t k) { return spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k], 0, 1); };
+    auto scratch = [&](int64_t k) { return spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k]); };
     parallel_for(ns, threads, [&](int64_t q0, int64_t q1) { /* A3 */
         for (int64_t q = q0; q < q1; ++q) {
             const int64_t k = slot_grp[(size_t)q];

@@ -25,9 +25,6 @@ struct spx_group_info { /* per dispatched group, copied back with the results */
     int64_t cells;
 };
 
-/* lanes that share interleaved tables / scratch lists: the wavefront */
-#define SPX_PREP_LANES 64
-
 struct spx_prep_args {
     int32_t n_slots, n_dgroups;
     const spxl::Rec *recs;
@@ -40,10 +37,7 @@ struct spx_prep_args {
     spxl::Params par;
     spxl::GroupCount *gc;  /* per dispatched group */
     spxl::GroupCount *ac;  /* per alignment: its share of the work list */
-    /* scratch of the group passes: capacities per group, one interleaved arena per wave of SPX_PREP_LANES groups */
-    spxl::GroupCaps *gcaps;
-    spxl::GroupArena *wa;
-    int64_t *wa_off;
+    int64_t *ga_bytes, *ga_off;
     char *arena;
     int64_t arena_cap;
     int32_t slack, pad;

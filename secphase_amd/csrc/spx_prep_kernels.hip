@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
     AlnState st = A.ast[s];
     const Rec r = A.recs[s];
     st.n_ops = 0; st.mm_cap = 0; st.conf_cap = 0; st.n_conf = 0; st.n_mm = 0;
-    st.err = build_ops<false>(r, A.P, A.par.min_q, A.par.indel_threshold, st, Sp<Op>{nullptr, 1});
+    st.err = build_ops<false>(r, A.P, A.par.min_q, A.par.indel_threshold, st, nullptr);
     if (st.err) { st.n_ops = 0; st.mm_cap = 0; st.conf_cap = 0; }
     A.ast[s] = st;
 }
@@ -80,38 +80,24 @@ __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
     if (s >= A.n_slots) return;
     AlnState st = A.ast[s];
     if (st.err) return;
-    /* the tables of the 64 alignments of this wave are interleaved: element t of every lane lies in one 2 KB stretch */
-    const int64_t L = A.P.lanes;
-    if (st.ops_off + (int64_t)st.n_ops * L > A.ops_cap || st.conf_off + (int64_t)st.conf_cap * L > A.conf_cap ||
-        st.mm_off + (int64_t)st.mm_cap * L > A.mm_cap) {
-        A.tot->overflow = 3;
+    if (st.ops_off + st.n_ops > A.ops_cap || st.conf_off + st.conf_cap > A.conf_cap || st.mm_off + st.mm_cap > A.mm_cap) {
+        A.tot->overflow = 1;
         return;
     }
     const Rec r = A.recs[s];
-    const Sp<Op> ops = ops_of(A.P, st);
+    Op *ops = A.P.ops + st.ops_off;
     st.err = build_ops<true>(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops);
-    if (!st.err) st.err = finish_alignment(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops, conf_of(A.P, st), mm_of(A.P, st));
+    if (!st.err) st.err = finish_alignment(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops, A.P.conf + st.conf_off, A.P.mm + st.mm_off);
     A.ast[s] = st;
 }
 
-__global__ __launch_bounds__(64) void group_caps_kernel(spx_prep_args A)
+__global__ __launch_bounds__(64) void group_arena_kernel(spx_prep_args A)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n_dgroups) return;
     const int s0 = A.slot0[k];
     GroupView G = {A.slot0[k + 1] - s0, A.recs + s0, A.ast + s0};
-    A.gcaps[k] = group_caps(G, A.par.all_rows != 0, A.slack);
-}
-
-/* one thread per wave of groups: the arena of the wave */
-__global__ __launch_bounds__(64) void wave_arena_kernel(spx_prep_args A)
-{
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nw = (A.n_dgroups + SPX_PREP_LANES - 1) / SPX_PREP_LANES;
-    if (w >= nw) return;
-    const int k0 = w * SPX_PREP_LANES;
-    const int cnt = min(SPX_PREP_LANES, A.n_dgroups - k0);
-    A.wa[w] = wave_arena_layout(A.gcaps + k0, cnt, SPX_PREP_LANES);
+    A.ga_bytes[k] = group_arena_layout(G, A.par.all_rows != 0, A.slack).bytes;
 }
 
 /* ---- the passes of spx_logic.h: G* one read group per thread, A* one alignment per thread ---- */
@@ -127,10 +113,9 @@ __device__ __forceinline__ GroupCtx group_ctx(const spx_prep_args &A, int k)
     c.G.n = A.slot0[k + 1] - s0;
     c.G.rec = A.recs + s0;
     c.G.st = A.ast + s0;
-    const int w = k / SPX_PREP_LANES;
-    const GroupArena ga = A.wa[w];
-    c.ok = A.wa_off[w] + ga.bytes <= A.arena_cap;
-    c.S = group_scratch(ga, A.arena + A.wa_off[w], k % SPX_PREP_LANES, SPX_PREP_LANES);
+    const GroupArena ga = group_arena_layout(c.G, A.par.all_rows != 0, A.slack);
+    c.ok = A.ga_off[k] + ga.bytes <= A.arena_cap;
+    c.S = group_scratch(ga, A.arena + A.ga_off[k]);
     return c;
 }
 
@@ -278,30 +263,17 @@ __device__ __forceinline__ int64_t block_exscan(int64_t v, int64_t *lds, int64_t
     return incl - v;
 }
 
-/* offsets of the per-alignment tables: one thread per WAVE of alignments -- the wave's tables are interleaved, each
- * sized for the longest of its 64 lists */
 __global__ __launch_bounds__(1024) void scan_slots_kernel(spx_prep_args A)
 {
     __shared__ int64_t lds[1024];
-    const int nw = (A.n_slots + SPX_PREP_LANES - 1) / SPX_PREP_LANES;
     int64_t run_ops = 0, run_conf = 0, run_mm = 0;
-    for (int base = 0; base < nw; base += 1024) {
-        const int w = base + threadIdx.x;
-        const bool in = w < nw;
-        int64_t a = 0, b = 0, c = 0;
-        const int s0 = w * SPX_PREP_LANES, s1 = in ? min(A.n_slots, s0 + SPX_PREP_LANES) : s0;
-        for (int s = s0; s < s1; ++s) {
-            const AlnState &st = A.ast[s];
-            a = max(a, (int64_t)st.n_ops); b = max(b, (int64_t)st.conf_cap); c = max(c, (int64_t)st.mm_cap);
-        }
-        a *= SPX_PREP_LANES; b *= SPX_PREP_LANES; c *= SPX_PREP_LANES;
+    for (int base = 0; base < A.n_slots; base += 1024) {
+        const int s = base + threadIdx.x;
+        const bool in = s < A.n_slots;
+        const int64_t a = in ? A.ast[s].n_ops : 0, b = in ? A.ast[s].conf_cap : 0, c = in ? A.ast[s].mm_cap : 0;
         int64_t ta, tb, tc;
         const int64_t ea = block_exscan(a, lds, ta), eb = block_exscan(b, lds, tb), ec = block_exscan(c, lds, tc);
-        for (int s = s0; s < s1; ++s) {
-            A.ast[s].ops_off = run_ops + ea + (s - s0);
-            A.ast[s].conf_off = run_conf + eb + (s - s0);
-            A.ast[s].mm_off = run_mm + ec + (s - s0);
-        }
+        if (in) { A.ast[s].ops_off = run_ops + ea; A.ast[s].conf_off = run_conf + eb; A.ast[s].mm_off = run_mm + ec; }
         run_ops += ta; run_conf += tb; run_mm += tc;
     }
     if (threadIdx.x == 0) { A.tot->n_ops = run_ops; A.tot->n_conf = run_conf; A.tot->n_mm = run_mm; }
@@ -310,15 +282,14 @@ __global__ __launch_bounds__(1024) void scan_slots_kernel(spx_prep_args A)
 __global__ __launch_bounds__(1024) void scan_arena_kernel(spx_prep_args A)
 {
     __shared__ int64_t lds[1024];
-    const int nw = (A.n_dgroups + SPX_PREP_LANES - 1) / SPX_PREP_LANES;
     int64_t run = 0;
-    for (int base = 0; base < nw; base += 1024) {
-        const int w = base + threadIdx.x;
-        const bool in = w < nw;
-        const int64_t a = in ? A.wa[w].bytes : 0;
+    for (int base = 0; base < A.n_dgroups; base += 1024) {
+        const int k = base + threadIdx.x;
+        const bool in = k < A.n_dgroups;
+        const int64_t a = in ? A.ga_bytes[k] : 0;
         int64_t ta;
         const int64_t ea = block_exscan(a, lds, ta);
-        if (in) A.wa_off[w] = run + ea;
+        if (in) A.ga_off[k] = run + ea;
         run += ta;
     }
     if (threadIdx.x == 0) A.tot->arena_bytes = run;
@@ -440,9 +411,7 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
 {
     if (A->n_dgroups <= 0) return hipSuccess;
     const dim3 gg((A->n_dgroups + 63) / 64), ga((A->n_slots + 63) / 64), b64(64);
-    const int nw = (A->n_dgroups + SPX_PREP_LANES - 1) / SPX_PREP_LANES;
-    hipLaunchKernelGGL(group_caps_kernel, gg, b64, 0, st, *A);
-    hipLaunchKernelGGL(wave_arena_kernel, dim3((nw + 63) / 64), b64, 0, st, *A);
+    hipLaunchKernelGGL(group_arena_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(scan_arena_kernel, dim3(1), dim3(1024), 0, st, *A);
     hipLaunchKernelGGL(group_merge_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(aln_filter_kernel, ga, b64, 0, st, *A);

@@ -147,7 +147,7 @@ struct spx_work {
     size_t h_stage_cap = 0;
     void *in_arena = nullptr;   /* device: staged buffer | recoded SEQ | per-alignment / per-group state */
     size_t in_cap = 0;
-    size_t o_code = 0, o_ast = 0, o_gc = 0, o_ac = 0, o_gab = 0, o_wa = 0, o_gao = 0, o_base = 0, o_mkb = 0;
+    size_t o_code = 0, o_ast = 0, o_gc = 0, o_ac = 0, o_gab = 0, o_gao = 0, o_base = 0, o_mkb = 0;
     spx_prep_args pa;
     spx_prep_totals tot;
     hipEvent_t ev_ready = nullptr; /* recorded on the preparation stream when the list may be launched */
@@ -669,9 +669,8 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->o_ast = cv.take<spxl::AlnState>(ns + 1);
     w->o_gc = cv.take<spxl::GroupCount>(ng + 1);
     w->o_ac = cv.take<spxl::GroupCount>(ns + 1);
-    w->o_gab = cv.take<spxl::GroupCaps>(ng + 1);
-    w->o_wa = cv.take<spxl::GroupArena>(ng / SPX_PREP_LANES + 2);
-    w->o_gao = cv.take<int64_t>(ng / SPX_PREP_LANES + 2);
+    w->o_gab = cv.take<int64_t>(ng + 1);
+    w->o_gao = cv.take<int64_t>(ng + 1);
     w->o_base = cv.take<spxl::PlanBase>(ns + 1);
     w->o_mkb = cv.take<int64_t>(ng + 2);
     (void)o_in;
@@ -715,10 +714,8 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.par = spx::logic_params(&w->par);
     A.gc = (spxl::GroupCount *)(base + w->o_gc);
     A.ac = (spxl::GroupCount *)(base + w->o_ac);
-    A.gcaps = (spxl::GroupCaps *)(base + w->o_gab);
-    A.wa = (spxl::GroupArena *)(base + w->o_wa);
-    A.wa_off = (int64_t *)(base + w->o_gao);
-    A.P.lanes = SPX_PREP_LANES;
+    A.ga_bytes = (int64_t *)(base + w->o_gab);
+    A.ga_off = (int64_t *)(base + w->o_gao);
     A.arena = (char *)c->pool_garena.p;
     A.arena_cap = (int64_t)c->pool_garena.cap;
     A.slack = 1;
@@ -744,55 +741,43 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         w->arena = nullptr;
     }
     w->prepared = false;
-    /* pools of the per-alignment pass.  Bounds the host knows without touching the payload (an op per CIGAR op or per
-     * two tag characters; a confident block per CIGAR op; a mismatch per tag character) size them the first time; the
-     * tables of a wave are interleaved and padded to its longest list, so the exact need comes back with the totals
-     * and a pool that turns out too small is grown and the pass repeated (first batches only). */
+    /* pools of the per-alignment pass, by bounds the host knows without touching the payload: an op per CIGAR op or
+     * per two tag characters; a confident block per CIGAR op; a mismatch per tag character */
     const size_t ops_bound = (size_t)L.cigar_words + (size_t)L.text_bytes / 2 + 2 * ns + 16;
-    const size_t conf_bound = (size_t)L.cigar_words + 2 * ns + 16, mm_bound = (size_t)L.text_bytes / 2 + 16;
+    const size_t conf_bound = (size_t)L.cigar_words + 2 * ns + 16, mm_bound = (size_t)L.text_bytes + 16;
     int rc;
-    if ((rc = ensure_pool(c, c->pool_ops, (ops_bound + ops_bound / 2) * sizeof(spxl::Op))) ||
-        (rc = ensure_pool(c, c->pool_conf, (conf_bound + conf_bound / 2) * sizeof(spxl::Blk))) ||
-        (rc = ensure_pool(c, c->pool_mm, (mm_bound + mm_bound / 2) * sizeof(spxl::MM))))
+    if ((rc = ensure_pool(c, c->pool_ops, ops_bound * sizeof(spxl::Op))) || (rc = ensure_pool(c, c->pool_conf, conf_bound * sizeof(spxl::Blk))) ||
+        (rc = ensure_pool(c, c->pool_mm, mm_bound * sizeof(spxl::MM))))
         return fail(rc, "device memory for the preparation pools");
     if ((rc = ensure_pool(c, c->pool_garena, (size_t)(32u << 20) + ns * 4096))) return fail(rc, "device memory for the group scratch");
     fill_prep_args(c, w);
     spx_prep_args &A = w->pa;
+    A.ops_cap = (int64_t)ops_bound; A.conf_cap = (int64_t)conf_bound; A.mm_cap = (int64_t)mm_bound;
     char *base = (char *)w->in_arena;
     spxl::PlanBase *d_base = (spxl::PlanBase *)(base + w->o_base);
     int64_t *d_mkb = (int64_t *)(base + w->o_mkb);
     if (w->ev_staged) HIPCHK(hipStreamWaitEvent(c->prep_stream, w->ev_staged, 0));
-    bool redo_phase1 = true;
+    HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), c->prep_stream));
+    HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
+    HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, c->prep_stream));
     for (int attempt = 0;; ++attempt) {
-        A.P.ops = (spxl::Op *)c->pool_ops.p; A.P.conf = (spxl::Blk *)c->pool_conf.p; A.P.mm = (spxl::MM *)c->pool_mm.p;
-        A.ops_cap = (int64_t)(c->pool_ops.cap / sizeof(spxl::Op)); A.conf_cap = (int64_t)(c->pool_conf.cap / sizeof(spxl::Blk));
-        A.mm_cap = (int64_t)(c->pool_mm.cap / sizeof(spxl::MM));
-        A.arena = (char *)c->pool_garena.p;
-        A.arena_cap = (int64_t)c->pool_garena.cap;
-        HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
-        if (redo_phase1) {
-            HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), c->prep_stream));
-            HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, c->prep_stream));
-        }
         HIPCHK(spx_prep_phase2(&A, d_base, d_mkb, c->prep_stream));
         HIPCHK(hipMemcpyAsync(c->h_tot, c->d_tot, sizeof(spx_prep_totals), hipMemcpyDeviceToHost, c->prep_stream));
         HIPCHK(hipStreamSynchronize(c->prep_stream));
         w->tot = *c->h_tot;
         if (!w->tot.overflow) break;
-        if (attempt >= 6) return fail(SPX_ENOMEM, "preparation scratch keeps overflowing");
-        redo_phase1 = false;
-        if (w->tot.overflow == 3) { /* a table pool was too small: the exact need is known now */
-            if ((rc = ensure_pool(c, c->pool_ops, ((size_t)w->tot.n_ops + 64) * sizeof(spxl::Op))) ||
-                (rc = ensure_pool(c, c->pool_conf, ((size_t)w->tot.n_conf + 64) * sizeof(spxl::Blk))) ||
-                (rc = ensure_pool(c, c->pool_mm, ((size_t)w->tot.n_mm + 64) * sizeof(spxl::MM))))
-                return fail(rc, "device memory for the preparation pools");
-            redo_phase1 = true;
-        } else if (w->tot.overflow == 1) {
+        if (attempt >= 6) return fail(SPX_ENOMEM, "group scratch keeps overflowing");
+        if (w->tot.overflow == 1) {
             if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes + 4096))) return fail(rc, "device memory for the group scratch");
+            A.arena = (char *)c->pool_garena.p;
+            A.arena_cap = (int64_t)c->pool_garena.cap;
         } else {
             A.slack *= 4;
             if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes * 4 + 4096))) return fail(rc, "device memory for the group scratch");
+            A.arena = (char *)c->pool_garena.p;
+            A.arena_cap = (int64_t)c->pool_garena.cap;
         }
+        HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
     }
     const double t1 = now_s();
     /* ---- part B: the work list, its scratch and its outputs, carved to measure ---- */
