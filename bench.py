@@ -87,8 +87,8 @@ def main():
     ap.add_argument("--platform", default="hifi", choices=["hifi", "ont", "mixed"])
     ap.add_argument("--kernel-only", action="store_true", help="only the replay of one prepared work list (profiles, kernel A/B)")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline")
-    ap.add_argument("--distinct", type=int, default=32, help="at most this many distinct batches per rank (HBM / host memory)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight in the pipeline")
+    ap.add_argument("--distinct", type=int, default=8, help="at most this many distinct batches per rank (HBM / host memory)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,7 +133,9 @@ def main():
 
     ont = args.platform == "ont"
     mixed = args.platform == "mixed"
-    gps = args.groups_per_step or (4096 if ont else 8192 if mixed else 32768)
+    gps = args.groups_per_step or (16384 if ont else 16384 if mixed else 131072)
+    # (large batches: the preparation kernels are dependent chains -- one lane walks one alignment / one group -- whose
+    # duration hardly depends on the number of groups, so their cost per group falls with the batch size)
     # config 5 (mixed HiFi+ONT, power-law lengths, <= 8 secondaries) is run as --hifi over the whole mix, SURVEY 8(d)
     params = records.preset("ont", bandwidth=50) if ont else records.preset("hifi")
     cfg = synth.default_cfg(synth.ONT if ont else synth.MIXED if mixed else synth.HIFI)
