@@ -41,6 +41,9 @@ struct spx_prep_args {
     char *arena;
     int64_t arena_cap;
     int32_t slack, pad;
+    /* scratch of the prefix sums: five int64 columns of scan_stride entries, their tile totals, the grand totals */
+    int64_t *scan_v, *scan_tile, *scan_grand;
+    int64_t scan_stride;
     spx_prep_totals *tot;
 };
 

@@ -12,7 +12,7 @@
  *                        the passes over one alignment (the walks over ops and markers: most of the work)
  *   aln_emit / group_finish / problem_constants kernels
  *                        DP problems (with their HMM constants), wanted rows, marker table
- *   scan kernels         exclusive prefix sums that turn the counts into offsets (single workgroup, LDS)
+ *   scan kernels         exclusive prefix sums that turn the counts into offsets (tiles of 1024 through LDS)
  *   order kernels        launch orders of the band classes: radix sort by (class, band, length) + padding to whole waves
  *
  * This is integer, pointer-chasing, latency-bound work: one lane walks one alignment's ops.  It costs a few per cent of
@@ -263,79 +263,115 @@ __device__ __forceinline__ int64_t block_exscan(int64_t v, int64_t *lds, int64_t
     return incl - v;
 }
 
-__global__ __launch_bounds__(1024) void scan_slots_kernel(spx_prep_args A)
+/* Multi-block exclusive scans of up to five int64 columns v[col][n] at once (n = alignments or groups of a batch,
+ * 10^4 .. 10^6): scan_local scans every 1024-element tile in place and leaves the tile totals, scan_tops scans those
+ * (one workgroup; n <= 2^20), and the consumers add tile offset + local value themselves. */
+#define SPX_SCAN_TILE 1024
+__global__ __launch_bounds__(1024) void scan_local_kernel(int64_t *__restrict__ v, int64_t n, int ncol, int64_t stride,
+                                                          int64_t *__restrict__ tile_tot)
 {
     __shared__ int64_t lds[1024];
-    int64_t run_ops = 0, run_conf = 0, run_mm = 0;
-    for (int base = 0; base < A.n_slots; base += 1024) {
-        const int s = base + threadIdx.x;
-        const bool in = s < A.n_slots;
-        const int64_t a = in ? A.ast[s].n_ops : 0, b = in ? A.ast[s].conf_cap : 0, c = in ? A.ast[s].mm_cap : 0;
-        int64_t ta, tb, tc;
-        const int64_t ea = block_exscan(a, lds, ta), eb = block_exscan(b, lds, tb), ec = block_exscan(c, lds, tc);
-        if (in) { A.ast[s].ops_off = run_ops + ea; A.ast[s].conf_off = run_conf + eb; A.ast[s].mm_off = run_mm + ec; }
-        run_ops += ta; run_conf += tb; run_mm += tc;
+    const int64_t i = (int64_t)blockIdx.x * SPX_SCAN_TILE + threadIdx.x;
+    for (int c = 0; c < ncol; ++c) {
+        const int64_t x = i < n ? v[c * stride + i] : 0;
+        int64_t tot;
+        const int64_t e = block_exscan(x, lds, tot);
+        if (i < n) v[c * stride + i] = e;
+        if (threadIdx.x == 0) tile_tot[c * SPX_SCAN_TILE + blockIdx.x] = tot;
     }
-    if (threadIdx.x == 0) { A.tot->n_ops = run_ops; A.tot->n_conf = run_conf; A.tot->n_mm = run_mm; }
+}
+__global__ __launch_bounds__(1024) void scan_tops_kernel(int64_t *__restrict__ tile_tot, int n_tiles, int ncol, int64_t *__restrict__ grand)
+{
+    __shared__ int64_t lds[1024];
+    for (int c = 0; c < ncol; ++c) {
+        const int64_t x = (int)threadIdx.x < n_tiles ? tile_tot[c * SPX_SCAN_TILE + threadIdx.x] : 0;
+        int64_t tot;
+        const int64_t e = block_exscan(x, lds, tot);
+        if ((int)threadIdx.x < n_tiles) tile_tot[c * SPX_SCAN_TILE + threadIdx.x] = e;
+        if (threadIdx.x == 0) grand[c] = tot;
+    }
+}
+__device__ __forceinline__ int64_t scanned(const spx_prep_args &A, int col, int64_t i)
+{
+    return A.scan_v[col * A.scan_stride + i] + A.scan_tile[col * SPX_SCAN_TILE + i / SPX_SCAN_TILE];
+}
+static hipError_t run_scan(const spx_prep_args *A, int64_t n, int ncol, hipStream_t st)
+{
+    const int tiles = (int)((n + SPX_SCAN_TILE - 1) / SPX_SCAN_TILE);
+    if (tiles > SPX_SCAN_TILE) return hipErrorInvalidValue; /* > 2^20 entries: stage fewer groups at a time */
+    hipLaunchKernelGGL(scan_local_kernel, dim3(tiles), dim3(1024), 0, st, A->scan_v, n, ncol, A->scan_stride, A->scan_tile);
+    hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(1024), 0, st, A->scan_tile, tiles, ncol, A->scan_grand);
+    return hipGetLastError();
 }
 
-__global__ __launch_bounds__(1024) void scan_arena_kernel(spx_prep_args A)
+__global__ __launch_bounds__(256) void slots_extract_kernel(spx_prep_args A)
 {
-    __shared__ int64_t lds[1024];
-    int64_t run = 0;
-    for (int base = 0; base < A.n_dgroups; base += 1024) {
-        const int k = base + threadIdx.x;
-        const bool in = k < A.n_dgroups;
-        const int64_t a = in ? A.ga_bytes[k] : 0;
-        int64_t ta;
-        const int64_t ea = block_exscan(a, lds, ta);
-        if (in) A.ga_off[k] = run + ea;
-        run += ta;
-    }
-    if (threadIdx.x == 0) A.tot->arena_bytes = run;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    A.scan_v[0 * A.scan_stride + s] = A.ast[s].n_ops;
+    A.scan_v[1 * A.scan_stride + s] = A.ast[s].conf_cap;
+    A.scan_v[2 * A.scan_stride + s] = A.ast[s].mm_cap;
+}
+__global__ __launch_bounds__(256) void slots_apply_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) { A.tot->n_ops = A.scan_grand[0]; A.tot->n_conf = A.scan_grand[1]; A.tot->n_mm = A.scan_grand[2]; }
+    if (s >= A.n_slots) return;
+    A.ast[s].ops_off = scanned(A, 0, s);
+    A.ast[s].conf_off = scanned(A, 1, s);
+    A.ast[s].mm_off = scanned(A, 2, s);
 }
 
-__global__ __launch_bounds__(1024) void scan_plan_kernel(spx_prep_args A, PlanBase *__restrict__ base_out, int64_t *__restrict__ mk_base)
+__global__ __launch_bounds__(256) void arena_extract_kernel(spx_prep_args A)
 {
-    __shared__ int64_t lds[1024];
-    /* per alignment: where its problems / rows / edits / scratch start */
-    int64_t r_prob = 0, r_row = 0, r_qe = 0, r_s = 0, r_f = 0;
-    for (int b0 = 0; b0 < A.n_slots; b0 += 1024) {
-        const int q = b0 + threadIdx.x;
-        const bool in = q < A.n_slots;
-        int64_t v_prob = 0, v_row = 0, v_qe = 0, v_s = 0, v_f = 0;
-        if (in) { const GroupCount ac = A.ac[q]; v_prob = ac.n_prob; v_row = ac.n_rows; v_qe = ac.n_qe; v_s = ac.s_need; v_f = ac.f_need; }
-        int64_t t1, t2, t3, t4, t5;
-        const int64_t e1 = block_exscan(v_prob, lds, t1), e2 = block_exscan(v_row, lds, t2), e3 = block_exscan(v_qe, lds, t3),
-                      e4 = block_exscan(v_s, lds, t4), e5 = block_exscan(v_f, lds, t5);
-        if (in) {
-            PlanBase pb;
-            pb.prob = r_prob + e1; pb.row = r_row + e2; pb.qe = r_qe + e3; pb.s_off = r_s + e4; pb.f_off = r_f + e5;
-            base_out[q] = pb;
-        }
-        r_prob += t1; r_row += t2; r_qe += t3; r_s += t4; r_f += t5;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < A.n_dgroups) A.scan_v[k] = A.ga_bytes[k];
+}
+__global__ __launch_bounds__(256) void arena_apply_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) A.tot->arena_bytes = A.scan_grand[0];
+    if (k < A.n_dgroups) A.ga_off[k] = scanned(A, 0, k);
+}
+
+__global__ __launch_bounds__(256) void plan_extract_slots_kernel(spx_prep_args A)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= A.n_slots) return;
+    const GroupCount &ac = A.ac[q];
+    A.scan_v[0 * A.scan_stride + q] = ac.n_prob;
+    A.scan_v[1 * A.scan_stride + q] = ac.n_rows;
+    A.scan_v[2 * A.scan_stride + q] = ac.n_qe;
+    A.scan_v[3 * A.scan_stride + q] = ac.s_need;
+    A.scan_v[4 * A.scan_stride + q] = ac.f_need;
+}
+__global__ __launch_bounds__(256) void plan_apply_slots_kernel(spx_prep_args A, PlanBase *__restrict__ base_out)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) {
+        A.tot->n_prob = A.scan_grand[0]; A.tot->n_rows = A.scan_grand[1]; A.tot->n_qe = A.scan_grand[2];
+        A.tot->s_tot = A.scan_grand[3]; A.tot->f_tot = A.scan_grand[4];
     }
-    /* per group: where its marker table starts */
-    int64_t r_mk = 0, r_cells = 0, r_ok = 0;
-    for (int b0 = 0; b0 < A.n_dgroups; b0 += 1024) {
-        const int k = b0 + threadIdx.x;
-        const bool in = k < A.n_dgroups;
-        int64_t v_mk = 0, v_c = 0, v_ok = 0;
-        if (in) {
-            const GroupCount gc = A.gc[k];
-            if (gc.err == 0) { v_mk = (int64_t)gc.n_cols * (A.slot0[k + 1] - A.slot0[k]); v_c = gc.cells; v_ok = 1; }
-        }
-        int64_t t6, t7, t8;
-        const int64_t e6 = block_exscan(v_mk, lds, t6);
-        block_exscan(v_c, lds, t7);
-        block_exscan(v_ok, lds, t8);
-        if (in) mk_base[k] = r_mk + e6;
-        r_mk += t6; r_cells += t7; r_ok += t8;
-    }
-    if (threadIdx.x == 0) {
-        A.tot->n_prob = r_prob; A.tot->n_rows = r_row; A.tot->n_qe = r_qe; A.tot->s_tot = r_s; A.tot->f_tot = r_f;
-        A.tot->n_mk = r_mk; A.tot->cells = r_cells; A.tot->n_ok = r_ok;
-    }
+    if (q >= A.n_slots) return;
+    PlanBase pb;
+    pb.prob = scanned(A, 0, q); pb.row = scanned(A, 1, q); pb.qe = scanned(A, 2, q); pb.s_off = scanned(A, 3, q); pb.f_off = scanned(A, 4, q);
+    base_out[q] = pb;
+}
+__global__ __launch_bounds__(256) void plan_extract_groups_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    const GroupCount &gc = A.gc[k];
+    const bool ok = gc.err == 0;
+    A.scan_v[0 * A.scan_stride + k] = ok ? (int64_t)gc.n_cols * (A.slot0[k + 1] - A.slot0[k]) : 0;
+    A.scan_v[1 * A.scan_stride + k] = ok ? gc.cells : 0;
+    A.scan_v[2 * A.scan_stride + k] = ok ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void plan_apply_groups_kernel(spx_prep_args A, int64_t *__restrict__ mk_base)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { A.tot->n_mk = A.scan_grand[0]; A.tot->cells = A.scan_grand[1]; A.tot->n_ok = A.scan_grand[2]; }
+    if (k < A.n_dgroups) mk_base[k] = scanned(A, 0, k);
 }
 
 /* ---------------------------------------------------------------------- */
@@ -402,7 +438,9 @@ extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *ra
     if (seq_words > 0)
         hipLaunchKernelGGL(recode_kernel, dim3((unsigned)std::min<int64_t>((seq_words + 255) / 256, 2048)), dim3(256), 0, st, raw_seq,
                            (uint32_t *)(A->code4_w + A->P.code_lead_bytes), seq_words, A->recs, A->n_slots, A->ast);
-    hipLaunchKernelGGL(scan_slots_kernel, dim3(1), dim3(1024), 0, st, *A);
+    hipLaunchKernelGGL(slots_extract_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
+    { hipError_t e = run_scan(A, A->n_slots, 3, st); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(slots_apply_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
     hipLaunchKernelGGL(aln_build_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
     return hipGetLastError();
 }
@@ -412,13 +450,20 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
     if (A->n_dgroups <= 0) return hipSuccess;
     const dim3 gg((A->n_dgroups + 63) / 64), ga((A->n_slots + 63) / 64), b64(64);
     hipLaunchKernelGGL(group_arena_kernel, gg, b64, 0, st, *A);
-    hipLaunchKernelGGL(scan_arena_kernel, dim3(1), dim3(1024), 0, st, *A);
+    hipLaunchKernelGGL(arena_extract_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
+    { hipError_t e = run_scan(A, A->n_dgroups, 1, st); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(arena_apply_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
     hipLaunchKernelGGL(group_merge_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(aln_filter_kernel, ga, b64, 0, st, *A);
     hipLaunchKernelGGL(group_blocks_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(aln_count_plan_kernel, ga, b64, 0, st, *A);
     hipLaunchKernelGGL(group_sum_kernel, gg, b64, 0, st, *A);
-    hipLaunchKernelGGL(scan_plan_kernel, dim3(1), dim3(1024), 0, st, *A, base_out, mk_base);
+    hipLaunchKernelGGL(plan_extract_slots_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
+    { hipError_t e = run_scan(A, A->n_slots, 5, st); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(plan_apply_slots_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A, base_out);
+    hipLaunchKernelGGL(plan_extract_groups_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
+    { hipError_t e = run_scan(A, A->n_dgroups, 3, st); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(plan_apply_groups_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A, mk_base);
     return hipGetLastError();
 }
 

@@ -147,7 +147,7 @@ struct spx_work {
     size_t h_stage_cap = 0;
     void *in_arena = nullptr;   /* device: staged buffer | recoded SEQ | per-alignment / per-group state */
     size_t in_cap = 0;
-    size_t o_code = 0, o_ast = 0, o_gc = 0, o_ac = 0, o_gab = 0, o_gao = 0, o_base = 0, o_mkb = 0;
+    size_t o_code = 0, o_ast = 0, o_gc = 0, o_ac = 0, o_gab = 0, o_gao = 0, o_base = 0, o_mkb = 0, o_scan = 0;
     spx_prep_args pa;
     spx_prep_totals tot;
     hipEvent_t ev_ready = nullptr; /* recorded on the preparation stream when the list may be launched */
@@ -673,6 +673,7 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->o_gao = cv.take<int64_t>(ng + 1);
     w->o_base = cv.take<spxl::PlanBase>(ns + 1);
     w->o_mkb = cv.take<int64_t>(ng + 2);
+    w->o_scan = cv.take<int64_t>(5 * (std::max(ns, ng) + 8) + 5 * 1024 + 16);
     (void)o_in;
     w->in_arena = arena_get(c, cv.off + 256, &w->in_cap);
     if (!w->in_arena) { spx_work_free(c, w); return fail(SPX_ENOMEM, "device memory for the staged records"); }
@@ -719,6 +720,10 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.arena = (char *)c->pool_garena.p;
     A.arena_cap = (int64_t)c->pool_garena.cap;
     A.slack = 1;
+    A.scan_stride = (int64_t)std::max(L.n_slots, L.n_dgroups) + 8;
+    A.scan_v = (int64_t *)(base + w->o_scan);
+    A.scan_tile = A.scan_v + 5 * A.scan_stride;
+    A.scan_grand = A.scan_tile + 5 * 1024;
     A.tot = c->d_tot;
 }
 
