@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the pipelined-from-host measurement")
     ap.add_argument("--cpu-bracket", action="store_true", help="also time the -O0 / calloc-per-call / 4-thread variants of the CPU baseline")
     ap.add_argument("--verify", type=int, default=256, help="groups checked against the oracle before timing")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: test rig for the N>1 code path on a box with fewer GPUs than ranks (ranks share devices, "
+                         "records cross ranks through host memory); never a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,9 +129,15 @@ def main():
     ge.build_cpu_helpers()
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the scoring path has no CPU fallback")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the collectives' tensors live
     L = api.lib()
 
     ont = args.platform == "ont"
@@ -233,7 +242,7 @@ def main():
             return
         gbase = (step_global * world + rank) * gps
         nd = work.pack_decisions(gbase, dec_dev.data_ptr(), gps)  # device -> device, then RCCL
-        dparts = shard.gather_bytes(dec_dev[: nd * shard.DECISION_BYTES], dist, torch)
+        dparts = shard.gather_bytes(dec_dev[: nd * shard.DECISION_BYTES].to(coll_dev), dist, torch)
         cands = []
         base = 0
         for bp in ptrs[i]:
@@ -244,7 +253,7 @@ def main():
                 cands.append(np.frombuffer(memoryview(arr), np.uint8).copy())
             base += bp.contents.n_groups
         cbytes = np.concatenate(cands) if cands else np.zeros(0, np.uint8)
-        cparts = shard.gather_bytes(torch.from_numpy(cbytes).to("cuda"), dist, torch)
+        cparts = shard.gather_bytes(torch.from_numpy(cbytes).to(coll_dev), dist, torch)
         if rank == 0:
             _, nw = shard.merge_and_write(api, params, fin, genome.ref, dparts, cparts, log_path)
             relabelled[0] += nw
@@ -291,7 +300,7 @@ def main():
             el_h = time.perf_counter() - t1
             host_leg = (hs, el_h)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -302,7 +311,7 @@ def main():
     cells = sum(int(s.dp_cells) for s in per_step_stats) / nst
     bytes_in = sum(int(s.bytes_h2d) for s in per_step_stats) / nst
     if world > 1:
-        tot = torch.tensor([n_disp, n_prob, cells], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([n_disp, n_prob, cells], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot)
         n_disp_all, n_prob_all, cells_all = [float(x) for x in tot.tolist()]
     else:

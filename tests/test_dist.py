@@ -164,3 +164,69 @@ def test_shard_ranges_cover_everything():
         assert b[0] == 0 and b[-1] == 5000 and all(b[i] <= b[i + 1] for i in range(w))
         assert imb < 1.25  # heaviest shard within 25 % of the mean on a heavy-tailed cost vector
     assert shard.shard_by_cost([], 4)[0] == [0, 0, 0, 0, 0]
+
+
+def _gpu_worker(rank, world, port, tmp):
+    """two ranks sharing ONE MI355X (the pool's boxes have one): each scores its shard on the device through the
+    pipeline, packs its 16-byte decision records with the device kernel, builds its candidate records; the collectives
+    run over gloo here (RCCL needs one GPU per rank) -- everything else is the multi-GPU path of bench.py"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    torch.cuda.is_available()  # torch's HIP runtime first (see conftest.py)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from secphase_amd import api
+    g, p = _setup()
+    whole = g.reads(0, N_GROUPS)
+    b = whole.batch.contents
+    cost = [sum(b.l_qseq[a] for a in range(b.grp_first[k], b.grp_first[k + 1])) * (1 + 7 * (k < N_GROUPS // 3)) for k in range(N_GROUPS)]
+    bounds, _ = shard.shard_by_cost(cost, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n = hi - lo
+    r = g.reads(lo, n)
+    ctx = api.Context(0)
+    ctx.set_reference(g.ref)
+    w = ctx.stage(r.batch, p)
+    pipe = api.Pipe(ctx, p, depth=2, host_threads=4)
+    pipe.submit(staged=w)
+    out, got = pipe.next()
+    assert got == n
+    dev = torch.zeros(max(n, 1) * 16, dtype=torch.uint8, device="cuda")
+    nd = w.pack_decisions(lo, dev.data_ptr(), max(n, 1))
+    L = api.lib()
+    nc = L.spx_relabel_candidates(r.batch, lo, out, C.byref(p), None, 0)
+    cand = (api.RelabelRec * max(nc, 1))()
+    assert L.spx_relabel_candidates(r.batch, lo, out, C.byref(p), cand, nc) == nc
+    dparts = shard.gather_bytes(dev[: nd * 16].cpu(), dist, torch)
+    cparts = shard.gather_bytes(torch.from_numpy(np.frombuffer(memoryview(cand), np.uint8)[: nc * C.sizeof(api.RelabelRec)].copy()), dist, torch)
+    if rank == 0:
+        fin = C.c_void_p()
+        api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+        log = os.path.join(tmp, "dist_gpu.out.log")
+        open(log, "w").close()
+        ndec, nrec = shard.merge_and_write(api, p, fin, g.ref, dparts, cparts, log)
+        L.spx_finalizer_free(fin)
+        open(os.path.join(tmp, "info_gpu.txt"), "w").write(f"{ndec} {nrec} {bounds[1]}\n")
+    pipe.close()
+    w.free()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_device_emit_the_same_relabel_list(built, tmp_path):
+    """the multi-GPU path with the scores coming from the HIP kernels: unequal shards, device-packed decision records,
+    tie groups -- rank 0's out.log is byte-identical to the oracle's single-process list"""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from oracle import orc
+    g, p = _setup()
+    r = g.reads(0, N_GROUPS)
+    log_o = str(tmp_path / "one.out.log")
+    nre, res = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1, log_path=log_o)
+    ndec, nrec, cut = open(str(tmp_path / "info_gpu.txt")).read().split()
+    assert int(cut) != N_GROUPS // 2 and int(ndec) == sum(1 for e in res if e.n_aln >= 2) and int(nrec) == nre
+    assert filecmp.cmp(log_o, str(tmp_path / "dist_gpu.out.log"), shallow=False)
