@@ -499,7 +499,7 @@ struct GroupView {
 /* what one group needs in its scratch arena (bytes), from the per-alignment counts */
 struct GroupArena {
     int32_t P_cap, blk_cap, rows_cap;
-    int64_t o_pos, o_mk, o_keep, o_flank, o_cur, o_nxt, o_proj, o_nproj, o_rowsmk, bytes;
+    int64_t o_pos, o_mk, o_keep, o_flank, o_cur, o_nxt, o_proj, o_nproj, o_state, o_rowsmk, bytes;
 };
 SPX_HD GroupArena group_arena_layout(const GroupView &G, bool all_rows, int slack)
 {
@@ -527,7 +527,8 @@ SPX_HD GroupArena group_arena_layout(const GroupView &G, bool all_rows, int slac
     A.o_cur = take((int64_t)sizeof(Iv) * A.blk_cap);
     A.o_nxt = take((int64_t)sizeof(Iv) * A.blk_cap);
     A.o_proj = take((int64_t)sizeof(Blk) * A.blk_cap * G.n);
-    A.o_nproj = take(4 * 16);
+    A.o_nproj = take(4 * 32); /* [0..10): block counts per alignment, [16..26): their too-long flags */
+    A.o_state = take(64);
     A.o_rowsmk = take(4 * (int64_t)A.rows_cap * (G.n > 0 ? G.n : 1)); /* one list per alignment: their passes run side by side */
     A.bytes = o;
     return A;
@@ -700,8 +701,9 @@ SPX_HD void sort_intervals(Iv *b, int n)
 /* intersect_by_rd_f (ptMarker.c:398-435): strict '<' overlap test, windows that merely touch do not intersect.
  * GetY(j) yields interval j of the second list (an Iv list, or the read coordinates of a block list). */
 template <class GetY>
-SPX_HD int intersect(const Iv *x, int nx, GetY gety, int ny, Iv *out, int cap)
+SPX_HD int intersect(const Iv *x, int nx, GetY gety, int ny, Iv *out, int cap, bool *all_positive = nullptr)
 {
+    if (all_positive) *all_positive = true;
     if (nx == 0 || ny == 0) return 0;
     int cnt = 0, j = 0;
     Iv y = gety(0);
@@ -712,6 +714,7 @@ SPX_HD int intersect(const Iv *x, int nx, GetY gety, int ny, Iv *out, int cap)
             if (cnt >= cap) return -1;
             Iv b = {xi.s > y.s ? xi.s : y.s, xi.e < y.e ? xi.e : y.e};
             out[cnt++] = b;
+            if (all_positive && !(b.s < b.e)) *all_positive = false;
             if (y.e <= xi.e) { ++j; if (j < ny) y = gety(j); } else break;
         }
     }
@@ -764,6 +767,16 @@ SPX_HD int project_blocks(const Rec &r, const AlnState &st, const Op *ops, const
     return cnt;
 }
 
+/* the consensus rounds of a group can be interrupted where the windows have to be projected onto the alignments (a
+ * walk over every alignment's ops: one thread per alignment does that on the device) and resumed afterwards */
+struct BlocksState {
+    int32_t margin, iter, nblk, same, np, nc, too_long;
+    int32_t phase;      /* 0: rounds running, 1: projections of cur[0..nc) wanted, 2: finished */
+    int32_t pi, ci, ni; /* which of the three interval buffers is prev / cur / nxt */
+    int32_t result;     /* at phase 2: 1 scored, 0 not scored, < 0 SPX_E* */
+    int32_t ncol, pad[3];
+};
+
 /* the scratch arrays of one group */
 struct GroupScratch {
     int32_t *pos;
@@ -772,6 +785,7 @@ struct GroupScratch {
     Iv *flank, *cur, *nxt; /* interval lists of the consensus rounds: read coordinates only */
     Blk *proj;       /* [n][blk_cap]: each alignment's current block list (confident blocks, then projected windows) */
     int32_t *nproj;  /* [n] */
+    struct BlocksState *bstate;
     int32_t *rows_mk;
     int32_t blk_cap, rows_cap;
 };
@@ -786,50 +800,43 @@ SPX_HD GroupScratch group_scratch(const GroupArena &A, char *base)
     S.nxt = (Iv *)(base + A.o_nxt);
     S.proj = (Blk *)(base + A.o_proj);
     S.nproj = (int32_t *)(base + A.o_nproj);
+    S.bstate = (struct BlocksState *)(base + A.o_state);
     S.rows_mk = (int32_t *)(base + A.o_rowsmk);
     S.blk_cap = A.blk_cap;
     S.rows_cap = A.rows_cap;
     return S;
 }
 
-/* consensus windows (secphase.c:162-170 + ptMarker.c:398-667).  On return S.proj/S.nproj hold, per alignment, the
- * blocks plan_baq walks.  Returns 1 if the group is scored, 0 if not, < 0 on SPX_E*. */
-SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, int ncol)
+SPX_HD Iv *blocks_buf(const GroupScratch &S, int k) { return k == 0 ? S.flank : k == 1 ? S.cur : S.nxt; }
+
+/* rounds of the consensus loop (secphase.c:162-170 + ptMarker.c:398-667) until the windows must be projected onto the
+ * alignments (phase 1) or the loop ends (phase 2) */
+SPX_HD void blocks_rounds(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, BlocksState &B)
 {
-    const int n = G.n, cap = S.blk_cap;
-    bool too_long = false; /* needs_to_find_blocks: a block longer than 1000 (SEQ or reference), or an alignment without blocks */
-    for (int i = 0; i < n; ++i) {
-        const AlnState &st = G.st[i];
-        if (st.n_conf > cap) return SPX_ENOMEM;
-        Blk *dst = S.proj + (int64_t)i * cap;
-        for (int k = 0; k < st.n_conf; ++k) {
-            const Blk b = P.conf[st.conf_off + k];
-            dst[k] = b;
-            if ((b.sqe - b.sqs) > 1000 || (b.rfe - b.rfs) > 1000) too_long = true;
-        }
-        S.nproj[i] = st.n_conf;
-        if (st.n_conf == 0) too_long = true;
-    }
-    int margin = par.flank_margin, nblk = 1 /* DESIGN.md U1 */, iter = 0;
-    /* `same`: every alignment's block list is, in read coordinates, the interval list prev[0..np) of the round before
-     * (see the long-window shortcut below); otherwise the lists are S.proj */
-    bool same = false;
-    Iv *prev = S.flank; /* three buffers rotate: prev / cur / nxt; flank windows are generated into the spare one */
-    int np = 0;
-    Iv *cur = S.cur, *nxt = S.nxt;
-    while (par.consensus && too_long) {
-        margin = (int)(margin * 0.8);
-        /* intersect every alignment's blocks, then every alignment's flanking windows, in read coordinates */
+    const int n = G.n, cap = S.blk_cap, ncol = B.ncol;
+    Iv *prev = blocks_buf(S, B.pi), *cur = blocks_buf(S, B.ci), *nxt = blocks_buf(S, B.ni);
+    int pi = B.pi, ci = B.ci, ni = B.ni;
+    auto swap_cn = [&]() { Iv *t = cur; cur = nxt; nxt = t; const int q = ci; ci = ni; ni = q; };
+    auto fail = [&](int code) { B.phase = 2; B.result = code; };
+    while (par.consensus && B.too_long) {
+        B.margin = (int)(B.margin * 0.8);
+        const int margin = B.margin;
+        /* intersect every alignment's blocks, then every alignment's flanking windows, in read coordinates.  Once a
+         * list has been intersected with one copy of another list, every interval lies inside ONE interval of that
+         * list; intersecting it with the same list again changes nothing as long as no interval is empty (strict '<'
+         * drops those) -- such repeats are skipped. */
         int nc;
-        if (same) {
-            nc = np;
-            for (int k = 0; k < np; ++k) cur[k] = prev[k];
+        bool positive = false;
+        if (B.same) {
+            nc = B.np;
+            for (int k = 0; k < nc; ++k) cur[k] = prev[k];
             for (int i = 1; i < n; ++i) {
+                if (i > 1 && positive) continue;
                 const Iv *pv = prev;
-                const int m = intersect(cur, nc, [&](int j) { return pv[j]; }, np, nxt, cap);
-                if (m < 0) return SPX_ENOMEM;
+                const int m = intersect(cur, nc, [&](int j) { return pv[j]; }, B.np, nxt, cap, &positive);
+                if (m < 0) return fail(SPX_ENOMEM);
                 nc = m;
-                Iv *t = cur; cur = nxt; nxt = t;
+                swap_cn();
             }
         } else {
             sort_blocks<0>(S.proj, S.nproj[0]);
@@ -839,9 +846,9 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
                 Blk *bi = S.proj + (int64_t)i * cap;
                 sort_blocks<0>(bi, S.nproj[i]);
                 const int m = intersect(cur, nc, [&](int j) { Iv v = {bi[j].rds, bi[j].rde}; return v; }, S.nproj[i], nxt, cap);
-                if (m < 0) return SPX_ENOMEM;
+                if (m < 0) return fail(SPX_ENOMEM);
                 nc = m;
-                Iv *t = cur; cur = nxt; nxt = t;
+                swap_cn();
             }
         }
         /* prev is free now: it takes the flanking windows.  With a positive margin and every marker position inside
@@ -857,37 +864,40 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
             AlnState wide = G.st[0];
             wide.rds = -0x3fffffff; wide.rde = 0x3fffffff;
             nu = flank_blocks(wide, S.pos, ncol, n, margin, fl, cap);
-            if (nu < 0) return SPX_ENOMEM;
+            if (nu < 0) return fail(SPX_ENOMEM);
         }
+        positive = false;
         for (int i = 0; i < n; ++i) {
             int nf, m;
             if (shared) {
+                const int lo = G.st[i].rds, hi = G.st[i].rde, lastj = nu - 1;
+                /* after the first alignment: same windows, another clamp -- nothing to do when the clamp cuts nothing */
+                if (i > 0 && positive && nc > 0 && lo <= cur[0].s && hi >= cur[nc - 1].e) continue;
                 nf = nu;
                 const Iv *fv = fl;
-                const int lo = G.st[i].rds, hi = G.st[i].rde, lastj = nu - 1;
                 m = intersect(cur, nc, [&](int j) {
                     Iv v = fv[j];
                     if (j == 0 && v.s < lo) v.s = lo;
                     if (j == lastj && v.e > hi) v.e = hi;
                     return v;
-                }, nf, nxt, cap);
+                }, nf, nxt, cap, &positive);
             } else {
                 nf = flank_blocks(G.st[i], S.pos, ncol, n, margin, fl, cap);
-                if (nf < 0) return SPX_ENOMEM;
+                if (nf < 0) return fail(SPX_ENOMEM);
                 sort_intervals(fl, nf);
                 const Iv *fv = fl;
                 m = intersect(cur, nc, [&](int j) { return fv[j]; }, nf, nxt, cap);
             }
-            if (m < 0) return SPX_ENOMEM;
+            if (m < 0) return fail(SPX_ENOMEM);
             nc = m;
-            Iv *t = cur; cur = nxt; nxt = t;
+            swap_cn();
         }
         if (nc == 0) {
             for (int i = 0; i < n; ++i) S.nproj[i] = 0;
-            nblk = 0;
+            B.nblk = 0;
             break;
         }
-        ++iter;
+        ++B.iter;
         /* A window longer than 1000 bases in READ coordinates is longer than 1000 in SEQ coordinates on every
          * alignment (inside an alignment SEQ index and read position move together), so the loop is certain to go
          * round again and this round's projection onto the alignments -- a walk over all their ops -- would only
@@ -897,28 +907,92 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
         bool long_window = false;
         for (int k = 0; k < nc; ++k)
             if (cur[k].e - cur[k].s > 1000) long_window = true;
-        nblk = nc;
-        if (long_window && iter < 64) {
-            same = true;
-            Iv *t = prev; prev = cur; cur = t; /* this round's windows become `prev` */
-            np = nc;
-            too_long = true;
+        B.nblk = nc;
+        if (long_window && B.iter < 64) {
+            B.same = 1;
+            { Iv *t = prev; prev = cur; cur = t; const int q = pi; pi = ci; ci = q; } /* this round's windows become `prev` */
+            B.np = nc;
+            B.too_long = 1;
         } else {
-            same = false;
-            too_long = false;
-            for (int i = 0; i < n; ++i) {
-                Blk *dst = S.proj + (int64_t)i * cap;
-                const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, cur, nc, par.indel_threshold, dst, cap);
-                if (m < 0) return SPX_ENOMEM;
-                S.nproj[i] = m;
-                if (m == 0) too_long = true;
-                for (int k = 0; k < m; ++k)
-                    if ((dst[k].sqe - dst[k].sqs) > 1000 || (dst[k].rfe - dst[k].rfs) > 1000) too_long = true;
-            }
+            B.same = 0;
+            B.nc = nc;
+            B.pi = pi; B.ci = ci; B.ni = ni;
+            B.phase = 1; /* project cur[0..nc) onto every alignment, then blocks_after_projection */
+            return;
         }
-        if (iter >= 64) break;
     }
-    return (nblk > 0 || !par.consensus) ? 1 : 0;
+    B.pi = pi; B.ci = ci; B.ni = ni;
+    B.phase = 2;
+    B.result = (B.nblk > 0 || !par.consensus) ? 1 : 0;
+}
+
+SPX_HD void blocks_begin(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, int ncol, BlocksState &B)
+{
+    const int n = G.n, cap = S.blk_cap;
+    B.margin = par.flank_margin; B.iter = 0; B.nblk = 1 /* DESIGN.md U1 */; B.same = 0; B.np = 0; B.nc = 0;
+    B.phase = 0; B.pi = 0; B.ci = 1; B.ni = 2; B.result = 0; B.ncol = ncol; B.pad[0] = B.pad[1] = B.pad[2] = 0;
+    bool too_long = false; /* needs_to_find_blocks: a block longer than 1000 (SEQ or reference), or an alignment without blocks */
+    for (int i = 0; i < n; ++i) {
+        const AlnState &st = G.st[i];
+        if (st.n_conf > cap) { B.phase = 2; B.result = SPX_ENOMEM; return; }
+        Blk *dst = S.proj + (int64_t)i * cap;
+        for (int k = 0; k < st.n_conf; ++k) {
+            const Blk b = P.conf[st.conf_off + k];
+            dst[k] = b;
+            if ((b.sqe - b.sqs) > 1000 || (b.rfe - b.rfs) > 1000) too_long = true;
+        }
+        S.nproj[i] = st.n_conf;
+        if (st.n_conf == 0) too_long = true;
+    }
+    B.too_long = too_long;
+    blocks_rounds(G, P, par, S, B);
+}
+
+/* phase 1, one alignment: its blocks for the windows cur[0..nc) */
+SPX_HD void blocks_project(const GroupView &G, int i, const Pools &P, const Params &par, GroupScratch &S, const BlocksState &B)
+{
+    if (B.phase != 1) return;
+    const int cap = S.blk_cap;
+    Blk *dst = S.proj + (int64_t)i * cap;
+    const int m = project_blocks(G.rec[i], G.st[i], P.ops + G.st[i].ops_off, blocks_buf(S, B.ci), B.nc, par.indel_threshold, dst, cap);
+    S.nproj[i] = m;
+    bool tl = m <= 0;
+    for (int k = 0; k < m; ++k)
+        if ((dst[k].sqe - dst[k].sqs) > 1000 || (dst[k].rfe - dst[k].rfs) > 1000) tl = true;
+    S.nproj[16 + i] = tl ? 1 : 0;
+}
+
+/* phase 1 -> after every alignment has its blocks: goes on with the rounds or ends */
+SPX_HD void blocks_after_projection(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, BlocksState &B)
+{
+    if (B.phase != 1) return;
+    bool too_long = false;
+    for (int i = 0; i < G.n; ++i) {
+        if (S.nproj[i] < 0) { B.phase = 2; B.result = SPX_ENOMEM; return; }
+        if (S.nproj[16 + i]) too_long = true;
+    }
+    B.too_long = too_long;
+    B.phase = 0;
+    if (B.iter >= 64) { B.phase = 2; B.result = (B.nblk > 0 || !par.consensus) ? 1 : 0; return; }
+    blocks_rounds(G, P, par, S, B);
+}
+
+/* the whole loop in one go (host plan; on the device the tail of groups that need more projection rounds than the
+ * kernel sequence provides).  On return S.proj / S.nproj hold, per alignment, the blocks plan_baq walks.  Returns 1 if
+ * the group is scored, 0 if not, < 0 on SPX_E*. */
+SPX_HD int blocks_finish(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, BlocksState &B)
+{
+    while (B.phase == 1) {
+        for (int i = 0; i < G.n; ++i) blocks_project(G, i, P, par, S, B);
+        blocks_after_projection(G, P, par, S, B);
+    }
+    return B.result;
+}
+SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, int ncol)
+{
+    BlocksState B;
+    blocks_begin(G, P, par, S, ncol, B);
+    return blocks_finish(G, P, par, S, B);
 }
 
 /* where the emitting pass writes */
@@ -1162,6 +1236,25 @@ SPX_HD void group_pass_blocks(const GroupView &G, const Pools &P, const Params &
     gc.n_cols = ncol;
     if (ncol == 0) return;
     const int sc = group_blocks(G, P, par, S, ncol);
+    if (sc < 0) { gc.err = sc; gc.n_cols = 0; return; }
+    gc.scored = sc;
+    if (!sc) gc.n_cols = 0;
+}
+
+/* G2 on the device, split at the projections: begin (columns, rounds up to the first projection), per-alignment
+ * projections and resume (a fixed number of times), end (whatever is left, serially) */
+SPX_HD void group_pass_blocks_begin(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, GroupCount &gc)
+{
+    if (gc.err || gc.n_cols == 0) return;
+    const int ncol = group_compact(G, S.pos, S.mk, S.keep, gc.n_cols);
+    gc.n_cols = ncol;
+    if (ncol == 0) return;
+    blocks_begin(G, P, par, S, ncol, *S.bstate);
+}
+SPX_HD void group_pass_blocks_end(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, GroupCount &gc)
+{
+    if (gc.err || gc.n_cols == 0) return;
+    const int sc = blocks_finish(G, P, par, S, *S.bstate);
     if (sc < 0) { gc.err = sc; gc.n_cols = 0; return; }
     gc.scored = sc;
     if (!sc) gc.n_cols = 0;

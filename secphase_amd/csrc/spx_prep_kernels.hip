@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
     aln_pass_filter(c.G, s - A.slot0[k], A.P, c.S, gc);
 }
 
+/* consensus windows: rounds run per group, the projections of the windows onto the alignments per alignment */
 __global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,7 +155,40 @@ __global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
     GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
-    group_pass_blocks(c.G, A.P, A.par, c.S, gc);
+    group_pass_blocks_begin(c.G, A.P, A.par, c.S, gc);
+    A.gc[k] = gc;
+}
+__global__ __launch_bounds__(64) void aln_project_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    const int k = A.recs[s].grp;
+    const GroupCount gc = A.gc[k];
+    if (gc.err || gc.n_cols == 0) return;
+    GroupCtx c = group_ctx(A, k);
+    const BlocksState B = *c.S.bstate;
+    blocks_project(c.G, s - A.slot0[k], A.P, A.par, c.S, B);
+}
+__global__ __launch_bounds__(64) void group_resume_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    const GroupCount gc = A.gc[k];
+    if (gc.err || gc.n_cols == 0) return;
+    GroupCtx c = group_ctx(A, k);
+    if (c.S.bstate->phase != 1) return;
+    BlocksState B = *c.S.bstate;
+    blocks_after_projection(c.G, A.P, A.par, c.S, B);
+    *c.S.bstate = B;
+}
+__global__ __launch_bounds__(64) void group_blocks_end_kernel(spx_prep_args A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
+    GroupCount gc = A.gc[k];
+    if (gc.err || gc.n_cols == 0) return;
+    GroupCtx c = group_ctx(A, k);
+    group_pass_blocks_end(c.G, A.P, A.par, c.S, gc);
     if (gc.err == SPX_ENOMEM) A.tot->overflow = 2; /* an interval list outgrew its estimate: repeat with more slack */
     A.gc[k] = gc;
 }
@@ -456,6 +490,11 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
     hipLaunchKernelGGL(group_merge_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(aln_filter_kernel, ga, b64, 0, st, *A);
     hipLaunchKernelGGL(group_blocks_kernel, gg, b64, 0, st, *A);
+    for (int round = 0; round < 3; ++round) { /* nearly every group needs one or two projection rounds */
+        hipLaunchKernelGGL(aln_project_kernel, ga, b64, 0, st, *A);
+        hipLaunchKernelGGL(group_resume_kernel, gg, b64, 0, st, *A);
+    }
+    hipLaunchKernelGGL(group_blocks_end_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(aln_count_plan_kernel, ga, b64, 0, st, *A);
     hipLaunchKernelGGL(group_sum_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(plan_extract_slots_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
