@@ -361,12 +361,11 @@ struct Prob {
 };
 
 template <int G>
-__device__ __forceinline__ Prob load_problem(const spx_dev_batch &B, int lane, HmmC &h, int &hasN, bool bwd = false,
-                                              int wave_slot = -1)
+__device__ __forceinline__ Prob load_problem(const spx_dev_batch &B, int lane, HmmC &h, int &hasN, bool bwd = false)
 {
     constexpr int PPW = 64 / G;
     Prob P;
-    const int oslot = (wave_slot < 0 ? (int)blockIdx.x : wave_slot) * PPW + lane / G;
+    const int oslot = blockIdx.x * PPW + lane / G;
     P.pid = bwd ? (oslot < B.n_order_bwd ? B.order_bwd[oslot] : -1) : (oslot < B.n_order ? B.order[oslot] : -1);
     P.L = P.R = P.bw = P.nrows = P.row0 = 0;
     P.ref0 = P.qry0 = 0;
@@ -408,9 +407,6 @@ __device__ __forceinline__ int wave_min(int v)
 #endif
 #ifndef SPX_WAVES_B
 #define SPX_WAVES_B 2
-#endif
-#ifndef SPX_WAVES_C
-#define SPX_WAVES_C 2
 #endif
 
 /* ====================================================================== */
@@ -588,354 +584,6 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
         }
         const double sL1 = __shfl(mysum, tlast, G);
         if (act && g == 0) { sinv[L] = s_cur; sinv[L + 1] = sL1; } /* raw s[L], s[L+1] for the backward start */
-    }
-}
-
-/* ====================================================================== */
-/* Cooperative forward pass for the four-lane classes (the ONT band widths): a workgroup of four waves holds 64
- * problems (16 per wave, 4 lanes x C slots each, as in baq_fwd_kernel<4,C>).  In the one-wave kernel half of all
- * instructions are the serial passes -- the D recurrence and the ordered row sum, executed by the whole wave for the
- * benefit of one lane in four.  Here the D recurrence of all 64 problems is handed to ONE wave (the waves take turns,
- * row by row): every lane writes its a(k) = m2*M(i,k-1) to LDS, [cell][problem], the serving wave runs the chain
- * D(k) = a(k) + m8*D(k-1) with one problem per lane -- 2 instructions per cell for 64 problems instead of for 16 -- and
- * writes D back in place; the D row stays in LDS (it is read again, scaled, by the next row), which frees the registers
- * that hold x(k) = (M+I)+D for the ordered sum, so that the four sum passes cost one add per slot.  Same operations in
- * the same order as the reference: results are bit-identical to baq_fwd_kernel's.
- * LDS image: cell k of problem p lives at double index k*64 + (p ^ swz(k/C)); the swizzle makes the 16-lane groups of
- * ds_write_b64 and the 32-lane groups of ds_read_b64 of the OWNING lanes (4 lanes x 16 problems per wave) conflict-free,
- * and the serving wave (lane = problem) reads a permutation of 64 consecutive doubles. */
-/* workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global store and load in flight
- * (vmcnt(0)) -- the saved rows, 1/s[i], the next code chunk -- which would put an HBM round trip into every row */
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ int coop_swz(int t) { return (t << 2) ^ ((t & 1) << 4); }
-
-template <int C>
-__global__ __launch_bounds__(256, SPX_WAVES_C) void baq_fwdc_kernel(spx_dev_batch B)
-{
-    constexpr int G = 4, SLOTS = G * C;
-    __shared__ double sA[SLOTS * 64];
-    __shared__ double s_m8[64];
-    __shared__ double s_h[8][64]; /* m0 m1 m2 m3 m4 m6 e_match e_mis per problem: read back at the start of every row */
-    __shared__ int s_rb[64], s_wu[64]; /* R + bw and W of problem p (W = 0: no problem) */
-    __shared__ int s_red[4][8];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = lane % G, q = lane / G, p = wv * 16 + q;
-    HmmC h;
-    int hasN;
-    const Prob P = load_problem<G>(B, lane, h, hasN, false, blockIdx.x * 4 + wv);
-    const bool act = P.act;
-    const int L = P.L, R = P.R, bw = P.bw;
-    const int Wu = wave_max(act ? 2 * bw + 1 : 0);
-    const int Lw = wave_max(L);
-    const int anyN = wave_max(hasN);
-    const int fast_end = anyN ? 1 : min(wave_min(act ? R - bw : 0x7fffffff), Lw);
-    /* workgroup-wide figures: rows to walk, and the bounds of the serving wave's three zones */
-    if (g == 0) {
-        s_m8[p] = h.m8; s_rb[p] = act ? R + bw : 0; s_wu[p] = act ? 2 * bw + 1 : 0;
-        s_h[0][p] = h.m0; s_h[1][p] = h.m1; s_h[2][p] = h.m2; s_h[3][p] = h.m3; s_h[4][p] = h.m4; s_h[5][p] = h.m6;
-        s_h[6][p] = h.e_match; s_h[7][p] = h.e_mis;
-    }
-    {
-        const int wmin = wave_min(act ? 2 * bw + 1 : 0x7fffffff);
-        const int rbmin = wave_min(act ? R + bw : 0x7fffffff), rbmax = wave_max(act ? R + bw : 0);
-        if (lane == 0) {
-            s_red[wv][0] = Lw; s_red[wv][1] = wmin; s_red[wv][2] = Wu; s_red[wv][3] = rbmin; s_red[wv][4] = rbmax;
-            s_red[wv][5] = Lw > 0 ? fast_end : 0x7fffffff;
-        }
-    }
-    __syncthreads();
-    const int Lwg = max(max(s_red[0][0], s_red[1][0]), max(s_red[2][0], s_red[3][0]));
-    if (Lwg == 0) return;
-    const int Wmin = min(min(s_red[0][1], s_red[1][1]), min(s_red[2][1], s_red[3][1]));
-    const int Wmax = max(max(s_red[0][2], s_red[1][2]), max(s_red[2][2], s_red[3][2]));
-    const int RBmin = min(min(s_red[0][3], s_red[1][3]), min(s_red[2][3], s_red[3][3]));
-    const int RBmax = max(max(s_red[0][4], s_red[1][4]), max(s_red[2][4], s_red[3][4]));
-    const int tlast = (Wu - 1) / C;
-    const int jbase = g * C;
-    const int bwu = (Wu - 1) / 2;
-
-    double fM[C], fI[C], xs[C];
-    double *myA = sA + (int64_t)jbase * 64 + (p ^ coop_swz(g)); /* slot c: myA[c * 64] */
-    double dinv = 1.0;
-    CodeWin<C> cw, padw;
-    double *sinv = B.sinv + (act ? B.s_off[P.pid] : 0);
-    const int pid = P.pid;
-    double s_cur = 1.0;
-    int wnext = 0;
-    int next_row = P.nrows > 0 ? B.rows[P.row0] : 0x7fffffff;
-    auto save_row = [&]() { /* rare: what it needs is fetched again rather than kept in registers over the row loop */
-        double *dst = B.fsave + B.fsave_off[pid] + (int64_t)wnext * B.fsave_stride + jbase;
-#pragma unroll
-        for (int c = 0; c < C; ++c) { dst[c] = fM[c]; dst[SLOTS + c] = fI[c]; }
-        wnext++;
-        next_row = wnext < B.n_rows[pid] ? B.rows[B.row_off[pid] + wnext] : 0x7fffffff;
-    };
-    /* row 1 (no D state): as in baq_fwd_kernel */
-    {
-        const double bM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_BM] : 0.0;
-        const double bI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_BI] : 0.0;
-        const uint32_t qy = act ? fetch_code(B.qry4, P.qry0, 0, L) : 0;
-#pragma unroll
-        for (int k = 0; k < CodeWin<C>::NW; ++k) { cw.w[k] = 0; padw.w[k] = 0; }
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int j = jbase + c;
-            cw.set(c, act ? fetch_code(B.ref4, P.ref0, j - bw, R) : SPX_CODE_OUT);
-            padw.set(c, j < Wu ? 0u : (uint32_t)SPX_CODE_OUT);
-        }
-        CodeWin<C> ew;
-#pragma unroll
-        for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const uint32_t code = ew.get(c);
-            const bool valid = !(code & SPX_CODE_OUT);
-            const double e = emission<false>(code, qy, h.e_match, h.e_mis);
-            fM[c] = valid ? e * bM : 0.0;
-            fI[c] = valid ? SPX_EI * bI : 0.0;
-            myA[c * 64] = 0.0;
-        }
-        double carry = 0.0, mysum = 0.0;
-        for (int t = 0; t <= tlast; ++t) {
-            if (g == t) {
-                double s = carry;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const bool valid = !(ew.get(c) & SPX_CODE_OUT);
-                    const double tt = fM[c] + fI[c];
-                    s = valid ? s + tt : s;
-                }
-                mysum = s;
-                carry = s;
-            }
-            carry = shfl_up1<G>(carry);
-        }
-        const double tot = __shfl(mysum, tlast, G);
-        s_cur = tot;
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                fM[c] = fM[c] / tot;
-                fI[c] = fI[c] / tot;
-            }
-            if (g == 0) sinv[1] = 1.0 / tot;
-            if (B.s_raw && g == 0) B.s_raw[(sinv - B.sinv) + 1] = tot;
-            if (next_row == 1) save_row();
-        }
-    }
-    const int top = jbase + C - 1;
-    auto ref_chunk = [&](int ib) { return fetch8(B.ref4, P.ref0 + (ib - bw + top - 1)); };
-    auto qry_chunk = [&](int ib) { return fetch8(B.qry4, P.qry0 + (ib - 1)); };
-    uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
-    uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
-    CodeWin<C> ew;
-
-    /* part A of a row: M and I of row i (unscaled) into fM, fI; a(k) into the LDS image */
-    auto part_a = [&](int i, auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        HmmC h;
-        h.m0 = s_h[0][p]; h.m1 = s_h[1][p]; h.m2 = s_h[2][p]; h.m3 = s_h[3][p]; h.m4 = s_h[4][p]; h.m6 = s_h[5][p];
-        h.e_match = s_h[6][p]; h.e_mis = s_h[7][p];
-        const uint32_t t4 = (uint32_t)((i - 1) & 7) * 4u;
-        if (t4 == 0) {
-            qwin = qwin_n; rwin = rwin_n;
-            qwin_n = qry_chunk(i + 8); rwin_n = ref_chunk(i + 8);
-        }
-        const uint32_t qy = (qwin >> t4) & 0xfu;
-        uint32_t rc = (rwin >> t4) & 0xfu;
-        if ((unsigned)(i - bw + top - 1) >= (unsigned)R) rc = SPX_CODE_OUT;
-        cw.shift_down(rc);
-#pragma unroll
-        for (int k = 0; k < CodeWin<C>::NW; ++k) ew.w[k] = cw.w[k] | padw.w[k];
-        double nM = shfl_down1<G>(fM[0]), nI = shfl_down1<G>(fI[0]);
-        if (g == G - 1) { nM = 0.0; nI = 0.0; }
-        double prevM = 0.0;
-        /* the D row comes from LDS a few slots ahead of its use -- and no further: the scheduler would otherwise hoist
-         * all C loads to the top and spill what they displace */
-        constexpr int CH = 7, NCH = (C + CH - 1) / CH;
-        double pdc[CH], pdn[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) pdc[c] = myA[c * 64];
-#pragma unroll
-        for (int b = 0; b < NCH; ++b) {
-            if (b + 1 < NCH) {
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    if ((b + 1) * CH + c < C) pdn[c] = myA[((b + 1) * CH + c) * 64];
-            }
-#pragma unroll
-            for (int cc = 0; cc < CH; ++cc) {
-                const int c = b * CH + cc;
-                if (c >= C) break;
-                const double pD = pdc[cc] * dinv;
-                const double S = (h.m0 * fM[c] + h.m3 * fI[c]) + h.m6 * pD;
-                const double e = emission<FAST>(ew.get(c), qy, h.e_match, h.e_mis);
-                const double pMn = (c + 1 < C) ? fM[c + 1] : nM, pIn = (c + 1 < C) ? fI[c + 1] : nI;
-                const double newM = e * S;
-                fI[c] = SPX_EI * (h.m1 * pMn + h.m4 * pIn);
-                if (c > 0) myA[c * 64] = h.m2 * prevM;
-                fM[c] = newM;
-                prevM = newM;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) pdc[c] = pdn[c];
-        }
-        double pl = shfl_up1<G>(prevM);
-        if (g == 0 || g > tlast) pl = 0.0;
-        myA[0] = h.m2 * pl;
-    };
-    /* the serving wave: D chain of problem `lane` over all cells, in column order; cells right of the band's last
-     * column (j >= W, column > R) get D = 0 -- left of column 1 the chain produces exact zeros by itself */
-    auto serve = [&](int i) {
-        const double sv_m8 = s_m8[lane]; /* the serving wave's view: lane = problem */
-        const int khi = min(s_wu[lane] - 1, s_rb[lane] - i); /* last band cell of this lane's problem on row i */
-        const int kA = max(0, min(min(Wmin - 1, RBmin - i) + 1, SLOTS));   /* [0,kA): band cells for every problem */
-        const int kB = max(kA, min(min(Wmax - 1, RBmax - i) + 1, SLOTS));  /* [kB,SLOTS): band cells for none */
-        constexpr int H = C / 4 + (C % 4 ? 1 : 0), NBL = (C + H - 1) / H, NB = NBL * G; /* blocks of a quarter of a lane's slots; the next block's a(k) are fetched ahead */
-        double d = 0.0;
-        double cur[H], nxt[H];
-        double *col0 = sA + (lane ^ coop_swz(0));
-#pragma unroll
-        for (int c = 0; c < H; ++c) cur[c] = col0[c * 64];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int t = b / NBL, c0 = (b % NBL) * H, k0 = t * C + c0;
-            const int nb = (C - c0) < H ? (C - c0) : H; /* cells in this block */
-            double *col = sA + (int64_t)k0 * 64 + (lane ^ coop_swz(t));
-            if (b + 1 < NB) {
-                const int t1 = (b + 1) / NBL, c1 = ((b + 1) % NBL) * H, k1 = t1 * C + c1;
-                const int nb1 = (C - c1) < H ? (C - c1) : H;
-                const double *coln = sA + (int64_t)k1 * 64 + (lane ^ coop_swz(t1));
-#pragma unroll
-                for (int c = 0; c < H; ++c)
-                    if (c < nb1) nxt[c] = coln[c * 64];
-            }
-            if (k0 + nb <= kA) { /* wave-uniform: every cell of the block is a band cell of every problem */
-#pragma unroll
-                for (int c = 0; c < H; ++c)
-                    if (c < nb) {
-                        d = cur[c] + sv_m8 * d;
-                        col[c * 64] = d;
-                    }
-            } else if (k0 < kB) {
-#pragma unroll
-                for (int c = 0; c < H; ++c)
-                    if (c < nb) {
-                        const double dn = cur[c] + sv_m8 * d;
-                        d = (k0 + c <= khi) ? dn : 0.0;
-                        col[c * 64] = d;
-                    }
-            } else {
-                d = 0.0;
-#pragma unroll
-                for (int c = 0; c < H; ++c)
-                    if (c < nb) col[c * 64] = 0.0;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < H; ++c) cur[c] = nxt[c];
-        }
-    };
-    /* part B: x(k) = (M+I)+D, ordered sum, scale */
-    auto part_b = [&](int i) {
-        {
-            constexpr int CH = 7, NCH = (C + CH - 1) / CH; /* bounded look-ahead, as in part A */
-            double dc[CH], dn[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) dc[c] = myA[c * 64];
-#pragma unroll
-            for (int b = 0; b < NCH; ++b) {
-                if (b + 1 < NCH) {
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        if ((b + 1) * CH + c < C) dn[c] = myA[((b + 1) * CH + c) * 64];
-                }
-#pragma unroll
-                for (int cc = 0; cc < CH; ++cc) {
-                    const int c = b * CH + cc;
-                    if (c < C) xs[c] = (fM[c] + fI[c]) + dc[cc];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < CH; ++c) dc[c] = dn[c];
-            }
-        }
-        const int t_first = max(0, bwu + 1 - i) / C;
-        double carryS = 0.0, mysum = 0.0;
-        for (int t = t_first; t <= tlast; ++t) {
-            if (g == t) {
-                double s = carryS;
-#pragma unroll
-                for (int c = 0; c < C; ++c) s = s + xs[c];
-                carryS = s; mysum = s;
-            }
-            if (t < tlast) carryS = shfl_up1<G>(carryS);
-        }
-        const double tot = __shfl(mysum, tlast, G);
-        const double inv = 1.0 / tot;
-#pragma unroll
-        for (int c = 0; c < C; ++c) { fM[c] *= inv; fI[c] *= inv; }
-        dinv = inv;
-        s_cur = tot;
-        if (g == 0) sinv[i] = inv;
-        if (B.s_raw && g == 0) B.s_raw[(sinv - B.sinv) + i] = tot;
-        if (i == next_row) save_row();
-    };
-#ifdef SPX_COOP_PROFILE
-    long long tA = 0, tW1 = 0, tS = 0, tW2 = 0, tB = 0;
-#define TICK(acc) { const long long now_ = wall_clock64(); acc += now_ - t_last; t_last = now_; }
-    long long t_last = wall_clock64();
-#else
-#define TICK(acc)
-#endif
-    /* two loops, not one loop with a branch: with both variants of part A inside one loop body the register allocator
-     * wanted 62 registers more than with either alone.  The split is workgroup-uniform (the barriers are inside). */
-    auto rows = [&](int i_from, int i_to, auto fast_tag) {
-        for (int i = i_from; i <= i_to; ++i) {
-            const bool on = act && i <= L;
-            if (on) part_a(i, fast_tag);
-            TICK(tA)
-            lds_barrier();
-            TICK(tW1)
-            if (wv == (i & 3)) serve(i);
-            TICK(tS)
-            lds_barrier();
-            TICK(tW2)
-            if (on) part_b(i);
-            TICK(tB)
-        }
-    };
-    const int fast_wg = max(1, min(min(s_red[0][5], s_red[1][5]), min(s_red[2][5], s_red[3][5])));
-    rows(2, fast_wg, std::true_type{});
-    rows(fast_wg + 1, Lwg, std::false_type{});
-#ifdef SPX_COOP_PROFILE
-    if ((blockIdx.x % 4096) == 77 && lane == 0)
-        printf("coop C=%d blk %d wave %d rows %d: A %lld W1 %lld S %lld W2 %lld B %lld (100MHz ticks)\n", C, (int)blockIdx.x, wv, Lwg, tA, tW1, tS, tW2, tB);
-#endif
-#undef TICK
-    /* terminal: s[L+1] = sum_k f(L,k).M*sM + f(L,k).I*sI in column order */
-    {
-        const double sM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SM] : 0.0;
-        const double sI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SI] : 0.0;
-        double carry = 0.0, mysum = 0.0;
-        for (int t = 0; t <= tlast; ++t) {
-            const int nc = min(C, Wu - t * C);
-            if (g == t) {
-                double s = carry;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const int k = L - bw + jbase + c;
-                    const bool valid = c < nc && k >= 1 && k <= R;
-                    const double tt = fM[c] * sM + fI[c] * sI;
-                    s = valid ? s + tt : s;
-                }
-                carry = s; mysum = s;
-            }
-            carry = shfl_up1<G>(carry);
-        }
-        const double sL1 = __shfl(mysum, tlast, G);
-        if (act && g == 0) { sinv[L] = s_cur; sinv[L + 1] = sL1; }
     }
 }
 
@@ -1483,35 +1131,9 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 
 /* ---------------------------------------------------------------------- */
 /* phase 0 = forward kernel, 1 = backward kernel, 2 = both (back to back on the same stream) */
-/* SPX_COOP=0 falls back to the one-wave kernels for the four-lane classes (A/B runs) */
-static int coop_mode()
-{
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("SPX_COOP");
-        mode = e ? atoi(e) : 0;
-    }
-    return mode;
-}
-
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st)
 {
     if (B->n_order <= 0 && B->n_order_bwd <= 0) return hipSuccess;
-    if (coop_mode() & 1) {
-        const int wgs = (B->n_order + 63) / 64;
-        bool done = true;
-        if (phase != 1 && B->n_order > 0) switch (cls) {
-            case 6: hipLaunchKernelGGL((baq_fwdc_kernel<26>), dim3(wgs), dim3(256), 0, st, *B); break;
-            case 12: hipLaunchKernelGGL((baq_fwdc_kernel<28>), dim3(wgs), dim3(256), 0, st, *B); break;
-            case 13: hipLaunchKernelGGL((baq_fwdc_kernel<30>), dim3(wgs), dim3(256), 0, st, *B); break;
-            default: done = false;
-            }
-        else done = (cls == 6 || cls == 12 || cls == 13);
-        if (done) {
-            if (phase == 0) return hipGetLastError();
-            phase = 1; /* the backward kernel below */
-        }
-    }
 #define SPX_LAUNCH(G_, C_, W0_, LDS_)                                                                                  \
     {                                                                                                                  \
         int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw, blocks_b = (B->n_order_bwd + ppw - 1) / ppw;         \
