@@ -79,6 +79,49 @@ def gen_parallel(genome, first, n, chunk, threads):
     return out
 
 
+def from_bam_leg(args, genome, n_groups, ncpu):
+    """BASELINE.json's 'GB BAM/sec': the command-line drop-in (BGZF inflate, record scan, staging, device path, finalizer,
+    relabel list) on a BAM file of n_groups of the same workload, as a CHILD process (this one holds the GPU already).
+    Two figures: the whole process (start-up = FASTA load, reference upload, HIP init, first allocations included) and
+    its scoring loop alone (from the program's own timing line)."""
+    import re
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamio
+    ont = args.platform == "ont"
+    r = genome.reads(1 << 20, n_groups)  # groups the timed steps did not use
+    d = tempfile.mkdtemp(prefix="spx_bench_bam_")
+    fa, bam, outd = os.path.join(d, "asm.fa"), os.path.join(d, "reads.bam"), os.path.join(d, "out")
+    bamio.write_fasta(fa, genome.ref)
+    bamio.write_bam(bam, r.batch, genome.ref)
+    exe = os.path.join(ROOT, "secphase_amd", "bin", "secphase")
+    flags = ["--ont", "-b", "50"] if ont else ["--hifi"]
+    threads = min(ncpu, 64)
+    t0 = time.perf_counter()
+    p = subprocess.run([exe] + flags + ["-@", str(threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "bench"],
+                       capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    size = os.path.getsize(bam)
+    res = {"groups": n_groups, "bam_bytes": size, "host_threads": threads, "wall_s": round(wall, 3), "rc": p.returncode}
+    if p.returncode == 0:
+        res["groups_per_s"] = round(n_groups / wall, 1)
+        res["gb_bam_per_s"] = round(size / wall / 1e9, 4)
+        m = re.search(r"time in the scoring loop: ([0-9.]+) s", p.stderr)
+        if m and float(m.group(1)) > 0:
+            loop = float(m.group(1))
+            res["loop_s"] = loop
+            res["loop_groups_per_s"] = round(n_groups / loop, 1)
+            res["loop_gb_bam_per_s"] = round(size / loop / 1e9, 4)
+        res["what"] = ("secphase_amd/bin/secphase on a synthetic BAM of the same workload, whole process (FASTA load, reference "
+                       "upload, HIP start-up included) and its scoring loop alone; reader-bound (DESIGN.md 6b)")
+    else:
+        res["stderr_tail"] = p.stderr[-400:]
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +137,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the pipelined-from-host measurement")
     ap.add_argument("--cpu-bracket", action="store_true", help="also time the -O0 / calloc-per-call / 4-thread variants of the CPU baseline")
+    ap.add_argument("--from-bam", type=int, default=0, metavar="N",
+                    help="also run the command-line drop-in end to end on a synthetic BAM of N groups of the same workload "
+                         "(GB of compressed BAM per second: the second half of BASELINE.json's metric); N = 1 GPU only")
     ap.add_argument("--verify", type=int, default=256, help="groups checked against the oracle before timing")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test rig for the N>1 code path on a box with fewer GPUs than ranks (ranks share devices, "
@@ -162,7 +208,34 @@ def main():
     first = rank * D * gps  # every rank scores its own shard of the read-group stream (weak scaling)
     t0 = time.time()
     batches = []  # batches[i] = the record blocks (generator chunks) of distinct batch i
-    for i in range(D):
+    batches.append(gen_parallel(genome, first, gps, args.gen_chunk, host_threads))
+    if D > 1:
+        # the distinct batches stay in HOST memory for the whole run (names for the relabel list, the from-host leg) and in
+        # HBM: bound them by what this rank's share of the host can hold (8 ranks x 8 batches x 7.5 GB would not fit everywhere)
+        def batch_bytes(b):
+            tot = 0
+            for ch in b:
+                bt = ch.batch.contents
+                la = int(bt.n_alns) - 1  # offsets of the LAST record: the payload arrays end just behind them
+                if la < 0:
+                    continue
+                tot += int(bt.cigar_off[la]) * 4 + int(bt.seq_off[la]) + int(bt.qual_off[la]) + 2 * int(bt.l_qseq[la]) + 64 * (la + 1)
+                tot += max(0, int(bt.cs_off[la])) if bt.cs_off else 0
+                tot += max(0, int(bt.md_off[la])) if bt.md_off else 0
+            return tot
+        try:
+            per = max(1, batch_bytes(batches[0]))
+            avail = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            fit = int(0.45 * avail / max(1, local_world) // per)
+            D = max(2, min(D, fit))
+        except Exception:  # noqa: BLE001  (no /proc/meminfo, another record layout: keep the preset)
+            pass
+        if world > 1:
+            dmin = torch.tensor([D], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(dmin, op=dist.ReduceOp.MIN)
+            D = int(dmin.item())
+    for i in range(1, D):
         batches.append(gen_parallel(genome, first + i * gps, gps, args.gen_chunk, host_threads))
     t_gen = time.time() - t0
     ptrs = [[ch.batch for ch in b] for b in batches]
@@ -458,6 +531,11 @@ def main():
                                            "GB_per_s_over_pcie": round(bytes_in * hs / el_h / 1e9, 2)}
         if not args.kernel_only:
             line["relabelled_sampled"] = relabelled[0]
+        # uncompressed record bytes (what spx_stage hands to the device: flags, CIGAR, SEQ, QUAL, cs/MD text) through the step
+        line["gb_records_per_s"] = round(bytes_in * world * args.steps / elapsed / 1e9, 2)
+        if args.from_bam > 0 and world == 1:
+            line["from_bam"] = from_bam_leg(args, genome, args.from_bam, ncpu)
+            line["gb_bam_per_s"] = line["from_bam"].get("gb_bam_per_s")
         print(json.dumps(line), flush=True)
     if pipe is not None:
         pipe.close()

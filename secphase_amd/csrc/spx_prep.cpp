@@ -324,6 +324,14 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
     std::vector<spxl::Op> ops((size_t)n_ops + 1);
     std::vector<spxl::Blk> conf((size_t)n_conf + 1);
     std::vector<spxl::MM> mm((size_t)n_mm + 1);
+    /* SPX_POISON=1 (tests): the device's pools and arenas are recycled, never zeroed -- give the host plan the same
+     * conditions, so that a read of something never written shows up on the CPU too */
+    const bool poison = getenv("SPX_POISON") != nullptr;
+    if (poison) {
+        memset((void *)ops.data(), 0xA5, ops.size() * sizeof(spxl::Op));
+        memset((void *)conf.data(), 0xA5, conf.size() * sizeof(spxl::Blk));
+        memset((void *)mm.data(), 0xA5, mm.size() * sizeof(spxl::MM));
+    }
     P.ops = ops.data(); P.conf = conf.data(); P.mm = mm.data();
     /* pass B: op tables, extents, confident blocks, mismatch lists */
     parallel_for(ns, threads, [&](int64_t a0, int64_t a1) {
@@ -354,7 +362,11 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
             ga[(size_t)k] = spxl::group_arena_layout(view(k), lp.all_rows != 0, slack);
             ga_off[(size_t)k + 1] = ga_off[(size_t)k] + ga[(size_t)k].bytes;
         }
-        arena.assign((size_t)ga_off[(size_t)ng] + 64, 0);
+        arena.assign((size_t)ga_off[(size_t)ng] + 64, poison ? (char)0xA5 : (char)0);
+        if (poison) {
+            memset((void *)gc.data(), 0xA5, gc.size() * sizeof(spxl::GroupCount));
+            memset((void *)ac.data(), 0xA5, ac.size() * sizeof(spxl::GroupCount));
+        }
         auto scratch = [&](int64_t k) { return spxl::group_scratch(ga[(size_t)k], arena.data() + ga_off[(size_t)k]); };
         std::atomic<int> overflow(0);
         parallel_for(ng, threads, [&](int64_t k0, int64_t k1) { /* G1 */
@@ -388,6 +400,15 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
         slack *= 4; /* an interval list outgrew its estimate: bigger scratch, same computation */
     }
     for (int64_t k = 0; k < ng; ++k) spxl::group_pass_sum(view(k), gc[(size_t)k], ac.data() + st.slot0[(size_t)k]); /* G3 */
+    if (getenv("SPX_DEBUG_GC")) /* debugging aid: the same line spx_prepare_staged prints for the device */
+        for (int64_t k = 0; k < ng; ++k) {
+            fprintf(stderr, "[spx debug host] group %lld: err %d scored %d n_cols %d n_prob %d n_rows %d |", (long long)k, gc[(size_t)k].err, gc[(size_t)k].scored,
+                    gc[(size_t)k].n_cols, gc[(size_t)k].n_prob, gc[(size_t)k].n_rows);
+            for (int32_t q = st.slot0[(size_t)k]; q < st.slot0[(size_t)k + 1]; ++q)
+                fprintf(stderr, " [ops %d visit %d conf %d mm %d err %d rds %d rde %d rfs %d rfe %d]", ast[(size_t)q].n_ops, ast[(size_t)q].n_visit, ast[(size_t)q].n_conf,
+                        ast[(size_t)q].n_mm, ast[(size_t)q].err, ast[(size_t)q].rds, ast[(size_t)q].rde, ast[(size_t)q].rfs, ast[(size_t)q].rfe);
+            fprintf(stderr, "\n");
+        }
     /* offsets: errored groups are left out of the work list (their code goes to grp_error) */
     std::vector<spxl::PlanBase> base((size_t)ns + 1);
     std::vector<int64_t> mk_base((size_t)ng + 1, 0);

@@ -15,7 +15,7 @@ struct spx_prep_totals {
     int64_t arena_bytes;              /* scratch need of the per-group pass */
     int64_t n_prob, n_rows, n_qe, n_mk, s_tot, f_tot, cells;
     int64_t n_ok;                     /* dispatched groups without an error */
-    int32_t overflow;                 /* 1: a pool was too small, 2: a group's interval lists outgrew their estimate */
+    int32_t overflow;                 /* bits: 1 group scratch arena too small, 2 a group's interval lists outgrew their estimate, 4 an op / block / mismatch pool too small */
     int32_t pad;
     int64_t cls_prob[SPX_N_CLASSES], cls_cells[SPX_N_CLASSES];
 };

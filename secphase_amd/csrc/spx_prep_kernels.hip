@@ -81,7 +81,12 @@ __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
     AlnState st = A.ast[s];
     if (st.err) return;
     if (st.ops_off + st.n_ops > A.ops_cap || st.conf_off + st.conf_cap > A.conf_cap || st.mm_off + st.mm_cap > A.mm_cap) {
-        A.tot->overflow = 1;
+        /* a pool sized from the host's bounds is too small: the host grows it to the exact totals (slots_apply_kernel
+         * has them) and runs this phase again; until then the alignment counts as failed, so that nothing walks its
+         * unwritten op table */
+        atomicOr(&A.tot->overflow, 4);
+        st.err = SPX_ENOMEM;
+        A.ast[s] = st;
         return;
     }
     const Rec r = A.recs[s];
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(64) void group_merge_kernel(spx_prep_args A)
     GroupCtx c = group_ctx(A, k);
     GroupCount gc;
     if (!c.ok) {
-        A.tot->overflow = 1;
+        atomicOr(&A.tot->overflow, 1);
         count_clear(gc);
         gc.err = SPX_ENOMEM;
         A.gc[k] = gc;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(64) void group_blocks_end_kernel(spx_prep_args A)
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
     group_pass_blocks_end(c.G, A.P, A.par, c.S, gc);
-    if (gc.err == SPX_ENOMEM) A.tot->overflow = 2; /* an interval list outgrew its estimate: repeat with more slack */
+    if (gc.err == SPX_ENOMEM) atomicOr(&A.tot->overflow, 2); /* an interval list outgrew its estimate: repeat with more slack */
     A.gc[k] = gc;
 }
 
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64) void aln_count_plan_kernel(spx_prep_args A)
     if (gc.err || !gc.scored) { count_clear(ac); A.ac[s] = ac; return; }
     GroupCtx c = group_ctx(A, k);
     aln_pass_count(c.G, s - A.slot0[k], A.P, A.rv, A.par, c.S, gc, ac);
-    if (ac.err == SPX_ENOMEM) A.tot->overflow = 2;
+    if (ac.err == SPX_ENOMEM) atomicOr(&A.tot->overflow, 2);
     A.ac[s] = ac;
 }
 

@@ -94,6 +94,7 @@ struct spx_ctx {
     hipStream_t side_stream[SPX_N_SIDE] = {};
     hipEvent_t side_done[SPX_N_SIDE] = {};
     hipStream_t copy_stream = nullptr; /* host -> HBM copies of staged records */
+    bool dense_tags = false; /* a batch needed more ops than one per two tag characters (MD tags): size the op pool for one per character */
     std::mutex launch_mu;              /* spx_launch may be called from several threads (pipelined callers) */
     uint8_t *d_ref4 = nullptr;
     int64_t ref_bytes = 0;
@@ -748,12 +749,18 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     w->prepared = false;
     /* pools of the per-alignment pass, by bounds the host knows without touching the payload: an op per CIGAR op or
      * per two tag characters; a confident block per CIGAR op; a mismatch per tag character */
-    const size_t ops_bound = (size_t)L.cigar_words + (size_t)L.text_bytes / 2 + 2 * ns + 16;
-    const size_t conf_bound = (size_t)L.cigar_words + 2 * ns + 16, mm_bound = (size_t)L.text_bytes + 16;
+    /* (a first guess: cs tokens take two characters or more, MD tokens one; the device reports a pool that is too small) */
+    size_t ops_bound = (size_t)L.cigar_words + (size_t)L.text_bytes / (c->dense_tags ? 1 : 2) + 2 * ns + 16;
+    size_t conf_bound = (size_t)L.cigar_words + 2 * ns + 16, mm_bound = (size_t)L.text_bytes + 16;
     int rc;
-    if ((rc = ensure_pool(c, c->pool_ops, ops_bound * sizeof(spxl::Op))) || (rc = ensure_pool(c, c->pool_conf, conf_bound * sizeof(spxl::Blk))) ||
-        (rc = ensure_pool(c, c->pool_mm, mm_bound * sizeof(spxl::MM))))
-        return fail(rc, "device memory for the preparation pools");
+    auto size_pools = [&]() -> int {
+        int r_;
+        if ((r_ = ensure_pool(c, c->pool_ops, ops_bound * sizeof(spxl::Op))) || (r_ = ensure_pool(c, c->pool_conf, conf_bound * sizeof(spxl::Blk))) ||
+            (r_ = ensure_pool(c, c->pool_mm, mm_bound * sizeof(spxl::MM))))
+            return r_;
+        return 0;
+    };
+    if ((rc = size_pools())) return fail(rc, "device memory for the preparation pools");
     if ((rc = ensure_pool(c, c->pool_garena, (size_t)(32u << 20) + ns * 4096))) return fail(rc, "device memory for the group scratch");
     fill_prep_args(c, w);
     spx_prep_args &A = w->pa;
@@ -762,27 +769,54 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     spxl::PlanBase *d_base = (spxl::PlanBase *)(base + w->o_base);
     int64_t *d_mkb = (int64_t *)(base + w->o_mkb);
     if (w->ev_staged) HIPCHK(hipStreamWaitEvent(c->prep_stream, w->ev_staged, 0));
-    HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), c->prep_stream));
     HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
-    HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, c->prep_stream));
+    bool phase1 = true;
     for (int attempt = 0;; ++attempt) {
+        if (phase1) {
+            HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), c->prep_stream));
+            HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, c->prep_stream));
+        }
         HIPCHK(spx_prep_phase2(&A, d_base, d_mkb, c->prep_stream));
         HIPCHK(hipMemcpyAsync(c->h_tot, c->d_tot, sizeof(spx_prep_totals), hipMemcpyDeviceToHost, c->prep_stream));
         HIPCHK(hipStreamSynchronize(c->prep_stream));
         w->tot = *c->h_tot;
-        if (!w->tot.overflow) break;
-        if (attempt >= 6) return fail(SPX_ENOMEM, "group scratch keeps overflowing");
-        if (w->tot.overflow == 1) {
-            if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes + 4096))) return fail(rc, "device memory for the group scratch");
-            A.arena = (char *)c->pool_garena.p;
-            A.arena_cap = (int64_t)c->pool_garena.cap;
-        } else {
+        const int ov = w->tot.overflow;
+        if (!ov) break;
+        if (attempt >= 8) return fail(SPX_ENOMEM, "preparation scratch keeps overflowing");
+        phase1 = (ov & 4) != 0;
+        if (ov & 4) { /* exact sizes are known now (the prefix sums of the counting pass) */
+            c->dense_tags = true; /* MD-tagged records: from now on one op per tag character is assumed */
+            ops_bound = std::max(ops_bound, (size_t)w->tot.n_ops + 16);
+            conf_bound = std::max(conf_bound, (size_t)w->tot.n_conf + 16);
+            mm_bound = std::max(mm_bound, (size_t)w->tot.n_mm + 16);
+            if ((rc = size_pools())) return fail(rc, "device memory for the preparation pools");
+            A.P.ops = (spxl::Op *)c->pool_ops.p; A.P.conf = (spxl::Blk *)c->pool_conf.p; A.P.mm = (spxl::MM *)c->pool_mm.p;
+            A.ops_cap = (int64_t)ops_bound; A.conf_cap = (int64_t)conf_bound; A.mm_cap = (int64_t)mm_bound;
+        } else if (ov & 2) {
             A.slack *= 4;
             if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes * 4 + 4096))) return fail(rc, "device memory for the group scratch");
             A.arena = (char *)c->pool_garena.p;
             A.arena_cap = (int64_t)c->pool_garena.cap;
+        } else {
+            if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes + 4096))) return fail(rc, "device memory for the group scratch");
+            A.arena = (char *)c->pool_garena.p;
+            A.arena_cap = (int64_t)c->pool_garena.cap;
         }
         HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
+    }
+    if (getenv("SPX_DEBUG_GC")) { /* debugging aid: the per-group and per-alignment state the device arrived at */
+        std::vector<spxl::GroupCount> hg(ng);
+        std::vector<spxl::AlnState> ha(ns);
+        (void)hipMemcpy(hg.data(), A.gc, ng * sizeof(spxl::GroupCount), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ha.data(), A.ast, ns * sizeof(spxl::AlnState), hipMemcpyDeviceToHost);
+        for (size_t k = 0; k < ng; ++k) {
+            fprintf(stderr, "[spx debug] group %zu: err %d scored %d n_cols %d n_prob %d n_rows %d |", k, hg[k].err, hg[k].scored, hg[k].n_cols,
+                    hg[k].n_prob, hg[k].n_rows);
+            for (int32_t q = w->stage.slot0[k]; q < w->stage.slot0[k + 1]; ++q)
+                fprintf(stderr, " [ops %d visit %d conf %d mm %d err %d rds %d rde %d rfs %d rfe %d]", ha[q].n_ops, ha[q].n_visit, ha[q].n_conf, ha[q].n_mm,
+                        ha[q].err, ha[q].rds, ha[q].rde, ha[q].rfs, ha[q].rfe);
+            fprintf(stderr, "\n");
+        }
     }
     const double t1 = now_s();
     /* ---- part B: the work list, its scratch and its outputs, carved to measure ---- */

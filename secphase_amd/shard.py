@@ -69,33 +69,43 @@ def gather_bytes(local, dist, torch, dst=0):
 def merge_and_write(api, params, fin, ref, dec_parts, cand_parts, log_path, mode="a"):
     """rank 0: dec_parts / cand_parts = lists (one entry per rank) of raw bytes holding spx_decision / spx_relabel_rec
     arrays.  Replays the draws of every group in global group order on finalizer `fin` (a c_void_p from
-    spx_finalizer_create) and appends the relabelled candidates to log_path.  Returns (#decisions, #records written)."""
+    spx_finalizer_create) and appends the relabelled candidates to log_path.  Returns (#decisions, #records written).
+    No per-group Python work: at 8 ranks x 131 072 groups per step this runs once per step on rank 0."""
     L = api.lib()
-    dec = np.concatenate([np.frombuffer(p.tobytes(), np.uint8) for p in dec_parts]) if dec_parts else np.zeros(0, np.uint8)
+    dec = np.concatenate([np.asarray(p, np.uint8).reshape(-1) for p in dec_parts]) if dec_parts else np.zeros(0, np.uint8)
     nd = len(dec) // DECISION_BYTES
     dt = np.dtype([("group", "<u4"), ("n_aln", "i1"), ("prim_idx", "i1"), ("max_idx", "i1"), ("pass_", "u1"),
                    ("tie_mask", "<u2"), ("reserved", "<u2"), ("absdiff", "<i4")])
-    d = np.frombuffer(dec.tobytes(), dt, count=nd)
+    d = dec[: nd * DECISION_BYTES].view(dt)
     d = d[d["n_aln"] >= 2]  # device records keep a slot for rejected groups (n_aln 0): they draw nothing
-    order = np.argsort(d["group"], kind="stable")
-    d = np.ascontiguousarray(d[order])
+    grp = d["group"]
+    if len(grp) > 1 and np.any(grp[1:] < grp[:-1]):  # rank order = group order already, unless shards interleave
+        d = d[np.argsort(grp, kind="stable")]
+    d = np.ascontiguousarray(d)
     nd = len(d)
-    best = (C.c_int8 * max(nd, 1))()
-    rel = (C.c_int8 * max(nd, 1))()
-    darr = (api.Decision * max(nd, 1)).from_buffer_copy(d.tobytes() if nd else bytes(DECISION_BYTES))
-    api._chk(L.spx_finalizer_apply_decisions(fin, C.byref(params), darr, nd, best, rel), "spx_finalizer_apply_decisions")
-    best_of = dict(zip(d["group"].tolist(), [best[k] for k in range(nd)]))
+    best = np.zeros(max(nd, 1), np.int8)
+    rel = np.zeros(max(nd, 1), np.int8)
+    dbuf = d.view(np.uint8) if nd else np.zeros(DECISION_BYTES, np.uint8)
+    api._chk(L.spx_finalizer_apply_decisions(fin, C.byref(params), C.cast(dbuf.ctypes.data, C.POINTER(api.Decision)), nd,
+                                             C.cast(best.ctypes.data, C.POINTER(C.c_int8)),
+                                             C.cast(rel.ctypes.data, C.POINTER(C.c_int8))), "spx_finalizer_apply_decisions")
     rsz = C.sizeof(api.RelabelRec)
-    cand = np.concatenate([np.frombuffer(p.tobytes(), np.uint8) for p in cand_parts]) if cand_parts else np.zeros(0, np.uint8)
+    cand = np.concatenate([np.asarray(p, np.uint8).reshape(-1) for p in cand_parts]) if cand_parts else np.zeros(0, np.uint8)
     nc = len(cand) // rsz
-    recs = (api.RelabelRec * max(nc, 1)).from_buffer_copy(cand.tobytes() if nc else bytes(rsz))
-    idx = sorted(range(nc), key=lambda k: recs[k].group)
-    srt = (api.RelabelRec * max(nc, 1))()
-    bsel = (C.c_int8 * max(nc, 1))()
-    for j, k in enumerate(idx):
-        srt[j] = recs[k]
-        bsel[j] = best_of.get(recs[k].group, -1)
-    n = L.spx_write_relabel_records(log_path.encode(), mode.encode(), ref, srt, nc, bsel)
+    if nc:
+        rows = cand[: nc * rsz].reshape(nc, rsz)
+        cgrp = np.ascontiguousarray(rows[:, :4]).view("<u4").reshape(-1)
+        order = np.argsort(cgrp, kind="stable")
+        rows = np.ascontiguousarray(rows[order])
+        cgrp = cgrp[order]
+        at = np.searchsorted(d["group"], cgrp) if nd else np.zeros(nc, np.int64)
+        hit = (at < nd) & (d["group"][np.minimum(at, max(nd - 1, 0))] == cgrp) if nd else np.zeros(nc, bool)
+        bsel = np.where(hit, best[np.minimum(at, max(nd - 1, 0))], -1).astype(np.int8)
+    else:
+        rows = np.zeros((1, rsz), np.uint8)
+        bsel = np.zeros(1, np.int8)
+    n = L.spx_write_relabel_records(log_path.encode(), mode.encode(), ref, C.cast(rows.ctypes.data, C.POINTER(api.RelabelRec)), nc,
+                                    C.cast(bsel.ctypes.data, C.POINTER(C.c_int8)))
     if n < 0:
         raise api.SpxError(n, "spx_write_relabel_records")
     return nd, n

@@ -234,6 +234,45 @@ def test_device_work_list_equals_host_plan(ctx):
             w.free()
 
 
+
+def test_md_tagged_records_on_a_fresh_context(built):
+    """Found by tools/fuzz.py gpu (seed 20261003): the op pool of the preparation kernels is sized from the tag lengths
+    before any payload byte is read -- one op per two tag characters, which holds for cs but not for MD ("10A5C3": a token
+    per character).  On a context whose pools have not grown yet the last alignments of an MD-tagged batch overflowed it;
+    the overflow was reported as 'group scratch too small', only the group passes were repeated, and the groups of the
+    unbuilt alignments came back unscored (all scores 0).  Now the device reports pool overflows separately and the host
+    repeats the per-alignment phase with pools of the exact size.  Fresh context: the module-wide one has large pools."""
+    import copy
+    kw = dict(seed=831971708757, n_contigs=2, contig_len=60000, n_paralogs=5, softclip_frac=0.0, hardclip_frac=1.0, shuffle_records=1,
+              inverted_paralogs=1, n_base_frac=0.001, snv_rate=0.0002, indel_rate=2e-05, paralog_snv_rate=0.04, tag_mode=1, read_len=1000,
+              max_secondaries=5, min_secondaries=5)
+    par = records.preset("hifi")
+    par.prim_margin_score, par.conf_d, par.conf_e, par.conf_b, par.flank_margin = 40.0, 1e-4, 0.1, 20.0, 500
+    g = synth.Genome(synth.default_cfg(synth.MIXED, **kw))
+    for first, n in ((2364, 26), (2389, 1), (2364, 40)):
+        c = api.Context(0)
+        try:
+            c.set_reference(g.ref)
+            r = g.reads(first, n)
+            _, res = orc.run_batch(r.batch, g.ref, par, threads=2, seed=1)
+            for flags in (0, 1):
+                p2 = copy.copy(par)
+                p2.flags = flags
+                w = c.prepare(r.batch, p2)
+                dev = w.export_plan()
+                host = api.Plan(g.ref, r.batch, p2)
+                _plans_equal(dev, host, n)
+                dev.close()
+                w.launch()
+                out = w.collect(finalize_seed=1)
+                for k in range(n):
+                    assert out[k].n_aln == res[k].n_aln
+                    assert [out[k].score[a] for a in range(max(res[k].n_aln, 0))] == [res[k].score[a] for a in range(max(res[k].n_aln, 0))], (first, n, k)
+                w.free()
+        finally:
+            c.close()
+
+
 def _batch_parity(ctx, genome, reads, params, tmp_path, tag):
     ctx.set_reference(genome.ref)
     out, st = ctx.score_batch(reads.batch, params, finalize_seed=1)
