@@ -387,8 +387,12 @@ def main():
         tot = torch.tensor([n_disp, n_prob, cells], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot)
         n_disp_all, n_prob_all, cells_all = [float(x) for x in tot.tolist()]
+        mx = torch.tensor([cells], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        imbalance = float(mx.item()) * world / cells_all if cells_all > 0 else 1.0  # heaviest rank / mean rank, in DP cells
     else:
         n_disp_all, n_prob_all, cells_all = n_disp, n_prob, cells
+        imbalance = 1.0
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -514,6 +518,7 @@ def main():
                 "parallelism": (f"reads sharded over {world} GPUs; RCCL gather of 16-byte decision records + candidate records to "
                                 f"rank 0, which replays the draws and writes the list") if world > 1 else "single GPU",
                 "verified_groups_vs_oracle": verified,
+                "rank_imbalance_dp_cells": round(imbalance, 4),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
