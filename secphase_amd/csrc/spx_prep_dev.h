@@ -41,7 +41,6 @@ struct spx_prep_args {
     char *arena;
     int64_t arena_cap;
     int32_t slack, pad;
-    int32_t lpw_g, lpw_a;             /* active lanes per wave of the group / alignment pass kernels (spx_prep_kernels.hip prep_index) */
     /* scratch of the prefix sums: five int64 columns of scan_stride entries, their tile totals, the grand totals */
     int64_t *scan_v, *scan_tile, *scan_grand;
     int64_t scan_stride;

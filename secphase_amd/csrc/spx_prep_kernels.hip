@@ -29,17 +29,6 @@
 
 using namespace spxl;
 
-/* Index of the group / alignment a lane of a pass kernel works on.  These kernels are walks with one dependent load
- * after the other, every lane in its own cache lines: a wave-level load costs as many memory transactions as the wave
- * has active lanes, and nothing hides its latency but other waves.  So a pass over few items (16 384 ONT groups = 256
- * full waves on 1 024 SIMDs) runs with FEWER ACTIVE LANES PER WAVE and more waves -- lpw is chosen by the launcher so
- * that the pass fills the chip's wave slots. */
-__device__ __forceinline__ int prep_index(int lpw)
-{
-    const int lane = threadIdx.x;
-    return lane < lpw ? (int)blockIdx.x * lpw + lane : -1;
-}
-
 /* ---------------------------------------------------------------------- */
 __global__ __launch_bounds__(256) void recode_kernel(const uint32_t *__restrict__ raw, uint32_t *__restrict__ code, int64_t n_words,
                                                      const Rec *__restrict__ recs, int32_t n_slots, AlnState *__restrict__ ast)
@@ -75,8 +64,8 @@ __global__ __launch_bounds__(256) void recode_kernel(const uint32_t *__restrict_
 
 __global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
 {
-    const int s = prep_index(A.lpw_a);
-    if (s < 0 || s >= A.n_slots) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
     AlnState st = A.ast[s];
     const Rec r = A.recs[s];
     st.n_ops = 0; st.mm_cap = 0; st.conf_cap = 0; st.n_conf = 0; st.n_mm = 0;
@@ -87,8 +76,8 @@ __global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
 {
-    const int s = prep_index(A.lpw_a);
-    if (s < 0 || s >= A.n_slots) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
     AlnState st = A.ast[s];
     if (st.err) return;
     if (st.ops_off + st.n_ops > A.ops_cap || st.conf_off + st.conf_cap > A.conf_cap || st.mm_off + st.mm_cap > A.mm_cap) {
@@ -110,7 +99,7 @@ __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
 __global__ __launch_bounds__(64) void group_arena_kernel(spx_prep_args A)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < 0 || k >= A.n_dgroups) return;
+    if (k >= A.n_dgroups) return;
     const int s0 = A.slot0[k];
     GroupView G = {A.slot0[k + 1] - s0, A.recs + s0, A.ast + s0};
     A.ga_bytes[k] = group_arena_layout(G, A.par.all_rows != 0, A.slack).bytes;
@@ -137,8 +126,8 @@ __device__ __forceinline__ GroupCtx group_ctx(const spx_prep_args &A, int k)
 
 __global__ __launch_bounds__(64) void group_merge_kernel(spx_prep_args A)
 {
-    const int k = prep_index(A.lpw_g);
-    if (k < 0 || k >= A.n_dgroups) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
     GroupCtx c = group_ctx(A, k);
     GroupCount gc;
     if (!c.ok) {
@@ -154,8 +143,8 @@ __global__ __launch_bounds__(64) void group_merge_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
 {
-    const int s = prep_index(A.lpw_a);
-    if (s < 0 || s >= A.n_slots) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
@@ -166,8 +155,8 @@ __global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
 /* consensus windows: rounds run per group, the projections of the windows onto the alignments per alignment */
 __global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
 {
-    const int k = prep_index(A.lpw_g);
-    if (k < 0 || k >= A.n_dgroups) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
     GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
@@ -176,8 +165,8 @@ __global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
 }
 __global__ __launch_bounds__(64) void aln_project_kernel(spx_prep_args A)
 {
-    const int s = prep_index(A.lpw_a);
-    if (s < 0 || s >= A.n_slots) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
@@ -187,8 +176,8 @@ __global__ __launch_bounds__(64) void aln_project_kernel(spx_prep_args A)
 }
 __global__ __launch_bounds__(64) void group_resume_kernel(spx_prep_args A)
 {
-    const int k = prep_index(A.lpw_g);
-    if (k < 0 || k >= A.n_dgroups) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
@@ -199,8 +188,8 @@ __global__ __launch_bounds__(64) void group_resume_kernel(spx_prep_args A)
 }
 __global__ __launch_bounds__(64) void group_blocks_end_kernel(spx_prep_args A)
 {
-    const int k = prep_index(A.lpw_g);
-    if (k < 0 || k >= A.n_dgroups) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
     GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
@@ -211,8 +200,8 @@ __global__ __launch_bounds__(64) void group_blocks_end_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_count_plan_kernel(spx_prep_args A)
 {
-    const int s = prep_index(A.lpw_a);
-    if (s < 0 || s >= A.n_slots) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     GroupCount ac;
@@ -225,8 +214,8 @@ __global__ __launch_bounds__(64) void aln_count_plan_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void group_sum_kernel(spx_prep_args A)
 {
-    const int k = prep_index(A.lpw_g);
-    if (k < 0 || k >= A.n_dgroups) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
     GroupCount gc = A.gc[k];
     GroupView G;
     const int s0 = A.slot0[k];
@@ -244,8 +233,8 @@ __global__ __launch_bounds__(64) void group_sum_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_emit_kernel(spx_prep_args A, spx_emit_args E)
 {
-    const int s = prep_index(A.lpw_a);
-    if (s < 0 || s >= A.n_slots) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || !gc.scored) return;
@@ -255,8 +244,8 @@ __global__ __launch_bounds__(64) void aln_emit_kernel(spx_prep_args A, spx_emit_
 
 __global__ __launch_bounds__(64) void group_finish_kernel(spx_prep_args A, spx_emit_args E)
 {
-    const int k = prep_index(A.lpw_g);
-    if (k < 0 || k >= A.n_dgroups) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n_dgroups) return;
     const GroupCount gc = A.gc[k];
     GroupCtx c = group_ctx(A, k);
     const int n = c.G.n;
@@ -357,7 +346,7 @@ static hipError_t run_scan(const spx_prep_args *A, int64_t n, int ncol, hipStrea
 __global__ __launch_bounds__(256) void slots_extract_kernel(spx_prep_args A)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < 0 || s >= A.n_slots) return;
+    if (s >= A.n_slots) return;
     A.scan_v[0 * A.scan_stride + s] = A.ast[s].n_ops;
     A.scan_v[1 * A.scan_stride + s] = A.ast[s].conf_cap;
     A.scan_v[2 * A.scan_stride + s] = A.ast[s].mm_cap;
@@ -366,7 +355,7 @@ __global__ __launch_bounds__(256) void slots_apply_kernel(spx_prep_args A)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0) { A.tot->n_ops = A.scan_grand[0]; A.tot->n_conf = A.scan_grand[1]; A.tot->n_mm = A.scan_grand[2]; }
-    if (s < 0 || s >= A.n_slots) return;
+    if (s >= A.n_slots) return;
     A.ast[s].ops_off = scanned(A, 0, s);
     A.ast[s].conf_off = scanned(A, 1, s);
     A.ast[s].mm_off = scanned(A, 2, s);
@@ -410,7 +399,7 @@ __global__ __launch_bounds__(256) void plan_apply_slots_kernel(spx_prep_args A, 
 __global__ __launch_bounds__(256) void plan_extract_groups_kernel(spx_prep_args A)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < 0 || k >= A.n_dgroups) return;
+    if (k >= A.n_dgroups) return;
     const GroupCount &gc = A.gc[k];
     const bool ok = gc.err == 0;
     A.scan_v[0 * A.scan_stride + k] = ok ? (int64_t)gc.n_cols * (A.slot0[k + 1] - A.slot0[k]) : 0;
@@ -484,23 +473,22 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint64_t *__re
 extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *raw_seq, int64_t seq_words, hipStream_t st)
 {
     if (A->n_slots <= 0) return hipSuccess;
-    const dim3 ga((A->n_slots + A->lpw_a - 1) / A->lpw_a), b64(64);
-    hipLaunchKernelGGL(aln_count_kernel, ga, b64, 0, st, *A);
+    hipLaunchKernelGGL(aln_count_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
     if (seq_words > 0)
         hipLaunchKernelGGL(recode_kernel, dim3((unsigned)std::min<int64_t>((seq_words + 255) / 256, 2048)), dim3(256), 0, st, raw_seq,
                            (uint32_t *)(A->code4_w + A->P.code_lead_bytes), seq_words, A->recs, A->n_slots, A->ast);
     hipLaunchKernelGGL(slots_extract_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
     { hipError_t e = run_scan(A, A->n_slots, 3, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(slots_apply_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
-    hipLaunchKernelGGL(aln_build_kernel, ga, b64, 0, st, *A);
+    hipLaunchKernelGGL(aln_build_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
     return hipGetLastError();
 }
 
 extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *base_out, int64_t *mk_base, hipStream_t st)
 {
     if (A->n_dgroups <= 0) return hipSuccess;
-    const dim3 gg((A->n_dgroups + A->lpw_g - 1) / A->lpw_g), ga((A->n_slots + A->lpw_a - 1) / A->lpw_a), b64(64);
-    hipLaunchKernelGGL(group_arena_kernel, dim3((A->n_dgroups + 63) / 64), b64, 0, st, *A);
+    const dim3 gg((A->n_dgroups + 63) / 64), ga((A->n_slots + 63) / 64), b64(64);
+    hipLaunchKernelGGL(group_arena_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(arena_extract_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
     { hipError_t e = run_scan(A, A->n_dgroups, 1, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(arena_apply_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
@@ -526,8 +514,8 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
 extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st)
 {
     if (A->n_dgroups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aln_emit_kernel, dim3((A->n_slots + A->lpw_a - 1) / A->lpw_a), dim3(64), 0, st, *A, *E);
-    hipLaunchKernelGGL(group_finish_kernel, dim3((A->n_dgroups + A->lpw_g - 1) / A->lpw_g), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(aln_emit_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(group_finish_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A, *E);
     if (E->n_prob > 0)
         hipLaunchKernelGGL(problem_constants_kernel, dim3((E->n_prob + 255) / 256), dim3(256), 0, st, A->par, E->n_prob, E->out.L, E->out.R,
                            E->out.has_n, E->hmm);

@@ -721,21 +721,6 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.arena = (char *)c->pool_garena.p;
     A.arena_cap = (int64_t)c->pool_garena.cap;
     A.slack = 1;
-    {
-        /* lanes per wave of the pass kernels: enough waves to fill the chip (256 CUs x 4 SIMDs x 8 wave slots); SPX_PREP_LPW
-         * fixes both for experiments */
-        auto lanes = [](int64_t n) {
-            int l = 4;
-            while (l < 64 && n > (int64_t)l * 8192) l *= 2;
-            return l;
-        };
-        A.lpw_g = lanes(L.n_dgroups);
-        A.lpw_a = lanes(L.n_slots);
-        if (const char *e = getenv("SPX_PREP_LPW")) {
-            const int v = atoi(e);
-            if (v >= 1 && v <= 64) A.lpw_g = A.lpw_a = v;
-        }
-    }
     A.scan_stride = (int64_t)std::max(L.n_slots, L.n_dgroups) + 8;
     A.scan_v = (int64_t *)(base + w->o_scan);
     A.scan_tile = A.scan_v + 5 * A.scan_stride;
