@@ -186,6 +186,53 @@ def gpu_batch(ctx, rng):
     return st.n_problems
 
 
+def gpu_pipe(ctx, rng):
+    """several batches of different sizes through the in-order pipeline (spx_pipe): work lists of different shapes share
+    the context's recycled arenas and pools, submissions may hold more than one record block"""
+    from oracle import orc
+    from secphase_amd import api, synth
+    plat, kw, par = draw_case(rng)
+    kw["read_len"] = min(kw.get("read_len") or 6000, 6000)
+    kw.pop("max_read_len", None)
+    g = synth.Genome(synth.default_cfg(plat, **kw))
+    ctx.set_reference(g.ref)
+    what = describe(plat, kw, par, 0, 0)
+    subs = []
+    first = int(rng.integers(0, 3000))
+    for _ in range(int(rng.integers(3, 8))):
+        blocks = []
+        for _ in range(int(rng.choice([1, 1, 2, 3]))):
+            n = int(rng.choice([1, 2, 5, 17, 40, 96]))
+            blocks.append(g.reads(first, n))
+            first += n
+        subs.append(blocks)
+    depth = int(rng.integers(1, 4))
+    pipe = api.Pipe(ctx, par, depth=depth, host_threads=4)
+    nprob = 0
+    try:
+        sent = got = 0
+        while got < len(subs):
+            while sent < len(subs) and pipe.pending() < depth + 1:
+                pipe.submit(batch=[b.batch for b in subs[sent]])
+                sent += 1
+            out, n = pipe.next()
+            base = 0
+            for b in subs[got]:
+                _, res = orc.run_batch(b.batch, g.ref, par, threads=8, seed=1)
+                for k in range(b.batch.contents.n_groups):
+                    o, e = out[base + k], res[k]
+                    assert o.n_aln == e.n_aln, (what, "pipe", got, k, o.n_aln, e.n_aln)
+                    for a in range(max(e.n_aln, 0)):
+                        assert o.score[a] == e.score[a], (what, "pipe", got, k, a, o.score[a], e.score[a])
+                    nprob += max(e.n_baq_calls, 0) if e.n_aln > 0 else 0
+                base += b.batch.contents.n_groups
+            assert base == n, (what, "pipe", got, base, n)
+            got += 1
+    finally:
+        pipe.close()
+    return nprob
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("mode", choices=["cpu", "gpu"])
@@ -217,6 +264,9 @@ def run(args, rng):
             problems += gpu_problems(ctx, rng, 96)
             problems += gpu_batch(ctx, rng)
             cases += 2
+            if cases % 8 == 0:
+                problems += gpu_pipe(ctx, rng)
+                cases += 1
     print(f"fuzz {args.mode}: seed {args.seed}, {cases} cases, {problems} DP problems, no mismatch, {time.time() - t0:.0f} s")
 
 
