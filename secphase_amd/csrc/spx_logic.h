@@ -560,7 +560,7 @@ SPX_HD Mk match_marker(const Rec &r, const AlnState &st, const uint8_t *qual, in
  *               (sort_and_fill_markers); returns the number of columns
  * aln_filter    one alignment's walk over its ops and the columns (filter_ins_markers): columns inside an insertion /
  *               clip are marked for removal, the reference positions of its match markers inside '=' ops filled in
- * group_compact removes the marked columns; returns the number kept */
+ * aln_compact / group_compact remove the marked columns (cells per alignment, positions per group; returns the number kept) */
 SPX_HD int group_merge(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk, uint8_t *keep)
 {
     const int n = G.n;
@@ -628,19 +628,30 @@ SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t 
     }
 }
 
-SPX_HD int group_compact(const GroupView &G, int32_t *pos, Mk *mk, const uint8_t *keep, int ncol)
+/* (the columns' marker cells are moved by aln_compact, one alignment per thread: a column of a 9-alignment group is
+ * 144 bytes, and on the device one lane moving the 45 000 columns of a 100 kb group was most of the pass) */
+SPX_HD int group_compact(const GroupView &G, int32_t *pos, const uint8_t *keep, int ncol)
+{
+    (void)G;
+    int w = 0;
+    for (int c = 0; c < ncol; ++c) {
+        if (!keep[c]) continue;
+        if (w != c) pos[w] = pos[c];
+        ++w;
+    }
+    return w;
+}
+/* this alignment's cell of every kept column moves to the column's new place (cells of different alignments never
+ * share an address, so the alignments of a group can do this side by side) */
+SPX_HD void aln_compact(const GroupView &G, int i, Mk *mk, const uint8_t *keep, int ncol)
 {
     const int n = G.n;
     int w = 0;
     for (int c = 0; c < ncol; ++c) {
         if (!keep[c]) continue;
-        if (w != c) {
-            pos[w] = pos[c];
-            for (int i = 0; i < n; ++i) mk[(int64_t)w * n + i] = mk[(int64_t)c * n + i];
-        }
+        if (w != c) mk[(int64_t)w * n + i] = mk[(int64_t)c * n + i];
         ++w;
     }
-    return w;
 }
 
 /* ascending by key; inputs are monotone (ascending, or descending on the reverse strand), so: reverse when
@@ -669,7 +680,10 @@ SPX_HD int flank_blocks(const AlnState &st, const int32_t *pos, int ncol, int n,
         const int p = pos[col];
         const int v0 = p - margin, v1 = p + margin;
         const int cs = st.rds > v0 ? st.rds : v0, ce = st.rde < v1 ? st.rde : v1;
-        for (int rep = 0; rep < n; ++rep) {
+        /* after the first cell of a position the window is [.., ce]; its n - 1 repeats take the "cs < end" branch and set
+         * end = ce again -- unless the window is empty (cs >= ce), where every repeat opens a new block */
+        const int reps = cs < ce ? 1 : n;
+        for (int rep = 0; rep < reps; ++rep) {
             if (col == 0 && rep == 0) { start = cs; end = ce; continue; }
             if (cs < end) end = ce;
             else {
@@ -1227,12 +1241,19 @@ SPX_HD void aln_pass_filter(const GroupView &G, int i, const Pools &P, GroupScra
     if (gc.err || gc.n_cols == 0) return;
     aln_filter(G, i, P, S.pos, S.mk, S.keep, gc.n_cols);
 }
+/* A1b: after EVERY alignment of the group has been through aln_pass_filter (keep[] is final), before the group pass that
+ * compacts the positions */
+SPX_HD void aln_pass_compact(const GroupView &G, int i, GroupScratch &S, const GroupCount &gc)
+{
+    if (gc.err || gc.n_cols == 0) return;
+    aln_compact(G, i, S.mk, S.keep, gc.n_cols);
+}
 
 /* G2: filtered columns, consensus windows */
 SPX_HD void group_pass_blocks(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, GroupCount &gc)
 {
     if (gc.err || gc.n_cols == 0) return;
-    const int ncol = group_compact(G, S.pos, S.mk, S.keep, gc.n_cols);
+    const int ncol = group_compact(G, S.pos, S.keep, gc.n_cols);
     gc.n_cols = ncol;
     if (ncol == 0) return;
     const int sc = group_blocks(G, P, par, S, ncol);
@@ -1246,7 +1267,7 @@ SPX_HD void group_pass_blocks(const GroupView &G, const Pools &P, const Params &
 SPX_HD void group_pass_blocks_begin(const GroupView &G, const Pools &P, const Params &par, GroupScratch &S, GroupCount &gc)
 {
     if (gc.err || gc.n_cols == 0) return;
-    const int ncol = group_compact(G, S.pos, S.mk, S.keep, gc.n_cols);
+    const int ncol = group_compact(G, S.pos, S.keep, gc.n_cols);
     gc.n_cols = ncol;
     if (ncol == 0) return;
     blocks_begin(G, P, par, S, ncol, *S.bstate);

@@ -379,6 +379,13 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
                 spxl::aln_pass_filter(view(k), (int)(q - st.slot0[(size_t)k]), P, S, gc[(size_t)k]);
             }
         });
+        parallel_for(ns, threads, [&](int64_t q0, int64_t q1) { /* A1b */
+            for (int64_t q = q0; q < q1; ++q) {
+                const int64_t k = slot_grp[(size_t)q];
+                spxl::GroupScratch S = scratch(k);
+                spxl::aln_pass_compact(view(k), (int)(q - st.slot0[(size_t)k]), S, gc[(size_t)k]);
+            }
+        });
         parallel_for(ng, threads, [&](int64_t k0, int64_t k1) { /* G2 */
             for (int64_t k = k0; k < k1; ++k) {
                 spxl::GroupScratch S = scratch(k);

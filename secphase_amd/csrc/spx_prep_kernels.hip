@@ -152,6 +152,17 @@ __global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
     aln_pass_filter(c.G, s - A.slot0[k], A.P, c.S, gc);
 }
 
+__global__ __launch_bounds__(64) void aln_compact_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    const int k = A.recs[s].grp;
+    const GroupCount gc = A.gc[k];
+    if (gc.err || gc.n_cols == 0) return;
+    GroupCtx c = group_ctx(A, k);
+    aln_pass_compact(c.G, s - A.slot0[k], c.S, gc);
+}
+
 /* consensus windows: rounds run per group, the projections of the windows onto the alignments per alignment */
 __global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
 {
@@ -494,6 +505,7 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
     hipLaunchKernelGGL(arena_apply_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
     hipLaunchKernelGGL(group_merge_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(aln_filter_kernel, ga, b64, 0, st, *A);
+    hipLaunchKernelGGL(aln_compact_kernel, ga, b64, 0, st, *A);
     hipLaunchKernelGGL(group_blocks_kernel, gg, b64, 0, st, *A);
     for (int round = 0; round < 3; ++round) { /* nearly every group needs one or two projection rounds */
         hipLaunchKernelGGL(aln_project_kernel, ga, b64, 0, st, *A);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -106,6 +107,7 @@ struct spx_ctx {
     std::vector<std::pair<void *, size_t>> arena_cache;
     std::vector<std::pair<void *, size_t>> pinned_cache; /* hipHostMalloc'ed staging buffers */
     std::mutex arena_mu;
+    std::condition_variable arena_cv; /* signalled when a work list gives device memory back (arena_put) */
     /* work-list preparation on the device: its own stream (it overlaps the DP kernels of the previous list), pools
      * that only live during a preparation and are shared by all of them (prep_mu serialises preparations) */
     hipStream_t prep_stream = nullptr;
@@ -367,6 +369,7 @@ struct Carver {
     }
 };
 
+static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap);
 static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
 {
     spx::HostBatch &hb = w->hb;
@@ -463,22 +466,8 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
            o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
            o_tie = cv.take<uint16_t>(ng);
     w->arena_bytes = cv.off + 256;
-    {
-        std::lock_guard<std::mutex> lk(c->arena_mu);
-        int best = -1;
-        for (size_t i = 0; i < c->arena_cache.size(); ++i)
-            if (c->arena_cache[i].second >= w->arena_bytes && (best < 0 || c->arena_cache[i].second < c->arena_cache[best].second))
-                best = (int)i;
-        if (best >= 0) {
-            w->arena = c->arena_cache[best].first;
-            w->arena_cap = c->arena_cache[best].second;
-            c->arena_cache.erase(c->arena_cache.begin() + best);
-        }
-    }
-    if (!w->arena) {
-        w->arena_cap = w->arena_bytes + w->arena_bytes / 8; /* head room so that the next, slightly larger list fits */
-        HIPCHK(hipMalloc(&w->arena, w->arena_cap));
-    }
+    w->arena = arena_get(c, w->arena_bytes, &w->arena_cap);
+    if (!w->arena) return fail(SPX_ENOMEM, "device memory for the work list");
     char *base = (char *)w->arena;
     double t0 = now_s();
     if (timing_on()) fprintf(stderr, "[spx timing] device batch: launch orders %.3f s, offsets+arena %.3f s (%.2f GB)\n", tb1 - tb0, t0 - tb1, w->arena_bytes / 1e9);
@@ -569,37 +558,50 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
 /* device allocations of finished work lists are kept for the next one (hipMalloc of several GB costs ~0.2 s) */
 static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
 {
-    {
-        std::lock_guard<std::mutex> lk(c->arena_mu);
-        int best = -1;
-        for (size_t i = 0; i < c->arena_cache.size(); ++i)
-            if (c->arena_cache[i].second >= bytes && (best < 0 || c->arena_cache[i].second < c->arena_cache[best].second))
-                best = (int)i;
-        if (best >= 0) {
-            void *p = c->arena_cache[best].first;
-            *cap = c->arena_cache[best].second;
-            c->arena_cache.erase(c->arena_cache.begin() + best);
-            return p;
+    /* When HBM is full -- several large work lists in flight: 16 384 ONT groups need ~70 GB of saved rows -- the caller
+     * WAITS for an older list to be collected and freed instead of failing: in a pipeline the oldest list always holds
+     * its memory already and finishes.  Gives up after two minutes (a single list that cannot fit). */
+    const double t_end = now_s() + 120.0;
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(c->arena_mu);
+            int best = -1;
+            for (size_t i = 0; i < c->arena_cache.size(); ++i)
+                if (c->arena_cache[i].second >= bytes && (best < 0 || c->arena_cache[i].second < c->arena_cache[best].second))
+                    best = (int)i;
+            if (best >= 0) {
+                void *p = c->arena_cache[best].first;
+                *cap = c->arena_cache[best].second;
+                c->arena_cache.erase(c->arena_cache.begin() + best);
+                return p;
+            }
         }
-    }
-    void *p = nullptr;
-    *cap = bytes + bytes / 8 + 4096; /* head room so that the next, slightly larger list fits */
-    if (hipMalloc(&p, *cap) != hipSuccess) {
+        void *p = nullptr;
+        *cap = bytes + bytes / 8 + 4096; /* head room so that the next, slightly larger list fits */
+        if (hipMalloc(&p, *cap) == hipSuccess) return p;
         (void)hipGetLastError();
-        /* give cached blocks back to the driver and try once more */
-        std::lock_guard<std::mutex> lk(c->arena_mu);
+        std::unique_lock<std::mutex> lk(c->arena_mu);
+        /* give cached blocks (all too small) back to the driver and try once more, without the head room */
         for (auto &a : c->arena_cache) (void)hipFree(a.first);
         c->arena_cache.clear();
-        if (hipMalloc(&p, *cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *cap = bytes + 4096;
+        if (hipMalloc(&p, *cap) == hipSuccess) return p;
+        (void)hipGetLastError();
+        if (now_s() >= t_end) return nullptr;
+        c->arena_cv.wait_for(lk, std::chrono::milliseconds(250));
     }
-    return p;
 }
 static void arena_put(spx_ctx *c, void *p, size_t cap)
 {
     if (!p) return;
     if (c) {
-        std::lock_guard<std::mutex> lk(c->arena_mu);
-        if (c->arena_cache.size() < 8) { c->arena_cache.emplace_back(p, cap); return; }
+        {
+            std::lock_guard<std::mutex> lk(c->arena_mu);
+            if (c->arena_cache.size() < 8) { c->arena_cache.emplace_back(p, cap); p = nullptr; }
+        }
+        if (p) (void)hipFree(p);
+        c->arena_cv.notify_all();
+        return;
     }
     (void)hipFree(p);
 }
