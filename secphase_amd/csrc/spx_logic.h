@@ -556,13 +556,14 @@ SPX_HD Mk match_marker(const Rec &r, const AlnState &st, const uint8_t *qual, in
 
 /* Marker columns of a group, in three steps so that the middle one can run one alignment per thread:
  * group_merge   k-way merge of the alignments' mismatch lists by read position, positions where every alignment
- *               mismatches dropped (remove_all_mismatch_markers), the others completed with match markers
- *               (sort_and_fill_markers); returns the number of columns
+ *               mismatches dropped (remove_all_mismatch_markers); returns the number of columns
+ * aln_fill      one alignment's cell of every column: its mismatch, or a match marker (sort_and_fill_markers)
  * aln_filter    one alignment's walk over its ops and the columns (filter_ins_markers): columns inside an insertion /
  *               clip are marked for removal, the reference positions of its match markers inside '=' ops filled in
  * aln_compact / group_compact remove the marked columns (cells per alignment, positions per group; returns the number kept) */
-SPX_HD int group_merge(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk, uint8_t *keep)
+SPX_HD int group_merge(const GroupView &G, const Pools &P, int32_t *pos, uint8_t *keep)
 {
+    /* positions only: the cells of a column (16 bytes per alignment) are written by aln_fill, one alignment per thread */
     const int n = G.n;
     int head[10], left[10], hpos[10]; /* hpos: read position of each list's head (0x7fffffff: exhausted) */
     for (int i = 0; i < n; ++i) {
@@ -577,30 +578,49 @@ SPX_HD int group_merge(const GroupView &G, const Pools &P, int32_t *pos, Mk *mk,
         for (int i = 0; i < n; ++i)
             if (hpos[i] < best) best = hpos[i];
         if (best == 0x7fffffff) break;
-        for (int i = 0; i < n; ++i)
-            if (hpos[i] == best) ++cnt;
         for (int i = 0; i < n; ++i) {
-            const bool has = hpos[i] == best;
-            if (cnt != n) {
-                Mk m;
-                if (has) {
-                    const MM s = P.mm[G.st[i].mm_off + head[i]];
-                    m.base_idx = s.base_idx; m.ref_pos = s.ref_pos; m.row = -1; m.q = (uint8_t)s.q; m.is_match = 0;
-                    m.pad0 = m.pad1 = 0;
-                } else
-                    m = match_marker(G.rec[i], G.st[i], P.qual + G.rec[i].qual_off, best);
-                mk[(int64_t)ncol * n + i] = m;
-            }
-            if (has) {
-                const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
-                head[i] += rev ? -1 : 1;
-                left[i]--;
-                hpos[i] = left[i] > 0 ? P.mm[G.st[i].mm_off + head[i]].pos : 0x7fffffff;
-            }
+            if (hpos[i] != best) continue;
+            ++cnt;
+            const bool rev = (G.rec[i].flag & SPX_FREVERSE) != 0;
+            head[i] += rev ? -1 : 1;
+            left[i]--;
+            hpos[i] = left[i] > 0 ? P.mm[G.st[i].mm_off + head[i]].pos : 0x7fffffff;
         }
         if (cnt != n) { pos[ncol] = best; keep[ncol] = 1; ++ncol; }
     }
     return ncol;
+}
+
+/* this alignment's cell of every column: its mismatch at that position, or a match marker.  Its mismatches at positions
+ * that are no column (every alignment mismatches there) are stepped over. */
+SPX_HD void aln_fill(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, int ncol)
+{
+    const int n = G.n;
+    const Rec &r = G.rec[i];
+    const AlnState &st = G.st[i];
+    const bool rev = (r.flag & SPX_FREVERSE) != 0;
+    const int step = rev ? -1 : 1;
+    const uint8_t *qual = P.qual + r.qual_off;
+    int left = st.n_mm, head = rev ? st.n_mm - 1 : 0;
+    MM s;
+    s.pos = 0x7fffffff; s.base_idx = 0; s.q = 0; s.ref_pos = 0;
+    if (left > 0) s = P.mm[st.mm_off + head];
+    for (int col = 0; col < ncol; ++col) {
+        const int p = pos[col];
+        while (left > 0 && s.pos < p) {
+            head += step;
+            if (--left > 0) s = P.mm[st.mm_off + head];
+        }
+        Mk m;
+        if (left > 0 && s.pos == p) {
+            m.base_idx = s.base_idx; m.ref_pos = s.ref_pos; m.row = -1; m.q = (uint8_t)s.q; m.is_match = 0;
+            m.pad0 = m.pad1 = 0;
+            head += step;
+            if (--left > 0) s = P.mm[st.mm_off + head];
+        } else
+            m = match_marker(r, st, qual, p);
+        mk[(int64_t)col * n + i] = m;
+    }
 }
 
 SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, uint8_t *keep, int ncol)
@@ -1232,13 +1252,14 @@ SPX_HD void group_pass_merge(const GroupView &G, const Pools &P, const RefView &
         if (G.st[i].err) { gc.err = G.st[i].err; return; }
     for (int i = 0; i < G.n; ++i)
         if (G.rec[i].tid < 0 || G.rec[i].tid >= rv.n_contigs) { gc.err = SPX_EINVAL; return; }
-    gc.n_cols = group_merge(G, P, S.pos, S.mk, S.keep);
+    gc.n_cols = group_merge(G, P, S.pos, S.keep);
 }
 
 /* A1 */
 SPX_HD void aln_pass_filter(const GroupView &G, int i, const Pools &P, GroupScratch &S, const GroupCount &gc)
 {
     if (gc.err || gc.n_cols == 0) return;
+    aln_fill(G, i, P, S.pos, S.mk, gc.n_cols);
     aln_filter(G, i, P, S.pos, S.mk, S.keep, gc.n_cols);
 }
 /* A1b: after EVERY alignment of the group has been through aln_pass_filter (keep[] is final), before the group pass that
