@@ -304,8 +304,28 @@ SPX_HD bool mx(int op) { return op == SPX_CMATCH || op == SPX_CEQUAL || op == SP
  * EMIT = false: counts the op table (st.n_ops) and bounds the mismatch list and the confident blocks (st.mm_cap,
  * st.conf_cap); EMIT = true: writes ops[0..n_ops) (ops[0] = state before the first step).  Both fill lclip/rclip,
  * n_visit, rest and return 0 or SPX_E*. */
+/* Upper bounds of what build_ops / finish_alignment produce, from the record's lengths alone (no payload byte read):
+ * an op per CIGAR op and per tag token (a cs token takes two characters or more, an MD token one), a confident block per
+ * CIGAR op, a mismatch per three cs characters / per MD character.  The device sizes its tables with these and parses
+ * every tag ONCE; an alignment that outgrows them (malformed tags: the reference's tokenizer then re-uses the previous
+ * token) sends the whole batch through the exact counting pass instead. */
+SPX_HD void aln_caps(const Rec &r, int32_t &ops_cap, int32_t &conf_cap, int32_t &mm_cap)
+{
+    const int64_t nc = r.n_cigar > 0 ? r.n_cigar : 0;
+    const int64_t tl = r.cs_len >= 0 ? r.cs_len : (r.md_len >= 0 ? r.md_len : 0);
+    const int64_t tokens = r.cs_len >= 0 ? tl / 2 : tl;
+    int64_t mm = r.cs_len >= 0 ? tl / 3 : tl;
+    const int64_t lq = r.l_qseq > 0 ? r.l_qseq : 0;
+    if (mm > lq) mm = lq;
+    const int64_t oc = nc + tokens + 4;
+    ops_cap = (int32_t)(oc > 0x3fffffff ? 0x3fffffff : oc);
+    conf_cap = (int32_t)(nc + 2 > 0x3fffffff ? 0x3fffffff : nc + 2);
+    mm_cap = (int32_t)(mm + 1);
+}
+
+/* cap: room in ops[] (EMIT only; 0 = the table was sized by the counting pass) */
 template <bool EMIT>
-SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, AlnState &st, Op *ops)
+SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, AlnState &st, Op *ops, int32_t cap = 0)
 {
     if (r.n_cigar <= 0) return SPX_EINVAL;
     const uint32_t *cigar = P.cigar + r.cigar_off;
@@ -386,7 +406,10 @@ SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, Aln
         else { cur.rds = cur.rde + 1; cur.rde += rd; }
         cur.sqs = cur.sqe + 1; cur.sqe += sq;
         cur.rfs = cur.rfe + 1; cur.rfe += rf;
-        if (EMIT) ops[n] = cur;
+        if (EMIT) {
+            if (cap && n >= cap) return SPX_ENOMEM;
+            ops[n] = cur;
+        }
         aligned = aligned || (mx(cur.op) && cur.len > 0);
         if (visiting && cur.len == 0) { visiting = false; n_visit = n; }
         if (!EMIT && visiting) {

@@ -234,6 +234,11 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
         r.tag_off = tb; tb += (r.cs_len >= 0 ? r.cs_len : r.md_len >= 0 ? r.md_len : 0) + 1;
     }
     L.cigar_words = cw; L.seq_bytes = sb; L.qual_bytes = qb; L.text_bytes = tb;
+    for (int64_t s = 0; s < ns; ++s) {
+        int32_t oc, cc, mc;
+        spxl::aln_caps(st.recs[(size_t)s], oc, cc, mc);
+        L.ops_bound += oc; L.conf_bound += cc; L.mm_bound += mc;
+    }
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
     L.o_recs = take((size_t)ns * sizeof(spxl::Rec));

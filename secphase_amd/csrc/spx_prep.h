@@ -73,6 +73,7 @@ struct StageLayout {
     int64_t n_dgroups = 0;   /* groups passing the dispatch filter (src/secphase.c:285-288) */
     int64_t n_slots = 0;     /* their alignments */
     int64_t cigar_words = 0, seq_bytes = 0, qual_bytes = 0, text_bytes = 0;
+    int64_t ops_bound = 0, conf_bound = 0, mm_bound = 0; /* sums of spxl::aln_caps over the alignments */
     /* byte offsets inside the staged buffer */
     size_t o_recs = 0, o_slot0 = 0, o_gidx = 0, o_cigar = 0, o_seq = 0, o_qual = 0, o_text = 0, bytes = 0;
 };

@@ -15,7 +15,7 @@ struct spx_prep_totals {
     int64_t arena_bytes;              /* scratch need of the per-group pass */
     int64_t n_prob, n_rows, n_qe, n_mk, s_tot, f_tot, cells;
     int64_t n_ok;                     /* dispatched groups without an error */
-    int32_t overflow;                 /* bits: 1 group scratch arena too small, 2 a group's interval lists outgrew their estimate, 4 an op / block / mismatch pool too small */
+    int32_t overflow;                 /* bits: 1 group scratch arena too small, 2 a group's interval lists outgrew their estimate, 4 an op / block / mismatch pool too small, 8 an alignment outgrew the length bounds of its tables */
     int32_t pad;
     int64_t cls_prob[SPX_N_CLASSES], cls_cells[SPX_N_CLASSES];
 };
@@ -41,6 +41,7 @@ struct spx_prep_args {
     char *arena;
     int64_t arena_cap;
     int32_t slack, pad;
+    int32_t exact_counts, tight_caps;  /* phase 1: table sizes from the counting pass (fallback) instead of the length bounds; tests: shrunken bounds */
     /* scratch of the prefix sums: five int64 columns of scan_stride entries, their tile totals, the grand totals */
     int64_t *scan_v, *scan_tile, *scan_grand;
     int64_t scan_stride;

@@ -74,6 +74,18 @@ __global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
     A.ast[s] = st;
 }
 
+/* the fast path of phase 1: table sizes from the record lengths (aln_caps), the tags are parsed once (aln_build_kernel) */
+__global__ __launch_bounds__(256) void aln_caps_kernel(spx_prep_args A)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_slots) return;
+    AlnState st = A.ast[s];
+    st.n_conf = 0; st.n_mm = 0; st.err = 0;
+    aln_caps(A.recs[s], st.n_ops, st.conf_cap, st.mm_cap);
+    if (A.tight_caps) { st.n_ops = st.n_ops / 8 + 2; st.mm_cap = st.mm_cap / 8 + 1; } /* tests: forces the fallback */
+    A.ast[s] = st;
+}
+
 __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,8 +103,10 @@ __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
     }
     const Rec r = A.recs[s];
     Op *ops = A.P.ops + st.ops_off;
-    st.err = build_ops<true>(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops);
+    const int32_t cap = A.exact_counts ? 0 : st.n_ops; /* bounded tables: n_ops holds the bound until build_ops sets the count */
+    st.err = build_ops<true>(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops, cap);
     if (!st.err) st.err = finish_alignment(r, A.P, A.par.min_q, A.par.indel_threshold, st, ops, A.P.conf + st.conf_off, A.P.mm + st.mm_off);
+    if (st.err == SPX_ENOMEM && !A.exact_counts) atomicOr(&A.tot->overflow, 8); /* a bound did not hold: count exactly */
     A.ast[s] = st;
 }
 
@@ -484,7 +498,8 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint64_t *__re
 extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *raw_seq, int64_t seq_words, hipStream_t st)
 {
     if (A->n_slots <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aln_count_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
+    if (A->exact_counts) hipLaunchKernelGGL(aln_count_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
+    else hipLaunchKernelGGL(aln_caps_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
     if (seq_words > 0)
         hipLaunchKernelGGL(recode_kernel, dim3((unsigned)std::min<int64_t>((seq_words + 255) / 256, 2048)), dim3(256), 0, st, raw_seq,
                            (uint32_t *)(A->code4_w + A->P.code_lead_bytes), seq_words, A->recs, A->n_slots, A->ast);

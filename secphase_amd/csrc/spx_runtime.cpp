@@ -95,7 +95,6 @@ struct spx_ctx {
     hipStream_t side_stream[SPX_N_SIDE] = {};
     hipEvent_t side_done[SPX_N_SIDE] = {};
     hipStream_t copy_stream = nullptr; /* host -> HBM copies of staged records */
-    bool dense_tags = false; /* a batch needed more ops than one per two tag characters (MD tags): size the op pool for one per character */
     std::mutex launch_mu;              /* spx_launch may be called from several threads (pipelined callers) */
     uint8_t *d_ref4 = nullptr;
     int64_t ref_bytes = 0;
@@ -749,11 +748,9 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         w->arena = nullptr;
     }
     w->prepared = false;
-    /* pools of the per-alignment pass, by bounds the host knows without touching the payload: an op per CIGAR op or
-     * per two tag characters; a confident block per CIGAR op; a mismatch per tag character */
-    /* (a first guess: cs tokens take two characters or more, MD tokens one; the device reports a pool that is too small) */
-    size_t ops_bound = (size_t)L.cigar_words + (size_t)L.text_bytes / (c->dense_tags ? 1 : 2) + 2 * ns + 16;
-    size_t conf_bound = (size_t)L.cigar_words + 2 * ns + 16, mm_bound = (size_t)L.text_bytes + 16;
+    /* tables of the per-alignment pass: by the per-alignment bounds of spxl::aln_caps (the device carves them the same
+     * way and parses every tag once); SPX_PREP_EXACT=1 sizes them with the counting pass instead (two parses) */
+    size_t ops_bound = (size_t)L.ops_bound + 16, conf_bound = (size_t)L.conf_bound + 16, mm_bound = (size_t)L.mm_bound + 16;
     int rc;
     auto size_pools = [&]() -> int {
         int r_;
@@ -767,6 +764,8 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     fill_prep_args(c, w);
     spx_prep_args &A = w->pa;
     A.ops_cap = (int64_t)ops_bound; A.conf_cap = (int64_t)conf_bound; A.mm_cap = (int64_t)mm_bound;
+    A.exact_counts = getenv("SPX_PREP_EXACT") ? 1 : 0;
+    A.tight_caps = getenv("SPX_PREP_TIGHT") ? 1 : 0;
     char *base = (char *)w->in_arena;
     spxl::PlanBase *d_base = (spxl::PlanBase *)(base + w->o_base);
     int64_t *d_mkb = (int64_t *)(base + w->o_mkb);
@@ -785,9 +784,10 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         const int ov = w->tot.overflow;
         if (!ov) break;
         if (attempt >= 8) return fail(SPX_ENOMEM, "preparation scratch keeps overflowing");
-        phase1 = (ov & 4) != 0;
-        if (ov & 4) { /* exact sizes are known now (the prefix sums of the counting pass) */
-            c->dense_tags = true; /* MD-tagged records: from now on one op per tag character is assumed */
+        phase1 = (ov & (4 | 8)) != 0;
+        if (ov & 8) { /* an alignment outgrew the length bounds: count exactly, then carve */
+            A.exact_counts = 1;
+        } else if (ov & 4) { /* exact sizes are known now (the prefix sums of the counting pass) */
             ops_bound = std::max(ops_bound, (size_t)w->tot.n_ops + 16);
             conf_bound = std::max(conf_bound, (size_t)w->tot.n_conf + 16);
             mm_bound = std::max(mm_bound, (size_t)w->tot.n_mm + 16);

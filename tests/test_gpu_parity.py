@@ -273,6 +273,38 @@ def test_md_tagged_records_on_a_fresh_context(built):
             c.close()
 
 
+
+def test_preparation_table_bounds_and_their_fallback(built, monkeypatch):
+    """Phase 1 of the preparation sizes the op / block / mismatch tables from the record lengths (spxl::aln_caps) and
+    parses every tag once.  SPX_PREP_TIGHT shrinks the bounds so that alignments outgrow them: the device must report it
+    and the host must fall back to the exact counting pass; SPX_PREP_EXACT takes that path from the start.  All three
+    give the host plan's work list, cs and MD tags, clips, long and short reads."""
+    import copy
+    cases = [
+        (small_genome(synth.HIFI, read_len=6000, max_secondaries=3, hardclip_frac=0.3, softclip_frac=0.3), 32, records.preset("hifi")),
+        (small_genome(synth.HIFI, tag_mode=1, read_len=3000, max_secondaries=3, n_paralogs=3, paralog_snv_rate=0.04), 32, records.preset("hifi")),
+        (small_genome(synth.ONT, n_paralogs=3), 12, records.preset("ont", bandwidth=50)),
+    ]
+    for env in ({}, {"SPX_PREP_TIGHT": "1"}, {"SPX_PREP_EXACT": "1"}):
+        for k in ("SPX_PREP_TIGHT", "SPX_PREP_EXACT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = api.Context(0)
+        try:
+            for g, n, par in cases:
+                r = g.reads(0, n)
+                c.set_reference(g.ref)
+                w = c.prepare(r.batch, par)
+                dev = w.export_plan()
+                host = api.Plan(g.ref, r.batch, par)
+                _plans_equal(dev, host, n)
+                dev.close()
+                w.free()
+        finally:
+            c.close()
+
+
 def _batch_parity(ctx, genome, reads, params, tmp_path, tag):
     ctx.set_reference(genome.ref)
     out, st = ctx.score_batch(reads.batch, params, finalize_seed=1)
