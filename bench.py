@@ -546,6 +546,15 @@ def main():
         # uncompressed record bytes (what spx_stage hands to the device: flags, CIGAR, SEQ, QUAL, cs/MD text) through the step
         line["gb_records_per_s"] = round(bytes_in * world * args.steps / elapsed / 1e9, 2)
         if args.from_bam > 0 and world == 1:
+            # the command line runs as another process on the same GPU: hand back what this one holds first
+            if pipe is not None:
+                pipe.close()
+                pipe = None
+            for w_ in staged:
+                w_.free()
+            staged = []
+            api._chk(L.spx_trim(ctx.h), "spx_trim")
+            torch.cuda.empty_cache()
             line["from_bam"] = from_bam_leg(args, genome, args.from_bam, ncpu)
             line["gb_bam_per_s"] = line["from_bam"].get("gb_bam_per_s")
         print(json.dumps(line), flush=True)

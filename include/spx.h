@@ -126,6 +126,9 @@ int spx_prepare_staged(spx_ctx *ctx, spx_work *work);
 int spx_work_release(spx_ctx *ctx, spx_work *work);
 int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */
 int spx_sync(spx_ctx *ctx);
+/* Returns the device and pinned memory the context keeps for re-use (arenas of freed work lists, preparation pools)
+ * to the driver -- before another process needs the GPU, or after an unusually large batch. */
+int spx_trim(spx_ctx *ctx);
 /* ---- multi-GPU: what crosses ranks (spx_gather.cpp).  Read groups shard over ranks; the relabel list is a property of
  * the whole file -- records in file order, the tie-breaking rand() stream consumed in file order (src/secphase.c:194-217,
  * ptAlignment.c:163-176 at -@1).  Every rank contributes (a) one spx_decision per dispatched group (ONE gather of

@@ -84,7 +84,7 @@ class PlanView(C.Structure):
 
 EXPORTS = [
     "spx_strerror", "spx_last_error", "spx_device_count", "spx_create", "spx_destroy", "spx_set_reference",
-    "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_prepare_many", "spx_launch", "spx_sync", "spx_collect",
+    "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_prepare_many", "spx_launch", "spx_sync", "spx_trim", "spx_collect",
     "spx_work_stats", "spx_work_free", "spx_finalize", "spx_write_relabel_log", "spx_probaln_glocal",
     "spx_probaln_batch", "spx_pack_decisions", "spx_plan_create", "spx_plan_get", "spx_plan_free", "spx_host_tables",
     "spx_finalizer_create", "spx_finalizer_apply", "spx_finalizer_free",
@@ -149,6 +149,8 @@ def lib():
         L.spx_pipe_destroy.restype = None
     L.spx_launch.argtypes = [vp, vp]
     L.spx_sync.argtypes = [vp]
+    if hasattr(L, "spx_trim"):
+        L.spx_trim.argtypes = [vp]
     L.spx_pack_decisions.argtypes = [vp, vp, C.c_int32, vp, C.c_int64]
     L.spx_collect.argtypes = [vp, vp, C.POINTER(GroupOut)]
     L.spx_work_stats.argtypes = [vp, C.POINTER(Stats)]

@@ -106,6 +106,7 @@ struct spx_ctx {
     std::vector<std::pair<void *, size_t>> arena_cache;
     std::vector<std::pair<void *, size_t>> pinned_cache; /* hipHostMalloc'ed staging buffers */
     std::mutex arena_mu;
+    size_t hbm_bytes = (size_t)256 << 30; /* the device's total memory (hipMemGetInfo at spx_create) */
     std::condition_variable arena_cv; /* signalled when a work list gives device memory back (arena_put) */
     /* work-list preparation on the device: its own stream (it overlaps the DP kernels of the previous list), pools
      * that only live during a preparation and are shared by all of them (prep_mu serialises preparations) */
@@ -230,6 +231,7 @@ extern "C" int spx_create(int device, spx_ctx **out)
         return fail(SPX_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     spx_ctx *c = new spx_ctx();
     c->device = device;
+    if (prop.totalGlobalMem > 0) c->hbm_bytes = (size_t)prop.totalGlobalMem;
     /* Optional spatial partition of the chip (SPX_PREP_CUS=k, off by default): k CUs are reserved for the preparation
      * stream and masked out of the DP streams.  Measured on MI355X (round 2): the DP kernels fill every SIMD's register
      * file, so preparation waves launched beside them wait for the DP launch to drain -- but the preparation kernels
@@ -596,7 +598,9 @@ static void arena_put(spx_ctx *c, void *p, size_t cap)
     if (c) {
         {
             std::lock_guard<std::mutex> lk(c->arena_mu);
-            if (c->arena_cache.size() < 8) { c->arena_cache.emplace_back(p, cap); p = nullptr; }
+            size_t held = 0; /* at most 8 blocks and half of the device's memory wait for re-use */
+            for (auto &a : c->arena_cache) held += a.second;
+            if (c->arena_cache.size() < 8 && held + cap <= c->hbm_bytes / 2) { c->arena_cache.emplace_back(p, cap); p = nullptr; }
         }
         if (p) (void)hipFree(p);
         c->arena_cv.notify_all();
@@ -1090,6 +1094,28 @@ extern "C" int spx_pack_decisions(spx_ctx *c, spx_work *w, int32_t group_base, v
     HIPCHK(spx_launch_pack(&w->dg, w->d_grp_index, group_base, (spx_decision *)device_out, c->copy_stream));
     HIPCHK(hipStreamSynchronize(c->copy_stream));
     return (int)ng;
+}
+
+/* Gives the device and pinned memory the context keeps for re-use (arenas of freed work lists, preparation pools)
+ * back to the driver.  The next work list allocates afresh. */
+extern "C" int spx_trim(spx_ctx *c)
+{
+    if (!c) return fail(SPX_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> pl(c->prep_mu);
+    HIPCHK(hipStreamSynchronize(c->prep_stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        for (auto &a : c->arena_cache) (void)hipFree(a.first);
+        c->arena_cache.clear();
+        for (auto &a : c->pinned_cache) (void)hipHostFree(a.first);
+        c->pinned_cache.clear();
+    }
+    for (spx_ctx::DevBuf *b : {&c->pool_ops, &c->pool_conf, &c->pool_mm, &c->pool_garena, &c->pool_keys, &c->pool_sort})
+        if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    c->arena_cv.notify_all();
+    return SPX_OK;
 }
 
 extern "C" int spx_sync(spx_ctx *c)
