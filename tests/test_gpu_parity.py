@@ -305,6 +305,28 @@ def test_preparation_table_bounds_and_their_fallback(built, monkeypatch):
             c.close()
 
 
+
+def test_trim_between_batches(built):
+    """spx_trim hands the cached arenas and pools back to the driver; the next work list allocates afresh and gives the
+    same result"""
+    g = small_genome(synth.HIFI, read_len=4000, max_secondaries=2)
+    par = records.preset("hifi")
+    r = g.reads(0, 48)
+    c = api.Context(0)
+    try:
+        c.set_reference(g.ref)
+        out1, _ = c.score_batch(r.batch, par, finalize_seed=1)
+        s1 = [[out1[k].score[a] for a in range(max(out1[k].n_aln, 0))] for k in range(48)]
+        api._chk(api.lib().spx_trim(c.h), "spx_trim")
+        out2, _ = c.score_batch(r.batch, par, finalize_seed=1)
+        s2 = [[out2[k].score[a] for a in range(max(out2[k].n_aln, 0))] for k in range(48)]
+        assert s1 == s2
+        _, res = orc.run_batch(r.batch, g.ref, par, threads=2, seed=1)
+        assert s2 == [[res[k].score[a] for a in range(max(res[k].n_aln, 0))] for k in range(48)]
+    finally:
+        c.close()
+
+
 def _batch_parity(ctx, genome, reads, params, tmp_path, tag):
     ctx.set_reference(genome.ref)
     out, st = ctx.score_batch(reads.batch, params, finalize_seed=1)
