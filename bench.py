@@ -329,8 +329,39 @@ def main():
         cbytes = np.concatenate(cands) if cands else np.zeros(0, np.uint8)
         cparts = shard.gather_bytes(torch.from_numpy(cbytes).to(coll_dev), dist, torch)
         if rank == 0:
-            _, nw = shard.merge_and_write(api, params, fin, genome.ref, dparts, cparts, log_path)
-            relabelled[0] += nw
+            # the merge + replay + formatting of ALL ranks' groups (half a million records per step at 8 ranks) runs on a
+            # helper thread, in step order, so that rank 0 keeps feeding its own GPU; the timed region ends only when the
+            # helper has caught up
+            writer_q.put((dparts, cparts))
+
+    import queue
+    writer_q = queue.Queue()
+    writer_err = []
+
+    def writer_main():
+        while True:
+            item = writer_q.get()
+            try:
+                if item is None:
+                    return
+                if not writer_err:
+                    _, nw = shard.merge_and_write(api, params, fin, genome.ref, item[0], item[1], log_path)
+                    relabelled[0] += nw
+            except Exception as ex:  # noqa: BLE001
+                writer_err.append(ex)
+            finally:
+                writer_q.task_done()
+
+    writer = None
+    if world > 1 and rank == 0:
+        writer = threading.Thread(target=writer_main, daemon=True)
+        writer.start()
+
+    def writer_drain():
+        if writer is not None:
+            writer_q.join()
+            if writer_err:
+                raise writer_err[0]
 
     def run(nsteps, offset, from_host):
         submitted = received = 0
@@ -358,9 +389,11 @@ def main():
         open(log_path, "w").close()
         run(args.depth + 1, 0, False)  # set-up, like the staging above: the context's HBM arenas of every pipeline slot exist
         run(args.warmup, 0, False)
+        writer_drain()
         sync_all()
         t0 = time.perf_counter()
         run(args.steps, args.warmup, False)
+        writer_drain()  # rank 0: the list of every timed step is on disk
         sync_all()
         elapsed = time.perf_counter() - t0
         per_step_stats = [staged[(args.warmup + k) % D].stats() for k in range(min(args.steps, D))]
@@ -558,6 +591,9 @@ def main():
             line["from_bam"] = from_bam_leg(args, genome, args.from_bam, ncpu)
             line["gb_bam_per_s"] = line["from_bam"].get("gb_bam_per_s")
         print(json.dumps(line), flush=True)
+    if writer is not None:
+        writer_q.put(None)
+        writer.join()
     if pipe is not None:
         pipe.close()
     if fin:

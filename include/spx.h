@@ -235,6 +235,8 @@ typedef struct spx_bedset spx_bedset;
 int spx_bedset_create(spx_bedset **out);
 void spx_bedset_free(spx_bedset *b);
 int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, int32_t end /* inclusive */, int32_t count);
+/* n single-base blocks (count 0) on one contig: the marker positions of one alignment */
+int spx_bedset_add_points(spx_bedset *set, const char *contig, const int32_t *pos, int32_t n);
 int64_t spx_bedset_size(const spx_bedset *b);
 /* sort + ptBlock_merge_blocks_v2 per contig + ptBlock_save_in_bed; the file is created even when empty */
 int spx_bedset_save(const spx_bedset *b, const char *path, int print_count);

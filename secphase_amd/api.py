@@ -84,7 +84,7 @@ class PlanView(C.Structure):
 
 EXPORTS = [
     "spx_strerror", "spx_last_error", "spx_device_count", "spx_create", "spx_destroy", "spx_set_reference",
-    "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_prepare_many", "spx_launch", "spx_sync", "spx_trim", "spx_collect",
+    "spx_group_is_dispatched", "spx_score_batch", "spx_prepare", "spx_prepare_many", "spx_launch", "spx_sync", "spx_trim", "spx_bedset_add_points", "spx_collect",
     "spx_work_stats", "spx_work_free", "spx_finalize", "spx_write_relabel_log", "spx_probaln_glocal",
     "spx_probaln_batch", "spx_pack_decisions", "spx_plan_create", "spx_plan_get", "spx_plan_free", "spx_host_tables",
     "spx_finalizer_create", "spx_finalizer_apply", "spx_finalizer_free",

@@ -200,6 +200,7 @@ int main(int argc, char *argv[])
     fprintf(stderr, "[%s] Started parsing alignments\n", timestamp());
     long long n_alns = 0, n_reads = 0, n_modified = 0, n_rejected = 0;
     double t_read = 0, t_wait = 0, t_out = 0, t_start = now_s(), t_hostprep = 0, t_kernel = 0;
+    double t_fin = 0, t_log = 0, t_bed = 0, t_free = 0;
     std::vector<spx_group_out> out;
     /* the reference hands every group to a pool thread and serialises the output with a mutex; here whole batches
      * flow through an in-order pipeline: while batch k is on the GPU, batch k+1 is staged and copied, batch k+2 is
@@ -257,18 +258,25 @@ int main(int argc, char *argv[])
                     return 1;
                 }
         }
+        const double ta = now_s();
         spx_finalizer_apply(fin, &par, out.data(), ng);
+        const double tb = now_s();
         spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
+        const double tc = now_s();
         n_modified += spx_relabel_blocks(w, ref, out.data(), bed_mod, bed_mk);
+        const double td = now_s();
         for (int g = 0; g < ng; ++g) if (out[g].n_aln < 0) ++n_rejected;
         spx_work_free(ctx, w);
         t_out += now_s() - t0;
+        t_fin += tb - ta; t_log += tc - tb; t_bed += td - tc; t_free += now_s() - td;
         fprintf(stderr, "[%s] #parsed alignments = %lld, #parsed reads = %lld, #modifed by phased variants = 0, #modifed by markers = %lld\n",
                 timestamp(), n_alns, n_reads, n_modified);
     }
     if (pipe) spx_pipe_destroy(pipe);
     fprintf(stderr, "[%s] time in the scoring loop: %.3f s (BAM read+inflate not hidden by the read-ahead %.3f, waiting for results %.3f, "
                     "finalise+write %.3f); on pipeline threads: staging %.3f; GPU kernels %.3f\n", timestamp(), now_s() - t_start, t_read, t_wait, t_out, t_hostprep, t_kernel);
+    if (getenv("SPX_TIMING"))
+        fprintf(stderr, "[%s] finalise+write: draws %.3f, relabel list %.3f, BED bookkeeping %.3f, work free %.3f\n", timestamp(), t_fin, t_log, t_bed, t_free);
     if (n_rejected) fprintf(stderr, "[%s] %lld read group(s) use constructs the reference leaves undefined and were skipped\n", timestamp(), n_rejected);
     fprintf(stderr, "[%s] Number of reads modified by phased variants = 0\n", timestamp());
     fprintf(stderr, "[%s] Number of reads modified by marker score = %lld\n", timestamp(), n_modified);

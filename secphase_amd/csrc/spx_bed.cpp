@@ -89,6 +89,16 @@ extern "C" int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, 
     b->per_contig[contig].push_back({start, end, count});
     return SPX_OK;
 }
+/* n single-base blocks on one contig (the marker positions of one relabelled alignment): one look-up of the contig
+ * instead of one per position */
+extern "C" int spx_bedset_add_points(spx_bedset *b, const char *contig, const int32_t *pos, int32_t n)
+{
+    if (!b || !contig || (!pos && n > 0)) return SPX_EINVAL;
+    if (n <= 0) return SPX_OK;
+    auto &v = b->per_contig[contig]; /* (no reserve: an exact reserve per call would defeat the vector's geometric growth) */
+    for (int32_t k = 0; k < n; ++k) v.push_back({pos[k], pos[k], 0});
+    return SPX_OK;
+}
 extern "C" int64_t spx_bedset_size(const spx_bedset *b)
 {
     int64_t n = 0;

@@ -12,6 +12,7 @@
  */
 #include <limits.h>
 #include <stdio.h>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 
@@ -160,21 +161,48 @@ extern "C" int spx_write_relabel_records(const char *path, const char *mode, con
     if (!path || !ref || (!recs && n > 0) || (!best_idx && n > 0)) return SPX_EINVAL;
     FILE *f = fopen(path, mode && *mode ? mode : "w");
     if (!f) { spx_internal_set_error((std::string("cannot open ") + path).c_str()); return SPX_EINVAL; }
-    int written = 0;
-    for (int32_t k = 0; k < n; ++k) {
-        const spx_relabel_rec &r = recs[k];
-        const int best = best_idx[k];
-        if (best < 0 || best == r.prim_idx) continue;
-        ++written;
-        fprintf(f, "#MARKER SCORE\n");
-        fprintf(f, "$\t%s\n", r.qname);
-        for (int i = 0; i < r.n_aln && i < 10; ++i) {
-            const char *tag = !(r.flag[i] & SPX_FSECONDARY) ? "*" : (i == best ? "@" : "!");
-            const char *contig = (r.tid[i] >= 0 && r.tid[i] < ref->n_contigs) ? ref->names + ref->name_off[r.tid[i]] : "*";
-            fprintf(f, "%s\t%.2f\t%s\t%ld\t%d\n", tag, r.score[i], contig, (long)r.pos[i], r.rfe[i]);
+    /* formatted in slices on several threads, written in order: at 8 ranks x 131 072 groups per step rank 0 writes half
+     * a million records per step, and one thread of fprintf would be the slowest thing in the job */
+    int nthr = (int)std::thread::hardware_concurrency();
+    nthr = std::max(1, std::min(nthr, 16));
+    if (n < 4096) nthr = 1;
+    std::vector<std::string> text((size_t)nthr);
+    std::vector<int> wrote((size_t)nthr, 0);
+    auto slice = [&](int t) {
+        const int32_t k0 = (int32_t)((int64_t)n * t / nthr), k1 = (int32_t)((int64_t)n * (t + 1) / nthr);
+        std::string &s = text[(size_t)t];
+        s.reserve((size_t)(k1 - k0) * 160);
+        char line[512];
+        for (int32_t k = k0; k < k1; ++k) {
+            const spx_relabel_rec &r = recs[k];
+            const int best = best_idx[k];
+            if (best < 0 || best == r.prim_idx) continue;
+            ++wrote[(size_t)t];
+            s += "#MARKER SCORE\n$\t";
+            s.append(r.qname, strnlen(r.qname, sizeof r.qname));
+            s += '\n';
+            for (int i = 0; i < r.n_aln && i < 10; ++i) {
+                const char *tag = !(r.flag[i] & SPX_FSECONDARY) ? "*" : (i == best ? "@" : "!");
+                const char *contig = (r.tid[i] >= 0 && r.tid[i] < ref->n_contigs) ? ref->names + ref->name_off[r.tid[i]] : "*";
+                const int m = snprintf(line, sizeof line, "%s\t%.2f\t%s\t%ld\t%d\n", tag, r.score[i], contig, (long)r.pos[i], r.rfe[i]);
+                if (m > 0) s.append(line, (size_t)std::min<int>(m, (int)sizeof line - 1));
+            }
+            s += '\n';
         }
-        fprintf(f, "\n");
+    };
+    if (nthr == 1) slice(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t) th.emplace_back(slice, t);
+        for (auto &x : th) x.join();
     }
-    fclose(f);
+    int written = 0;
+    bool ok = true;
+    for (int t = 0; t < nthr; ++t) {
+        written += wrote[(size_t)t];
+        if (!text[(size_t)t].empty() && fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) != text[(size_t)t].size()) ok = false;
+    }
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { spx_internal_set_error((std::string("write error on ") + path).c_str()); return SPX_EINVAL; }
     return written;
 }

@@ -1397,6 +1397,7 @@ extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const s
     const spx::HostBatch &hb = w->hb;
     if (marker_blocks && !w->staged && w->posmin_host.size() != hb.markers.size()) return fail(SPX_EINVAL, "spx_collect has not run");
     int n = 0;
+    std::vector<int32_t> pts;
     for (size_t k = 0; k < hb.grp_index.size(); ++k) {
         const spx_group_out &o = out[hb.grp_index[k]];
         if (!o.relabel) continue;
@@ -1410,11 +1411,12 @@ extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const s
             if (!marker_blocks) continue;
             const int na = hb.n_aln[k];
             if (na <= 0) continue;
+            pts.clear();
             for (int32_t m = hb.mk_first[k]; m < hb.mk_first[k + 1]; m += na) {
                 if (w->posmin_host[m] <= w->par.min_q) continue; /* position removed by filter_lowq_markers */
-                const int32_t rp = hb.mk_ref_pos[m + a];
-                spx_bedset_add(marker_blocks, contig, rp, rp, 0);
+                pts.push_back(hb.mk_ref_pos[m + a]);
             }
+            spx_bedset_add_points(marker_blocks, contig, pts.data(), (int32_t)pts.size());
         }
     }
     return n;
@@ -1426,24 +1428,47 @@ extern "C" int spx_write_relabel_log(const char *path, const char *mode, const s
     if (!path || !bt || !ref || !out) return fail(SPX_EINVAL, "NULL argument");
     FILE *f = fopen(path, mode && *mode ? mode : "w");
     if (!f) return fail(SPX_EINVAL, std::string("cannot open ") + path);
-    for (int32_t g = 0; g < bt->n_groups; ++g) {
-        const spx_group_out &o = out[g];
-        if (!o.relabel) continue;
-        fprintf(f, "#MARKER SCORE\n");
-        fprintf(f, "$\t%s\n", bt->qnames + bt->qname_off[g]);
-        int i = 0;
-        for (int a = bt->grp_first[g]; a < bt->grp_first[g + 1]; ++a) {
-            if (bt->flag[a] & SPX_FUNMAP) continue;
-            if (i >= o.n_aln) break;
-            const char *tag = !(bt->flag[a] & SPX_FSECONDARY) ? "*" : (i == o.best_idx ? "@" : "!");
-            fprintf(f, "%s\t%.2f\t%s\t%ld\t%d\n", tag, o.score[i], ref->names + ref->name_off[bt->tid[a]],
-                    (long)bt->pos[a], o.rfe[i]);
-            ++i;
+    /* formatted in slices on several threads, written in file order (print_alignment_scores, src/secphase.c:32-57): with
+     * tens of thousands of relabelled groups per batch one thread of fprintf was a third of the command line's loop */
+    const int32_t n = bt->n_groups;
+    int nthr = (int)std::thread::hardware_concurrency();
+    nthr = std::max(1, std::min(nthr, 16));
+    if (n < 4096) nthr = 1;
+    std::vector<std::string> text((size_t)nthr);
+    auto slice = [&](int t) {
+        const int32_t g0 = (int32_t)((int64_t)n * t / nthr), g1 = (int32_t)((int64_t)n * (t + 1) / nthr);
+        std::string &s = text[(size_t)t];
+        char line[512];
+        for (int32_t g = g0; g < g1; ++g) {
+            const spx_group_out &o = out[g];
+            if (!o.relabel) continue;
+            s += "#MARKER SCORE\n$\t";
+            s += bt->qnames + bt->qname_off[g];
+            s += '\n';
+            int i = 0;
+            for (int a = bt->grp_first[g]; a < bt->grp_first[g + 1]; ++a) {
+                if (bt->flag[a] & SPX_FUNMAP) continue;
+                if (i >= o.n_aln) break;
+                const char *tag = !(bt->flag[a] & SPX_FSECONDARY) ? "*" : (i == o.best_idx ? "@" : "!");
+                const int m = snprintf(line, sizeof line, "%s\t%.2f\t%s\t%ld\t%d\n", tag, o.score[i], ref->names + ref->name_off[bt->tid[a]],
+                                       (long)bt->pos[a], o.rfe[i]);
+                if (m > 0) s.append(line, (size_t)std::min<int>(m, (int)sizeof line - 1));
+                ++i;
+            }
+            s += '\n';
         }
-        fprintf(f, "\n");
+    };
+    if (nthr == 1) slice(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t) th.emplace_back(slice, t);
+        for (auto &x : th) x.join();
     }
-    fclose(f);
-    return SPX_OK;
+    bool ok = true;
+    for (int t = 0; t < nthr; ++t)
+        if (!text[(size_t)t].empty() && fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) != text[(size_t)t].size()) ok = false;
+    if (fclose(f) != 0) ok = false;
+    return ok ? SPX_OK : fail(SPX_EINVAL, std::string("write error on ") + path);
 }
 
 /* ------------------------------------------------------------------ */

@@ -90,22 +90,44 @@ def merge_and_write(api, params, fin, ref, dec_parts, cand_parts, log_path, mode
                                              C.cast(best.ctypes.data, C.POINTER(C.c_int8)),
                                              C.cast(rel.ctypes.data, C.POINTER(C.c_int8))), "spx_finalizer_apply_decisions")
     rsz = C.sizeof(api.RelabelRec)
-    cand = np.concatenate([np.asarray(p, np.uint8).reshape(-1) for p in cand_parts]) if cand_parts else np.zeros(0, np.uint8)
-    nc = len(cand) // rsz
-    if nc:
-        rows = cand[: nc * rsz].reshape(nc, rsz)
-        cgrp = np.ascontiguousarray(rows[:, :4]).view("<u4").reshape(-1)
+    dgrp = d["group"]
+
+    def best_of(cgrp):
+        if not nd:
+            return np.full(len(cgrp), -1, np.int8)
+        at = np.minimum(np.searchsorted(dgrp, cgrp), nd - 1)
+        return np.where(dgrp[at] == cgrp, best[at], -1).astype(np.int8)
+
+    def write(rows, cgrp, md):
+        nc_ = len(cgrp)
+        if nc_ == 0:
+            return 0
+        bsel = best_of(cgrp)
+        n_ = L.spx_write_relabel_records(log_path.encode(), md.encode(), ref, C.cast(rows.ctypes.data, C.POINTER(api.RelabelRec)), nc_,
+                                         C.cast(bsel.ctypes.data, C.POINTER(C.c_int8)))
+        if n_ < 0:
+            raise api.SpxError(n_, "spx_write_relabel_records")
+        return n_
+
+    parts = []
+    for p in (cand_parts or []):
+        a_ = np.ascontiguousarray(np.asarray(p, np.uint8).reshape(-1))
+        k = len(a_) // rsz
+        if k:
+            rows = a_[: k * rsz].reshape(k, rsz)
+            parts.append((rows, np.ascontiguousarray(rows[:, :4]).view("<u4").reshape(-1)))
+    # contiguous shards in rank order arrive sorted already: written part by part, nothing is copied or re-ordered
+    in_order = all(len(g) < 2 or not np.any(g[1:] < g[:-1]) for _, g in parts) and \
+        all(parts[i][1][-1] <= parts[i + 1][1][0] for i in range(len(parts) - 1))
+    if mode == "w":
+        open(log_path, "w").close()
+    n = 0
+    if in_order:
+        for rows, cgrp in parts:
+            n += write(rows, cgrp, "a")
+    elif parts:
+        rows = np.concatenate([r for r, _ in parts])
+        cgrp = np.concatenate([g for _, g in parts])
         order = np.argsort(cgrp, kind="stable")
-        rows = np.ascontiguousarray(rows[order])
-        cgrp = cgrp[order]
-        at = np.searchsorted(d["group"], cgrp) if nd else np.zeros(nc, np.int64)
-        hit = (at < nd) & (d["group"][np.minimum(at, max(nd - 1, 0))] == cgrp) if nd else np.zeros(nc, bool)
-        bsel = np.where(hit, best[np.minimum(at, max(nd - 1, 0))], -1).astype(np.int8)
-    else:
-        rows = np.zeros((1, rsz), np.uint8)
-        bsel = np.zeros(1, np.int8)
-    n = L.spx_write_relabel_records(log_path.encode(), mode.encode(), ref, C.cast(rows.ctypes.data, C.POINTER(api.RelabelRec)), nc,
-                                    C.cast(bsel.ctypes.data, C.POINTER(C.c_int8)))
-    if n < 0:
-        raise api.SpxError(n, "spx_write_relabel_records")
+        n += write(np.ascontiguousarray(rows[order]), cgrp[order], "a")
     return nd, n

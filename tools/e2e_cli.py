@@ -42,7 +42,7 @@ def main():
     flags = ["--ont", "-b", "50"] if ont else ["--hifi"]
     t0 = time.time()
     p = subprocess.run([exe] + flags + ["-@", str(args.threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "e2e",
-                                        "--groupsPerBatch", str(args.batch)], capture_output=True, text=True)
+                                        "--groupsPerBatch", str(args.batch)], capture_output=True, text=True, env=dict(os.environ, SPX_TIMING="1"))
     wall = time.time() - t0
     if p.returncode != 0:
         sys.exit(p.stderr)
@@ -61,7 +61,7 @@ def main():
                       "groups_per_s": round(args.groups / wall, 1), "GB_bam_per_s": round(size / wall / 1e9, 4),
                       "cpu_oracle_groups_per_s": round(sub.batch.contents.n_groups / cpu, 1), "cpu_threads": args.threads,
                       "out_log_identical_to_oracle": same, "bam_write_s": round(t_write, 1),
-                      "stderr_tail": [l for l in p.stderr.strip().splitlines() if "time in the scoring loop" in l or "spx timing" in l]}, indent=0))
+                      "stderr_tail": [l for l in p.stderr.strip().splitlines() if "time in the scoring loop" in l or "finalise+write:" in l]}, indent=0))
 
 
 if __name__ == "__main__":
