@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <time.h>
 #include <dlfcn.h>
 #include <zlib.h>
@@ -45,6 +46,21 @@ struct RawBuf {
     void reserve(size_t c)
     {
         if (c <= cap) return;
+        if (c >= ((size_t)32 << 20)) {
+            /* batch-sized buffers: 2 MB alignment + MADV_HUGEPAGE, so that the inflate threads' first touch of a
+             * gigabyte costs a few hundred page faults instead of a quarter of a million (where the kernel offers
+             * transparent huge pages on request; harmless otherwise) */
+            const size_t al = (size_t)2 << 20, want = (c + al - 1) & ~(al - 1);
+            void *q = nullptr;
+            if (posix_memalign(&q, al, want) != 0 || !q) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+            (void)madvise(q, want, MADV_HUGEPAGE);
+#endif
+            if (n) memcpy(q, p, n);
+            free(p);
+            p = (uint8_t *)q; cap = want;
+            return;
+        }
         uint8_t *q = (uint8_t *)realloc(p, c);
         if (!q) throw std::bad_alloc();
         p = q; cap = c;
@@ -415,6 +431,17 @@ static double io_now()
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+/* f(k0, k1) over [0, n) on up to `threads` threads */
+template <class F>
+static void io_parallel(int64_t n, int threads, F f)
+{
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(threads, 16), n / 2048));
+    if (T <= 1) { f((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] { f(n * t / T, n * (t + 1) / T); });
+    for (auto &x : th) x.join();
+}
+
 static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
 {
     const double t_fill0 = io_now();
@@ -425,15 +452,19 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
     u.reserve(r->last_batch_bytes + r->last_batch_bytes / 8 + (320u << 20)); /* one allocation per batch, not a doubling chain */
     size_t at = 0;
     bool open_group = false;
+    /* Pass 1, serial (every record says where the next one starts, and the batch ends on a name change): record
+     * offsets, field-length validation, group boundaries.  One cache line per record.  The fields themselves, the tag
+     * search (a walk over the aux bytes of every record) and the copies are pass 2, on threads. */
+    std::vector<int64_t> rec_at;     /* offset of the record body (behind block_size) */
+    std::vector<uint8_t> rec_new;    /* the record opens a group */
     for (;;) {
         if (!need(r, u, at, 4)) break;
         const int32_t bs = le32(u.data() + at);
         if (bs < 32) { g_io_err = "corrupt BAM record"; S.rc = SPX_EINVAL; break; }
         if (!need(r, u, at, (size_t)bs + 4)) { g_io_err = "truncated BAM record"; S.rc = SPX_EINVAL; break; }
         const uint8_t *p = u.data() + at + 4;
-        const int32_t refid = le32(p), posv = le32(p + 4);
         const uint32_t l_name = p[8];
-        const uint32_t ncig = p[12] | (p[13] << 8), flg = p[14] | (p[15] << 8);
+        const uint32_t ncig = p[12] | (p[13] << 8);
         const int32_t lseq = le32(p + 16);
         const char *name = (const char *)p + 32;
         /* the fixed part announces the lengths of the variable part: none of them may reach past the record, and the
@@ -446,48 +477,93 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
         }
         /* group boundary on a name change (src/secphase.c:273-279) */
         const bool same = r->have_last && r->last_name == name;
+        bool opens = false;
         if (!same || !open_group) {
             if (open_group && S.ng == max_groups) break; /* this record opens the next batch */
-            S.grp_first.push_back((int32_t)S.flag.size());
-            S.qname_off.push_back((int64_t)S.qnames.size());
-            S.qnames.insert(S.qnames.end(), name, name + strlen(name) + 1);
             r->last_name = name;
             r->have_last = true;
             open_group = true;
+            opens = true;
             ++S.ng;
         }
-        const uint8_t *cig = p + 32 + l_name, *sq = cig + 4 * (size_t)ncig, *ql = sq + ((size_t)lseq + 1) / 2, *aux = ql + lseq,
-                      *end = p + bs;
-        S.flag.push_back((uint16_t)flg);
-        S.tid.push_back((refid >= 0 && (size_t)refid < r->tmap.size()) ? r->tmap[refid] : -1);
-        S.pos.push_back(posv);
-        S.l_qseq.push_back(lseq);
-        /* more than 65535 CIGAR operations: the record carries the placeholder <l_seq>S<ref_len>N and the real CIGAR
-         * in the CG:B,I tag; sam_read1 puts it back before secphase sees the record, so do we */
-        const uint8_t *cg = nullptr;
-        uint32_t cg_n = 0;
-        if (ncig == 2 && aux <= end && ((uint32_t)le32(cig) & 0xf) == SPX_CSOFT_CLIP && ((uint32_t)le32(cig) >> 4) == (uint32_t)lseq &&
-            ((uint32_t)le32(cig + 4) & 0xf) == SPX_CREF_SKIP) {
-            const uint8_t *b = find_tag_b(aux, end, 'C', 'G');
-            if (b && (b[0] == 'I' || b[0] == 'i')) {
-                cg_n = (uint32_t)le32(b + 1);
-                if (cg_n > 0 && b + 5 + 4 * (size_t)cg_n <= end) cg = b + 5; else cg_n = 0;
-            }
-        }
-        S.n_cigar.push_back((int32_t)(cg ? cg_n : ncig));
-        S.cigar_off.push_back((int64_t)S.cigar.size());
-        if (cg) for (uint32_t k = 0; k < cg_n; ++k) S.cigar.push_back((uint32_t)le32(cg + 4 * k));
-        else for (uint32_t k = 0; k < ncig; ++k) S.cigar.push_back((uint32_t)le32(cig + 4 * k));
-        S.seq_off.push_back((int64_t)(sq - u.data()));
-        S.qual_off.push_back((int64_t)(ql - u.data()));
-        S.rec_off.push_back((int64_t)(p - u.data()));
-        const char *csz = aux <= end ? find_tag(aux, end, 'c', 's') : nullptr;
-        S.cs_off.push_back(csz ? (int64_t)((const uint8_t *)csz - u.data()) : -1);
-        const char *mdz = (!csz && aux <= end) ? find_tag(aux, end, 'M', 'D') : nullptr; /* only looked at without cs */
-        S.md_off.push_back(mdz ? (int64_t)((const uint8_t *)mdz - u.data()) : -1);
+        rec_at.push_back((int64_t)(at + 4));
+        rec_new.push_back(opens ? 1 : 0);
         at += (size_t)bs + 4;
         r->n_records++;
     }
+    const double t_p1 = io_now();
+    const int64_t nrec = (int64_t)rec_at.size();
+    S.flag.resize((size_t)nrec); S.tid.resize((size_t)nrec); S.pos.resize((size_t)nrec); S.l_qseq.resize((size_t)nrec);
+    S.n_cigar.resize((size_t)nrec); S.cigar_off.resize((size_t)nrec); S.seq_off.resize((size_t)nrec); S.qual_off.resize((size_t)nrec);
+    S.rec_off.resize((size_t)nrec); S.cs_off.resize((size_t)nrec); S.md_off.resize((size_t)nrec);
+    std::vector<int64_t> cg_at((size_t)nrec, -1); /* CG:B,I payload when the real CIGAR lives in the tag */
+    const uint8_t *base = u.data();
+    io_parallel(nrec, r->threads, [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const uint8_t *p = base + rec_at[(size_t)k];
+            const int32_t bs = le32(p - 4);
+            const int32_t refid = le32(p), posv = le32(p + 4);
+            const uint32_t l_name = p[8];
+            const uint32_t ncig = p[12] | (p[13] << 8), flg = p[14] | (p[15] << 8);
+            const int32_t lseq = le32(p + 16);
+            const uint8_t *cig = p + 32 + l_name, *sq = cig + 4 * (size_t)ncig, *ql = sq + ((size_t)lseq + 1) / 2, *aux = ql + lseq,
+                          *end = p + bs;
+            S.flag[(size_t)k] = (uint16_t)flg;
+            S.tid[(size_t)k] = (refid >= 0 && (size_t)refid < r->tmap.size()) ? r->tmap[refid] : -1;
+            S.pos[(size_t)k] = posv;
+            S.l_qseq[(size_t)k] = lseq;
+            /* more than 65535 CIGAR operations: the record carries the placeholder <l_seq>S<ref_len>N and the real CIGAR
+             * in the CG:B,I tag; sam_read1 puts it back before secphase sees the record, so do we */
+            uint32_t cg_n = 0;
+            if (ncig == 2 && aux <= end && ((uint32_t)le32(cig) & 0xf) == SPX_CSOFT_CLIP && ((uint32_t)le32(cig) >> 4) == (uint32_t)lseq &&
+                ((uint32_t)le32(cig + 4) & 0xf) == SPX_CREF_SKIP) {
+                const uint8_t *b = find_tag_b(aux, end, 'C', 'G');
+                if (b && (b[0] == 'I' || b[0] == 'i')) {
+                    cg_n = (uint32_t)le32(b + 1);
+                    if (cg_n > 0 && b + 5 + 4 * (size_t)cg_n <= end) cg_at[(size_t)k] = (int64_t)(b + 5 - base); else cg_n = 0;
+                }
+            }
+            S.n_cigar[(size_t)k] = (int32_t)(cg_at[(size_t)k] >= 0 ? cg_n : ncig);
+            S.seq_off[(size_t)k] = (int64_t)(sq - base);
+            S.qual_off[(size_t)k] = (int64_t)(ql - base);
+            S.rec_off[(size_t)k] = (int64_t)(p - base);
+            const char *csz = aux <= end ? find_tag(aux, end, 'c', 's') : nullptr;
+            S.cs_off[(size_t)k] = csz ? (int64_t)((const uint8_t *)csz - base) : -1;
+            const char *mdz = (!csz && aux <= end) ? find_tag(aux, end, 'M', 'D') : nullptr; /* only looked at without cs */
+            S.md_off[(size_t)k] = mdz ? (int64_t)((const uint8_t *)mdz - base) : -1;
+        }
+    });
+    const double t_p2 = io_now();
+    /* offsets of the copied parts (CIGAR words, group names), then the copies */
+    int64_t cw = 0, nb = 0;
+    std::vector<int64_t> grp_rec; /* first record of every group */
+    for (int64_t k = 0; k < nrec; ++k) {
+        S.cigar_off[(size_t)k] = cw;
+        cw += S.n_cigar[(size_t)k];
+        if (rec_new[(size_t)k]) {
+            S.grp_first.push_back((int32_t)k);
+            S.qname_off.push_back(nb);
+            grp_rec.push_back(k);
+            nb += (int64_t)(base + rec_at[(size_t)k])[8]; /* l_read_name counts the NUL */
+        }
+    }
+    S.cigar.resize((size_t)cw);
+    S.qnames.resize((size_t)nb);
+    io_parallel(nrec, r->threads, [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const uint8_t *p = base + rec_at[(size_t)k];
+            const uint8_t *src = cg_at[(size_t)k] >= 0 ? base + cg_at[(size_t)k] : p + 32 + p[8];
+            uint32_t *dst = S.cigar.data() + S.cigar_off[(size_t)k];
+            for (int32_t c = 0; c < S.n_cigar[(size_t)k]; ++c) dst[c] = (uint32_t)le32(src + 4 * (size_t)c);
+        }
+    });
+    io_parallel((int64_t)grp_rec.size(), r->threads, [&](int64_t g0, int64_t g1) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const uint8_t *p = base + rec_at[(size_t)grp_rec[(size_t)g]];
+            memcpy(S.qnames.data() + S.qname_off[(size_t)g], p + 32, (size_t)p[8]);
+        }
+    });
+    const double t_p3 = io_now();
     /* bytes of the records that belong to the next batch */
     r->leftover.assign(u.data() + at, u.data() + u.size());
     r->last_batch_bytes = at;
@@ -507,8 +583,9 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
     b.md_off = S.md_off.data(); b.md = (const char *)u.data();
     r->n_groups_total += S.ng;
     if (getenv("SPX_TIMING"))
-        fprintf(stderr, "[spx timing] BAM batch: %d groups, %.1f MB inflated, %.3f s (of which read+inflate %.3f s)\n", S.ng,
-                u.size() / 1e6, io_now() - t_fill0, r->t_inflate);
+        fprintf(stderr, "[spx timing] BAM batch: %d groups, %.1f MB inflated, %.3f s (record chain incl. read+inflate %.3f [read+inflate %.3f], "
+                        "fields+tags %.3f, CIGAR+names %.3f, tail %.3f)\n", S.ng, u.size() / 1e6, io_now() - t_fill0, t_p1 - t_fill0, r->t_inflate,
+                t_p2 - t_p1, t_p3 - t_p2, io_now() - t_p3);
     r->t_inflate = 0;
 }
 
