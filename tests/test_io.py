@@ -82,6 +82,39 @@ def _round_trip(tmp_path, tag_mode):
     assert got == _records(r.batch)
 
 
+
+def test_bam_round_trip_large_batches_on_threads(built, tmp_path):
+    """batches of thousands of records: the field / tag / copy passes of the reader run on threads (they are serial below
+    2 048 records per thread), batches end on group boundaries, short reads keep the file small"""
+    L = api.lib()
+    _declare(L)
+    g = small_genome(synth.HIFI, read_len=300, max_secondaries=3, min_secondaries=1, n_paralogs=3, hardclip_frac=0.3, softclip_frac=0.3)
+    r = g.reads(0, 5000)
+    fa, bam = str(tmp_path / "asm.fa"), str(tmp_path / "reads.bam")
+    write_fasta(fa, g.ref)
+    write_bam(bam, r.batch, g.ref)
+    fh = C.c_void_p()
+    assert L.spx_fasta_load(fa.encode(), C.byref(fh)) == 0, L.spx_io_last_error()
+    ref2 = L.spx_fasta_ref(fh)
+    rd = C.c_void_p()
+    assert L.spx_bam_open(bam.encode(), 8, C.byref(rd)) == 0, L.spx_io_last_error()
+    assert L.spx_bam_bind_reference(rd, ref2) == 0
+    got = []
+    sizes = []
+    while True:
+        bp = C.POINTER(records.SpxBatch)()
+        n = L.spx_bam_next_batch(rd, 3000, C.byref(bp))
+        assert n >= 0, L.spx_io_last_error()
+        if n == 0:
+            break
+        sizes.append((n, bp.contents.n_alns))
+        got += _records(bp)
+    L.spx_bam_close(rd)
+    L.spx_fasta_free(fh)
+    assert sizes[0][0] == 3000 and sizes[0][1] >= 4096  # enough records for more than one thread
+    assert got == _records(r.batch)
+
+
 def _sam_decl(L):
     vp = C.c_void_p
     L.spx_sam_open.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
