@@ -230,3 +230,75 @@ def test_two_ranks_on_the_device_emit_the_same_relabel_list(built, tmp_path):
     ndec, nrec, cut = open(str(tmp_path / "info_gpu.txt")).read().split()
     assert int(cut) != N_GROUPS // 2 and int(ndec) == sum(1 for e in res if e.n_aln >= 2) and int(nrec) == nre
     assert filecmp.cmp(log_o, str(tmp_path / "dist_gpu.out.log"), shallow=False)
+
+
+def test_relabel_record_writer_on_threads_keeps_order_and_format(built, tmp_path):
+    """spx_write_relabel_records formats slices of >= 4 096 records on threads: the file must be what one pass of
+    print_alignment_scores (src/secphase.c:32-57) over the records in order would write"""
+    import ctypes as C
+
+    import numpy as np
+
+    from common import small_genome
+    from secphase_amd import api, synth
+    L = api.lib()
+    g = small_genome(synth.HIFI)
+    ref = g.ref.contents
+    names = [C.string_at(ref.names + ref.name_off[i]).decode() for i in range(ref.n_contigs)]
+    rng = np.random.default_rng(5)
+    n = 9000
+    recs = (api.RelabelRec * n)()
+    best = (C.c_int8 * n)()
+    want = []
+    for k in range(n):
+        r = recs[k]
+        r.group = k
+        na = int(rng.integers(2, 6))
+        r.n_aln, r.prim_idx = na, int(rng.integers(0, na))
+        r.qname = f"read_{k}_{int(rng.integers(0, 10 ** 9))}".encode()
+        for i in range(na):
+            r.score[i] = float(np.round(rng.normal(-50, 40), 3))
+            r.rfe[i] = int(rng.integers(0, 10 ** 6))
+            r.pos[i] = int(rng.integers(0, 10 ** 6))
+            r.tid[i] = int(rng.integers(0, len(names)))
+            r.flag[i] = 0 if i == r.prim_idx else 256
+        b = int(rng.integers(-1, na))
+        best[k] = b
+        if b < 0 or b == r.prim_idx:
+            continue
+        want.append("#MARKER SCORE\n$\t%s\n" % r.qname.decode())
+        for i in range(na):
+            tag = "*" if not (r.flag[i] & 256) else ("@" if i == b else "!")
+            want.append("%s\t%.2f\t%s\t%d\t%d\n" % (tag, r.score[i], names[r.tid[i]], r.pos[i], r.rfe[i]))
+        want.append("\n")
+    path = str(tmp_path / "records.log")
+    nw = L.spx_write_relabel_records(path.encode(), b"w", g.ref, recs, n, best)
+    assert nw == sum(1 for x in want if x.startswith("#MARKER"))
+    assert open(path).read() == "".join(want)
+
+
+def test_relabel_log_writer_on_threads_equals_the_oracles_log(built, tmp_path):
+    """spx_write_relabel_log formats batches of >= 4 096 groups on threads: fed with the oracle's results it must write
+    the oracle's own log byte for byte"""
+    import filecmp
+
+    from common import small_genome
+    from oracle import orc
+    from secphase_amd import api, records, synth
+    g = small_genome(synth.HIFI, read_len=300, max_secondaries=3, min_secondaries=1, n_paralogs=3)
+    n = 5000
+    r = g.reads(0, n)
+    par = records.preset("hifi")
+    log_o, log_s = str(tmp_path / "oracle.log"), str(tmp_path / "spx.log")
+    _, res = orc.run_batch(r.batch, g.ref, par, threads=8, seed=1, log_path=log_o)
+    out = (api.GroupOut * n)()
+    nrel = 0
+    for k in range(n):
+        e, o = res[k], out[k]
+        o.n_aln, o.prim_idx, o.best_idx, o.relabel = e.n_aln, e.prim_idx, e.best_idx, int(bool(e.relabel))
+        nrel += int(bool(e.relabel))
+        for a in range(max(e.n_aln, 0)):
+            o.score[a], o.rfe[a] = e.score[a], e.rfe[a]
+    assert nrel > 50
+    api.write_relabel_log(log_s, r.batch, g.ref, out)
+    assert filecmp.cmp(log_o, log_s, shallow=False)
