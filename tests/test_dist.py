@@ -302,3 +302,44 @@ def test_relabel_log_writer_on_threads_equals_the_oracles_log(built, tmp_path):
     assert nrel > 50
     api.write_relabel_log(log_s, r.batch, g.ref, out)
     assert filecmp.cmp(log_o, log_s, shallow=False)
+
+
+def test_merge_and_write_with_interleaved_shards(built, tmp_path):
+    """shards that are NOT contiguous in rank order (round-robin blocks): merge_and_write has to sort decisions and
+    candidate records by group before the replay; the list equals the single-process one"""
+    import filecmp
+
+    import numpy as np
+
+    from oracle import orc
+    from secphase_amd import api, shard
+    g, p = _setup()
+    n = N_GROUPS
+    r = g.reads(0, n)
+    L = api.lib()
+    log_o, log_s = str(tmp_path / "oracle.log"), str(tmp_path / "merged.log")
+    _, res = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1, log_path=log_o)
+    out = _results_from_oracle(api, res, p)
+    dparts, cparts = [], []
+    for rank in range(3):  # blocks of 7 groups dealt round-robin to three "ranks"
+        dec_bytes, cand_bytes = [], []
+        for lo in range(rank * 7, n, 21):
+            hi = min(lo + 7, n)
+            sub = g.reads(lo, hi - lo)
+            sub_out = (api.GroupOut * (hi - lo))(*[out[k] for k in range(lo, hi)])
+            dec = (api.Decision * (hi - lo))()
+            nd = L.spx_decisions_from_results(sub_out, hi - lo, lo, dec, hi - lo)
+            dec_bytes.append(np.frombuffer(memoryview(dec), np.uint8)[: nd * shard.DECISION_BYTES].copy())
+            nc = L.spx_relabel_candidates(sub.batch, lo, sub_out, C.byref(p), None, 0)
+            if nc > 0:
+                arr = (api.RelabelRec * nc)()
+                L.spx_relabel_candidates(sub.batch, lo, sub_out, C.byref(p), arr, nc)
+                cand_bytes.append(np.frombuffer(memoryview(arr), np.uint8).copy())
+        dparts.append(np.concatenate(dec_bytes) if dec_bytes else np.zeros(0, np.uint8))
+        cparts.append(np.concatenate(cand_bytes) if cand_bytes else np.zeros(0, np.uint8))
+    fin = C.c_void_p()
+    api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+    nd, nw = shard.merge_and_write(api, p, fin, g.ref, dparts, cparts, log_s, mode="w")
+    L.spx_finalizer_free(fin)
+    assert nd == sum(1 for e in res if e.n_aln >= 2)
+    assert filecmp.cmp(log_o, log_s, shallow=False)
