@@ -15,6 +15,22 @@ python3 bench.py --platform ont > "$OUT/${TAG}_bench_ont.json" 2>> "$OUT/${TAG}_
 python3 bench.py --platform mixed > "$OUT/${TAG}_bench_mixed.json" 2>> "$OUT/${TAG}_bench.err"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/kt" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-host-leg > "$ROOT/$OUT/${TAG}_bench_under_rocprof.json" 2>> "$ROOT/$OUT/${TAG}_bench.err")
 cp "$OUT/kt/run_kernel_stats.csv" "$OUT/${TAG}_kernel_stats.csv" 2>/dev/null
+# the dominant kernel's TIMED launches in the trace (the stats file averages set-up and warm-up launches in as well)
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+b = json.loads(open(f"{out}/{tag}_bench_under_rocprof.json").read().strip().splitlines()[-1])
+k = b["roofline"]["kernel"]
+rows = [r for r in csv.DictReader(open(f"{out}/kt/run_kernel_trace.csv")) if r["Kernel_Name"].startswith("void " + k)]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+n = b["steps"]
+json.dump({"kernel": k, "launches_in_trace": len(d), "all_launches_avg_ms": round(sum(d) / max(len(d), 1), 3),
+           "timed_launches_avg_ms": round(sum(d[-n:]) / max(len(d[-n:]), 1), 3), "timed_launches_ms": [round(x, 2) for x in d[-n:]],
+           "bench_avg_launch_ms_hip_events": b["roofline"]["avg_launch_ms"], "bench_value": b["value"],
+           "note": "rocprofv3 --kernel-trace of the default bench command: durations of the dominant kernel; the last `steps` launches "
+                   "are the timed steps, the ones before are set-up and warm-up (other concurrency)"},
+          open(f"{out}/{tag}_kernel_trace_dominant.json", "w"), indent=1)
+PY
 rm -rf "$OUT/kt"
 python3 tools/pmc_collect.py --platform hifi --out "$OUT/${TAG}_counters_hifi.json" >> "$OUT/${TAG}_bench.err" 2>&1
 python3 tools/pmc_collect.py --platform ont --out "$OUT/${TAG}_counters_ont.json" >> "$OUT/${TAG}_bench.err" 2>&1
