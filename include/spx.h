@@ -249,22 +249,57 @@ int spx_merge_blocks_count(int32_t n, const int32_t *s, const int32_t *e, const 
 int spx_relabel_blocks(const spx_work *work, const spx_ref *ref, const spx_group_out *out, spx_bedset *modified_blocks,
                        spx_bedset *marker_blocks);
 
-/* ---- input side: name-grouped BAM and FASTA readers (zlib only; the reference reads through htslib:
- * sam_open/sam_read1 src/secphase.c:236-268, fai_load/fai_fetch src/secphase.c:101, ptMarker.c:739-744) ---- */
+/* ---- input side: name-grouped BAM and FASTA readers (the reference reads through htslib on one thread:
+ * sam_open/sam_read1 src/secphase.c:236-268, fai_load/fai_fetch src/secphase.c:101, ptMarker.c:739-744).  The BAM
+ * reader maps the file, walks the BGZF block chain on the mapping, inflates runs of blocks on a persistent pool of
+ * threads (libdeflate when the machine has it, zlib otherwise; CRC32 checked) into slots of one arena, follows the
+ * record chain on one thread and hands out batches that POINT INTO the arena (SEQ / QUAL / tag text are not copied);
+ * finished batches wait in a read-ahead queue.  A BAM record may not exceed the chunk size (32 MB by default). ---- */
 typedef struct spx_bam_reader spx_bam_reader;
 typedef struct spx_fasta spx_fasta;
+#define SPX_BAM_WANT_VOFFSETS 1 /* keep the BGZF virtual offset of every group's first record (index building) */
+#define SPX_BAM_NO_CRC 2        /* skip the CRC32 check of the inflated blocks */
+typedef struct spx_bam_options {
+    int32_t threads;        /* inflate / parse threads [4] */
+    int32_t batch_groups;   /* > 0: batches of this many groups are cut in the background from spx_bam_open_opts on (the
+                             * first spx_bam_next_batch must ask for the same number); 0: cutting starts with the first call */
+    int32_t ahead_batches;  /* finished batches kept ahead of the caller [2] */
+    int32_t flags;          /* SPX_BAM_* */
+    int64_t chunk_bytes;    /* inflated bytes per inflate chunk [32 MB]; also the largest BAM record the reader accepts */
+    int64_t max_bytes;      /* soft cap of the inflate arena [a quarter of the machine's memory] */
+    int64_t start_voffset;  /* BGZF virtual offsets (compressed offset << 16 | offset in the inflated block) of a record    */
+    int64_t end_voffset;    /* range [start, end): one shard of the file, cut at group starts; -1: header end / end of file */
+    int32_t keep_batches;   /* batches that stay valid after they were handed out [SPX_BAM_KEEP]; a caller with more
+                             * batches in flight (several devices) raises it and releases with spx_bam_release_batch */
+    int32_t reserved;
+} spx_bam_options;
+void spx_bam_default_options(spx_bam_options *opt);
 const char *spx_io_last_error(void);
 int spx_bam_open(const char *path, int threads, spx_bam_reader **out);
+int spx_bam_open_opts(const char *path, const spx_bam_options *opt, spx_bam_reader **out);
 int32_t spx_bam_n_targets(const spx_bam_reader *r);
 const char *spx_bam_target_name(const spx_bam_reader *r, int32_t i);
-/* map BAM target ids to the contig indices of `ref` by name; returns the number of targets the FASTA lacks */
+/* map BAM target ids to the contig indices of `ref` by name; returns the number of targets the FASTA lacks.  Applies to
+ * the batches handed out from then on (the mapping happens at hand-out, the background work does not wait for it). */
 int spx_bam_bind_reference(spx_bam_reader *r, const spx_ref *ref);
 /* up to max_groups complete name groups (consecutive records with one read name, src/secphase.c:273-279);
  * the batch is owned by the reader and stays valid for the next SPX_BAM_KEEP calls (a pipelined caller has several
- * batches in flight); returns groups read, 0 at EOF, <0 on error */
+ * batches in flight) or until spx_bam_release_batch; returns groups read, 0 at EOF, <0 on error.  The bytes a batch
+ * points to (SEQ, QUAL, tag text) belong to that batch alone: the caller may edit them in place until it lets the
+ * batch go (the command line applies the BAQ qualities of -w that way, like calc_local_baq does in the bam1_t). */
 #define SPX_BAM_KEEP 6
 int spx_bam_next_batch(spx_bam_reader *r, int32_t max_groups, const spx_batch **out);
+/* done with a batch: its part of the inflate arena is recycled now rather than SPX_BAM_KEEP calls later */
+int spx_bam_release_batch(spx_bam_reader *r, const spx_batch *batch);
 void spx_bam_close(spx_bam_reader *r);
+/* Index of group starts in the reference's on-disk format (src/secphase_index.c:76-119 writes, get_offset_array
+ * src/secphase.c:357-385 reads: int64 count, then that many int64 BGZF virtual offsets): the offset of the first record
+ * of every step_groups-th read group plus the offset where the records end.  A reader opened with start_voffset = a[i]
+ * and end_voffset = a[j] yields exactly the groups [i*step, j*step): N readers / N devices can share one file.
+ * spx_bam_index_build returns the number of offsets (offsets == NULL: only counts) or SPX_E*. */
+int64_t spx_bam_index_build(const char *path, int threads, int32_t step_groups, int64_t *offsets, int64_t capacity);
+int spx_bam_index_save(const char *index_path, const int64_t *offsets, int64_t n);
+int64_t spx_bam_index_load(const char *index_path, int64_t *offsets, int64_t capacity);
 /* -w/--writeBam (src/secphase.c:182-189,643-657): the reference opens the output with sam_open(path, "w"), i.e.
  * SAM text despite the .bam name, writes the input header (sam_hdr_write) and then sam_write1()s every stored
  * alignment of every dispatched group with the qualities calc_local_baq left in the record.

@@ -91,7 +91,8 @@ EXPORTS = [
     "spx_bedset_create", "spx_bedset_free", "spx_bedset_add", "spx_bedset_size", "spx_bedset_save",
     "spx_merge_blocks_count", "spx_relabel_blocks",
     "spx_io_last_error", "spx_bam_open", "spx_bam_n_targets", "spx_bam_target_name", "spx_bam_bind_reference",
-    "spx_bam_next_batch", "spx_bam_close", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
+    "spx_bam_next_batch", "spx_bam_close", "spx_bam_open_opts", "spx_bam_default_options", "spx_bam_release_batch",
+    "spx_bam_index_build", "spx_bam_index_save", "spx_bam_index_load", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
@@ -192,6 +193,7 @@ def lib():
     L.spx_bam_next_batch.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(SpxBatch))]
     L.spx_bam_close.argtypes = [vp]
     L.spx_bam_close.restype = None
+    L.spx_bam_release_batch.argtypes = [vp, C.POINTER(SpxBatch)]
     L.spx_fasta_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.spx_fasta_ref.argtypes = [vp]
     L.spx_fasta_ref.restype = C.POINTER(SpxRef)

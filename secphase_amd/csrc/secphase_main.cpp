@@ -11,9 +11,17 @@
  * (wdls/workflows/secphase.wdl:100-107) are created; the three variant-mode BEDs stay empty, as they do in
  * the reference when no VCF is given.
  *
- * Pipeline: the reader inflates BGZF blocks in parallel and cuts the name-grouped BAM into blocks of
- * --groupsPerBatch groups; each block is prepared on -@ host threads, scored on the GPU, finalised in file
- * order with one rand() stream (= the reference at -@1) and appended to <prefix>.out.log.
+ * Pipeline: the reader (spx_io.cpp) inflates BGZF blocks on a pool of -@ threads and cuts the name-grouped BAM into
+ * batches of --groupsPerBatch groups; batches are dealt round-robin to the devices of --devices (one scoring context
+ * and one in-order pipeline per GPU: staging into pinned memory, copy to HBM, device preparation, DP + scoring
+ * kernels, one packed result copy back); results are taken in FILE order, finalised with one rand() stream
+ * (= the reference at -@1) and appended to <prefix>.out.log; BED bookkeeping and the release of device memory run
+ * on a helper thread.  Start-up is overlapped: HIP initialisation per device, the FASTA parse and the first batches
+ * of the BAM run concurrently.
+ * Multi-GPU: reads shard over the devices batch by batch; what comes back from every device is the packed decision
+ * record of each group (spx_group_out, one device-to-host copy per batch) -- the consumer of the decisions is the
+ * host-side finalizer, so the gather IS that copy: no RCCL hop through another GPU is needed inside one process
+ * (bench.py's one-process-per-GPU job gathers over RCCL, spx_gather.cpp).
  */
 #include <getopt.h>
 #include <stdio.h>
@@ -24,7 +32,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spx.h"
@@ -71,6 +83,7 @@ static struct option long_options[] = {{"inputBam", required_argument, NULL, 'i'
                                        {"flankMargin", required_argument, NULL, 'F'},
                                        {"groupsPerBatch", required_argument, NULL, 1001},
                                        {"device", required_argument, NULL, 1002},
+                                       {"devices", required_argument, NULL, 1003},
                                        {NULL, 0, NULL, 0}};
 
 static void usage(const char *prog)
@@ -89,6 +102,8 @@ static void usage(const char *prog)
             "         --threads, -@          host threads for BGZF inflation and group preparation [4]\n"
             "         --groupsPerBatch       read groups per GPU work list [16384]\n"
             "         --device               GPU index [0]\n"
+            "         --devices              several GPUs, e.g. 0-7 or 0,2,5: batches are dealt round-robin, the output is\n"
+            "                                the same file-order list\n"
             "         --writeBam, -w         Write <prefix>.quality_modified.out.bam (SAM text, as the reference does) with\n"
             "                                the base qualities modified by BAQ\n"
             "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode)\n");
@@ -105,7 +120,22 @@ int main(int argc, char *argv[])
     par.conf_b = 20; par.flank_margin = 500;
     std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
     bool preset_ont = false, preset_hifi = false, marker_mode = true, write_bam = false, batch_given = false;
-    int threads = 4, groups_per_batch = 16384, device = 0, c;
+    int threads = 4, groups_per_batch = 16384, c;
+    std::vector<int> devices;
+    auto parse_devices = [&](const char *txt) { /* "0-3", "0,2,5", "1" */
+        devices.clear();
+        const char *q = txt;
+        while (*q) {
+            char *e = nullptr;
+            long a = strtol(q, &e, 10), b = a;
+            if (e == q) return false;
+            if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); if (e == q) return false; }
+            for (long d = a; d <= b && devices.size() < 64; ++d) devices.push_back((int)d);
+            q = e;
+            if (*q == ',') ++q; else if (*q) return false;
+        }
+        return !devices.empty();
+    };
     const char *prog = strrchr(argv[0], '/') ? strrchr(argv[0], '/') + 1 : argv[0];
     while (~(c = getopt_long(argc, argv, "i:p:P:G:o:f:v:qd:e:b:n:r:m:ct:s:B:g:@:wxyMh", long_options, NULL))) {
         switch (c) {
@@ -138,7 +168,9 @@ int main(int argc, char *argv[])
         case 'F': par.flank_margin = atoi(optarg); break;
         case 'M': marker_mode = false; break;
         case 1001: groups_per_batch = atoi(optarg); batch_given = true; break;
-        case 1002: device = atoi(optarg); break;
+        case 1002: case 1003:
+            if (!parse_devices(optarg)) { fprintf(stderr, "[%s] cannot parse the device list %s\n", timestamp(), optarg); return 1; }
+            break;
         case 'v': case 'B': case 'g': case 'G':
             fprintf(stderr, "[%s] variant mode (-v/-B/-g/-G) is not part of this build: marker mode only\n", timestamp());
             return 2;
@@ -155,6 +187,9 @@ int main(int argc, char *argv[])
         return EXIT_FAILURE;
     }
     if (groups_per_batch < 1) groups_per_batch = 1;
+    /* the device-side scans of a work list handle 2^20 alignments (SPX_MAX_STAGE_SLOTS): 11 records per group at most */
+    if (groups_per_batch > 95000) groups_per_batch = 95000;
+    if (devices.empty()) devices.push_back(0);
     /* with -w every base of every realigned window keeps its forward row in HBM until the MAP kernel has run
      * (~0.7 KB per base): smaller work lists */
     if (write_bam && !batch_given) groups_per_batch = 1024;
@@ -171,25 +206,62 @@ int main(int argc, char *argv[])
     const std::string log_path = out_path(".out.log");
     { FILE *f = fopen(log_path.c_str(), "w"); if (!f) { fprintf(stderr, "cannot write %s\n", log_path.c_str()); return 1; } fclose(f); }
 
-    spx_fasta *fa = nullptr;
-    if (spx_fasta_load(fastaPath.c_str(), &fa) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); return 1; }
-    const spx_ref *ref = spx_fasta_ref(fa);
+    const double t_proc0 = now_s();
+    const int n_dev = (int)devices.size();
+    const int depth = 3;
+    /* ---- start-up, overlapped: (a) one thread per device initialises HIP and creates the scoring context, (b) the BAM
+     * reader starts inflating and cutting batches right away, (c) this thread parses the FASTA; then the reference goes
+     * to every device and the loop starts with batches already waiting ---- */
+    std::vector<spx_ctx *> ctxs((size_t)n_dev, nullptr);
+    std::vector<int> ctx_rc((size_t)n_dev, SPX_OK);
+    std::vector<std::string> ctx_err((size_t)n_dev);
+    std::vector<std::thread> ctx_threads;
+    for (int d = 0; d < n_dev; ++d)
+        ctx_threads.emplace_back([&, d] {
+            ctx_rc[(size_t)d] = spx_create(devices[(size_t)d], &ctxs[(size_t)d]);
+            if (ctx_rc[(size_t)d] != SPX_OK) ctx_err[(size_t)d] = spx_last_error();
+        });
+    auto join_ctx = [&] { for (auto &t : ctx_threads) if (t.joinable()) t.join(); };
+    spx_bam_options bo;
+    spx_bam_default_options(&bo);
+    bo.threads = threads;
+    bo.batch_groups = marker_mode ? groups_per_batch : 0;
+    bo.ahead_batches = 2;
+    bo.keep_batches = n_dev * (depth + 1) + 3;
     spx_bam_reader *bam = nullptr;
-    if (spx_bam_open(inputPath.c_str(), threads, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); return 1; }
+    if (spx_bam_open_opts(inputPath.c_str(), &bo, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); return 1; }
+    const double t_bam_open = now_s();
+    spx_fasta *fa = nullptr;
+    if (spx_fasta_load(fastaPath.c_str(), &fa) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); return 1; }
+    const spx_ref *ref = spx_fasta_ref(fa);
+    const double t_fasta = now_s();
     int missing = spx_bam_bind_reference(bam, ref);
     if (missing > 0) fprintf(stderr, "[%s] warning: %d BAM target(s) are not in the FASTA; reads on them are skipped\n", timestamp(), missing);
 
     spx_sam_writer *sam = nullptr;
     if (write_bam && spx_sam_open(out_path(".quality_modified.out.bam").c_str(), bam, &sam) != SPX_OK) {
         fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error());
+        join_ctx();
         return 1;
     }
-    std::vector<uint8_t> qbuf;
 
-    spx_ctx *ctx = nullptr;
-    int rc = spx_create(device, &ctx);
-    if (rc != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
-    if ((rc = spx_set_reference(ctx, ref)) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
+    join_ctx();
+    const double t_ctx = now_s();
+    int rc = SPX_OK;
+    for (int d = 0; d < n_dev; ++d)
+        if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); return 1; }
+    { /* the assembly into every device's HBM, in parallel */
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_dev; ++d)
+            th.emplace_back([&, d] {
+                ctx_rc[(size_t)d] = spx_set_reference(ctxs[(size_t)d], ref);
+                if (ctx_rc[(size_t)d] != SPX_OK) ctx_err[(size_t)d] = spx_last_error();
+            });
+        for (auto &t : th) t.join();
+        for (int d = 0; d < n_dev; ++d)
+            if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); return 1; }
+    }
+    const double t_ref = now_s();
 
     spx_finalizer *fin = nullptr;
     spx_finalizer_create(1, &fin); /* unseeded rand() == srand(1) */
@@ -198,96 +270,160 @@ int main(int argc, char *argv[])
     spx_bedset_create(&bed_mk);
 
     fprintf(stderr, "[%s] Started parsing alignments\n", timestamp());
+    if (getenv("SPX_TIMING"))
+        fprintf(stderr, "[%s] start-up %.3f s: BAM open (header) %.3f, FASTA parse %.3f, waiting for the device context(s) %.3f, reference to HBM %.3f\n",
+                timestamp(), t_ref - t_proc0, t_bam_open - t_proc0, t_fasta - t_bam_open, t_ctx - t_fasta, t_ref - t_ctx);
     long long n_alns = 0, n_reads = 0, n_modified = 0, n_rejected = 0;
     double t_read = 0, t_wait = 0, t_out = 0, t_start = now_s(), t_hostprep = 0, t_kernel = 0;
-    double t_fin = 0, t_log = 0, t_bed = 0, t_free = 0;
-    std::vector<spx_group_out> out;
+    double t_fin = 0, t_log = 0;
     /* the reference hands every group to a pool thread and serialises the output with a mutex; here whole batches
-     * flow through an in-order pipeline: while batch k is on the GPU, batch k+1 is staged and copied, batch k+2 is
-     * inflated by the reader, and the results of batch k-1 are written -- in file order */
-    const int depth = 3;
-    spx_pipe *pipe = nullptr;
-    if (marker_mode && (rc = spx_pipe_create(ctx, &par, depth, threads, &pipe)) != SPX_OK) {
-        fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
-        return 1;
-    }
+     * flow through in-order pipelines (one per device): while batch k is on a GPU, batch k+1 is staged and copied,
+     * batch k+2 is inflated by the reader, and the results of batch k-1 are written -- in file order */
+    std::vector<spx_pipe *> pipes((size_t)n_dev, nullptr);
+    const int stage_threads = std::max(1, threads / n_dev);
+    for (int d = 0; d < n_dev && marker_mode; ++d)
+        if ((rc = spx_pipe_create(ctxs[(size_t)d], &par, depth, stage_threads, &pipes[(size_t)d])) != SPX_OK) {
+            fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
+            return 1;
+        }
+    /* BED bookkeeping (marker arrays come back from the device) and the release of a work list's device memory happen on
+     * a helper thread: the sets are order-independent (sorted and merged at the end), only the counts come back */
+    struct Post { spx_work *w; int lane; std::vector<spx_group_out> out; };
+    std::mutex post_mu;
+    std::condition_variable post_cv;
+    std::deque<Post> post_q;
+    bool post_stop = false;
+    long long post_modified = 0;
+    double t_bed = 0, t_free = 0;
+    std::thread post_thread([&] {
+        for (;;) {
+            Post ps;
+            {
+                std::unique_lock<std::mutex> lk(post_mu);
+                post_cv.wait(lk, [&] { return post_stop || !post_q.empty(); });
+                if (post_q.empty()) return;
+                ps = std::move(post_q.front());
+                post_q.pop_front();
+            }
+            const double ta = now_s();
+            const int nm = spx_relabel_blocks(ps.w, ref, ps.out.data(), bed_mod, bed_mk);
+            const double tb = now_s();
+            spx_work_free(ctxs[(size_t)ps.lane], ps.w);
+            const double tc = now_s();
+            std::lock_guard<std::mutex> lk(post_mu);
+            if (nm > 0) post_modified += nm;
+            t_bed += tb - ta;
+            t_free += tc - tb;
+            post_cv.notify_all();
+        }
+    });
+    auto stop_post = [&] {
+        {
+            std::lock_guard<std::mutex> lk(post_mu);
+            post_stop = true;
+        }
+        post_cv.notify_all();
+        if (post_thread.joinable()) post_thread.join();
+    };
     bool eof = false;
-    int inflight = 0;
+    long long submitted = 0, received = 0;
+    std::vector<spx_group_out> out;
+    int fail_rc = 0;
     for (;;) {
-        while (!eof && inflight < depth + 1 && inflight < SPX_BAM_KEEP - 1) {
+        while (!eof && submitted - received < (long long)n_dev * (depth + 1)) {
             const spx_batch *bt = nullptr;
             double t0 = now_s();
             int ng = spx_bam_next_batch(bam, groups_per_batch, &bt);
             t_read += now_s() - t0;
-            if (ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), spx_io_last_error()); return 1; }
+            if (ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), spx_io_last_error()); fail_rc = 1; break; }
             if (ng == 0) { eof = true; break; }
             n_alns += bt->n_alns;
             n_reads += ng;
-            if (!marker_mode) continue;
-            if ((rc = spx_pipe_submit(pipe, &bt, 1, nullptr, 0, (void *)bt)) != SPX_OK) {
+            if (!marker_mode) { spx_bam_release_batch(bam, bt); continue; }
+            if ((rc = spx_pipe_submit(pipes[(size_t)(submitted % n_dev)], &bt, 1, nullptr, 0, (void *)bt)) != SPX_OK) {
                 fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
-                return 1;
+                fail_rc = 1;
+                break;
             }
-            ++inflight;
+            ++submitted;
         }
-        if (inflight == 0) break;
+        if (fail_rc || submitted == received) break;
+        const int lane = (int)(received % n_dev);
         spx_work *w = nullptr;
         void *tag = nullptr;
         double t0 = now_s();
         out.resize((size_t)groups_per_batch + 1);
-        const int ng = spx_pipe_next(pipe, out.data(), groups_per_batch, &w, &tag);
+        const int ng = spx_pipe_next(pipes[(size_t)lane], out.data(), groups_per_batch, &w, &tag);
         t_wait += now_s() - t0;
-        --inflight;
-        if (ng < 0) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(ng), spx_last_error()); return 1; }
+        ++received;
+        if (ng < 0) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(ng), spx_last_error()); fail_rc = 1; break; }
+        out.resize((size_t)ng);
         const spx_batch *bt = (const spx_batch *)tag;
         { spx_stats st; spx_work_stats(w, &st); t_hostprep += st.prep_seconds; t_kernel += st.kernel_seconds; }
         for (int g = 0; g < ng; ++g)
-            if (out[g].n_aln == SPX_ENOTAG) { /* the reference stops here: cigar_it.c:64-67 */
+            if (out[(size_t)g].n_aln == SPX_ENOTAG) { /* the reference stops here: cigar_it.c:64-67 */
                 fprintf(stderr, "At least one of the MD or CS tags should be present!\n");
-                return 1;
+                fail_rc = 1;
             }
+        if (fail_rc) break;
         t0 = now_s();
         if (sam) { /* src/secphase.c:182-189: written before the decision, file order = the reference at -@1 */
-            int64_t qend = 0;
-            for (int32_t a = 0; a < bt->n_alns; ++a) qend = std::max<int64_t>(qend, bt->qual_off[a] + bt->l_qseq[a]);
-            qbuf.assign(bt->qual, bt->qual + qend);
-            if ((rc = spx_apply_quals(ctx, w, 0, bt, qbuf.data())) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); return 1; }
+            /* calc_local_baq edits the record's quality array in place (ptMarker.c:706,759,763); so do we: the batch's bytes
+             * live in the reader's arena, belong to this batch alone and are not read again after staging */
+            uint8_t *qv = const_cast<uint8_t *>(bt->qual);
+            if ((rc = spx_apply_quals(ctxs[(size_t)lane], w, 0, bt, qv)) != SPX_OK) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error()); fail_rc = 1; break; }
             for (int g = 0; g < ng; ++g)
-                if (spx_group_is_dispatched(bt, g) && spx_sam_write_group_of(sam, bam, bt, g, qbuf.data()) < 0) {
+                if (spx_group_is_dispatched(bt, g) && spx_sam_write_group_of(sam, bam, bt, g, qv) < 0) {
                     fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error());
-                    return 1;
+                    fail_rc = 1;
+                    break;
                 }
+            if (fail_rc) break;
         }
         const double ta = now_s();
         spx_finalizer_apply(fin, &par, out.data(), ng);
         const double tb = now_s();
         spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
         const double tc = now_s();
-        n_modified += spx_relabel_blocks(w, ref, out.data(), bed_mod, bed_mk);
-        const double td = now_s();
-        for (int g = 0; g < ng; ++g) if (out[g].n_aln < 0) ++n_rejected;
-        spx_work_free(ctx, w);
+        for (int g = 0; g < ng; ++g) if (out[(size_t)g].n_aln < 0) ++n_rejected;
+        spx_bam_release_batch(bam, bt); /* its share of the inflate arena is recycled */
+        long long shown;
+        {
+            std::lock_guard<std::mutex> lk(post_mu);
+            post_q.push_back(Post{w, lane, std::move(out)});
+            shown = post_modified;
+        }
+        post_cv.notify_all();
+        out = std::vector<spx_group_out>();
         t_out += now_s() - t0;
-        t_fin += tb - ta; t_log += tc - tb; t_bed += td - tc; t_free += now_s() - td;
+        t_fin += tb - ta; t_log += tc - tb;
         fprintf(stderr, "[%s] #parsed alignments = %lld, #parsed reads = %lld, #modifed by phased variants = 0, #modifed by markers = %lld\n",
-                timestamp(), n_alns, n_reads, n_modified);
+                timestamp(), n_alns, n_reads, shown);
     }
-    if (pipe) spx_pipe_destroy(pipe);
+    stop_post();
+    n_modified = post_modified;
+    for (spx_pipe *p : pipes) if (p) spx_pipe_destroy(p);
+    if (fail_rc) return 1;
     fprintf(stderr, "[%s] time in the scoring loop: %.3f s (BAM read+inflate not hidden by the read-ahead %.3f, waiting for results %.3f, "
-                    "finalise+write %.3f); on pipeline threads: staging %.3f; GPU kernels %.3f\n", timestamp(), now_s() - t_start, t_read, t_wait, t_out, t_hostprep, t_kernel);
+                    "finalise+write %.3f); on pipeline threads: staging %.3f; GPU kernels %.3f; %d device(s)\n", timestamp(), now_s() - t_start, t_read, t_wait, t_out, t_hostprep, t_kernel, n_dev);
     if (getenv("SPX_TIMING"))
-        fprintf(stderr, "[%s] finalise+write: draws %.3f, relabel list %.3f, BED bookkeeping %.3f, work free %.3f\n", timestamp(), t_fin, t_log, t_bed, t_free);
+        fprintf(stderr, "[%s] finalise+write: draws %.3f, relabel list %.3f; on the helper thread: BED bookkeeping %.3f, work free %.3f\n", timestamp(), t_fin, t_log, t_bed, t_free);
     if (n_rejected) fprintf(stderr, "[%s] %lld read group(s) use constructs the reference leaves undefined and were skipped\n", timestamp(), n_rejected);
     fprintf(stderr, "[%s] Number of reads modified by phased variants = 0\n", timestamp());
     fprintf(stderr, "[%s] Number of reads modified by marker score = %lld\n", timestamp(), n_modified);
+    const double t_end0 = now_s();
     spx_bedset_save(bed_mod, out_path(".modified_read_blocks.markers.bed").c_str(), 1);
     spx_bedset_save(bed_mk, out_path(".marker_blocks.bed").c_str(), 0);
     spx_bedset_free(bed_mod);
     spx_bedset_free(bed_mk);
     spx_finalizer_free(fin);
     if (sam && spx_sam_close(sam) != SPX_OK) { fprintf(stderr, "[%s] could not finish the quality-modified output\n", timestamp()); return 1; }
+    const double t_end1 = now_s();
     spx_bam_close(bam);
-    spx_destroy(ctx);
+    for (spx_ctx *c_ : ctxs) spx_destroy(c_);
     spx_fasta_free(fa);
+    if (getenv("SPX_TIMING"))
+        fprintf(stderr, "[%s] wind-down: BED merge + write %.3f s, closing reader / contexts %.3f s; whole process %.3f s\n", timestamp(), t_end1 - t_end0,
+                now_s() - t_end1, now_s() - t_proc0);
     return 0;
 }

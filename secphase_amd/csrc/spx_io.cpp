@@ -1,23 +1,43 @@
 /*
  * spx_io.cpp -- input side of the drop-in: name-grouped BAM -> spx_batch blocks, FASTA -> spx_ref.
  *
- * The reference reads through htslib (sam_open/sam_read1 at src/secphase.c:236-268, fai_load/fai_fetch at
- * src/secphase.c:101, submodules/ptMarker/ptMarker.c:739-744).  htslib is not available in this environment,
- * so this is a small self-contained reader on zlib: BGZF blocks are inflated in parallel, BAM records are
- * copied field by field into the flat record format (SEQ and CIGAR keep BAM's own packing).
+ * The reference reads through htslib on ONE thread (sam_open/sam_read1 at src/secphase.c:236-268, fai_load/fai_fetch at
+ * src/secphase.c:101, submodules/ptMarker/ptMarker.c:739-744).  htslib is not available in this environment, and a
+ * single inflate thread could not feed the device anyway, so this is a self-contained reader (round 3 design):
+ *
+ *   file      mmap'ed; the BGZF block chain (BSIZE of every block header, ISIZE/CRC32 of every trailer) is walked on
+ *             the mapping -- no read() copies, 2 cache lines per block;
+ *   chunks    runs of blocks (~32 MB inflated) are inflated by a PERSISTENT pool of worker threads (libdeflate through
+ *             dlopen when the machine has it, zlib otherwise; CRC32 checked) straight into slots of one arena
+ *             (2 MB-aligned, MADV_HUGEPAGE; slots are recycled most-recently-freed first, so a long run touches a
+ *             bounded set of pages);
+ *   records   ONE walker thread follows the record chain over the inflated chunks in file order (block_size fields,
+ *             length validation, group boundaries on a name change -- src/secphase.c:273-279); a record that straddles
+ *             two chunks is made contiguous by copying the few bytes in front of it into the head room of the next slot;
+ *             fields, tag search (cs / MD / CG) and the CIGAR / name copies of a finished batch run on the pool;
+ *   batches   SEQ, QUAL and tag text are NOT copied: a batch points into the arena (offsets from the arena base) and
+ *             holds a reference on every slot it touches; finished batches wait in a read-ahead queue.
  * Grouping follows src/secphase.c:273-279: consecutive records with the same read name form a group.
  */
+#include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 #include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
-#include <future>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -29,128 +49,28 @@ namespace {
 
 thread_local std::string g_io_err;
 
-struct Block { size_t coff, clen, uoff, ulen; };
-
-/* byte buffer that grows WITHOUT zero-filling (a batch inflates to ~1 GB: value-initialising that much memory
- * on one thread costs more than inflating it on 64) */
-struct RawBuf {
-    uint8_t *p = nullptr;
-    size_t n = 0, cap = 0;
-    RawBuf() = default;
-    RawBuf(const RawBuf &) = delete;
-    RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
-    uint8_t *data() { return p; }
-    const uint8_t *data() const { return p; }
-    size_t size() const { return n; }
-    void reserve(size_t c)
-    {
-        if (c <= cap) return;
-        if (c >= ((size_t)32 << 20)) {
-            /* batch-sized buffers: 2 MB alignment + MADV_HUGEPAGE, so that the inflate threads' first touch of a
-             * gigabyte costs a few hundred page faults instead of a quarter of a million (where the kernel offers
-             * transparent huge pages on request; harmless otherwise) */
-            const size_t al = (size_t)2 << 20, want = (c + al - 1) & ~(al - 1);
-            void *q = nullptr;
-            if (posix_memalign(&q, al, want) != 0 || !q) throw std::bad_alloc();
-#ifdef MADV_HUGEPAGE
-            (void)madvise(q, want, MADV_HUGEPAGE);
-#endif
-            if (n) memcpy(q, p, n);
-            free(p);
-            p = (uint8_t *)q; cap = want;
-            return;
-        }
-        uint8_t *q = (uint8_t *)realloc(p, c);
-        if (!q) throw std::bad_alloc();
-        p = q; cap = c;
-    }
-    void resize(size_t m) /* new bytes are NOT initialised */
-    {
-        if (m > cap) reserve(std::max(m, cap + cap / 2));
-        n = m;
-    }
-    void clear() { n = 0; }
-    void swap(RawBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
-    void assign(const uint8_t *b, const uint8_t *e) { resize((size_t)(e - b)); if (e > b) memmove(p, b, (size_t)(e - b)); }
-    void erase_front(size_t k) { if (k >= n) { n = 0; return; } memmove(p, p + k, n - k); n -= k; }
-};
-
-/* one batch under construction / handed out: SEQ, QUAL and cs are NOT copied, they are offsets into the
- * inflated byte stream `ubuf` (only CIGAR is copied, it needs 4-byte alignment) */
-struct Slot {
-    RawBuf ubuf;
-    std::vector<int32_t> grp_first, tid, pos, l_qseq, n_cigar;
-    std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off, md_off;
-    std::vector<int64_t> rec_off; /* first byte (after block_size) of each raw BAM record in ubuf */
-    std::vector<uint16_t> flag;
-    std::vector<uint32_t> cigar;
-    std::vector<char> qnames;
-    spx_batch view;
-    int ng = 0;
-    int rc = 0;
-    void clear()
-    {
-        grp_first.clear(); tid.clear(); pos.clear(); l_qseq.clear(); n_cigar.clear(); qname_off.clear(); cigar_off.clear();
-        seq_off.clear(); qual_off.clear(); cs_off.clear(); md_off.clear(); flag.clear(); cigar.clear(); qnames.clear(); ng = 0; rc = 0;
-        rec_off.clear();
-    }
-};
-
-struct CChunk { /* compressed blocks of one chunk */
-    std::vector<uint8_t> cbuf;
-    std::vector<Block> blocks;
-    bool eof = false;
-    std::string err;
-};
-
-struct Reader {
-    FILE *fp = nullptr;
-    CChunk cchunk[2];              /* the chunk being inflated and the one a helper thread reads ahead */
-    int ccur = 0;
-    std::future<void> ahead;
-    bool have_ahead = false;
-    RawBuf leftover; /* inflated bytes after the last complete group of the previous batch */
-    bool eof = false;
-    int threads = 4;
-    /* header */
-    std::vector<std::string> tname;
-    std::vector<int64_t> tlen;
-    std::vector<int32_t> tmap; /* BAM tid -> contig index of the reference handed to the scorer (-1 unknown) */
-    std::string header_text;
-    /* ring of batches: the caller may keep the last SPX_BAM_SLOTS - 2 batches alive (a pipelined caller has several in
-     * flight), one more is being read ahead */
-    static const int NSLOT = 8;
-    Slot slot[NSLOT];
-    int cur = 0;
-    std::future<void> pending; /* the NEXT batch is read while the caller works on the current one */
-    bool have_pending = false;
-    int32_t pending_max = 0;
-    std::string last_name;
-    bool have_last = false;
-    int64_t n_records = 0, n_groups_total = 0;
-    double t_inflate = 0;
-    size_t last_batch_bytes = 0;
-};
-
-/* read up to 1024 BGZF blocks (~64 MB inflated), inflate them in parallel, append to `ubuf`; false at EOF / error */
-bool read_chunk_impl(Reader *r, RawBuf &ubuf);
-bool read_chunk(Reader *r, RawBuf &ubuf)
+double io_now()
 {
-    struct timespec a, b;
-    clock_gettime(CLOCK_MONOTONIC, &a);
-    const bool ok = read_chunk_impl(r, ubuf);
-    clock_gettime(CLOCK_MONOTONIC, &b);
-    r->t_inflate += (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec);
-    return ok;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
-/* libdeflate inflates BGZF blocks 2-3x faster than zlib.  The image ships its runtime library without headers, so the
- * three entry points are bound at run time (their C signatures are part of libdeflate's stable ABI); zlib is what
- * runs when the library is not there. */
+bool io_timing()
+{
+    static const bool on = getenv("SPX_TIMING") != nullptr;
+    return on;
+}
+
+inline int32_t le32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+
+/* ---- libdeflate inflates BGZF blocks 2-3x faster than zlib and has a carry-less-multiply CRC32.  The image ships its
+ * runtime library without headers, so the entry points are bound at run time (their C signatures are part of
+ * libdeflate's stable ABI); zlib is what runs when the library is not there. ---- */
 struct Deflate {
     void *(*alloc)(void) = nullptr;
     int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
     void (*release)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
     Deflate()
     {
         if (getenv("SPX_NO_LIBDEFLATE")) return;
@@ -159,132 +79,443 @@ struct Deflate {
         alloc = (void *(*)(void))dlsym(h, "libdeflate_alloc_decompressor");
         decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
         release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        crc = (uint32_t(*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
         if (!alloc || !decompress || !release) alloc = nullptr;
     }
 };
-static const Deflate &deflate_lib()
+const Deflate &deflate_lib()
 {
     static const Deflate d;
     return d;
 }
 
-/* compressed side of one chunk: up to kChunkBlocks BGZF blocks read from the file (serial freads).  It is fetched by a
- * helper thread while the previous chunk is being inflated on the worker threads. */
-static const int kChunkBlocks = 4096; /* ~256 MB inflated */
-static void read_compressed(Reader *r, CChunk &c)
-{
-    c.cbuf.clear();
-    c.blocks.clear();
-    c.eof = false;
-    c.err.clear();
-    size_t utot = 0;
-    for (int n = 0; n < kChunkBlocks; ++n) {
-        uint8_t hdr[18];
-        size_t got = fread(hdr, 1, 18, r->fp);
-        if (got == 0) { c.eof = true; break; }
-        if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { c.err = "not a BGZF block"; c.eof = true; return; }
-        const unsigned xlen = hdr[10] | (hdr[11] << 8);
-        /* the BC subfield is first in every BAM written by htslib/samtools; general case: scan the extra field */
-        std::vector<uint8_t> extra(xlen);
-        memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
-        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, r->fp) != xlen - 6) { c.err = "truncated BGZF header"; c.eof = true; return; }
-        int bsize = -1;
-        for (size_t o = 0; o + 4 <= xlen;) {
-            const unsigned slen = extra[o + 2] | (extra[o + 3] << 8);
-            if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2) bsize = extra[o + 4] | (extra[o + 5] << 8);
-            o += 4 + slen;
+/* per-thread inflate state (lives as long as its pool thread) */
+struct Inflater {
+    void *ld = nullptr;
+    z_stream zs;
+    bool z_ok = false;
+    Inflater()
+    {
+        const Deflate &DL = deflate_lib();
+        if (DL.alloc) ld = DL.alloc();
+        if (!ld) {
+            memset(&zs, 0, sizeof zs);
+            z_ok = inflateInit2(&zs, -15) == Z_OK;
         }
-        if (bsize < 0) { c.err = "BGZF block without BC field"; c.eof = true; return; }
-        const size_t clen = (size_t)bsize + 1 - 12 - xlen; /* deflate data + crc32 + isize */
-        const size_t coff = c.cbuf.size();
-        c.cbuf.resize(coff + clen);
-        if (fread(c.cbuf.data() + coff, 1, clen, r->fp) != clen || clen < 8) { c.err = "truncated BGZF block"; c.eof = true; return; }
-        const uint8_t *t = c.cbuf.data() + coff + clen - 4;
-        const size_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((size_t)t[3] << 24);
-        c.blocks.push_back({coff, clen - 8, utot, isize});
-        utot += isize;
     }
+    ~Inflater()
+    {
+        if (ld) deflate_lib().release(ld);
+        if (z_ok) inflateEnd(&zs);
+    }
+    bool run(const uint8_t *src, size_t clen, uint8_t *dst, size_t ulen)
+    {
+        if (ld) {
+            size_t got = 0;
+            return deflate_lib().decompress(ld, src, clen, dst, ulen, &got) == 0 && got == ulen;
+        }
+        if (!z_ok || inflateReset(&zs) != Z_OK) return false;
+        zs.next_in = (Bytef *)src; zs.avail_in = (uInt)clen;
+        zs.next_out = dst; zs.avail_out = (uInt)ulen;
+        return inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
+    }
+};
+uint32_t crc_of(const uint8_t *p, size_t n)
+{
+    const Deflate &DL = deflate_lib();
+    if (DL.crc) return DL.crc(0, p, n);
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
 }
 
-bool read_chunk_impl(Reader *r, RawBuf &ubuf)
-{
-    if (r->eof && !r->have_ahead) return false;
-    CChunk *c = &r->cchunk[r->ccur];
-    if (r->have_ahead) {
-        r->ahead.get(); /* the helper thread has filled cchunk[ccur] */
-        r->have_ahead = false;
-    } else
-        read_compressed(r, *c);
-    if (!c->err.empty()) { g_io_err = c->err; r->eof = true; return false; }
-    if (c->eof) r->eof = true;
-    if (!r->eof) { /* fetch the next chunk's compressed bytes while this one is inflated */
-        r->ccur ^= 1;
-        CChunk *nx = &r->cchunk[r->ccur];
-        r->ahead = std::async(std::launch::async, [r, nx]() { read_compressed(r, *nx); });
-        r->have_ahead = true;
+/* ---- persistent worker pool ---- */
+class Pool {
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    bool stop_ = false;
+
+public:
+    explicit Pool(int n)
+    {
+        for (int t = 0; t < std::max(1, n); ++t)
+            th_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                        if (q_.empty()) return;
+                        f = std::move(q_.front());
+                        q_.pop_front();
+                    }
+                    f();
+                }
+            });
     }
-    const std::vector<Block> &blocks = c->blocks;
-    if (blocks.empty()) return false;
-    const size_t ubase = ubuf.size();
-    ubuf.resize(ubase + blocks.back().uoff + blocks.back().ulen);
-    std::atomic<size_t> next(0);
-    std::atomic<int> bad(0);
-    const Deflate &DL = deflate_lib();
-    auto work = [&]() {
-        if (DL.alloc) {
-            void *d = DL.alloc();
-            if (!d) { bad = 1; return; }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int size() const { return (int)th_.size(); }
+    void submit(std::function<void()> f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            q_.push_back(std::move(f));
+        }
+        cv_.notify_one();
+    }
+    /* f(k0, k1) over [0, n) in pieces of `grain`; the caller works too and returns when every piece is done */
+    template <class F>
+    void parallel_for(int64_t n, int64_t grain, F f)
+    {
+        if (n <= 0) return;
+        grain = std::max<int64_t>(1, grain);
+        const int64_t pieces = (n + grain - 1) / grain;
+        if (pieces <= 1) { f((int64_t)0, n); return; }
+        struct St {
+            std::atomic<int64_t> next{0}, done{0};
+            std::mutex mu;
+            std::condition_variable cv;
+        };
+        auto st = std::make_shared<St>();
+        F *fp = &f; /* late helpers find no piece left and never touch it */
+        auto run = [st, fp, n, grain, pieces] {
             for (;;) {
-                size_t k = next.fetch_add(4);
-                if (k >= blocks.size()) break;
-                for (size_t q = k; q < std::min(blocks.size(), k + 4); ++q) {
-                    const Block &b = blocks[q];
-                    if (b.ulen == 0) continue;
-                    size_t got = 0;
-                    if (DL.decompress(d, c->cbuf.data() + b.coff, b.clen, ubuf.data() + ubase + b.uoff, b.ulen, &got) != 0 || got != b.ulen) bad = 1;
+                const int64_t k = st->next.fetch_add(1);
+                if (k >= pieces) return;
+                (*fp)(k * grain, std::min(n, (k + 1) * grain));
+                if (st->done.fetch_add(1) + 1 == pieces) {
+                    std::lock_guard<std::mutex> lk(st->mu);
+                    st->cv.notify_all();
                 }
             }
-            DL.release(d);
-            return;
-        }
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
-        for (;;) {
-            size_t k = next.fetch_add(4);
-            if (k >= blocks.size()) break;
-            for (size_t q = k; q < std::min(blocks.size(), k + 4); ++q) {
-                const Block &b = blocks[q];
-                if (b.ulen == 0) continue;
-                if (inflateReset(&zs) != Z_OK) { bad = 1; continue; }
-                zs.next_in = c->cbuf.data() + b.coff; zs.avail_in = (uInt)b.clen;
-                zs.next_out = ubuf.data() + ubase + b.uoff; zs.avail_out = (uInt)b.ulen;
-                int rc = inflate(&zs, Z_FINISH);
-                if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
-            }
-        }
-        inflateEnd(&zs);
-    };
-    int nt = std::max(1, std::min<int>(r->threads, (int)(blocks.size() + 3) / 4));
-    if (nt == 1) work();
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work);
-        for (auto &t : th) t.join();
+        };
+        const int helpers = (int)std::min<int64_t>(size(), pieces - 1);
+        for (int t = 0; t < helpers; ++t) submit(run);
+        run();
+        std::unique_lock<std::mutex> lk(st->mu);
+        st->cv.wait(lk, [&] { return st->done.load() == pieces; });
     }
-    if (bad) { g_io_err = "inflate failed"; r->eof = true; return false; }
-    return true;
-}
+};
 
-/* make sure n bytes are available at `at` in ubuf; false at clean EOF / error */
-bool need(Reader *r, RawBuf &ubuf, size_t at, size_t n)
+/* ---- arena of chunk slots: one virtual reservation, slots handed out lazily, recycled LIFO ---- */
+struct Arena {
+    uint8_t *base = nullptr;
+    size_t vbytes = 0, slot_bytes = 0;
+    int n_max = 0, n_fresh = 0;
+    std::vector<int> free_list;
+    ~Arena()
+    {
+        if (base) munmap(base, vbytes);
+    }
+    bool init(size_t slot, size_t want_bytes)
+    {
+        slot_bytes = slot;
+        for (size_t v = want_bytes; v >= 4 * slot; v /= 2) {
+            void *p = mmap(nullptr, v + ((size_t)2 << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (p == MAP_FAILED) continue;
+            vbytes = v + ((size_t)2 << 20);
+            const uintptr_t a = ((uintptr_t)p + (((size_t)2 << 20) - 1)) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+            base = (uint8_t *)p; /* munmap needs the original address */
+            aligned = (uint8_t *)a;
+            n_max = (int)(v / slot);
+#ifdef MADV_HUGEPAGE
+            (void)madvise(aligned, (size_t)n_max * slot, MADV_HUGEPAGE);
+#endif
+            return true;
+        }
+        return false;
+    }
+    uint8_t *aligned = nullptr;
+    uint8_t *slot_ptr(int s) const { return aligned + (size_t)s * slot_bytes; }
+    int take() /* caller holds the reader's lock; -1: nothing free and the reservation is used up */
+    {
+        if (!free_list.empty()) { const int s = free_list.back(); free_list.pop_back(); return s; }
+        if (n_fresh < n_max) return n_fresh++;
+        return -1;
+    }
+};
+
+struct Block { size_t boff, coff, clen; uint32_t uoff, ulen, crc; }; /* block start, deflate data, inflated range */
+
+struct Chunk {
+    int slot = -1;
+    uint8_t *data = nullptr; /* inflated bytes: data[0 .. len); data[-head .. 0) is the head room */
+    size_t len = 0;
+    int64_t g0 = 0;          /* stream offset (inflated bytes since the reader's start) of data[0] */
+    std::vector<Block> blocks;
+    std::atomic<int> pending{0}, bad{0};
+    int refs = 0;            /* walker + batches; under Reader::mu */
+    size_t stop_at = (size_t)-1; /* the shard ends at data + stop_at (a record start) */
+    bool last = false;
+};
+
+/* one batch under construction / handed out: SEQ, QUAL and tag text are NOT copied, they are offsets from the arena
+ * base (only CIGAR is copied, it needs 4-byte alignment) */
+struct Batch {
+    std::vector<int32_t> grp_first, tid, pos, l_qseq, n_cigar, refid;
+    std::vector<int64_t> qname_off, cigar_off, seq_off, qual_off, cs_off, md_off;
+    std::vector<int64_t> rec_off; /* first byte (after block_size) of each raw BAM record, from the arena base */
+    std::vector<int64_t> grp_voff; /* BGZF virtual offset of every group's first record (index building only) */
+    std::vector<uint8_t> rec_new;
+    std::vector<uint16_t> flag;
+    std::vector<uint32_t> cigar;
+    std::vector<char> qnames;
+    std::vector<Chunk *> chunks; /* slots this batch points into (one reference each) */
+    spx_batch view;
+    int ng = 0;
+    int rc = 0;
+    std::string err;
+    bool released = false;
+    int64_t end_voff = -1;
+};
+
+struct Reader {
+    /* file */
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t fsize = 0;
+    bool map_is_malloc = false;
+    /* header */
+    std::vector<std::string> tname;
+    std::vector<int64_t> tlen;
+    std::vector<int32_t> tmap; /* BAM tid -> contig index of the reference handed to the scorer (-1 unknown) */
+    std::string header_text;
+    /* configuration */
+    int threads = 4;
+    size_t chunk_target = (size_t)32 << 20, head = 0;
+    int max_inflight = 4, ahead = 2, keep = SPX_BAM_KEEP;
+    bool want_voff = false, check_crc = true;
+    size_t soft_cap_slots = 0;
+    /* block-chain walk (dispatcher state; reader thread only) */
+    size_t fpos = 0;
+    bool index_eof = false;
+    size_t end_coff = (size_t)-1;
+    uint32_t end_uoff = 0;
+    int64_t g_next = 0;
+    /* shared state */
+    std::mutex mu;
+    std::condition_variable cv_chunk, cv_out, cv_room;
+    Arena arena;
+    std::deque<Chunk *> inflight;   /* dispatched, not yet taken by the walker (in file order) */
+    std::deque<Batch *> outq;       /* finished batches */
+    std::deque<Batch *> handed;     /* handed to the caller, newest last */
+    std::atomic<int32_t> batch_groups{0};
+    bool closing = false, consumer_waiting = false;
+    std::unique_ptr<Pool> pool;
+    std::thread walker;
+    /* walker cursor (reader thread only) */
+    Chunk *cur = nullptr;
+    uint8_t *at = nullptr, *end = nullptr;
+    int64_t gpos = 0; /* stream offset of `at` */
+    std::vector<Block> prev_blocks;
+    int64_t prev_g0 = 0;
+    bool stream_eof = false;
+    std::string werr;
+    std::string last_name;
+    bool have_last = false;
+    int64_t n_records = 0, n_groups_total = 0;
+    double t_wait_inflate = 0, t_wait_slot = 0;
+};
+
+bool parse_block_header(const uint8_t *p, size_t avail, size_t *total, size_t *hdr_len, std::string &err)
 {
-    while (ubuf.size() < at + n)
-        if (!read_chunk(r, ubuf)) return ubuf.size() >= at + n;
+    if (avail < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) { err = "not a BGZF block"; return false; }
+    const size_t xlen = p[10] | (p[11] << 8);
+    if (12 + xlen > avail) { err = "truncated BGZF header"; return false; }
+    int bsize = -1;
+    /* the BC subfield is first in every BAM written by htslib/samtools; general case: scan the extra field */
+    for (size_t o = 0; o + 4 <= xlen;) {
+        const uint8_t *e = p + 12 + o;
+        const size_t slen = e[2] | (e[3] << 8);
+        if (e[0] == 'B' && e[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = e[4] | (e[5] << 8);
+        o += 4 + slen;
+    }
+    if (bsize < 0) { err = "BGZF block without BC field"; return false; }
+    *total = (size_t)bsize + 1;
+    *hdr_len = 12 + xlen;
+    if (*total < *hdr_len + 8) { err = "corrupt BGZF block"; return false; }
+    if (*total > avail) { err = "truncated BGZF block"; return false; }
     return true;
 }
 
-inline int32_t le32(const uint8_t *p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+void chunk_unref_locked(Reader *r, Chunk *c)
+{
+    if (--c->refs > 0) return;
+    if (c->slot >= 0) r->arena.free_list.push_back(c->slot);
+    delete c;
+    r->cv_room.notify_all();
+}
+
+void inflate_blocks(Reader *r, Chunk *c, size_t b0, size_t b1)
+{
+    thread_local Inflater inf;
+    for (size_t q = b0; q < b1; ++q) {
+        const Block &b = c->blocks[q];
+        if (!inf.run(r->map + b.coff, b.clen, c->data + b.uoff, b.ulen)) { c->bad = 1; continue; }
+        if (r->check_crc && crc_of(c->data + b.uoff, b.ulen) != b.crc) c->bad = 2;
+    }
+}
+
+/* next run of blocks -> a slot -> inflate tasks; false: nothing dispatched (end of the block chain, error, closing) */
+bool dispatch_chunk(Reader *r)
+{
+    if (r->index_eof) return false;
+    std::unique_ptr<Chunk> c(new Chunk());
+    size_t u = 0;
+    while (u < r->chunk_target) {
+        if (r->fpos >= r->fsize) { r->index_eof = true; break; }
+        if (r->fpos == r->end_coff && r->end_uoff == 0) { r->index_eof = true; break; }
+        size_t total = 0, hl = 0;
+        std::string err;
+        if (!parse_block_header(r->map + r->fpos, r->fsize - r->fpos, &total, &hl, err)) {
+            r->werr = err;
+            r->index_eof = true;
+            return false;
+        }
+        const uint8_t *t = r->map + r->fpos + total - 8;
+        const uint32_t crc = (uint32_t)le32(t), isize = (uint32_t)le32(t + 4);
+        if (isize > 65536) { r->werr = "corrupt BGZF block (ISIZE)"; r->index_eof = true; return false; }
+        const bool stop_here = r->fpos == r->end_coff;
+        if (isize > 0) c->blocks.push_back({r->fpos, r->fpos + hl, total - hl - 8, (uint32_t)u, isize, crc});
+        if (stop_here) {
+            c->stop_at = u + std::min<uint32_t>(r->end_uoff, isize);
+            r->index_eof = true;
+        }
+        u += isize;
+        r->fpos += total;
+        if (stop_here) break;
+    }
+    if (r->index_eof) c->last = true;
+    c->len = u;
+    c->g0 = r->g_next;
+    r->g_next += (int64_t)u;
+    const double t0 = io_now();
+    {
+        std::unique_lock<std::mutex> lk(r->mu);
+        for (;;) {
+            if (r->closing) return false;
+            const bool over = (size_t)(r->arena.n_fresh - (int)r->arena.free_list.size()) >= r->soft_cap_slots;
+            /* above the soft cap: wait for a slot to come back -- but only while the caller still has finished batches
+             * to take (it releases older ones as it goes); a starving caller is never kept waiting for memory */
+            if (over && !r->outq.empty() && !r->consumer_waiting) { r->cv_room.wait(lk); continue; }
+            c->slot = r->arena.take();
+            if (c->slot < 0) {
+                if (!r->outq.empty() && !r->consumer_waiting) { r->cv_room.wait(lk); continue; }
+                r->werr = "BAM reader: inflate arena exhausted (too many batches held by the caller)";
+                return false;
+            }
+            break;
+        }
+        c->data = r->arena.slot_ptr(c->slot) + r->head;
+        c->refs = 1; /* the walker's */
+        const size_t nb = c->blocks.size();
+        const size_t per = 16;
+        const int tasks = (int)((nb + per - 1) / per);
+        c->pending = tasks;
+        r->inflight.push_back(c.get());
+    }
+    r->t_wait_slot += io_now() - t0;
+    Chunk *cp = c.release();
+    const size_t nb = cp->blocks.size(), per = 16;
+    if (nb == 0) { r->cv_chunk.notify_all(); return true; }
+    for (size_t b0 = 0; b0 < nb; b0 += per) {
+        const size_t b1 = std::min(nb, b0 + per);
+        r->pool->submit([r, cp, b0, b1] {
+            inflate_blocks(r, cp, b0, b1);
+            if (cp->pending.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(r->mu);
+                r->cv_chunk.notify_all();
+            }
+        });
+    }
+    return true;
+}
+
+/* the walker moves on to the next chunk: bytes [at, end) of the current one (the front part of a record) are copied in
+ * front of the next chunk's data.  false: end of the stream or error (r->werr set). */
+bool advance_chunk(Reader *r)
+{
+    for (;;) {
+        size_t n_in;
+        {
+            std::lock_guard<std::mutex> lk(r->mu);
+            n_in = r->inflight.size();
+        }
+        if ((int)n_in >= r->max_inflight || !dispatch_chunk(r)) break;
+    }
+    if (!r->werr.empty()) return false;
+    Chunk *nx = nullptr;
+    const double t0 = io_now();
+    {
+        std::unique_lock<std::mutex> lk(r->mu);
+        if (r->inflight.empty()) { r->stream_eof = true; return false; }
+        nx = r->inflight.front();
+        r->cv_chunk.wait(lk, [&] { return nx->pending.load() == 0 || r->closing; });
+        if (r->closing) return false;
+        r->inflight.pop_front();
+    }
+    r->t_wait_inflate += io_now() - t0;
+    if (nx->bad) {
+        r->werr = nx->bad == 2 ? "BGZF block CRC mismatch" : "inflate failed";
+        std::lock_guard<std::mutex> lk(r->mu);
+        chunk_unref_locked(r, nx);
+        return false;
+    }
+    const size_t tail = r->cur ? (size_t)(r->end - r->at) : 0;
+    if (tail > r->head) {
+        r->werr = "BAM record larger than the reader's chunk size";
+        std::lock_guard<std::mutex> lk(r->mu);
+        chunk_unref_locked(r, nx);
+        return false;
+    }
+    if (tail) memcpy(nx->data - tail, r->at, tail);
+    if (r->cur) {
+        /* (a record front that already sits in this slot's head room started in an even earlier chunk: keep that one) */
+        if (r->want_voff && r->at >= r->cur->data) { r->prev_blocks = r->cur->blocks; r->prev_g0 = r->cur->g0; }
+        std::lock_guard<std::mutex> lk(r->mu);
+        chunk_unref_locked(r, r->cur);
+    }
+    r->cur = nx;
+    r->at = nx->data - tail;
+    r->end = nx->data + nx->len;
+    return true;
+}
+
+/* makes [at, at+n) contiguous inflated bytes; false at the end of the stream (or error: r->werr) */
+bool ensure(Reader *r, size_t n)
+{
+    while (!r->cur || (size_t)(r->end - r->at) < n) {
+        if (r->cur && r->cur->last) { r->stream_eof = true; return false; }
+        if (!advance_chunk(r)) return false;
+    }
+    return true;
+}
+
+/* BGZF virtual offset of stream position g (inside the current or the previous chunk) */
+int64_t voffset_of(const Reader *r, int64_t g)
+{
+    const std::vector<Block> *bl = nullptr;
+    int64_t g0 = 0;
+    if (r->cur && g >= r->cur->g0) { bl = &r->cur->blocks; g0 = r->cur->g0; }
+    else { bl = &r->prev_blocks; g0 = r->prev_g0; }
+    const int64_t u = g - g0;
+    size_t lo = 0, hi = bl->size();
+    while (hi - lo > 1) {
+        const size_t m = (lo + hi) / 2;
+        if ((int64_t)(*bl)[m].uoff <= u) lo = m; else hi = m;
+    }
+    if (bl->empty()) return -1;
+    const Block &b = (*bl)[lo];
+    return (int64_t)(((uint64_t)b.boff << 16) | (uint64_t)(u - b.uoff));
+}
 
 /* find a Z tag (cs or MD) in the aux block */
 /* value of a B-array tag (sub-type byte, count, elements) or NULL */
@@ -299,8 +530,8 @@ const uint8_t *find_tag_b(const uint8_t *aux, const uint8_t *end, char k0, char 
         case 's': case 'S': len = 2; break;
         case 'i': case 'I': case 'f': len = 4; break;
         case 'Z': case 'H': {
-            const uint8_t *z = v;
-            while (z < end && *z) ++z;
+            const uint8_t *z = (const uint8_t *)memchr(v, 0, (size_t)(end - v));
+            if (!z) return nullptr;
             len = (size_t)(z - v) + 1;
             break;
         }
@@ -331,8 +562,8 @@ const char *find_tag(const uint8_t *aux, const uint8_t *end, char k0, char k1)
         case 's': case 'S': len = 2; break;
         case 'i': case 'I': case 'f': len = 4; break;
         case 'Z': case 'H': {
-            const uint8_t *z = v;
-            while (z < end && *z) ++z;
+            const uint8_t *z = (const uint8_t *)memchr(v, 0, (size_t)(end - v));
+            if (!z) return nullptr; /* unterminated string: the record's aux block is corrupt */
             if (t0 == k0 && t1 == k1 && ty == 'Z') return (const char *)v;
             len = (size_t)(z - v) + 1;
             break;
@@ -352,117 +583,41 @@ const char *find_tag(const uint8_t *aux, const uint8_t *end, char k0, char k1)
     return nullptr;
 }
 
-} // namespace
-
-struct spx_bam_reader { Reader r; };
-struct spx_fasta {
-    std::vector<int64_t> name_off, seq_off;
-    std::vector<char> names, bases;
-    spx_ref ref;
-};
-
-extern "C" const char *spx_io_last_error(void) { return g_io_err.c_str(); }
-
-extern "C" int spx_bam_open(const char *path, int threads, spx_bam_reader **out)
+void batch_add_chunk(Reader *r, Batch &B, Chunk *c)
 {
-    if (!path || !out) return SPX_EINVAL;
-    *out = nullptr;
-    FILE *fp = fopen(path, "rb");
-    if (!fp) { g_io_err = std::string("cannot open ") + path; return SPX_EINVAL; }
-    spx_bam_reader *h = new spx_bam_reader();
-    Reader *r = &h->r;
-    r->fp = fp;
-    r->threads = threads > 0 ? threads : 4;
-    RawBuf &u = r->leftover;
-    size_t at = 0;
-    auto bail = [&](const char *msg) { g_io_err = msg; fclose(fp); delete h; return SPX_EINVAL; };
-    if (!need(r, u, at, 12) || memcmp(u.data(), "BAM\1", 4) != 0) return bail("not a BAM file");
-    const int32_t l_text = le32(u.data() + 4);
-    at = 8;
-    if (!need(r, u, at, (size_t)l_text + 4)) return bail("truncated BAM header");
-    r->header_text.assign((const char *)u.data() + at, strnlen((const char *)u.data() + at, (size_t)l_text));
-    at += (size_t)l_text;
-    const int32_t n_ref = le32(u.data() + at);
-    at += 4;
-    for (int32_t i = 0; i < n_ref; ++i) {
-        if (!need(r, u, at, 4)) return bail("truncated BAM header");
-        const int32_t ln = le32(u.data() + at);
-        at += 4;
-        if (!need(r, u, at, (size_t)ln + 4)) return bail("truncated BAM header");
-        r->tname.emplace_back((const char *)u.data() + at);
-        at += (size_t)ln;
-        r->tlen.push_back(le32(u.data() + at));
-        at += 4;
-    }
-    u.erase_front(at);
-    r->tmap.assign(n_ref, -1);
-    for (int32_t i = 0; i < n_ref; ++i) r->tmap[i] = i;
-    *out = h;
-    return SPX_OK;
+    if (!B.chunks.empty() && B.chunks.back() == c) return;
+    B.chunks.push_back(c);
+    std::lock_guard<std::mutex> lk(r->mu);
+    ++c->refs;
 }
 
-extern "C" int32_t spx_bam_n_targets(const spx_bam_reader *h) { return h ? (int32_t)h->r.tname.size() : 0; }
-extern "C" const char *spx_bam_target_name(const spx_bam_reader *h, int32_t i)
-{
-    return (h && i >= 0 && (size_t)i < h->r.tname.size()) ? h->r.tname[i].c_str() : nullptr;
-}
-
-/* BAM target ids -> contig indices of `ref` (by name); alignments on contigs the FASTA lacks get tid -1
- * and their group is rejected by the scorer with SPX_EINVAL */
-extern "C" int spx_bam_bind_reference(spx_bam_reader *h, const spx_ref *ref)
-{
-    if (!h || !ref) return SPX_EINVAL;
-    Reader *r = &h->r;
-    int missing = 0;
-    for (size_t i = 0; i < r->tname.size(); ++i) {
-        r->tmap[i] = -1;
-        for (int32_t c = 0; c < ref->n_contigs; ++c)
-            if (r->tname[i] == ref->names + ref->name_off[c]) { r->tmap[i] = c; break; }
-        if (r->tmap[i] < 0) ++missing;
-    }
-    return missing;
-}
-
-/* fill one slot with up to max_groups complete name groups */
-static double io_now()
-{
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec + 1e-9 * ts.tv_nsec;
-}
-
-/* f(k0, k1) over [0, n) on up to `threads` threads */
-template <class F>
-static void io_parallel(int64_t n, int threads, F f)
-{
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(threads, 16), n / 2048));
-    if (T <= 1) { f((int64_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back([&, t] { f(n * t / T, n * (t + 1) / T); });
-    for (auto &x : th) x.join();
-}
-
-static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
+/* fill B with up to max_groups complete name groups */
+void fill_batch(Reader *r, Batch &B, int32_t max_groups)
 {
     const double t_fill0 = io_now();
-    S.clear();
-    S.ubuf.swap(r->leftover);
-    r->leftover.clear();
-    RawBuf &u = S.ubuf;
-    u.reserve(r->last_batch_bytes + r->last_batch_bytes / 8 + (320u << 20)); /* one allocation per batch, not a doubling chain */
-    size_t at = 0;
+    r->t_wait_inflate = r->t_wait_slot = 0;
+    const uint8_t *base = r->arena.aligned;
     bool open_group = false;
     /* Pass 1, serial (every record says where the next one starts, and the batch ends on a name change): record
      * offsets, field-length validation, group boundaries.  One cache line per record.  The fields themselves, the tag
-     * search (a walk over the aux bytes of every record) and the copies are pass 2, on threads. */
-    std::vector<int64_t> rec_at;     /* offset of the record body (behind block_size) */
-    std::vector<uint8_t> rec_new;    /* the record opens a group */
+     * search (a walk over the aux bytes of every record) and the copies are pass 2, on the pool. */
     for (;;) {
-        if (!need(r, u, at, 4)) break;
-        const int32_t bs = le32(u.data() + at);
-        if (bs < 32) { g_io_err = "corrupt BAM record"; S.rc = SPX_EINVAL; break; }
-        if (!need(r, u, at, (size_t)bs + 4)) { g_io_err = "truncated BAM record"; S.rc = SPX_EINVAL; break; }
-        const uint8_t *p = u.data() + at + 4;
+        if (r->cur && r->cur->stop_at != (size_t)-1 && r->at >= r->cur->data + r->cur->stop_at) { r->stream_eof = true; break; }
+        if (!ensure(r, 4)) {
+            if (!r->werr.empty()) { B.err = r->werr; B.rc = SPX_EINVAL; }
+            else if (r->cur && r->end > r->at) { B.err = "truncated BAM record"; B.rc = SPX_EINVAL; }
+            break;
+        }
+        const int32_t bs = le32(r->at);
+        if (bs < 32) { B.err = "corrupt BAM record"; B.rc = SPX_EINVAL; break; }
+        int64_t voff = -1;
+        if (r->want_voff) voff = voffset_of(r, r->gpos); /* before the record may move into the next slot */
+        if (!ensure(r, (size_t)bs + 4)) {
+            B.err = r->werr.empty() ? "truncated BAM record" : r->werr;
+            B.rc = SPX_EINVAL;
+            break;
+        }
+        const uint8_t *p = r->at + 4;
         const uint32_t l_name = p[8];
         const uint32_t ncig = p[12] | (p[13] << 8);
         const int32_t lseq = le32(p + 16);
@@ -471,36 +626,40 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
          * name must be NUL-terminated inside it (strlen / the CIGAR copy below would walk off the buffer otherwise) */
         if (lseq < 0 || l_name < 1 || 32 + (uint64_t)l_name + 4 * (uint64_t)ncig + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs ||
             name[l_name - 1] != 0) {
-            g_io_err = "corrupt BAM record (field lengths exceed the record)";
-            S.rc = SPX_EINVAL;
+            B.err = "corrupt BAM record (field lengths exceed the record)";
+            B.rc = SPX_EINVAL;
             break;
         }
         /* group boundary on a name change (src/secphase.c:273-279) */
-        const bool same = r->have_last && r->last_name == name;
+        const bool same = r->have_last && r->last_name.size() + 1 == l_name && memcmp(r->last_name.data(), name, l_name - 1) == 0;
         bool opens = false;
         if (!same || !open_group) {
-            if (open_group && S.ng == max_groups) break; /* this record opens the next batch */
-            r->last_name = name;
+            if (open_group && B.ng == max_groups) break; /* this record opens the next batch */
+            r->last_name.assign(name, l_name - 1);
             r->have_last = true;
             open_group = true;
             opens = true;
-            ++S.ng;
+            ++B.ng;
+            if (r->want_voff) B.grp_voff.push_back(voff);
         }
-        rec_at.push_back((int64_t)(at + 4));
-        rec_new.push_back(opens ? 1 : 0);
-        at += (size_t)bs + 4;
+        batch_add_chunk(r, B, r->cur);
+        B.rec_off.push_back((int64_t)(p - base));
+        B.rec_new.push_back(opens ? 1 : 0);
+        r->at += (size_t)bs + 4;
+        r->gpos += (int64_t)bs + 4;
         r->n_records++;
     }
+    if (r->want_voff) B.end_voff = (r->cur && r->at < r->end) ? voffset_of(r, r->gpos) : (int64_t)((uint64_t)std::min(r->fpos, r->fsize) << 16);
     const double t_p1 = io_now();
-    const int64_t nrec = (int64_t)rec_at.size();
-    S.flag.resize((size_t)nrec); S.tid.resize((size_t)nrec); S.pos.resize((size_t)nrec); S.l_qseq.resize((size_t)nrec);
-    S.n_cigar.resize((size_t)nrec); S.cigar_off.resize((size_t)nrec); S.seq_off.resize((size_t)nrec); S.qual_off.resize((size_t)nrec);
-    S.rec_off.resize((size_t)nrec); S.cs_off.resize((size_t)nrec); S.md_off.resize((size_t)nrec);
-    std::vector<int64_t> cg_at((size_t)nrec, -1); /* CG:B,I payload when the real CIGAR lives in the tag */
-    const uint8_t *base = u.data();
-    io_parallel(nrec, r->threads, [&](int64_t k0, int64_t k1) {
+    const int64_t nrec = (int64_t)B.rec_off.size();
+    const size_t n = (size_t)nrec;
+    B.flag.resize(n); B.refid.resize(n); B.tid.resize(n); B.pos.resize(n); B.l_qseq.resize(n);
+    B.n_cigar.resize(n); B.cigar_off.resize(n); B.seq_off.resize(n); B.qual_off.resize(n);
+    B.cs_off.resize(n); B.md_off.resize(n);
+    std::vector<int64_t> cg_at(n, -1); /* CG:B,I payload when the real CIGAR lives in the tag */
+    r->pool->parallel_for(nrec, 1024, [&](int64_t k0, int64_t k1) {
         for (int64_t k = k0; k < k1; ++k) {
-            const uint8_t *p = base + rec_at[(size_t)k];
+            const uint8_t *p = base + B.rec_off[(size_t)k];
             const int32_t bs = le32(p - 4);
             const int32_t refid = le32(p), posv = le32(p + 4);
             const uint32_t l_name = p[8];
@@ -508,10 +667,10 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
             const int32_t lseq = le32(p + 16);
             const uint8_t *cig = p + 32 + l_name, *sq = cig + 4 * (size_t)ncig, *ql = sq + ((size_t)lseq + 1) / 2, *aux = ql + lseq,
                           *end = p + bs;
-            S.flag[(size_t)k] = (uint16_t)flg;
-            S.tid[(size_t)k] = (refid >= 0 && (size_t)refid < r->tmap.size()) ? r->tmap[refid] : -1;
-            S.pos[(size_t)k] = posv;
-            S.l_qseq[(size_t)k] = lseq;
+            B.flag[(size_t)k] = (uint16_t)flg;
+            B.refid[(size_t)k] = refid;
+            B.pos[(size_t)k] = posv;
+            B.l_qseq[(size_t)k] = lseq;
             /* more than 65535 CIGAR operations: the record carries the placeholder <l_seq>S<ref_len>N and the real CIGAR
              * in the CG:B,I tag; sam_read1 puts it back before secphase sees the record, so do we */
             uint32_t cg_n = 0;
@@ -523,106 +682,469 @@ static void fill_slot(Reader *r, Slot &S, int32_t max_groups)
                     if (cg_n > 0 && b + 5 + 4 * (size_t)cg_n <= end) cg_at[(size_t)k] = (int64_t)(b + 5 - base); else cg_n = 0;
                 }
             }
-            S.n_cigar[(size_t)k] = (int32_t)(cg_at[(size_t)k] >= 0 ? cg_n : ncig);
-            S.seq_off[(size_t)k] = (int64_t)(sq - base);
-            S.qual_off[(size_t)k] = (int64_t)(ql - base);
-            S.rec_off[(size_t)k] = (int64_t)(p - base);
+            B.n_cigar[(size_t)k] = (int32_t)(cg_at[(size_t)k] >= 0 ? cg_n : ncig);
+            B.seq_off[(size_t)k] = (int64_t)(sq - base);
+            B.qual_off[(size_t)k] = (int64_t)(ql - base);
             const char *csz = aux <= end ? find_tag(aux, end, 'c', 's') : nullptr;
-            S.cs_off[(size_t)k] = csz ? (int64_t)((const uint8_t *)csz - base) : -1;
+            B.cs_off[(size_t)k] = csz ? (int64_t)((const uint8_t *)csz - base) : -1;
             const char *mdz = (!csz && aux <= end) ? find_tag(aux, end, 'M', 'D') : nullptr; /* only looked at without cs */
-            S.md_off[(size_t)k] = mdz ? (int64_t)((const uint8_t *)mdz - base) : -1;
+            B.md_off[(size_t)k] = mdz ? (int64_t)((const uint8_t *)mdz - base) : -1;
         }
     });
     const double t_p2 = io_now();
     /* offsets of the copied parts (CIGAR words, group names), then the copies */
     int64_t cw = 0, nb = 0;
     std::vector<int64_t> grp_rec; /* first record of every group */
+    grp_rec.reserve((size_t)B.ng);
+    B.grp_first.reserve((size_t)B.ng + 1);
+    B.qname_off.reserve((size_t)B.ng);
     for (int64_t k = 0; k < nrec; ++k) {
-        S.cigar_off[(size_t)k] = cw;
-        cw += S.n_cigar[(size_t)k];
-        if (rec_new[(size_t)k]) {
-            S.grp_first.push_back((int32_t)k);
-            S.qname_off.push_back(nb);
+        B.cigar_off[(size_t)k] = cw;
+        cw += B.n_cigar[(size_t)k];
+        if (B.rec_new[(size_t)k]) {
+            B.grp_first.push_back((int32_t)k);
+            B.qname_off.push_back(nb);
             grp_rec.push_back(k);
-            nb += (int64_t)(base + rec_at[(size_t)k])[8]; /* l_read_name counts the NUL */
+            nb += (int64_t)(base + B.rec_off[(size_t)k])[8]; /* l_read_name counts the NUL */
         }
     }
-    S.cigar.resize((size_t)cw);
-    S.qnames.resize((size_t)nb);
-    io_parallel(nrec, r->threads, [&](int64_t k0, int64_t k1) {
+    B.cigar.resize((size_t)cw + 1);
+    B.qnames.resize((size_t)nb + 1);
+    r->pool->parallel_for(nrec, 2048, [&](int64_t k0, int64_t k1) {
         for (int64_t k = k0; k < k1; ++k) {
-            const uint8_t *p = base + rec_at[(size_t)k];
+            const uint8_t *p = base + B.rec_off[(size_t)k];
             const uint8_t *src = cg_at[(size_t)k] >= 0 ? base + cg_at[(size_t)k] : p + 32 + p[8];
-            uint32_t *dst = S.cigar.data() + S.cigar_off[(size_t)k];
-            for (int32_t c = 0; c < S.n_cigar[(size_t)k]; ++c) dst[c] = (uint32_t)le32(src + 4 * (size_t)c);
+            uint32_t *dst = B.cigar.data() + B.cigar_off[(size_t)k];
+            for (int32_t c = 0; c < B.n_cigar[(size_t)k]; ++c) dst[c] = (uint32_t)le32(src + 4 * (size_t)c);
         }
     });
-    io_parallel((int64_t)grp_rec.size(), r->threads, [&](int64_t g0, int64_t g1) {
+    r->pool->parallel_for((int64_t)grp_rec.size(), 4096, [&](int64_t g0, int64_t g1) {
         for (int64_t g = g0; g < g1; ++g) {
-            const uint8_t *p = base + rec_at[(size_t)grp_rec[(size_t)g]];
-            memcpy(S.qnames.data() + S.qname_off[(size_t)g], p + 32, (size_t)p[8]);
+            const uint8_t *p = base + B.rec_off[(size_t)grp_rec[(size_t)g]];
+            memcpy(B.qnames.data() + B.qname_off[(size_t)g], p + 32, (size_t)p[8]);
         }
     });
     const double t_p3 = io_now();
-    /* bytes of the records that belong to the next batch */
-    r->leftover.assign(u.data() + at, u.data() + u.size());
-    r->last_batch_bytes = at;
-    S.grp_first.push_back((int32_t)S.flag.size());
-    S.qnames.push_back(0);
-    S.cigar.push_back(0);
-    u.resize(at + 8); /* keep the consumed part (+ slack), drop the tail that was copied out */
-    memset(u.data() + at, 0, 8);
-    spx_batch &b = S.view;
-    b.n_groups = S.ng;
-    b.n_alns = (int32_t)S.flag.size();
-    b.grp_first = S.grp_first.data(); b.qname_off = S.qname_off.data(); b.qnames = S.qnames.data();
-    b.flag = S.flag.data(); b.tid = S.tid.data(); b.pos = S.pos.data(); b.l_qseq = S.l_qseq.data();
-    b.n_cigar = S.n_cigar.data(); b.cigar_off = S.cigar_off.data(); b.seq_off = S.seq_off.data();
-    b.qual_off = S.qual_off.data(); b.cs_off = S.cs_off.data(); b.cigar = S.cigar.data();
-    b.seq4 = u.data(); b.qual = u.data(); b.cs = (const char *)u.data();
-    b.md_off = S.md_off.data(); b.md = (const char *)u.data();
-    r->n_groups_total += S.ng;
-    if (getenv("SPX_TIMING"))
-        fprintf(stderr, "[spx timing] BAM batch: %d groups, %.1f MB inflated, %.3f s (record chain incl. read+inflate %.3f [read+inflate %.3f], "
-                        "fields+tags %.3f, CIGAR+names %.3f, tail %.3f)\n", S.ng, u.size() / 1e6, io_now() - t_fill0, t_p1 - t_fill0, r->t_inflate,
-                t_p2 - t_p1, t_p3 - t_p2, io_now() - t_p3);
-    r->t_inflate = 0;
+    B.grp_first.push_back((int32_t)n);
+    B.qnames[(size_t)nb] = 0;
+    B.cigar[(size_t)cw] = 0;
+    spx_batch &b = B.view;
+    memset(&b, 0, sizeof b);
+    b.n_groups = B.ng;
+    b.n_alns = (int32_t)n;
+    b.grp_first = B.grp_first.data(); b.qname_off = B.qname_off.data(); b.qnames = B.qnames.data();
+    b.flag = B.flag.data(); b.tid = B.tid.data(); b.pos = B.pos.data(); b.l_qseq = B.l_qseq.data();
+    b.n_cigar = B.n_cigar.data(); b.cigar_off = B.cigar_off.data(); b.seq_off = B.seq_off.data();
+    b.qual_off = B.qual_off.data(); b.cs_off = B.cs_off.data(); b.cigar = B.cigar.data();
+    b.seq4 = base; b.qual = base; b.cs = (const char *)base;
+    b.md_off = B.md_off.data(); b.md = (const char *)base;
+    r->n_groups_total += B.ng;
+    if (io_timing())
+        fprintf(stderr, "[spx timing] BAM batch: %d groups, %lld records, %.3f s (record chain %.3f [waiting for inflate %.3f, for a slot %.3f], "
+                        "fields+tags %.3f, CIGAR+names %.3f)\n", B.ng, (long long)nrec, io_now() - t_fill0, t_p1 - t_fill0, r->t_wait_inflate,
+                r->t_wait_slot, t_p2 - t_p1, t_p3 - t_p2);
 }
 
-/* up to max_groups complete name groups; the batch stays valid until the next call.  The following batch is
- * read and inflated in the background while the caller works on this one.  Returns the number of groups
- * (0 at end of file) or SPX_E*. */
+void batch_release_locked(Reader *r, Batch *B)
+{
+    if (B->released) return;
+    B->released = true;
+    for (Chunk *c : B->chunks) chunk_unref_locked(r, c);
+    B->chunks.clear();
+}
+
+void walker_main(Reader *r)
+{
+    for (;;) {
+        int32_t mg = 0;
+        {
+            std::unique_lock<std::mutex> lk(r->mu);
+            r->cv_out.wait(lk, [&] { return r->closing || (r->batch_groups.load() > 0 && (int)r->outq.size() < r->ahead); });
+            if (r->closing) return;
+            mg = r->batch_groups.load();
+        }
+        Batch *B = new Batch();
+        fill_batch(r, *B, mg);
+        const bool fin = B->ng == 0 || B->rc < 0;
+        {
+            std::lock_guard<std::mutex> lk(r->mu);
+            r->outq.push_back(B);
+        }
+        r->cv_out.notify_all();
+        r->cv_room.notify_all();
+        if (fin) { /* the sentinel stays at the end of the queue; the walker gives its slots back and rests */
+            std::unique_lock<std::mutex> lk(r->mu);
+            if (r->cur) { chunk_unref_locked(r, r->cur); r->cur = nullptr; }
+            while (!r->inflight.empty()) { /* dispatched but not walked (error / closing): wait for the tasks, then drop */
+                Chunk *c = r->inflight.front();
+                r->cv_chunk.wait(lk, [&] { return c->pending.load() == 0; });
+                r->inflight.pop_front();
+                chunk_unref_locked(r, c);
+            }
+            return;
+        }
+    }
+}
+
+/* serial inflate of the blocks at the start of the file until `need` bytes are there (header parsing) */
+bool header_bytes(Reader *r, std::vector<uint8_t> &buf, std::vector<size_t> &blk_coff, std::vector<size_t> &blk_uoff, size_t &fpos, size_t need)
+{
+    Inflater inf;
+    while (buf.size() < need) {
+        if (fpos >= r->fsize) return false;
+        size_t total = 0, hl = 0;
+        std::string err;
+        if (!parse_block_header(r->map + fpos, r->fsize - fpos, &total, &hl, err)) { g_io_err = err; return false; }
+        const uint32_t isize = (uint32_t)le32(r->map + fpos + total - 4);
+        if (isize > 65536) { g_io_err = "corrupt BGZF block (ISIZE)"; return false; }
+        blk_coff.push_back(fpos);
+        blk_uoff.push_back(buf.size());
+        const size_t o = buf.size();
+        buf.resize(o + isize);
+        if (isize && !inf.run(r->map + fpos + hl, total - hl - 8, buf.data() + o, isize)) { g_io_err = "inflate failed"; return false; }
+        fpos += total;
+    }
+    return true;
+}
+
+} // namespace
+
+struct spx_bam_reader { Reader r; };
+struct spx_fasta {
+    std::vector<int64_t> name_off, seq_off;
+    std::vector<char> names, bases;
+    spx_ref ref;
+};
+
+extern "C" const char *spx_io_last_error(void) { return g_io_err.c_str(); }
+
+extern "C" void spx_bam_default_options(spx_bam_options *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->threads = 4;
+    o->ahead_batches = 2;
+    o->start_voffset = -1;
+    o->end_voffset = -1;
+}
+
+extern "C" int spx_bam_open_opts(const char *path, const spx_bam_options *opt, spx_bam_reader **out)
+{
+    if (!path || !out) return SPX_EINVAL;
+    *out = nullptr;
+    spx_bam_options o;
+    if (opt) o = *opt; else spx_bam_default_options(&o);
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { g_io_err = std::string("cannot open ") + path; return SPX_EINVAL; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); g_io_err = std::string("cannot stat ") + path; return SPX_EINVAL; }
+    std::unique_ptr<spx_bam_reader> h(new spx_bam_reader());
+    Reader *r = &h->r;
+    r->fd = fd;
+    auto bail = [&](const char *msg) {
+        g_io_err = msg;
+        if (r->map && !r->map_is_malloc) munmap((void *)r->map, r->fsize);
+        if (r->map && r->map_is_malloc) free((void *)r->map);
+        close(fd);
+        return SPX_EINVAL;
+    };
+    if (S_ISREG(st.st_mode) && st.st_size > 0) {
+        r->fsize = (size_t)st.st_size;
+        void *m = mmap(nullptr, r->fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            r->map = (const uint8_t *)m;
+            (void)madvise(m, r->fsize, MADV_SEQUENTIAL);
+        }
+    }
+    if (!r->map) { /* a pipe, or a file system without mmap: the whole input in memory */
+        size_t cap = (size_t)64 << 20, n = 0;
+        uint8_t *buf = (uint8_t *)malloc(cap);
+        if (!buf) return bail("out of memory");
+        for (;;) {
+            if (n == cap) {
+                cap *= 2;
+                uint8_t *q = (uint8_t *)realloc(buf, cap);
+                if (!q) { free(buf); return bail("out of memory"); }
+                buf = q;
+            }
+            const ssize_t got = read(fd, buf + n, cap - n);
+            if (got < 0 && errno == EINTR) continue;
+            if (got < 0) { free(buf); return bail("read error"); }
+            if (got == 0) break;
+            n += (size_t)got;
+        }
+        r->map = buf;
+        r->fsize = n;
+        r->map_is_malloc = true;
+    }
+    /* ---- header: serial, from the start of the file ---- */
+    std::vector<uint8_t> hb;
+    std::vector<size_t> hcoff, huoff;
+    size_t hpos = 0;
+    if (!header_bytes(r, hb, hcoff, huoff, hpos, 12) || memcmp(hb.data(), "BAM\1", 4) != 0) return bail("not a BAM file");
+    const int32_t l_text = le32(hb.data() + 4);
+    size_t at = 8;
+    if (l_text < 0 || !header_bytes(r, hb, hcoff, huoff, hpos, at + (size_t)l_text + 4)) return bail("truncated BAM header");
+    r->header_text.assign((const char *)hb.data() + at, strnlen((const char *)hb.data() + at, (size_t)l_text));
+    at += (size_t)l_text;
+    const int32_t n_ref = le32(hb.data() + at);
+    at += 4;
+    if (n_ref < 0) return bail("corrupt BAM header");
+    for (int32_t i = 0; i < n_ref; ++i) {
+        if (!header_bytes(r, hb, hcoff, huoff, hpos, at + 4)) return bail("truncated BAM header");
+        const int32_t ln = le32(hb.data() + at);
+        at += 4;
+        if (ln < 1 || !header_bytes(r, hb, hcoff, huoff, hpos, at + (size_t)ln + 4)) return bail("truncated BAM header");
+        r->tname.emplace_back((const char *)hb.data() + at, strnlen((const char *)hb.data() + at, (size_t)ln));
+        at += (size_t)ln;
+        r->tlen.push_back(le32(hb.data() + at));
+        at += 4;
+    }
+    r->tmap.assign((size_t)n_ref, -1);
+    for (int32_t i = 0; i < n_ref; ++i) r->tmap[(size_t)i] = i;
+    /* where the records start: inside the block holding header byte `at` (or at the next block) */
+    size_t start_coff = hpos;
+    uint32_t start_uoff = 0;
+    for (size_t k = 0; k < hcoff.size(); ++k)
+        if (huoff[k] <= at && (k + 1 == hcoff.size() ? at < hb.size() : at < huoff[k + 1])) { start_coff = hcoff[k]; start_uoff = (uint32_t)(at - huoff[k]); }
+    if (o.start_voffset >= 0) { start_coff = (size_t)((uint64_t)o.start_voffset >> 16); start_uoff = (uint32_t)(o.start_voffset & 0xffff); }
+    if (o.end_voffset >= 0) { r->end_coff = (size_t)((uint64_t)o.end_voffset >> 16); r->end_uoff = (uint32_t)(o.end_voffset & 0xffff); }
+    if (start_coff > r->fsize) return bail("start offset beyond the end of the file");
+    hb.clear(); hb.shrink_to_fit();
+    /* ---- configuration ---- */
+    r->threads = o.threads > 0 ? o.threads : 4;
+    r->ahead = o.ahead_batches > 0 ? o.ahead_batches : 2;
+    r->keep = o.keep_batches > 0 ? o.keep_batches : SPX_BAM_KEEP;
+    r->want_voff = (o.flags & SPX_BAM_WANT_VOFFSETS) != 0;
+    r->check_crc = !(o.flags & SPX_BAM_NO_CRC) && !getenv("SPX_BAM_NOCRC");
+    size_t target = o.chunk_bytes > 0 ? (size_t)o.chunk_bytes : ((size_t)32 << 20);
+    if (const char *e = getenv("SPX_BAM_CHUNK_KB")) target = (size_t)atoll(e) << 10;
+    target = std::max<size_t>(target, (size_t)64 << 10);
+    r->chunk_target = target;
+    r->head = target + ((size_t)64 << 10);
+    const size_t al = (size_t)2 << 20;
+    const size_t slot = (2 * r->head + al - 1) & ~(al - 1);
+    r->max_inflight = std::max(3, r->threads / 8 + 2);
+    const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+    const size_t phys = (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz : ((size_t)64 << 30);
+    size_t cap_bytes = o.max_bytes > 0 ? (size_t)o.max_bytes : phys / 4;
+    if (const char *e = getenv("SPX_BAM_ARENA_GB")) cap_bytes = (size_t)atoll(e) << 30;
+    r->soft_cap_slots = std::max<size_t>(cap_bytes / slot, (size_t)r->max_inflight + 4);
+    /* the reservation is virtual (MAP_NORESERVE, touched slot by slot): room for the soft cap twice over */
+    const size_t want = std::max(std::min<size_t>((size_t)4 << 40, 2 * (r->soft_cap_slots + 8) * slot), 8 * slot);
+    if (!r->arena.init(slot, want)) return bail("cannot reserve the inflate arena");
+    r->pool.reset(new Pool(r->threads));
+    r->fpos = start_coff;
+    /* the walker starts start_uoff bytes into its first chunk */
+    r->batch_groups = o.batch_groups > 0 ? o.batch_groups : 0;
+    if (start_uoff) {
+        /* position the cursor: take the first chunk synchronously */
+        if (!advance_chunk(r)) {
+            const std::string e = r->werr.empty() ? "start offset beyond the end of the file" : r->werr;
+            r->pool.reset();
+            return bail(e.c_str());
+        }
+        if ((size_t)start_uoff > r->cur->len) { r->pool.reset(); return bail("start offset beyond its block"); }
+        r->at += start_uoff;
+        r->gpos = start_uoff;
+    }
+    r->walker = std::thread(walker_main, r);
+    *out = h.release();
+    return SPX_OK;
+}
+
+extern "C" int spx_bam_open(const char *path, int threads, spx_bam_reader **out)
+{
+    spx_bam_options o;
+    spx_bam_default_options(&o);
+    o.threads = threads > 0 ? threads : 4;
+    return spx_bam_open_opts(path, &o, out);
+}
+
+extern "C" int32_t spx_bam_n_targets(const spx_bam_reader *h) { return h ? (int32_t)h->r.tname.size() : 0; }
+extern "C" const char *spx_bam_target_name(const spx_bam_reader *h, int32_t i)
+{
+    return (h && i >= 0 && (size_t)i < h->r.tname.size()) ? h->r.tname[i].c_str() : nullptr;
+}
+
+/* BAM target ids -> contig indices of `ref` (by name); alignments on contigs the FASTA lacks get tid -1
+ * and their group is rejected by the scorer with SPX_EINVAL.  Applies to the batches handed out from now on (the
+ * reader may already be inflating and cutting batches in the background: target ids are mapped at hand-out). */
+extern "C" int spx_bam_bind_reference(spx_bam_reader *h, const spx_ref *ref)
+{
+    if (!h || !ref) return SPX_EINVAL;
+    Reader *r = &h->r;
+    std::vector<int32_t> tm(r->tname.size(), -1);
+    int missing = 0;
+    if (r->tname.size() > 64) { /* many targets: by sorted names instead of the quadratic scan */
+        std::vector<std::pair<std::string, int32_t>> byname;
+        byname.reserve((size_t)ref->n_contigs);
+        for (int32_t c = ref->n_contigs - 1; c >= 0; --c) byname.emplace_back(ref->names + ref->name_off[c], c);
+        std::stable_sort(byname.begin(), byname.end(), [](const std::pair<std::string, int32_t> &a, const std::pair<std::string, int32_t> &b) { return a.first < b.first; });
+        for (size_t i = 0; i < r->tname.size(); ++i) {
+            auto it = std::lower_bound(byname.begin(), byname.end(), r->tname[i],
+                                       [](const std::pair<std::string, int32_t> &a, const std::string &k) { return a.first < k; });
+            /* the FIRST contig of that name, like the linear scan */
+            int32_t best = -1;
+            for (; it != byname.end() && it->first == r->tname[i]; ++it) best = best < 0 ? it->second : std::min(best, it->second);
+            tm[i] = best;
+            if (best < 0) ++missing;
+        }
+    } else
+        for (size_t i = 0; i < r->tname.size(); ++i) {
+            for (int32_t c = 0; c < ref->n_contigs; ++c)
+                if (r->tname[i] == ref->names + ref->name_off[c]) { tm[i] = c; break; }
+            if (tm[i] < 0) ++missing;
+        }
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->tmap.swap(tm);
+    return missing;
+}
+
+/* up to max_groups complete name groups; the batch stays valid for the next SPX_BAM_KEEP calls (or until
+ * spx_bam_release_batch).  Following batches are inflated and cut in the background.  Returns the number of groups
+ * (0 at end of file) or SPX_E*.  The batch size of a reader is fixed by its first call (or its options): batches that
+ * were cut ahead keep the size they were cut with. */
 extern "C" int spx_bam_next_batch(spx_bam_reader *h, int32_t max_groups, const spx_batch **out)
 {
     if (!h || !out || max_groups <= 0) return SPX_EINVAL;
     Reader *r = &h->r;
-    if (r->have_pending && r->pending_max == max_groups) {
-        r->pending.get();
-        r->cur = (r->cur + 1) % Reader::NSLOT; /* the slot the background task filled */
-    } else {
-        if (r->have_pending) r->pending.get(); /* different batch size requested: cannot happen in the CLI */
-        fill_slot(r, r->slot[r->cur], max_groups);
+    Batch *B = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(r->mu);
+        if (r->batch_groups.load() != max_groups) r->batch_groups = max_groups;
+        r->consumer_waiting = true;
+        r->cv_out.notify_all();
+        r->cv_room.notify_all();
+        r->cv_out.wait(lk, [&] { return !r->outq.empty(); });
+        r->consumer_waiting = false;
+        B = r->outq.front();
+        if (B->ng == 0 || B->rc < 0) { /* end of the stream: the sentinel stays */
+            *out = &B->view;
+            if (B->rc < 0) { g_io_err = B->err; return B->rc; }
+            return 0;
+        }
+        r->outq.pop_front();
+        for (size_t k = 0; k < B->refid.size(); ++k) {
+            const int32_t t = B->refid[k];
+            B->tid[k] = (t >= 0 && (size_t)t < r->tmap.size()) ? r->tmap[(size_t)t] : -1;
+        }
+        r->handed.push_back(B);
+        while ((int)r->handed.size() > r->keep + 1) {
+            Batch *old = r->handed.front();
+            r->handed.pop_front();
+            batch_release_locked(r, old);
+            delete old;
+        }
     }
-    r->have_pending = false;
-    Slot &S = r->slot[r->cur];
-    *out = &S.view;
-    if (S.rc < 0) return S.rc;
-    if (S.ng > 0) {
-        Slot *nxt = &r->slot[(r->cur + 1) % Reader::NSLOT];
-        r->pending_max = max_groups;
-        r->pending = std::async(std::launch::async, [r, nxt, max_groups]() { fill_slot(r, *nxt, max_groups); });
-        r->have_pending = true;
-    }
-    return S.ng;
+    r->cv_out.notify_all();
+    *out = &B->view;
+    return B->ng;
+}
+
+/* the caller is done with a batch it was handed: its share of the inflate arena is recycled now instead of
+ * SPX_BAM_KEEP calls later (the spx_batch itself must not be used afterwards) */
+extern "C" int spx_bam_release_batch(spx_bam_reader *h, const spx_batch *bt)
+{
+    if (!h || !bt) return SPX_EINVAL;
+    Reader *r = &h->r;
+    std::lock_guard<std::mutex> lk(r->mu);
+    for (Batch *B : r->handed)
+        if (&B->view == bt) { batch_release_locked(r, B); return SPX_OK; }
+    return SPX_EINVAL;
 }
 
 extern "C" void spx_bam_close(spx_bam_reader *h)
 {
     if (!h) return;
-    if (h->r.have_pending) h->r.pending.get();
-    if (h->r.have_ahead) h->r.ahead.get();
-    if (h->r.fp) fclose(h->r.fp);
+    Reader *r = &h->r;
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->closing = true;
+    }
+    r->cv_out.notify_all();
+    r->cv_room.notify_all();
+    r->cv_chunk.notify_all();
+    if (r->walker.joinable()) r->walker.join();
+    r->pool.reset(); /* joins the workers: no inflate task is running after this */
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        for (Batch *B : r->outq) { batch_release_locked(r, B); delete B; }
+        r->outq.clear();
+        for (Batch *B : r->handed) { batch_release_locked(r, B); delete B; }
+        r->handed.clear();
+        if (r->cur) { chunk_unref_locked(r, r->cur); r->cur = nullptr; }
+        for (Chunk *c : r->inflight) chunk_unref_locked(r, c);
+        r->inflight.clear();
+    }
+    if (r->map && !r->map_is_malloc) munmap((void *)r->map, r->fsize);
+    if (r->map && r->map_is_malloc) free((void *)r->map);
+    if (r->fd >= 0) close(r->fd);
     delete h;
+}
+
+/* ---- index of group starts in the reference's on-disk format (src/secphase_index.c:76-119: int64 count, then that
+ * many int64 BGZF virtual offsets; consumer get_offset_array, src/secphase.c:357-385): the virtual offset of the first
+ * record of every step-th read group, and the offset where the records end.  A reader opened with
+ * start_voffset = a[i], end_voffset = a[j] yields exactly the groups [i*step, j*step). ---- */
+extern "C" int64_t spx_bam_index_build(const char *path, int threads, int32_t step_groups, int64_t *offsets, int64_t capacity)
+{
+    if (!path || step_groups < 1) return SPX_EINVAL;
+    spx_bam_options o;
+    spx_bam_default_options(&o);
+    o.threads = threads;
+    o.flags = SPX_BAM_WANT_VOFFSETS;
+    o.batch_groups = 8192;
+    spx_bam_reader *h = nullptr;
+    int rc = spx_bam_open_opts(path, &o, &h);
+    if (rc != SPX_OK) return rc;
+    int64_t n = 0, g = 0, end = -1;
+    for (;;) {
+        const spx_batch *bt = nullptr;
+        const int ng = spx_bam_next_batch(h, o.batch_groups, &bt);
+        if (ng < 0) { spx_bam_close(h); return ng; }
+        Batch *B = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(h->r.mu);
+            B = ng > 0 ? h->r.handed.back() : h->r.outq.front();
+        }
+        end = B->end_voff;
+        if (ng == 0) break;
+        for (int k = 0; k < ng; ++k, ++g)
+            if (g % step_groups == 0) {
+                if (offsets && n < capacity) offsets[n] = B->grp_voff[(size_t)k];
+                ++n;
+            }
+        spx_bam_release_batch(h, bt);
+    }
+    if (offsets && n < capacity) offsets[n] = end;
+    ++n;
+    spx_bam_close(h);
+    return n;
+}
+
+extern "C" int spx_bam_index_save(const char *index_path, const int64_t *offsets, int64_t n)
+{
+    if (!index_path || !offsets || n < 0) return SPX_EINVAL;
+    FILE *fp = fopen(index_path, "wb");
+    if (!fp) { g_io_err = std::string("cannot create ") + index_path; return SPX_EINVAL; }
+    const bool ok = fwrite(&n, sizeof(int64_t), 1, fp) == 1 && (n == 0 || fwrite(offsets, sizeof(int64_t), (size_t)n, fp) == (size_t)n);
+    return (fclose(fp) == 0 && ok) ? SPX_OK : SPX_EINVAL;
+}
+
+extern "C" int64_t spx_bam_index_load(const char *index_path, int64_t *offsets, int64_t capacity)
+{
+    if (!index_path) return SPX_EINVAL;
+    FILE *fp = fopen(index_path, "rb");
+    if (!fp) { g_io_err = std::string("cannot open ") + index_path; return SPX_EINVAL; }
+    int64_t n = 0;
+    if (fread(&n, sizeof(int64_t), 1, fp) != 1 || n < 0) { fclose(fp); g_io_err = "corrupt index"; return SPX_EINVAL; }
+    if (offsets) {
+        const int64_t m = std::min(n, capacity);
+        if (m > 0 && fread(offsets, sizeof(int64_t), (size_t)m, fp) != (size_t)m) { fclose(fp); g_io_err = "truncated index"; return SPX_EINVAL; }
+    }
+    fclose(fp);
+    return n;
 }
 
 /* ---- -w/--writeBam: the reference opens `<prefix>.quality_modified.out.bam` with sam_open(path, "w")
@@ -756,7 +1278,7 @@ static bool format_sam(const Reader &r, const uint8_t *p, int32_t bs, const uint
 
 /* group g of the reader's CURRENT batch; `qual` is laid out like that batch's qual[] (NULL: the record's own
  * qualities).  Unmapped records are skipped, as the reference never stores them (src/secphase.c:340). */
-static int sam_write_group_of(spx_sam_writer *w, const Reader &r, const Slot &S, int32_t g, const uint8_t *qual)
+static int sam_write_group_of(spx_sam_writer *w, const Reader &r, const Batch &S, int32_t g, const uint8_t *qual)
 {
     if (g < 0 || g >= S.ng) return SPX_EINVAL;
     int n = 0;
@@ -764,7 +1286,7 @@ static int sam_write_group_of(spx_sam_writer *w, const Reader &r, const Slot &S,
         if (S.flag[a] & SPX_FUNMAP) continue;
         if (n > 10) continue;
         ++n;
-        const uint8_t *p = S.ubuf.data() + S.rec_off[a];
+        const uint8_t *p = r.arena.aligned + S.rec_off[a];
         const int32_t bs = le32(p - 4);
         if (!format_sam(r, p, bs, qual ? qual + S.qual_off[a] : nullptr, w->line)) { g_io_err = "corrupt aux block"; return SPX_EINVAL; }
         if (fwrite(w->line.data(), 1, w->line.size(), w->fp) != w->line.size()) { g_io_err = "write failed"; return SPX_EINVAL; }
@@ -775,15 +1297,26 @@ static int sam_write_group_of(spx_sam_writer *w, const Reader &r, const Slot &S,
 extern "C" int spx_sam_write_group(spx_sam_writer *w, const spx_bam_reader *src, int32_t g, const uint8_t *qual)
 {
     if (!w || !src) return SPX_EINVAL;
-    return sam_write_group_of(w, src->r, src->r.slot[src->r.cur], g, qual);
+    const Batch *B = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<Reader &>(src->r).mu);
+        if (!src->r.handed.empty()) B = src->r.handed.back();
+    }
+    if (!B || B->released) { g_io_err = "no current batch"; return SPX_EINVAL; }
+    return sam_write_group_of(w, src->r, *B, g, qual);
 }
 
 /* the same for a batch handed out earlier and still alive (pipelined callers) */
 extern "C" int spx_sam_write_group_of(spx_sam_writer *w, const spx_bam_reader *src, const spx_batch *bt, int32_t g, const uint8_t *qual)
 {
     if (!w || !src || !bt) return SPX_EINVAL;
-    for (int k = 0; k < Reader::NSLOT; ++k)
-        if (&src->r.slot[k].view == bt) return sam_write_group_of(w, src->r, src->r.slot[k], g, qual);
+    const Batch *B = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<Reader &>(src->r).mu);
+        for (const Batch *b : src->r.handed)
+            if (&b->view == bt && !b->released) B = b;
+    }
+    if (B) return sam_write_group_of(w, src->r, *B, g, qual);
     g_io_err = "batch is no longer held by the reader";
     return SPX_EINVAL;
 }
@@ -797,43 +1330,56 @@ extern "C" int spx_sam_close(spx_sam_writer *w)
 }
 
 /* whole FASTA into RAM (the scorer keeps its own 4-bit copy in HBM; this one feeds spx_set_reference and
- * the contig names of the relabel list) */
+ * the contig names of the relabel list).  The file is mapped and copied line by line (memchr + memcpy); blanks inside
+ * sequence lines -- legal, rare -- send a line through the character filter. */
 extern "C" int spx_fasta_load(const char *path, spx_fasta **out)
 {
     if (!path || !out) return SPX_EINVAL;
     *out = nullptr;
-    FILE *fp = fopen(path, "rb");
-    if (!fp) { g_io_err = std::string("cannot open ") + path; return SPX_EINVAL; }
-    spx_fasta *f = new spx_fasta();
-    std::vector<char> buf(1 << 22);
-    bool in_name = false, name_done = false, bol = true;
-    size_t got;
-    while ((got = fread(buf.data(), 1, buf.size(), fp)) > 0) {
-        for (size_t i = 0; i < got; ++i) {
-            const char c = buf[i];
-            if (in_name) {
-                if (c == '\n') { f->names.push_back(0); in_name = false; bol = true; }
-                else if (!name_done) {
-                    if (c == ' ' || c == '\t' || c == '\r') name_done = true;
-                    else f->names.push_back(c);
-                }
-                continue;
-            }
-            if (c == '\n') { bol = true; continue; }
-            if (bol && c == '>') {
-                f->name_off.push_back((int64_t)f->names.size());
-                f->seq_off.push_back((int64_t)f->bases.size());
-                in_name = true; name_done = false; bol = false;
-                continue;
-            }
-            bol = false;
-            if (c == '\r' || c == ' ' || c == '\t') continue;
-            if (f->seq_off.empty()) continue; /* junk before the first header */
-            f->bases.push_back(c);
-        }
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { g_io_err = std::string("cannot open ") + path; return SPX_EINVAL; }
+    struct stat st;
+    std::vector<char> slurp;
+    const char *buf = nullptr;
+    size_t n = 0;
+    void *m = MAP_FAILED;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) { buf = (const char *)m; n = (size_t)st.st_size; (void)madvise(m, n, MADV_SEQUENTIAL); }
     }
-    fclose(fp);
-    if (in_name) f->names.push_back(0);
+    if (!buf) {
+        char tmp[1 << 16];
+        ssize_t got;
+        while ((got = read(fd, tmp, sizeof tmp)) > 0) slurp.insert(slurp.end(), tmp, tmp + got);
+        buf = slurp.data();
+        n = slurp.size();
+    }
+    spx_fasta *f = new spx_fasta();
+    f->bases.reserve(n + 1);
+    const char *p = buf, *e = buf + n;
+    while (p < e) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        const char *le = nl ? nl : e;
+        if (*p == '>') {
+            f->name_off.push_back((int64_t)f->names.size());
+            f->seq_off.push_back((int64_t)f->bases.size());
+            const char *q = p + 1;
+            while (q < le && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+            f->names.insert(f->names.end(), p + 1, q);
+            f->names.push_back(0);
+        } else if (!f->seq_off.empty() && le > p) { /* (junk before the first header is skipped) */
+            const char *l1 = le;
+            if (l1[-1] == '\r') --l1;
+            const size_t len = (size_t)(l1 - p);
+            if (len && !memchr(p, ' ', len) && !memchr(p, '\t', len) && !memchr(p, '\r', len)) f->bases.insert(f->bases.end(), p, l1);
+            else
+                for (const char *q = p; q < l1; ++q)
+                    if (*q != ' ' && *q != '\t' && *q != '\r') f->bases.push_back(*q);
+        }
+        p = nl ? nl + 1 : e;
+    }
+    if (m != MAP_FAILED) munmap(m, n);
+    close(fd);
     f->seq_off.push_back((int64_t)f->bases.size());
     f->bases.push_back(0);
     f->ref.n_contigs = (int32_t)f->name_off.size();

@@ -20,6 +20,7 @@
 #include "../../include/spx.h"
 
 extern "C" void spx_internal_set_error(const char *msg);
+extern "C" int spx_internal_work_claim(spx_work *w, int claim); /* 1: mark in flight (fails when it already is), 0: clear */
 
 namespace {
 
@@ -29,6 +30,7 @@ struct Job {
     bool own_work = false;
     void *tag = nullptr;
     int32_t n_groups = 0;
+    int64_t ticket = 0; /* submission number: device memory is taken in this order */
     std::vector<spx_group_out> out;
     int rc = 0;
     std::string err;
@@ -47,16 +49,38 @@ struct spx_pipe {
     std::deque<Job *> inflight; /* submission order, delivered from the front */
     bool stop = false;
     std::vector<std::thread> workers;
+    /* Device memory is handed out in SUBMISSION order: a job stages (takes the HBM of its records) only after every
+     * older job has staged, and builds its work list only after every older job holds its list.  Results are delivered
+     * in order and a list is freed by the caller after delivery, so the oldest job in flight can always finish; a
+     * younger job that took memory first could leave it waiting for ever (the lists of 16 384 ONT groups take ~70 GB each).
+     * Staging of job k+1 still overlaps the preparation / kernels of job k. */
+    int64_t next_ticket = 0, stage_turn = 0, prep_turn = 0;
+    std::condition_variable cv_turn;
 };
 
 static void run_job(spx_pipe *p, Job *j)
 {
     int rc = SPX_OK;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_turn.wait(lk, [&] { return p->stage_turn == j->ticket; });
+    }
     if (!j->work) {
         rc = spx_stage(p->ctx, j->batches.data(), (int32_t)j->batches.size(), &p->par, p->stage_threads, &j->work);
         j->own_work = rc == SPX_OK;
     }
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        ++p->stage_turn;
+        p->cv_turn.notify_all();
+        p->cv_turn.wait(lk, [&] { return p->prep_turn == j->ticket; });
+    }
     if (rc == SPX_OK) rc = spx_prepare_staged(p->ctx, j->work);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        ++p->prep_turn;
+    }
+    p->cv_turn.notify_all();
     if (rc == SPX_OK) rc = spx_launch(p->ctx, j->work);
     if (rc == SPX_OK) {
         j->out.resize((size_t)(j->n_groups > 0 ? j->n_groups : 1));
@@ -94,7 +118,7 @@ extern "C" int spx_pipe_create(spx_ctx *ctx, const spx_params *par, int depth, i
     p->par = *par;
     p->depth = depth < 1 ? 1 : (depth > 8 ? 8 : depth);
     int ht = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
-    p->stage_threads = ht / p->depth > 0 ? ht / p->depth : 1;
+    p->stage_threads = ht > 0 ? ht : 1; /* stagings run one after the other (ticket order): each gets all the threads */
     for (int t = 0; t < p->depth; ++t) p->workers.emplace_back(worker_main, p);
     *out = p;
     return SPX_OK;
@@ -107,6 +131,18 @@ extern "C" int spx_pipe_submit(spx_pipe *p, const spx_batch *const *batches, int
     Job *j = new Job();
     j->tag = tag;
     if (staged) {
+        /* the result buffer is sized from the list itself; a list may be in flight once */
+        spx_stats st;
+        if (spx_work_stats(staged, &st) != SPX_OK || st.n_groups != (int64_t)n_groups_staged) {
+            delete j;
+            spx_internal_set_error("n_groups_staged does not match the staged work list");
+            return SPX_EINVAL;
+        }
+        if (spx_internal_work_claim(staged, 1) != SPX_OK) {
+            delete j;
+            spx_internal_set_error("work list is already in flight");
+            return SPX_EINVAL;
+        }
         j->work = staged;
         j->n_groups = n_groups_staged;
     } else {
@@ -121,6 +157,7 @@ extern "C" int spx_pipe_submit(spx_pipe *p, const spx_batch *const *batches, int
     {
         std::unique_lock<std::mutex> lk(p->mu);
         p->cv_room.wait(lk, [&] { return (int)p->inflight.size() < p->depth + 1; }); /* one waiting beside `depth` running */
+        j->ticket = p->next_ticket++;
         p->todo.push_back(j);
         p->inflight.push_back(j);
     }
@@ -155,6 +192,7 @@ extern "C" int spx_pipe_next(spx_pipe *p, spx_group_out *out, int32_t capacity, 
         for (int32_t g = 0; g < j->n_groups; ++g) out[g] = j->out[(size_t)g];
         rc = j->n_groups;
     }
+    if (!j->own_work && j->work) spx_internal_work_claim(j->work, 0);
     if (work) *work = j->work; /* the caller frees it (or keeps its own staged list) */
     else if (j->own_work && j->work) spx_work_free(p->ctx, j->work);
     delete j;
@@ -171,6 +209,7 @@ extern "C" void spx_pipe_destroy(spx_pipe *p)
     p->cv_work.notify_all();
     for (auto &t : p->workers) t.join();
     for (Job *j : p->inflight) {
+        if (!j->own_work && j->work) spx_internal_work_claim(j->work, 0);
         if (j->own_work && j->work) spx_work_free(p->ctx, j->work);
         delete j;
     }

@@ -108,6 +108,7 @@ struct spx_ctx {
     std::mutex arena_mu;
     size_t hbm_bytes = (size_t)256 << 30; /* the device's total memory (hipMemGetInfo at spx_create) */
     std::condition_variable arena_cv; /* signalled when a work list gives device memory back (arena_put) */
+    std::atomic<bool> hbm_tight{false}; /* an allocation has failed once: no more head room on new blocks */
     /* work-list preparation on the device: its own stream (it overlaps the DP kernels of the previous list), pools
      * that only live during a preparation and are shared by all of them (prep_mu serialises preparations) */
     hipStream_t prep_stream = nullptr;
@@ -186,6 +187,7 @@ struct spx_work {
     std::vector<int64_t> launch_ids; /* this work list's launches since its last spx_collect (indices into the ctx event ring) */
     std::vector<uint8_t> posmin_host; /* filled by spx_collect: per first-of-position marker, min quality */
     std::vector<uint8_t> bq_host;     /* filled by spx_apply_quals: BAQ value of every wanted row */
+    std::atomic<int> in_pipe{0};      /* submitted to a pipeline and not yet delivered: no second submission, no release */
 };
 
 extern "C" const char *spx_strerror(int code)
@@ -205,6 +207,14 @@ extern "C" const char *spx_strerror(int code)
 extern "C" const char *spx_last_error(void) { return g_err.c_str(); }
 /* internal: lets the pipeline hand a worker thread's error text to the thread that asks for the results */
 extern "C" void spx_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+
+extern "C" int spx_internal_work_claim(spx_work *w, int claim)
+{
+    if (!w) return SPX_EINVAL;
+    if (!claim) { w->in_pipe = 0; return SPX_OK; }
+    int expect = 0;
+    return w->in_pipe.compare_exchange_strong(expect, 1) ? SPX_OK : SPX_EINVAL;
+}
 
 extern "C" int spx_device_count(void)
 {
@@ -578,9 +588,11 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
             }
         }
         void *p = nullptr;
-        *cap = bytes + bytes / 8 + 4096; /* head room so that the next, slightly larger list fits */
+        /* head room so that the next, slightly larger list fits -- until memory has been tight once */
+        *cap = bytes + (c->hbm_tight.load() ? 0 : bytes / 8) + 4096;
         if (hipMalloc(&p, *cap) == hipSuccess) return p;
         (void)hipGetLastError();
+        c->hbm_tight = true;
         std::unique_lock<std::mutex> lk(c->arena_mu);
         /* give cached blocks (all too small) back to the driver and try once more, without the head room */
         for (auto &a : c->arena_cache) (void)hipFree(a.first);
@@ -989,6 +1001,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
 extern "C" int spx_work_release(spx_ctx *c, spx_work *w)
 {
     if (!c || !w) return fail(SPX_EINVAL, "NULL argument");
+    if (w->in_pipe.load()) return fail(SPX_EINVAL, "work list is in flight in a pipeline");
     if (!w->staged || !w->arena) return SPX_OK;
     HIPCHK(hipSetDevice(c->device));
     if (w->ev_ready) HIPCHK(hipEventSynchronize(w->ev_ready));
@@ -1238,7 +1251,9 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
 static int pull_marker_mirrors(spx_ctx *c, spx_work *w)
 {
     if (!w->staged || w->mirrors_markers) return SPX_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipSetDevice(c->device));
+    if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done)); /* this list's kernels, not whatever follows on the stream */
+    else HIPCHK(hipStreamSynchronize(c->stream));
     spx::HostBatch &hb = w->hb;
     const size_t ng = (size_t)w->n_dgroups, nm = (size_t)w->n_mk_dev;
     hb.grp_index = w->stage.grp_index;

@@ -46,6 +46,10 @@ def lib():
         L.spx_synth_reads_batch.restype = C.POINTER(SpxBatch)
         L.spx_synth_reads_batch.argtypes = [C.c_void_p]
         L.spx_synth_reads_free.argtypes = [C.c_void_p]
+        L.spx_synth_write_bam.restype = C.c_int64
+        L.spx_synth_write_bam.argtypes = [C.c_char_p, C.POINTER(C.POINTER(SpxBatch)), C.c_int32, C.POINTER(SpxRef),
+                                          C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int]
+        L.spx_synth_write_fasta.argtypes = [C.c_char_p, C.POINTER(SpxRef), C.c_int]
         _lib = L
     return _lib
 
@@ -91,3 +95,20 @@ class Reads:
 
     def __del__(self):
         self.close()
+
+
+def write_bam(path, batches, ref, contig_order=None, threads=8, level=6, extra_tags=True):
+    """the record batches (ctypes pointers to spx_batch), in order, as one name-grouped BAM; returns the file size"""
+    arr = (C.POINTER(SpxBatch) * len(batches))(*batches)
+    order = None
+    if contig_order is not None:
+        order = (C.c_int32 * len(contig_order))(*contig_order)
+    n = lib().spx_synth_write_bam(os.fsencode(path), arr, len(batches), ref, order, threads, level, 1 if extra_tags else 0)
+    if n < 0:
+        raise OSError(f"could not write {path}")
+    return n
+
+
+def write_fasta(path, ref, width=80):
+    if lib().spx_synth_write_fasta(os.fsencode(path), ref, width) != 0:
+        raise OSError(f"could not write {path}")

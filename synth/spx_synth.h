@@ -51,6 +51,13 @@ spx_synth_reads *spx_synth_reads_create(const spx_synth_genome *g, const spx_syn
 const spx_batch *spx_synth_reads_batch(const spx_synth_reads *r);
 void spx_synth_reads_free(spx_synth_reads *r);
 
+/* bench/test-side writers (spx_bamwrite.c): the batches, in order, as one name-grouped BAM (htslib block policy,
+ * zlib `level`, compressed on `threads` threads; contig_order: BAM target order as a permutation of the contig
+ * indices or NULL); returns the file size or -1.  FASTA with `width` bases per line. */
+int64_t spx_synth_write_bam(const char *path, const spx_batch *const *batches, int32_t n_batches, const spx_ref *ref,
+                            const int32_t *contig_order, int threads, int level, int extra_tags);
+int spx_synth_write_fasta(const char *path, const spx_ref *ref, int width);
+
 #ifdef __cplusplus
 }
 #endif

@@ -262,3 +262,182 @@ def test_bam_records_with_impossible_lengths_are_rejected(built, tmp_path):
         assert L.spx_bam_next_batch(h, 8, C.byref(bp)) == api.EINVAL, k
         assert b"corrupt" in L.spx_io_last_error()
         L.spx_bam_close(h)
+
+
+# ---------------------------------------------------------------- round 3: chunked reader, shards, index
+class BamOptions(C.Structure):
+    _fields_ = [("threads", C.c_int32), ("batch_groups", C.c_int32), ("ahead_batches", C.c_int32), ("flags", C.c_int32),
+                ("chunk_bytes", C.c_int64), ("max_bytes", C.c_int64), ("start_voffset", C.c_int64), ("end_voffset", C.c_int64),
+                ("keep_batches", C.c_int32), ("reserved", C.c_int32)]
+
+
+def _declare_opts(L):
+    _declare(L)
+    vp = C.c_void_p
+    L.spx_bam_default_options.argtypes = [C.POINTER(BamOptions)]
+    L.spx_bam_default_options.restype = None
+    L.spx_bam_open_opts.argtypes = [C.c_char_p, C.POINTER(BamOptions), C.POINTER(vp)]
+    L.spx_bam_release_batch.argtypes = [vp, C.POINTER(records.SpxBatch)]
+    L.spx_bam_index_build.argtypes = [C.c_char_p, C.c_int, C.c_int32, C.POINTER(C.c_int64), C.c_int64]
+    L.spx_bam_index_build.restype = C.c_int64
+    L.spx_bam_index_save.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int64]
+    L.spx_bam_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int64]
+    L.spx_bam_index_load.restype = C.c_int64
+
+
+def _read_all(L, bam, batch, release=False, **kw):
+    o = BamOptions()
+    L.spx_bam_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    rd = C.c_void_p()
+    assert L.spx_bam_open_opts(bam.encode(), C.byref(o), C.byref(rd)) == 0, L.spx_io_last_error()
+    got, sizes = [], []
+    while True:
+        bp = C.POINTER(records.SpxBatch)()
+        n = L.spx_bam_next_batch(rd, batch, C.byref(bp))
+        assert n >= 0, L.spx_io_last_error()
+        if n == 0:
+            break
+        assert n <= batch
+        sizes.append(n)
+        got += _records(bp)
+        if release:
+            assert L.spx_bam_release_batch(rd, bp) == 0
+    L.spx_bam_close(rd)
+    return got, sizes
+
+
+def test_records_straddling_inflate_chunks(built, tmp_path):
+    """64 KB inflate chunks against 4.5 KB records: hundreds of records start in one chunk and end in the next (their
+    front part is copied into the next slot's head room); both writers' block policies; batches released early, so
+    slots are recycled while later batches still point into their neighbours"""
+    L = api.lib()
+    _declare_opts(L)
+    g = small_genome(synth.HIFI, read_len=3000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.2, softclip_frac=0.3)
+    chunks = [g.reads(i * 100, 100) for i in range(6)]
+    want = []
+    for ch in chunks:
+        want += _records(ch.batch)
+    a, b = str(tmp_path / "c.bam"), str(tmp_path / "py.bam")
+    synth.write_bam(a, [c.batch for c in chunks], g.ref, threads=3)
+    whole = g.reads(0, 600)
+    write_bam(b, whole.batch, g.ref)
+    for path in (a, b):
+        for batch, rel in ((7, False), (64, True), (1000, False)):
+            got, sizes = _read_all(L, path, batch, release=rel, threads=3, chunk_bytes=65536, ahead_batches=3)
+            assert got == want, (path, batch)
+            assert all(s == batch for s in sizes[:-1])
+    # the same through a reader that starts cutting batches at open (the command line does: start-up overlap)
+    got, _ = _read_all(L, a, 50, threads=2, chunk_bytes=65536, batch_groups=50)
+    assert got == want
+
+
+def test_index_round_trip_and_shards(built, tmp_path):
+    """group-start index in the reference's format (int64 count + int64 BGZF virtual offsets, src/secphase_index.c:76-119);
+    readers opened on [a[i], a[j]) return exactly the groups [i*step, j*step), whatever the chunk size"""
+    L = api.lib()
+    _declare_opts(L)
+    g = small_genome(synth.HIFI, read_len=2000, max_secondaries=2, n_paralogs=2)
+    chunks = [g.reads(i * 64, 64) for i in range(5)]
+    want = []
+    for ch in chunks:
+        want += _records(ch.batch)
+    whole = g.reads(0, 320)  # (kept alive: the batch pointer does not own the records)
+    for writer in ("c", "py"):
+        bam = str(tmp_path / f"{writer}.bam")
+        if writer == "c":
+            synth.write_bam(bam, [c.batch for c in chunks], g.ref, threads=2)
+        else:
+            write_bam(bam, whole.batch, g.ref)
+        step = 10
+        n = L.spx_bam_index_build(bam.encode(), 3, step, None, 0)
+        assert n == 320 // step + 1
+        off = (C.c_int64 * n)()
+        assert L.spx_bam_index_build(bam.encode(), 3, step, off, n) == n
+        idx = bam + ".secphase.index"
+        assert L.spx_bam_index_save(idx.encode(), off, n) == 0
+        raw = np.fromfile(idx, dtype="<i8")
+        assert raw[0] == n and list(raw[1:]) == list(off)
+        back = (C.c_int64 * n)()
+        assert L.spx_bam_index_load(idx.encode(), back, n) == n and list(back) == list(off)
+        assert all(off[i] < off[i + 1] for i in range(n - 1))
+        for chunk_bytes in (65536, 1 << 20):
+            for i, j in ((0, n - 1), (0, 3), (3, 17), (17, n - 1), (5, 6), (n - 2, n - 1)):
+                got, _ = _read_all(L, bam, 23, threads=2, chunk_bytes=chunk_bytes, start_voffset=off[i], end_voffset=off[j])
+                assert got == want[i * step:j * step], (writer, chunk_bytes, i, j)
+        # an empty shard
+        got, _ = _read_all(L, bam, 23, threads=2, start_voffset=off[4], end_voffset=off[4])
+        assert got == []
+
+
+def test_damaged_files_end_with_an_error(built, tmp_path):
+    """a flipped payload byte (CRC32 of the block), a file cut inside a block, a file cut inside a record"""
+    L = api.lib()
+    _declare_opts(L)
+    g = small_genome(synth.HIFI, read_len=2000, max_secondaries=2, n_paralogs=2)
+    r = g.reads(0, 200)
+    bam = str(tmp_path / "ok.bam")
+    synth.write_bam(bam, [r.batch], g.ref, threads=2)
+    data = bytearray(open(bam, "rb").read())
+
+    def outcome(blob, **kw):
+        p = str(tmp_path / "damaged.bam")
+        open(p, "wb").write(bytes(blob))
+        o = BamOptions()
+        L.spx_bam_default_options(C.byref(o))
+        o.threads = 2
+        o.chunk_bytes = 1 << 18
+        for k, v in kw.items():
+            setattr(o, k, v)
+        rd = C.c_void_p()
+        if L.spx_bam_open_opts(p.encode(), C.byref(o), C.byref(rd)) != 0:
+            return "open", L.spx_io_last_error()
+        total = 0
+        while True:
+            bp = C.POINTER(records.SpxBatch)()
+            n = L.spx_bam_next_batch(rd, 64, C.byref(bp))
+            if n < 0:
+                err = L.spx_io_last_error()
+                # the error is sticky
+                assert L.spx_bam_next_batch(rd, 64, C.byref(bp)) == n
+                L.spx_bam_close(rd)
+                return "error", err
+            if n == 0:
+                L.spx_bam_close(rd)
+                return "eof", total
+            total += n
+
+    assert outcome(data) == ("eof", 200)
+    flipped = bytearray(data)
+    flipped[len(data) // 2] ^= 0x55
+    kind, err = outcome(flipped)
+    assert kind == "error" and (b"CRC" in err or b"inflate" in err or b"BGZF" in err)
+    kind, err = outcome(data[: len(data) // 2])
+    assert kind == "error" and b"truncated" in err
+    # cut on a block boundary but inside a record: write the first half of the record stream as its own valid BGZF file
+    import gzip
+    payload = gzip.open(bam).read()
+    p2 = str(tmp_path / "cutrec.bam")
+    write_bgzf(p2, payload[: len(payload) // 2 + 3])
+    kind, err = outcome(open(p2, "rb").read())
+    assert kind == "error" and b"truncated BAM record" in err
+    # without the EOF marker block the file still reads (htslib only warns)
+    assert outcome(data[:-28]) == ("eof", 200)
+
+
+def test_c_writer_equals_python_writer_records(built, tmp_path):
+    """the bench-side C writer (synth/spx_bamwrite.c) and tests/bamio.py produce the same record stream"""
+    import gzip
+    g = small_genome(synth.HIFI, read_len=1500, max_secondaries=3, n_paralogs=2, tag_mode=2)
+    parts = [g.reads(i * 40, 40) for i in range(3)]
+    whole = g.reads(0, 120)
+    order = list(range(g.ref.contents.n_contigs))[::-1]
+    a, b = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    synth.write_bam(a, [p.batch for p in parts], g.ref, contig_order=order, threads=2)
+    write_bam(b, whole.batch, g.ref, contig_order=order)
+    assert gzip.open(a).read() == gzip.open(b).read()
+    fa, fb = str(tmp_path / "a.fa"), str(tmp_path / "b.fa")
+    synth.write_fasta(fa, g.ref)
+    write_fasta(fb, g.ref)
+    assert open(fa, "rb").read() == open(fb, "rb").read()
