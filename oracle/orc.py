@@ -75,6 +75,8 @@ def _load(path):
     L.orc_phred_from_posterior.argtypes = [C.c_double]
     L.orc_set_scratch_reuse.argtypes = [C.c_int]
     L.orc_set_scratch_reuse.restype = None
+    L.orc_set_reference_overheads.argtypes = [C.c_int]
+    L.orc_set_reference_overheads.restype = None
     L.orc_probaln_consts.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(HmmConsts)]
     L.orc_srand.argtypes = [C.POINTER(Rand), C.c_uint]
     L.orc_rand_next.restype = C.c_int
@@ -131,6 +133,12 @@ def run_batch_quals(batch, ref, params, qual, threads=1):
     res = (GroupResult * n)()
     lib().orc_run_batch_quals(batch, ref, C.byref(params), threads, res, qual.ctypes.data_as(C.POINTER(C.c_uint8)))
     return qual, res
+
+
+def set_reference_overheads(on, variant=None):
+    """bench.py's CPU-baseline bracket: per-group fai_load (src/secphase.c:101) and per-iterator regcomp + per-token regexec
+    (cigar_it.c:50,148) executed beside the restated algorithm (their results are not used: same outputs)"""
+    lib(variant).orc_set_reference_overheads(1 if on else 0)
 
 
 def run_batch(batch, ref, params, threads=1, seed=1, log_path=None, reuse_scratch=False, bed_modified=None,

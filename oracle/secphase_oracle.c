@@ -985,9 +985,12 @@ static void decide_group(const spx_batch *bt, int g, const spx_params *par, orc_
     r->relabel = r->best_idx >= 0 && (flag[r->best_idx] & SPX_FSECONDARY) != 0;
 }
 
+static int g_ref_overheads;
+static void reference_overheads(const spx_batch *bt, const spx_ref *ref, int g);
 int orc_score_group(const spx_batch *bt, const spx_ref *ref, int g, const spx_params *par, orc_rand *rng,
                     orc_group_result *out, FILE *log, orc_baq_call *calls, int max_calls)
 {
+    if (g_ref_overheads) reference_overheads(bt, ref, g);
     int rc = score_group(bt, ref, g, par, out, calls, max_calls);
     if (rc < 0) return rc;
     if (rng) {
@@ -999,6 +1002,83 @@ int orc_score_group(const spx_batch *bt, const spx_ref *ref, int g, const spx_pa
         }
     }
     return 0;
+}
+
+/* ---- bench.py's CPU-baseline bracket: work the reference does around the algorithm and this restatement does not ----
+ * (a) runOneThread calls fai_load(fastaPath) for EVERY group (src/secphase.c:101): the .fai index is opened, parsed line
+ *     by line and freed again; (b) every ptCigarIt_construct compiles the cs / MD pattern with regcomp (cigar_it.c:50,59)
+ *     and every token is found with regexec (cigar_it.c:75,148); the marker path constructs >= 7 iterators per alignment
+ *     (initial markers, all-mismatch removal via sort_and_fill, filter_ins, confident blocks, correct_conf_blocks per
+ *     round, calc_local_baq, init_coordinates).  When the switch is on, the same calls are executed beside the restated
+ *     algorithm; their results are not used, so the outputs do not change. */
+#include <pthread.h>
+#include <regex.h>
+#include <unistd.h>
+static char g_fai_path[256];
+static pthread_mutex_t g_fai_mu = PTHREAD_MUTEX_INITIALIZER;
+void orc_set_reference_overheads(int on) { g_ref_overheads = on; }
+static const char *kCsPattern = "(:([0-9]+))|(([+-])([a-z]+)|([\\*]([a-z]+))+)";      /* cigar_it.h:8 */
+static const char *kMdPattern = "(([A-Z])([0][A-Z])*)|([0-9]+)|([\\^]([A-Z]+))";          /* cigar_it.h:10 */
+
+static void overhead_fai(const spx_ref *ref)
+{
+    pthread_mutex_lock(&g_fai_mu);
+    if (!g_fai_path[0]) { /* the index fai_load would read: name, length, offset, line bases, line width */
+        snprintf(g_fai_path, sizeof g_fai_path, "/tmp/spx_oracle_%d.fai", (int)getpid());
+        FILE *f = fopen(g_fai_path, "w");
+        if (f) {
+            long long off = 0;
+            for (int c = 0; c < ref->n_contigs; ++c) {
+                const char *nm = ref->names + ref->name_off[c];
+                const long long ln = ref->seq_off[c + 1] - ref->seq_off[c];
+                off += (long long)strlen(nm) + 12;
+                fprintf(f, "%s\t%lld\t%lld\t80\t81\n", nm, ln, off);
+                off += ln + (ln + 79) / 80;
+            }
+            fclose(f);
+        }
+    }
+    pthread_mutex_unlock(&g_fai_mu);
+    FILE *f = fopen(g_fai_path, "r");
+    if (!f) return;
+    char line[1024], name[512];
+    int cap = 16, n = 0;
+    struct ent { char *name; long long len, off; int lb, lw; } *tab = malloc(sizeof(*tab) * cap);
+    while (fgets(line, sizeof line, f)) {
+        long long ln, of;
+        int lb, lw;
+        if (sscanf(line, "%511s\t%lld\t%lld\t%d\t%d", name, &ln, &of, &lb, &lw) != 5) continue;
+        if (n == cap) { cap *= 2; tab = realloc(tab, sizeof(*tab) * cap); }
+        tab[n].name = strdup(name); tab[n].len = ln; tab[n].off = of; tab[n].lb = lb; tab[n].lw = lw;
+        ++n;
+    }
+    fclose(f);
+    for (int i = 0; i < n; ++i) free(tab[i].name);
+    free(tab);
+}
+
+static void overhead_regex(const char *cs, const char *md)
+{
+    const char *text = cs ? cs : md;
+    if (!text) return;
+    for (int rep = 0; rep < 7; ++rep) {
+        regex_t re;
+        regmatch_t m[8];
+        if (regcomp(&re, cs ? kCsPattern : kMdPattern, REG_EXTENDED) != 0) return;
+        const char *p = text;
+        while (*p && regexec(&re, p, 8, m, 0) == 0 && m[0].rm_eo > 0) p += m[0].rm_eo;
+        regfree(&re);
+    }
+}
+
+static void reference_overheads(const spx_batch *bt, const spx_ref *ref, int g)
+{
+    overhead_fai(ref);
+    for (int a = bt->grp_first[g]; a < bt->grp_first[g + 1]; ++a) {
+        const char *cs = bt->cs_off[a] >= 0 ? bt->cs + bt->cs_off[a] : NULL;
+        const char *md = (!cs && bt->md_off && bt->md && bt->md_off[a] >= 0) ? bt->md + bt->md_off[a] : NULL;
+        overhead_regex(cs, md);
+    }
 }
 
 /* ---- batch driver (pool over groups like secphase.c:257,303) ------------- */

@@ -42,7 +42,9 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
 int orc_probaln_posteriors(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
                            const orc_probaln_par *c, double *s, double *zM, double *zI);
 int orc_phred_from_posterior(double max_over_sum);
-void orc_set_scratch_reuse(int on); /* CPU-baseline runs: per-thread scratch instead of calloc/free per call */
+void orc_set_scratch_reuse(int on);
+/* CPU-baseline runs: per-thread scratch instead of calloc/free per call */
+void orc_set_reference_overheads(int on); /* bench bracket: per-group fai_load, per-iterator regcomp / regexec */
 void orc_probaln_consts(int l_ref, int l_query, float d, float e, int set_q, orc_hmm_consts *c);
 
 /* glibc rand() (TYPE_3 additive feedback) replay, so that the tie-breaking

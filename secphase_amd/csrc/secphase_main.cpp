@@ -227,7 +227,8 @@ int main(int argc, char *argv[])
     bo.threads = threads;
     bo.batch_groups = marker_mode ? groups_per_batch : 0;
     bo.ahead_batches = 2;
-    bo.keep_batches = n_dev * (depth + 1) + 3;
+    bo.keep_batches = n_dev * (depth + 1) + 2 * n_dev + 6;
+    bo.ahead_batches = 4; /* the reader keeps cutting batches while the devices start up */
     spx_bam_reader *bam = nullptr;
     if (spx_bam_open_opts(inputPath.c_str(), &bo, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); return 1; }
     const double t_bam_open = now_s();
@@ -275,7 +276,7 @@ int main(int argc, char *argv[])
                 timestamp(), t_ref - t_proc0, t_bam_open - t_proc0, t_fasta - t_bam_open, t_ctx - t_fasta, t_ref - t_ctx);
     long long n_alns = 0, n_reads = 0, n_modified = 0, n_rejected = 0;
     double t_read = 0, t_wait = 0, t_out = 0, t_start = now_s(), t_hostprep = 0, t_kernel = 0;
-    double t_fin = 0, t_log = 0;
+    double t_fin = 0;
     /* the reference hands every group to a pool thread and serialises the output with a mutex; here whole batches
      * flow through in-order pipelines (one per device): while batch k is on a GPU, batch k+1 is staged and copied,
      * batch k+2 is inflated by the reader, and the results of batch k-1 are written -- in file order */
@@ -288,13 +289,15 @@ int main(int argc, char *argv[])
         }
     /* BED bookkeeping (marker arrays come back from the device) and the release of a work list's device memory happen on
      * a helper thread: the sets are order-independent (sorted and merged at the end), only the counts come back */
-    struct Post { spx_work *w; int lane; std::vector<spx_group_out> out; };
+    struct Post { spx_work *w; int lane; const spx_batch *bt; std::vector<spx_group_out> out; };
     std::mutex post_mu;
     std::condition_variable post_cv;
     std::deque<Post> post_q;
     bool post_stop = false;
     long long post_modified = 0;
-    double t_bed = 0, t_free = 0;
+    int post_pending = 0;
+    bool post_failed = false;
+    double t_bed = 0, t_free = 0, t_log = 0;
     std::thread post_thread([&] {
         for (;;) {
             Post ps;
@@ -305,6 +308,10 @@ int main(int argc, char *argv[])
                 ps = std::move(post_q.front());
                 post_q.pop_front();
             }
+            /* the queue is FIFO and this is its only consumer: the list grows in file order */
+            const double t9 = now_s();
+            if (spx_write_relabel_log(log_path.c_str(), "a", ps.bt, ref, ps.out.data()) != SPX_OK) post_failed = true;
+            spx_bam_release_batch(bam, ps.bt); /* its share of the inflate arena is recycled */
             const double ta = now_s();
             const int nm = spx_relabel_blocks(ps.w, ref, ps.out.data(), bed_mod, bed_mk);
             const double tb = now_s();
@@ -312,8 +319,10 @@ int main(int argc, char *argv[])
             const double tc = now_s();
             std::lock_guard<std::mutex> lk(post_mu);
             if (nm > 0) post_modified += nm;
+            t_log += ta - t9;
             t_bed += tb - ta;
             t_free += tc - tb;
+            --post_pending;
             post_cv.notify_all();
         }
     });
@@ -383,31 +392,32 @@ int main(int argc, char *argv[])
         const double ta = now_s();
         spx_finalizer_apply(fin, &par, out.data(), ng);
         const double tb = now_s();
-        spx_write_relabel_log(log_path.c_str(), "a", bt, ref, out.data());
-        const double tc = now_s();
         for (int g = 0; g < ng; ++g) if (out[(size_t)g].n_aln < 0) ++n_rejected;
-        spx_bam_release_batch(bam, bt); /* its share of the inflate arena is recycled */
         long long shown;
         {
-            std::lock_guard<std::mutex> lk(post_mu);
-            post_q.push_back(Post{w, lane, std::move(out)});
+            /* (the helper may lag a few batches behind: their work lists, and the slots of the reader they point into,
+             * stay alive meanwhile -- not without bound) */
+            std::unique_lock<std::mutex> lk(post_mu);
+            post_cv.wait(lk, [&] { return post_pending < 2 * n_dev + 2; });
+            post_q.push_back(Post{w, lane, bt, std::move(out)});
+            ++post_pending;
             shown = post_modified;
         }
         post_cv.notify_all();
         out = std::vector<spx_group_out>();
         t_out += now_s() - t0;
-        t_fin += tb - ta; t_log += tc - tb;
+        t_fin += tb - ta;
         fprintf(stderr, "[%s] #parsed alignments = %lld, #parsed reads = %lld, #modifed by phased variants = 0, #modifed by markers = %lld\n",
                 timestamp(), n_alns, n_reads, shown);
     }
     stop_post();
     n_modified = post_modified;
     for (spx_pipe *p : pipes) if (p) spx_pipe_destroy(p);
-    if (fail_rc) return 1;
+    if (fail_rc || post_failed) return 1;
     fprintf(stderr, "[%s] time in the scoring loop: %.3f s (BAM read+inflate not hidden by the read-ahead %.3f, waiting for results %.3f, "
                     "finalise+write %.3f); on pipeline threads: staging %.3f; GPU kernels %.3f; %d device(s)\n", timestamp(), now_s() - t_start, t_read, t_wait, t_out, t_hostprep, t_kernel, n_dev);
     if (getenv("SPX_TIMING"))
-        fprintf(stderr, "[%s] finalise+write: draws %.3f, relabel list %.3f; on the helper thread: BED bookkeeping %.3f, work free %.3f\n", timestamp(), t_fin, t_log, t_bed, t_free);
+        fprintf(stderr, "[%s] finalise: draws %.3f; on the helper thread: relabel list %.3f, BED bookkeeping %.3f, work free %.3f\n", timestamp(), t_fin, t_log, t_bed, t_free);
     if (n_rejected) fprintf(stderr, "[%s] %lld read group(s) use constructs the reference leaves undefined and were skipped\n", timestamp(), n_rejected);
     fprintf(stderr, "[%s] Number of reads modified by phased variants = 0\n", timestamp());
     fprintf(stderr, "[%s] Number of reads modified by marker score = %lld\n", timestamp(), n_modified);
@@ -420,10 +430,12 @@ int main(int argc, char *argv[])
     if (sam && spx_sam_close(sam) != SPX_OK) { fprintf(stderr, "[%s] could not finish the quality-modified output\n", timestamp()); return 1; }
     const double t_end1 = now_s();
     spx_bam_close(bam);
+    const double t_end2 = now_s();
     for (spx_ctx *c_ : ctxs) spx_destroy(c_);
+    const double t_end3 = now_s();
     spx_fasta_free(fa);
     if (getenv("SPX_TIMING"))
-        fprintf(stderr, "[%s] wind-down: BED merge + write %.3f s, closing reader / contexts %.3f s; whole process %.3f s\n", timestamp(), t_end1 - t_end0,
-                now_s() - t_end1, now_s() - t_proc0);
+        fprintf(stderr, "[%s] wind-down: BED merge + write %.3f s, closing the reader %.3f s, the context(s) %.3f s; whole process %.3f s\n", timestamp(),
+                t_end1 - t_end0, t_end2 - t_end1, t_end3 - t_end2, now_s() - t_proc0);
     return 0;
 }

@@ -19,8 +19,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/spx.h"
@@ -74,6 +77,19 @@ extern "C" int spx_merge_blocks_count(int32_t n, const int32_t *s, const int32_t
 
 struct spx_bedset {
     std::map<std::string, std::vector<Blk3>> per_contig; /* std::map iterates in strcmp order for plain ASCII names */
+    /* callers pass the same name POINTERS over and over (the contig table of the assembly): pointer -> list, in front of
+     * the string-keyed map (std::map nodes never move) */
+    std::unordered_map<const char *, std::pair<const std::string *, std::vector<Blk3> *>> by_ptr;
+    std::vector<Blk3> &list(const char *contig)
+    {
+        auto it = by_ptr.find(contig);
+        /* (the text is compared too: an address may be re-used for another name by a caller with short-lived strings) */
+        if (it != by_ptr.end() && strcmp(it->second.first->c_str(), contig) == 0) return *it->second.second;
+        auto node = per_contig.find(contig);
+        if (node == per_contig.end()) node = per_contig.emplace(contig, std::vector<Blk3>()).first;
+        by_ptr[contig] = {&node->first, &node->second};
+        return node->second;
+    }
 };
 
 extern "C" int spx_bedset_create(spx_bedset **out)
@@ -86,7 +102,7 @@ extern "C" void spx_bedset_free(spx_bedset *b) { delete b; }
 extern "C" int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, int32_t end, int32_t count)
 {
     if (!b || !contig) return SPX_EINVAL;
-    b->per_contig[contig].push_back({start, end, count});
+    b->list(contig).push_back({start, end, count});
     return SPX_OK;
 }
 /* n single-base blocks on one contig (the marker positions of one relabelled alignment): one look-up of the contig
@@ -95,7 +111,7 @@ extern "C" int spx_bedset_add_points(spx_bedset *b, const char *contig, const in
 {
     if (!b || !contig || (!pos && n > 0)) return SPX_EINVAL;
     if (n <= 0) return SPX_OK;
-    auto &v = b->per_contig[contig]; /* (no reserve: an exact reserve per call would defeat the vector's geometric growth) */
+    auto &v = b->list(contig); /* (no reserve: an exact reserve per call would defeat the vector's geometric growth) */
     for (int32_t k = 0; k < n; ++k) v.push_back({pos[k], pos[k], 0});
     return SPX_OK;
 }
@@ -108,20 +124,54 @@ extern "C" int64_t spx_bedset_size(const spx_bedset *b)
 
 /* merge_and_save_blocks (src/secphase.c:59-72): merge per contig, write the BED.  The file is created even
  * when there is nothing to write (the WDLs glob for it, wdls/workflows/secphase.wdl:100-107). */
+static void put_i32(std::string &s, int32_t v)
+{
+    char b[16];
+    int n = 0;
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) b[n++] = '-';
+    while (n) s += b[--n];
+}
+
 extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_count)
 {
     if (!b || !path) return SPX_EINVAL;
     FILE *fp = fopen(path, "w");
     if (!fp) return SPX_EINVAL;
-    std::vector<Blk3> merged;
-    for (const auto &kv : b->per_contig) {
-        merge_count(kv.second, print_count != 0, merged);
-        for (const Blk3 &m : merged) {
-            if (m.e < m.s) continue;
-            if (print_count) fprintf(fp, "%s\t%d\t%d\t%d\n", kv.first.c_str(), m.s, m.e + 1, m.c);
-            else fprintf(fp, "%s\t%d\t%d\n", kv.first.c_str(), m.s, m.e + 1);
+    /* contigs are independent: merged and formatted on threads, written in strcmp order */
+    std::vector<const std::pair<const std::string, std::vector<Blk3>> *> items;
+    for (const auto &kv : b->per_contig) items.push_back(&kv);
+    std::vector<std::string> text(items.size());
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        std::vector<Blk3> merged;
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= items.size()) break;
+            merge_count(items[k]->second, print_count != 0, merged);
+            std::string &t = text[k];
+            t.reserve(merged.size() * (items[k]->first.size() + 24));
+            for (const Blk3 &m : merged) {
+                if (m.e < m.s) continue;
+                t += items[k]->first; t += '\t';
+                put_i32(t, m.s); t += '\t';
+                put_i32(t, m.e + 1);
+                if (print_count) { t += '\t'; put_i32(t, m.c); }
+                t += '\n';
+            }
         }
+    };
+    const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(32, std::thread::hardware_concurrency()), items.size()));
+    if (nthr <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work);
+        for (auto &t : th) t.join();
     }
-    fclose(fp);
-    return SPX_OK;
+    bool ok = true;
+    for (const std::string &t : text)
+        if (!t.empty() && fwrite(t.data(), 1, t.size(), fp) != t.size()) ok = false;
+    if (fclose(fp) != 0) ok = false;
+    return ok ? SPX_OK : SPX_EINVAL;
 }

@@ -11,6 +11,7 @@
  * SPX_CODE_OUT = column outside [1,R] (no such DP cell) */
 /* band classes = kernel instantiations (lanes per problem x slots per lane), see spx_launch_baq */
 #define SPX_N_CLASSES 14
+#define SPX_MAX_STAGE_SLOTS (1 << 20) /* alignments (and groups) per work list: the tiled device scans cover 1024 tiles of 1024 */
 
 #define SPX_CODE_N 4
 #define SPX_CODE_OUT 8

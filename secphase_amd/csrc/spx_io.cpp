@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "../../include/spx.h"
+#include "spx_pool.h"
 
 namespace {
 
@@ -127,84 +128,6 @@ uint32_t crc_of(const uint8_t *p, size_t n)
     return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
 }
 
-/* ---- persistent worker pool ---- */
-class Pool {
-    std::vector<std::thread> th_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::deque<std::function<void()>> q_;
-    bool stop_ = false;
-
-public:
-    explicit Pool(int n)
-    {
-        for (int t = 0; t < std::max(1, n); ++t)
-            th_.emplace_back([this] {
-                for (;;) {
-                    std::function<void()> f;
-                    {
-                        std::unique_lock<std::mutex> lk(mu_);
-                        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
-                        if (q_.empty()) return;
-                        f = std::move(q_.front());
-                        q_.pop_front();
-                    }
-                    f();
-                }
-            });
-    }
-    ~Pool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    int size() const { return (int)th_.size(); }
-    void submit(std::function<void()> f)
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            q_.push_back(std::move(f));
-        }
-        cv_.notify_one();
-    }
-    /* f(k0, k1) over [0, n) in pieces of `grain`; the caller works too and returns when every piece is done */
-    template <class F>
-    void parallel_for(int64_t n, int64_t grain, F f)
-    {
-        if (n <= 0) return;
-        grain = std::max<int64_t>(1, grain);
-        const int64_t pieces = (n + grain - 1) / grain;
-        if (pieces <= 1) { f((int64_t)0, n); return; }
-        struct St {
-            std::atomic<int64_t> next{0}, done{0};
-            std::mutex mu;
-            std::condition_variable cv;
-        };
-        auto st = std::make_shared<St>();
-        F *fp = &f; /* late helpers find no piece left and never touch it */
-        auto run = [st, fp, n, grain, pieces] {
-            for (;;) {
-                const int64_t k = st->next.fetch_add(1);
-                if (k >= pieces) return;
-                (*fp)(k * grain, std::min(n, (k + 1) * grain));
-                if (st->done.fetch_add(1) + 1 == pieces) {
-                    std::lock_guard<std::mutex> lk(st->mu);
-                    st->cv.notify_all();
-                }
-            }
-        };
-        const int helpers = (int)std::min<int64_t>(size(), pieces - 1);
-        for (int t = 0; t < helpers; ++t) submit(run);
-        run();
-        std::unique_lock<std::mutex> lk(st->mu);
-        st->cv.wait(lk, [&] { return st->done.load() == pieces; });
-    }
-};
-
 /* ---- arena of chunk slots: one virtual reservation, slots handed out lazily, recycled LIFO ---- */
 struct Arena {
     uint8_t *base = nullptr;
@@ -227,7 +150,7 @@ struct Arena {
             aligned = (uint8_t *)a;
             n_max = (int)(v / slot);
 #ifdef MADV_HUGEPAGE
-            (void)madvise(aligned, (size_t)n_max * slot, MADV_HUGEPAGE);
+            if (!getenv("SPX_BAM_NO_THP")) (void)madvise(aligned, (size_t)n_max * slot, MADV_HUGEPAGE);
 #endif
             return true;
         }
@@ -295,6 +218,7 @@ struct Reader {
     bool want_voff = false, check_crc = true;
     size_t soft_cap_slots = 0;
     /* block-chain walk (dispatcher state; reader thread only) */
+    size_t populated = 0; /* the mapping is faulted in up to here (tasks on the pool, ahead of the walk) */
     size_t fpos = 0;
     bool index_eof = false;
     size_t end_coff = (size_t)-1;
@@ -309,7 +233,7 @@ struct Reader {
     std::deque<Batch *> handed;     /* handed to the caller, newest last */
     std::atomic<int32_t> batch_groups{0};
     bool closing = false, consumer_waiting = false;
-    std::unique_ptr<Pool> pool;
+    std::unique_ptr<spx::Pool> pool;
     std::thread walker;
     /* walker cursor (reader thread only) */
     Chunk *cur = nullptr;
@@ -322,7 +246,7 @@ struct Reader {
     std::string last_name;
     bool have_last = false;
     int64_t n_records = 0, n_groups_total = 0;
-    double t_wait_inflate = 0, t_wait_slot = 0;
+    double t_wait_inflate = 0, t_wait_slot = 0, t_dispatch = 0;
 };
 
 bool parse_block_header(const uint8_t *p, size_t avail, size_t *total, size_t *hdr_len, std::string &err)
@@ -357,17 +281,45 @@ void chunk_unref_locked(Reader *r, Chunk *c)
 void inflate_blocks(Reader *r, Chunk *c, size_t b0, size_t b1)
 {
     thread_local Inflater inf;
+    static const bool use_pread = getenv("SPX_BAM_PREAD") != nullptr;
+    thread_local std::vector<uint8_t> cbuf;
     for (size_t q = b0; q < b1; ++q) {
         const Block &b = c->blocks[q];
-        if (!inf.run(r->map + b.coff, b.clen, c->data + b.uoff, b.ulen)) { c->bad = 1; continue; }
+        const uint8_t *src = r->map + b.coff;
+        if (use_pread && !r->map_is_malloc) {
+            cbuf.resize(65536 + 64);
+            if (pread(r->fd, cbuf.data(), b.clen, (off_t)b.coff) != (ssize_t)b.clen) { c->bad = 1; continue; }
+            src = cbuf.data();
+        }
+        if (!inf.run(src, b.clen, c->data + b.uoff, b.ulen)) { c->bad = 1; continue; }
         if (r->check_crc && crc_of(c->data + b.uoff, b.ulen) != b.crc) c->bad = 2;
     }
 }
 
 /* next run of blocks -> a slot -> inflate tasks; false: nothing dispatched (end of the block chain, error, closing) */
+void populate_ahead(Reader *r)
+{
+#ifdef MADV_POPULATE_READ
+    /* the chain walk touches two cache lines per block: without this every touch of a new page is a page fault on the
+     * walker thread; with it the pool threads map the file 64 MB at a time, 256 MB ahead */
+    if (r->map_is_malloc) return;
+    const size_t step = (size_t)64 << 20, lead = (size_t)256 << 20;
+    if (r->populated < r->fpos) r->populated = r->fpos & ~(size_t)4095;
+    while (r->populated < r->fsize && r->populated < r->fpos + lead) {
+        const size_t a = r->populated, n = std::min(step, r->fsize - a);
+        const uint8_t *base = r->map;
+        r->pool->submit([base, a, n] { (void)madvise((void *)(base + a), n, MADV_POPULATE_READ); });
+        r->populated = a + n;
+    }
+#else
+    (void)r;
+#endif
+}
+
 bool dispatch_chunk(Reader *r)
 {
     if (r->index_eof) return false;
+    populate_ahead(r);
     std::unique_ptr<Chunk> c(new Chunk());
     size_t u = 0;
     while (u < r->chunk_target) {
@@ -443,6 +395,7 @@ bool dispatch_chunk(Reader *r)
  * front of the next chunk's data.  false: end of the stream or error (r->werr set). */
 bool advance_chunk(Reader *r)
 {
+    const double td0 = io_now();
     for (;;) {
         size_t n_in;
         {
@@ -451,6 +404,7 @@ bool advance_chunk(Reader *r)
         }
         if ((int)n_in >= r->max_inflight || !dispatch_chunk(r)) break;
     }
+    r->t_dispatch += io_now() - td0;
     if (!r->werr.empty()) return false;
     Chunk *nx = nullptr;
     const double t0 = io_now();
@@ -595,7 +549,7 @@ void batch_add_chunk(Reader *r, Batch &B, Chunk *c)
 void fill_batch(Reader *r, Batch &B, int32_t max_groups)
 {
     const double t_fill0 = io_now();
-    r->t_wait_inflate = r->t_wait_slot = 0;
+    r->t_wait_inflate = r->t_wait_slot = r->t_dispatch = 0;
     const uint8_t *base = r->arena.aligned;
     bool open_group = false;
     /* Pass 1, serial (every record says where the next one starts, and the batch ends on a name change): record
@@ -740,9 +694,9 @@ void fill_batch(Reader *r, Batch &B, int32_t max_groups)
     b.md_off = B.md_off.data(); b.md = (const char *)base;
     r->n_groups_total += B.ng;
     if (io_timing())
-        fprintf(stderr, "[spx timing] BAM batch: %d groups, %lld records, %.3f s (record chain %.3f [waiting for inflate %.3f, for a slot %.3f], "
-                        "fields+tags %.3f, CIGAR+names %.3f)\n", B.ng, (long long)nrec, io_now() - t_fill0, t_p1 - t_fill0, r->t_wait_inflate,
-                r->t_wait_slot, t_p2 - t_p1, t_p3 - t_p2);
+        fprintf(stderr, "[spx timing] BAM batch: %d groups, %lld records, %.3f s (record chain %.3f [block chain + dispatch %.3f incl. waiting for a slot %.3f; "
+                        "waiting for inflate %.3f], fields+tags %.3f, CIGAR+names %.3f)\n", B.ng, (long long)nrec, io_now() - t_fill0, t_p1 - t_fill0,
+                r->t_dispatch, r->t_wait_slot, r->t_wait_inflate, t_p2 - t_p1, t_p3 - t_p2);
 }
 
 void batch_release_locked(Reader *r, Batch *B)
@@ -933,7 +887,24 @@ extern "C" int spx_bam_open_opts(const char *path, const spx_bam_options *opt, s
     /* the reservation is virtual (MAP_NORESERVE, touched slot by slot): room for the soft cap twice over */
     const size_t want = std::max(std::min<size_t>((size_t)4 << 40, 2 * (r->soft_cap_slots + 8) * slot), 8 * slot);
     if (!r->arena.init(slot, want)) return bail("cannot reserve the inflate arena");
-    r->pool.reset(new Pool(r->threads));
+    r->pool.reset(new spx::Pool(r->threads));
+    if (getenv("SPX_BAM_POPULATE_ALL") && !r->map_is_malloc) { /* experiment: the whole mapping faulted in up front */
+        const size_t step = (size_t)64 << 20;
+        const uint8_t *mb = r->map;
+        const size_t fs = r->fsize;
+        r->pool->parallel_for((int64_t)((fs + step - 1) / step), 1, [mb, fs, step](int64_t a, int64_t b) {
+            for (int64_t k = a; k < b; ++k) (void)madvise((void *)(mb + (size_t)k * step), std::min(step, fs - (size_t)k * step), MADV_POPULATE_READ);
+        });
+        r->populated = fs;
+    }
+    if (const char *e = getenv("SPX_BAM_PRETOUCH_GB")) { /* experiment: arena pages touched up front */
+        const size_t nb = std::min((size_t)atoll(e) << 30, (size_t)r->arena.n_max * slot);
+        uint8_t *ab = r->arena.aligned;
+        const size_t step = (size_t)2 << 20;
+        r->pool->parallel_for((int64_t)(nb / step), 64, [ab, step](int64_t a, int64_t b) {
+            for (int64_t k = a; k < b; ++k) ab[(size_t)k * step] = 1, ab[(size_t)k * step + 4096] = 1;
+        });
+    }
     r->fpos = start_coff;
     /* the walker starts start_uoff bytes into its first chunk */
     r->batch_groups = o.batch_groups > 0 ? o.batch_groups : 0;

@@ -34,17 +34,43 @@ void RefIndex::build(const spx_ref *ref)
         len[i] = ref->seq_off[i + 1] - ref->seq_off[i];
         nib += (len[i] + 1) & ~(int64_t)1; /* every contig starts on a byte boundary */
     }
+    /* positions of the non-ACGT bases: the contigs are scanned in pieces on threads, the pieces' lists joined in order */
     npos_off.assign(nc + 1, 0);
     npos.clear();
-    for (int i = 0; i < nc; ++i) {
-        const char *s = ref->bases + ref->seq_off[i];
-        const int64_t n = len[i];
-        for (int64_t k = 0; k < n; ++k) {
-            const char c = s[k] & ~0x20;
-            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') npos.push_back((int32_t)k);
+    struct Piece { int contig; int64_t k0, k1; std::vector<int32_t> pos; };
+    std::vector<Piece> pieces;
+    const int64_t step = (int64_t)4 << 20;
+    for (int i = 0; i < nc; ++i)
+        for (int64_t k = 0; k < len[i] || (k == 0 && len[i] == 0); k += step) {
+            pieces.push_back({i, k, std::min(len[i], k + step), {}});
+            if (len[i] == 0) break;
         }
-        npos_off[i + 1] = (int64_t)npos.size();
+    {
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            static const struct Tbl { bool acgt[256]; Tbl() { for (int c = 0; c < 256; ++c) { const char u = (char)(c & ~0x20); acgt[c] = u == 'A' || u == 'C' || u == 'G' || u == 'T'; } } } T;
+            for (;;) {
+                const size_t q = next.fetch_add(1);
+                if (q >= pieces.size()) break;
+                Piece &pc = pieces[q];
+                const unsigned char *s_ = (const unsigned char *)ref->bases + ref->seq_off[pc.contig];
+                for (int64_t k = pc.k0; k < pc.k1; ++k)
+                    if (!T.acgt[s_[k]]) pc.pos.push_back((int32_t)k);
+            }
+        };
+        const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(32, std::thread::hardware_concurrency()), pieces.size()));
+        if (nthr <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work);
+            for (auto &t : th) t.join();
+        }
     }
+    for (const Piece &pc : pieces) {
+        npos.insert(npos.end(), pc.pos.begin(), pc.pos.end());
+        npos_off[pc.contig + 1] = (int64_t)npos.size();
+    }
+    for (int i = 0; i < nc; ++i) npos_off[i + 1] = std::max(npos_off[i + 1], npos_off[i]);
 }
 
 spxl::RefView RefIndex::view() const
@@ -273,6 +299,81 @@ void stage_copy(const Stage &st, char *dst, int threads)
             if (r.cs_len >= 0) memcpy(text + r.tag_off, bt->cs + bt->cs_off[r.rec], (size_t)r.cs_len + 1);
             else if (r.md_len >= 0) memcpy(text + r.tag_off, bt->md + bt->md_off[r.rec], (size_t)r.md_len + 1);
             else text[r.tag_off] = 0;
+        }
+    });
+}
+
+/* ---------------- piecewise staging ---------------- */
+int64_t stage_section_bytes(const Stage &st, int sec)
+{
+    const StageLayout &L = st.lay;
+    return sec == 0 ? L.cigar_words * 4 : sec == 1 ? L.seq_bytes : sec == 2 ? L.qual_bytes : L.text_bytes;
+}
+size_t stage_section_offset(const Stage &st, int sec)
+{
+    const StageLayout &L = st.lay;
+    return sec == 0 ? L.o_cigar : sec == 1 ? L.o_seq : sec == 2 ? L.o_qual : L.o_text;
+}
+
+namespace {
+/* section-relative byte offset / stored length / source of record r's part */
+inline int64_t sec_off(const spxl::Rec &r, int sec) { return sec == 0 ? r.cigar_off * 4 : sec == 1 ? r.seq_off : sec == 2 ? r.qual_off : r.tag_off; }
+inline int64_t sec_len(const spxl::Rec &r, int sec)
+{
+    const int64_t lq = r.l_qseq > 0 ? r.l_qseq : 0;
+    switch (sec) {
+    case 0: return (int64_t)(r.n_cigar > 0 ? r.n_cigar : 0) * 4;
+    case 1: return (((lq + 1) / 2) + 3) & ~(int64_t)3;
+    case 2: return lq;
+    default: return (r.cs_len >= 0 ? r.cs_len : r.md_len >= 0 ? r.md_len : 0) + 1;
+    }
+}
+} // namespace
+
+void stage_fill(const Stage &st, int sec, int64_t b0, int64_t b1, char *dst,
+                const std::function<void(int64_t, int64_t, const std::function<void(int64_t, int64_t)> &)> &f_parallel)
+{
+    const int64_t ns = (int64_t)st.recs.size();
+    if (b1 <= b0 || ns == 0) return;
+    /* first record whose part ends behind b0 (offsets ascend with the record index) */
+    int64_t lo = 0, hi = ns;
+    while (lo < hi) {
+        const int64_t m = (lo + hi) / 2;
+        if (sec_off(st.recs[(size_t)m], sec) + sec_len(st.recs[(size_t)m], sec) <= b0) lo = m + 1; else hi = m;
+    }
+    const int64_t s0 = lo;
+    lo = s0; hi = ns;
+    while (lo < hi) { /* first record that starts at or behind b1 */
+        const int64_t m = (lo + hi) / 2;
+        if (sec_off(st.recs[(size_t)m], sec) < b1) lo = m + 1; else hi = m;
+    }
+    const int64_t s1 = lo;
+    if (s1 <= s0) return;
+    const int64_t grain = std::max<int64_t>(1, (int64_t)(((int64_t)4 << 20) / std::max<int64_t>(1, (b1 - b0) / (s1 - s0)))); /* ~4 MB per piece */
+    f_parallel(s1 - s0, grain, [&](int64_t k0, int64_t k1) {
+        for (int64_t s = s0 + k0; s < s0 + k1; ++s) {
+            const spxl::Rec &r = st.recs[(size_t)s];
+            const spx_batch *bt = st.batches[r.batch];
+            const int64_t off = sec_off(r, sec), len = sec_len(r, sec);
+            const int64_t a = std::max(off, b0), e = std::min(off + len, b1); /* the part of this record inside the range */
+            if (e <= a) continue;
+            char *d = dst + (a - b0);
+            const int64_t skip = a - off, n = e - a;
+            const char *src = nullptr;
+            int64_t have = 0; /* bytes the record really has (the rest of `len` is padding / the terminator) */
+            switch (sec) {
+            case 0: src = (const char *)(bt->cigar + bt->cigar_off[r.rec]); have = len; break;
+            case 1: src = (const char *)(bt->seq4 + bt->seq_off[r.rec]); have = ((r.l_qseq > 0 ? r.l_qseq : 0) + 1) / 2; break;
+            case 2: src = (const char *)(bt->qual + bt->qual_off[r.rec]); have = len; break;
+            default:
+                if (r.cs_len >= 0) { src = bt->cs + bt->cs_off[r.rec]; have = r.cs_len; }
+                else if (r.md_len >= 0) { src = bt->md + bt->md_off[r.rec]; have = r.md_len; }
+                break;
+            }
+            const int64_t c1 = std::min(skip + n, have); /* copy [skip, c1), zero the rest */
+            if (c1 > skip) memcpy(d, src + skip, (size_t)(c1 - skip));
+            const int64_t z0 = std::max(skip, have);
+            if (skip + n > z0) memset(d + (z0 - skip), 0, (size_t)(skip + n - z0));
         }
     });
 }

@@ -9,6 +9,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 #include "../../include/spx.h"
@@ -90,6 +91,13 @@ struct Stage {
 int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, Stage &st);
 /* copy the payload into dst (lay.bytes bytes) on `threads` threads */
 void stage_copy(const Stage &st, char *dst, int threads);
+/* The same image piecewise, for staging through a ring of pinned chunks: byte range [b0, b1) of payload section `sec`
+ * (0 CIGAR words, 1 SEQ, 2 QUAL, 3 tag text; section-relative offsets) into dst (= the byte at b0).  Records that
+ * straddle the range are copied in part.  f_parallel(n, grain, fn(k0,k1)) runs the record loop (a thread pool). */
+int64_t stage_section_bytes(const Stage &st, int sec);
+size_t stage_section_offset(const Stage &st, int sec);
+void stage_fill(const Stage &st, int sec, int64_t b0, int64_t b1, char *dst,
+                const std::function<void(int64_t, int64_t, const std::function<void(int64_t, int64_t)> &)> &f_parallel);
 
 /* what the work list needs from spx_params, in the shape spx_logic.h wants (qf through the host libm) */
 spxl::Params logic_params(const spx_params *par);

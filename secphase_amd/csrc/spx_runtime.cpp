@@ -27,6 +27,7 @@
 #include "spx_device.h"
 #include "spx_prep.h"
 #include "spx_prep_dev.h"
+#include "spx_pool.h"
 
 struct spx_bedset;
 
@@ -109,6 +110,17 @@ struct spx_ctx {
     size_t hbm_bytes = (size_t)256 << 30; /* the device's total memory (hipMemGetInfo at spx_create) */
     std::condition_variable arena_cv; /* signalled when a work list gives device memory back (arena_put) */
     std::atomic<bool> hbm_tight{false}; /* an allocation has failed once: no more head room on new blocks */
+    /* Staging ring: record batches go to HBM through a few pinned chunks that are filled by a thread pool and copied
+     * asynchronously, one behind the other (a pinned buffer per batch would mean pinning gigabytes anew whenever a batch
+     * is larger than any before -- ~0.2 s per GB -- and again after every spx_trim) */
+    static const int SPX_PIN_CHUNKS = 4;
+    void *pin_chunk[SPX_PIN_CHUNKS] = {};
+    hipEvent_t pin_done[SPX_PIN_CHUNKS] = {};
+    bool pin_busy[SPX_PIN_CHUNKS] = {};
+    size_t pin_bytes = 0;
+    int pin_next = 0;
+    std::mutex stage_mu; /* one staging at a time per context */
+    std::unique_ptr<spx::Pool> stage_pool;
     /* work-list preparation on the device: its own stream (it overlaps the DP kernels of the previous list), pools
      * that only live during a preparation and are shared by all of them (prep_mu serialises preparations) */
     hipStream_t prep_stream = nullptr;
@@ -301,6 +313,11 @@ extern "C" void spx_destroy(spx_ctx *c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     for (auto &a : c->arena_cache) (void)hipFree(a.first);
     for (auto &a : c->pinned_cache) (void)hipHostFree(a.first);
+    for (int k = 0; k < spx_ctx::SPX_PIN_CHUNKS; ++k) {
+        if (c->pin_chunk[k]) (void)hipHostFree(c->pin_chunk[k]);
+        if (c->pin_done[k]) (void)hipEventDestroy(c->pin_done[k]);
+    }
+    c->stage_pool.reset();
     for (spx_ctx::DevBuf *b : {&c->pool_ops, &c->pool_conf, &c->pool_mm, &c->pool_garena, &c->pool_keys, &c->pool_sort})
         if (b->p) (void)hipFree(b->p);
     if (c->d_tot) (void)hipFree(c->d_tot);
@@ -328,21 +345,34 @@ extern "C" int spx_set_reference(spx_ctx *c, const spx_ref *ref)
     int64_t nib = spx::kRefLeadNibbles;
     for (int i = 0; i < nc; ++i) nib += (c->ref.len[i] + 1) & ~(int64_t)1;
     std::vector<uint8_t> packed((size_t)(nib / 2) + spx::kRefTailBytes, 0); /* slack: ... and past a window */
-    unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> th;
-    auto work = [&](unsigned tid) {
-        for (int i = (int)tid; i < nc; i += (int)nthr) {
-            const char *s = ref->bases + ref->seq_off[i];
-            uint8_t *d = packed.data() + c->ref.nib_off[i] / 2;
-            const int64_t len = c->ref.len[i];
-            for (int64_t k = 0; k + 1 < len; k += 2)
-                d[k >> 1] = (uint8_t)(kNt16Int[kNt16Table[(unsigned char)s[k]]] |
-                                      (kNt16Int[kNt16Table[(unsigned char)s[k + 1]]] << 4));
-            if (len & 1) d[len >> 1] = kNt16Int[kNt16Table[(unsigned char)s[len - 1]]];
+    { /* characters -> 4-bit codes, in pieces of 4 Mbp on threads (htslib's seq_nt16_table / seq_nt16_int, ptMarker.c:744) */
+        struct Piece { int contig; int64_t k0, k1; };
+        std::vector<Piece> pieces;
+        const int64_t step = (int64_t)4 << 20; /* even: a piece starts on a byte boundary */
+        for (int i = 0; i < nc; ++i)
+            for (int64_t k = 0; k < c->ref.len[i]; k += step) pieces.push_back({i, k, std::min(c->ref.len[i], k + step)});
+        static const struct Tbl { uint8_t code[256]; Tbl() { for (int x = 0; x < 256; ++x) code[x] = kNt16Int[kNt16Table[x]]; } } T;
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const size_t q = next.fetch_add(1);
+                if (q >= pieces.size()) break;
+                const Piece &pc = pieces[q];
+                const unsigned char *s = (const unsigned char *)ref->bases + ref->seq_off[pc.contig];
+                uint8_t *d = packed.data() + c->ref.nib_off[pc.contig] / 2;
+                int64_t k = pc.k0;
+                for (; k + 1 < pc.k1; k += 2) d[k >> 1] = (uint8_t)(T.code[s[k]] | (T.code[s[k + 1]] << 4));
+                if (k < pc.k1) d[k >> 1] = T.code[s[k]];
+            }
+        };
+        const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(32, std::thread::hardware_concurrency()), pieces.size()));
+        if (nthr <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work);
+            for (auto &t : th) t.join();
         }
-    };
-    for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work, t);
-    for (auto &t : th) t.join();
+    }
     if (c->d_ref4) { (void)hipFree(c->d_ref4); c->d_ref4 = nullptr; }
     c->ref_bytes = (int64_t)packed.size();
     HIPCHK(hipMalloc((void **)&c->d_ref4, packed.size()));
@@ -668,18 +698,18 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->owner = c;
     const double t0 = now_s();
     int nthr = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
-    nthr = std::max(1, std::min(nthr, 64));
+    nthr = std::max(1, std::min(nthr, 128));
     int rc = spx::stage_measure(bts, n_batches, nthr, w->stage);
     if (rc) { delete w; return fail(rc, "invalid batch"); }
     const spx::StageLayout &L = w->stage.lay;
     w->n_groups_in = (int32_t)L.n_groups_in;
     w->n_dgroups = (int32_t)L.n_dgroups;
     w->hb.grp_error = w->stage.grp_error;
-    w->h_stage = pinned_get(c, L.bytes + 64, &w->h_stage_cap);
-    if (!w->h_stage) { delete w; return fail(SPX_ENOMEM, "pinned staging buffer"); }
-    spx::stage_copy(w->stage, (char *)w->h_stage, nthr);
-    const double t1 = now_s();
     /* part A in HBM: staged records | recoded SEQ | per-alignment state | per-group counts and offsets */
+    if (L.n_slots > SPX_MAX_STAGE_SLOTS || L.n_dgroups > SPX_MAX_STAGE_SLOTS) {
+        delete w;
+        return fail(SPX_EINVAL, "more than 2^20 alignments in one work list: stage fewer groups at a time");
+    }
     Carver cv;
     const size_t ns = (size_t)L.n_slots, ng = (size_t)L.n_dgroups;
     const size_t o_in = cv.take<char>(L.bytes + 64);
@@ -696,7 +726,68 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->in_arena = arena_get(c, cv.off + 256, &w->in_cap);
     if (!w->in_arena) { spx_work_free(c, w); return fail(SPX_ENOMEM, "device memory for the staged records"); }
     char *base = (char *)w->in_arena;
-    HIPCHK(hipMemcpyAsync(base, w->h_stage, L.bytes, hipMemcpyHostToDevice, c->copy_stream));
+    {
+        /* through the ring of pinned chunks: fill chunk k on the pool while chunk k-1 is on its way over PCIe */
+        std::lock_guard<std::mutex> sl(c->stage_mu);
+        if (!c->pin_bytes) {
+            size_t mb = 64;
+            if (const char *e = getenv("SPX_PIN_MB")) mb = (size_t)std::max(1, atoi(e));
+            c->pin_bytes = mb << 20;
+        }
+        if (!c->stage_pool || c->stage_pool->size() < nthr) c->stage_pool.reset(new spx::Pool(nthr));
+        spx::Pool *pool = c->stage_pool.get();
+        const std::function<void(int64_t, int64_t, const std::function<void(int64_t, int64_t)> &)> par_for =
+            [pool](int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)> &fn) { pool->parallel_for(n, grain, fn); };
+        int rc2 = SPX_OK;
+        auto chunk_get = [&](char **p) -> int { /* next chunk of the ring, free again */
+            const int k = c->pin_next;
+            c->pin_next = (k + 1) % spx_ctx::SPX_PIN_CHUNKS;
+            if (!c->pin_chunk[k]) {
+                if (hipHostMalloc(&c->pin_chunk[k], c->pin_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->pin_chunk[k] = nullptr; return -1; }
+                if (hipEventCreateWithFlags(&c->pin_done[k], hipEventDisableTiming) != hipSuccess) return -1;
+            }
+            if (c->pin_busy[k] && hipEventSynchronize(c->pin_done[k]) != hipSuccess) return -1;
+            c->pin_busy[k] = false;
+            *p = (char *)c->pin_chunk[k];
+            return k;
+        };
+        auto chunk_send = [&](int k, char *dev_dst, size_t bytes) -> bool {
+            if (hipMemcpyAsync(dev_dst, c->pin_chunk[k], bytes, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) return false;
+            if (hipEventRecord(c->pin_done[k], c->copy_stream) != hipSuccess) return false;
+            c->pin_busy[k] = true;
+            return true;
+        };
+        /* the small arrays: record descriptors, group -> first alignment, group -> input group */
+        struct Raw { const void *src; size_t bytes, off; };
+        const Raw raws[3] = {{w->stage.recs.data(), w->stage.recs.size() * sizeof(spxl::Rec), L.o_recs},
+                             {w->stage.slot0.data(), w->stage.slot0.size() * 4, L.o_slot0},
+                             {w->stage.grp_index.data(), w->stage.grp_index.size() * 4, L.o_gidx}};
+        for (const Raw &r : raws)
+            for (size_t o = 0; o < r.bytes && rc2 == SPX_OK; o += c->pin_bytes) {
+                char *h = nullptr;
+                const int k = chunk_get(&h);
+                if (k < 0) { rc2 = SPX_ENOMEM; break; }
+                const size_t n = std::min(c->pin_bytes, r.bytes - o);
+                const char *src = (const char *)r.src + o;
+                if (n > ((size_t)8 << 20)) pool->parallel_for((int64_t)n, (int64_t)4 << 20, [&](int64_t a, int64_t b) { memcpy(h + a, src + a, (size_t)(b - a)); });
+                else memcpy(h, src, n);
+                if (!chunk_send(k, base + r.off + o, n)) rc2 = SPX_EHIP;
+            }
+        for (int sec = 0; sec < 4 && rc2 == SPX_OK; ++sec) {
+            const int64_t tot = spx::stage_section_bytes(w->stage, sec);
+            const size_t doff = spx::stage_section_offset(w->stage, sec);
+            for (int64_t b0 = 0; b0 < tot && rc2 == SPX_OK; b0 += (int64_t)c->pin_bytes) {
+                const int64_t b1 = std::min<int64_t>(tot, b0 + (int64_t)c->pin_bytes);
+                char *h = nullptr;
+                const int k = chunk_get(&h);
+                if (k < 0) { rc2 = SPX_ENOMEM; break; }
+                spx::stage_fill(w->stage, sec, b0, b1, h, par_for);
+                if (!chunk_send(k, base + doff + b0, (size_t)(b1 - b0))) rc2 = SPX_EHIP;
+            }
+        }
+        if (rc2 != SPX_OK) { spx_work_free(c, w); return fail(rc2, rc2 == SPX_ENOMEM ? "pinned staging chunk" : "copy of the staged records"); }
+    }
+    const double t1 = now_s();
     HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes), c->copy_stream));
     HIPCHK(hipEventCreateWithFlags(&w->ev_staged, hipEventDisableTiming));
     HIPCHK(hipEventRecord(w->ev_staged, c->copy_stream));
@@ -1404,11 +1495,13 @@ extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const s
                                   spx_bedset *modified_blocks, spx_bedset *marker_blocks)
 {
     if (!w || !ref || !out) return fail(SPX_EINVAL, "NULL argument");
+    const double t_rb0 = now_s();
     if (w->staged) {
         if (!w->owner) return fail(SPX_EINVAL, "work list has no context");
         int rc = pull_marker_mirrors(w->owner, const_cast<spx_work *>(w));
         if (rc) return rc;
     }
+    const double t_rb1 = now_s();
     const spx::HostBatch &hb = w->hb;
     if (marker_blocks && !w->staged && w->posmin_host.size() != hb.markers.size()) return fail(SPX_EINVAL, "spx_collect has not run");
     int n = 0;
@@ -1434,6 +1527,7 @@ extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const s
             spx_bedset_add_points(marker_blocks, contig, pts.data(), (int32_t)pts.size());
         }
     }
+    if (timing_on()) fprintf(stderr, "[spx timing] relabel blocks: marker arrays back from the device %.3f s, sets %.3f s\n", t_rb1 - t_rb0, now_s() - t_rb1);
     return n;
 }
 
