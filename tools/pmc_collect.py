@@ -37,11 +37,14 @@ def main():
     ap.add_argument("--full", action="store_true", help="the whole pipelined step (preparation kernels included) instead of --kernel-only")
     a = ap.parse_args()
     os.environ.setdefault("TMPDIR", "/tmp")
+    # build once, here: the profiled bench never builds (a process the profiler has initialised must not spawn compilers)
+    subprocess.check_call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT)
     res, meta = {}, {"platform": a.platform, "steps": a.steps, "warmup": a.warmup, "passes": PASSES,
                      "note": "each pass = rocprofv3 --pmc <counters> -- python3 bench.py ...; dispatches are serialised under "
                              "--pmc, so duration_ns_alone is the kernel alone on the chip; FETCH_SIZE/WRITE_SIZE in KB"}
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--platform", a.platform, "--steps", str(a.steps), "--warmup",
-             str(a.warmup), "--no-cpu-baseline", "--verify", "0"] + (["--no-host-leg", "--depth", "1"] if a.full else ["--kernel-only"]) + a.extra
+             str(a.warmup), "--no-cpu-baseline", "--verify", "0", "--no-build", "--no-from-bam", "--no-also"] + \
+            (["--no-host-leg", "--depth", "1"] if a.full else ["--kernel-only"]) + a.extra
     if a.groups_per_step:
         bench += ["--groups-per-step", str(a.groups_per_step)]
     for k, ctrs in enumerate(PASSES):
