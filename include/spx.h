@@ -210,7 +210,12 @@ int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *b
                           const spx_group_out *out);
 
 /* single banded-HMM problem on the device (unit tests / drop-in for the htslib symbol).
- * Uses a process-wide context on device 0 created on first use. */
+ * Uses a process-wide context on device 0 created on first use.
+ * RESTRICTION: iqual must be NULL (htslib then assumes Q30) or hold ONE value for all bases -- which is the only way
+ * secphase calls it (submodules/ptMarker/ptMarker.c:747-749 fills the array with set_q before the call at :755).  The
+ * kernels keep the two emission values of that quality in registers for the whole problem; base-by-base qualities
+ * (samtools' BAQ use of probaln_glocal) are refused: the call returns INT_MIN and spx_last_error() says why, nothing is
+ * computed with a wrong model. */
 int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
                        const spx_probaln_par *c, int *state, uint8_t *q);
 

@@ -426,6 +426,42 @@ def test_command_line_drop_in(ctx, tmp_path):
     assert f"Number of reads modified by marker score = {nre}" in p.stderr
 
 
+def test_command_line_several_devices(ctx, tmp_path):
+    """secphase --devices 0,0,0 : three scoring contexts (here on one GPU), batches dealt round-robin, results taken in file
+    order by ONE finalizer -- the relabel list (tie groups included: their rand() draws are replayed in file order), both
+    BEDs and the counters are byte-identical to the oracle's single stream (src/secphase.c:194-217 at -@1)."""
+    import subprocess
+    g = small_genome(synth.HIFI, max_secondaries=4, n_paralogs=3, read_len=4000, min_secondaries=0, paralog_snv_rate=0.0002)
+    chunks = [g.reads(i * 50, 50) for i in range(6)]
+    whole = g.reads(0, 300)
+    fa, bam = str(tmp_path / "asm.fa"), str(tmp_path / "reads.bam")
+    synth.write_fasta(fa, g.ref)
+    synth.write_bam(bam, [c.batch for c in chunks], g.ref, threads=2)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "secphase_amd", "bin", "secphase")
+    par = records.preset("hifi")
+    par.prim_margin_score = 5.0
+    log_o, bm_o, bk_o = (str(tmp_path / n) for n in ("o.log", "o.mod.bed", "o.mk.bed"))
+    nre, res = orc.run_batch(whole.batch, g.ref, par, threads=2, seed=1, log_path=log_o, bed_modified=bm_o, bed_markers=bk_o)
+    ties = 0
+    for e in res:
+        if e.n_aln >= 2:
+            sec = [a for a in range(e.n_aln) if a != e.prim_idx]
+            mxs = max(e.score[a] for a in sec)
+            ties += sum(1 for a in sec if e.score[a] >= mxs) > 1
+    assert ties > 0 and nre > 5
+    for devs, batch in (("0,0,0", "17"), ("0-0", "40"), ("0,0", "1000")):
+        outd = str(tmp_path / f"out_{batch}")
+        p = subprocess.run([exe, "--hifi", "-p", "5", "-@", "4", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t", "--devices", devs,
+                            "--groupsPerBatch", batch], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False), devs
+        assert filecmp.cmp(bm_o, os.path.join(outd, "t.modified_read_blocks.markers.bed"), shallow=False)
+        assert filecmp.cmp(bk_o, os.path.join(outd, "t.marker_blocks.bed"), shallow=False)
+        assert f"Number of reads modified by marker score = {nre}" in p.stderr
+    p = subprocess.run([exe, "--hifi", "-i", bam, "-f", fa, "--outDir", str(tmp_path / "bad"), "--devices", "0,99"], capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "device" in p.stderr
+
+
 def _quals_parity(ctx, genome, reads, params):
     """all-rows work list (-w/--writeBam): record qualities after BAQ equal the oracle's, scores unchanged"""
     import copy
