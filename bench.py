@@ -149,7 +149,7 @@ def also_leg(platform, steps, warmup):
     this very script; its JSON line is returned (cut down to the figures the headline has)"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
-           "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--distinct", "3", "--verify", "64", "--cpu-runs", "1"]
+           "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--distinct", "4", "--verify", "64", "--cpu-runs", "1"]
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--platform", default="hifi", choices=["hifi", "ont", "mixed"])
     ap.add_argument("--kernel-only", action="store_true", help="only the replay of one prepared work list (profiles, kernel A/B)")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight in the pipeline")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline (their device preparations run side by side)")
     ap.add_argument("--distinct", type=int, default=4, help="at most this many distinct batches per rank (HBM / host memory)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")

@@ -281,17 +281,9 @@ void chunk_unref_locked(Reader *r, Chunk *c)
 void inflate_blocks(Reader *r, Chunk *c, size_t b0, size_t b1)
 {
     thread_local Inflater inf;
-    static const bool use_pread = getenv("SPX_BAM_PREAD") != nullptr;
-    thread_local std::vector<uint8_t> cbuf;
     for (size_t q = b0; q < b1; ++q) {
         const Block &b = c->blocks[q];
-        const uint8_t *src = r->map + b.coff;
-        if (use_pread && !r->map_is_malloc) {
-            cbuf.resize(65536 + 64);
-            if (pread(r->fd, cbuf.data(), b.clen, (off_t)b.coff) != (ssize_t)b.clen) { c->bad = 1; continue; }
-            src = cbuf.data();
-        }
-        if (!inf.run(src, b.clen, c->data + b.uoff, b.ulen)) { c->bad = 1; continue; }
+        if (!inf.run(r->map + b.coff, b.clen, c->data + b.uoff, b.ulen)) { c->bad = 1; continue; }
         if (r->check_crc && crc_of(c->data + b.uoff, b.ulen) != b.crc) c->bad = 2;
     }
 }
@@ -888,23 +880,6 @@ extern "C" int spx_bam_open_opts(const char *path, const spx_bam_options *opt, s
     const size_t want = std::max(std::min<size_t>((size_t)4 << 40, 2 * (r->soft_cap_slots + 8) * slot), 8 * slot);
     if (!r->arena.init(slot, want)) return bail("cannot reserve the inflate arena");
     r->pool.reset(new spx::Pool(r->threads));
-    if (getenv("SPX_BAM_POPULATE_ALL") && !r->map_is_malloc) { /* experiment: the whole mapping faulted in up front */
-        const size_t step = (size_t)64 << 20;
-        const uint8_t *mb = r->map;
-        const size_t fs = r->fsize;
-        r->pool->parallel_for((int64_t)((fs + step - 1) / step), 1, [mb, fs, step](int64_t a, int64_t b) {
-            for (int64_t k = a; k < b; ++k) (void)madvise((void *)(mb + (size_t)k * step), std::min(step, fs - (size_t)k * step), MADV_POPULATE_READ);
-        });
-        r->populated = fs;
-    }
-    if (const char *e = getenv("SPX_BAM_PRETOUCH_GB")) { /* experiment: arena pages touched up front */
-        const size_t nb = std::min((size_t)atoll(e) << 30, (size_t)r->arena.n_max * slot);
-        uint8_t *ab = r->arena.aligned;
-        const size_t step = (size_t)2 << 20;
-        r->pool->parallel_for((int64_t)(nb / step), 64, [ab, step](int64_t a, int64_t b) {
-            for (int64_t k = a; k < b; ++k) ab[(size_t)k * step] = 1, ab[(size_t)k * step + 4096] = 1;
-        });
-    }
     r->fpos = start_coff;
     /* the walker starts start_uoff bytes into its first chunk */
     r->batch_groups = o.batch_groups > 0 ? o.batch_groups : 0;

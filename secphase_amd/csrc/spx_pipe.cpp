@@ -21,6 +21,11 @@
 
 extern "C" void spx_internal_set_error(const char *msg);
 extern "C" int spx_internal_work_claim(spx_work *w, int claim); /* 1: mark in flight (fails when it already is), 0: clear */
+struct spx_alloc_gate;
+extern "C" spx_alloc_gate *spx_internal_gate_create(void);
+extern "C" void spx_internal_gate_free(spx_alloc_gate *g);
+extern "C" void spx_internal_gate_skip(spx_alloc_gate *g, int64_t ticket);
+extern "C" void spx_internal_work_gate(spx_work *w, spx_alloc_gate *g, int64_t ticket);
 
 namespace {
 
@@ -50,12 +55,15 @@ struct spx_pipe {
     bool stop = false;
     std::vector<std::thread> workers;
     /* Device memory is handed out in SUBMISSION order: a job stages (takes the HBM of its records) only after every
-     * older job has staged, and builds its work list only after every older job holds its list.  Results are delivered
-     * in order and a list is freed by the caller after delivery, so the oldest job in flight can always finish; a
-     * younger job that took memory first could leave it waiting for ever (the lists of 16 384 ONT groups take ~70 GB each).
-     * Staging of job k+1 still overlaps the preparation / kernels of job k. */
-    int64_t next_ticket = 0, stage_turn = 0, prep_turn = 0;
+     * older job has staged, and its work list takes its memory only after every older job holds its list (the allocation
+     * gate inside spx_prepare_staged).  Results are delivered in order and a list is freed by the caller after delivery,
+     * so the oldest job in flight can always finish; a younger job that took memory first could leave it waiting for
+     * ever (the lists of 16 384 ONT groups take ~70 GB each).  The device PREPARATIONS of several jobs run side by side
+     * (preparation lanes of the context: chains of dependent loads that leave the chip idle); the DP launches go out in
+     * submission order again. */
+    int64_t next_ticket = 0, stage_turn = 0, launch_turn = 0;
     std::condition_variable cv_turn;
+    spx_alloc_gate *gate = nullptr;
 };
 
 static void run_job(spx_pipe *p, Job *j)
@@ -70,18 +78,26 @@ static void run_job(spx_pipe *p, Job *j)
         j->own_work = rc == SPX_OK;
     }
     {
-        std::unique_lock<std::mutex> lk(p->mu);
-        ++p->stage_turn;
-        p->cv_turn.notify_all();
-        p->cv_turn.wait(lk, [&] { return p->prep_turn == j->ticket; });
-    }
-    if (rc == SPX_OK) rc = spx_prepare_staged(p->ctx, j->work);
-    {
         std::lock_guard<std::mutex> lk(p->mu);
-        ++p->prep_turn;
+        ++p->stage_turn;
     }
     p->cv_turn.notify_all();
+    if (rc == SPX_OK) {
+        spx_internal_work_gate(j->work, p->gate, j->ticket);
+        rc = spx_prepare_staged(p->ctx, j->work);
+        spx_internal_work_gate(j->work, nullptr, 0);
+    }
+    spx_internal_gate_skip(p->gate, j->ticket); /* (no-op when the preparation went through the gate) */
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_turn.wait(lk, [&] { return p->launch_turn == j->ticket; });
+    }
     if (rc == SPX_OK) rc = spx_launch(p->ctx, j->work);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        ++p->launch_turn;
+    }
+    p->cv_turn.notify_all();
     if (rc == SPX_OK) {
         j->out.resize((size_t)(j->n_groups > 0 ? j->n_groups : 1));
         rc = spx_collect(p->ctx, j->work, j->out.data());
@@ -119,6 +135,7 @@ extern "C" int spx_pipe_create(spx_ctx *ctx, const spx_params *par, int depth, i
     p->depth = depth < 1 ? 1 : (depth > 8 ? 8 : depth);
     int ht = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
     p->stage_threads = ht > 0 ? ht : 1; /* stagings run one after the other (ticket order): each gets all the threads */
+    p->gate = spx_internal_gate_create();
     for (int t = 0; t < p->depth; ++t) p->workers.emplace_back(worker_main, p);
     *out = p;
     return SPX_OK;
@@ -213,5 +230,6 @@ extern "C" void spx_pipe_destroy(spx_pipe *p)
         if (j->own_work && j->work) spx_work_free(p->ctx, j->work);
         delete j;
     }
+    spx_internal_gate_free(p->gate);
     delete p;
 }

@@ -123,24 +123,33 @@ struct spx_ctx {
     std::unique_ptr<spx::Pool> stage_pool;
     /* work-list preparation on the device: its own stream (it overlaps the DP kernels of the previous list), pools
      * that only live during a preparation and are shared by all of them (prep_mu serialises preparations) */
-    hipStream_t prep_stream = nullptr;
-    int prep_cus = 0; /* CUs reserved for the preparation stream (0: no CU masks) */
-    std::mutex prep_mu;
+    int prep_cus = 0; /* CUs reserved for the preparation streams (0: no CU masks) */
     struct DevBuf {
         void *p = nullptr;
         size_t cap = 0;
-    } pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort;
-    spx_prep_totals *d_tot = nullptr, *h_tot = nullptr; /* device / pinned host */
-    int32_t *d_bins = nullptr;                          /* 3 x SPX_N_CLASSES x 1024 */
+    };
+    /* Preparation LANES (round 3): the preparation kernels are chains of dependent loads -- one lane walks one alignment --
+     * that leave most of the chip idle, and their duration is set by the longest alignment of the batch, not by the number
+     * of groups.  So the preparations of several batches run SIDE BY SIDE, each on its own stream with its own pools
+     * (a lane's mutex serialises the preparations that share it; work list w uses lane w->lane). */
+    static const int SPX_N_PREP = 3;
+    struct PrepLane {
+        hipStream_t stream = nullptr;
+        std::mutex mu;
+        DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort;
+        spx_prep_totals *d_tot = nullptr, *h_tot = nullptr; /* device / pinned host */
+        int32_t *d_bins = nullptr;                          /* 3 x SPX_N_CLASSES x 1024 */
+    } lane[SPX_N_PREP];
+    std::atomic<unsigned> lane_rr{0};
 };
 
-/* grow-only device buffer; the caller holds prep_mu.  Kernels of an earlier preparation may still read the old
- * allocation, so the stream is drained before it is released. */
-static int ensure_pool(spx_ctx *c, spx_ctx::DevBuf &b, size_t bytes)
+/* grow-only device buffer of a preparation lane; the caller holds the lane's mutex.  Kernels of an earlier preparation
+ * may still read the old allocation, so the lane's stream is drained before it is released. */
+static int ensure_pool(spx_ctx::PrepLane &PL, spx_ctx::DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return SPX_OK;
     if (b.p) {
-        if (hipStreamSynchronize(c->prep_stream) != hipSuccess) return SPX_EHIP;
+        if (hipStreamSynchronize(PL.stream) != hipSuccess) return SPX_EHIP;
         (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
@@ -149,6 +158,23 @@ static int ensure_pool(spx_ctx *c, spx_ctx::DevBuf &b, size_t bytes)
     if (hipMalloc(&b.p, want) != hipSuccess) { (void)hipGetLastError(); return SPX_ENOMEM; }
     b.cap = want;
     return SPX_OK;
+}
+
+/* work lists of one pipeline take the memory of their lists in ticket order */
+struct spx_alloc_gate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t turn = 0;
+};
+extern "C" spx_alloc_gate *spx_internal_gate_create(void) { return new spx_alloc_gate(); }
+extern "C" void spx_internal_gate_free(spx_alloc_gate *g) { delete g; }
+/* a ticket that will never reach the allocation (its job failed earlier) is passed over */
+extern "C" void spx_internal_gate_skip(spx_alloc_gate *g, int64_t ticket)
+{
+    if (!g) return;
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [&] { return g->turn >= ticket; });
+    if (g->turn == ticket) { ++g->turn; g->cv.notify_all(); }
 }
 
 struct spx_work {
@@ -200,6 +226,10 @@ struct spx_work {
     std::vector<uint8_t> posmin_host; /* filled by spx_collect: per first-of-position marker, min quality */
     std::vector<uint8_t> bq_host;     /* filled by spx_apply_quals: BAQ value of every wanted row */
     std::atomic<int> in_pipe{0};      /* submitted to a pipeline and not yet delivered: no second submission, no release */
+    int lane = 0;                     /* preparation lane of the latest spx_prepare_staged */
+    /* a pipeline's allocation gate: work lists take their device memory in submission order (see spx_pipe.cpp) */
+    spx_alloc_gate *gate = nullptr;
+    int64_t gate_ticket = 0;
 };
 
 extern "C" const char *spx_strerror(int code)
@@ -219,6 +249,13 @@ extern "C" const char *spx_strerror(int code)
 extern "C" const char *spx_last_error(void) { return g_err.c_str(); }
 /* internal: lets the pipeline hand a worker thread's error text to the thread that asks for the results */
 extern "C" void spx_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+
+extern "C" void spx_internal_work_gate(spx_work *w, spx_alloc_gate *g, int64_t ticket)
+{
+    if (!w) return;
+    w->gate = g;
+    w->gate_ticket = ticket;
+}
 
 extern "C" int spx_internal_work_claim(spx_work *w, int claim)
 {
@@ -280,12 +317,15 @@ extern "C" int spx_create(int device, spx_ctx **out)
         }
         return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     };
-    HIPCHK(mk_stream(&c->prep_stream, m_prep));
+    for (int l = 0; l < spx_ctx::SPX_N_PREP; ++l) {
+        spx_ctx::PrepLane &PL = c->lane[l];
+        HIPCHK(mk_stream(&PL.stream, m_prep));
+        HIPCHK(hipMalloc((void **)&PL.d_tot, sizeof(spx_prep_totals)));
+        HIPCHK(hipHostMalloc((void **)&PL.h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&PL.d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
+    }
     c->prep_cus = masked ? prep_cus : 0;
     HIPCHK(mk_stream(&c->stream, m_dp));
-    HIPCHK(hipMalloc((void **)&c->d_tot, sizeof(spx_prep_totals)));
-    HIPCHK(hipHostMalloc((void **)&c->h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
-    HIPCHK(hipMalloc((void **)&c->d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
     for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
     for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
@@ -318,12 +358,15 @@ extern "C" void spx_destroy(spx_ctx *c)
         if (c->pin_done[k]) (void)hipEventDestroy(c->pin_done[k]);
     }
     c->stage_pool.reset();
-    for (spx_ctx::DevBuf *b : {&c->pool_ops, &c->pool_conf, &c->pool_mm, &c->pool_garena, &c->pool_keys, &c->pool_sort})
-        if (b->p) (void)hipFree(b->p);
-    if (c->d_tot) (void)hipFree(c->d_tot);
-    if (c->h_tot) (void)hipHostFree(c->h_tot);
-    if (c->d_bins) (void)hipFree(c->d_bins);
-    if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
+    for (int l = 0; l < spx_ctx::SPX_N_PREP; ++l) {
+        spx_ctx::PrepLane &PL = c->lane[l];
+        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort})
+            if (b->p) (void)hipFree(b->p);
+        if (PL.d_tot) (void)hipFree(PL.d_tot);
+        if (PL.h_tot) (void)hipHostFree(PL.h_tot);
+        if (PL.d_bins) (void)hipFree(PL.d_bins);
+        if (PL.stream) (void)hipStreamDestroy(PL.stream);
+    }
     for (int i = 0; i < 6; ++i)
         for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
             if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
@@ -817,23 +860,24 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.P.code4 = (const uint8_t *)(base + w->o_code);
     A.P.code_lead_bytes = spx::kCodeLeadBytes;
     A.code4_w = (uint8_t *)(base + w->o_code);
-    A.P.ops = (spxl::Op *)c->pool_ops.p;
-    A.P.conf = (spxl::Blk *)c->pool_conf.p;
-    A.P.mm = (spxl::MM *)c->pool_mm.p;
+    spx_ctx::PrepLane &PL = c->lane[w->lane];
+    A.P.ops = (spxl::Op *)PL.pool_ops.p;
+    A.P.conf = (spxl::Blk *)PL.pool_conf.p;
+    A.P.mm = (spxl::MM *)PL.pool_mm.p;
     A.rv = c->d_rv;
     A.par = spx::logic_params(&w->par);
     A.gc = (spxl::GroupCount *)(base + w->o_gc);
     A.ac = (spxl::GroupCount *)(base + w->o_ac);
     A.ga_bytes = (int64_t *)(base + w->o_gab);
     A.ga_off = (int64_t *)(base + w->o_gao);
-    A.arena = (char *)c->pool_garena.p;
-    A.arena_cap = (int64_t)c->pool_garena.cap;
+    A.arena = (char *)PL.pool_garena.p;
+    A.arena_cap = (int64_t)PL.pool_garena.cap;
     A.slack = 1;
     A.scan_stride = (int64_t)std::max(L.n_slots, L.n_dgroups) + 8;
     A.scan_v = (int64_t *)(base + w->o_scan);
     A.scan_tile = A.scan_v + 5 * A.scan_stride;
     A.scan_grand = A.scan_tile + 5 * 1024;
-    A.tot = c->d_tot;
+    A.tot = PL.d_tot;
 }
 
 /* Step 2: the work list is built ON THE DEVICE from the staged records (spx_prep_kernels.hip).  One small copy of the
@@ -846,7 +890,29 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     HIPCHK(hipSetDevice(c->device));
     const spx::StageLayout &L = w->stage.lay;
     const size_t ns = (size_t)L.n_slots, ng = (size_t)L.n_dgroups;
-    std::lock_guard<std::mutex> lk(c->prep_mu);
+    /* whatever happens below, this list's turn at the pipeline's allocation gate is used up when we leave */
+    struct GateGuard {
+        spx_work *w;
+        bool passed = false;
+        void wait()
+        {
+            if (!w->gate || passed) return;
+            std::unique_lock<std::mutex> lk(w->gate->mu);
+            w->gate->cv.wait(lk, [&] { return w->gate->turn >= w->gate_ticket; });
+        }
+        void pass()
+        {
+            if (!w->gate || passed) return;
+            passed = true;
+            std::lock_guard<std::mutex> lk(w->gate->mu);
+            if (w->gate->turn == w->gate_ticket) { ++w->gate->turn; w->gate->cv.notify_all(); }
+        }
+        ~GateGuard() { if (w->gate && !passed) { wait(); pass(); } }
+    } gate{w};
+    w->lane = (int)(c->lane_rr.fetch_add(1) % spx_ctx::SPX_N_PREP);
+    if (w->gate) w->lane = (int)(w->gate_ticket % spx_ctx::SPX_N_PREP);
+    spx_ctx::PrepLane &PL = c->lane[w->lane];
+    std::lock_guard<std::mutex> lk(PL.mu);
     const double t0 = now_s();
     if (w->arena) { /* re-preparation: the previous list of this work must have left the device */
         if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done));
@@ -861,13 +927,13 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     int rc;
     auto size_pools = [&]() -> int {
         int r_;
-        if ((r_ = ensure_pool(c, c->pool_ops, ops_bound * sizeof(spxl::Op))) || (r_ = ensure_pool(c, c->pool_conf, conf_bound * sizeof(spxl::Blk))) ||
-            (r_ = ensure_pool(c, c->pool_mm, mm_bound * sizeof(spxl::MM))))
+        if ((r_ = ensure_pool(PL, PL.pool_ops, ops_bound * sizeof(spxl::Op))) || (r_ = ensure_pool(PL, PL.pool_conf, conf_bound * sizeof(spxl::Blk))) ||
+            (r_ = ensure_pool(PL, PL.pool_mm, mm_bound * sizeof(spxl::MM))))
             return r_;
         return 0;
     };
     if ((rc = size_pools())) return fail(rc, "device memory for the preparation pools");
-    if ((rc = ensure_pool(c, c->pool_garena, (size_t)(32u << 20) + ns * 4096))) return fail(rc, "device memory for the group scratch");
+    if ((rc = ensure_pool(PL, PL.pool_garena, (size_t)(32u << 20) + ns * 4096))) return fail(rc, "device memory for the group scratch");
     fill_prep_args(c, w);
     spx_prep_args &A = w->pa;
     A.ops_cap = (int64_t)ops_bound; A.conf_cap = (int64_t)conf_bound; A.mm_cap = (int64_t)mm_bound;
@@ -876,18 +942,18 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     char *base = (char *)w->in_arena;
     spxl::PlanBase *d_base = (spxl::PlanBase *)(base + w->o_base);
     int64_t *d_mkb = (int64_t *)(base + w->o_mkb);
-    if (w->ev_staged) HIPCHK(hipStreamWaitEvent(c->prep_stream, w->ev_staged, 0));
-    HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
+    if (w->ev_staged) HIPCHK(hipStreamWaitEvent(PL.stream, w->ev_staged, 0));
+    HIPCHK(hipMemsetAsync(PL.d_tot, 0, sizeof(spx_prep_totals), PL.stream));
     bool phase1 = true;
     for (int attempt = 0;; ++attempt) {
         if (phase1) {
-            HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), c->prep_stream));
-            HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, c->prep_stream));
+            HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), PL.stream));
+            HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, PL.stream));
         }
-        HIPCHK(spx_prep_phase2(&A, d_base, d_mkb, c->prep_stream));
-        HIPCHK(hipMemcpyAsync(c->h_tot, c->d_tot, sizeof(spx_prep_totals), hipMemcpyDeviceToHost, c->prep_stream));
-        HIPCHK(hipStreamSynchronize(c->prep_stream));
-        w->tot = *c->h_tot;
+        HIPCHK(spx_prep_phase2(&A, d_base, d_mkb, PL.stream));
+        HIPCHK(hipMemcpyAsync(PL.h_tot, PL.d_tot, sizeof(spx_prep_totals), hipMemcpyDeviceToHost, PL.stream));
+        HIPCHK(hipStreamSynchronize(PL.stream));
+        w->tot = *PL.h_tot;
         const int ov = w->tot.overflow;
         if (!ov) break;
         if (attempt >= 8) return fail(SPX_ENOMEM, "preparation scratch keeps overflowing");
@@ -899,19 +965,19 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
             conf_bound = std::max(conf_bound, (size_t)w->tot.n_conf + 16);
             mm_bound = std::max(mm_bound, (size_t)w->tot.n_mm + 16);
             if ((rc = size_pools())) return fail(rc, "device memory for the preparation pools");
-            A.P.ops = (spxl::Op *)c->pool_ops.p; A.P.conf = (spxl::Blk *)c->pool_conf.p; A.P.mm = (spxl::MM *)c->pool_mm.p;
+            A.P.ops = (spxl::Op *)PL.pool_ops.p; A.P.conf = (spxl::Blk *)PL.pool_conf.p; A.P.mm = (spxl::MM *)PL.pool_mm.p;
             A.ops_cap = (int64_t)ops_bound; A.conf_cap = (int64_t)conf_bound; A.mm_cap = (int64_t)mm_bound;
         } else if (ov & 2) {
             A.slack *= 4;
-            if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes * 4 + 4096))) return fail(rc, "device memory for the group scratch");
-            A.arena = (char *)c->pool_garena.p;
-            A.arena_cap = (int64_t)c->pool_garena.cap;
+            if ((rc = ensure_pool(PL, PL.pool_garena, (size_t)w->tot.arena_bytes * 4 + 4096))) return fail(rc, "device memory for the group scratch");
+            A.arena = (char *)PL.pool_garena.p;
+            A.arena_cap = (int64_t)PL.pool_garena.cap;
         } else {
-            if ((rc = ensure_pool(c, c->pool_garena, (size_t)w->tot.arena_bytes + 4096))) return fail(rc, "device memory for the group scratch");
-            A.arena = (char *)c->pool_garena.p;
-            A.arena_cap = (int64_t)c->pool_garena.cap;
+            if ((rc = ensure_pool(PL, PL.pool_garena, (size_t)w->tot.arena_bytes + 4096))) return fail(rc, "device memory for the group scratch");
+            A.arena = (char *)PL.pool_garena.p;
+            A.arena_cap = (int64_t)PL.pool_garena.cap;
         }
-        HIPCHK(hipMemsetAsync(c->d_tot, 0, sizeof(spx_prep_totals), c->prep_stream));
+        HIPCHK(hipMemsetAsync(PL.d_tot, 0, sizeof(spx_prep_totals), PL.stream));
     }
     if (getenv("SPX_DEBUG_GC")) { /* debugging aid: the per-group and per-alignment state the device arrived at */
         std::vector<spxl::GroupCount> hg(ng);
@@ -968,12 +1034,14 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
                  o_results = cv.take<spx_group_out>(ng + 1);
     (void)in_bytes;
     w->arena_bytes = cv.off + 256;
+    gate.wait(); /* lists of one pipeline take their memory in submission order: the oldest can always finish */
     w->arena = arena_get(c, w->arena_bytes, &w->arena_cap);
+    gate.pass();
     if (!w->arena) return fail(SPX_ENOMEM, "device memory for the work list");
     char *B0 = (char *)w->arena;
     /* temporaries of the launch-order sort (context pools) */
     const size_t sort_tmp = spx_order_temp_bytes((int32_t)np);
-    if ((rc = ensure_pool(c, c->pool_keys, (np + 16) * (3 * 8 + 2 * 4))) || (rc = ensure_pool(c, c->pool_sort, sort_tmp + 256)))
+    if ((rc = ensure_pool(PL, PL.pool_keys, (np + 16) * (3 * 8 + 2 * 4))) || (rc = ensure_pool(PL, PL.pool_sort, sort_tmp + 256)))
         return fail(rc, "device memory for the launch-order sort");
     spx_emit_args E;
     memset(&E, 0, sizeof E);
@@ -995,26 +1063,26 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     E.sec_mask = (uint16_t *)(B0 + o_sec);
     E.rfe = (int32_t *)(B0 + o_rfe); E.rfs = (int32_t *)(B0 + o_rfs); E.atid = (int32_t *)(B0 + o_atid);
     E.info = (spx_group_info *)(B0 + o_info);
-    HIPCHK(hipMemsetAsync(B0 + o_mk_first, 0, (ng + 2) * 4, c->prep_stream));
-    HIPCHK(spx_prep_emit(&A, &E, c->prep_stream));
+    HIPCHK(hipMemsetAsync(B0 + o_mk_first, 0, (ng + 2) * 4, PL.stream));
+    HIPCHK(spx_prep_emit(&A, &E, PL.stream));
     /* launch orders */
-    HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (order_f_n + 64) * 4, c->prep_stream));
-    HIPCHK(hipMemsetAsync(B0 + o_order_b, 0xff, (order_b_n + 64) * 4, c->prep_stream));
+    HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (order_f_n + 64) * 4, PL.stream));
+    HIPCHK(hipMemsetAsync(B0 + o_order_b, 0xff, (order_b_n + 64) * 4, PL.stream));
     if (np) {
         spx_order_args O;
         memset(&O, 0, sizeof O);
         O.n_prob = (int32_t)np;
         O.bw = E.out.bw; O.L = E.out.L; O.n_rows = E.out.n_rows; O.row_off = E.out.row_off; O.rows = E.out.rows;
-        char *kp = (char *)c->pool_keys.p;
+        char *kp = (char *)PL.pool_keys.p;
         O.key_f = (uint64_t *)kp; O.key_b = O.key_f + (np + 2); O.key_sorted = O.key_b + (np + 2);
         O.val = (int32_t *)(O.key_sorted + (np + 2)); O.val_sorted = O.val + (np + 2);
-        O.bin_start = c->d_bins; O.bin_end = c->d_bins + SPX_N_CLASSES * 1024; O.pad_base = c->d_bins + 2 * SPX_N_CLASSES * 1024;
-        O.temp = c->pool_sort.p; O.temp_bytes = sort_tmp;
+        O.bin_start = PL.d_bins; O.bin_end = PL.d_bins + SPX_N_CLASSES * 1024; O.pad_base = PL.d_bins + 2 * SPX_N_CLASSES * 1024;
+        O.temp = PL.pool_sort.p; O.temp_bytes = sort_tmp;
         O.order_f = (int32_t *)(B0 + o_order_f); O.order_b = (int32_t *)(B0 + o_order_b);
-        HIPCHK(spx_prep_orders(&O, &sf, &sb, c->prep_stream));
+        HIPCHK(spx_prep_orders(&O, &sf, &sb, PL.stream));
     }
     if (!w->ev_ready) HIPCHK(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(w->ev_ready, c->prep_stream));
+    HIPCHK(hipEventRecord(w->ev_ready, PL.stream));
     /* ---- kernel argument blocks ---- */
     w->d_bq = (uint8_t *)(B0 + o_bq);
     w->d_posmin = (uint8_t *)(B0 + o_posmin);
@@ -1206,8 +1274,13 @@ extern "C" int spx_trim(spx_ctx *c)
 {
     if (!c) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
-    std::lock_guard<std::mutex> pl(c->prep_mu);
-    HIPCHK(hipStreamSynchronize(c->prep_stream));
+    for (int l = 0; l < spx_ctx::SPX_N_PREP; ++l) {
+        spx_ctx::PrepLane &PL = c->lane[l];
+        std::lock_guard<std::mutex> pl(PL.mu);
+        HIPCHK(hipStreamSynchronize(PL.stream));
+        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort})
+            if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     {
         std::lock_guard<std::mutex> lk(c->arena_mu);
@@ -1216,8 +1289,6 @@ extern "C" int spx_trim(spx_ctx *c)
         for (auto &a : c->pinned_cache) (void)hipHostFree(a.first);
         c->pinned_cache.clear();
     }
-    for (spx_ctx::DevBuf *b : {&c->pool_ops, &c->pool_conf, &c->pool_mm, &c->pool_garena, &c->pool_keys, &c->pool_sort})
-        if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     c->arena_cv.notify_all();
     return SPX_OK;
 }
@@ -1433,7 +1504,7 @@ extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
     if (c && (w->arena || w->in_arena)) { /* nothing of this work list may still be running */
         if (w->ev_staged) (void)hipEventSynchronize(w->ev_staged);
         if (w->ev_ready) (void)hipEventSynchronize(w->ev_ready);
-        else if (w->staged) (void)hipStreamSynchronize(c->prep_stream);
+        else if (w->staged) (void)hipStreamSynchronize(c->lane[w->lane].stream);
         if (w->ev_done) (void)hipEventSynchronize(w->ev_done);
         else (void)hipStreamSynchronize(c->stream);
     }
@@ -1778,7 +1849,7 @@ extern "C" int spx_work_export(spx_ctx *c, spx_work *w, spx_plan **out)
     if (!c || !w || !out) return fail(SPX_EINVAL, "NULL argument");
     if (!w->staged || !w->prepared) return fail(SPX_EINVAL, "not a device-prepared work list");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->prep_stream));
+    HIPCHK(hipStreamSynchronize(c->lane[w->lane].stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     spx_plan *p = new spx_plan();
     spx::HostBatch &hb = p->hb;
