@@ -149,7 +149,9 @@ def also_leg(platform, steps, warmup):
     this very script; its JSON line is returned (cut down to the figures the headline has)"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
-           "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--distinct", "4", "--verify", "64", "--cpu-runs", "1"]
+           "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "1"]
+    # (mixed: small batches whose preparations overlap -- one more in flight; ONT: ~70 GB of saved rows per list in flight)
+    cmd += ["--distinct", "5", "--depth", "4"] if platform == "mixed" else ["--distinct", "4", "--depth", "3"]
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
@@ -202,7 +204,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per stream of the context (before HIP initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # one hardware queue per stream of the context (before HIP initialises)
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start the one-rank-per-GPU job as a CHILD process -- nothing has touched the
         # GPU yet (torch is not even imported), and the launcher is never exec'd -- and relay its JSON line
@@ -356,7 +358,6 @@ def main():
         pipe = api.Pipe(ctx, params, depth=args.depth, host_threads=host_threads)
         api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
     outbuf = (api.GroupOut * gps)()
-    dec_dev = torch.zeros(gps * shard.DECISION_BYTES, dtype=torch.uint8, device="cuda") if world > 1 else None
 
     def out_at(base):
         return C.cast(C.byref(outbuf, base * C.sizeof(api.GroupOut)), C.POINTER(api.GroupOut))
@@ -372,25 +373,16 @@ def main():
                 base += bp.contents.n_groups
             relabelled[0] += sum(1 for g in range(0, n, 997) if outbuf[g].relabel)  # (sampled: keeps Python out of the timing)
             return
-        gbase = (step_global * world + rank) * gps
-        nd = work.pack_decisions(gbase, dec_dev.data_ptr(), gps)  # device -> device, then RCCL
-        dparts = shard.gather_bytes(dec_dev[: nd * shard.DECISION_BYTES].to(coll_dev), dist, torch)
-        cands = []
-        base = 0
-        for bp in ptrs[i]:
-            nc = L.spx_relabel_candidates(bp, gbase + base, out_at(base), C.byref(params), None, 0)
-            if nc > 0:
-                arr = (api.RelabelRec * nc)()
-                L.spx_relabel_candidates(bp, gbase + base, out_at(base), C.byref(params), arr, nc)
-                cands.append(np.frombuffer(memoryview(arr), np.uint8).copy())
-            base += bp.contents.n_groups
-        cbytes = np.concatenate(cands) if cands else np.zeros(0, np.uint8)
-        cparts = shard.gather_bytes(torch.from_numpy(cbytes).to(coll_dev), dist, torch)
+        # N > 1 (round 3): every rank decides its own groups -- the ranks exchange the number of draws their groups consume,
+        # each moves its copy of the rand() stream over the others' draws, finalizes and formats its own fragment of the
+        # list; ONE gather (RCCL) brings the fragments to rank 0, which appends them in rank order.  Rank 0 no longer replays
+        # and formats every rank's records (~250 ms per 8 x 131 072 groups against a 170 ms step in round 2).
+        shard.decide_locally(api, params, fin, outbuf, n, dist, torch, coll_dev)
+        relabelled[0] += sum(1 for g in range(0, n, 997) if outbuf[g].relabel)
+        frag = shard.relabel_text(api, ptrs[i], genome.ref, outbuf)
+        parts = shard.gather_bytes(torch.from_numpy(frag).to(coll_dev), dist, torch)
         if rank == 0:
-            # the merge + replay + formatting of ALL ranks' groups (half a million records per step at 8 ranks) runs on a
-            # helper thread, in step order, so that rank 0 keeps feeding its own GPU; the timed region ends only when the
-            # helper has caught up
-            writer_q.put((dparts, cparts))
+            writer_q.put(parts)  # appended on a helper thread; the timed region ends only when it has caught up
 
     import queue
     writer_q = queue.Queue()
@@ -403,8 +395,7 @@ def main():
                 if item is None:
                     return
                 if not writer_err:
-                    _, nw = shard.merge_and_write(api, params, fin, genome.ref, item[0], item[1], log_path)
-                    relabelled[0] += nw
+                    shard.append_fragments(item, log_path)
             except Exception as ex:  # noqa: BLE001
                 writer_err.append(ex)
             finally:
@@ -640,8 +631,9 @@ def main():
                 "dp_cells_per_step": int(cells_all),
                 "wanted_rows_per_step_rank0": int(n_rows),
                 "record_bytes_per_step_rank0": int(bytes_in),
-                "parallelism": (f"reads sharded over {world} GPUs; RCCL gather of 16-byte decision records + candidate records to "
-                                f"rank 0, which replays the draws and writes the list") if world > 1 else "single GPU",
+                "parallelism": (f"reads sharded over {world} GPUs; every rank decides and formats its own groups (draw counts exchanged, "
+                                f"rand() stream kept in global step), ONE RCCL gather of the relabel-list fragments to rank 0, which "
+                                f"appends them in rank order") if world > 1 else "single GPU",
                 "verified_groups_vs_oracle": verified,
                 "rank_imbalance_dp_cells": round(imbalance, 4),
             },

@@ -170,6 +170,14 @@ int spx_finalizer_apply_decisions(spx_finalizer *f, const spx_params *par, const
  * returns how many were written */
 int spx_write_relabel_records(const char *path, const char *mode, const spx_ref *ref, const spx_relabel_rec *recs, int32_t n,
                               const int8_t *best_idx);
+/* Decisions made where the groups are (round 3): the rand() values a rank's groups consume are known locally, so ranks
+ * exchange one count each, pass over the others' draws and finalize + format their own groups; rank 0 appends the text
+ * fragments in rank order -- the same list, without a serial replay of every group on one rank. */
+int64_t spx_count_draws(const spx_group_out *out, int32_t n_groups);
+int spx_finalizer_skip(spx_finalizer *f, int64_t n_draws);
+/* what spx_write_relabel_log would append for a finalized batch, into malloc'ed memory (spx_free_text) */
+int spx_format_relabel_text(const spx_batch *bt, const spx_ref *ref, const spx_group_out *out, char **text, int64_t *len);
+void spx_free_text(char *text);
 int spx_collect(spx_ctx *ctx, spx_work *work, spx_group_out *out);
 /* Quality arrays as the reference leaves them in the records after calc_local_baq (ptMarker.c:706,759,763),
  * for a work list prepared with params.flags & SPX_PAR_ALL_ROWS and already launched.  `qual` must hold a copy

@@ -92,7 +92,8 @@ EXPORTS = [
     "spx_merge_blocks_count", "spx_relabel_blocks",
     "spx_io_last_error", "spx_bam_open", "spx_bam_n_targets", "spx_bam_target_name", "spx_bam_bind_reference",
     "spx_bam_next_batch", "spx_bam_close", "spx_bam_open_opts", "spx_bam_default_options", "spx_bam_release_batch",
-    "spx_bam_index_build", "spx_bam_index_save", "spx_bam_index_load", "spx_fasta_load", "spx_fasta_ref", "spx_fasta_free",
+    "spx_bam_index_build", "spx_bam_index_save", "spx_bam_index_load", "spx_fasta_load",
+    "spx_count_draws", "spx_finalizer_skip", "spx_format_relabel_text", "spx_free_text", "spx_fasta_ref", "spx_fasta_free",
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
@@ -173,6 +174,12 @@ def lib():
     L.spx_host_tables.restype = None
     L.spx_finalizer_create.argtypes = [C.c_uint, C.POINTER(vp)]
     L.spx_finalizer_apply.argtypes = [vp, C.POINTER(SpxParams), C.POINTER(GroupOut), C.c_int32]
+    L.spx_count_draws.argtypes = [C.POINTER(GroupOut), C.c_int32]
+    L.spx_count_draws.restype = C.c_int64
+    L.spx_finalizer_skip.argtypes = [vp, C.c_int64]
+    L.spx_format_relabel_text.argtypes = [C.POINTER(SpxBatch), C.POINTER(SpxRef), C.POINTER(GroupOut), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.spx_free_text.argtypes = [C.c_void_p]
+    L.spx_free_text.restype = None
     L.spx_finalizer_free.argtypes = [vp]
     L.spx_finalizer_free.restype = None
     L.spx_bedset_create.argtypes = [C.POINTER(vp)]

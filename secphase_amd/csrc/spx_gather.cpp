@@ -9,6 +9,13 @@
  *       (margin test passed, or a coin flip decides): read name, per-alignment flag / contig / position / score / end,
  *       i.e. everything print_alignment_scores (src/secphase.c:32-57) writes;
  * rank 0 merges (a) by group index, replays the draws, and writes the records of (b) whose decision is a relabel.
+ *
+ * Round 3, what bench.py does at N > 1: rank 0's replay + formatting of EVERY rank's records was the slowest thing in an
+ * 8-GPU step (~250 ms against a 170 ms step).  The draws a group consumes are known locally (spx_count_draws), so the
+ * ranks exchange ONE number each per step, every rank moves its own copy of the stream over the other ranks' draws
+ * (spx_finalizer_skip), decides its own groups (spx_finalizer_apply) and formats its own fragment of the list
+ * (spx_format_relabel_text); what is gathered over RCCL are the fragments -- the per-read decisions in their final
+ * form -- and rank 0 appends them in rank order.  The record-based path above stays (tests compare the two).
  */
 #include <limits.h>
 #include <stdio.h>
@@ -107,6 +114,18 @@ extern "C" int spx_finalizer_apply_decisions(spx_finalizer *f, const spx_params 
         decide(f, par, dec[k].n_aln, dec[k].prim_idx, dec[k].max_idx, dec[k].tie_mask, dec[k].pass, dec[k].absdiff, &best_idx[k], &relabel[k]);
     }
     return SPX_OK;
+}
+
+/* how many values of the rand() stream the groups out[0..n) consume (ptAlignment.c:163-176: one for the coin, one more
+ * when several secondaries tie) -- what a rank tells the others so that every rank can keep its copy of the stream at the
+ * global position and decide its own groups itself */
+extern "C" int64_t spx_count_draws(const spx_group_out *out, int32_t n_groups)
+{
+    if (!out) return SPX_EINVAL;
+    int64_t n = 0;
+    for (int32_t g = 0; g < n_groups; ++g)
+        if (out[g].n_aln >= 2) n += 1 + (popcount16(out[g].tie_mask) > 1 ? 1 : 0);
+    return n;
 }
 
 extern "C" int spx_finalize(const spx_params *par, unsigned rand_seed, spx_group_out *out, int32_t n_groups)

@@ -132,7 +132,8 @@ struct spx_ctx {
      * that leave most of the chip idle, and their duration is set by the longest alignment of the batch, not by the number
      * of groups.  So the preparations of several batches run SIDE BY SIDE, each on its own stream with its own pools
      * (a lane's mutex serialises the preparations that share it; work list w uses lane w->lane). */
-    static const int SPX_N_PREP = 3;
+    static const int SPX_N_PREP = 6; /* lanes that exist; n_prep of them are used (SPX_PREP_LANES, default 4) */
+    int n_prep = 4;
     struct PrepLane {
         hipStream_t stream = nullptr;
         std::mutex mu;
@@ -277,9 +278,9 @@ extern "C" int spx_create(int device, spx_ctx **out)
     if (!out) return fail(SPX_EINVAL, "out is NULL");
     *out = nullptr;
     /* HIP multiplexes streams onto hardware queues (4 by default): two streams that share one run their kernels one
-     * after the other.  Ask for 8 before the runtime initialises; a process that has initialised HIP already (e.g.
+     * after the other.  Ask for 12 (main, three side, copy and the preparation lanes' streams) before the runtime initialises; a process that has initialised HIP already (e.g.
      * after importing torch) must have set the variable itself -- bench.py and the command line do. */
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SPX_ENODEVICE, "hipGetDeviceCount found no device");
     if (device < 0 || device >= n) return fail(SPX_ENODEVICE, "device index out of range");
@@ -317,7 +318,8 @@ extern "C" int spx_create(int device, spx_ctx **out)
         }
         return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     };
-    for (int l = 0; l < spx_ctx::SPX_N_PREP; ++l) {
+    if (const char *e = getenv("SPX_PREP_LANES")) c->n_prep = std::max(1, std::min(atoi(e), (int)spx_ctx::SPX_N_PREP));
+    for (int l = 0; l < c->n_prep; ++l) {
         spx_ctx::PrepLane &PL = c->lane[l];
         HIPCHK(mk_stream(&PL.stream, m_prep));
         HIPCHK(hipMalloc((void **)&PL.d_tot, sizeof(spx_prep_totals)));
@@ -909,8 +911,8 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         }
         ~GateGuard() { if (w->gate && !passed) { wait(); pass(); } }
     } gate{w};
-    w->lane = (int)(c->lane_rr.fetch_add(1) % spx_ctx::SPX_N_PREP);
-    if (w->gate) w->lane = (int)(w->gate_ticket % spx_ctx::SPX_N_PREP);
+    w->lane = (int)(c->lane_rr.fetch_add(1) % (unsigned)c->n_prep);
+    if (w->gate) w->lane = (int)(w->gate_ticket % c->n_prep);
     spx_ctx::PrepLane &PL = c->lane[w->lane];
     std::lock_guard<std::mutex> lk(PL.mu);
     const double t0 = now_s();
@@ -1274,7 +1276,7 @@ extern "C" int spx_trim(spx_ctx *c)
 {
     if (!c) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(c->device));
-    for (int l = 0; l < spx_ctx::SPX_N_PREP; ++l) {
+    for (int l = 0; l < c->n_prep; ++l) {
         spx_ctx::PrepLane &PL = c->lane[l];
         std::lock_guard<std::mutex> pl(PL.mu);
         HIPCHK(hipStreamSynchronize(PL.stream));
@@ -1559,6 +1561,16 @@ extern "C" int spx_finalizer_draw(spx_finalizer *f, int32_t *out)
     return SPX_OK;
 }
 
+/* advances the stream by n values without using them (a rank of a multi-GPU run passes over the draws of the groups
+ * that other ranks decide; ~1 ns per value) */
+extern "C" int spx_finalizer_skip(spx_finalizer *f, int64_t n)
+{
+    if (!f || n < 0) return SPX_EINVAL;
+    int32_t v;
+    for (int64_t k = 0; k < n; ++k) random_r(&f->rd, &v);
+    return SPX_OK;
+}
+
 /* BED bookkeeping of relabelled reads (src/secphase.c:201-212): extents of the old primary and of the promoted
  * secondary (count 1 each), and the reference positions of their surviving markers */
 extern "C" int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, int32_t end, int32_t count);
@@ -1602,19 +1614,16 @@ extern "C" int spx_relabel_blocks(const spx_work *w, const spx_ref *ref, const s
     return n;
 }
 
-extern "C" int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *bt, const spx_ref *ref,
-                                     const spx_group_out *out)
+/* the records print_alignment_scores (src/secphase.c:32-57) + the header lines (:194-200) would write for the relabelled
+ * groups of a finalized batch, formatted in slices on several threads (tens of thousands of relabelled groups per batch:
+ * one thread of fprintf was a third of the command line's loop) and returned in file order */
+static void format_relabel_text(const spx_batch *bt, const spx_ref *ref, const spx_group_out *out, std::vector<std::string> &text)
 {
-    if (!path || !bt || !ref || !out) return fail(SPX_EINVAL, "NULL argument");
-    FILE *f = fopen(path, mode && *mode ? mode : "w");
-    if (!f) return fail(SPX_EINVAL, std::string("cannot open ") + path);
-    /* formatted in slices on several threads, written in file order (print_alignment_scores, src/secphase.c:32-57): with
-     * tens of thousands of relabelled groups per batch one thread of fprintf was a third of the command line's loop */
     const int32_t n = bt->n_groups;
     int nthr = (int)std::thread::hardware_concurrency();
     nthr = std::max(1, std::min(nthr, 16));
     if (n < 4096) nthr = 1;
-    std::vector<std::string> text((size_t)nthr);
+    text.assign((size_t)nthr, std::string());
     auto slice = [&](int t) {
         const int32_t g0 = (int32_t)((int64_t)n * t / nthr), g1 = (int32_t)((int64_t)n * (t + 1) / nthr);
         std::string &s = text[(size_t)t];
@@ -1644,12 +1653,42 @@ extern "C" int spx_write_relabel_log(const char *path, const char *mode, const s
         for (int t = 0; t < nthr; ++t) th.emplace_back(slice, t);
         for (auto &x : th) x.join();
     }
+}
+
+extern "C" int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *bt, const spx_ref *ref,
+                                     const spx_group_out *out)
+{
+    if (!path || !bt || !ref || !out) return fail(SPX_EINVAL, "NULL argument");
+    FILE *f = fopen(path, mode && *mode ? mode : "w");
+    if (!f) return fail(SPX_EINVAL, std::string("cannot open ") + path);
+    std::vector<std::string> text;
+    format_relabel_text(bt, ref, out, text);
     bool ok = true;
-    for (int t = 0; t < nthr; ++t)
-        if (!text[(size_t)t].empty() && fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) != text[(size_t)t].size()) ok = false;
+    for (const std::string &t : text)
+        if (!t.empty() && fwrite(t.data(), 1, t.size(), f) != t.size()) ok = false;
     if (fclose(f) != 0) ok = false;
     return ok ? SPX_OK : fail(SPX_EINVAL, std::string("write error on ") + path);
 }
+
+/* the same text into memory (malloc'ed, free it with spx_free_text): a rank of a multi-GPU run formats the fragment of
+ * the list that its own groups contribute; rank 0 only appends the fragments in rank order */
+extern "C" int spx_format_relabel_text(const spx_batch *bt, const spx_ref *ref, const spx_group_out *out, char **text_out, int64_t *len_out)
+{
+    if (!bt || !ref || !out || !text_out || !len_out) return fail(SPX_EINVAL, "NULL argument");
+    std::vector<std::string> text;
+    format_relabel_text(bt, ref, out, text);
+    size_t n = 0;
+    for (const std::string &t : text) n += t.size();
+    char *buf = (char *)malloc(n + 1);
+    if (!buf) return fail(SPX_ENOMEM, "relabel text");
+    size_t at = 0;
+    for (const std::string &t : text) { memcpy(buf + at, t.data(), t.size()); at += t.size(); }
+    buf[n] = 0;
+    *text_out = buf;
+    *len_out = (int64_t)n;
+    return SPX_OK;
+}
+extern "C" void spx_free_text(char *text) { free(text); }
 
 /* ------------------------------------------------------------------ */
 /* raw banded-HMM problems, all rows wanted */

@@ -66,6 +66,54 @@ def gather_bytes(local, dist, torch, dst=0):
     return [b[:s].cpu().numpy() for b, s in zip(bufs, sizes)]
 
 
+def decide_locally(api, params, fin, out, n, dist, torch, device):
+    """Round 3: every rank decides its own groups.  out[0..n) = this rank's collected results of the step (in its shard's
+    file order).  The ranks exchange the number of rand() values their groups consume (one all_gather of 8 bytes per
+    rank), every rank moves its copy of the stream `fin` over the draws of the lower ranks, finalizes its groups, and moves
+    over the higher ranks' draws -- all copies stay at the global position of the stream (the reference at -@1 over the
+    groups in (step, rank, group) order)."""
+    L = api.lib()
+    mine = int(L.spx_count_draws(out, n))
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        api._chk(L.spx_finalizer_apply(fin, C.byref(params), out, n), "spx_finalizer_apply")
+        return mine
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.tensor([mine], dtype=torch.int64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    draws = [int(p.item()) for p in parts]
+    api._chk(L.spx_finalizer_skip(fin, sum(draws[:rank])), "spx_finalizer_skip")
+    api._chk(L.spx_finalizer_apply(fin, C.byref(params), out, n), "spx_finalizer_apply")
+    api._chk(L.spx_finalizer_skip(fin, sum(draws[rank + 1:])), "spx_finalizer_skip")
+    return mine
+
+
+def relabel_text(api, batches, ref, out):
+    """the fragment of the relabel list that the finalized groups of `batches` (record blocks in order, results out[]
+    concatenated the same way) contribute, as a uint8 numpy array"""
+    L = api.lib()
+    parts = []
+    base = 0
+    gsz = C.sizeof(api.GroupOut)
+    for bp in batches:
+        txt, ln = C.c_void_p(), C.c_int64()
+        sub = C.cast(C.byref(out, base * gsz), C.POINTER(api.GroupOut))
+        api._chk(L.spx_format_relabel_text(bp, ref, sub, C.byref(txt), C.byref(ln)), "spx_format_relabel_text")
+        if ln.value:
+            parts.append(np.frombuffer(C.string_at(txt, ln.value), np.uint8))
+        L.spx_free_text(txt)
+        base += bp.contents.n_groups
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+
+
+def append_fragments(parts, log_path):
+    """rank 0: the ranks' fragments of one step, in rank order"""
+    with open(log_path, "ab") as f:
+        for p in parts:
+            if len(p):
+                f.write(memoryview(np.ascontiguousarray(p)))
+
+
 def merge_and_write(api, params, fin, ref, dec_parts, cand_parts, log_path, mode="a"):
     """rank 0: dec_parts / cand_parts = lists (one entry per rank) of raw bytes holding spx_decision / spx_relabel_rec
     arrays.  Replays the draws of every group in global group order on finalizer `fin` (a c_void_p from

@@ -174,7 +174,7 @@ def _gpu_worker(rank, world, port, tmp):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     torch.cuda.is_available()  # torch's HIP runtime first (see conftest.py)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from secphase_amd import api
@@ -343,3 +343,82 @@ def test_merge_and_write_with_interleaved_shards(built, tmp_path):
     L.spx_finalizer_free(fin)
     assert nd == sum(1 for e in res if e.n_aln >= 2)
     assert filecmp.cmp(log_o, log_s, shallow=False)
+
+
+# ---------------------------------------------------------------- round 3: decisions made where the groups are
+def _local_worker(rank, world, port, tmp):
+    """what bench.py does per step at N > 1: draw counts exchanged, every rank decides and formats its own groups, ONE
+    gather of the text fragments, rank 0 appends them.  Three steps of unequal shards: the stream position carries over."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import orc
+    from secphase_amd import api
+    g, p = _setup()
+    L = api.lib()
+    fin = C.c_void_p()
+    api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+    log = os.path.join(tmp, "local.out.log")
+    if rank == 0:
+        open(log, "w").close()
+    # global order = (step, rank, group): step s covers groups [s*20, s*20+20), cut unevenly between the ranks
+    cuts = [(0, 7, 20), (20, 33, 40), (40, 41, 60)]
+    for lo, mid, hi in cuts:
+        a, b = (lo, mid) if rank == 0 else (mid, hi)
+        r = g.reads(a, b - a)
+        _, res = orc.run_batch(r.batch, g.ref, p, threads=1, seed=1)
+        out = _results_from_oracle(api, res, p)
+        shard.decide_locally(api, p, fin, out, b - a, dist, torch, torch.device("cpu"))
+        frag = shard.relabel_text(api, [r.batch], g.ref, out)
+        parts = shard.gather_bytes(torch.from_numpy(frag.copy()), dist, torch)
+        if rank == 0:
+            shard.append_fragments(parts, log)
+    L.spx_finalizer_free(fin)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_deciding_their_own_groups_emit_the_same_list(built, tmp_path):
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_local_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from oracle import orc
+    g, p = _setup()
+    r = g.reads(0, N_GROUPS)
+    log_o = str(tmp_path / "one.out.log")
+    nre, res = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1, log_path=log_o)
+    ties = 0
+    for e in res:
+        if e.n_aln >= 2:
+            sec = [a for a in range(e.n_aln) if a != e.prim_idx]
+            mxs = max(e.score[a] for a in sec)
+            ties += sum(1 for a in sec if e.score[a] >= mxs) > 1
+    assert ties > 0 and nre > 3
+    assert filecmp.cmp(log_o, str(tmp_path / "local.out.log"), shallow=False)
+
+
+def test_draw_count_and_skip(built):
+    """spx_count_draws = the number of values spx_finalizer_apply consumes; spx_finalizer_skip moves a second copy of the
+    stream by exactly that much (checked through the next draw of both)"""
+    from oracle import orc
+    from secphase_amd import api
+    g, p = _setup()
+    r = g.reads(0, 40)
+    L = api.lib()
+    L.spx_finalizer_draw.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    _, res = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1)
+    out = _results_from_oracle(api, res, p)
+    n = L.spx_count_draws(out, 40)
+    assert n >= sum(1 for e in res if e.n_aln >= 2)
+    f1, f2 = C.c_void_p(), C.c_void_p()
+    L.spx_finalizer_create(1, C.byref(f1))
+    L.spx_finalizer_create(1, C.byref(f2))
+    api._chk(L.spx_finalizer_apply(f1, C.byref(p), out, 40), "apply")
+    api._chk(L.spx_finalizer_skip(f2, n), "skip")
+    a, b = C.c_int32(), C.c_int32()
+    L.spx_finalizer_draw(f1, C.byref(a))
+    L.spx_finalizer_draw(f2, C.byref(b))
+    assert a.value == b.value
+    L.spx_finalizer_free(f1)
+    L.spx_finalizer_free(f2)
