@@ -328,6 +328,18 @@ int spx_fasta_load(const char *path, spx_fasta **out);
 const spx_ref *spx_fasta_ref(const spx_fasta *f);
 void spx_fasta_free(spx_fasta *f);
 
+/* ---- BGZF inflate on the device (spx_inflate_kernels.hip: one wavefront per BGZF block; decoder core shared with the
+ * host build in spx_inflate.h).  htslib inflates on the reading thread (bgzf_read_block under sam_read1,
+ * src/secphase.c:268).  `file` + block_off[0 .. n_blocks] delimit consecutive BGZF blocks; their inflated bytes are
+ * written back to back to out (host memory); status[b]: 0 ok, -1 corrupt DEFLATE data, -2/-3 size mismatch, -4 CRC-32
+ * mismatch.  Returns the inflated size or SPX_E*. */
+int64_t spx_inflate_bgzf_device(spx_ctx *ctx, const uint8_t *file, const int64_t *block_off, int32_t n_blocks, uint8_t *out,
+                                int64_t out_cap, int32_t *status, double *kernel_ms);
+/* the same decoder core compiled for the host (diagnostics: lets CPU tests check it against zlib): one raw DEFLATE
+ * stream; and the kernel's striped CRC-32 */
+int spx_inflate_core_host(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len);
+uint32_t spx_crc32_core_host(const uint8_t *p, int64_t n, int32_t pieces);
+
 /* ---- host-only view of the work list (no device needed) ------------------
  * What spx_prepare would upload: the banded DP problems and the marker table.
  * Lets CPU-only tests check the host logic against the oracle, and documents

@@ -1,0 +1,393 @@
+/*
+ * spx_inflate.h -- DEFLATE (RFC 1951) decoder core for BGZF blocks, written ONCE for both sides: the gfx950 kernel of
+ * spx_inflate_kernels.hip (one wavefront per BGZF block) and a host build that the CPU tests run against zlib.
+ *
+ * Why it exists: the reference inflates on ONE thread inside htslib (sam_read1, src/secphase.c:268); round 3's host
+ * reader inflates on a thread pool, but the MI355X boxes give a container ~16 cores of CPU time for a GPU that scores
+ * 780 k groups/s -- inflate alone (57 KB per HiFi group at ~0.6 GB/s per core) caps the host at ~150 k groups/s.  On the
+ * device a BGZF block is one independent DEFLATE stream of at most 64 KB, so blocks map to wavefronts: the bit-serial
+ * Huffman decode of a block is wave-UNIFORM work (every lane computes the same thing: the compiler keeps it on the
+ * scalar unit, decode tables live in LDS), and the 64 lanes do the parts that are data parallel -- table fill, LZ77
+ * copies, flushing literals, CRC32.
+ *
+ * The decoder is parameterised by an environment E that provides
+ *     E::in32(k)              compressed dword k of the block (little endian; reads past the end return 0)
+ *     E::put_literal(b)       one output byte
+ *     E::copy_match(len,dist) LZ77 copy at the current output position
+ *     E::out_pos()            bytes produced so far
+ *     E::tables()             scratch for the decode tables (LDS on the device)
+ *     E::sync()               wave barrier around cooperative table fills (no-op on the host)
+ *     E::lane(), E::lanes()   for the cooperative loops
+ * Returns 0 or a negative code (-1 corrupt stream, -2 output overrun, -3 input overrun).
+ */
+#ifndef SPX_INFLATE_H
+#define SPX_INFLATE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SPXZ_HD __host__ __device__ inline
+#else
+#define SPXZ_HD inline
+#endif
+
+namespace spxz {
+
+constexpr int kLitRoot = 10;  /* bits of the literal/length root table */
+constexpr int kDistRoot = 8;  /* bits of the distance root table */
+
+/* root-table entry: bits 0-3 code length (0: not a root code -> canonical walk), 4-5 kind (0 literal, 1 length /
+ * distance with base+extra, 2 end of block), 8-11 extra bits, 16-31 base value (literal byte, length base, distance base) */
+SPXZ_HD uint32_t mk_entry(int nbits, int kind, int extra, int base) { return (uint32_t)nbits | ((uint32_t)kind << 4) | ((uint32_t)extra << 8) | ((uint32_t)base << 16); }
+
+struct Tables {
+    uint32_t lit[1 << kLitRoot];
+    uint32_t dist[1 << kDistRoot];
+    /* canonical description (walked for codes longer than the root, and while building) */
+    uint16_t lit_count[16], dist_count[16];   /* codes per length */
+    uint16_t lit_sorted[288], dist_sorted[32]; /* symbols ordered by (length, symbol) */
+    uint8_t lens[288 + 32];                    /* code lengths of the block being set up */
+    uint16_t code_of[288];                     /* canonical code of every symbol (table fill) */
+};
+
+SPXZ_HD int len_base(int sym) /* sym 257..285 */
+{
+    const int k = sym - 257;
+    if (k < 8) return 3 + k;
+    if (k == 28) return 258;
+    const int e = (k - 4) >> 2;
+    return 3 + ((4 + (k & 3)) << e);
+}
+SPXZ_HD int len_extra(int sym)
+{
+    const int k = sym - 257;
+    if (k < 8 || k == 28) return 0;
+    return (k - 4) >> 2;
+}
+SPXZ_HD int dist_base(int sym) /* 0..29 */
+{
+    if (sym < 4) return 1 + sym;
+    const int e = (sym - 2) >> 1;
+    return 1 + ((2 + (sym & 1)) << e);
+}
+SPXZ_HD int dist_extra(int sym) { return sym < 4 ? 0 : (sym - 2) >> 1; }
+
+SPXZ_HD uint32_t rev_bits(uint32_t code, int n)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) { r = (r << 1) | (code & 1); code >>= 1; }
+    return r;
+}
+
+/* bit reader over E::in32: at least 32 valid bits after refill() */
+template <class E>
+struct Bits {
+    E &env;
+    uint64_t buf = 0;
+    int cnt = 0;
+    uint32_t next = 0; /* dword index of the next refill */
+    SPXZ_HD explicit Bits(E &e) : env(e) {}
+    SPXZ_HD void refill()
+    {
+        if (cnt <= 32) {
+            buf |= (uint64_t)env.in32(next) << cnt;
+            ++next;
+            cnt += 32;
+        }
+    }
+    SPXZ_HD uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    SPXZ_HD void drop(int n) { buf >>= n; cnt -= n; }
+    SPXZ_HD uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
+    /* bits consumed so far (for the input-overrun check) */
+    SPXZ_HD int64_t consumed() const { return (int64_t)next * 32 - cnt; }
+};
+
+/* canonical walk (Mark Adler's puff): one bit at a time; used for codes longer than the root tables and for the
+ * code-length code.  Does NOT consume: returns (code length << 16) | symbol, or 0xffffffff.  (The tables it reads live in
+ * LDS / scratch on the device, i.e. in vector registers: the caller makes the result wave-uniform before it touches the
+ * bit reader, so that the reader's state stays on the scalar unit.) */
+template <class E>
+SPXZ_HD uint32_t decode_slow(const Bits<E> &b, const uint16_t *count, const uint16_t *sorted, int max_len)
+{
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= max_len; ++len) {
+        code |= (int)((b.buf >> (len - 1)) & 1);
+        const int c = count[len];
+        if (code - c < first) return ((uint32_t)len << 16) | sorted[index + (code - first)];
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return 0xffffffffu;
+}
+
+/* counts + sorted symbols + canonical codes from lens[0..n); returns 0, or -1 for an over-subscribed / incomplete set
+ * (an incomplete set is allowed when it has a single code, as zlib allows for distance trees) */
+SPXZ_HD int canon_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sorted, uint16_t *code_of)
+{
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    for (int s = 0; s < n; ++s) count[lens[s] & 15]++;
+    int left = 1;
+    for (int l = 1; l < 16; ++l) {
+        left <<= 1;
+        left -= count[l];
+        if (left < 0) return -1; /* over-subscribed */
+    }
+    uint16_t offs[16], nextc[16];
+    offs[0] = 0; offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+    int code = 0;
+    nextc[0] = 0;
+    for (int l = 1; l < 16; ++l) { /* RFC 1951 3.2.2 with bl_count[0] = 0 */
+        code = (code + (l > 1 ? count[l - 1] : 0)) << 1;
+        nextc[l] = (uint16_t)code;
+    }
+    for (int s = 0; s < n; ++s) {
+        const int l = lens[s] & 15;
+        if (!l) continue;
+        sorted[offs[l]++] = (uint16_t)s;
+        if (code_of) code_of[s] = nextc[l]++;
+    }
+    const int used = n - count[0];
+    if (left > 0 && used > 1) return -1; /* incomplete: only a set of at most one code may be (zlib accepts those too) */
+    return 0;
+}
+
+/* root-table fill for symbols s = first, first + stride, ...: every code of length <= root is replicated over the
+ * high index bits; longer codes leave their (shared) root slots at 0 = "walk" */
+template <bool LIT>
+SPXZ_HD void fill_root(uint32_t *tab, int root, const uint8_t *lens, const uint16_t *code_of, int n, int first, int stride)
+{
+    for (int s = first; s < n; s += stride) {
+        const int l = lens[s];
+        if (l == 0 || l > root) continue;
+        uint32_t e;
+        if (LIT) {
+            if (s < 256) e = mk_entry(l, 0, 0, s);
+            else if (s == 256) e = mk_entry(l, 2, 0, 0);
+            else if (s <= 285) e = mk_entry(l, 1, len_extra(s), len_base(s));
+            else continue; /* 286, 287: never valid */
+        } else {
+            if (s > 29) continue;
+            e = mk_entry(l, 1, dist_extra(s), dist_base(s));
+        }
+        const uint32_t r = rev_bits(code_of[s], l);
+        for (uint32_t k = r; k < (1u << root); k += (1u << l)) tab[k] = e;
+    }
+}
+
+template <class E>
+SPXZ_HD int build_tables(E &env, int nlit, int ndist)
+{
+    Tables &T = env.tables();
+    const int lane = env.lane(), lanes = env.lanes();
+    for (int k = lane; k < (1 << kLitRoot); k += lanes) T.lit[k] = 0;
+    for (int k = lane; k < (1 << kDistRoot); k += lanes) T.dist[k] = 0;
+    int rc = 0;
+    if (lane == 0) {
+        rc = canon_build(T.lens, nlit, T.lit_count, T.lit_sorted, T.code_of);
+    }
+    env.sync();
+    fill_root<true>(T.lit, kLitRoot, T.lens, T.code_of, nlit, lane, lanes);
+    env.sync();
+    int rc2 = 0;
+    if (lane == 0) rc2 = canon_build(T.lens + nlit, ndist, T.dist_count, T.dist_sorted, T.code_of);
+    env.sync();
+    fill_root<false>(T.dist, kDistRoot, T.lens + nlit, T.code_of, ndist, lane, lanes);
+    env.sync();
+    rc = env.uniform(rc | rc2);
+    return rc ? -1 : 0;
+}
+
+/* one DEFLATE stream (all its blocks).  out_limit: bytes the caller expects (ISIZE) */
+template <class E>
+SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
+{
+    Bits<E> b(env);
+    Tables &T = env.tables();
+    for (;;) {
+        b.refill();
+        const uint32_t hdr = b.take(3);
+        const int final_blk = (int)(hdr & 1), type = (int)(hdr >> 1);
+        if (type == 0) { /* stored */
+            b.drop(b.cnt & 7); /* to the byte boundary */
+            b.refill();
+            const uint32_t len = b.take(16);
+            b.refill();
+            const uint32_t nlen = b.take(16);
+            if ((len ^ 0xffffu) != nlen) return -1;
+            if (env.out_pos() + len > out_limit) return -2;
+            for (uint32_t k = 0; k < len; ++k) {
+                b.refill();
+                env.put_literal((uint8_t)b.take(8));
+            }
+        } else if (type == 1 || type == 2) {
+            int nlit, ndist;
+            if (type == 1) {
+                const int lane = env.lane(), lanes = env.lanes();
+                for (int s = lane; s < 288; s += lanes) T.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                for (int s = lane; s < 32; s += lanes) T.lens[288 + s] = 5;
+                env.sync();
+                nlit = 288; ndist = 32;
+                /* the fixed distance code has 32 codes of 5 bits; symbols 30, 31 never occur in valid data */
+            } else {
+                b.refill();
+                nlit = (int)b.take(5) + 257;
+                ndist = (int)b.take(5) + 1;
+                const int ncode = (int)b.take(4) + 4;
+                if (nlit > 286 || ndist > 30) return -1;
+                /* code-length code: 19 symbols of <= 7 bits; decoded by the canonical walk (it is used ~300 times) */
+                uint8_t cl[19];
+                const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                for (int k = 0; k < 19; ++k) cl[k] = 0;
+                for (int k = 0; k < ncode; ++k) { b.refill(); cl[order[k]] = (uint8_t)b.take(3); }
+                uint16_t ccount[16], csorted[19];
+                if (env.uniform(canon_build(cl, 19, ccount, csorted, nullptr)) != 0) return -1;
+                int idx = 0;
+                int bad = 0;
+                while (idx < nlit + ndist) {
+                    b.refill();
+                    const uint32_t r = env.uniform_u32(decode_slow(b, ccount, csorted, 7));
+                    if (r == 0xffffffffu) { bad = 1; break; }
+                    b.drop((int)(r >> 16));
+                    const int sym = (int)(r & 0xffff);
+                    if (sym < 16) { if (env.lane() == 0) T.lens[idx] = (uint8_t)sym; ++idx; continue; }
+                    int rep, val = 0;
+                    if (sym == 16) {
+                        if (idx == 0) { bad = 1; break; }
+                        val = -1; /* previous length */
+                        rep = 3 + (int)b.take(2);
+                    } else if (sym == 17) rep = 3 + (int)b.take(3);
+                    else rep = 11 + (int)b.take(7);
+                    if (idx + rep > nlit + ndist) { bad = 1; break; }
+                    if (env.lane() == 0) {
+                        const uint8_t v = val < 0 ? T.lens[idx - 1] : 0;
+                        for (int k = 0; k < rep; ++k) T.lens[idx + k] = v;
+                    }
+                    idx += rep;
+                }
+                if (bad) return -1;
+                env.sync();
+                if (env.uniform((int)T.lens[256]) == 0) return -1; /* no end-of-block code */
+                /* the distance lengths follow the literal lengths directly: build_tables expects them at lens + nlit */
+            }
+            if (build_tables(env, nlit, ndist) != 0) return -1;
+            /* ---- the symbol loop ---- */
+            for (;;) {
+                b.refill();
+                uint32_t e = env.uniform_u32(T.lit[b.peek(kLitRoot)]);
+                int kind, base, extra;
+                if ((e & 0xf) != 0) {
+                    b.drop((int)(e & 0xf));
+                    kind = (int)((e >> 4) & 3); extra = (int)((e >> 8) & 0xf); base = (int)(e >> 16);
+                } else {
+                    const uint32_t r = env.uniform_u32(decode_slow(b, T.lit_count, T.lit_sorted, 15));
+                    if (r == 0xffffffffu) return -1;
+                    b.drop((int)(r >> 16));
+                    const int sym = (int)(r & 0xffff);
+                    if (sym > 285) return -1;
+                    if (sym < 256) { kind = 0; base = sym; extra = 0; }
+                    else if (sym == 256) { kind = 2; base = 0; extra = 0; }
+                    else { kind = 1; base = len_base(sym); extra = len_extra(sym); }
+                }
+                if (kind == 0) {
+                    if (env.out_pos() >= out_limit) return -2;
+                    env.put_literal((uint8_t)base);
+                    continue;
+                }
+                if (kind == 2) break;
+                b.refill();
+                const int len = base + (int)b.take(extra);
+                b.refill();
+                uint32_t d = env.uniform_u32(T.dist[b.peek(kDistRoot)]);
+                int dbase, dextra;
+                if ((d & 0xf) != 0) {
+                    b.drop((int)(d & 0xf));
+                    dextra = (int)((d >> 8) & 0xf); dbase = (int)(d >> 16);
+                } else {
+                    const uint32_t r = env.uniform_u32(decode_slow(b, T.dist_count, T.dist_sorted, 15));
+                    if (r == 0xffffffffu) return -1;
+                    b.drop((int)(r >> 16));
+                    const int sym = (int)(r & 0xffff);
+                    if (sym > 29) return -1;
+                    dbase = dist_base(sym); dextra = dist_extra(sym);
+                }
+                b.refill();
+                const int dist = dbase + (int)b.take(dextra);
+                if ((uint32_t)dist > env.out_pos()) return -1;
+                if (env.out_pos() + (uint32_t)len > out_limit) return -2;
+                env.copy_match(len, dist);
+            }
+        } else
+            return -1;
+        if (b.consumed() > in_bits_limit) return -3;
+        if (final_blk) break;
+    }
+    if (b.consumed() > in_bits_limit) return -3;
+    return env.out_pos() == out_limit ? 0 : -2;
+}
+
+/* ---- CRC-32 (IEEE 802.3, reflected; what gzip / BGZF store) ---- */
+SPXZ_HD uint32_t crc_table_entry(uint32_t n)
+{
+    uint32_t c = n;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+    return c;
+}
+/* a * b mod P over GF(2), reflected representation (bit 31 = x^0) */
+SPXZ_HD uint32_t gf2_mul(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+    for (int k = 0; k < 32; ++k) {
+        if (a & 0x80000000u) r ^= b;
+        a <<= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+    }
+    return r;
+}
+/* x^(8 * n_bytes) mod P */
+SPXZ_HD uint32_t gf2_xpow8n(uint64_t n_bytes)
+{
+    uint32_t r = 0x80000000u;        /* x^0 */
+    uint32_t p = 0x00800000u;        /* x^8 */
+    while (n_bytes) {
+        if (n_bytes & 1) r = gf2_mul(r, p);
+        p = gf2_mul(p, p);
+        n_bytes >>= 1;
+    }
+    return r;
+}
+/* crc(A || B) from crc(A), crc(B), len(B) (both "finished" CRCs, i.e. with the final complement) */
+SPXZ_HD uint32_t crc_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return gf2_mul(gf2_xpow8n(len_b), crc_a) ^ crc_b; }
+
+/* ---- host environment: plain buffers ---- */
+struct HostEnv {
+    const uint8_t *in;
+    size_t in_len;
+    uint8_t *out;
+    uint32_t pos = 0;
+    Tables T;
+    uint32_t in32(uint32_t k) const
+    {
+        uint32_t v = 0;
+        for (int q = 0; q < 4; ++q) {
+            const size_t at = (size_t)k * 4 + (size_t)q;
+            if (at < in_len) v |= (uint32_t)in[at] << (8 * q);
+        }
+        return v;
+    }
+    void put_literal(uint8_t c) { out[pos++] = c; }
+    void copy_match(int len, int dist) { for (int k = 0; k < len; ++k, ++pos) out[pos] = out[pos - dist]; }
+    uint32_t out_pos() const { return pos; }
+    Tables &tables() { return T; }
+    void sync() {}
+    int lane() const { return 0; }
+    int lanes() const { return 1; }
+    int uniform(int v) const { return v; }
+    uint32_t uniform_u32(uint32_t v) const { return v; }
+};
+
+} // namespace spxz
+#endif

@@ -1,0 +1,159 @@
+/*
+ * spx_inflate_kernels.hip -- BGZF inflate on gfx950: ONE WAVEFRONT PER BGZF BLOCK (a block is an independent DEFLATE
+ * stream of at most 64 KB), the decoder core of spx_inflate.h.
+ *
+ * What replaces what: htslib inflates every block on the reading thread (bgzf_read_block under sam_read1,
+ * /root/reference/programs/src/secphase.c:268); the host reader of spx_io.cpp does it on a thread pool.  The MI355X boxes
+ * give a container ~16 cores of CPU time, which caps host inflate at ~10 GB/s of inflated bytes (~150 k HiFi groups/s)
+ * beside a device that scores 780 k groups/s -- so the compressed bytes cross PCIe (26 KB per group instead of 57) and
+ * are inflated here.
+ *
+ * Mapping onto a wavefront:
+ *   - the bit-serial Huffman decode is WAVE-UNIFORM: every lane executes the same decode of the same block, so the
+ *     compiler keeps bit buffer, counters and table indices in SGPRs / on the scalar unit; the root tables (10-bit
+ *     literal/length, 8-bit distance) live in LDS and are read back through v_readfirstlane;
+ *   - the 64 lanes share the data-parallel parts: zeroing and filling the decode tables, LZ77 copies (lane i copies
+ *     bytes i, i + 64, ...: an overlapping match is a repeat of its first `dist` bytes, so the lanes are independent),
+ *     flushing finished output to HBM, and the CRC-32 (64 stripes, combined with the GF(2) shift operator);
+ *   - every output byte goes through an LDS ring of the last kRing bytes: near matches (distance <= kRing / 2, the
+ *     bulk of what zlib finds in quality strings) never touch HBM; far matches (a secondary alignment repeats the
+ *     primary's SEQ / QUAL ~23 KB back) read what earlier flushes wrote (flush = stores + agent-scope fence; the
+ *     loads bypass the vector L1).
+ * LDS per wave: tables 6.7 KB + ring 4 KB + CRC table 1 KB: 13 waves per CU.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spx_inflate.h"
+
+namespace {
+
+constexpr int kRing = 4096;
+constexpr int kFlush = 1024; /* flush when this many bytes wait in the ring (<= kRing / 2 - 258) */
+
+struct BlockDesc {
+    int64_t in_off;   /* byte offset of the DEFLATE data in the compressed buffer */
+    int64_t out_off;  /* byte offset of the block's inflated bytes in the output buffer */
+    uint32_t clen, ulen, crc, pad;
+};
+
+struct DevEnv {
+    const uint32_t *in_al;
+    uint32_t in_shift; /* bits: 0, 8, 16, 24 */
+    uint8_t *out;
+    uint32_t pos, flushed;
+    spxz::Tables *T;
+    uint8_t *ring;
+    int lane_;
+
+    __device__ __forceinline__ uint32_t in32(uint32_t k) const
+    {
+        const uint32_t lo = in_al[k], hi = in_al[k + 1];
+        return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
+    }
+    __device__ __forceinline__ spxz::Tables &tables() { return *T; }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ int lane() const { return lane_; }
+    __device__ __forceinline__ int lanes() const { return 64; }
+    __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    __device__ __forceinline__ uint32_t out_pos() const { return pos; }
+
+    /* ring -> HBM, all lanes; afterwards every byte below `pos` is visible to loads that bypass the vector L1 */
+    __device__ __forceinline__ void flush()
+    {
+        __syncthreads();
+        for (uint32_t i = flushed + (uint32_t)lane_; i < pos; i += 64) out[i] = ring[i & (kRing - 1)];
+        flushed = pos;
+        __threadfence();
+    }
+    __device__ __forceinline__ void put_literal(uint8_t c)
+    {
+        if (lane_ == 0) ring[pos & (kRing - 1)] = c;
+        ++pos;
+        if (pos - flushed >= (uint32_t)kFlush) flush();
+    }
+    __device__ __forceinline__ void copy_match(int len, int dist)
+    {
+        const uint32_t src0 = pos - (uint32_t)dist;
+        if (dist <= kRing / 2) {
+            /* near: ring -> ring.  Lane i produces bytes i, i + 64, ...; source byte = first `dist` bytes of the match
+             * region repeated, all of them older than pos: no lane depends on another */
+            __syncthreads();
+            for (int i = lane_; i < len; i += 64) {
+                const uint32_t s = src0 + (uint32_t)(dist >= len ? i : i % dist);
+                ring[(pos + (uint32_t)i) & (kRing - 1)] = ring[s & (kRing - 1)];
+            }
+        } else {
+            /* far: the source lies below `flushed` (kFlush <= kRing / 2), read it from HBM past the L1 */
+            __syncthreads();
+            for (int i = lane_; i < len; i += 64) {
+                const uint8_t v = __hip_atomic_load(out + src0 + (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ring[(pos + (uint32_t)i) & (kRing - 1)] = v;
+            }
+        }
+        pos += (uint32_t)len;
+        if (pos - flushed >= (uint32_t)kFlush) flush();
+        else __syncthreads();
+    }
+};
+
+__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
+                                                          uint8_t *__restrict__ outbuf, int32_t *__restrict__ status, int check_crc)
+{
+    __shared__ spxz::Tables T;
+    __shared__ uint8_t ring[kRing];
+    __shared__ uint32_t crc_tab[256];
+    const int b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    DevEnv env;
+    env.in_al = reinterpret_cast<const uint32_t *>(comp + (d.in_off & ~(int64_t)3));
+    env.in_shift = (uint32_t)(d.in_off & 3) * 8u;
+    env.out = outbuf + d.out_off;
+    env.pos = 0;
+    env.flushed = 0;
+    env.T = &T;
+    env.ring = ring;
+    env.lane_ = (int)threadIdx.x;
+    int rc = 0;
+    if (d.ulen > 0) {
+        rc = spxz::inflate_stream(env, (int64_t)d.clen * 8, d.ulen);
+        env.flush();
+    }
+    rc = __builtin_amdgcn_readfirstlane(rc);
+    if (rc == 0 && check_crc && d.ulen > 0) {
+        /* CRC-32 of the block: 64 stripes (byte-table recurrence per lane), folded with the GF(2) shift operator */
+        for (int k = (int)threadIdx.x; k < 256; k += 64) crc_tab[k] = spxz::crc_table_entry((uint32_t)k);
+        __syncthreads();
+        const uint32_t n = d.ulen, step = (n + 63) / 64;
+        const uint32_t a = min(n, step * threadIdx.x), e = min(n, a + step);
+        uint32_t c = 0xffffffffu;
+        const uint8_t *p = env.out;
+        for (uint32_t k = a; k < e; ++k) c = crc_tab[(c ^ p[k]) & 0xff] ^ (c >> 8);
+        c ^= 0xffffffffu;
+        uint32_t len = e - a;
+        /* tree: lane l absorbs lane l + s (the bytes that FOLLOW its own) */
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t oc = (uint32_t)__shfl_down((int)c, s), ol = (uint32_t)__shfl_down((int)len, s);
+            if ((threadIdx.x & (2 * s - 1)) == 0) {
+                if (ol > 0) c = len > 0 ? spxz::crc_combine(c, oc, ol) : oc;
+                len += ol;
+            }
+        }
+        if (threadIdx.x == 0 && c != d.crc) rc = -4;
+        rc = __builtin_amdgcn_readfirstlane(rc);
+    }
+    if (threadIdx.x == 0) status[b] = rc;
+}
+
+} // namespace
+
+extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
+                                              int check_crc, hipStream_t st)
+{
+    if (n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, comp, (const BlockDesc *)blocks, n_blocks, out, status,
+                       check_crc);
+    return hipGetLastError();
+}

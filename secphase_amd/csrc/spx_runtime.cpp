@@ -44,6 +44,9 @@ extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args 
 extern "C" size_t spx_order_temp_bytes(int32_t n_prob);
 extern "C" hipError_t spx_prep_orders(const spx_order_args *O, const spx_order_segs *sf, const spx_order_segs *sb, hipStream_t st);
 
+extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
+                                              int check_crc, hipStream_t st);
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
 {
@@ -1851,6 +1854,76 @@ extern "C" int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *
     for (int i = 0; i < l_query; ++i) state[i] = st32[i];
     /* phred-scaled likelihood, like htslib (secphase itself only tests the return value for INT_MIN, ptMarker.c:755-760) */
     return pr;
+}
+
+/* ------------------------------------------------------------------ */
+/* BGZF blocks inflated on the device (spx_inflate_kernels.hip): `file` holds n_blocks consecutive BGZF blocks starting at
+ * block_off[0] (block_off has n_blocks + 1 entries: the starts and the end).  The inflated bytes of the blocks are written
+ * back to back into out (host); status[b] = 0, -1 corrupt DEFLATE data, -2 / -3 size mismatch, -4 CRC mismatch.
+ * Returns the number of inflated bytes or SPX_E*; *kernel_ms (may be NULL) receives the kernel's duration. */
+struct SpxBgzfDesc { int64_t in_off, out_off; uint32_t clen, ulen, crc, pad; };
+extern "C" int64_t spx_inflate_bgzf_device(spx_ctx *c, const uint8_t *file, const int64_t *block_off, int32_t n_blocks, uint8_t *out,
+                                           int64_t out_cap, int32_t *status, double *kernel_ms)
+{
+    if (!c || !file || !block_off || n_blocks < 0 || (!out && out_cap > 0) || !status) return fail(SPX_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<SpxBgzfDesc> desc((size_t)n_blocks);
+    const int64_t base = n_blocks ? block_off[0] : 0;
+    int64_t utot = 0;
+    for (int32_t b = 0; b < n_blocks; ++b) {
+        const uint8_t *p = file + block_off[b];
+        const int64_t total = block_off[b + 1] - block_off[b];
+        if (total < 26 || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return fail(SPX_EINVAL, "not a BGZF block");
+        const int64_t xlen = p[10] | (p[11] << 8);
+        if (12 + xlen + 8 > total) return fail(SPX_EINVAL, "corrupt BGZF block");
+        const uint8_t *t = p + total - 8;
+        SpxBgzfDesc &d = desc[(size_t)b];
+        d.in_off = block_off[b] - base + 12 + xlen;
+        d.clen = (uint32_t)(total - 12 - xlen - 8);
+        d.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        d.ulen = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        d.out_off = utot;
+        d.pad = 0;
+        if (d.ulen > 65536) return fail(SPX_EINVAL, "corrupt BGZF block (ISIZE)");
+        utot += d.ulen;
+    }
+    if (utot > out_cap) return fail(SPX_EINVAL, "output buffer too small");
+    if (n_blocks == 0) return 0;
+    const size_t cbytes = (size_t)(block_off[n_blocks] - base);
+    uint8_t *d_comp = nullptr, *d_out = nullptr;
+    SpxBgzfDesc *d_desc = nullptr;
+    int32_t *d_status = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = SPX_OK;
+    auto cleanup = [&]() {
+        if (d_comp) (void)hipFree(d_comp);
+        if (d_out) (void)hipFree(d_out);
+        if (d_desc) (void)hipFree(d_desc);
+        if (d_status) (void)hipFree(d_status);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define ZCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); cleanup(); return fail(SPX_EHIP, #x); } } while (0)
+    ZCHK(hipMalloc((void **)&d_comp, cbytes + 64));
+    ZCHK(hipMalloc((void **)&d_out, (size_t)utot + 64));
+    ZCHK(hipMalloc((void **)&d_desc, desc.size() * sizeof(SpxBgzfDesc)));
+    ZCHK(hipMalloc((void **)&d_status, (size_t)n_blocks * 4));
+    ZCHK(hipMemset(d_comp + cbytes, 0, 64));
+    ZCHK(hipMemcpy(d_comp, file + base, cbytes, hipMemcpyHostToDevice));
+    ZCHK(hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(SpxBgzfDesc), hipMemcpyHostToDevice));
+    ZCHK(hipEventCreate(&e0));
+    ZCHK(hipEventCreate(&e1));
+    ZCHK(hipEventRecord(e0, c->stream));
+    ZCHK(spx_launch_bgzf_inflate(d_comp, d_desc, n_blocks, d_out, d_status, 1, c->stream));
+    ZCHK(hipEventRecord(e1, c->stream));
+    ZCHK(hipStreamSynchronize(c->stream));
+    if (kernel_ms) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *kernel_ms = ms; }
+    ZCHK(hipMemcpy(status, d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost));
+    if (utot) ZCHK(hipMemcpy(out, d_out, (size_t)utot, hipMemcpyDeviceToHost));
+#undef ZCHK
+    cleanup();
+    (void)rc;
+    return utot;
 }
 
 /* ------------------------------------------------------------------ */
