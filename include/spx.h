@@ -305,6 +305,32 @@ int spx_bam_next_batch(spx_bam_reader *r, int32_t max_groups, const spx_batch **
 /* done with a batch: its part of the inflate arena is recycled now rather than SPX_BAM_KEEP calls later */
 int spx_bam_release_batch(spx_bam_reader *r, const spx_batch *batch);
 void spx_bam_close(spx_bam_reader *r);
+/* Device inflate beside the host pool (round 3: the GPU boxes give a container ~16 cores of CPU time; inflate is what they
+ * are spent on).  Once attached, the reader hands a chunk (a run of BGZF blocks, ~32 MB inflated) to the device whenever
+ * one of n_workers device workers has room, and to its host pool otherwise.  fn inflates blocks[0..n) of the mapped file
+ * into dst (blocks[k] goes to dst + uoff) and returns 0, 1 (corrupt DEFLATE data), 2 (CRC-32 mismatch) or a negative value
+ * (the device could not do it: the reader inflates the chunk on the host).  spx_inflater_* (below) is that function on a
+ * scoring context. */
+typedef struct spx_bgzf_block {
+    int64_t data_off;  /* offset of the block's DEFLATE data in the file */
+    uint32_t clen;     /* bytes of DEFLATE data */
+    uint32_t uoff;     /* where its inflated bytes go, relative to dst */
+    uint32_t ulen;     /* ISIZE */
+    uint32_t crc;      /* CRC-32 of the inflated bytes */
+    uint32_t reserved;
+} spx_bgzf_block;
+typedef int (*spx_bgzf_inflate_fn)(void *user, int32_t worker, const uint8_t *file, int64_t file_bytes, const spx_bgzf_block *blocks,
+                                   int32_t n_blocks, uint8_t *dst, int64_t dst_bytes, int32_t check_crc);
+int spx_bam_attach_device_inflate(spx_bam_reader *r, spx_bgzf_inflate_fn fn, void *user, int32_t n_workers);
+void spx_bam_inflate_counts(const spx_bam_reader *r, int64_t *chunks_host, int64_t *chunks_device);
+/* the device side of the above on a scoring context: n_workers independent sets of {stream, pinned buffers, device
+ * buffers}; spx_inflater_run is an spx_bgzf_inflate_fn with user = the inflater */
+typedef struct spx_inflater spx_inflater;
+int spx_inflater_create(spx_ctx *ctx, int32_t n_workers, spx_inflater **out);
+int spx_inflater_run(void *inflater, int32_t worker, const uint8_t *file, int64_t file_bytes, const spx_bgzf_block *blocks, int32_t n_blocks,
+                     uint8_t *dst, int64_t dst_bytes, int32_t check_crc);
+void spx_inflater_free(spx_inflater *inf);
+
 /* Index of group starts in the reference's on-disk format (src/secphase_index.c:76-119 writes, get_offset_array
  * src/secphase.c:357-385 reads: int64 count, then that many int64 BGZF virtual offsets): the offset of the first record
  * of every step_groups-th read group plus the offset where the records end.  A reader opened with start_voffset = a[i]

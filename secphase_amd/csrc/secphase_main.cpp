@@ -84,6 +84,7 @@ static struct option long_options[] = {{"inputBam", required_argument, NULL, 'i'
                                        {"groupsPerBatch", required_argument, NULL, 1001},
                                        {"device", required_argument, NULL, 1002},
                                        {"devices", required_argument, NULL, 1003},
+                                       {"gpuInflate", required_argument, NULL, 1004},
                                        {NULL, 0, NULL, 0}};
 
 static void usage(const char *prog)
@@ -104,6 +105,7 @@ static void usage(const char *prog)
             "         --device               GPU index [0]\n"
             "         --devices              several GPUs, e.g. 0-7 or 0,2,5: batches are dealt round-robin, the output is\n"
             "                                the same file-order list\n"
+            "         --gpuInflate           BGZF inflate workers per GPU beside the host threads [3]; 0: host only\n"
             "         --writeBam, -w         Write <prefix>.quality_modified.out.bam (SAM text, as the reference does) with\n"
             "                                the base qualities modified by BAQ\n"
             "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode)\n");
@@ -120,7 +122,8 @@ int main(int argc, char *argv[])
     par.conf_b = 20; par.flank_margin = 500;
     std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
     bool preset_ont = false, preset_hifi = false, marker_mode = true, write_bam = false, batch_given = false;
-    int threads = 4, groups_per_batch = 16384, c;
+    int threads = 4, groups_per_batch = 16384, gpu_inflate = 3, c;
+    if (const char *e = getenv("SPX_GPU_INFLATE")) gpu_inflate = atoi(e);
     std::vector<int> devices;
     auto parse_devices = [&](const char *txt) { /* "0-3", "0,2,5", "1" */
         devices.clear();
@@ -168,6 +171,7 @@ int main(int argc, char *argv[])
         case 'F': par.flank_margin = atoi(optarg); break;
         case 'M': marker_mode = false; break;
         case 1001: groups_per_batch = atoi(optarg); batch_given = true; break;
+        case 1004: gpu_inflate = atoi(optarg); break;
         case 1002: case 1003:
             if (!parse_devices(optarg)) { fprintf(stderr, "[%s] cannot parse the device list %s\n", timestamp(), optarg); return 1; }
             break;
@@ -263,6 +267,25 @@ int main(int argc, char *argv[])
             if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); return 1; }
     }
     const double t_ref = now_s();
+    /* BGZF inflate on the device(s) beside the host pool: the reader hands a chunk to whichever side has room */
+    struct InflateRoute { std::vector<spx_inflater *> inf; int per_dev = 0; } route;
+    if (gpu_inflate > 0 && marker_mode) {
+        route.per_dev = std::min(gpu_inflate, 8);
+        for (int d = 0; d < n_dev; ++d) {
+            spx_inflater *inf = nullptr;
+            if (spx_inflater_create(ctxs[(size_t)d], route.per_dev, &inf) == SPX_OK) route.inf.push_back(inf);
+        }
+        if (!route.inf.empty()) {
+            auto fn = [](void *user, int32_t worker, const uint8_t *file, int64_t file_bytes, const spx_bgzf_block *blocks, int32_t n_blocks,
+                         uint8_t *dst, int64_t dst_bytes, int32_t check_crc) -> int {
+                InflateRoute *R = (InflateRoute *)user;
+                const size_t nd = R->inf.size();
+                return spx_inflater_run(R->inf[(size_t)worker % nd], (int32_t)((size_t)worker / nd), file, file_bytes, blocks, n_blocks, dst, dst_bytes,
+                                        check_crc);
+            };
+            spx_bam_attach_device_inflate(bam, fn, &route, (int32_t)(route.inf.size() * (size_t)route.per_dev));
+        }
+    }
 
     spx_finalizer *fin = nullptr;
     spx_finalizer_create(1, &fin); /* unseeded rand() == srand(1) */
@@ -429,7 +452,13 @@ int main(int argc, char *argv[])
     spx_finalizer_free(fin);
     if (sam && spx_sam_close(sam) != SPX_OK) { fprintf(stderr, "[%s] could not finish the quality-modified output\n", timestamp()); return 1; }
     const double t_end1 = now_s();
+    if (getenv("SPX_TIMING")) {
+        int64_t ch = 0, cd = 0;
+        spx_bam_inflate_counts(bam, &ch, &cd);
+        fprintf(stderr, "[%s] inflate chunks: %lld on the host pool, %lld on the device(s)\n", timestamp(), (long long)ch, (long long)cd);
+    }
     spx_bam_close(bam);
+    for (spx_inflater *inf : route.inf) spx_inflater_free(inf);
     const double t_end2 = now_s();
     for (spx_ctx *c_ : ctxs) spx_destroy(c_);
     const double t_end3 = now_s();

@@ -28,22 +28,25 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SPXZ_HD __host__ __device__ inline
+#define SPXZ_COLD __host__ __device__ __attribute__((noinline)) /* keeps a rare path (and its control flow) out of the hot loop */
 #else
 #define SPXZ_HD inline
+#define SPXZ_COLD __attribute__((noinline))
 #endif
 
 namespace spxz {
 
-constexpr int kLitRoot = 10;  /* bits of the literal/length root table */
-constexpr int kDistRoot = 8;  /* bits of the distance root table */
+constexpr int kLitRoot = 11;  /* bits of the literal/length root table: BAM payload (4-bit packed bases: 256 byte values of
+                               * ~0.1 % each; qualities) gives its literals codes of 6..11 bits -- all of them root codes */
+constexpr int kDistRoot = 9;  /* bits of the distance root table */
 
-/* root-table entry: bits 0-3 code length (0: not a root code -> canonical walk), 4-5 kind (0 literal, 1 length /
- * distance with base+extra, 2 end of block), 8-11 extra bits, 16-31 base value (literal byte, length base, distance base) */
-SPXZ_HD uint32_t mk_entry(int nbits, int kind, int extra, int base) { return (uint32_t)nbits | ((uint32_t)kind << 4) | ((uint32_t)extra << 8) | ((uint32_t)base << 16); }
+/* root-table entry (16 bits): bits 0-8 symbol (bit 8 set = not a literal), bits 9-12 code length; 0 = not a root code -> canonical walk.  Length and
+ * distance base / extra bits are computed from the symbol (len_base ..): the rarer path pays, the table stays small */
+SPXZ_HD uint16_t mk_entry(int nbits, int sym) { return (uint16_t)((unsigned)sym | ((unsigned)nbits << 9)); }
 
 struct Tables {
-    uint32_t lit[1 << kLitRoot];
-    uint32_t dist[1 << kDistRoot];
+    uint16_t lit[1 << kLitRoot];
+    uint16_t dist[1 << kDistRoot];
     /* canonical description (walked for codes longer than the root, and while building) */
     uint16_t lit_count[16], dist_count[16];   /* codes per length */
     uint16_t lit_sorted[288], dist_sorted[32]; /* symbols ordered by (length, symbol) */
@@ -80,23 +83,26 @@ SPXZ_HD uint32_t rev_bits(uint32_t code, int n)
     return r;
 }
 
-/* bit reader over E::in32: at least 32 valid bits after refill() */
+/* bit reader over E::in32: at least 32 valid bits after refill().  The next input word is fetched one refill AHEAD
+ * (`pre`): on the device the scalar load's latency then overlaps a symbol's worth of decoding. */
 template <class E>
 struct Bits {
     E &env;
     uint64_t buf = 0;
     int cnt = 0;
-    uint32_t next = 0; /* dword index of the next refill */
-    SPXZ_HD explicit Bits(E &e) : env(e) {}
+    uint32_t next = 0; /* dword index of the word in `pre` */
+    uint32_t pre;
+    SPXZ_HD explicit Bits(E &e) : env(e) { pre = env.in32(0); }
     SPXZ_HD void refill()
     {
         if (cnt <= 32) {
-            buf |= (uint64_t)env.in32(next) << cnt;
+            buf |= (uint64_t)pre << cnt;
             ++next;
             cnt += 32;
+            pre = env.in32(next);
         }
     }
-    SPXZ_HD uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    SPXZ_HD uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); } /* n <= 16 */
     SPXZ_HD void drop(int n) { buf >>= n; cnt -= n; }
     SPXZ_HD uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
     /* bits consumed so far (for the input-overrun check) */
@@ -107,12 +113,11 @@ struct Bits {
  * code-length code.  Does NOT consume: returns (code length << 16) | symbol, or 0xffffffff.  (The tables it reads live in
  * LDS / scratch on the device, i.e. in vector registers: the caller makes the result wave-uniform before it touches the
  * bit reader, so that the reader's state stays on the scalar unit.) */
-template <class E>
-SPXZ_HD uint32_t decode_slow(const Bits<E> &b, const uint16_t *count, const uint16_t *sorted, int max_len)
+static SPXZ_COLD uint32_t decode_slow_bits(uint32_t bits, const uint16_t *count, const uint16_t *sorted, int max_len)
 {
     int code = 0, first = 0, index = 0;
     for (int len = 1; len <= max_len; ++len) {
-        code |= (int)((b.buf >> (len - 1)) & 1);
+        code |= (int)((bits >> (len - 1)) & 1);
         const int c = count[len];
         if (code - c < first) return ((uint32_t)len << 16) | sorted[index + (code - first)];
         index += c;
@@ -121,6 +126,11 @@ SPXZ_HD uint32_t decode_slow(const Bits<E> &b, const uint16_t *count, const uint
         code <<= 1;
     }
     return 0xffffffffu;
+}
+template <class E>
+SPXZ_HD uint32_t decode_slow(const Bits<E> &b, const uint16_t *count, const uint16_t *sorted, int max_len)
+{
+    return decode_slow_bits((uint32_t)b.buf, count, sorted, max_len);
 }
 
 /* counts + sorted symbols + canonical codes from lens[0..n); returns 0, or -1 for an over-subscribed / incomplete set
@@ -158,21 +168,13 @@ SPXZ_HD int canon_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *s
 /* root-table fill for symbols s = first, first + stride, ...: every code of length <= root is replicated over the
  * high index bits; longer codes leave their (shared) root slots at 0 = "walk" */
 template <bool LIT>
-SPXZ_HD void fill_root(uint32_t *tab, int root, const uint8_t *lens, const uint16_t *code_of, int n, int first, int stride)
+SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint16_t *code_of, int n, int first, int stride)
 {
     for (int s = first; s < n; s += stride) {
         const int l = lens[s];
         if (l == 0 || l > root) continue;
-        uint32_t e;
-        if (LIT) {
-            if (s < 256) e = mk_entry(l, 0, 0, s);
-            else if (s == 256) e = mk_entry(l, 2, 0, 0);
-            else if (s <= 285) e = mk_entry(l, 1, len_extra(s), len_base(s));
-            else continue; /* 286, 287: never valid */
-        } else {
-            if (s > 29) continue;
-            e = mk_entry(l, 1, dist_extra(s), dist_base(s));
-        }
+        if (LIT ? s > 285 : s > 29) continue; /* 286, 287 / 30, 31: never valid (their slots stay 0 -> the walk rejects them) */
+        const uint16_t e = mk_entry(l, s);
         const uint32_t r = rev_bits(code_of[s], l);
         for (uint32_t k = r; k < (1u << root); k += (1u << l)) tab[k] = e;
     }
@@ -221,7 +223,7 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
             if (env.out_pos() + len > out_limit) return -2;
             for (uint32_t k = 0; k < len; ++k) {
                 b.refill();
-                env.put_literal((uint8_t)b.take(8));
+                if (!env.put_literal((uint8_t)b.take(8))) return -2;
             }
         } else if (type == 1 || type == 2) {
             int nlit, ndist;
@@ -274,52 +276,55 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                 /* the distance lengths follow the literal lengths directly: build_tables expects them at lens + nlit */
             }
             if (build_tables(env, nlit, ndist) != 0) return -1;
-            /* ---- the symbol loop ---- */
+            /* ---- the symbol loop: a tight inner loop over runs of literals (one table look-up, one v_writelane each on
+             * the device), everything else outside it ---- */
             for (;;) {
-                b.refill();
-                uint32_t e = env.uniform_u32(T.lit[b.peek(kLitRoot)]);
-                int kind, base, extra;
-                if ((e & 0xf) != 0) {
-                    b.drop((int)(e & 0xf));
-                    kind = (int)((e >> 4) & 3); extra = (int)((e >> 8) & 0xf); base = (int)(e >> 16);
+                uint32_t e;
+                for (;;) {
+                    b.refill();
+                    e = env.uniform_u32(T.lit[b.peek(kLitRoot)]);
+                    if (e == 0 || (e & 0x100u)) break;
+                    b.drop((int)(e >> 9));
+                    if (!env.put_literal((uint8_t)e)) return -2; /* false: more bytes than the block may hold */
+                }
+                int sym;
+                if (e != 0) {
+                    b.drop((int)(e >> 9));
+                    sym = (int)(e & 511);
                 } else {
                     const uint32_t r = env.uniform_u32(decode_slow(b, T.lit_count, T.lit_sorted, 15));
                     if (r == 0xffffffffu) return -1;
                     b.drop((int)(r >> 16));
-                    const int sym = (int)(r & 0xffff);
+                    sym = (int)(r & 0xffff);
                     if (sym > 285) return -1;
-                    if (sym < 256) { kind = 0; base = sym; extra = 0; }
-                    else if (sym == 256) { kind = 2; base = 0; extra = 0; }
-                    else { kind = 1; base = len_base(sym); extra = len_extra(sym); }
+                    if (sym < 256) {
+                        if (!env.put_literal((uint8_t)sym)) return -2;
+                        continue;
+                    }
                 }
-                if (kind == 0) {
-                    if (env.out_pos() >= out_limit) return -2;
-                    env.put_literal((uint8_t)base);
-                    continue;
-                }
-                if (kind == 2) break;
+                if (sym == 256) break;
                 b.refill();
-                const int len = base + (int)b.take(extra);
+                const int len = len_base(sym) + (int)b.take(len_extra(sym));
                 b.refill();
-                uint32_t d = env.uniform_u32(T.dist[b.peek(kDistRoot)]);
-                int dbase, dextra;
-                if ((d & 0xf) != 0) {
-                    b.drop((int)(d & 0xf));
-                    dextra = (int)((d >> 8) & 0xf); dbase = (int)(d >> 16);
+                const uint32_t d = env.uniform_u32(T.dist[b.peek(kDistRoot)]);
+                int dsym;
+                if (d != 0) {
+                    b.drop((int)(d >> 9));
+                    dsym = (int)(d & 511);
                 } else {
                     const uint32_t r = env.uniform_u32(decode_slow(b, T.dist_count, T.dist_sorted, 15));
                     if (r == 0xffffffffu) return -1;
                     b.drop((int)(r >> 16));
-                    const int sym = (int)(r & 0xffff);
-                    if (sym > 29) return -1;
-                    dbase = dist_base(sym); dextra = dist_extra(sym);
+                    dsym = (int)(r & 0xffff);
+                    if (dsym > 29) return -1;
                 }
                 b.refill();
-                const int dist = dbase + (int)b.take(dextra);
+                const int dist = dist_base(dsym) + (int)b.take(dist_extra(dsym));
                 if ((uint32_t)dist > env.out_pos()) return -1;
                 if (env.out_pos() + (uint32_t)len > out_limit) return -2;
                 env.copy_match(len, dist);
             }
+            if (env.out_pos() > out_limit) return -2;
         } else
             return -1;
         if (b.consumed() > in_bits_limit) return -3;
@@ -378,7 +383,8 @@ struct HostEnv {
         }
         return v;
     }
-    void put_literal(uint8_t c) { out[pos++] = c; }
+    uint32_t cap = 0xffffffffu; /* bytes out[] can take */
+    bool put_literal(uint8_t c) { if (pos >= cap) return false; out[pos++] = c; return true; }
     void copy_match(int len, int dist) { for (int k = 0; k < len; ++k, ++pos) out[pos] = out[pos - dist]; }
     uint32_t out_pos() const { return pos; }
     Tables &tables() { return T; }

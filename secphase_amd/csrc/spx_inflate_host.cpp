@@ -16,6 +16,7 @@ extern "C" int spx_inflate_core_host(const uint8_t *in, int64_t in_len, uint8_t 
     env.in = in;
     env.in_len = (size_t)in_len;
     env.out = out;
+    env.cap = (uint32_t)out_len;
     return spxz::inflate_stream(env, in_len * 8, (uint32_t)out_len);
 }
 

@@ -37,11 +37,22 @@ struct BlockDesc {
     uint32_t clen, ulen, crc, pad;
 };
 
+/* lane `n` of v <- the wave-uniform value c (v_writelane_b32; on gfx9 the lane select shares the constant bus with the
+ * value, so it travels through M0) */
+__device__ __forceinline__ int writelane(int v, int c, int n)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(c), "s"(n) : "m0");
+    return v;
+}
+
 struct DevEnv {
     const uint32_t *in_al;
     uint32_t in_shift; /* bits: 0, 8, 16, 24 */
     uint8_t *out;
+    uint32_t limit;    /* bytes the block may produce (ISIZE): nothing is written to HBM beyond it */
     uint32_t pos, flushed;
+    uint32_t npend;    /* literals decoded but not yet in the ring: byte k of the run sits in lane k of litv */
+    int litv;
     spxz::Tables *T;
     uint8_t *ring;
     int lane_;
@@ -59,37 +70,65 @@ struct DevEnv {
     __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ uint32_t out_pos() const { return pos; }
 
-    /* ring -> HBM, all lanes; afterwards every byte below `pos` is visible to loads that bypass the vector L1 */
+    /* pending literals (one per lane) -> ring: ONE LDS store for up to 64 bytes */
+    __device__ __forceinline__ void commit()
+    {
+        if (npend) {
+            if ((uint32_t)lane_ < npend) ring[(pos - npend + (uint32_t)lane_) & (kRing - 1)] = (uint8_t)litv;
+            npend = 0;
+        }
+    }
+    /* ring -> HBM, all lanes; afterwards every byte below `pos` is visible to loads that bypass the vector L1.
+     * (The loops below have wave-uniform trip counts with the lane test inside: a divergent loop bound would make the
+     * compiler structurize the whole decoder loop around it.) */
     __device__ __forceinline__ void flush()
     {
+        commit();
         __syncthreads();
-        for (uint32_t i = flushed + (uint32_t)lane_; i < pos; i += 64) out[i] = ring[i & (kRing - 1)];
+        const uint32_t end = pos < limit ? pos : limit;
+        for (uint32_t base = flushed; base < end; base += 64) {
+            const uint32_t i = base + (uint32_t)lane_;
+            if (i < end) out[i] = ring[i & (kRing - 1)];
+        }
         flushed = pos;
         __threadfence();
     }
-    __device__ __forceinline__ void put_literal(uint8_t c)
+    __device__ __forceinline__ bool put_literal(uint8_t c)
     {
-        if (lane_ == 0) ring[pos & (kRing - 1)] = c;
+        /* the decoder is wave-uniform: the byte is an SGPR value, v_writelane drops it into lane npend */
+        litv = writelane(litv, (int)c, (int)npend);
+        ++npend;
         ++pos;
-        if (pos - flushed >= (uint32_t)kFlush) flush();
+        if (npend == 64) { /* 64 literals are pending: into the ring, and on to HBM when enough has gathered */
+            commit();
+            if (pos - flushed >= (uint32_t)kFlush) flush();
+            return pos <= limit; /* false = the block overruns */
+        }
+        return true;
     }
     __device__ __forceinline__ void copy_match(int len, int dist)
     {
+        commit();
         const uint32_t src0 = pos - (uint32_t)dist;
+        __syncthreads();
         if (dist <= kRing / 2) {
             /* near: ring -> ring.  Lane i produces bytes i, i + 64, ...; source byte = first `dist` bytes of the match
              * region repeated, all of them older than pos: no lane depends on another */
-            __syncthreads();
-            for (int i = lane_; i < len; i += 64) {
-                const uint32_t s = src0 + (uint32_t)(dist >= len ? i : i % dist);
-                ring[(pos + (uint32_t)i) & (kRing - 1)] = ring[s & (kRing - 1)];
+            for (int base = 0; base < len; base += 64) {
+                const int i = base + lane_;
+                if (i < len) {
+                    const uint32_t s = src0 + (uint32_t)(dist >= len ? i : i % dist);
+                    ring[(pos + (uint32_t)i) & (kRing - 1)] = ring[s & (kRing - 1)];
+                }
             }
         } else {
-            /* far: the source lies below `flushed` (kFlush <= kRing / 2), read it from HBM past the L1 */
-            __syncthreads();
-            for (int i = lane_; i < len; i += 64) {
-                const uint8_t v = __hip_atomic_load(out + src0 + (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ring[(pos + (uint32_t)i) & (kRing - 1)] = v;
+            /* far: the source lies below `flushed` (kFlush + 64 + 258 <= kRing / 2), read it from HBM past the L1 */
+            for (int base = 0; base < len; base += 64) {
+                const int i = base + lane_;
+                if (i < len) {
+                    const uint8_t v = __hip_atomic_load(out + src0 + (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ring[(pos + (uint32_t)i) & (kRing - 1)] = v;
+                }
             }
         }
         pos += (uint32_t)len;
@@ -111,8 +150,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restr
     env.in_al = reinterpret_cast<const uint32_t *>(comp + (d.in_off & ~(int64_t)3));
     env.in_shift = (uint32_t)(d.in_off & 3) * 8u;
     env.out = outbuf + d.out_off;
+    env.limit = d.ulen;
     env.pos = 0;
     env.flushed = 0;
+    env.npend = 0;
+    env.litv = 0;
     env.T = &T;
     env.ring = ring;
     env.lane_ = (int)threadIdx.x;

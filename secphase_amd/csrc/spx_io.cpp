@@ -235,6 +235,15 @@ struct Reader {
     bool closing = false, consumer_waiting = false;
     std::unique_ptr<spx::Pool> pool;
     std::thread walker;
+    /* optional device inflate (spx_bam_attach_device_inflate): chunks go to whichever side has room -- the host pool or
+     * the device workers (each: compressed bytes -> pinned memory -> HBM -> inflate kernel -> back) */
+    spx_bgzf_inflate_fn dev_fn = nullptr;
+    void *dev_user = nullptr;
+    std::vector<std::thread> dev_workers;
+    std::deque<Chunk *> dev_q;
+    std::condition_variable cv_dev;
+    int dev_busy = 0, dev_cap = 0; /* chunks queued or in work on the device side / how many it may hold */
+    int64_t n_chunks_dev = 0, n_chunks_host = 0;
     /* walker cursor (reader thread only) */
     Chunk *cur = nullptr;
     uint8_t *at = nullptr, *end = nullptr;
@@ -370,6 +379,20 @@ bool dispatch_chunk(Reader *r)
     Chunk *cp = c.release();
     const size_t nb = cp->blocks.size(), per = 16;
     if (nb == 0) { r->cv_chunk.notify_all(); return true; }
+    {
+        /* the device takes a chunk whenever it has room (it then works beside the pool, not instead of it) */
+        std::unique_lock<std::mutex> lk(r->mu);
+        if (r->dev_fn && r->dev_busy < r->dev_cap) {
+            cp->pending = 1;
+            ++r->dev_busy;
+            ++r->n_chunks_dev;
+            r->dev_q.push_back(cp);
+            lk.unlock();
+            r->cv_dev.notify_one();
+            return true;
+        }
+        ++r->n_chunks_host;
+    }
     for (size_t b0 = 0; b0 < nb; b0 += per) {
         const size_t b1 = std::min(nb, b0 + per);
         r->pool->submit([r, cp, b0, b1] {
@@ -732,6 +755,46 @@ void walker_main(Reader *r)
     }
 }
 
+/* one device-inflate worker: chunks from dev_q through the caller's function; a chunk the device cannot do (error from
+ * the function itself, not from the data) falls back to the host pool */
+void dev_worker_main(Reader *r, int index)
+{
+    std::vector<spx_bgzf_block> blk;
+    for (;;) {
+        Chunk *c = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(r->mu);
+            r->cv_dev.wait(lk, [&] { return r->closing || !r->dev_q.empty(); });
+            if (r->dev_q.empty()) return;
+            c = r->dev_q.front();
+            r->dev_q.pop_front();
+        }
+        blk.resize(c->blocks.size());
+        for (size_t k = 0; k < c->blocks.size(); ++k) {
+            const Block &b = c->blocks[k];
+            blk[k].data_off = (int64_t)b.coff; blk[k].clen = (uint32_t)b.clen; blk[k].uoff = b.uoff; blk[k].ulen = b.ulen; blk[k].crc = b.crc;
+            blk[k].reserved = 0;
+        }
+        const int rc = r->dev_fn(r->dev_user, index, r->map, (int64_t)r->fsize, blk.data(), (int32_t)blk.size(), c->data, (int64_t)c->len,
+                                 r->check_crc ? 1 : 0);
+        if (rc == 1) c->bad = 1;       /* corrupt DEFLATE data */
+        else if (rc == 2) c->bad = 2;  /* CRC mismatch */
+        else if (rc != 0) {            /* the device side failed: the host does this chunk */
+            Inflater inf;
+            for (const Block &b : c->blocks) {
+                if (!inf.run(r->map + b.coff, b.clen, c->data + b.uoff, b.ulen)) { c->bad = 1; continue; }
+                if (r->check_crc && crc_of(c->data + b.uoff, b.ulen) != b.crc) c->bad = 2;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(r->mu);
+            c->pending = 0;
+            --r->dev_busy;
+            r->cv_chunk.notify_all();
+        }
+    }
+}
+
 /* serial inflate of the blocks at the start of the file until `need` bytes are there (header parsing) */
 bool header_bytes(Reader *r, std::vector<uint8_t> &buf, std::vector<size_t> &blk_coff, std::vector<size_t> &blk_uoff, size_t &fpos, size_t need)
 {
@@ -1000,6 +1063,28 @@ extern "C" int spx_bam_release_batch(spx_bam_reader *h, const spx_batch *bt)
     return SPX_EINVAL;
 }
 
+extern "C" int spx_bam_attach_device_inflate(spx_bam_reader *h, spx_bgzf_inflate_fn fn, void *user, int32_t n_workers)
+{
+    if (!h || !fn || n_workers < 1 || n_workers > 32) return SPX_EINVAL;
+    Reader *r = &h->r;
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (r->dev_fn) return SPX_EINVAL;
+    r->dev_user = user;
+    r->dev_cap = n_workers + 1; /* one waiting per set of workers */
+    for (int k = 0; k < n_workers; ++k) r->dev_workers.emplace_back(dev_worker_main, r, k);
+    r->dev_fn = fn;
+    return SPX_OK;
+}
+
+extern "C" void spx_bam_inflate_counts(const spx_bam_reader *h, int64_t *chunks_host, int64_t *chunks_device)
+{
+    if (!h) return;
+    Reader *r = const_cast<Reader *>(&h->r);
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (chunks_host) *chunks_host = r->n_chunks_host;
+    if (chunks_device) *chunks_device = r->n_chunks_dev;
+}
+
 extern "C" void spx_bam_close(spx_bam_reader *h)
 {
     if (!h) return;
@@ -1011,7 +1096,10 @@ extern "C" void spx_bam_close(spx_bam_reader *h)
     r->cv_out.notify_all();
     r->cv_room.notify_all();
     r->cv_chunk.notify_all();
+    r->cv_dev.notify_all();
     if (r->walker.joinable()) r->walker.join();
+    r->cv_dev.notify_all();
+    for (auto &t : r->dev_workers) if (t.joinable()) t.join(); /* (chunks still queued are finished first: their slots are live) */
     r->pool.reset(); /* joins the workers: no inflate task is running after this */
     {
         std::lock_guard<std::mutex> lk(r->mu);

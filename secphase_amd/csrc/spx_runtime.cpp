@@ -1926,6 +1926,123 @@ extern "C" int64_t spx_inflate_bgzf_device(spx_ctx *c, const uint8_t *file, cons
     return utot;
 }
 
+/* ---- device inflate workers for the BAM reader (spx_bam_attach_device_inflate) ---- */
+struct spx_inflater {
+    spx_ctx *c = nullptr;
+    struct Worker {
+        hipStream_t st = nullptr;
+        uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+        SpxBgzfDesc *h_desc = nullptr, *d_desc = nullptr;
+        int32_t *h_status = nullptr, *d_status = nullptr;
+        size_t in_cap = 0, out_cap = 0, desc_cap = 0;
+        std::mutex mu;
+    };
+    std::vector<Worker> w;
+};
+
+extern "C" int spx_inflater_create(spx_ctx *c, int32_t n_workers, spx_inflater **out)
+{
+    if (!c || !out || n_workers < 1 || n_workers > 32) return fail(SPX_EINVAL, "invalid argument");
+    HIPCHK(hipSetDevice(c->device));
+    spx_inflater *inf = new spx_inflater();
+    inf->c = c;
+    inf->w = std::vector<spx_inflater::Worker>((size_t)n_workers);
+    for (auto &k : inf->w)
+        if (hipStreamCreateWithFlags(&k.st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); spx_inflater_free(inf); return fail(SPX_EHIP, "stream"); }
+    *out = inf;
+    return SPX_OK;
+}
+
+extern "C" void spx_inflater_free(spx_inflater *inf)
+{
+    if (!inf) return;
+    if (inf->c) (void)hipSetDevice(inf->c->device);
+    for (auto &k : inf->w) {
+        if (k.st) { (void)hipStreamSynchronize(k.st); (void)hipStreamDestroy(k.st); }
+        if (k.h_in) (void)hipHostFree(k.h_in);
+        if (k.h_out) (void)hipHostFree(k.h_out);
+        if (k.h_desc) (void)hipHostFree(k.h_desc);
+        if (k.h_status) (void)hipHostFree(k.h_status);
+        if (k.d_in) (void)hipFree(k.d_in);
+        if (k.d_out) (void)hipFree(k.d_out);
+        if (k.d_desc) (void)hipFree(k.d_desc);
+        if (k.d_status) (void)hipFree(k.d_status);
+    }
+    delete inf;
+}
+
+/* one chunk: the file range of its blocks -> pinned -> HBM, descriptors, kernel, inflated bytes -> pinned -> dst */
+extern "C" int spx_inflater_run(void *user, int32_t worker, const uint8_t *file, int64_t file_bytes, const spx_bgzf_block *blocks,
+                                int32_t n_blocks, uint8_t *dst, int64_t dst_bytes, int32_t check_crc)
+{
+    spx_inflater *inf = (spx_inflater *)user;
+    if (!inf || worker < 0 || (size_t)worker >= inf->w.size() || !file || !blocks || n_blocks <= 0 || !dst) return -1;
+    spx_inflater::Worker &W = inf->w[(size_t)worker];
+    std::lock_guard<std::mutex> lk(W.mu);
+    if (hipSetDevice(inf->c->device) != hipSuccess) return -1;
+    int64_t lo = blocks[0].data_off, hi = 0, umax = 0;
+    for (int32_t b = 0; b < n_blocks; ++b) {
+        lo = std::min<int64_t>(lo, blocks[b].data_off);
+        hi = std::max<int64_t>(hi, blocks[b].data_off + blocks[b].clen);
+        umax = std::max<int64_t>(umax, (int64_t)blocks[b].uoff + blocks[b].ulen);
+        if (blocks[b].ulen > 65536) return 1;
+    }
+    lo &= ~(int64_t)3; /* the kernel reads aligned dwords */
+    if (lo < 0 || hi > file_bytes || umax > dst_bytes) return -1;
+    const size_t in_bytes = (size_t)(hi - lo), out_bytes = (size_t)umax;
+#define WCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return -1; } } while (0)
+    if (in_bytes + 64 > W.in_cap) {
+        if (W.h_in) (void)hipHostFree(W.h_in);
+        if (W.d_in) (void)hipFree(W.d_in);
+        W.h_in = nullptr; W.d_in = nullptr;
+        W.in_cap = in_bytes + in_bytes / 4 + ((size_t)1 << 20);
+        WCHK(hipHostMalloc((void **)&W.h_in, W.in_cap, hipHostMallocDefault));
+        WCHK(hipMalloc((void **)&W.d_in, W.in_cap));
+    }
+    if (out_bytes + 64 > W.out_cap) {
+        if (W.h_out) (void)hipHostFree(W.h_out);
+        if (W.d_out) (void)hipFree(W.d_out);
+        W.h_out = nullptr; W.d_out = nullptr;
+        W.out_cap = out_bytes + out_bytes / 4 + ((size_t)1 << 20);
+        WCHK(hipHostMalloc((void **)&W.h_out, W.out_cap, hipHostMallocDefault));
+        WCHK(hipMalloc((void **)&W.d_out, W.out_cap));
+    }
+    if ((size_t)n_blocks > W.desc_cap) {
+        if (W.h_desc) (void)hipHostFree(W.h_desc);
+        if (W.d_desc) (void)hipFree(W.d_desc);
+        if (W.h_status) (void)hipHostFree(W.h_status);
+        if (W.d_status) (void)hipFree(W.d_status);
+        W.h_desc = nullptr; W.d_desc = nullptr; W.h_status = nullptr; W.d_status = nullptr;
+        W.desc_cap = (size_t)n_blocks + 1024;
+        WCHK(hipHostMalloc((void **)&W.h_desc, W.desc_cap * sizeof(SpxBgzfDesc), hipHostMallocDefault));
+        WCHK(hipMalloc((void **)&W.d_desc, W.desc_cap * sizeof(SpxBgzfDesc)));
+        WCHK(hipHostMalloc((void **)&W.h_status, W.desc_cap * 4, hipHostMallocDefault));
+        WCHK(hipMalloc((void **)&W.d_status, W.desc_cap * 4));
+    }
+    memcpy(W.h_in, file + lo, in_bytes);
+    memset(W.h_in + in_bytes, 0, 64);
+    for (int32_t b = 0; b < n_blocks; ++b) {
+        SpxBgzfDesc &d = W.h_desc[b];
+        d.in_off = blocks[b].data_off - lo;
+        d.out_off = blocks[b].uoff;
+        d.clen = blocks[b].clen; d.ulen = blocks[b].ulen; d.crc = blocks[b].crc; d.pad = 0;
+    }
+    WCHK(hipMemcpyAsync(W.d_in, W.h_in, in_bytes + 64, hipMemcpyHostToDevice, W.st));
+    WCHK(hipMemcpyAsync(W.d_desc, W.h_desc, (size_t)n_blocks * sizeof(SpxBgzfDesc), hipMemcpyHostToDevice, W.st));
+    WCHK(spx_launch_bgzf_inflate(W.d_in, W.d_desc, n_blocks, W.d_out, W.d_status, check_crc, W.st));
+    WCHK(hipMemcpyAsync(W.h_status, W.d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, W.st));
+    WCHK(hipMemcpyAsync(W.h_out, W.d_out, out_bytes, hipMemcpyDeviceToHost, W.st));
+    WCHK(hipStreamSynchronize(W.st));
+#undef WCHK
+    int rc = 0;
+    for (int32_t b = 0; b < n_blocks; ++b) {
+        if (W.h_status[b] == -4) rc = rc ? rc : 2;
+        else if (W.h_status[b] != 0) rc = 1;
+    }
+    memcpy(dst, W.h_out, out_bytes);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ */
 /* host-only plan view */
 struct spx_plan {

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--devices", default="0")
     ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else None)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gpu-inflate", type=int, default=-1)
     args = ap.parse_args()
     from oracle import orc
     from secphase_amd import records, synth
@@ -69,6 +70,8 @@ def main():
     flags = ["--ont", "-b", "50"] if ont else ["--hifi"]
     cmd = [exe] + flags + ["-@", str(args.threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "e2e",
                            "--groupsPerBatch", str(args.batch), "--devices", args.devices]
+    if args.gpu_inflate >= 0:
+        cmd += ["--gpuInflate", str(args.gpu_inflate)]
     t0 = time.time()
     p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SPX_TIMING="1"))
     wall = time.time() - t0
@@ -89,7 +92,7 @@ def main():
         got = open(os.path.join(outd, "e2e.out.log"), "rb").read()
         same = got[:len(want)] == want and (args.groups > ncheck or len(got) == len(want))
     size = os.path.getsize(bam)
-    keep = ("start-up", "time in the scoring loop", "finalise+write:", "wind-down")
+    keep = ("start-up", "time in the scoring loop", "finalise", "wind-down", "inflate chunks")
     print(json.dumps({"groups": args.groups, "platform": args.platform, "devices": args.devices, "bam_bytes": size, "wall_s": round(wall, 3),
                       "groups_per_s": round(args.groups / wall, 1), "GB_bam_per_s": round(size / wall / 1e9, 4),
                       "cpu_oracle_groups_per_s": round(ncheck / cpu, 1) if cpu else None, "cpu_threads": args.threads,
