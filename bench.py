@@ -670,7 +670,7 @@ def main():
             api._chk(L.spx_trim(ctx.h), "spx_trim")
             torch.cuda.empty_cache()
         if want_bam:
-            nb = gps if args.from_bam < 0 else args.from_bam
+            nb = min(2 * gps, D * gps) if args.from_bam < 0 else args.from_bam  # (two steps' worth: the reader's read-ahead during start-up does not cover the whole file)
             chunks, have = [], 0
             for b in ptrs:  # the generator chunks of the timed batches, in order
                 for ch in b:

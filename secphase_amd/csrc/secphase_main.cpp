@@ -105,7 +105,7 @@ static void usage(const char *prog)
             "         --device               GPU index [0]\n"
             "         --devices              several GPUs, e.g. 0-7 or 0,2,5: batches are dealt round-robin, the output is\n"
             "                                the same file-order list\n"
-            "         --gpuInflate           BGZF inflate workers per GPU beside the host threads [3]; 0: host only\n"
+            "         --gpuInflate           BGZF inflate workers per GPU beside the host threads [5]; 0: host only\n"
             "         --writeBam, -w         Write <prefix>.quality_modified.out.bam (SAM text, as the reference does) with\n"
             "                                the base qualities modified by BAQ\n"
             "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode)\n");
@@ -122,7 +122,7 @@ int main(int argc, char *argv[])
     par.conf_b = 20; par.flank_margin = 500;
     std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
     bool preset_ont = false, preset_hifi = false, marker_mode = true, write_bam = false, batch_given = false;
-    int threads = 4, groups_per_batch = 16384, gpu_inflate = 3, c;
+    int threads = 4, groups_per_batch = 16384, gpu_inflate = 5, c;
     if (const char *e = getenv("SPX_GPU_INFLATE")) gpu_inflate = atoi(e);
     std::vector<int> devices;
     auto parse_devices = [&](const char *txt) { /* "0-3", "0,2,5", "1" */
@@ -270,7 +270,7 @@ int main(int argc, char *argv[])
     /* BGZF inflate on the device(s) beside the host pool: the reader hands a chunk to whichever side has room */
     struct InflateRoute { std::vector<spx_inflater *> inf; int per_dev = 0; } route;
     if (gpu_inflate > 0 && marker_mode) {
-        route.per_dev = std::min(gpu_inflate, 8);
+        route.per_dev = std::min(gpu_inflate, 16);
         for (int d = 0; d < n_dev; ++d) {
             spx_inflater *inf = nullptr;
             if (spx_inflater_create(ctxs[(size_t)d], route.per_dev, &inf) == SPX_OK) route.inf.push_back(inf);

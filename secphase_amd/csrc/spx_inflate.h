@@ -43,6 +43,7 @@ constexpr int kDistRoot = 9;  /* bits of the distance root table */
 /* root-table entry (16 bits): bits 0-8 symbol (bit 8 set = not a literal), bits 9-12 code length; 0 = not a root code -> canonical walk.  Length and
  * distance base / extra bits are computed from the symbol (len_base ..): the rarer path pays, the table stays small */
 SPXZ_HD uint16_t mk_entry(int nbits, int sym) { return (uint16_t)((unsigned)sym | ((unsigned)nbits << 9)); }
+constexpr uint16_t kNoEntry = 0x100; /* "not a literal", length 0: the literal loop needs ONE bit test */
 
 struct Tables {
     uint16_t lit[1 << kLitRoot];
@@ -185,8 +186,8 @@ SPXZ_HD int build_tables(E &env, int nlit, int ndist)
 {
     Tables &T = env.tables();
     const int lane = env.lane(), lanes = env.lanes();
-    for (int k = lane; k < (1 << kLitRoot); k += lanes) T.lit[k] = 0;
-    for (int k = lane; k < (1 << kDistRoot); k += lanes) T.dist[k] = 0;
+    for (int k = lane; k < (1 << kLitRoot); k += lanes) T.lit[k] = kNoEntry;
+    for (int k = lane; k < (1 << kDistRoot); k += lanes) T.dist[k] = kNoEntry;
     int rc = 0;
     if (lane == 0) {
         rc = canon_build(T.lens, nlit, T.lit_count, T.lit_sorted, T.code_of);
@@ -283,12 +284,12 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                 for (;;) {
                     b.refill();
                     e = env.uniform_u32(T.lit[b.peek(kLitRoot)]);
-                    if (e == 0 || (e & 0x100u)) break;
+                    if (e & 0x100u) break; /* a length / end-of-block code, or no root code at all */
                     b.drop((int)(e >> 9));
                     if (!env.put_literal((uint8_t)e)) return -2; /* false: more bytes than the block may hold */
                 }
                 int sym;
-                if (e != 0) {
+                if (e != kNoEntry) {
                     b.drop((int)(e >> 9));
                     sym = (int)(e & 511);
                 } else {
@@ -308,7 +309,7 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                 b.refill();
                 const uint32_t d = env.uniform_u32(T.dist[b.peek(kDistRoot)]);
                 int dsym;
-                if (d != 0) {
+                if (d != kNoEntry) {
                     b.drop((int)(d >> 9));
                     dsym = (int)(d & 511);
                 } else {

@@ -15,11 +15,11 @@
  *   - the 64 lanes share the data-parallel parts: zeroing and filling the decode tables, LZ77 copies (lane i copies
  *     bytes i, i + 64, ...: an overlapping match is a repeat of its first `dist` bytes, so the lanes are independent),
  *     flushing finished output to HBM, and the CRC-32 (64 stripes, combined with the GF(2) shift operator);
- *   - every output byte goes through an LDS ring of the last kRing bytes: near matches (distance <= kRing / 2, the
+ *   - every output byte goes through an LDS ring of the last kRing bytes: near matches (distance <= kRing / 2 = 1 KB, the
  *     bulk of what zlib finds in quality strings) never touch HBM; far matches (a secondary alignment repeats the
  *     primary's SEQ / QUAL ~23 KB back) read what earlier flushes wrote (flush = stores + agent-scope fence; the
  *     loads bypass the vector L1).
- * LDS per wave: tables 6.7 KB + ring 4 KB + CRC table 1 KB: 13 waves per CU.
+ * LDS per wave: tables 6.7 KB + ring 2 KB (the CRC's byte table re-uses the literal table): 18 waves per CU.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,8 +28,8 @@
 
 namespace {
 
-constexpr int kRing = 4096;
-constexpr int kFlush = 1024; /* flush when this many bytes wait in the ring (<= kRing / 2 - 258) */
+constexpr int kRing = 2048;
+constexpr int kFlush = 512; /* flush when this many bytes wait in the ring (kFlush + 64 + 258 <= kRing / 2) */
 
 struct BlockDesc {
     int64_t in_off;   /* byte offset of the DEFLATE data in the compressed buffer */
@@ -142,7 +142,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restr
 {
     __shared__ spxz::Tables T;
     __shared__ uint8_t ring[kRing];
-    __shared__ uint32_t crc_tab[256];
     const int b = blockIdx.x;
     if (b >= n_blocks) return;
     const BlockDesc d = blocks[b];
@@ -166,6 +165,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restr
     rc = __builtin_amdgcn_readfirstlane(rc);
     if (rc == 0 && check_crc && d.ulen > 0) {
         /* CRC-32 of the block: 64 stripes (byte-table recurrence per lane), folded with the GF(2) shift operator */
+        /* (the decode tables are dead now: the byte table of the CRC takes the literal table's place) */
+        uint32_t *crc_tab = reinterpret_cast<uint32_t *>(T.lit);
+        __syncthreads();
         for (int k = (int)threadIdx.x; k < 256; k += 64) crc_tab[k] = spxz::crc_table_entry((uint32_t)k);
         __syncthreads();
         const uint32_t n = d.ulen, step = (n + 63) / 64;

@@ -1071,6 +1071,9 @@ extern "C" int spx_bam_attach_device_inflate(spx_bam_reader *h, spx_bgzf_inflate
     if (r->dev_fn) return SPX_EINVAL;
     r->dev_user = user;
     r->dev_cap = n_workers + 1; /* one waiting per set of workers */
+    /* a chunk on the device takes tens of milliseconds (one wave per block: latency, not throughput), the walker takes
+     * chunks in file order: look further ahead, so that device chunks are dispatched long before they are needed */
+    r->max_inflight += 3 * n_workers;
     for (int k = 0; k < n_workers; ++k) r->dev_workers.emplace_back(dev_worker_main, r, k);
     r->dev_fn = fn;
     return SPX_OK;
