@@ -1052,6 +1052,7 @@ SPX_HD int group_blocks(const GroupView &G, const Pools &P, const Params &par, G
     return blocks_finish(G, P, par, S, B);
 }
 
+struct RowRec;
 /* where the emitting pass writes */
 struct PlanOut {
     /* per problem */
@@ -1063,9 +1064,14 @@ struct PlanOut {
     /* per wanted row */
     int32_t *rows, *row_expect, *row_prob;
     uint8_t *row_rawq;
+    /* device: the emitting pass writes the four row fields as ONE 16-byte record per row (a lane walks its alignment and
+     * writes its rows one after the other: one open cache line per lane instead of four; rows_unpack_kernel then spreads
+     * the records over the arrays above, coalesced).  NULL: the arrays are written directly (host plan). */
+    struct RowRec *rr;
     /* quality edits (all_rows) */
     int32_t *qe_rec, *qe_pos, *qe_len, *qe_row0, *qe_batch;
 };
+struct RowRec { int32_t row, expect, prob, rawq; };
 struct PlanBase { /* this group's first problem / row / edit and scratch offsets */
     int64_t prob, row, qe, s_off, f_off;
 };
@@ -1103,6 +1109,11 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
         at.qe++;
         if (!EMIT) gc.n_qe++;
     };
+    /* row fields: one record per row on the device, four arrays on the host */
+    auto row_get = [&](int64_t i) -> int { return out.rr ? out.rr[i].row : out.rows[i]; };
+    auto row_set = [&](int64_t i, int v) { if (out.rr) out.rr[i].row = v; else out.rows[i] = v; };
+    auto exp_get = [&](int64_t i) -> int { return out.rr ? out.rr[i].expect : out.row_expect[i]; };
+    auto exp_set = [&](int64_t i, int v) { if (out.rr) out.rr[i].expect = v; else out.row_expect[i] = v; };
     const Blk *blocks = S.proj + (int64_t)ai * S.blk_cap;
     const int nblocks = S.nproj[ai];
     int32_t *rows_mk = S.rows_mk + (int64_t)ai * S.rows_cap;
@@ -1146,7 +1157,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                         if (par.all_rows) { if (EMIT) rows_mk[t - margin] = k; }
                         else {
                             if (nrows >= S.rows_cap) return SPX_ENOMEM;
-                            if (EMIT) { rows_mk[nrows] = k; out.rows[at.row + nrows] = t + 1; }
+                            if (EMIT) { rows_mk[nrows] = k; row_set(at.row + nrows, t + 1); }
                             ++nrows;
                         }
                     }
@@ -1157,11 +1168,16 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
             const int64_t row0 = at.row;
             if (EMIT) {
                 for (int w = 0; w < nrows; ++w) {
-                    const int t = par.all_rows ? margin + w : out.rows[row0 + w] - 1;
-                    out.rows[row0 + w] = t + 1;
-                    out.row_expect[row0 + w] = -1;
-                    out.row_rawq[row0 + w] = qual[b.sqs + t];
-                    out.row_prob[row0 + w] = (int32_t)at.prob;
+                    const int t = par.all_rows ? margin + w : row_get(row0 + w) - 1;
+                    if (out.rr) {
+                        RowRec rec = {t + 1, -1, (int32_t)at.prob, (int32_t)qual[b.sqs + t]};
+                        out.rr[row0 + w] = rec;
+                    } else {
+                        out.rows[row0 + w] = t + 1;
+                        out.row_expect[row0 + w] = -1;
+                        out.row_rawq[row0 + w] = qual[b.sqs + t];
+                        out.row_prob[row0 + w] = (int32_t)at.prob;
+                    }
                 }
             }
             /* expected reference index of every wanted base, from the CIGAR walk of the write-back loop; the wanted
@@ -1176,9 +1192,9 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                     const int e1 = o.sqe < b.sqe ? o.sqe : b.sqe, s1 = o.sqs > b.sqs ? o.sqs : b.sqs;
                     int len = e1 - s1 + 1;
                     if (o.len < len) len = o.len;
-                    while (w < nrows && out.rows[row0 + w] - 1 < y) ++w;
-                    while (w < nrows && out.rows[row0 + w] - 1 < y + len) {
-                        out.row_expect[row0 + w] = x + (out.rows[row0 + w] - 1 - y);
+                    while (w < nrows && row_get(row0 + w) - 1 < y) ++w;
+                    while (w < nrows && row_get(row0 + w) - 1 < y + len) {
+                        exp_set(row0 + w, x + (row_get(row0 + w) - 1 - y));
                         ++w;
                     }
                 }
@@ -1198,7 +1214,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                     const int k = rows_mk[w2];
                     if (k < 0) continue;
                     Mk &m = own(k);
-                    if (out.row_expect[row0 + w2] >= 0) m.row = (int32_t)(row0 + w2);
+                    if (exp_get(row0 + w2) >= 0) m.row = (int32_t)(row0 + w2);
                     else { m.row = -1; m.q = (uint8_t)(par.set_q < 94 ? par.set_q : 93); } /* base not under an M op: keeps set_q */
                 }
                 const int64_t p = at.prob;

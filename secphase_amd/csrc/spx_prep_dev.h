@@ -54,6 +54,7 @@ struct spx_emit_args {
     spxl::PlanOut out;
     double *hmm;      /* [n_prob][SPX_H_N], filled by problem_constants_kernel */
     int32_t n_prob, pad;
+    int64_t n_rows;   /* wanted rows of the work list (rows_unpack_kernel) */
     spx_dev_marker *markers;
     int32_t *mk_ref_pos;
     int32_t *mk_first;

@@ -66,9 +66,9 @@ __global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= A.n_slots) return;
-    AlnState st = A.ast[s];
+    AlnState st;
+    memset(&st, 0, sizeof st); /* (first kernel of the phase: the state starts here; recode_kernel, which flags has_n, runs after it) */
     const Rec r = A.recs[s];
-    st.n_ops = 0; st.mm_cap = 0; st.conf_cap = 0; st.n_conf = 0; st.n_mm = 0;
     st.err = build_ops<false>(r, A.P, A.par.min_q, A.par.indel_threshold, st, nullptr);
     if (st.err) { st.n_ops = 0; st.mm_cap = 0; st.conf_cap = 0; }
     A.ast[s] = st;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void aln_caps_kernel(spx_prep_args A)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= A.n_slots) return;
-    AlnState st = A.ast[s];
-    st.n_conf = 0; st.n_mm = 0; st.err = 0;
+    AlnState st;
+    memset(&st, 0, sizeof st); /* (first kernel of the phase: the state starts here; recode_kernel, which flags has_n, runs after it) */
     aln_caps(A.recs[s], st.n_ops, st.conf_cap, st.mm_cap);
     if (A.tight_caps) { st.n_ops = st.n_ops / 8 + 2; st.mm_cap = st.mm_cap / 8 + 1; } /* tests: forces the fallback */
     A.ast[s] = st;
@@ -265,6 +265,16 @@ __global__ __launch_bounds__(64) void aln_emit_kernel(spx_prep_args A, spx_emit_
     if (gc.err || !gc.scored) return;
     GroupCtx c = group_ctx(A, k);
     aln_pass_emit(c.G, s - A.slot0[k], A.P, A.rv, A.par, c.S, gc, E.base[s], E.out);
+}
+
+/* one thread per wanted row: the emitting pass' 16-byte records -> the arrays the DP / MAP kernels read (coalesced) */
+__global__ __launch_bounds__(256) void rows_unpack_kernel(const RowRec *__restrict__ rr, int64_t n_rows, int32_t *__restrict__ rows,
+                                                          int32_t *__restrict__ expect, int32_t *__restrict__ prob, uint8_t *__restrict__ rawq)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const RowRec r = rr[i];
+    rows[i] = r.row; expect[i] = r.expect; prob[i] = r.prob; rawq[i] = (uint8_t)r.rawq;
 }
 
 __global__ __launch_bounds__(64) void group_finish_kernel(spx_prep_args A, spx_emit_args E)
@@ -542,6 +552,9 @@ extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args 
 {
     if (A->n_dgroups <= 0) return hipSuccess;
     hipLaunchKernelGGL(aln_emit_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A, *E);
+    if (E->out.rr && E->n_rows > 0)
+        hipLaunchKernelGGL(rows_unpack_kernel, dim3((unsigned)((E->n_rows + 255) / 256)), dim3(256), 0, st, E->out.rr, E->n_rows, E->out.rows,
+                           E->out.row_expect, E->out.row_prob, E->out.row_rawq);
     hipLaunchKernelGGL(group_finish_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A, *E);
     if (E->n_prob > 0)
         hipLaunchKernelGGL(problem_constants_kernel, dim3((E->n_prob + 255) / 256), dim3(256), 0, st, A->par, E->n_prob, E->out.L, E->out.R,

@@ -836,7 +836,10 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
         if (rc2 != SPX_OK) { spx_work_free(c, w); return fail(rc2, rc2 == SPX_ENOMEM ? "pinned staging chunk" : "copy of the staged records"); }
     }
     const double t1 = now_s();
-    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes), c->copy_stream));
+    /* the recoded-SEQ pool: recode_kernel writes every word behind the lead pad, only the pads need a value (they are read,
+     * never used); zeroing the whole pool was a 3.7 GB fill per 131 072 HiFi groups */
+    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)spx::kCodeLeadBytes, c->copy_stream));
+    HIPCHK(hipMemsetAsync(base + w->o_code + spx::kCodeLeadBytes + ((L.seq_bytes + 3) & ~(int64_t)3), 0, (size_t)spx::kCodeTailBytes - 8, c->copy_stream));
     HIPCHK(hipEventCreateWithFlags(&w->ev_staged, hipEventDisableTiming));
     HIPCHK(hipEventRecord(w->ev_staged, c->copy_stream));
     w->st.prep_seconds = t1 - t0;
@@ -951,10 +954,8 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     HIPCHK(hipMemsetAsync(PL.d_tot, 0, sizeof(spx_prep_totals), PL.stream));
     bool phase1 = true;
     for (int attempt = 0;; ++attempt) {
-        if (phase1) {
-            HIPCHK(hipMemsetAsync(A.ast, 0, (ns + 1) * sizeof(spxl::AlnState), PL.stream));
-            HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, PL.stream));
-        }
+        /* (the per-alignment state is initialised by the first kernel of phase 1, not by a fill launch) */
+        if (phase1) HIPCHK(spx_prep_phase1(&A, (const uint32_t *)(base + L.o_seq), (L.seq_bytes + 3) / 4, PL.stream));
         HIPCHK(spx_prep_phase2(&A, d_base, d_mkb, PL.stream));
         HIPCHK(hipMemcpyAsync(PL.h_tot, PL.d_tot, sizeof(spx_prep_totals), hipMemcpyDeviceToHost, PL.stream));
         HIPCHK(hipStreamSynchronize(PL.stream));
@@ -1027,7 +1028,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
                  o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N), o_row_off = cv.take<int32_t>(np),
                  o_n_rows = cv.take<int32_t>(np), o_s_off = cv.take<int64_t>(np), o_fs_off = cv.take<int64_t>(np),
                  o_prob_slots = cv.take<int32_t>(np), o_hasn = cv.take<uint8_t>(np + 16), o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr),
-                 o_rawq = cv.take<uint8_t>(nr + 16), o_row_prob = cv.take<int32_t>(nr), o_qe = cv.take<int32_t>(5 * nq + 4),
+                 o_rawq = cv.take<uint8_t>(nr + 16), o_row_prob = cv.take<int32_t>(nr), o_rr = cv.take<spxl::RowRec>(nr + 1), o_qe = cv.take<int32_t>(5 * nq + 4),
                  o_order_f = cv.take<int32_t>(order_f_n + 64), o_order_b = cv.take<int32_t>(order_b_n + 64),
                  o_mk_first = cv.take<int32_t>(ng + 2), o_markers = cv.take<spx_dev_marker>(nm + 1), o_mkref = cv.take<int32_t>(nm + 1),
                  o_naln = cv.take<uint8_t>(ng + 16), o_sec = cv.take<uint16_t>(ng + 8), o_rfe = cv.take<int32_t>(ng * 10 + 10),
@@ -1058,6 +1059,8 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     E.out.has_n = (uint8_t *)(B0 + o_hasn); E.hmm = (double *)(B0 + o_hmm); E.n_prob = (int32_t)np; E.out.s_off = (int64_t *)(B0 + o_s_off); E.out.fsave_off = (int64_t *)(B0 + o_fs_off);
     E.out.rows = (int32_t *)(B0 + o_rows); E.out.row_expect = (int32_t *)(B0 + o_expect); E.out.row_prob = (int32_t *)(B0 + o_row_prob);
     E.out.row_rawq = (uint8_t *)(B0 + o_rawq);
+    E.out.rr = (spxl::RowRec *)(B0 + o_rr);
+    E.n_rows = (int64_t)nr;
     int32_t *qe = (int32_t *)(B0 + o_qe);
     E.out.qe_rec = qe; E.out.qe_pos = qe + nq; E.out.qe_len = qe + 2 * nq; E.out.qe_row0 = qe + 3 * nq; E.out.qe_batch = qe + 4 * nq;
     for (int k = 0; k < 5; ++k) w->d_qe[k] = qe + (size_t)k * nq;
@@ -1068,8 +1071,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     E.sec_mask = (uint16_t *)(B0 + o_sec);
     E.rfe = (int32_t *)(B0 + o_rfe); E.rfs = (int32_t *)(B0 + o_rfs); E.atid = (int32_t *)(B0 + o_atid);
     E.info = (spx_group_info *)(B0 + o_info);
-    HIPCHK(hipMemsetAsync(B0 + o_mk_first, 0, (ng + 2) * 4, PL.stream));
-    HIPCHK(spx_prep_emit(&A, &E, PL.stream));
+    HIPCHK(spx_prep_emit(&A, &E, PL.stream)); /* (group_finish_kernel writes every entry of mk_first) */
     /* launch orders */
     HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (order_f_n + 64) * 4, PL.stream));
     HIPCHK(hipMemsetAsync(B0 + o_order_b, 0xff, (order_b_n + 64) * 4, PL.stream));
