@@ -47,10 +47,13 @@ def pmc_traffic(kernel, gps, platform):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             meta = prof.get("_meta", {})
-            if meta.get("groups_per_step") != gps or meta.get("platform", "hifi") != platform:
+            if meta.get("platform", "hifi") != platform or not meta.get("groups_per_step"):
                 continue
             k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel) or prof.get(kernel)
-            return int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
+            b = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024
+            # per launch of THIS run: the kernels' traffic is proportional to the groups of a launch (same workload, same
+            # per-problem volumes), the profile may have been taken at another batch size
+            return int(b * gps / meta["groups_per_step"])
         except Exception:
             continue
     return None
