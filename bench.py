@@ -302,8 +302,48 @@ def main():
     # a staged list may be in flight once: run() keeps depth + 1 submissions in flight and rotates over the D lists
     if not args.kernel_only:
         args.depth = max(1, min(args.depth, D - 1))
+    # ---- BASELINE config 5 at N > 1 (load-balance stress): the step's groups are cut by COST, not by count.  Every rank has
+    # generated its count-based share; the per-group costs (bases over all alignments of the group: what the preparation
+    # walks and the DP realigns) are all-gathered, the same cost boundaries come out on every rank (shard_by_cost), and a
+    # rank regenerates the groups of its cost-balanced range (the generator is deterministic per group index).
+    shard_info = None
+    if world > 1 and mixed and not args.kernel_only:
+        def group_costs(b):
+            out = []
+            for ch in b:
+                bt = ch.batch.contents
+                lq = np.ctypeslib.as_array(bt.l_qseq, shape=(bt.n_alns,)).astype(np.float64)
+                gf = np.ctypeslib.as_array(bt.grp_first, shape=(bt.n_groups + 1,))
+                cs_ = np.concatenate([[0.0], np.cumsum(lq)])
+                out.append(cs_[gf[1:]] - cs_[gf[:-1]])
+            return np.concatenate(out)
+
+        new_batches, imb_before, imb_after = [], [], []
+        for i in range(D):
+            mine = torch.from_numpy(group_costs(batches[i])).to(coll_dev)
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            cost = np.concatenate([p_.cpu().numpy() for p_ in parts])  # global order of the step: (rank, group)
+            per_rank = [float(p_.sum()) for p_ in parts]
+            imb_before.append(max(per_rank) * world / max(sum(per_rank), 1.0))
+            bounds, imb = shard.shard_by_cost(cost, world)
+            imb_after.append(imb)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            pieces = []
+            j = lo
+            while j < hi:  # global index j = owner * gps + offset  ->  generator index owner * D * gps + i * gps + offset
+                owner, off = divmod(j, gps)
+                n_ = min(hi - j, gps - off)
+                pieces += gen_parallel(genome, owner * D * gps + i * gps + off, n_, args.gen_chunk, host_threads)
+                j += n_
+            new_batches.append(pieces)
+        batches = new_batches
+        shard_info = {"by": "cost (bases over the alignments of a group), secphase_amd/shard.py::shard_by_cost",
+                      "imbalance_by_count": round(float(np.mean(imb_before)), 4), "imbalance_by_cost": round(float(np.mean(imb_after)), 4),
+                      "groups_of_rank0_per_step": [int(sum(ch.batch.contents.n_groups for ch in b)) for b in batches]}
     t_gen = time.time() - t0
     ptrs = [[ch.batch for ch in b] for b in batches]
+    gmax = max(int(sum(ch.batch.contents.n_groups for ch in b)) for b in batches)  # groups in this rank's largest batch
 
     # ---- parity gate on a sample of the very workload being timed (oracle = checker only) ----
     verified = 0
@@ -361,7 +401,7 @@ def main():
         t_stage = time.time() - t0
         pipe = api.Pipe(ctx, params, depth=args.depth, host_threads=host_threads)
         api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
-    outbuf = (api.GroupOut * gps)()
+    outbuf = (api.GroupOut * max(gps, gmax))()
 
     def out_at(base):
         return C.cast(C.byref(outbuf, base * C.sizeof(api.GroupOut)), C.POINTER(api.GroupOut))
@@ -640,6 +680,7 @@ def main():
                                 f"appends them in rank order") if world > 1 else "single GPU",
                 "verified_groups_vs_oracle": verified,
                 "rank_imbalance_dp_cells": round(imbalance, 4),
+                "sharding": shard_info,
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

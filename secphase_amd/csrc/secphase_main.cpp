@@ -229,7 +229,10 @@ int main(int argc, char *argv[])
     spx_bam_options bo;
     spx_bam_default_options(&bo);
     bo.threads = threads;
-    bo.batch_groups = marker_mode ? groups_per_batch : 0;
+    /* (tests: SPX_GPU_INFLATE_FIRST holds the reader back until the device inflate workers are attached, so that even a tiny
+     * file goes through them) */
+    const bool inflate_first = getenv("SPX_GPU_INFLATE_FIRST") != nullptr;
+    bo.batch_groups = (marker_mode && !inflate_first) ? groups_per_batch : 0;
     bo.ahead_batches = 2;
     bo.keep_batches = n_dev * (depth + 1) + 2 * n_dev + 6;
     bo.ahead_batches = 4; /* the reader keeps cutting batches while the devices start up */

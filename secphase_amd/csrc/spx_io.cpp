@@ -1071,6 +1071,7 @@ extern "C" int spx_bam_attach_device_inflate(spx_bam_reader *h, spx_bgzf_inflate
     if (r->dev_fn) return SPX_EINVAL;
     r->dev_user = user;
     r->dev_cap = n_workers + 1; /* one waiting per set of workers */
+    if (getenv("SPX_BAM_DEVICE_ALL")) r->dev_cap = 1 << 20; /* tests: every chunk from now on goes to the device */
     /* a chunk on the device takes tens of milliseconds (one wave per block: latency, not throughput), the walker takes
      * chunks in file order: look further ahead, so that device chunks are dispatched long before they are needed */
     r->max_inflight += 3 * n_workers;

@@ -462,6 +462,42 @@ def test_command_line_several_devices(ctx, tmp_path):
     assert p.returncode != 0 and "device" in p.stderr
 
 
+def test_command_line_with_device_inflate(ctx, tmp_path):
+    """every chunk of the BAM inflated by bgzf_inflate_kernel (the reader is held back until the device workers are
+    attached, 64 KB chunks): outputs identical to the oracle's; a flipped byte in the file ends the run with an error,
+    on the device path as on the host path"""
+    import subprocess
+    g = small_genome(synth.HIFI, max_secondaries=3, n_paralogs=3, read_len=6000)
+    chunks = [g.reads(i * 40, 40) for i in range(5)]
+    whole = g.reads(0, 200)
+    fa, bam = str(tmp_path / "asm.fa"), str(tmp_path / "reads.bam")
+    synth.write_fasta(fa, g.ref)
+    synth.write_bam(bam, [c.batch for c in chunks], g.ref, threads=2)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "secphase_amd", "bin", "secphase")
+    log_o, bm_o, bk_o = (str(tmp_path / n) for n in ("o.log", "o.mod.bed", "o.mk.bed"))
+    nre, _ = orc.run_batch(whole.batch, g.ref, records.preset("hifi"), threads=2, seed=1, log_path=log_o, bed_modified=bm_o, bed_markers=bk_o)
+    assert nre > 3
+    env = dict(os.environ, SPX_GPU_INFLATE_FIRST="1", SPX_BAM_DEVICE_ALL="1", SPX_BAM_CHUNK_KB="64", SPX_TIMING="1")
+    outd = str(tmp_path / "out")
+    p = subprocess.run([exe, "--hifi", "-@", "4", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t", "--groupsPerBatch", "37",
+                        "--gpuInflate", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr
+    import re
+    m = re.search(r"inflate chunks: (\d+) on the host pool, (\d+) on the device", p.stderr)
+    assert m and int(m.group(2)) > 10 and int(m.group(1)) == 0, p.stderr[-400:]
+    assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False)
+    assert filecmp.cmp(bm_o, os.path.join(outd, "t.modified_read_blocks.markers.bed"), shallow=False)
+    assert filecmp.cmp(bk_o, os.path.join(outd, "t.marker_blocks.bed"), shallow=False)
+    blob = bytearray(open(bam, "rb").read())
+    blob[len(blob) // 2] ^= 0x20
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(blob))
+    for e in (env, dict(os.environ)):
+        p = subprocess.run([exe, "--hifi", "-@", "4", "-i", bad, "-f", fa, "--outDir", str(tmp_path / "outbad"), "--prefix", "t",
+                            "--groupsPerBatch", "37"], capture_output=True, text=True, timeout=600, env=e)
+        assert p.returncode != 0 and "BAM read error" in p.stderr, p.stderr[-300:]
+
+
 def _quals_parity(ctx, genome, reads, params):
     """all-rows work list (-w/--writeBam): record qualities after BAQ equal the oracle's, scores unchanged"""
     import copy

@@ -441,3 +441,40 @@ def test_c_writer_equals_python_writer_records(built, tmp_path):
     synth.write_fasta(fa, g.ref)
     write_fasta(fb, g.ref)
     assert open(fa, "rb").read() == open(fb, "rb").read()
+
+
+def test_readers_closed_early_and_side_by_side(built, tmp_path):
+    """a reader closed while it is still inflating and cutting batches ahead (at open, in the middle, after one batch), and
+    four readers on one file at once from four threads: no hang, no crash, the same records"""
+    import threading
+    L = api.lib()
+    _declare_opts(L)
+    g = small_genome(synth.HIFI, read_len=2500, max_secondaries=2, n_paralogs=2)
+    chunks = [g.reads(i * 100, 100) for i in range(4)]
+    want = []
+    for ch in chunks:
+        want += _records(ch.batch)
+    bam = str(tmp_path / "r.bam")
+    synth.write_bam(bam, [c.batch for c in chunks], g.ref, threads=2)
+    for take in (0, 1, 3):
+        for pre in (0, 25):
+            o = BamOptions()
+            L.spx_bam_default_options(C.byref(o))
+            o.threads, o.chunk_bytes, o.batch_groups, o.ahead_batches = 3, 65536, pre, 4
+            rd = C.c_void_p()
+            assert L.spx_bam_open_opts(bam.encode(), C.byref(o), C.byref(rd)) == 0
+            for _ in range(take):
+                bp = C.POINTER(records.SpxBatch)()
+                assert L.spx_bam_next_batch(rd, 25, C.byref(bp)) == 25
+            L.spx_bam_close(rd)
+    got = [None] * 4
+
+    def run(k):
+        got[k], _ = _read_all(L, bam, 31 + k, threads=2, chunk_bytes=65536 * (k + 1))
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert all(x == want for x in got)
