@@ -110,7 +110,7 @@ def from_bam_leg(args, genome, record_chunks, n_groups, ncpu, oracle_log, oracle
         exe = os.path.join(ROOT, "secphase_amd", "bin", "secphase")
         flags = ["--ont", "-b", "50"] if ont else ["--hifi"]
         cmd = [exe] + flags + ["-@", str(threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "bench",
-                               "--groupsPerBatch", str(4096 if ont else 32768)]
+                               "--groupsPerBatch", str(4096 if ont else 16384)]
         runs = []
         for _ in range(2):  # two runs, the better one is reported (boxes of the pool differ; the first also warms the page cache of the binary)
             shutil.rmtree(outd, ignore_errors=True)

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else None)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--gpu-inflate", type=int, default=-1)
+    ap.add_argument("--tidy", action="store_true")
     args = ap.parse_args()
     from oracle import orc
     from secphase_amd import records, synth
@@ -73,7 +74,7 @@ def main():
     if args.gpu_inflate >= 0:
         cmd += ["--gpuInflate", str(args.gpu_inflate)]
     t0 = time.time()
-    p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SPX_TIMING="1"))
+    p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SPX_TIMING="1", **({"SPX_TIDY_EXIT": "1"} if args.tidy else {})))
     wall = time.time() - t0
     if p.returncode != 0:
         sys.exit(p.stderr[-3000:])
