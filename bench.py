@@ -183,7 +183,9 @@ def main():
     ap.add_argument("--platform", default="hifi", choices=["hifi", "ont", "mixed"])
     ap.add_argument("--kernel-only", action="store_true", help="only the replay of one prepared work list (profiles, kernel A/B)")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the pipeline (their device preparations run side by side)")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="batches in flight in the pipeline (their device preparations run side by side); 0: 3 (hifi), 4 (mixed), "
+                         "2 (ont: a list of 16 384 ONT groups keeps ~70 GB of saved rows, four of them do not fit in 288 GB)")
     ap.add_argument("--distinct", type=int, default=4, help="at most this many distinct batches per rank (HBM / host memory)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")
@@ -251,6 +253,10 @@ def main():
     ont = args.platform == "ont"
     mixed = args.platform == "mixed"
     gps = args.groups_per_step or (16384 if ont else 16384 if mixed else 131072)
+    if args.depth <= 0:
+        args.depth = 4 if mixed else (2 if ont and gps > 8192 else 3)
+        if mixed:
+            args.distinct = max(args.distinct, 5)
     # (large batches: the preparation kernels are dependent chains -- one lane walks one alignment / one group -- whose
     # duration hardly depends on the number of groups, so their cost per group falls with the batch size)
     # config 5 (mixed HiFi+ONT, power-law lengths, <= 8 secondaries) is run as --hifi over the whole mix, SURVEY 8(d)
