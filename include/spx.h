@@ -122,6 +122,14 @@ int spx_prepare_many(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_ba
 int spx_stage(spx_ctx *ctx, const spx_batch *const *batches, int32_t n_batches, const spx_params *par, int host_threads,
               spx_work **work);
 int spx_prepare_staged(spx_ctx *ctx, spx_work *work);
+/* CPUs this process can really use: online CPUs cut by the affinity mask and by the container's CPU-time quota (cgroup
+ * cpu.max).  The default wherever a host_threads argument is <= 0. */
+int spx_effective_cpus(void);
+/* Diagnostics, host only: what spx_stage would put on the wire for these batches.  A secondary whose SEQ / QUAL merely
+ * repeat the primary's (same strand: the same bytes; other strand: reverse complement / reversed qualities; each minus
+ * the record's hard clips -- verified base by base on the staging threads) is not transferred: the device rebuilds it.
+ * out[0] alignments of dispatched groups, out[1] aliased ones, out[2] SEQ + QUAL bytes of all, out[3] bytes transferred. */
+int spx_stage_transfer_stats(const spx_batch *const *batches, int32_t n_batches, int host_threads, int64_t *out);
 /* drops the prepared list (its HBM goes back to the context's cache), keeps the staged records */
 int spx_work_release(spx_ctx *ctx, spx_work *work);
 int spx_launch(spx_ctx *ctx, spx_work *work);  /* asynchronous on the ctx stream; inputs already in HBM */

@@ -114,7 +114,7 @@ static void usage(const char *prog)
 
 int main(int argc, char *argv[])
 {
-    setenv("GPU_MAX_HW_QUEUES", "12", 0); /* one hardware queue per stream of the scoring context */
+    setenv("GPU_MAX_HW_QUEUES", "14", 0); /* one hardware queue per stream of the scoring context */
     /* defaults: src/secphase.c:420-449 */
     spx_params par;
     memset(&par, 0, sizeof par);
@@ -308,7 +308,8 @@ int main(int argc, char *argv[])
      * flow through in-order pipelines (one per device): while batch k is on a GPU, batch k+1 is staged and copied,
      * batch k+2 is inflated by the reader, and the results of batch k-1 are written -- in file order */
     std::vector<spx_pipe *> pipes((size_t)n_dev, nullptr);
-    const int stage_threads = std::max(1, threads / n_dev);
+    /* staging copies into pinned memory: threads beyond the container's CPU quota only get the process throttled */
+    const int stage_threads = std::max(1, std::min(threads, spx_effective_cpus()) / n_dev);
     for (int d = 0; d < n_dev && marker_mode; ++d)
         if ((rc = spx_pipe_create(ctxs[(size_t)d], &par, depth, stage_threads, &pipes[(size_t)d])) != SPX_OK) {
             fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());

@@ -43,6 +43,14 @@ struct Rec {
     int64_t seq_off;   /* BYTE offset into the sequence pools (raw BAM nibbles / recoded 0..4 codes), multiple of 4 */
     int64_t qual_off;  /* BYTE offset into the quality pool */
     int64_t tag_off;   /* BYTE offset of the cs (or MD) string in the text pool, NUL-terminated */
+    /* what crosses PCIe (round 3): SEQ / QUAL of a secondary that merely repeat the primary's -- the same bases, or their
+     * reverse complement, minus hard clips: verified byte for byte on the staging threads -- are NOT transferred; the device
+     * rebuilds them from the primary's (seqqual_alias_kernel).  pk_*: offsets in the packed transfer buffers. */
+    int64_t pk_seq_off, pk_qual_off;
+    int32_t alias_slot;  /* -1: own bytes were transferred; else the slot (same work list) whose SEQ / QUAL this one repeats */
+    int32_t alias_shift; /* base i of this record = base (alias_rev ? alias_shift - i : alias_shift + i) of that slot */
+    int32_t alias_rev;   /* reverse complement (qualities reversed) */
+    int32_t pad_;
 };
 
 struct Op {

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/spx.h"
+#include "spx_pool.h"
 
 extern "C" void spx_internal_set_error(const char *msg);
 extern "C" int spx_internal_work_claim(spx_work *w, int claim); /* 1: mark in flight (fails when it already is), 0: clear */
@@ -26,6 +27,10 @@ extern "C" spx_alloc_gate *spx_internal_gate_create(void);
 extern "C" void spx_internal_gate_free(spx_alloc_gate *g);
 extern "C" void spx_internal_gate_skip(spx_alloc_gate *g, int64_t ticket);
 extern "C" void spx_internal_work_gate(spx_work *w, spx_alloc_gate *g, int64_t ticket);
+/* spx_stage in its two halves: host only (sizes, dispatch filter, repeated SEQ / QUAL) | device memory + copies */
+extern "C" int spx_internal_stage_begin(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par, int host_threads,
+                                        spx_work **out);
+extern "C" int spx_internal_stage_finish(spx_ctx *c, spx_work *w);
 
 namespace {
 
@@ -69,14 +74,16 @@ struct spx_pipe {
 static void run_job(spx_pipe *p, Job *j)
 {
     int rc = SPX_OK;
+    const bool stage_here = !j->work;
+    if (stage_here) { /* the host half runs beside the copies of the submission in front */
+        rc = spx_internal_stage_begin(p->ctx, j->batches.data(), (int32_t)j->batches.size(), &p->par, p->stage_threads, &j->work);
+        j->own_work = rc == SPX_OK;
+    }
     {
         std::unique_lock<std::mutex> lk(p->mu);
         p->cv_turn.wait(lk, [&] { return p->stage_turn == j->ticket; });
     }
-    if (!j->work) {
-        rc = spx_stage(p->ctx, j->batches.data(), (int32_t)j->batches.size(), &p->par, p->stage_threads, &j->work);
-        j->own_work = rc == SPX_OK;
-    }
+    if (stage_here && rc == SPX_OK) rc = spx_internal_stage_finish(p->ctx, j->work);
     {
         std::lock_guard<std::mutex> lk(p->mu);
         ++p->stage_turn;
@@ -133,7 +140,7 @@ extern "C" int spx_pipe_create(spx_ctx *ctx, const spx_params *par, int depth, i
     p->ctx = ctx;
     p->par = *par;
     p->depth = depth < 1 ? 1 : (depth > 8 ? 8 : depth);
-    int ht = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
+    int ht = host_threads > 0 ? host_threads : spx::effective_cpus();
     p->stage_threads = ht > 0 ? ht : 1; /* stagings run one after the other (ticket order): each gets all the threads */
     p->gate = spx_internal_gate_create();
     for (int t = 0; t < p->depth; ++t) p->workers.emplace_back(worker_main, p);

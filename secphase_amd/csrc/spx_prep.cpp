@@ -230,6 +230,7 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
                 r.flag = bt->flag[a]; r.tid = bt->tid[a]; r.pos = bt->pos[a]; r.l_qseq = bt->l_qseq[a];
                 r.n_cigar = bt->n_cigar[a];
                 r.cs_len = -1; r.md_len = -1;
+                r.alias_slot = -1;
                 st.recs.push_back(r);
             }
             st.slot0.push_back((int32_t)st.recs.size());
@@ -245,6 +246,87 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
             else if (bt->md_off && bt->md && bt->md_off[r.rec] >= 0) r.md_len = (int32_t)strlen(bt->md + bt->md_off[r.rec]);
         }
     });
+    /* SEQ / QUAL of a record that repeat those of another record of its group (ptMarker.c:48,79 read them from every record; an aligner writes
+     * the read once per record): same strand = the same bytes, other strand = reverse complement / reversed qualities,
+     * each minus the record's hard clips.  Verified base by base here; such a record's SEQ / QUAL stay on the host. */
+    const bool alias_on = !getenv("SPX_NO_ALIAS");
+    parallel_for((int64_t)st.grp_index.size(), threads, [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1 && alias_on; ++k) {
+            const int32_t s0 = st.slot0[(size_t)k], s1 = st.slot0[(size_t)k + 1];
+            /* the source: the record that holds most of the read (the primary unless it is the hard-clipped one) */
+            int32_t p = -1;
+            for (int32_t q = s0; q < s1; ++q) {
+                const spxl::Rec &rq = st.recs[(size_t)q];
+                if (p < 0 || rq.l_qseq > st.recs[(size_t)p].l_qseq ||
+                    (rq.l_qseq == st.recs[(size_t)p].l_qseq && !(rq.flag & SPX_FSECONDARY) && (st.recs[(size_t)p].flag & SPX_FSECONDARY)))
+                    p = q;
+            }
+            if (p < 0) continue;
+            const spxl::Rec &rp = st.recs[(size_t)p];
+            const spx_batch *bp = bts[rp.batch];
+            auto clips = [](const spx_batch *bt, const spxl::Rec &r, int &lc, int &rc) {
+                lc = rc = 0;
+                if (r.n_cigar <= 0) return;
+                const uint32_t *cg = bt->cigar + bt->cigar_off[r.rec];
+                if ((cg[0] & 0xf) == SPX_CHARD_CLIP) lc = (int)(cg[0] >> 4);
+                if (r.n_cigar > 1 && (cg[r.n_cigar - 1] & 0xf) == SPX_CHARD_CLIP) rc = (int)(cg[r.n_cigar - 1] >> 4);
+            };
+            int lcp, rcp;
+            clips(bp, rp, lcp, rcp);
+            const int64_t Tp = (int64_t)rp.l_qseq + lcp + rcp;
+            if (rp.l_qseq <= 0) continue;
+            const uint8_t *sp = bp->seq4 + bp->seq_off[rp.rec], *qp = bp->qual + bp->qual_off[rp.rec];
+            auto base_of = [](const uint8_t *sq, int64_t i) -> unsigned { return (sq[i >> 1] >> ((~i & 1) << 2)) & 0xf; };
+            static const uint8_t comp16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15}; /* nt16 complement = the nibble's bits reversed */
+            auto ld64 = [](const uint8_t *q) -> uint64_t { uint64_t v; memcpy(&v, q, 8); return v; };
+            /* 16 bases from base j of a BAM SEQ as one word, base j in the top nibble (reads the byte of base j + 15) */
+            auto nib16 = [&](const uint8_t *sq, int64_t j) -> uint64_t {
+                const uint64_t v = __builtin_bswap64(ld64(sq + (j >> 1)));
+                return (j & 1) ? (v << 4) | (uint64_t)(sq[(j >> 1) + 8] >> 4) : v;
+            };
+            for (int32_t q = s0; q < s1; ++q) {
+                if (q == p) continue;
+                spxl::Rec &rs = st.recs[(size_t)q];
+                const spx_batch *bs = bts[rs.batch];
+                int lcs, rcs;
+                clips(bs, rs, lcs, rcs);
+                const int64_t lq = rs.l_qseq;
+                if (lq <= 0 || (int64_t)lq + lcs + rcs != Tp) continue;
+                const bool rev = ((rs.flag ^ rp.flag) & SPX_FREVERSE) != 0;
+                /* base i of the record sits at oriented read coordinate lcs + i; in the source's orientation that is the
+                 * same coordinate, or T - 1 - it */
+                const int64_t shift = rev ? Tp - 1 - lcs - lcp : (int64_t)lcs - lcp;
+                const int64_t j0 = rev ? shift - (lq - 1) : shift, j1 = rev ? shift : shift + lq - 1;
+                if (j0 < 0 || j1 >= rp.l_qseq) continue;
+                const uint8_t *ss = bs->seq4 + bs->seq_off[rs.rec], *qs = bs->qual + bs->qual_off[rs.rec];
+                /* whole words (no early exit: a difference is the rare case), the last few bases one by one */
+                uint64_t diff = 0;
+                int64_t i = 0;
+                if (!rev) {
+                    if (memcmp(qs, qp + shift, (size_t)lq) != 0) continue;
+                    if ((shift & 1) == 0) {
+                        diff = memcmp(ss, sp + (shift >> 1), (size_t)(lq >> 1)) != 0;
+                        i = lq & ~(int64_t)1;
+                    } else
+                        for (; i + 16 <= lq; i += 16) diff |= ld64(ss + (i >> 1)) ^ __builtin_bswap64(nib16(sp, shift + i));
+                    for (; i < lq && !diff; ++i) diff = base_of(ss, i) != base_of(sp, shift + i);
+                } else {
+                    for (; i + 8 <= lq; i += 8) diff |= __builtin_bswap64(ld64(qs + i)) ^ ld64(qp + shift - i - 7);
+                    for (; i < lq; ++i) diff |= (uint64_t)(qs[i] ^ qp[shift - i]);
+                    if (diff) continue;
+                    /* bases i .. i+15 = the complements of the source's bases shift-i .. shift-i-15: the 16 nibbles in
+                     * reverse order with the bits of each reversed = the 64-bit word bit-reversed */
+                    for (i = 0; i + 16 <= lq; i += 16)
+                        diff |= __builtin_bswap64(ld64(ss + (i >> 1))) ^ __builtin_bitreverse64(nib16(sp, shift - i - 15));
+                    for (; i < lq && !diff; ++i) diff = base_of(ss, i) != comp16[base_of(sp, shift - i)];
+                }
+                if (diff) continue;
+                rs.alias_slot = p;
+                rs.alias_shift = (int32_t)shift;
+                rs.alias_rev = rev ? 1 : 0;
+            }
+        }
+    });
     StageLayout &L = st.lay;
     L = StageLayout();
     L.n_groups_in = n_in;
@@ -258,6 +340,9 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
         r.seq_off = sb; sb += (((lq + 1) / 2) + 3) & ~(int64_t)3;
         r.qual_off = qb; qb += lq;
         r.tag_off = tb; tb += (r.cs_len >= 0 ? r.cs_len : r.md_len >= 0 ? r.md_len : 0) + 1;
+        r.pk_seq_off = L.pk_seq_bytes; r.pk_qual_off = L.pk_qual_bytes;
+        if (r.alias_slot < 0) { L.pk_seq_bytes += (((lq + 1) / 2) + 3) & ~(int64_t)3; L.pk_qual_bytes += (lq + 3) & ~(int64_t)3; }
+        else L.n_aliased++;
     }
     L.cigar_words = cw; L.seq_bytes = sb; L.qual_bytes = qb; L.text_bytes = tb;
     for (int64_t s = 0; s < ns; ++s) {
@@ -307,7 +392,7 @@ void stage_copy(const Stage &st, char *dst, int threads)
 int64_t stage_section_bytes(const Stage &st, int sec)
 {
     const StageLayout &L = st.lay;
-    return sec == 0 ? L.cigar_words * 4 : sec == 1 ? L.seq_bytes : sec == 2 ? L.qual_bytes : L.text_bytes;
+    return sec == 0 ? L.cigar_words * 4 : sec == 1 ? L.seq_bytes : sec == 2 ? L.qual_bytes : sec == 3 ? L.text_bytes : sec == 4 ? L.pk_seq_bytes : L.pk_qual_bytes;
 }
 size_t stage_section_offset(const Stage &st, int sec)
 {
@@ -317,7 +402,10 @@ size_t stage_section_offset(const Stage &st, int sec)
 
 namespace {
 /* section-relative byte offset / stored length / source of record r's part */
-inline int64_t sec_off(const spxl::Rec &r, int sec) { return sec == 0 ? r.cigar_off * 4 : sec == 1 ? r.seq_off : sec == 2 ? r.qual_off : r.tag_off; }
+inline int64_t sec_off(const spxl::Rec &r, int sec)
+{
+    return sec == 0 ? r.cigar_off * 4 : sec == 1 ? r.seq_off : sec == 2 ? r.qual_off : sec == 3 ? r.tag_off : sec == 4 ? r.pk_seq_off : r.pk_qual_off;
+}
 inline int64_t sec_len(const spxl::Rec &r, int sec)
 {
     const int64_t lq = r.l_qseq > 0 ? r.l_qseq : 0;
@@ -325,7 +413,9 @@ inline int64_t sec_len(const spxl::Rec &r, int sec)
     case 0: return (int64_t)(r.n_cigar > 0 ? r.n_cigar : 0) * 4;
     case 1: return (((lq + 1) / 2) + 3) & ~(int64_t)3;
     case 2: return lq;
-    default: return (r.cs_len >= 0 ? r.cs_len : r.md_len >= 0 ? r.md_len : 0) + 1;
+    case 3: return (r.cs_len >= 0 ? r.cs_len : r.md_len >= 0 ? r.md_len : 0) + 1;
+    case 4: return r.alias_slot >= 0 ? 0 : (((lq + 1) / 2) + 3) & ~(int64_t)3;
+    default: return r.alias_slot >= 0 ? 0 : (lq + 3) & ~(int64_t)3;
     }
 }
 } // namespace
@@ -363,8 +453,9 @@ void stage_fill(const Stage &st, int sec, int64_t b0, int64_t b1, char *dst,
             int64_t have = 0; /* bytes the record really has (the rest of `len` is padding / the terminator) */
             switch (sec) {
             case 0: src = (const char *)(bt->cigar + bt->cigar_off[r.rec]); have = len; break;
-            case 1: src = (const char *)(bt->seq4 + bt->seq_off[r.rec]); have = ((r.l_qseq > 0 ? r.l_qseq : 0) + 1) / 2; break;
+            case 1: case 4: src = (const char *)(bt->seq4 + bt->seq_off[r.rec]); have = ((r.l_qseq > 0 ? r.l_qseq : 0) + 1) / 2; break;
             case 2: src = (const char *)(bt->qual + bt->qual_off[r.rec]); have = len; break;
+            case 5: src = (const char *)(bt->qual + bt->qual_off[r.rec]); have = r.l_qseq > 0 ? r.l_qseq : 0; break;
             default:
                 if (r.cs_len >= 0) { src = bt->cs + bt->cs_off[r.rec]; have = r.cs_len; }
                 else if (r.md_len >= 0) { src = bt->md + bt->md_off[r.rec]; have = r.md_len; }

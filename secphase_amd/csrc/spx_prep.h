@@ -74,6 +74,8 @@ struct StageLayout {
     int64_t n_dgroups = 0;   /* groups passing the dispatch filter (src/secphase.c:285-288) */
     int64_t n_slots = 0;     /* their alignments */
     int64_t cigar_words = 0, seq_bytes = 0, qual_bytes = 0, text_bytes = 0;
+    int64_t pk_seq_bytes = 0, pk_qual_bytes = 0; /* SEQ / QUAL bytes that are really transferred (aliased secondaries left out) */
+    int64_t n_aliased = 0;
     int64_t ops_bound = 0, conf_bound = 0, mm_bound = 0; /* sums of spxl::aln_caps over the alignments */
     /* byte offsets inside the staged buffer */
     size_t o_recs = 0, o_slot0 = 0, o_gidx = 0, o_cigar = 0, o_seq = 0, o_qual = 0, o_text = 0, bytes = 0;
@@ -92,7 +94,8 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
 /* copy the payload into dst (lay.bytes bytes) on `threads` threads */
 void stage_copy(const Stage &st, char *dst, int threads);
 /* The same image piecewise, for staging through a ring of pinned chunks: byte range [b0, b1) of payload section `sec`
- * (0 CIGAR words, 1 SEQ, 2 QUAL, 3 tag text; section-relative offsets) into dst (= the byte at b0).  Records that
+ * (0 CIGAR words, 1 SEQ, 2 QUAL, 3 tag text, 4 / 5 SEQ / QUAL in the PACKED transfer layout that leaves aliased
+ * secondaries out; section-relative offsets) into dst (= the byte at b0).  Records that
  * straddle the range are copied in part.  f_parallel(n, grain, fn(k0,k1)) runs the record loop (a thread pool). */
 int64_t stage_section_bytes(const Stage &st, int sec);
 size_t stage_section_offset(const Stage &st, int sec);

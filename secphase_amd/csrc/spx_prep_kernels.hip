@@ -62,6 +62,71 @@ __global__ __launch_bounds__(256) void recode_kernel(const uint32_t *__restrict_
     }
 }
 
+/* ---- staged records: packed transfer layout -> the pools the walks read.  One workgroup per alignment.
+ * unpack: a record whose SEQ / QUAL crossed PCIe: packed -> final place (whole dwords for SEQ, bytes for QUAL);
+ * alias:  a record whose SEQ / QUAL repeat those of another record of its group (verified on the host, spx_prep.cpp): rebuilt from that record's
+ *         final bytes -- base i = base (shift + i) of the primary, or the complement of base (shift - i) (nt16: the
+ *         nibble's bits reversed) with the qualities in reverse order.  Runs after unpack: a source is never aliased itself. */
+__global__ __launch_bounds__(256) void seqqual_unpack_kernel(const Rec *__restrict__ recs, int32_t n_slots, const uint8_t *__restrict__ pk_seq,
+                                                            const uint8_t *__restrict__ pk_qual, uint8_t *__restrict__ seq, uint8_t *__restrict__ qual)
+{
+    const int s = blockIdx.x;
+    if (s >= n_slots) return;
+    const Rec r = recs[s];
+    if (r.alias_slot >= 0 || r.l_qseq <= 0) return;
+    const int64_t lq = r.l_qseq, nsw = (((lq + 1) / 2) + 3) / 4;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(pk_seq + r.pk_seq_off);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(seq + r.seq_off);
+    for (int64_t k = threadIdx.x; k < nsw; k += blockDim.x) dst[k] = src[k];
+    const uint8_t *qs = pk_qual + r.pk_qual_off;
+    uint8_t *qd = qual + r.qual_off;
+    /* the packed qualities start on a dword; the final place does not: dword loads, byte stores */
+    const int64_t nqw = (lq + 3) / 4;
+    for (int64_t k = threadIdx.x; k < nqw; k += blockDim.x) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(qs)[k];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (4 * k + b < lq) qd[4 * k + b] = (uint8_t)(v >> (8 * b));
+    }
+}
+__global__ __launch_bounds__(256) void seqqual_alias_kernel(const Rec *__restrict__ recs, int32_t n_slots, uint8_t *__restrict__ seq,
+                                                           uint8_t *__restrict__ qual)
+{
+    const int s = blockIdx.x;
+    if (s >= n_slots) return;
+    const Rec r = recs[s];
+    if (r.alias_slot < 0 || r.l_qseq <= 0) return;
+    const Rec p = recs[r.alias_slot];
+    const int64_t lq = r.l_qseq, shift = r.alias_shift;
+    const bool rev = r.alias_rev != 0;
+    const uint8_t *ps = seq + p.seq_off, *pq = qual + p.qual_off;
+    uint8_t *ds = seq + r.seq_off, *dq = qual + r.qual_off;
+    for (int64_t i = threadIdx.x; i < lq; i += blockDim.x) dq[i] = pq[rev ? shift - i : shift + i];
+    auto base_of = [&](int64_t j) -> uint32_t { return (ps[j >> 1] >> ((~j & 1) << 2)) & 0xfu; };
+    auto comp = [](uint32_t c) -> uint32_t { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); };
+    const int64_t nb = (((lq + 1) / 2) + 3) & ~(int64_t)3; /* whole padded bytes: the pad stays zero */
+    for (int64_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t i = 2 * b + h;
+            if (i < lq) {
+                const uint32_t c = rev ? comp(base_of(shift - i)) : base_of(shift + i);
+                v |= c << (h ? 0 : 4); /* BAM: the first base of a byte is the high nibble */
+            }
+        }
+        ds[b] = (uint8_t)v;
+    }
+}
+extern "C" hipError_t spx_stage_expand(const void *recs, int32_t n_slots, const uint8_t *pk_seq, const uint8_t *pk_qual, uint8_t *seq, uint8_t *qual,
+                                       int has_alias, hipStream_t st)
+{
+    if (n_slots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(seqqual_unpack_kernel, dim3((unsigned)n_slots), dim3(256), 0, st, (const Rec *)recs, n_slots, pk_seq, pk_qual, seq, qual);
+    if (has_alias) hipLaunchKernelGGL(seqqual_alias_kernel, dim3((unsigned)n_slots), dim3(256), 0, st, (const Rec *)recs, n_slots, seq, qual);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;

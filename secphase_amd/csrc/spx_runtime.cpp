@@ -42,6 +42,8 @@ extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *ra
 extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *base_out, int64_t *mk_base, hipStream_t st);
 extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st);
 extern "C" size_t spx_order_temp_bytes(int32_t n_prob);
+extern "C" hipError_t spx_stage_expand(const void *recs, int32_t n_slots, const uint8_t *pk_seq, const uint8_t *pk_qual, uint8_t *seq, uint8_t *qual,
+                                       int has_alias, hipStream_t st);
 extern "C" hipError_t spx_prep_orders(const spx_order_args *O, const spx_order_segs *sf, const spx_order_segs *sb, hipStream_t st);
 
 extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
@@ -98,7 +100,12 @@ struct spx_ctx {
     static const int SPX_N_SIDE = 3;
     hipStream_t side_stream[SPX_N_SIDE] = {};
     hipEvent_t side_done[SPX_N_SIDE] = {};
-    hipStream_t copy_stream = nullptr; /* host -> HBM copies of staged records */
+    /* host -> HBM copies of staged records, and NOTHING else: once a kernel or a memset has gone through a stream the
+     * runtime serves its copies with a copy KERNEL instead of the DMA engines -- 18-24 GB/s beside the DP kernels instead
+     * of 52 (tools/scratch/h2d_probe.hip) */
+    hipStream_t copy_stream = nullptr;
+    hipStream_t unpack_stream = nullptr; /* what follows the copies of a staging: unpack / rebuild kernels, pad fills */
+    hipStream_t result_stream = nullptr; /* packed results -> host (never behind a staging in progress) */
     std::mutex launch_mu;              /* spx_launch may be called from several threads (pipelined callers) */
     uint8_t *d_ref4 = nullptr;
     int64_t ref_bytes = 0;
@@ -187,6 +194,7 @@ struct spx_work {
     /* ---- device-prepared work lists: the staged records (part A, resident until the list is freed) ---- */
     spx_ctx *owner = nullptr;
     bool staged = false;        /* spx_stage has run: records are in HBM */
+    int stage_threads = 1;
     bool prepared = false;      /* spx_prepare_staged has run: the work list exists */
     spx::Stage stage;
     void *h_stage = nullptr;    /* pinned host copy of the staged buffer */
@@ -281,15 +289,17 @@ extern "C" int spx_create(int device, spx_ctx **out)
     if (!out) return fail(SPX_EINVAL, "out is NULL");
     *out = nullptr;
     /* HIP multiplexes streams onto hardware queues (4 by default): two streams that share one run their kernels one
-     * after the other.  Ask for 12 (main, three side, copy and the preparation lanes' streams) before the runtime initialises; a process that has initialised HIP already (e.g.
+     * after the other.  Ask for 14 (main, three side, copy, unpack, result and the preparation lanes' streams) before the runtime initialises; a process that has initialised HIP already (e.g.
      * after importing torch) must have set the variable itself -- bench.py and the command line do. */
-    setenv("GPU_MAX_HW_QUEUES", "12", 0);
+    setenv("GPU_MAX_HW_QUEUES", "14", 0);
     int n = 0;
+    const double tc0 = now_s();
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SPX_ENODEVICE, "hipGetDeviceCount found no device");
     if (device < 0 || device >= n) return fail(SPX_ENODEVICE, "device index out of range");
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
+    const double tc1 = now_s();
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SPX_ENODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     spx_ctx *c = new spx_ctx();
@@ -338,12 +348,19 @@ extern "C" int spx_create(int device, spx_ctx **out)
         HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
     }
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->unpack_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->result_stream, hipStreamNonBlocking));
     {
         std::vector<double> t(102 + 512);
         spx::phred_thresholds(t.data());
         spx::score_tables(t.data() + 102, t.data() + 102 + 256);
         HIPCHK(hipMalloc((void **)&c->d_tables, t.size() * sizeof(double)));
         HIPCHK(hipMemcpy(c->d_tables, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (timing_on()) {
+        const double tc2 = now_s();
+        (void)hipFree(nullptr);
+        fprintf(stderr, "[spx timing] spx_create: device count + properties %.3f s, streams / events / first allocations %.3f s\n", tc1 - tc0, tc2 - tc1);
     }
     *out = c;
     return SPX_OK;
@@ -380,6 +397,8 @@ extern "C" void spx_destroy(spx_ctx *c)
         if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->unpack_stream) (void)hipStreamDestroy(c->unpack_stream);
+    if (c->result_stream) (void)hipStreamDestroy(c->result_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -655,8 +674,12 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
         {
             std::lock_guard<std::mutex> lk(c->arena_mu);
             int best = -1;
+            /* best fit, and never a block more than half again as large as asked for: the image of the staged records
+             * and the work list are two size classes, and a small request that takes a large block sends the next large
+             * request to hipMalloc (~25 ms per GB, with the device idle meanwhile) */
             for (size_t i = 0; i < c->arena_cache.size(); ++i)
-                if (c->arena_cache[i].second >= bytes && (best < 0 || c->arena_cache[i].second < c->arena_cache[best].second))
+                if (c->arena_cache[i].second >= bytes && c->arena_cache[i].second <= bytes + bytes / 2 + ((size_t)64 << 20) &&
+                    (best < 0 || c->arena_cache[i].second < c->arena_cache[best].second))
                     best = (int)i;
             if (best >= 0) {
                 void *p = c->arena_cache[best].first;
@@ -686,12 +709,25 @@ static void arena_put(spx_ctx *c, void *p, size_t cap)
 {
     if (!p) return;
     if (c) {
+        std::vector<void *> drop;
         {
+            /* at most 8 blocks and half of the device's memory wait for re-use; the OLDEST waiting blocks make room (the
+             * sizes in demand change with the workload: a cache full of blocks nobody asks for any more would send every
+             * request to hipMalloc) */
             std::lock_guard<std::mutex> lk(c->arena_mu);
-            size_t held = 0; /* at most 8 blocks and half of the device's memory wait for re-use */
-            for (auto &a : c->arena_cache) held += a.second;
-            if (c->arena_cache.size() < 8 && held + cap <= c->hbm_bytes / 2) { c->arena_cache.emplace_back(p, cap); p = nullptr; }
+            if (cap <= c->hbm_bytes / 2) {
+                size_t held = cap;
+                for (auto &a : c->arena_cache) held += a.second;
+                while (!c->arena_cache.empty() && (c->arena_cache.size() >= 8 || held > c->hbm_bytes / 2)) {
+                    held -= c->arena_cache.front().second;
+                    drop.push_back(c->arena_cache.front().first);
+                    c->arena_cache.erase(c->arena_cache.begin());
+                }
+                c->arena_cache.emplace_back(p, cap);
+                p = nullptr;
+            }
         }
+        for (void *d : drop) (void)hipFree(d);
         if (p) (void)hipFree(p);
         c->arena_cv.notify_all();
         return;
@@ -728,15 +764,13 @@ static void pinned_put(spx_ctx *c, void *p, size_t cap)
     (void)hipHostFree(p);
 }
 
-/* Step 1 of a work list: dispatch filter + staging of the dispatched groups' records into pinned memory (host
- * threads), one asynchronous copy into HBM.  Several record batches (e.g. the blocks a reader thread hands over) become
- * ONE work list; group g of batch b is reported at index (groups of batches < b) + g. */
-extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par, int host_threads,
-                         spx_work **out)
+/* host half: dispatch filter, payload sizes, which records repeat another one (no device call: the pipeline runs it
+ * for submission k+1 while the records of submission k are on their way over PCIe) */
+extern "C" int spx_internal_stage_begin(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par, int host_threads,
+                                        spx_work **out)
 {
     if (!c || !bts || n_batches <= 0 || !par || !out) return fail(SPX_EINVAL, "NULL argument");
     if (!c->d_ref4) return fail(SPX_ENOREF, "spx_set_reference has not been called");
-    HIPCHK(hipSetDevice(c->device));
     *out = nullptr;
     spx_work *w = new spx_work();
     memset(&w->st, 0, sizeof w->st);
@@ -745,7 +779,7 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->par = *par;
     w->owner = c;
     const double t0 = now_s();
-    int nthr = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
+    int nthr = host_threads > 0 ? host_threads : spx::effective_cpus();
     nthr = std::max(1, std::min(nthr, 128));
     int rc = spx::stage_measure(bts, n_batches, nthr, w->stage);
     if (rc) { delete w; return fail(rc, "invalid batch"); }
@@ -753,11 +787,28 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->n_groups_in = (int32_t)L.n_groups_in;
     w->n_dgroups = (int32_t)L.n_dgroups;
     w->hb.grp_error = w->stage.grp_error;
-    /* part A in HBM: staged records | recoded SEQ | per-alignment state | per-group counts and offsets */
     if (L.n_slots > SPX_MAX_STAGE_SLOTS || L.n_dgroups > SPX_MAX_STAGE_SLOTS) {
         delete w;
         return fail(SPX_EINVAL, "more than 2^20 alignments in one work list: stage fewer groups at a time");
     }
+    w->st.prep_seconds = now_s() - t0;
+    w->st.n_groups = w->n_groups_in;
+    w->stage_threads = nthr;
+    *out = w;
+    return SPX_OK;
+}
+
+/* device half: memory for the image, the payload through the ring of pinned chunks, unpack / rebuild kernels.  On failure
+ * the caller frees the list. */
+extern "C" int spx_internal_stage_finish(spx_ctx *c, spx_work *w)
+{
+    if (!c || !w || w->staged) return fail(SPX_EINVAL, "work list is not waiting for its records");
+    HIPCHK(hipSetDevice(c->device));
+    const spx::StageLayout &L = w->stage.lay;
+    const int nthr = w->stage_threads;
+    const double t0 = now_s();
+    /* part A in HBM: staged records | recoded SEQ | per-alignment state | per-group counts and offsets */
+    const double t_meas = now_s();
     Carver cv;
     const size_t ns = (size_t)L.n_slots, ng = (size_t)L.n_dgroups;
     const size_t o_in = cv.take<char>(L.bytes + 64);
@@ -770,15 +821,18 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     w->o_base = cv.take<spxl::PlanBase>(ns + 1);
     w->o_mkb = cv.take<int64_t>(ng + 2);
     w->o_scan = cv.take<int64_t>(5 * (std::max(ns, ng) + 8) + 5 * 1024 + 16);
+    /* packed SEQ / QUAL as they cross PCIe (aliased secondaries left out); unpacked into the image's pools on the device */
+    const size_t o_pkseq = cv.take<char>((size_t)L.pk_seq_bytes + 64), o_pkqual = cv.take<char>((size_t)L.pk_qual_bytes + 64);
     (void)o_in;
     w->in_arena = arena_get(c, cv.off + 256, &w->in_cap);
-    if (!w->in_arena) { spx_work_free(c, w); return fail(SPX_ENOMEM, "device memory for the staged records"); }
+    if (!w->in_arena) return fail(SPX_ENOMEM, "device memory for the staged records");
     char *base = (char *)w->in_arena;
+    const double t_arena = now_s();
     {
         /* through the ring of pinned chunks: fill chunk k on the pool while chunk k-1 is on its way over PCIe */
         std::lock_guard<std::mutex> sl(c->stage_mu);
         if (!c->pin_bytes) {
-            size_t mb = 64;
+            size_t mb = 128;
             if (const char *e = getenv("SPX_PIN_MB")) mb = (size_t)std::max(1, atoi(e));
             c->pin_bytes = mb << 20;
         }
@@ -821,9 +875,11 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
                 else memcpy(h, src, n);
                 if (!chunk_send(k, base + r.off + o, n)) rc2 = SPX_EHIP;
             }
-        for (int sec = 0; sec < 4 && rc2 == SPX_OK; ++sec) {
+        static const int kSections[4] = {0, 4, 5, 3}; /* CIGAR words, packed SEQ, packed QUAL, tag text */
+        for (int si = 0; si < 4 && rc2 == SPX_OK; ++si) {
+            const int sec = kSections[si];
             const int64_t tot = spx::stage_section_bytes(w->stage, sec);
-            const size_t doff = spx::stage_section_offset(w->stage, sec);
+            const size_t doff = sec == 4 ? o_pkseq : sec == 5 ? o_pkqual : spx::stage_section_offset(w->stage, sec);
             for (int64_t b0 = 0; b0 < tot && rc2 == SPX_OK; b0 += (int64_t)c->pin_bytes) {
                 const int64_t b1 = std::min<int64_t>(tot, b0 + (int64_t)c->pin_bytes);
                 char *h = nullptr;
@@ -833,20 +889,46 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
                 if (!chunk_send(k, base + doff + b0, (size_t)(b1 - b0))) rc2 = SPX_EHIP;
             }
         }
-        if (rc2 != SPX_OK) { spx_work_free(c, w); return fail(rc2, rc2 == SPX_ENOMEM ? "pinned staging chunk" : "copy of the staged records"); }
+        if (rc2 != SPX_OK) return fail(rc2, rc2 == SPX_ENOMEM ? "pinned staging chunk" : "copy of the staged records");
     }
+    {
+        hipEvent_t ev_copied = nullptr; /* the unpack stream goes on behind the last chunk */
+        HIPCHK(hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev_copied, c->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->unpack_stream, ev_copied, 0);
+        (void)hipEventDestroy(ev_copied); /* (released by the runtime once it has completed) */
+        HIPCHK(e);
+    }
+    HIPCHK(spx_stage_expand(base + L.o_recs, (int32_t)L.n_slots, (const uint8_t *)base + o_pkseq, (const uint8_t *)base + o_pkqual,
+                            (uint8_t *)base + L.o_seq, (uint8_t *)base + L.o_qual, L.n_aliased > 0, c->unpack_stream));
     const double t1 = now_s();
     /* the recoded-SEQ pool: recode_kernel writes every word behind the lead pad, only the pads need a value (they are read,
      * never used); zeroing the whole pool was a 3.7 GB fill per 131 072 HiFi groups */
-    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)spx::kCodeLeadBytes, c->copy_stream));
-    HIPCHK(hipMemsetAsync(base + w->o_code + spx::kCodeLeadBytes + ((L.seq_bytes + 3) & ~(int64_t)3), 0, (size_t)spx::kCodeTailBytes - 8, c->copy_stream));
+    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)spx::kCodeLeadBytes, c->unpack_stream));
+    HIPCHK(hipMemsetAsync(base + w->o_code + spx::kCodeLeadBytes + ((L.seq_bytes + 3) & ~(int64_t)3), 0, (size_t)spx::kCodeTailBytes - 8, c->unpack_stream));
     HIPCHK(hipEventCreateWithFlags(&w->ev_staged, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(w->ev_staged, c->copy_stream));
-    w->st.prep_seconds = t1 - t0;
-    w->st.bytes_h2d = (int64_t)L.bytes;
-    w->st.n_groups = w->n_groups_in;
+    HIPCHK(hipEventRecord(w->ev_staged, c->unpack_stream));
+    w->st.prep_seconds += t1 - t0;
+    w->st.bytes_h2d = (int64_t)L.bytes - (L.seq_bytes - L.pk_seq_bytes) - (L.qual_bytes - L.pk_qual_bytes); /* what really crossed PCIe */
     w->staged = true;
-    if (timing_on()) fprintf(stderr, "[spx timing] stage: %d threads, measure+copy %.3f s, %.1f MB\n", nthr, t1 - t0, L.bytes / 1e6);
+    if (timing_on())
+        fprintf(stderr, "[spx timing] stage: %d threads, measure %.3f s, device memory %.3f s, fill + copy %.3f s, %.1f MB\n", nthr,
+                w->st.prep_seconds - (t1 - t0), t_arena - t_meas, t1 - t_arena, w->st.bytes_h2d / 1e6);
+    return SPX_OK;
+}
+
+/* Step 1 of a work list: dispatch filter + staging of the dispatched groups' records into pinned memory (host
+ * threads), copies into HBM.  Several record batches (e.g. the blocks a reader thread hands over) become
+ * ONE work list; group g of batch b is reported at index (groups of batches < b) + g. */
+extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batches, const spx_params *par, int host_threads,
+                         spx_work **out)
+{
+    if (out) *out = nullptr;
+    spx_work *w = nullptr;
+    int rc = spx_internal_stage_begin(c, bts, n_batches, par, host_threads, &w);
+    if (rc != SPX_OK) return rc;
+    rc = spx_internal_stage_finish(c, w);
+    if (rc != SPX_OK) { spx_work_free(c, w); return rc; }
     *out = w;
     return SPX_OK;
 }
@@ -1266,12 +1348,12 @@ extern "C" int spx_pack_decisions(spx_ctx *c, spx_work *w, int32_t group_base, v
     const int64_t ng = w->staged ? (int64_t)w->n_dgroups : (int64_t)w->hb.grp_index.size();
     if (capacity < ng) return fail(SPX_EINVAL, "decision buffer too small");
     HIPCHK(hipSetDevice(c->device));
-    /* behind the work list's own kernels only (not behind lists launched later), on the copy stream; returns when the
+    /* behind the work list's own kernels only (not behind lists launched later), on the result stream; returns when the
      * records are in the buffer, so the caller can hand it to a collective on any stream */
-    if (w->ev_done) HIPCHK(hipStreamWaitEvent(c->copy_stream, w->ev_done, 0));
+    if (w->ev_done) HIPCHK(hipStreamWaitEvent(c->result_stream, w->ev_done, 0));
     else HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(spx_launch_pack(&w->dg, w->d_grp_index, group_base, (spx_decision *)device_out, c->copy_stream));
-    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    HIPCHK(spx_launch_pack(&w->dg, w->d_grp_index, group_base, (spx_decision *)device_out, c->result_stream));
+    HIPCHK(hipStreamSynchronize(c->result_stream));
     return (int)ng;
 }
 
@@ -1362,8 +1444,8 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         spx_group_out *h = ng ? (spx_group_out *)pinned_get(c, ng * sizeof(spx_group_out), &cap) : nullptr;
         if (ng && !h) return fail(SPX_ENOMEM, "pinned result buffer");
         if (ng) {
-            hipError_t e = hipMemcpyAsync(h, w->d_results, ng * sizeof(spx_group_out), hipMemcpyDeviceToHost, c->copy_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+            hipError_t e = hipMemcpyAsync(h, w->d_results, ng * sizeof(spx_group_out), hipMemcpyDeviceToHost, c->result_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->result_stream);
             if (e != hipSuccess) { pinned_put(c, h, cap); return fail(SPX_EHIP, std::string("result copy: ") + hipGetErrorString(e)); }
         }
         w->st.d2h_seconds = now_s() - t0;
@@ -1858,6 +1940,22 @@ extern "C" int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *
     return pr;
 }
 
+extern "C" int spx_effective_cpus(void) { return spx::effective_cpus(); }
+
+/* diagnostics (host only): what staging these batches would put on the wire.  out[0] alignments of dispatched groups,
+ * out[1] of them aliased to their group's primary (SEQ / QUAL not transferred), out[2] SEQ + QUAL bytes of all of them,
+ * out[3] SEQ + QUAL bytes really transferred */
+extern "C" int spx_stage_transfer_stats(const spx_batch *const *bts, int32_t n_batches, int host_threads, int64_t *out)
+{
+    if (!bts || n_batches <= 0 || !out) return fail(SPX_EINVAL, "NULL argument");
+    spx::Stage st;
+    int rc = spx::stage_measure(bts, n_batches, host_threads > 0 ? host_threads : 1, st);
+    if (rc) return fail(rc, "invalid batch");
+    out[0] = st.lay.n_slots; out[1] = st.lay.n_aliased;
+    out[2] = st.lay.seq_bytes + st.lay.qual_bytes; out[3] = st.lay.pk_seq_bytes + st.lay.pk_qual_bytes;
+    return SPX_OK;
+}
+
 /* ------------------------------------------------------------------ */
 /* BGZF blocks inflated on the device (spx_inflate_kernels.hip): `file` holds n_blocks consecutive BGZF blocks starting at
  * block_off[0] (block_off has n_blocks + 1 entries: the starts and the end).  The inflated bytes of the blocks are written
@@ -1931,8 +2029,13 @@ extern "C" int64_t spx_inflate_bgzf_device(spx_ctx *c, const uint8_t *file, cons
 /* ---- device inflate workers for the BAM reader (spx_bam_attach_device_inflate) ---- */
 struct spx_inflater {
     spx_ctx *c = nullptr;
+    /* copies have streams of their own, shared by the workers: a stream that has run a kernel gets its copies served by the
+     * runtime's copy kernel instead of the DMA engines (see spx_ctx::copy_stream) */
+    hipStream_t st_h2d = nullptr, st_d2h = nullptr;
+    std::mutex mu_h2d, mu_d2h; /* a copy and the event behind it go in together */
     struct Worker {
-        hipStream_t st = nullptr;
+        hipStream_t st = nullptr; /* the kernel */
+        hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
         uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
         SpxBgzfDesc *h_desc = nullptr, *d_desc = nullptr;
         int32_t *h_status = nullptr, *d_status = nullptr;
@@ -1949,8 +2052,14 @@ extern "C" int spx_inflater_create(spx_ctx *c, int32_t n_workers, spx_inflater *
     spx_inflater *inf = new spx_inflater();
     inf->c = c;
     inf->w = std::vector<spx_inflater::Worker>((size_t)n_workers);
+    bool ok = hipStreamCreateWithFlags(&inf->st_h2d, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&inf->st_d2h, hipStreamNonBlocking) == hipSuccess;
     for (auto &k : inf->w)
-        if (hipStreamCreateWithFlags(&k.st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); spx_inflater_free(inf); return fail(SPX_EHIP, "stream"); }
+        ok = ok && hipStreamCreateWithFlags(&k.st, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&k.ev_in, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&k.ev_k, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&k.ev_out, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); spx_inflater_free(inf); return fail(SPX_EHIP, "streams of the inflater"); }
     *out = inf;
     return SPX_OK;
 }
@@ -1961,6 +2070,9 @@ extern "C" void spx_inflater_free(spx_inflater *inf)
     if (inf->c) (void)hipSetDevice(inf->c->device);
     for (auto &k : inf->w) {
         if (k.st) { (void)hipStreamSynchronize(k.st); (void)hipStreamDestroy(k.st); }
+        if (k.ev_in) (void)hipEventDestroy(k.ev_in);
+        if (k.ev_k) (void)hipEventDestroy(k.ev_k);
+        if (k.ev_out) (void)hipEventDestroy(k.ev_out);
         if (k.h_in) (void)hipHostFree(k.h_in);
         if (k.h_out) (void)hipHostFree(k.h_out);
         if (k.h_desc) (void)hipHostFree(k.h_desc);
@@ -1970,6 +2082,8 @@ extern "C" void spx_inflater_free(spx_inflater *inf)
         if (k.d_desc) (void)hipFree(k.d_desc);
         if (k.d_status) (void)hipFree(k.d_status);
     }
+    if (inf->st_h2d) { (void)hipStreamSynchronize(inf->st_h2d); (void)hipStreamDestroy(inf->st_h2d); }
+    if (inf->st_d2h) { (void)hipStreamSynchronize(inf->st_d2h); (void)hipStreamDestroy(inf->st_d2h); }
     delete inf;
 }
 
@@ -2029,12 +2143,23 @@ extern "C" int spx_inflater_run(void *user, int32_t worker, const uint8_t *file,
         d.out_off = blocks[b].uoff;
         d.clen = blocks[b].clen; d.ulen = blocks[b].ulen; d.crc = blocks[b].crc; d.pad = 0;
     }
-    WCHK(hipMemcpyAsync(W.d_in, W.h_in, in_bytes + 64, hipMemcpyHostToDevice, W.st));
-    WCHK(hipMemcpyAsync(W.d_desc, W.h_desc, (size_t)n_blocks * sizeof(SpxBgzfDesc), hipMemcpyHostToDevice, W.st));
+    {
+        std::lock_guard<std::mutex> cl(inf->mu_h2d);
+        WCHK(hipMemcpyAsync(W.d_in, W.h_in, in_bytes + 64, hipMemcpyHostToDevice, inf->st_h2d));
+        WCHK(hipMemcpyAsync(W.d_desc, W.h_desc, (size_t)n_blocks * sizeof(SpxBgzfDesc), hipMemcpyHostToDevice, inf->st_h2d));
+        WCHK(hipEventRecord(W.ev_in, inf->st_h2d));
+    }
+    WCHK(hipStreamWaitEvent(W.st, W.ev_in, 0));
     WCHK(spx_launch_bgzf_inflate(W.d_in, W.d_desc, n_blocks, W.d_out, W.d_status, check_crc, W.st));
-    WCHK(hipMemcpyAsync(W.h_status, W.d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, W.st));
-    WCHK(hipMemcpyAsync(W.h_out, W.d_out, out_bytes, hipMemcpyDeviceToHost, W.st));
-    WCHK(hipStreamSynchronize(W.st));
+    WCHK(hipEventRecord(W.ev_k, W.st));
+    {
+        std::lock_guard<std::mutex> cl(inf->mu_d2h);
+        WCHK(hipStreamWaitEvent(inf->st_d2h, W.ev_k, 0));
+        WCHK(hipMemcpyAsync(W.h_status, W.d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, inf->st_d2h));
+        WCHK(hipMemcpyAsync(W.h_out, W.d_out, out_bytes, hipMemcpyDeviceToHost, inf->st_d2h));
+        WCHK(hipEventRecord(W.ev_out, inf->st_d2h));
+    }
+    WCHK(hipEventSynchronize(W.ev_out));
 #undef WCHK
     int rc = 0;
     for (int32_t b = 0; b < n_blocks; ++b) {

@@ -13,7 +13,7 @@ def pytest_configure(config):
     # torch brings its own copy of the HIP runtime: when libspx's runtime initialises first, torch later finds "no HIP
     # GPUs" in the same process.  Tests that hand torch tensors to libspx (decision records for the RCCL gather) need
     # both, so torch goes first -- as in bench.py.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
     try:
         import torch
         torch.cuda.is_available()

@@ -174,7 +174,7 @@ def _gpu_worker(rank, world, port, tmp):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
     torch.cuda.is_available()  # torch's HIP runtime first (see conftest.py)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from secphase_amd import api

@@ -426,6 +426,31 @@ def test_command_line_drop_in(ctx, tmp_path):
     assert f"Number of reads modified by marker score = {nre}" in p.stderr
 
 
+def test_aliased_and_altered_secondaries(ctx, tmp_path):
+    """staging leaves out SEQ / QUAL of secondaries that repeat the primary's and the device rebuilds them (both strands,
+    hard-clipped records): scores and the list equal the oracle's; with the qualities / bases of some secondaries ALTERED
+    those records are transferred as they are -- and the oracle, which reads every record's own bytes, still agrees"""
+    g = small_genome(synth.HIFI, read_len=4000, max_secondaries=3, min_secondaries=1, n_paralogs=3, hardclip_frac=0.5, softclip_frac=0.5,
+                     inverted_paralogs=1, shuffle_records=1)
+    r = g.reads(0, 150)
+    b = r.batch.contents
+    p = records.preset("hifi")
+    ctx.set_reference(g.ref)
+    _batch_parity(ctx, g, r, p, tmp_path, "alias")
+    rng = np.random.default_rng(9)
+    changed = 0
+    for a in range(b.n_alns):
+        if (b.flag[a] & 256) and rng.random() < 0.4:
+            lq = b.l_qseq[a]
+            lo = int(rng.integers(0, max(1, lq - 400)))
+            for k in range(lo, min(lq, lo + 400)):   # a stretch of low qualities: markers there fall under min_q
+                b.qual[b.qual_off[a] + k] = 3
+            b.seq4[b.seq_off[a] + lo // 2] ^= 0x33
+            changed += 1
+    assert changed > 10
+    _batch_parity(ctx, g, r, p, tmp_path, "alias")
+
+
 def test_command_line_several_devices(ctx, tmp_path):
     """secphase --devices 0,0,0 : three scoring contexts (here on one GPU), batches dealt round-robin, results taken in file
     order by ONE finalizer -- the relabel list (tie groups included: their rand() draws are replayed in file order), both

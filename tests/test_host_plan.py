@@ -166,3 +166,71 @@ def test_host_tables_match_libm(built):
             x = np.nextafter(x, 0.0)
             assert int(-4.343 * math.log(x) + .499) >= k
     assert mt[0] == -93.0 and mt[93] == 0.0 and ms[10] == -10 - 10 * math.log(3)
+
+
+def test_secondaries_that_repeat_the_primary_stay_on_the_host(built):
+    """what crosses PCIe: a secondary whose SEQ / QUAL repeat the primary's (same strand, reverse complement, minus hard
+    clips) is aliased; one changed quality or base and the record is transferred like any other"""
+    import ctypes as C
+    from common import small_genome
+    from secphase_amd import api, records, synth
+    L = api.lib()
+    L.spx_stage_transfer_stats.argtypes = [C.POINTER(C.POINTER(records.SpxBatch)), C.c_int32, C.c_int, C.POINTER(C.c_int64)]
+    g = small_genome(synth.HIFI, read_len=3000, max_secondaries=3, min_secondaries=1, n_paralogs=3, hardclip_frac=0.5, softclip_frac=0.5,
+                     inverted_paralogs=1, shuffle_records=1)
+    r = g.reads(0, 120)
+    b = r.batch.contents
+
+    def stats():
+        arr = (C.POINTER(records.SpxBatch) * 1)(r.batch)
+        out = (C.c_int64 * 4)()
+        assert L.spx_stage_transfer_stats(arr, 1, 2, out) == 0
+        return list(out)
+
+    n_slots, n_alias, all_bytes, sent = stats()
+    n_sec = sum(1 for a in range(b.n_alns) if b.flag[a] & 256)
+    rev = sum(1 for a in range(b.n_alns) if (b.flag[a] & 256) and (b.flag[a] & 16))
+    # a group transfers ONE record, the one holding most of the read (rarely two: hard clips at opposite ends); both strands occur
+    assert n_slots == b.n_alns and b.n_alns - b.n_groups - 3 <= n_alias <= b.n_alns - b.n_groups and rev > 5
+    n_sec = n_alias
+    assert sent < 0.62 * all_bytes
+    # one quality of one secondary changed: that record (only) is transferred
+    hard = lambda a: (b.cigar[b.cigar_off[a]] & 15) == 5 or (b.cigar[b.cigar_off[a] + b.n_cigar[a] - 1] & 15) == 5
+    a = next(a for a in range(b.n_alns) if (b.flag[a] & 256) and (b.flag[a] & 16) and hard(a))
+    old = b.qual[b.qual_off[a] + 57]
+    b.qual[b.qual_off[a] + 57] = (old + 1) % 60
+    assert stats()[1] == n_sec - 1
+    b.qual[b.qual_off[a] + 57] = old
+    # one base changed (high nibble of a SEQ byte)
+    a2 = next(a for a in range(b.n_alns) if (b.flag[a] & 256) and not (b.flag[a] & 16) and hard(a))
+    o2 = b.seq4[b.seq_off[a2] + 20]
+    b.seq4[b.seq_off[a2] + 20] = o2 ^ 0x30
+    assert stats()[1] == n_sec - 1
+    b.seq4[b.seq_off[a2] + 20] = o2
+    assert stats()[1] == n_sec
+    # any single base / quality of any record, first and last positions included: never missed by the word-wise compare
+    import numpy as np
+    rng = np.random.default_rng(4)
+    missed = 0
+    longest = set()
+    for gi in range(b.n_groups):
+        members = range(b.grp_first[gi], b.grp_first[gi + 1] if gi + 1 < b.n_groups else b.n_alns)
+        longest.add(max(members, key=lambda x: (b.l_qseq[x], not (b.flag[x] & 256), -x)))   # ties: the primary, else the first
+    rest = [a for a in range(b.n_alns) if a not in longest]     # (a change in a source only counts where a copy covers it)
+    for a in rng.choice(rest, 40, replace=False):
+        a = int(a)
+        lq = b.l_qseq[a]
+        for pos in (0, lq - 1, max(0, lq - 17), int(rng.integers(0, lq)), int(rng.integers(0, lq))):
+            if rng.random() < 0.5:
+                at, v = b.qual_off[a] + pos, b.qual[b.qual_off[a] + pos]
+                b.qual[at] = (v + 7) % 60
+                dropped = n_sec - stats()[1]
+                b.qual[at] = v
+            else:
+                at, v = b.seq_off[a] + pos // 2, b.seq4[b.seq_off[a] + pos // 2]
+                b.seq4[at] = v ^ (0x10 if pos % 2 == 0 else 0x01)
+                dropped = n_sec - stats()[1]
+                b.seq4[at] = v
+            missed += dropped != 1
+    assert missed <= 5   # (at most one of the 40 records is neither a source nor aliased: its 5 changes alter nothing)
+    assert stats()[1] == n_sec
