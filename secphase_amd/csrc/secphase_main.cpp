@@ -42,6 +42,15 @@
 
 #include "../../include/spx.h"
 
+extern "C" void spx_internal_cpu_report(FILE *f);              /* SPX_TIMING: core-seconds of the host side by kind of work */
+extern "C" void spx_internal_cpu_add(int kind, double seconds);
+
+static double thread_cpu_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
 static double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -341,7 +350,9 @@ int main(int argc, char *argv[])
             if (spx_write_relabel_log(log_path.c_str(), "a", ps.bt, ref, ps.out.data()) != SPX_OK) post_failed = true;
             spx_bam_release_batch(bam, ps.bt); /* its share of the inflate arena is recycled */
             const double ta = now_s();
+            const double cpu0 = thread_cpu_s();
             const int nm = spx_relabel_blocks(ps.w, ref, ps.out.data(), bed_mod, bed_mk);
+            spx_internal_cpu_add(8 /* BED bookkeeping */, thread_cpu_s() - cpu0);
             const double tb = now_s();
             spx_work_free(ctxs[(size_t)ps.lane], ps.w);
             const double tc = now_s();
@@ -467,9 +478,11 @@ int main(int argc, char *argv[])
          * staging chunks, device arenas -- page by page (munmap, hipHostFree, hipFree: 0.5-0.7 s), only for the process to
          * end right after; the kernel and the driver reclaim all of it at exit anyway.  SPX_TIDY_EXIT=1 runs the orderly
          * shutdown (leak checkers, tests of the close paths). */
-        if (getenv("SPX_TIMING"))
+        if (getenv("SPX_TIMING")) {
             fprintf(stderr, "[%s] wind-down: BED merge + write %.3f s; whole process %.3f s (memory is left to process exit)\n", timestamp(),
                     t_end1 - t_end0, now_s() - t_proc0);
+            spx_internal_cpu_report(stderr);
+        }
         fflush(NULL);
         _exit(0);
     }

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "../../include/spx.h"
+#include "spx_cpuacc.h"
 #include "spx_pool.h"
 
 namespace {
@@ -290,10 +291,18 @@ void chunk_unref_locked(Reader *r, Chunk *c)
 void inflate_blocks(Reader *r, Chunk *c, size_t b0, size_t b1)
 {
     thread_local Inflater inf;
+    {
+        spx::CpuScope cs(spx::CPU_INFLATE);
+        for (size_t q = b0; q < b1; ++q) {
+            const Block &b = c->blocks[q];
+            if (!inf.run(r->map + b.coff, b.clen, c->data + b.uoff, b.ulen)) c->bad = 1;
+        }
+    }
+    if (c->bad || !r->check_crc) return;
+    spx::CpuScope cs(spx::CPU_CRC);
     for (size_t q = b0; q < b1; ++q) {
         const Block &b = c->blocks[q];
-        if (!inf.run(r->map + b.coff, b.clen, c->data + b.uoff, b.ulen)) { c->bad = 1; continue; }
-        if (r->check_crc && crc_of(c->data + b.uoff, b.ulen) != b.crc) c->bad = 2;
+        if (crc_of(c->data + b.uoff, b.ulen) != b.crc) c->bad = 2;
     }
 }
 
@@ -309,7 +318,10 @@ void populate_ahead(Reader *r)
     while (r->populated < r->fsize && r->populated < r->fpos + lead) {
         const size_t a = r->populated, n = std::min(step, r->fsize - a);
         const uint8_t *base = r->map;
-        r->pool->submit([base, a, n] { (void)madvise((void *)(base + a), n, MADV_POPULATE_READ); });
+        r->pool->submit([base, a, n] {
+            spx::CpuScope cs(spx::CPU_POPULATE);
+            (void)madvise((void *)(base + a), n, MADV_POPULATE_READ);
+        });
         r->populated = a + n;
     }
 #else
@@ -564,6 +576,7 @@ void batch_add_chunk(Reader *r, Batch &B, Chunk *c)
 void fill_batch(Reader *r, Batch &B, int32_t max_groups)
 {
     const double t_fill0 = io_now();
+    spx::CpuScope cs_walk(spx::CPU_WALK);
     r->t_wait_inflate = r->t_wait_slot = r->t_dispatch = 0;
     const uint8_t *base = r->arena.aligned;
     bool open_group = false;
@@ -627,6 +640,7 @@ void fill_batch(Reader *r, Batch &B, int32_t max_groups)
     B.cs_off.resize(n); B.md_off.resize(n);
     std::vector<int64_t> cg_at(n, -1); /* CG:B,I payload when the real CIGAR lives in the tag */
     r->pool->parallel_for(nrec, 1024, [&](int64_t k0, int64_t k1) {
+        spx::CpuScope cs_parse(spx::CPU_PARSE);
         for (int64_t k = k0; k < k1; ++k) {
             const uint8_t *p = base + B.rec_off[(size_t)k];
             const int32_t bs = le32(p - 4);
@@ -680,6 +694,7 @@ void fill_batch(Reader *r, Batch &B, int32_t max_groups)
     B.cigar.resize((size_t)cw + 1);
     B.qnames.resize((size_t)nb + 1);
     r->pool->parallel_for(nrec, 2048, [&](int64_t k0, int64_t k1) {
+        spx::CpuScope cs_parse(spx::CPU_PARSE);
         for (int64_t k = k0; k < k1; ++k) {
             const uint8_t *p = base + B.rec_off[(size_t)k];
             const uint8_t *src = cg_at[(size_t)k] >= 0 ? base + cg_at[(size_t)k] : p + 32 + p[8];
@@ -688,6 +703,7 @@ void fill_batch(Reader *r, Batch &B, int32_t max_groups)
         }
     });
     r->pool->parallel_for((int64_t)grp_rec.size(), 4096, [&](int64_t g0, int64_t g1) {
+        spx::CpuScope cs_parse(spx::CPU_PARSE);
         for (int64_t g = g0; g < g1; ++g) {
             const uint8_t *p = base + B.rec_off[(size_t)grp_rec[(size_t)g]];
             memcpy(B.qnames.data() + B.qname_off[(size_t)g], p + 32, (size_t)p[8]);
@@ -775,8 +791,11 @@ void dev_worker_main(Reader *r, int index)
             blk[k].data_off = (int64_t)b.coff; blk[k].clen = (uint32_t)b.clen; blk[k].uoff = b.uoff; blk[k].ulen = b.ulen; blk[k].crc = b.crc;
             blk[k].reserved = 0;
         }
-        const int rc = r->dev_fn(r->dev_user, index, r->map, (int64_t)r->fsize, blk.data(), (int32_t)blk.size(), c->data, (int64_t)c->len,
-                                 r->check_crc ? 1 : 0);
+        int rc;
+        {
+            spx::CpuScope cs(spx::CPU_DEV_CHUNK);
+            rc = r->dev_fn(r->dev_user, index, r->map, (int64_t)r->fsize, blk.data(), (int32_t)blk.size(), c->data, (int64_t)c->len, r->check_crc ? 1 : 0);
+        }
         if (rc == 1) c->bad = 1;       /* corrupt DEFLATE data */
         else if (rc == 2) c->bad = 2;  /* CRC mismatch */
         else if (rc != 0) {            /* the device side failed: the host does this chunk */

@@ -10,6 +10,7 @@
  *   - tables that need libm (phred thresholds, score tables, the float quality LUT entry).
  */
 #include "spx_prep.h"
+#include "spx_cpuacc.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -200,6 +201,7 @@ static void parallel_for(int64_t n, int threads, F f)
 
 int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, Stage &st)
 {
+    CpuScope cs_serial(CPU_MEASURE);
     st.batches.assign(bts, bts + n_batches);
     st.batch_base.assign(n_batches, 0);
     int64_t n_in = 0;
@@ -239,6 +241,7 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
     const int64_t ns = (int64_t)st.recs.size();
     /* tag lengths: the only part that touches payload bytes */
     parallel_for(ns, threads, [&](int64_t a0, int64_t a1) {
+        CpuScope cs(CPU_MEASURE);
         for (int64_t s = a0; s < a1; ++s) {
             spxl::Rec &r = st.recs[(size_t)s];
             const spx_batch *bt = bts[r.batch];
@@ -251,6 +254,7 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
      * each minus the record's hard clips.  Verified base by base here; such a record's SEQ / QUAL stay on the host. */
     const bool alias_on = !getenv("SPX_NO_ALIAS");
     parallel_for((int64_t)st.grp_index.size(), threads, [&](int64_t k0, int64_t k1) {
+        CpuScope cs(CPU_MEASURE);
         for (int64_t k = k0; k < k1 && alias_on; ++k) {
             const int32_t s0 = st.slot0[(size_t)k], s1 = st.slot0[(size_t)k + 1];
             /* the source: the record that holds most of the read (the primary unless it is the hard-clipped one) */
@@ -441,6 +445,7 @@ void stage_fill(const Stage &st, int sec, int64_t b0, int64_t b1, char *dst,
     if (s1 <= s0) return;
     const int64_t grain = std::max<int64_t>(1, (int64_t)(((int64_t)4 << 20) / std::max<int64_t>(1, (b1 - b0) / (s1 - s0)))); /* ~4 MB per piece */
     f_parallel(s1 - s0, grain, [&](int64_t k0, int64_t k1) {
+        CpuScope cs(CPU_FILL);
         for (int64_t s = s0 + k0; s < s0 + k1; ++s) {
             const spxl::Rec &r = st.recs[(size_t)s];
             const spx_batch *bt = st.batches[r.batch];

@@ -27,6 +27,7 @@
 #include "spx_device.h"
 #include "spx_prep.h"
 #include "spx_prep_dev.h"
+#include "spx_cpuacc.h"
 #include "spx_pool.h"
 
 struct spx_bedset;
@@ -297,6 +298,10 @@ extern "C" int spx_create(int device, spx_ctx **out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SPX_ENODEVICE, "hipGetDeviceCount found no device");
     if (device < 0 || device >= n) return fail(SPX_ENODEVICE, "device index out of range");
     HIPCHK(hipSetDevice(device));
+    /* host threads that wait for the device SLEEP (the runtime's default is to spin): the waits of the pipeline workers,
+     * of the staging ring and of the inflate workers would otherwise burn the CPU time the container is short of (the boxes
+     * give it 16 cores; a device-inflated chunk cost 25 ms of CPU, most of it spinning beside a 20 ms kernel) */
+    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     const double tc1 = now_s();
@@ -345,7 +350,7 @@ extern "C" int spx_create(int device, spx_ctx **out)
         for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
     for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
         HIPCHK(mk_stream(&c->side_stream[i], m_dp));
-        HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming | hipEventBlockingSync));
     }
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->unpack_stream, hipStreamNonBlocking));
@@ -846,7 +851,7 @@ extern "C" int spx_internal_stage_finish(spx_ctx *c, spx_work *w)
             c->pin_next = (k + 1) % spx_ctx::SPX_PIN_CHUNKS;
             if (!c->pin_chunk[k]) {
                 if (hipHostMalloc(&c->pin_chunk[k], c->pin_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->pin_chunk[k] = nullptr; return -1; }
-                if (hipEventCreateWithFlags(&c->pin_done[k], hipEventDisableTiming) != hipSuccess) return -1;
+                if (hipEventCreateWithFlags(&c->pin_done[k], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return -1;
             }
             if (c->pin_busy[k] && hipEventSynchronize(c->pin_done[k]) != hipSuccess) return -1;
             c->pin_busy[k] = false;
@@ -893,7 +898,7 @@ extern "C" int spx_internal_stage_finish(spx_ctx *c, spx_work *w)
     }
     {
         hipEvent_t ev_copied = nullptr; /* the unpack stream goes on behind the last chunk */
-        HIPCHK(hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming | hipEventBlockingSync));
         hipError_t e = hipEventRecord(ev_copied, c->copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->unpack_stream, ev_copied, 0);
         (void)hipEventDestroy(ev_copied); /* (released by the runtime once it has completed) */
@@ -906,7 +911,7 @@ extern "C" int spx_internal_stage_finish(spx_ctx *c, spx_work *w)
      * never used); zeroing the whole pool was a 3.7 GB fill per 131 072 HiFi groups */
     HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)spx::kCodeLeadBytes, c->unpack_stream));
     HIPCHK(hipMemsetAsync(base + w->o_code + spx::kCodeLeadBytes + ((L.seq_bytes + 3) & ~(int64_t)3), 0, (size_t)spx::kCodeTailBytes - 8, c->unpack_stream));
-    HIPCHK(hipEventCreateWithFlags(&w->ev_staged, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_staged, hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(w->ev_staged, c->unpack_stream));
     w->st.prep_seconds += t1 - t0;
     w->st.bytes_h2d = (int64_t)L.bytes - (L.seq_bytes - L.pk_seq_bytes) - (L.qual_bytes - L.pk_qual_bytes); /* what really crossed PCIe */
@@ -1170,7 +1175,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         O.order_f = (int32_t *)(B0 + o_order_f); O.order_b = (int32_t *)(B0 + o_order_b);
         HIPCHK(spx_prep_orders(&O, &sf, &sb, PL.stream));
     }
-    if (!w->ev_ready) HIPCHK(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming));
+    if (!w->ev_ready) HIPCHK(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(w->ev_ready, PL.stream));
     /* ---- kernel argument blocks ---- */
     w->d_bq = (uint8_t *)(B0 + o_bq);
@@ -1336,7 +1341,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         if (w->staged) HIPCHK(spx_launch_results(&w->dg, w->d_info, w->d_rfe, w->d_results, c->stream));
     }
     HIPCHK(hipEventRecord(ev[2], c->stream));
-    if (!w->ev_done) HIPCHK(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming));
+    if (!w->ev_done) HIPCHK(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(w->ev_done, c->stream));
     w->launched = true;
     return SPX_OK;
@@ -1942,6 +1947,23 @@ extern "C" int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *
 
 extern "C" int spx_effective_cpus(void) { return spx::effective_cpus(); }
 
+extern "C" void spx_internal_cpu_add(int kind, double seconds)
+{
+    if (kind >= 0 && kind < spx::CPU_N && spx::cpu_acc_on()) spx::cpu_acc()[kind].fetch_add((int64_t)(seconds * 1e9), std::memory_order_relaxed);
+}
+/* diagnostics (SPX_TIMING): core-seconds of the host side by kind of work, all threads, since the process started */
+extern "C" void spx_internal_cpu_report(FILE *f)
+{
+    static const char *const names[spx::CPU_N] = {"host inflate", "CRC-32", "device-inflate chunks (copies in / out, waiting)", "mapping the file",
+                                                  "record chain (walker thread)", "fields / tags / CIGAR copies", "staging: sizes + repeated SEQ/QUAL",
+                                                  "staging: copies into pinned memory", "BED bookkeeping"};
+    struct timespec ts;
+    clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+    fprintf(f, "[spx timing] CPU time of the process %.3f core-s, of which:", ts.tv_sec + 1e-9 * ts.tv_nsec);
+    for (int k = 0; k < spx::CPU_N; ++k) fprintf(f, " %s %.3f;", names[k], 1e-9 * (double)spx::cpu_acc()[k].load());
+    fprintf(f, "\n");
+}
+
 /* diagnostics (host only): what staging these batches would put on the wire.  out[0] alignments of dispatched groups,
  * out[1] of them aliased to their group's primary (SEQ / QUAL not transferred), out[2] SEQ + QUAL bytes of all of them,
  * out[3] SEQ + QUAL bytes really transferred */
@@ -2056,9 +2078,9 @@ extern "C" int spx_inflater_create(spx_ctx *c, int32_t n_workers, spx_inflater *
               hipStreamCreateWithFlags(&inf->st_d2h, hipStreamNonBlocking) == hipSuccess;
     for (auto &k : inf->w)
         ok = ok && hipStreamCreateWithFlags(&k.st, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&k.ev_in, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&k.ev_k, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&k.ev_out, hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&k.ev_in, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess &&
+             hipEventCreateWithFlags(&k.ev_k, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess &&
+             hipEventCreateWithFlags(&k.ev_out, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); spx_inflater_free(inf); return fail(SPX_EHIP, "streams of the inflater"); }
     *out = inf;
     return SPX_OK;

@@ -1,0 +1,21 @@
+#!/bin/bash
+# one synthetic BAM, the command line under SPX_TIMING in several configurations: wall times + core-seconds by kind of work
+G=${1:-262144}
+python tools/e2e_cli.py --groups $G --batch 16384 --check-groups 0 --keep > /tmp/e2e_first.json 2>/tmp/e2e_first.err || { tail -5 /tmp/e2e_first.err; exit 1; }
+D=$(ls -d /dev/shm/spx_e2e_* | head -1)
+run() {
+  rm -rf $D/out
+  env SPX_TIMING=1 $2 secphase_amd/bin/secphase --hifi -i $D/reads.bam -f $D/asm.fa --outDir $D/out --prefix e2e --groupsPerBatch 16384 $3 2> /tmp/e2e.err > /dev/null
+  echo "== $1"; grep -h "CPU time\|scoring loop\|whole process\|inflate chunks" /tmp/e2e.err | sed 's/^\[[0-9: -]*\] //'
+}
+while read -r line; do
+  [ -z "$line" ] && continue
+  run "$line" "${line%%|*}" "${line#*|}"
+done <<CFG
+A=1|-@ 16 --gpuInflate 5
+A=1|-@ 16 --gpuInflate 10
+A=1|-@ 16 --gpuInflate 16
+A=1|-@ 12 --gpuInflate 12
+A=1|-@ 64 --gpuInflate 5
+CFG
+rm -rf $D
