@@ -115,7 +115,7 @@ static void usage(const char *prog)
             "         --device               GPU index [0]\n"
             "         --devices              several GPUs, e.g. 0-7 or 0,2,5: batches are dealt round-robin, the output is\n"
             "                                the same file-order list\n"
-            "         --gpuInflate           BGZF inflate workers per GPU beside the host threads [5]; 0: host only\n"
+            "         --gpuInflate           BGZF inflate workers per GPU beside the host threads [8]; 0: host only\n"
             "         --writeBam, -w         Write <prefix>.quality_modified.out.bam (SAM text, as the reference does) with\n"
             "                                the base qualities modified by BAQ\n"
             "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode)\n");
@@ -132,7 +132,7 @@ int main(int argc, char *argv[])
     par.conf_b = 20; par.flank_margin = 500;
     std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
     bool preset_ont = false, preset_hifi = false, marker_mode = true, write_bam = false, batch_given = false;
-    int threads = 4, groups_per_batch = 16384, gpu_inflate = 5, c;
+    int threads = 4, groups_per_batch = 16384, gpu_inflate = 8, c;
     if (const char *e = getenv("SPX_GPU_INFLATE")) gpu_inflate = atoi(e);
     std::vector<int> devices;
     auto parse_devices = [&](const char *txt) { /* "0-3", "0,2,5", "1" */
@@ -246,6 +246,7 @@ int main(int argc, char *argv[])
     bo.ahead_batches = 2;
     bo.keep_batches = n_dev * (depth + 1) + 2 * n_dev + 6;
     bo.ahead_batches = 3; /* the reader keeps cutting batches while the devices start up */
+    if (const char *e = getenv("SPX_BAM_AHEAD")) bo.ahead_batches = std::max(1, atoi(e));
     spx_bam_reader *bam = nullptr;
     if (spx_bam_open_opts(inputPath.c_str(), &bo, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); return 1; }
     const double t_bam_open = now_s();

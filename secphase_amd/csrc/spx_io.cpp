@@ -236,14 +236,19 @@ struct Reader {
     bool closing = false, consumer_waiting = false;
     std::unique_ptr<spx::Pool> pool;
     std::thread walker;
-    /* optional device inflate (spx_bam_attach_device_inflate): chunks go to whichever side has room -- the host pool or
-     * the device workers (each: compressed bytes -> pinned memory -> HBM -> inflate kernel -> back) */
+    /* Who inflates a dispatched chunk is decided when somebody has TIME for it, not when it is dispatched: the chunks wait
+     * in `unclaimed` (file order); the host pool claims from the FRONT (the walker needs those first, and a chunk takes
+     * the pool a few milliseconds) as long as fewer than `host_window` chunks are in work on it; a device worker
+     * (spx_bam_attach_device_inflate: compressed bytes -> pinned memory -> HBM -> inflate kernel -> back, tens of
+     * milliseconds per chunk, next to no CPU time) that is idle while the pool is saturated claims from the BACK.  Both
+     * sides stay busy, the split follows their speeds. */
+    std::deque<Chunk *> unclaimed;
+    int host_active = 0, host_window = 3;
     spx_bgzf_inflate_fn dev_fn = nullptr;
     void *dev_user = nullptr;
     std::vector<std::thread> dev_workers;
-    std::deque<Chunk *> dev_q;
     std::condition_variable cv_dev;
-    int dev_busy = 0, dev_cap = 0; /* chunks queued or in work on the device side / how many it may hold */
+    bool dev_all = false; /* tests: the pool claims nothing */
     int64_t n_chunks_dev = 0, n_chunks_host = 0;
     /* walker cursor (reader thread only) */
     Chunk *cur = nullptr;
@@ -329,6 +334,34 @@ void populate_ahead(Reader *r)
 #endif
 }
 
+/* the pool takes the front-most waiting chunks while fewer than host_window are in work on it (caller holds r->mu) */
+void host_pump_locked(Reader *r)
+{
+    while (!r->dev_all && !r->closing && r->host_active < r->host_window && !r->unclaimed.empty()) {
+        Chunk *cp = r->unclaimed.front();
+        r->unclaimed.pop_front();
+        ++r->host_active;
+        ++r->n_chunks_host;
+        const size_t nb = cp->blocks.size(), per = 16;
+        cp->pending = (int)((nb + per - 1) / per);
+        for (size_t b0 = 0; b0 < nb; b0 += per) {
+            const size_t b1 = std::min(nb, b0 + per);
+            r->pool->submit([r, cp, b0, b1] {
+                inflate_blocks(r, cp, b0, b1);
+                if (cp->pending.fetch_sub(1) == 1) {
+                    {
+                        std::lock_guard<std::mutex> lk(r->mu);
+                        --r->host_active;
+                        host_pump_locked(r);
+                        r->cv_chunk.notify_all();
+                    }
+                    r->cv_dev.notify_one();
+                }
+            });
+        }
+    }
+}
+
 bool dispatch_chunk(Reader *r)
 {
     if (r->index_eof) return false;
@@ -381,40 +414,18 @@ bool dispatch_chunk(Reader *r)
         }
         c->data = r->arena.slot_ptr(c->slot) + r->head;
         c->refs = 1; /* the walker's */
-        const size_t nb = c->blocks.size();
-        const size_t per = 16;
-        const int tasks = (int)((nb + per - 1) / per);
-        c->pending = tasks;
+        c->pending = c->blocks.empty() ? 0 : 1; /* (the claimer sets the real count) */
         r->inflight.push_back(c.get());
     }
     r->t_wait_slot += io_now() - t0;
     Chunk *cp = c.release();
-    const size_t nb = cp->blocks.size(), per = 16;
-    if (nb == 0) { r->cv_chunk.notify_all(); return true; }
+    if (cp->blocks.empty()) { r->cv_chunk.notify_all(); return true; }
     {
-        /* the device takes a chunk whenever it has room (it then works beside the pool, not instead of it) */
-        std::unique_lock<std::mutex> lk(r->mu);
-        if (r->dev_fn && r->dev_busy < r->dev_cap) {
-            cp->pending = 1;
-            ++r->dev_busy;
-            ++r->n_chunks_dev;
-            r->dev_q.push_back(cp);
-            lk.unlock();
-            r->cv_dev.notify_one();
-            return true;
-        }
-        ++r->n_chunks_host;
+        std::lock_guard<std::mutex> lk(r->mu);
+        r->unclaimed.push_back(cp);
+        host_pump_locked(r);
     }
-    for (size_t b0 = 0; b0 < nb; b0 += per) {
-        const size_t b1 = std::min(nb, b0 + per);
-        r->pool->submit([r, cp, b0, b1] {
-            inflate_blocks(r, cp, b0, b1);
-            if (cp->pending.fetch_sub(1) == 1) {
-                std::lock_guard<std::mutex> lk(r->mu);
-                r->cv_chunk.notify_all();
-            }
-        });
-    }
+    r->cv_dev.notify_one();
     return true;
 }
 
@@ -771,7 +782,7 @@ void walker_main(Reader *r)
     }
 }
 
-/* one device-inflate worker: chunks from dev_q through the caller's function; a chunk the device cannot do (error from
+/* one device-inflate worker: chunks claimed from the back of `unclaimed` go through the caller's function; a chunk the device cannot do (error from
  * the function itself, not from the data) falls back to the host pool */
 void dev_worker_main(Reader *r, int index)
 {
@@ -780,10 +791,15 @@ void dev_worker_main(Reader *r, int index)
         Chunk *c = nullptr;
         {
             std::unique_lock<std::mutex> lk(r->mu);
-            r->cv_dev.wait(lk, [&] { return r->closing || !r->dev_q.empty(); });
-            if (r->dev_q.empty()) return;
-            c = r->dev_q.front();
-            r->dev_q.pop_front();
+            /* a chunk the pool will not get to right away: the pool is saturated, or out of the game */
+            r->cv_dev.wait(lk, [&] {
+                return r->closing || (r->dev_all ? !r->unclaimed.empty() : (r->unclaimed.size() >= 2 && r->host_active >= r->host_window));
+            });
+            if (r->closing || r->unclaimed.empty()) return;
+            c = r->unclaimed.back();
+            r->unclaimed.pop_back();
+            c->pending = 1;
+            ++r->n_chunks_dev;
         }
         blk.resize(c->blocks.size());
         for (size_t k = 0; k < c->blocks.size(); ++k) {
@@ -808,7 +824,6 @@ void dev_worker_main(Reader *r, int index)
         {
             std::lock_guard<std::mutex> lk(r->mu);
             c->pending = 0;
-            --r->dev_busy;
             r->cv_chunk.notify_all();
         }
     }
@@ -953,6 +968,7 @@ extern "C" int spx_bam_open_opts(const char *path, const spx_bam_options *opt, s
     const size_t al = (size_t)2 << 20;
     const size_t slot = (2 * r->head + al - 1) & ~(al - 1);
     r->max_inflight = std::max(3, r->threads / 8 + 2);
+    r->host_window = std::max(2, r->threads / 16 + 2);
     const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
     const size_t phys = (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz : ((size_t)64 << 30);
     size_t cap_bytes = o.max_bytes > 0 ? (size_t)o.max_bytes : phys / 4;
@@ -1089,8 +1105,7 @@ extern "C" int spx_bam_attach_device_inflate(spx_bam_reader *h, spx_bgzf_inflate
     std::lock_guard<std::mutex> lk(r->mu);
     if (r->dev_fn) return SPX_EINVAL;
     r->dev_user = user;
-    r->dev_cap = n_workers + 1; /* one waiting per set of workers */
-    if (getenv("SPX_BAM_DEVICE_ALL")) r->dev_cap = 1 << 20; /* tests: every chunk from now on goes to the device */
+    if (getenv("SPX_BAM_DEVICE_ALL")) r->dev_all = true; /* tests: every chunk from now on goes to the device */
     /* a chunk on the device takes tens of milliseconds (one wave per block: latency, not throughput), the walker takes
      * chunks in file order: look further ahead, so that device chunks are dispatched long before they are needed */
     r->max_inflight += 3 * n_workers;

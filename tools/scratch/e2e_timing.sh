@@ -12,10 +12,10 @@ while read -r line; do
   [ -z "$line" ] && continue
   run "$line" "${line%%|*}" "${line#*|}"
 done <<CFG
-A=1|-@ 16 --gpuInflate 5
-A=1|-@ 16 --gpuInflate 10
-A=1|-@ 16 --gpuInflate 16
-A=1|-@ 12 --gpuInflate 12
-A=1|-@ 64 --gpuInflate 5
+A=1|-@ 16
+SPX_BAM_AHEAD=6|-@ 16
+SPX_BAM_AHEAD=10|-@ 16
+SPX_BAM_AHEAD=16|-@ 16
+SPX_BAM_AHEAD=10|-@ 16 --groupsPerBatch 8192
 CFG
 rm -rf $D
