@@ -2174,9 +2174,11 @@ extern "C" int spx_inflater_run(void *user, int32_t worker, const uint8_t *file,
     WCHK(hipStreamWaitEvent(W.st, W.ev_in, 0));
     WCHK(spx_launch_bgzf_inflate(W.d_in, W.d_desc, n_blocks, W.d_out, W.d_status, check_crc, W.st));
     WCHK(hipEventRecord(W.ev_k, W.st));
+    /* the HOST waits for the kernel (asleep): a copy stream that waits for a kernel's event is served by the copy kernel
+     * from then on, like one that has run a kernel itself */
+    WCHK(hipEventSynchronize(W.ev_k));
     {
         std::lock_guard<std::mutex> cl(inf->mu_d2h);
-        WCHK(hipStreamWaitEvent(inf->st_d2h, W.ev_k, 0));
         WCHK(hipMemcpyAsync(W.h_status, W.d_status, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, inf->st_d2h));
         WCHK(hipMemcpyAsync(W.h_out, W.d_out, out_bytes, hipMemcpyDeviceToHost, inf->st_d2h));
         WCHK(hipEventRecord(W.ev_out, inf->st_d2h));

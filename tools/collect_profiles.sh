@@ -34,11 +34,13 @@ json.dump({"kernel": k, "launches_in_trace": len(d), "all_launches_avg_ms": roun
           open(f"{out}/{tag}_kernel_trace_dominant.json", "w"), indent=1)
 PY
 rm -rf "$OUT/kt"
+if [ -z "${SKIP_PMC:-}" ]; then
 python3 tools/pmc_collect.py --platform hifi --out "$OUT/${TAG}_counters_hifi.json" >> "$OUT/${TAG}_bench.err" 2>&1
 python3 tools/pmc_collect.py --platform ont --out "$OUT/${TAG}_counters_ont.json" >> "$OUT/${TAG}_bench.err" 2>&1
 python3 tools/pmc_collect.py --platform mixed --out "$OUT/${TAG}_counters_mixed.json" >> "$OUT/${TAG}_bench.err" 2>&1
 python3 tools/pmc_collect.py --platform hifi --full --out "$OUT/${TAG}_counters_prep.json" >> "$OUT/${TAG}_bench.err" 2>&1
 python3 tools/pmc_collect.py --platform mixed --full --out "$OUT/${TAG}_counters_prep_mixed.json" >> "$OUT/${TAG}_bench.err" 2>&1
-python3 tools/e2e_cli.py --groups 131072 --threads 64 --batch 32768 > "$OUT/${TAG}_e2e_cli.json" 2>> "$OUT/${TAG}_bench.err"
+fi
+python3 tools/e2e_cli.py --groups 262144 --threads 64 --batch 16384 > "$OUT/${TAG}_e2e_cli.json" 2>> "$OUT/${TAG}_bench.err"
 rm -rf "$ROOT/gpurun_out/pmc_tmp"
 ls -la "$OUT"

@@ -51,10 +51,12 @@ def main():
     ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else None)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--gpu-inflate", type=int, default=-1)
+    ap.add_argument("--cli-threads", type=int, default=0, help="-@ of the command line (default: the CPUs the container may use)")
     ap.add_argument("--tidy", action="store_true")
     args = ap.parse_args()
     from oracle import orc
-    from secphase_amd import records, synth
+    from secphase_amd import api, records, synth
+    cli_threads = args.cli_threads or max(1, min(args.threads, api.lib().spx_effective_cpus()))
     ont = args.platform == "ont"
     cfg = synth.default_cfg(synth.ONT if ont else synth.HIFI)
     g = synth.Genome(cfg)
@@ -69,7 +71,7 @@ def main():
     t_write = time.time() - t0
     exe = os.path.join(ROOT, "secphase_amd", "bin", "secphase")
     flags = ["--ont", "-b", "50"] if ont else ["--hifi"]
-    cmd = [exe] + flags + ["-@", str(args.threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "e2e",
+    cmd = [exe] + flags + ["-@", str(cli_threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "e2e",
                            "--groupsPerBatch", str(args.batch), "--devices", args.devices]
     if args.gpu_inflate >= 0:
         cmd += ["--gpuInflate", str(args.gpu_inflate)]
@@ -96,7 +98,7 @@ def main():
     keep = ("start-up", "time in the scoring loop", "finalise", "wind-down", "inflate chunks")
     print(json.dumps({"groups": args.groups, "platform": args.platform, "devices": args.devices, "bam_bytes": size, "wall_s": round(wall, 3),
                       "groups_per_s": round(args.groups / wall, 1), "GB_bam_per_s": round(size / wall / 1e9, 4),
-                      "cpu_oracle_groups_per_s": round(ncheck / cpu, 1) if cpu else None, "cpu_threads": args.threads,
+                      "cpu_oracle_groups_per_s": round(ncheck / cpu, 1) if cpu else None, "cpu_threads": args.threads, "cli_threads": cli_threads,
                       "out_log_identical_to_oracle": same, "checked_groups": ncheck, "generate_s": round(t_gen, 1), "bam_write_s": round(t_write, 1),
                       "stderr_tail": [l for l in p.stderr.strip().splitlines() if any(k in l for k in keep)]}, indent=0))
     if not args.keep:

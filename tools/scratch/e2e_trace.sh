@@ -15,6 +15,8 @@ rows = list(csv.DictReader(open(f)))
 t0 = min(int(r["Start_Timestamp"]) for r in rows)
 inf = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0))) for r in rows if "bgzf_inflate" in r["Kernel_Name"]]
 dp = [(int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0) for r in rows if "baq_" in r["Kernel_Name"]]
+cb = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if "copyBuffer" in r["Kernel_Name"]]
+print("copy KERNELS:", len(cb), "total ms", round(sum(cb), 1), "of them > 1 ms:", sum(1 for x in cb if x > 1))
 import statistics as st
 d = [(b - a) / 1e6 for a, b, _ in inf]
 print("inflate kernels", len(inf), "duration ms: median", round(st.median(d), 2), "mean", round(st.mean(d), 2), "max", round(max(d), 2), "grid", inf[0][2])
