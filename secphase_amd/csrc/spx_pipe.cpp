@@ -139,7 +139,7 @@ extern "C" int spx_pipe_create(spx_ctx *ctx, const spx_params *par, int depth, i
     spx_pipe *p = new spx_pipe();
     p->ctx = ctx;
     p->par = *par;
-    p->depth = depth < 1 ? 1 : (depth > 8 ? 8 : depth);
+    p->depth = depth < 1 ? 1 : (depth > 16 ? 16 : depth);
     int ht = host_threads > 0 ? host_threads : spx::effective_cpus();
     p->stage_threads = ht > 0 ? ht : 1; /* stagings run one after the other (ticket order): each gets all the threads */
     p->gate = spx_internal_gate_create();

@@ -143,7 +143,7 @@ struct spx_ctx {
      * that leave most of the chip idle, and their duration is set by the longest alignment of the batch, not by the number
      * of groups.  So the preparations of several batches run SIDE BY SIDE, each on its own stream with its own pools
      * (a lane's mutex serialises the preparations that share it; work list w uses lane w->lane). */
-    static const int SPX_N_PREP = 6; /* lanes that exist; n_prep of them are used (SPX_PREP_LANES, default 4) */
+    static const int SPX_N_PREP = 12; /* lanes that exist; n_prep of them are used (SPX_PREP_LANES, default 4) */
     int n_prep = 4;
     struct PrepLane {
         hipStream_t stream = nullptr;
@@ -696,7 +696,10 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
         void *p = nullptr;
         /* head room so that the next, slightly larger list fits -- until memory has been tight once */
         *cap = bytes + (c->hbm_tight.load() ? 0 : bytes / 8) + 4096;
-        if (hipMalloc(&p, *cap) == hipSuccess) return p;
+        const double tm0 = now_s();
+        const hipError_t me = hipMalloc(&p, *cap);
+        if (timing_on()) fprintf(stderr, "[spx timing] hipMalloc of %.2f GB: %.3f s%s\n", *cap / 1e9, now_s() - tm0, me == hipSuccess ? "" : " (failed)");
+        if (me == hipSuccess) return p;
         (void)hipGetLastError();
         c->hbm_tight = true;
         std::unique_lock<std::mutex> lk(c->arena_mu);

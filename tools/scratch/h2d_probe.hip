@@ -14,7 +14,9 @@ __global__ void tiny(int *p) { if (threadIdx.x == 999) p[0] = 1; }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv)
 {
-    const int mode = argc > 1 ? atoi(argv[1]) : 0;
+    int mode = argc > 1 ? atoi(argv[1]) : 0;
+    if (mode == 9) { CK(hipSetDeviceFlags(hipDeviceScheduleBlockingSync)); mode = 7; printf("(hipDeviceScheduleBlockingSync) "); }
+    if (mode == 10) { mode = 7; printf("(offset source, event-sync first) "); }
     const size_t CH = 64u << 20; const int NCH = 4, N = 64;
     void *pin[NCH]; hipEvent_t ev[NCH]; char *dev; double *o; int *ip;
     for (int k = 0; k < NCH; ++k) { CK(hipHostMalloc(&pin[k], CH, hipHostMallocDefault)); memset(pin[k], k, CH); CK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); }
