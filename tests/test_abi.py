@@ -77,3 +77,21 @@ def test_finalize_and_relabel_log_reproduce_the_reference_tail(built, tmp_path):
     api.write_relabel_log(log_g, r.batch, g.ref, out)
     assert filecmp.cmp(log_o, log_g, shallow=False)
     assert sum(o.relabel for o in out) == nre > 0
+
+
+def test_effective_cpus_respects_affinity_and_quota(built):
+    """default of every host_threads argument: online CPUs cut by the affinity mask and the cgroup CPU quota"""
+    import os
+    from secphase_amd import api
+    n = api.lib().spx_effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert n <= len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = -(-int(q) // int(per))
+    except OSError:
+        pass
+    if quota:
+        assert n <= quota
