@@ -314,8 +314,9 @@ int spx_bam_next_batch(spx_bam_reader *r, int32_t max_groups, const spx_batch **
 int spx_bam_release_batch(spx_bam_reader *r, const spx_batch *batch);
 void spx_bam_close(spx_bam_reader *r);
 /* Device inflate beside the host pool (round 3: the GPU boxes give a container ~16 cores of CPU time; inflate is what they
- * are spent on).  Once attached, the reader hands a chunk (a run of BGZF blocks, ~32 MB inflated) to the device whenever
- * one of n_workers device workers has room, and to its host pool otherwise.  fn inflates blocks[0..n) of the mapped file
+ * are spent on).  Once attached, dispatched chunks (runs of BGZF blocks, ~32 MB inflated) wait in one queue: the host pool
+ * claims from its front, an idle one of the n_workers device workers claims from its back while the pool is saturated, so
+ * the split follows the speeds of the two sides.  fn inflates blocks[0..n) of the mapped file
  * into dst (blocks[k] goes to dst + uoff) and returns 0, 1 (corrupt DEFLATE data), 2 (CRC-32 mismatch) or a negative value
  * (the device could not do it: the reader inflates the chunk on the host).  spx_inflater_* (below) is that function on a
  * scoring context. */

@@ -281,7 +281,8 @@ int main(int argc, char *argv[])
             if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); return 1; }
     }
     const double t_ref = now_s();
-    /* BGZF inflate on the device(s) beside the host pool: the reader hands a chunk to whichever side has room */
+    /* BGZF inflate on the device(s) beside the host pool: the host pool claims chunks from the front of the reader's queue, idle device
+     * workers from its back */
     struct InflateRoute { std::vector<spx_inflater *> inf; int per_dev = 0; } route;
     if (gpu_inflate > 0 && marker_mode) {
         route.per_dev = std::min(gpu_inflate, 16);

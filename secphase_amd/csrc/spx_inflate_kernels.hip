@@ -10,8 +10,8 @@
  *
  * Mapping onto a wavefront:
  *   - the bit-serial Huffman decode is WAVE-UNIFORM: every lane executes the same decode of the same block, so the
- *     compiler keeps bit buffer, counters and table indices in SGPRs / on the scalar unit; the root tables (10-bit
- *     literal/length, 8-bit distance) live in LDS and are read back through v_readfirstlane;
+ *     compiler keeps bit buffer, counters and table indices in SGPRs / on the scalar unit; the root tables (11-bit
+ *     literal/length, 9-bit distance) live in LDS and are read back through v_readfirstlane;
  *   - the 64 lanes share the data-parallel parts: zeroing and filling the decode tables, LZ77 copies (lane i copies
  *     bytes i, i + 64, ...: an overlapping match is a repeat of its first `dist` bytes, so the lanes are independent),
  *     flushing finished output to HBM, and the CRC-32 (64 stripes, combined with the GF(2) shift operator);
