@@ -505,6 +505,11 @@ def main():
         if world == 1 and not args.no_host_leg:
             # the same steps fed from HOST memory: staging (host threads) + PCIe copy inside the timed region
             hs = max(2, min(args.steps, 8))
+            # the resident copies of the records have served their purpose (the timed steps above): their HBM (15 GB per
+            # batch) goes back to the context, or `depth` work lists of 44 GB + their images do not fit beside them
+            for w_ in staged:
+                w_.free()
+            staged = []
             try:
                 run(args.depth + 2, 0, True)  # warm-up: pinned staging buffers and device arenas of every slot exist
                 sync_all()

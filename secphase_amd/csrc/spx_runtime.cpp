@@ -121,6 +121,7 @@ struct spx_ctx {
     size_t hbm_bytes = (size_t)256 << 30; /* the device's total memory (hipMemGetInfo at spx_create) */
     std::condition_variable arena_cv; /* signalled when a work list gives device memory back (arena_put) */
     std::atomic<bool> hbm_tight{false}; /* an allocation has failed once: no more head room on new blocks */
+    size_t arena_in_use = 0;            /* bytes of blocks handed out by arena_get (under arena_mu) */
     /* Staging ring: record batches go to HBM through a few pinned chunks that are filled by a thread pool and copied
      * asynchronously, one behind the other (a pinned buffer per batch would mean pinning gigabytes anew whenever a batch
      * is larger than any before -- ~0.2 s per GB -- and again after every spx_trim) */
@@ -690,16 +691,45 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
                 void *p = c->arena_cache[best].first;
                 *cap = c->arena_cache[best].second;
                 c->arena_cache.erase(c->arena_cache.begin() + best);
+                c->arena_in_use += *cap;
                 return p;
             }
         }
         void *p = nullptr;
         /* head room so that the next, slightly larger list fits -- until memory has been tight once */
         *cap = bytes + (c->hbm_tight.load() ? 0 : bytes / 8) + 4096;
+        {
+            /* blocks in use + blocks waiting for re-use + this one stay under ~7/8 of the device: the OLDEST waiting blocks
+             * go back to the driver first (a failed hipMalloc costs a flush of the whole cache and, with several lists in
+             * flight, sends the pipeline into a slow mode: mixed config, 6 lists of 27 GB: 157 k or 56 k groups/s) */
+            std::vector<void *> drop;
+            {
+                std::lock_guard<std::mutex> lk(c->arena_mu);
+                size_t held = 0;
+                for (auto &a : c->arena_cache) held += a.second;
+                const size_t budget = c->hbm_bytes - c->hbm_bytes / 8;
+                while (!c->arena_cache.empty() && c->arena_in_use + held + *cap > budget) {
+                    held -= c->arena_cache.front().second;
+                    drop.push_back(c->arena_cache.front().first);
+                    c->arena_cache.erase(c->arena_cache.begin());
+                }
+            }
+            for (void *d : drop) (void)hipFree(d);
+        }
         const double tm0 = now_s();
         const hipError_t me = hipMalloc(&p, *cap);
-        if (timing_on()) fprintf(stderr, "[spx timing] hipMalloc of %.2f GB: %.3f s%s\n", *cap / 1e9, now_s() - tm0, me == hipSuccess ? "" : " (failed)");
-        if (me == hipSuccess) return p;
+        if (timing_on()) {
+            size_t held = 0;
+            std::lock_guard<std::mutex> lk(c->arena_mu);
+            for (auto &a : c->arena_cache) held += a.second;
+            fprintf(stderr, "[spx timing] hipMalloc of %.2f GB: %.3f s%s (in use %.1f GB, %zu blocks / %.1f GB waiting for re-use)\n", *cap / 1e9,
+                    now_s() - tm0, me == hipSuccess ? "" : " (failed)", c->arena_in_use / 1e9, c->arena_cache.size(), held / 1e9);
+        }
+        if (me == hipSuccess) {
+            std::lock_guard<std::mutex> lk(c->arena_mu);
+            c->arena_in_use += *cap;
+            return p;
+        }
         (void)hipGetLastError();
         c->hbm_tight = true;
         std::unique_lock<std::mutex> lk(c->arena_mu);
@@ -707,7 +737,7 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
         for (auto &a : c->arena_cache) (void)hipFree(a.first);
         c->arena_cache.clear();
         *cap = bytes + 4096;
-        if (hipMalloc(&p, *cap) == hipSuccess) return p;
+        if (hipMalloc(&p, *cap) == hipSuccess) { c->arena_in_use += *cap; return p; }
         (void)hipGetLastError();
         if (now_s() >= t_end) return nullptr;
         c->arena_cv.wait_for(lk, std::chrono::milliseconds(250));
@@ -723,10 +753,12 @@ static void arena_put(spx_ctx *c, void *p, size_t cap)
              * sizes in demand change with the workload: a cache full of blocks nobody asks for any more would send every
              * request to hipMalloc) */
             std::lock_guard<std::mutex> lk(c->arena_mu);
+            c->arena_in_use -= std::min(c->arena_in_use, cap);
             if (cap <= c->hbm_bytes / 2) {
                 size_t held = cap;
                 for (auto &a : c->arena_cache) held += a.second;
-                while (!c->arena_cache.empty() && (c->arena_cache.size() >= 8 || held > c->hbm_bytes / 2)) {
+                while (!c->arena_cache.empty() && (c->arena_cache.size() >= 8 || held > c->hbm_bytes / 2 ||
+                                                   c->arena_in_use + held > c->hbm_bytes - c->hbm_bytes / 8)) {
                     held -= c->arena_cache.front().second;
                     drop.push_back(c->arena_cache.front().first);
                     c->arena_cache.erase(c->arena_cache.begin());
