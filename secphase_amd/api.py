@@ -94,7 +94,7 @@ EXPORTS = [
     "spx_bam_next_batch", "spx_bam_close", "spx_bam_open_opts", "spx_bam_default_options", "spx_bam_release_batch",
     "spx_bam_index_build", "spx_bam_index_save", "spx_bam_index_load", "spx_fasta_load",
     "spx_count_draws", "spx_finalizer_skip", "spx_format_relabel_text", "spx_free_text",
-    "spx_inflate_bgzf_device", "spx_inflate_core_host", "spx_crc32_core_host", "spx_stage_transfer_stats", "spx_effective_cpus",
+    "spx_inflate_bgzf_device", "spx_inflate_core_host", "spx_crc32_core_host", "spx_stage_transfer_stats", "spx_effective_cpus", "spx_bam_drop_pages",
     "spx_bam_attach_device_inflate", "spx_bam_inflate_counts", "spx_inflater_create", "spx_inflater_run", "spx_inflater_free", "spx_fasta_ref", "spx_fasta_free",
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",

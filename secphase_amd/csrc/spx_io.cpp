@@ -1123,10 +1123,34 @@ extern "C" void spx_bam_inflate_counts(const spx_bam_reader *h, int64_t *chunks_
     if (chunks_device) *chunks_device = r->n_chunks_dev;
 }
 
+/* Give the reader's pages back to the kernel ON THE POOL: madvise(MADV_DONTNEED) takes the address-space lock shared, so
+ * the 13 GB of a 262 144-group run (arena slots touched + the populated file mapping) go in parallel instead of in one
+ * serial munmap / process exit (0.36 + 0.10 s, or 0.8 s of the parent's wait for the exit).  The batches handed out are
+ * dead afterwards: called when every output is written. */
+static void drop_pages(Reader *r)
+{
+    if (!r->pool) return;
+    struct Piece { uint8_t *p; size_t n; };
+    std::vector<Piece> pieces;
+    const size_t step = (size_t)64 << 20;
+    for (int s = 0; s < r->arena.n_fresh; ++s) pieces.push_back({r->arena.slot_ptr(s), r->arena.slot_bytes});
+    if (r->map && !r->map_is_malloc)
+        for (size_t a = 0; a < r->fsize; a += step) pieces.push_back({(uint8_t *)r->map + a, std::min(step, r->fsize - a)});
+    r->pool->parallel_for((int64_t)pieces.size(), 1, [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) (void)madvise(pieces[(size_t)k].p, pieces[(size_t)k].n, MADV_DONTNEED);
+    });
+}
+
+extern "C" void spx_bam_drop_pages(spx_bam_reader *h)
+{
+    if (h) drop_pages(&h->r);
+}
+
 extern "C" void spx_bam_close(spx_bam_reader *h)
 {
     if (!h) return;
     Reader *r = &h->r;
+    const double tc0 = io_now();
     {
         std::lock_guard<std::mutex> lk(r->mu);
         r->closing = true;
@@ -1138,6 +1162,7 @@ extern "C" void spx_bam_close(spx_bam_reader *h)
     if (r->walker.joinable()) r->walker.join();
     r->cv_dev.notify_all();
     for (auto &t : r->dev_workers) if (t.joinable()) t.join(); /* (chunks still queued are finished first: their slots are live) */
+    drop_pages(r);   /* (behind whatever inflate tasks are still queued; nobody reads the arena any more) */
     r->pool.reset(); /* joins the workers: no inflate task is running after this */
     {
         std::lock_guard<std::mutex> lk(r->mu);
@@ -1149,10 +1174,16 @@ extern "C" void spx_bam_close(spx_bam_reader *h)
         for (Chunk *c : r->inflight) chunk_unref_locked(r, c);
         r->inflight.clear();
     }
+    const double tc1 = io_now();
     if (r->map && !r->map_is_malloc) munmap((void *)r->map, r->fsize);
     if (r->map && r->map_is_malloc) free((void *)r->map);
     if (r->fd >= 0) close(r->fd);
+    const double tc2 = io_now();
+    const int slots = r->arena.n_fresh;
     delete h;
+    if (io_timing())
+        fprintf(stderr, "[spx timing] reader closed: threads joined + batches released %.3f s, file unmapped %.3f s, arena (%d slots touched) unmapped %.3f s\n",
+                tc1 - tc0, tc2 - tc1, slots, io_now() - tc2);
 }
 
 /* ---- index of group starts in the reference's on-disk format (src/secphase_index.c:76-119: int64 count, then that

@@ -77,7 +77,13 @@ def main():
         cmd += ["--gpuInflate", str(args.gpu_inflate)]
     t0 = time.time()
     p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SPX_TIMING="1", **({"SPX_TIDY_EXIT": "1"} if args.tidy else {})))
-    wall = time.time() - t0
+    t1 = time.time()
+    wall = t1 - t0
+    outside = None
+    for l in p.stderr.splitlines():
+        if "main() entered at" in l:
+            a, b = [float(x) for x in l.replace(",", " ").split() if x.replace(".", "").isdigit() and "." in x][:2]
+            outside = {"exec_to_main_s": round(a - t0, 3), "exit_to_parent_s": round(t1 - b, 3)}
     if p.returncode != 0:
         sys.exit(p.stderr[-3000:])
     params = records.preset("ont", bandwidth=50) if ont else records.preset("hifi")
@@ -95,11 +101,11 @@ def main():
         got = open(os.path.join(outd, "e2e.out.log"), "rb").read()
         same = got[:len(want)] == want and (args.groups > ncheck or len(got) == len(want))
     size = os.path.getsize(bam)
-    keep = ("start-up", "time in the scoring loop", "finalise", "wind-down", "inflate chunks")
+    keep = ("start-up", "time in the scoring loop", "finalise", "wind-down", "inflate chunks", "reader closed", "CPU time")
     print(json.dumps({"groups": args.groups, "platform": args.platform, "devices": args.devices, "bam_bytes": size, "wall_s": round(wall, 3),
                       "groups_per_s": round(args.groups / wall, 1), "GB_bam_per_s": round(size / wall / 1e9, 4),
                       "cpu_oracle_groups_per_s": round(ncheck / cpu, 1) if cpu else None, "cpu_threads": args.threads, "cli_threads": cli_threads,
-                      "out_log_identical_to_oracle": same, "checked_groups": ncheck, "generate_s": round(t_gen, 1), "bam_write_s": round(t_write, 1),
+                      "outside_main": outside, "out_log_identical_to_oracle": same, "checked_groups": ncheck, "generate_s": round(t_gen, 1), "bam_write_s": round(t_write, 1),
                       "stderr_tail": [l for l in p.stderr.strip().splitlines() if any(k in l for k in keep)]}, indent=0))
     if not args.keep:
         shutil.rmtree(d, ignore_errors=True)
