@@ -478,3 +478,30 @@ def test_readers_closed_early_and_side_by_side(built, tmp_path):
     for t in ths:
         t.join()
     assert all(x == want for x in got)
+
+
+def test_pages_dropped_before_close(built, tmp_path):
+    """spx_bam_drop_pages (what the command line calls before it exits without closing): the reader's pages go back to the
+    kernel on its pool; the reader can still be closed afterwards, also in the middle of a file with batches handed out"""
+    L = api.lib()
+    _declare_opts(L)
+    L.spx_bam_drop_pages.argtypes = [C.c_void_p]
+    L.spx_bam_drop_pages.restype = None
+    g = small_genome(synth.HIFI, read_len=2500, max_secondaries=2, n_paralogs=2)
+    chunks = [g.reads(i * 100, 100) for i in range(3)]
+    bam = str(tmp_path / "d.bam")
+    synth.write_bam(bam, [c.batch for c in chunks], g.ref, threads=2)
+    for take in (1, 12):  # in the middle / at the end of the file
+        o = BamOptions()
+        L.spx_bam_default_options(C.byref(o))
+        o.threads, o.chunk_bytes, o.batch_groups, o.ahead_batches = 3, 65536, 25, 2
+        rd = C.c_void_p()
+        assert L.spx_bam_open_opts(bam.encode(), C.byref(o), C.byref(rd)) == 0
+        n = 0
+        for _ in range(take):
+            bp = C.POINTER(records.SpxBatch)()
+            n += L.spx_bam_next_batch(rd, 25, C.byref(bp))
+        assert n == 25 * take
+        L.spx_bam_drop_pages(rd)
+        L.spx_bam_drop_pages(None)
+        L.spx_bam_close(rd)
