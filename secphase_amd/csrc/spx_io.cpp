@@ -969,6 +969,7 @@ extern "C" int spx_bam_open_opts(const char *path, const spx_bam_options *opt, s
     const size_t slot = (2 * r->head + al - 1) & ~(al - 1);
     r->max_inflight = std::max(3, r->threads / 8 + 2);
     r->host_window = std::max(2, r->threads / 16 + 2);
+    if (const char *e = getenv("SPX_BAM_HOST_WINDOW")) r->host_window = std::max(1, atoi(e)); /* (experiments) */
     const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
     const size_t phys = (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz : ((size_t)64 << 30);
     size_t cap_bytes = o.max_bytes > 0 ? (size_t)o.max_bytes : phys / 4;

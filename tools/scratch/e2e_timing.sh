@@ -14,8 +14,13 @@ while read -r line; do
   [ -z "$line" ] && continue
   run "$line" "${line%%|*}" "${line#*|}"
 done <<CFG
-A=1|-@ 16
-A=1|-@ 16
-SPX_TIDY_EXIT=1|-@ 16
+A=1|-@ 16 --gpuInflate 8
+A=1|-@ 16 --gpuInflate 12
+A=1|-@ 16 --gpuInflate 16
+SPX_BAM_HOST_WINDOW=2|-@ 16 --gpuInflate 12
+A=1|-@ 16 --gpuInflate 8
+A=1|-@ 16 --gpuInflate 12
+A=1|-@ 16 --gpuInflate 16
+SPX_BAM_HOST_WINDOW=2|-@ 16 --gpuInflate 12
 CFG
 rm -rf $D
