@@ -773,7 +773,8 @@ void walker_main(Reader *r)
             if (r->cur) { chunk_unref_locked(r, r->cur); r->cur = nullptr; }
             while (!r->inflight.empty()) { /* dispatched but not walked (error / closing): wait for the tasks, then drop */
                 Chunk *c = r->inflight.front();
-                r->cv_chunk.wait(lk, [&] { return c->pending.load() == 0; });
+                r->cv_chunk.wait(lk, [&] { return c->pending.load() == 0 || r->closing; });
+                if (r->closing) return; /* (nobody claims chunks any more; spx_bam_close drops what is left once the pool has stopped) */
                 r->inflight.pop_front();
                 chunk_unref_locked(r, c);
             }
