@@ -12,7 +12,9 @@
  *
  * The decoder is parameterised by an environment E that provides
  *     E::in32(k)              compressed dword k of the block (little endian; reads past the end return 0)
- *     E::put_literal(b)       one output byte
+ *     E::put_literal(b)       one output byte (checked)
+ *     E::lit_full(), E::lit_push(b), E::lit_commit()   the same in three steps for the literal loop: no room for another
+ *                             literal right now / append one (unchecked) / make room (false: the output is full)
  *     E::copy_match(len,dist) LZ77 copy at the current output position
  *     E::out_pos()            bytes produced so far
  *     E::tables()             scratch for the decode tables (LDS on the device)
@@ -284,9 +286,16 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                 for (;;) {
                     b.refill();
                     e = env.uniform_u32(T.lit[b.peek(kLitRoot)]);
-                    if (e & 0x100u) break; /* a length / end-of-block code, or no root code at all */
+                    /* a length / end-of-block code, or no root code at all -- or no room for one more literal (the device
+                     * keeps up to 64 in a register; committing them, flushing and the overrun check stay OUT of this loop:
+                     * inlined into it they cost a dozen scalar moves per literal) */
+                    if ((e & 0x100u) || env.lit_full()) break;
                     b.drop((int)(e >> 9));
-                    if (!env.put_literal((uint8_t)e)) return -2; /* false: more bytes than the block may hold */
+                    env.lit_push((uint8_t)e);
+                }
+                if (!(e & 0x100u)) {
+                    if (!env.lit_commit()) return -2; /* false: more bytes than the block may hold */
+                    continue;
                 }
                 int sym;
                 if (e != kNoEntry) {
@@ -386,6 +395,9 @@ struct HostEnv {
     }
     uint32_t cap = 0xffffffffu; /* bytes out[] can take */
     bool put_literal(uint8_t c) { if (pos >= cap) return false; out[pos++] = c; return true; }
+    bool lit_full() const { return pos >= cap; }
+    void lit_push(uint8_t c) { out[pos++] = c; }
+    bool lit_commit() const { return pos < cap; }
     void copy_match(int len, int dist) { for (int k = 0; k < len; ++k, ++pos) out[pos] = out[pos - dist]; }
     uint32_t out_pos() const { return pos; }
     Tables &tables() { return T; }

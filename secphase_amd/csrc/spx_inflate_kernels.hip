@@ -68,13 +68,15 @@ struct DevEnv {
     __device__ __forceinline__ int lanes() const { return 64; }
     __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
     __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-    __device__ __forceinline__ uint32_t out_pos() const { return pos; }
+    /* pos = bytes COMMITTED to the ring; the literals in litv come on top */
+    __device__ __forceinline__ uint32_t out_pos() const { return pos + npend; }
 
     /* pending literals (one per lane) -> ring: ONE LDS store for up to 64 bytes */
     __device__ __forceinline__ void commit()
     {
         if (npend) {
-            if ((uint32_t)lane_ < npend) ring[(pos - npend + (uint32_t)lane_) & (kRing - 1)] = (uint8_t)litv;
+            if ((uint32_t)lane_ < npend) ring[(pos + (uint32_t)lane_) & (kRing - 1)] = (uint8_t)litv;
+            pos += npend;
             npend = 0;
         }
     }
@@ -93,17 +95,25 @@ struct DevEnv {
         flushed = pos;
         __threadfence();
     }
-    __device__ __forceinline__ bool put_literal(uint8_t c)
+    /* the literal loop of the decoder: append (the decoder is wave-uniform: the byte is an SGPR value, v_writelane drops
+     * it into lane npend) ... */
+    __device__ __forceinline__ bool lit_full() const { return npend == 64; }
+    __device__ __forceinline__ void lit_push(uint8_t c)
     {
-        /* the decoder is wave-uniform: the byte is an SGPR value, v_writelane drops it into lane npend */
         litv = writelane(litv, (int)c, (int)npend);
         ++npend;
-        ++pos;
-        if (npend == 64) { /* 64 literals are pending: into the ring, and on to HBM when enough has gathered */
-            commit();
-            if (pos - flushed >= (uint32_t)kFlush) flush();
-            return pos <= limit; /* false = the block overruns */
-        }
+    }
+    /* ... and make room: 64 literals into the ring, on to HBM when enough has gathered; false = the block overruns */
+    __device__ __forceinline__ bool lit_commit()
+    {
+        commit();
+        if (pos - flushed >= (uint32_t)kFlush) flush();
+        return pos <= limit;
+    }
+    __device__ __forceinline__ bool put_literal(uint8_t c) /* (outside the literal loop: stored blocks, codes beyond the root table) */
+    {
+        if (npend == 64 && !lit_commit()) return false; /* the loop may leave the register full */
+        lit_push(c);
         return true;
     }
     __device__ __forceinline__ void copy_match(int len, int dist)
