@@ -338,8 +338,12 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], DS &D,
             if (t > 0) carryD = shfl_down1<G>(carryD);
         }
         if (any_first) { /* wave-uniform: some problem of the wave is on its row 1 */
+            /* the reference MULTIPLIES the D values of row 1 by y = 0 (probaln.c: `(e*m[6] + m[8]*bi[v01+2]) * y`): where the
+             * backward values have overflowed -- unrelated sequences over a thousand rows -- that is inf * 0 = NaN, not 0,
+             * and the NaN reaches M(1,k) and the MAP state of row 1 (found by the GPU fuzz: state 0 here, 1 there) */
+            const double y = first_row ? 0.0 : 1.0;
 #pragma unroll
-            for (int c = 0; c < C; ++c) D.set(c, first_row ? 0.0 : D.get(c));
+            for (int c = 0; c < C; ++c) D.set(c, D.get(c) * y);
         }
     }
     /* parallel phase B: M += m2*D(i,k+1); scale */

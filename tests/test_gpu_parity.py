@@ -93,6 +93,28 @@ def test_probaln_ambiguous_bases(ctx):
     _check(ctx, probs, [40] * len(probs), pars)
 
 
+def test_probaln_overflowed_backward_values(ctx):
+    """found by tools/fuzz.py gpu (seed 777): unrelated sequences, 1 294 x 1 281, band 268.  The backward values overflow
+    to inf; the reference multiplies the D values of row 1 by y = 0 (inf * 0 = NaN, which reaches M(1,k) and the MAP state
+    of row 1) where the kernel used to SELECT 0.  States, qualities, 1/s and every z = f*b must equal the oracle's, NaNs
+    included."""
+    import json
+    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "probaln_overflow_case.json")))
+    ref = np.array([int(x) for x in c["ref"]], np.uint8)
+    q = np.array([int(x) for x in c["qry"]], np.uint8)
+    par = (c["d"], c["e"], c["bw"])
+    st, qq, _ = ctx.probaln_batch([ref], [q], [c["set_q"]], [par])
+    _, est, eq = oracle_probaln(ref, q, c["set_q"], *par)
+    assert np.array_equal(st[0], est) and np.array_equal(qq[0], eq)
+    sc, zM, zI = ctx.probaln_posteriors([ref], [q], [c["set_q"]], [par], which=0)
+    s, oM, oI = orc.probaln_posteriors(ref, q, c["set_q"], *par)
+    L = len(q)
+    assert np.isnan(np.asarray(oM[0])).any()      # the case still exercises what it was kept for
+    with np.errstate(divide="ignore", invalid="ignore"):
+        assert np.array_equal(sc[1:L], 1.0 / s[1:L], equal_nan=True)
+    assert np.array_equal(zM, oM, equal_nan=True) and np.array_equal(zI, oI, equal_nan=True)
+
+
 def test_probaln_wide_bands(ctx):
     rng = np.random.default_rng(11)
     probs, pars = [], []
