@@ -156,9 +156,12 @@ def also_leg(platform, steps, warmup):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
            "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "1"]
-    # (mixed: small batches whose preparations overlap -- one more in flight; ONT: 16 384 groups keep ~70 GB of saved rows per
-    # list, three of them in flight beside what the parent process still holds do not fit: 8 192 groups per step)
-    cmd += ["--distinct", "5", "--depth", "4"] if platform == "mixed" else ["--distinct", "4", "--depth", "3", "--groups-per-step", "8192"]
+    # (mixed: small batches whose preparations overlap -- one more in flight; ONT: the preset of BASELINE config 3, 16 384 groups
+    # per step with two lists of ~70 GB in flight -- the parent has handed its device memory back (spx_trim) before this runs;
+    # SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
+    ont_gps = os.environ.get("SPX_BENCH_ALSO_ONT_GPS")
+    cmd += ["--distinct", "5", "--depth", "4"] if platform == "mixed" else \
+        (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "3"])
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
