@@ -1138,11 +1138,26 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st)
 {
     if (B->n_order <= 0 && B->n_order_bwd <= 0) return hipSuccess;
+    /* A class' launch may go out in several pieces (SPX_DP_PIECES, default 1): the waves of a DP kernel fill every SIMD's
+     * register file and the kernels of the NEXT list's preparation, queued on other streams, get no slot until the whole
+     * launch has drained; between two pieces of a stream the chip drains for a moment and they get in. */
+    static const int n_pieces = [] { const char *e = getenv("SPX_DP_PIECES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    auto pieces = [&](int blocks, int ppw, bool bwd, auto &&launch) {
+        if (blocks <= 0) return;
+        int per = (blocks + n_pieces - 1) / n_pieces;
+        if (per < 2048) per = blocks < 2048 ? blocks : 2048; /* (a piece should still fill the chip a few times) */
+        for (int b0 = 0; b0 < blocks; b0 += per) {
+            spx_dev_batch P = *B;
+            if (bwd) { P.order_bwd += (int64_t)b0 * ppw; P.n_order_bwd -= b0 * ppw; }
+            else { P.order += (int64_t)b0 * ppw; P.n_order -= b0 * ppw; }
+            launch(P, blocks - b0 < per ? blocks - b0 : per);
+        }
+    };
 #define SPX_LAUNCH(G_, C_, W0_, LDS_)                                                                                  \
     {                                                                                                                  \
         int ppw = 64 / G_, blocks = (B->n_order + ppw - 1) / ppw, blocks_b = (B->n_order_bwd + ppw - 1) / ppw;         \
-        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<G_, C_, W0_, LDS_>), dim3(blocks), dim3(64), 0, st, *B);    \
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_, LDS_>), dim3(blocks_b), dim3(64), 0, st, *B);  \
+        if (phase != 1) pieces(blocks, ppw, false, [&](const spx_dev_batch &P, int nb) { hipLaunchKernelGGL((baq_fwd_kernel<G_, C_, W0_, LDS_>), dim3(nb), dim3(64), 0, st, P); }); \
+        if (phase != 0) pieces(blocks_b, ppw, true, [&](const spx_dev_batch &P, int nb) { hipLaunchKernelGGL((baq_bwd_kernel<G_, C_, W0_, LDS_>), dim3(nb), dim3(64), 0, st, P); }); \
     }                                                                                                                  \
     break;
     /* exact-width classes (the HiFi preset: bw = 20 + |R-L|): forward with one lane per problem (no half-idle serial
@@ -1150,9 +1165,9 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
      * wanted rows cost more than the serial passes do */
 #define SPX_LAUNCH_EXACT(W_, CB_)                                                                                      \
     {                                                                                                                  \
-        if (phase != 1) hipLaunchKernelGGL((baq_fwd1_kernel<W_>), dim3((B->n_order + 63) / 64), dim3(64), 0, st, *B);  \
+        if (phase != 1) pieces((B->n_order + 63) / 64, 64, false, [&](const spx_dev_batch &P, int nb) { hipLaunchKernelGGL((baq_fwd1_kernel<W_>), dim3(nb), dim3(64), 0, st, P); }); \
         if (phase != 0)                                                                                                \
-            hipLaunchKernelGGL((baq_bwd_kernel<2, CB_, W_, false>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, *B); \
+            pieces((B->n_order_bwd + 31) / 32, 32, true, [&](const spx_dev_batch &P, int nb) { hipLaunchKernelGGL((baq_bwd_kernel<2, CB_, W_, false>), dim3(nb), dim3(64), 0, st, P); }); \
     }                                                                                                                  \
     break;
     switch (cls) { /* keep in step with spx_prep.cpp kClass* */
@@ -1168,8 +1183,8 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
     case 7: /* forward (8,16); backward (4,32): half the serial passes, and unlike the forward kernel (134 spilled
              * VGPRs at (4,32), 99 with the D row in LDS -- both slower) it fits the register file */
     {
-        if (phase != 1) hipLaunchKernelGGL((baq_fwd_kernel<8, 16, 0, false>), dim3((B->n_order + 7) / 8), dim3(64), 0, st, *B);
-        if (phase != 0) hipLaunchKernelGGL((baq_bwd_kernel<4, 32, 0, false>), dim3((B->n_order_bwd + 15) / 16), dim3(64), 0, st, *B);
+        if (phase != 1) pieces((B->n_order + 7) / 8, 8, false, [&](const spx_dev_batch &P, int nb) { hipLaunchKernelGGL((baq_fwd_kernel<8, 16, 0, false>), dim3(nb), dim3(64), 0, st, P); });
+        if (phase != 0) pieces((B->n_order_bwd + 15) / 16, 16, true, [&](const spx_dev_batch &P, int nb) { hipLaunchKernelGGL((baq_bwd_kernel<4, 32, 0, false>), dim3(nb), dim3(64), 0, st, P); });
     }
     break;
     case 8: SPX_LAUNCH(16, 16, 0, false)
