@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/scratch/h2d_probe tools/scratch/h2d_probe.hip ; run: ./tools/scratch/h2d_probe MODE
 // H2D copies from a ring of pinned chunks beside a kernel that fills the chip: which variations make the runtime fall back
 // from the DMA engines to its copy kernel (18 GB/s beside compute instead of 52)?
 // modes: 0 pure H2D stream, 1 a tiny kernel per 16 copies on the copy stream, 2 a memset per 16 copies, 3 waits on copy events,
