@@ -1135,7 +1135,12 @@ static void drop_pages(Reader *r)
     struct Piece { uint8_t *p; size_t n; };
     std::vector<Piece> pieces;
     const size_t step = (size_t)64 << 20;
-    for (int s = 0; s < r->arena.n_fresh; ++s) pieces.push_back({r->arena.slot_ptr(s), r->arena.slot_bytes});
+    int n_slots;
+    {
+        std::lock_guard<std::mutex> lk(r->mu); /* (the walker may be taking a fresh slot right now) */
+        n_slots = r->arena.n_fresh;
+    }
+    for (int s = 0; s < n_slots; ++s) pieces.push_back({r->arena.slot_ptr(s), r->arena.slot_bytes});
     if (r->map && !r->map_is_malloc)
         for (size_t a = 0; a < r->fsize; a += step) pieces.push_back({(uint8_t *)r->map + a, std::min(step, r->fsize - a)});
     r->pool->parallel_for((int64_t)pieces.size(), 1, [&](int64_t k0, int64_t k1) {

@@ -670,7 +670,9 @@ SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t 
         const Op o = ops[t];
         while (col >= 0 && col < ncol) {
             if (!(o.rds <= p && p <= o.rde)) break;
-            if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) keep[col] = 0; /* (every alignment writes the same 0) */
+            /* (every alignment writes the same 0; a relaxed atomic store, so that the host plan's threads -- one per alignment,
+             * like the lanes of the kernel -- do it without a data race: ThreadSanitizer run of the CPU suite) */
+            if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) __atomic_store_n(&keep[col], (uint8_t)0, __ATOMIC_RELAXED);
             if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
                 mk[(int64_t)col * n + i].ref_pos = rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
             col += step;
