@@ -93,7 +93,7 @@ struct spx_ctx {
      * the main class' forward and backward kernels): spx_collect averages over the launches since the previous collect */
     static const int SPX_EV_RING = 64;
     hipEvent_t evr[SPX_EV_RING][6] = {};
-    int64_t n_launch = 0;
+    std::atomic<int64_t> n_launch{0}; /* written under launch_mu, read by collects of other lists (ThreadSanitizer run on the GPU box) */
     /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
      * (or in front of) the bulk class */
     /* (three side streams, the classes spread over them by band cells: with the main, the preparation and the copy
@@ -1344,8 +1344,9 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (w->staged && !w->prepared) return fail(SPX_EINVAL, "work list has been staged but not prepared");
     std::lock_guard<std::mutex> lk(c->launch_mu);
     if (w->ev_ready) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_ready, 0)); /* the list is built on the preparation stream */
-    hipEvent_t *ev = c->evr[c->n_launch % spx_ctx::SPX_EV_RING];
-    w->launch_ids.push_back(c->n_launch);
+    const int64_t launch_id = c->n_launch.load();
+    hipEvent_t *ev = c->evr[launch_id % spx_ctx::SPX_EV_RING];
+    w->launch_ids.push_back(launch_id);
     if (w->launch_ids.size() > (size_t)spx_ctx::SPX_EV_RING) w->launch_ids.erase(w->launch_ids.begin());
     c->n_launch++;
     HIPCHK(hipEventRecord(ev[0], c->stream));
@@ -1461,7 +1462,7 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         int n = 0;
         bool ok = true;
         for (int64_t l : w->launch_ids) {
-            if (c->n_launch - l > spx_ctx::SPX_EV_RING) continue; /* slot reused since */
+            if (c->n_launch.load() - l > spx_ctx::SPX_EV_RING) continue; /* slot reused since */
             hipEvent_t *ev = c->evr[l % spx_ctx::SPX_EV_RING];
             float ms = 0;
             ok = ok && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
@@ -1900,7 +1901,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(SPX_EHIP, "kernel execution failed");
     if (!rc) {
         float ms = 0;
-        hipEvent_t *ev = c->evr[(c->n_launch - 1) % spx_ctx::SPX_EV_RING];
+        hipEvent_t *ev = c->evr[(c->n_launch.load() - 1) % spx_ctx::SPX_EV_RING];
         (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
         if (kernel_ms) *kernel_ms = ms;
         const size_t nr = hb.rows.size();
