@@ -1,5 +1,11 @@
 #!/bin/bash
-# the command line built with ThreadSanitizer (build/tsan/: secphase_tsan + its libspx.so) on a small synthetic BAM
+# the command line built with ThreadSanitizer (build/tsan/: secphase_tsan + its libspx.so) on a small synthetic BAM.
+# Build first, in the CPU container (build/ is git-ignored but travels to the GPU box with the snapshot):
+#   tools/sanitize_cpu.sh tsan                      # leaves /tmp/spx_tsan/secphase_amd/{libspx.so,csrc}
+#   mkdir -p build/tsan && cp /tmp/spx_tsan/secphase_amd/libspx.so build/tsan/
+#   (cd /tmp/spx_tsan/secphase_amd/csrc && hipcc -O1 -g -std=c++17 -fsanitize=thread -o $OLDPWD/build/tsan/secphase_tsan \
+#        secphase_main.cpp -L.. -lspx -lpthread -Wl,-rpath,'$ORIGIN')
+# then:  gpurun -- 'bash tools/scratch/cli_tsan.sh 8192'
 python tools/e2e_cli.py --groups ${1:-8192} --batch 2048 --check-groups 0 --keep > /tmp/e2e_first.json 2>/tmp/e2e_first.err || { tail -5 /tmp/e2e_first.err; exit 1; }
 D=$(ls -d /dev/shm/spx_e2e_* | head -1)
 rm -rf $D/out $D/out2
