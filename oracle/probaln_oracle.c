@@ -127,9 +127,15 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
     bw2 = bw * 2 + 1;
     i_dim = bw2 < l_ref ? (size_t)bw2 * 3 + 6 : (size_t)l_ref * 3 + 6;
 
+    /* The reference reads bi1[v11] for k = l_ref (multiplied by 0: probaln.c, `e = (k >= l_ref? 0 : ...) * bi1[v11]`); when the
+     * band covers the whole reference (i_dim = 3*l_ref + 6) that slot is the first one behind the row, and for row l_query the
+     * first double behind the matrix: a heap over-read in the reference, harmless there as long as the bytes behind happen to
+     * be a finite double (0 * x = 0).  Here the matrices get a zeroed tail, so that the oracle's result does not depend on the
+     * allocator (found when the CPU fuzz ran under ThreadSanitizer's allocator: NaN behind the block, every state -1). */
+    const size_t tail = 8;
     const int reuse = g_reuse_scratch;
     if (reuse) {
-        size_t nm = (size_t)(l_query + 1) * i_dim;
+        size_t nm = (size_t)(l_query + 1) * i_dim + tail;
         double *blk = scratch_zeroed(nm * (is_backward ? 2 : 1) + (size_t)l_query + 2 + ((size_t)l_query + 1) / 2 + 1);
         if (!blk) return INT_MIN;
         f = blk;
@@ -137,8 +143,8 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
         s = blk + nm * (is_backward ? 2 : 1);
         qual = (float *)(s + l_query + 2);
     } else {
-        f = calloc((size_t)(l_query + 1) * i_dim, sizeof(double));
-        if (is_backward) b = calloc((size_t)(l_query + 1) * i_dim, sizeof(double));
+        f = calloc((size_t)(l_query + 1) * i_dim + tail, sizeof(double));
+        if (is_backward) b = calloc((size_t)(l_query + 1) * i_dim + tail, sizeof(double));
         s = calloc((size_t)l_query + 2, sizeof(double));
         qual = calloc((size_t)l_query, sizeof(float));
         if (!f || (is_backward && !b) || !s || !qual) {
