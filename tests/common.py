@@ -226,5 +226,5 @@ def walk(batch, a):
     n = orc.lib().orc_walk_cigar(batch, a, C.byref(ops))
     assert n > 0, n
     out = [{f: getattr(ops[i], f) for f, _ in orc.Op._fields_} for i in range(n)]
-    C.CDLL("libc.so.6").free(ops)
+    C.CDLL(None).free(ops)
     return out
