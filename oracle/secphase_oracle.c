@@ -446,7 +446,7 @@ static void sort_and_fill(mvec *mk, const waln *al, int n_aln)
     }
     if (n0 > 0)
         for (j = idx; j < n_aln; ++j) mpush(mk, make_match(al, j, mk->v[n0 - 1].read_pos_f));
-    qsort(mk->v, mk->n, sizeof(orc_marker), marker_cmp);
+    if (mk->n > 1) qsort(mk->v, mk->n, sizeof(orc_marker), marker_cmp); /* (no markers: v is NULL, which qsort must not be given) */
 }
 
 /* filter_ins_markers (ptMarker.c:156-206) */
