@@ -1,6 +1,7 @@
 """GPU fuzz of the BGZF inflate kernel against zlib: random payloads (literal runs, matches at every distance up to 32 KB,
 overlapping matches, stored / fixed / dynamic blocks, all levels and strategies, sizes around the ring and flush boundaries),
-byte-identical output and status 0 for every block.  Usage: python tools/fuzz_inflate.py [seed] [seconds]"""
+byte-identical output and status 0 for every block.  Usage: python tools/fuzz_inflate.py [seed] [seconds] [host]
+("host": the same decoder core compiled for the CPU, spx_inflate_core_host -- no GPU needed; sanitizer runs.)"""
 import ctypes as C
 import os
 import struct
@@ -42,8 +43,29 @@ def payload(rng):
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 120
+    host = len(sys.argv) > 3 and sys.argv[3] == "host"
     rng = np.random.default_rng(seed)
     L = api.lib()
+    if host:
+        L.spx_inflate_core_host.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+        t0, nblocks, nbytes = time.time(), 0, 0
+        while time.time() - t0 < seconds:
+            data = payload(rng)
+            level = int(rng.choice([0, 1, 3, 6, 9]))
+            strat = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]))
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, int(rng.choice([1, 8, 9])), strat)
+            comp = co.compress(data) + co.flush()
+            out = C.create_string_buffer(max(len(data), 1))
+            rc = L.spx_inflate_core_host(comp, len(comp), out, len(data))
+            if rc != 0 or out.raw[:len(data)] != data:
+                sys.exit(f"inflate fuzz (host): seed {seed}: rc {rc}, {len(data)} bytes, level {level}, strategy {strat}")
+            # a damaged copy must end with an error or with different bytes, never with a crash
+            if len(comp) > 8 and rng.random() < 0.3:
+                bad = bytearray(comp); bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+                L.spx_inflate_core_host(bytes(bad), len(bad), out, len(data))
+            nblocks += 1; nbytes += len(data)
+        print(f"inflate fuzz (host core): seed {seed}, {nblocks} streams, {nbytes / 1e6:.0f} MB, no mismatch, {time.time() - t0:.0f} s")
+        return
     L.spx_inflate_bgzf_device.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_int64,
                                           C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.spx_inflate_bgzf_device.restype = C.c_int64
