@@ -1,0 +1,108 @@
+"""CPU fuzz of the BAM reader on DAMAGED input (it parses untrusted files): the uncompressed bytes of a small valid BAM are
+mutated (bit flips, overwritten length fields, truncation, inserted / deleted bytes) and re-packed into valid BGZF blocks
+with correct CRCs, so that the damage reaches the record chain, the field / tag / CIGAR parsers and the index builder.  Every
+file must end in batches or in an error -- never in a crash, a hang or (under AddressSanitizer, tools/sanitize_cpu.sh) a
+report.  Usage: python tools/fuzz_reader.py [seed] [seconds]"""
+import ctypes as C
+import gzip
+import os
+import struct
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bamio import write_bgzf  # noqa: E402
+from common import small_genome  # noqa: E402
+from secphase_amd import api, records, synth  # noqa: E402
+
+
+class BamOptions(C.Structure):
+    _fields_ = [("threads", C.c_int32), ("batch_groups", C.c_int32), ("ahead_batches", C.c_int32), ("flags", C.c_int32),
+                ("chunk_bytes", C.c_int64), ("max_bytes", C.c_int64), ("start_voffset", C.c_int64), ("end_voffset", C.c_int64),
+                ("keep_batches", C.c_int32), ("reserved", C.c_int32)]
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+    rng = np.random.default_rng(seed)
+    L = api.lib()
+    vp = C.c_void_p
+    L.spx_bam_open_opts.argtypes = [C.c_char_p, C.POINTER(BamOptions), C.POINTER(vp)]
+    L.spx_bam_default_options.argtypes = [C.POINTER(BamOptions)]
+    L.spx_bam_next_batch.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(records.SpxBatch))]
+    L.spx_bam_close.argtypes = [vp]
+    L.spx_bam_close.restype = None
+    L.spx_bam_index_build.argtypes = [C.c_char_p, C.c_int, C.c_int32, C.POINTER(C.c_int64), C.c_int64]
+    L.spx_bam_index_build.restype = C.c_int64
+    g = small_genome(synth.HIFI, read_len=1500, max_secondaries=3, n_paralogs=3, hardclip_frac=0.3, softclip_frac=0.3)
+    d = tempfile.mkdtemp(prefix="spx_fuzz_reader_")
+    good = os.path.join(d, "good.bam")
+    reads = g.reads(0, 60)  # (kept alive: the writer reads its memory)
+    synth.write_bam(good, [reads.batch], g.ref, threads=2)
+    raw = gzip.open(good).read()
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    n_ref = struct.unpack_from("<i", raw, 8 + l_text)[0]
+    at = 12 + l_text
+    for _ in range(n_ref):
+        at += 8 + struct.unpack_from("<i", raw, at)[0]
+    first_rec = at
+    t0, n, outcomes = time.time(), 0, {"records": 0, "error": 0}
+    bad = os.path.join(d, "bad.bam")
+    while time.time() - t0 < seconds:
+        b = bytearray(raw)
+        kind = rng.random()
+        for _ in range(int(rng.integers(1, 6))):
+            if len(b) < 8:
+                break
+            pos = int(rng.integers(0, len(b))) if rng.random() < 0.3 or first_rec >= len(b) else int(rng.integers(first_rec, len(b)))
+            if kind < 0.4:
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind < 0.6:  # a plausible place of a length field: overwrite 4 bytes
+                struct.pack_into("<i", b, min(pos, len(b) - 4), int(rng.choice([-1, 0, 1, 31, 32, 255, 65535, 65536, 2 ** 31 - 1, -2 ** 31, int(rng.integers(-10 ** 6, 10 ** 6))])))
+            elif kind < 0.75:
+                del b[pos:pos + int(rng.integers(1, 64))]
+            elif kind < 0.9:
+                b[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8))
+            else:
+                del b[pos:]
+        write_bgzf(bad, bytes(b), block=int(rng.choice([200, 4096, 60000])))
+        o = BamOptions()
+        L.spx_bam_default_options(C.byref(o))
+        o.threads, o.chunk_bytes, o.batch_groups, o.ahead_batches = 3, int(rng.choice([65536, 1 << 20])), int(rng.choice([0, 7])), 2
+        rd = vp()
+        if L.spx_bam_open_opts(bad.encode(), C.byref(o), C.byref(rd)) != 0:
+            outcomes["error"] += 1
+        else:
+            ok = True
+            for _ in range(200):
+                bp = C.POINTER(records.SpxBatch)()
+                k = L.spx_bam_next_batch(rd, 7, C.byref(bp))
+                if k <= 0:
+                    ok = k == 0
+                    break
+                bt = bp.contents  # touch what a consumer touches
+                for a in range(bt.n_alns):
+                    lq = bt.l_qseq[a]
+                    if lq > 0:
+                        _ = bt.qual[bt.qual_off[a] + lq - 1] + bt.seq4[bt.seq_off[a] + (lq - 1) // 2]
+                    if bt.cs_off[a] >= 0:
+                        C.string_at(bt.cs + bt.cs_off[a])
+                    for c_ in range(bt.n_cigar[a]):
+                        _ = bt.cigar[bt.cigar_off[a] + c_]
+            outcomes["records" if ok else "error"] += 1
+            L.spx_bam_close(rd)
+        if rng.random() < 0.1:
+            off = (C.c_int64 * 64)()
+            L.spx_bam_index_build(bad.encode(), 2, 5, off, 64)
+        n += 1
+    print(f"reader fuzz: seed {seed}, {n} damaged files ({outcomes['records']} read to the end, {outcomes['error']} ended in an error), no crash, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
