@@ -2,7 +2,9 @@
 mutated (bit flips, overwritten length fields, truncation, inserted / deleted bytes) and re-packed into valid BGZF blocks
 with correct CRCs, so that the damage reaches the record chain, the field / tag / CIGAR parsers and the index builder.  Every
 file must end in batches or in an error -- never in a crash, a hang or (under AddressSanitizer, tools/sanitize_cpu.sh) a
-report.  Usage: python tools/fuzz_reader.py [seed] [seconds]"""
+report.  Every batch the reader does hand out goes through spx_plan_create as well: the host plan runs the SAME source
+(spx_logic.h) as the preparation kernels, so a walk that leaves its arrays on damaged CIGAR / cs / MD content shows up here, on
+the CPU, under the sanitizer -- instead of as a GPU fault.  Usage: python tools/fuzz_reader.py [seed] [seconds]"""
 import ctypes as C
 import gzip
 import os
@@ -38,6 +40,7 @@ def main():
     L.spx_bam_next_batch.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(records.SpxBatch))]
     L.spx_bam_close.argtypes = [vp]
     L.spx_bam_close.restype = None
+    L.spx_bam_bind_reference.argtypes = [vp, C.POINTER(records.SpxRef)]
     L.spx_bam_index_build.argtypes = [C.c_char_p, C.c_int, C.c_int32, C.POINTER(C.c_int64), C.c_int64]
     L.spx_bam_index_build.restype = C.c_int64
     g = small_genome(synth.HIFI, read_len=1500, max_secondaries=3, n_paralogs=3, hardclip_frac=0.3, softclip_frac=0.3)
@@ -53,6 +56,8 @@ def main():
         at += 8 + struct.unpack_from("<i", raw, at)[0]
     first_rec = at
     t0, n, outcomes = time.time(), 0, {"records": 0, "error": 0}
+    plans, plan_err = 0, 0
+    presets = [records.preset("hifi"), records.preset("ont", bandwidth=50)]
     bad = os.path.join(d, "bad.bam")
     while time.time() - t0 < seconds:
         b = bytearray(raw)
@@ -79,6 +84,7 @@ def main():
         if L.spx_bam_open_opts(bad.encode(), C.byref(o), C.byref(rd)) != 0:
             outcomes["error"] += 1
         else:
+            L.spx_bam_bind_reference(rd, g.ref)
             ok = True
             for _ in range(200):
                 bp = C.POINTER(records.SpxBatch)()
@@ -95,13 +101,21 @@ def main():
                         C.string_at(bt.cs + bt.cs_off[a])
                     for c_ in range(bt.n_cigar[a]):
                         _ = bt.cigar[bt.cigar_off[a] + c_]
+                h = vp()
+                rc = L.spx_plan_create(g.ref, bp, C.byref(presets[n % 2]), C.byref(h))
+                plans += 1
+                if rc != 0:
+                    plan_err += 1
+                else:
+                    L.spx_plan_free(h)
             outcomes["records" if ok else "error"] += 1
             L.spx_bam_close(rd)
         if rng.random() < 0.1:
             off = (C.c_int64 * 64)()
             L.spx_bam_index_build(bad.encode(), 2, 5, off, 64)
         n += 1
-    print(f"reader fuzz: seed {seed}, {n} damaged files ({outcomes['records']} read to the end, {outcomes['error']} ended in an error), no crash, {time.time() - t0:.0f} s")
+    print(f"reader fuzz: seed {seed}, {n} damaged files ({outcomes['records']} read to the end, {outcomes['error']} ended in an error); "
+          f"{plans} batches through the host plan ({plan_err} rejected); no crash, {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
