@@ -155,7 +155,7 @@ def also_leg(platform, steps, warmup):
     this very script; its JSON line is returned (cut down to the figures the headline has)"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
-           "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "1"]
+           "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "3", "--cpu-threads", "32"]
     # (mixed: small batches whose preparations overlap -- one more in flight; ONT: the preset of BASELINE config 3, 16 384 groups
     # per step with two lists of ~70 GB in flight -- the parent has handed its device memory back (spx_trim) before this runs;
     # SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
@@ -178,6 +178,8 @@ def also_leg(platform, steps, warmup):
             "dp_cells_per_step": d["config"]["dp_cells_per_step"], "verified_groups_vs_oracle": d["config"]["verified_groups_vs_oracle"],
             "roofline": {"kernel": r.get("kernel"), "frac": r.get("frac"), "achieved": r.get("achieved"), "avg_launch_ms": r.get("avg_launch_ms"),
                          "traffic": r.get("traffic"), "phase": r.get("phase")},
+            "verified_timed_groups": d["config"].get("verified_timed_groups"),
+            "verified_own_relabel_list": (d["config"].get("verified_own_relabel_list") or {}).get("oracle_list_is_byte_prefix_of_this_runs_list"),
             "kernel_ms_per_step": d.get("kernel_ms_per_step"), "cpu_baseline": d.get("cpu_baseline"), "wall_s": round(dt, 1)}
 
 
@@ -206,7 +208,11 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the short ONT / mixed legs that follow the headline (N = 1, --platform hifi)")
     ap.add_argument("--no-build", action="store_true", help="never build (under a profiler: no child processes)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU baseline after one warm-up; the median is reported")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="thread count of the CPU baseline (0: all hardware threads and 32, the better one)")
     ap.add_argument("--verify", type=int, default=256, help="groups checked against the oracle before timing")
+    ap.add_argument("--keep-log", default="", metavar="PATH", help="tests: rank 0 copies the relabel list of the whole run (set-up, warm-up and timed "
+                    "steps: one rand() stream) to PATH, and every rank writes PATH.rank<r>.json = which generator ranges made up its batches "
+                    "and the order the batches were run in")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test rig for the N>1 code path on a box with fewer GPUs than ranks (ranks share devices, "
                          "records cross ranks through host memory); never a measurement")
@@ -286,6 +292,7 @@ def main():
     t0 = time.time()
     batches = []  # batches[i] = the record blocks (generator chunks) of distinct batch i
     batches.append(gen_parallel(genome, first, gps, args.gen_chunk, host_threads))
+    batch_ranges = {0: [(first, gps)]}  # generator ranges (first group, count) of every distinct batch of this rank
     if D > 1:
         # the distinct batches stay in HOST memory for the whole run (names for the relabel list, the from-host leg) and in
         # HBM: bound them by what this rank's share of the host can hold (8 ranks x 8 batches x 7.5 GB would not fit everywhere)
@@ -314,6 +321,7 @@ def main():
             D = int(dmin.item())
     for i in range(1, D):
         batches.append(gen_parallel(genome, first + i * gps, gps, args.gen_chunk, host_threads))
+        batch_ranges[i] = [(first + i * gps, gps)]
     # a staged list may be in flight once: run() keeps depth + 1 submissions in flight and rotates over the D lists
     if not args.kernel_only:
         args.depth = max(1, min(args.depth, D - 1))
@@ -344,14 +352,16 @@ def main():
             bounds, imb = shard.shard_by_cost(cost, world)
             imb_after.append(imb)
             lo, hi = bounds[rank], bounds[rank + 1]
-            pieces = []
+            pieces, ranges_i = [], []
             j = lo
             while j < hi:  # global index j = owner * gps + offset  ->  generator index owner * D * gps + i * gps + offset
                 owner, off = divmod(j, gps)
                 n_ = min(hi - j, gps - off)
                 pieces += gen_parallel(genome, owner * D * gps + i * gps + off, n_, args.gen_chunk, host_threads)
+                ranges_i.append((owner * D * gps + i * gps + off, n_))
                 j += n_
             new_batches.append(pieces)
+            batch_ranges[i] = ranges_i
         batches = new_batches
         shard_info = {"by": "cost (bases over the alignments of a group), secphase_amd/shard.py::shard_by_cost",
                       "imbalance_by_count": round(float(np.mean(imb_before)), 4), "imbalance_by_cost": round(float(np.mean(imb_after)), 4),
@@ -471,8 +481,12 @@ def main():
             if writer_err:
                 raise writer_err[0]
 
+    batch_sequence = []  # batch index of every step whose list went into log_path, in order
+
     def run(nsteps, offset, from_host):
         submitted = received = 0
+        if not from_host:
+            batch_sequence.extend((offset + k) % D for k in range(nsteps))
         while received < nsteps:
             while submitted < nsteps and pipe.pending() < args.depth + 1:
                 i = (offset + submitted) % D
@@ -488,6 +502,38 @@ def main():
                 staged[i].release()  # the list's HBM goes back to the context for the next step's list
             received += 1
 
+    def verify_last_step(i_last):
+        """whole generator chunks of batch i_last (the records that were staged and timed) through the oracle: n_aln, primary,
+        every score bit for bit; best_idx / relabel after replaying the chunk's draws from a fresh seed on both sides"""
+        from oracle import orc
+        chunks = ptrs[i_last]
+        bases, b_ = [], 0
+        for bp in chunks:
+            bases.append(b_)
+            b_ += bp.contents.n_groups
+        want = max(256, args.verify)
+        rng = np.random.default_rng(20241220 + i_last)
+        order = rng.permutation(len(chunks))
+        checked = 0
+        for ci in order:
+            if checked >= want:
+                break
+            bp, base = chunks[ci], bases[ci]
+            n = bp.contents.n_groups
+            _, res = orc.run_batch(bp, genome.ref, params, threads=min(ncpu, 64), seed=1, reuse_scratch=True)
+            mine = (api.GroupOut * n)()
+            C.memmove(mine, C.byref(outbuf, base * C.sizeof(api.GroupOut)), n * C.sizeof(api.GroupOut))
+            api._chk(L.spx_finalize(C.byref(params), 1, mine, n), "spx_finalize")
+            for g in range(n):
+                o, e = mine[g], res[g]
+                ok = (o.n_aln == e.n_aln and (e.n_aln <= 0 or (o.prim_idx == e.prim_idx and o.best_idx == e.best_idx and bool(o.relabel) == bool(e.relabel)))
+                      and all(o.score[a] == e.score[a] for a in range(max(e.n_aln, 0))))
+                if not ok:
+                    sys.exit(f"parity check failed on group {base + g} of the last timed step: GPU result differs from the oracle")
+            checked += n
+        return checked
+
+    verified_timed = 0
     host_leg = None
     host_leg_error = None
     if args.kernel_only:
@@ -505,6 +551,19 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         per_step_stats = [staged[(args.warmup + k) % D].stats() for k in range(min(args.steps, D))]
+        if args.keep_log:
+            import shutil
+            if rank == 0:
+                shutil.copyfile(log_path, args.keep_log)
+            with open(f"{args.keep_log}.rank{rank}.json", "w") as f_:
+                json.dump({"rank": rank, "world": world, "D": D, "gps": gps, "sequence": batch_sequence,
+                           "ranges": {str(k): v for k, v in batch_ranges.items() if k < D}}, f_)
+        # ---- the TIMED steps' own output against the oracle (rank 0; the oracle is the checker, never the thing measured):
+        # (a) scores / decision fields of whole generator chunks of the LAST timed step, straight from the buffer the step's
+        # results were collected into; (b) the relabel list this run wrote: the oracle's list of the run's first groups must be
+        # a byte prefix of it (one rand() stream in (step, rank, group) order, so rank 0's first groups come first at any N)
+        if rank == 0 and args.verify > 0:
+            verified_timed = verify_last_step((args.warmup + args.steps - 1) % D)
         if world == 1 and not args.no_host_leg:
             # the same steps fed from HOST memory: staging (host threads) + PCIe copy inside the timed region
             hs = max(2, min(args.steps, 8))
@@ -619,7 +678,7 @@ def main():
             # threads than that only add switching).
             best = None
             nrun = max(1, args.cpu_runs)
-            for cores in sorted({ncpu, min(ncpu, 32)}, reverse=True):
+            for cores in ([min(ncpu, args.cpu_threads)] if args.cpu_threads > 0 else sorted({ncpu, min(ncpu, 32)}, reverse=True)):
                 time_oracle(cores, True, log=oracle_log if world == 1 else None)  # warm-up; also writes the list the BAM leg is checked against
                 runs = sorted(time_oracle(cores, True) for _ in range(nrun))
                 v, dt, cps = runs[len(runs) // 2]
@@ -668,6 +727,22 @@ def main():
                     except Exception:  # noqa: BLE001
                         pass
                 cpu["bracket"] = br
+        own_log_check = None
+        if not args.kernel_only and args.verify > 0:
+            from oracle import orc
+            o_log, o_groups = (cpu.get("oracle_log"), cpu.get("oracle_groups")) if cpu else (None, 0)
+            if not o_log or not os.path.exists(o_log):
+                # (N > 1, or no CPU baseline asked for: the oracle on the first generator chunk of this rank's first batch)
+                o_log = os.path.join(tmpdir, "oracle_first_chunk.out.log")
+                first_chunk = ptrs[0][0]
+                orc.run_batch(first_chunk, genome.ref, params, threads=min(ncpu, 64), seed=1, reuse_scratch=True, log_path=o_log)
+                o_groups = int(first_chunk.contents.n_groups)
+            want_b = open(o_log, "rb").read()
+            got_b = open(log_path, "rb").read()
+            own_log_check = {"oracle_list_is_byte_prefix_of_this_runs_list": bool(len(want_b) > 0 and got_b[:len(want_b)] == want_b),
+                             "groups": int(o_groups), "oracle_list_bytes": len(want_b), "this_runs_list_bytes": len(got_b)}
+            if not own_log_check["oracle_list_is_byte_prefix_of_this_runs_list"]:
+                sys.exit("parity check failed: the oracle's relabel list of the first groups is not a byte prefix of the list this run wrote")
         line = {
             "metric": "reads/sec (primary+secondary groups scored)",
             "value": round(value, 2),
@@ -699,6 +774,10 @@ def main():
                                 f"rand() stream kept in global step), ONE RCCL gather of the relabel-list fragments to rank 0, which "
                                 f"appends them in rank order") if world > 1 else "single GPU",
                 "verified_groups_vs_oracle": verified,
+                "verified_timed_groups": verified_timed,
+                "verified_own_relabel_list": own_log_check,
+                "distinct_groups": (f"{D} distinct batches x {gps} groups per GPU in rotation (a steady-state figure: "
+                                    f"{(args.steps + args.warmup) * gps} group scorings over {D * gps} distinct groups per GPU)"),
                 "rank_imbalance_dp_cells": round(imbalance, 4),
                 "sharding": shard_info,
             },

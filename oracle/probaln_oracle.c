@@ -206,7 +206,12 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
         sum = 1. / sum;
         for (k = lo; k <= hi; ++k) fi[k] *= sum;
     }
-    { /* terminal */
+    { /* terminal.  GUARD VARIANTS (parity unpinned): this restatement skips a column when its slot lies outside the band,
+       * `u < 3 || u >= bw2*3+3` -- kprobaln's test, kept as far as we know by the htslib releases that shrank the row to
+       * i_dim = min(bw2, l_ref)*3+6.  The other reading, `u >= i_dim-3`, differs exactly when l_query <= bw and
+       * 2*bw+1 > l_ref (set_u's row offset is 0, u = 3*(k+1), i_dim-3 = 3*l_ref+3): it would drop column l_ref from this
+       * sum and from the backward start below.  secphase reaches that regime (--ont -b 50, blocks of <= 50 bases).  Only a
+       * real htslib 1.17 decides; tools/pin_htslib/make_problems.py carries 240 problems of that shape. */
         double sum = 0.;
         for (k = 1; k <= l_ref; ++k) {
             int u = slot3(bw, l_query, k);
@@ -232,7 +237,7 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
     for (k = 1; k <= l_ref; ++k) {
         int u = slot3(bw, l_query, k);
         double *bi = b + (size_t)l_query * i_dim;
-        if (u < 3 || u >= bw2 * 3 + 3) continue;
+        if (u < 3 || u >= bw2 * 3 + 3) continue; /* (same guard as the terminal sum: see GUARD VARIANTS above) */
         bi[u + 0] = sM / s[l_query] / s[l_query + 1];
         bi[u + 1] = sI / s[l_query] / s[l_query + 1];
     }

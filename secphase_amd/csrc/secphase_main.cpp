@@ -286,8 +286,9 @@ int main(int argc, char *argv[])
      * workers from its back */
     struct InflateRoute { std::vector<spx_inflater *> inf; int per_dev = 0; } route;
     if (gpu_inflate > 0 && marker_mode) {
-        route.per_dev = std::min(gpu_inflate, 16);
-        for (int d = 0; d < n_dev; ++d) {
+        /* the reader takes at most 32 device workers in all: with many devices each contributes fewer */
+        route.per_dev = std::max(1, std::min(std::min(gpu_inflate, 16), 32 / n_dev));
+        for (int d = 0; d < n_dev && (int)route.inf.size() * route.per_dev + route.per_dev <= 32; ++d) {
             spx_inflater *inf = nullptr;
             if (spx_inflater_create(ctxs[(size_t)d], route.per_dev, &inf) == SPX_OK) route.inf.push_back(inf);
         }
@@ -299,7 +300,11 @@ int main(int argc, char *argv[])
                 return spx_inflater_run(R->inf[(size_t)worker % nd], (int32_t)((size_t)worker / nd), file, file_bytes, blocks, n_blocks, dst, dst_bytes,
                                         check_crc);
             };
-            spx_bam_attach_device_inflate(bam, fn, &route, (int32_t)(route.inf.size() * (size_t)route.per_dev));
+            if (spx_bam_attach_device_inflate(bam, fn, &route, (int32_t)(route.inf.size() * (size_t)route.per_dev)) != SPX_OK) {
+                fprintf(stderr, "[%s] warning: the device inflate workers could not be attached; BGZF blocks are inflated on the host only\n", timestamp());
+                for (spx_inflater *inf : route.inf) spx_inflater_free(inf);
+                route.inf.clear();
+            }
         }
     }
 
@@ -464,8 +469,13 @@ int main(int argc, char *argv[])
     fprintf(stderr, "[%s] Number of reads modified by phased variants = 0\n", timestamp());
     fprintf(stderr, "[%s] Number of reads modified by marker score = %lld\n", timestamp(), n_modified);
     const double t_end0 = now_s();
-    spx_bedset_save(bed_mod, out_path(".modified_read_blocks.markers.bed").c_str(), 1);
-    spx_bedset_save(bed_mk, out_path(".marker_blocks.bed").c_str(), 0);
+    const int rc_bed1 = spx_bedset_save(bed_mod, out_path(".modified_read_blocks.markers.bed").c_str(), 1);
+    const int rc_bed2 = spx_bedset_save(bed_mk, out_path(".marker_blocks.bed").c_str(), 0);
+    if (rc_bed1 != SPX_OK || rc_bed2 != SPX_OK) {
+        fprintf(stderr, "[%s] could not write the BED outputs: %s\n", timestamp(), spx_last_error());
+        fflush(NULL);
+        _exit(1); /* (reader, pool and context threads are still running: no static destructors under them) */
+    }
     spx_bedset_free(bed_mod);
     spx_bedset_free(bed_mk);
     spx_finalizer_free(fin);

@@ -48,6 +48,8 @@ __device__ __forceinline__ int writelane(int v, int c, int n)
 struct DevEnv {
     const uint32_t *in_al;
     uint32_t in_shift; /* bits: 0, 8, 16, 24 */
+    uint32_t n_dw;     /* dwords of in_al that hold bytes of this block: reads beyond them return 0 (the decoder's contract; a damaged
+                        * stream behind valid BGZF framing may ask for ~6 bytes per output byte before the end-of-block check stops it) */
     uint8_t *out;
     uint32_t limit;    /* bytes the block may produce (ISIZE): nothing is written to HBM beyond it */
     uint32_t pos, flushed;
@@ -59,7 +61,7 @@ struct DevEnv {
 
     __device__ __forceinline__ uint32_t in32(uint32_t k) const
     {
-        const uint32_t lo = in_al[k], hi = in_al[k + 1];
+        const uint32_t lo = k < n_dw ? in_al[k] : 0u, hi = k + 1 < n_dw ? in_al[k + 1] : 0u;
         return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
     }
     __device__ __forceinline__ spxz::Tables &tables() { return *T; }
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restr
     DevEnv env;
     env.in_al = reinterpret_cast<const uint32_t *>(comp + (d.in_off & ~(int64_t)3));
     env.in_shift = (uint32_t)(d.in_off & 3) * 8u;
+    env.n_dw = ((uint32_t)(d.in_off & 3) + d.clen + 3u) >> 2;
     env.out = outbuf + d.out_off;
     env.limit = d.ulen;
     env.pos = 0;

@@ -215,7 +215,8 @@ struct Reader {
     /* configuration */
     int threads = 4;
     size_t chunk_target = (size_t)32 << 20, head = 0;
-    int max_inflight = 4, ahead = 2, keep = SPX_BAM_KEEP;
+    std::atomic<int> max_inflight{4}; /* raised by spx_bam_attach_device_inflate while the walker runs */
+    int ahead = 2, keep = SPX_BAM_KEEP;
     bool want_voff = false, check_crc = true;
     size_t soft_cap_slots = 0;
     /* block-chain walk (dispatcher state; reader thread only) */
@@ -440,7 +441,7 @@ bool advance_chunk(Reader *r)
             std::lock_guard<std::mutex> lk(r->mu);
             n_in = r->inflight.size();
         }
-        if ((int)n_in >= r->max_inflight || !dispatch_chunk(r)) break;
+        if ((int)n_in >= r->max_inflight.load(std::memory_order_relaxed) || !dispatch_chunk(r)) break;
     }
     r->t_dispatch += io_now() - td0;
     if (!r->werr.empty()) return false;
@@ -975,7 +976,7 @@ extern "C" int spx_bam_open_opts(const char *path, const spx_bam_options *opt, s
     const size_t phys = (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz : ((size_t)64 << 30);
     size_t cap_bytes = o.max_bytes > 0 ? (size_t)o.max_bytes : phys / 4;
     if (const char *e = getenv("SPX_BAM_ARENA_GB")) cap_bytes = (size_t)atoll(e) << 30;
-    r->soft_cap_slots = std::max<size_t>(cap_bytes / slot, (size_t)r->max_inflight + 4);
+    r->soft_cap_slots = std::max<size_t>(cap_bytes / slot, (size_t)r->max_inflight.load() + 4);
     /* the reservation is virtual (MAP_NORESERVE, touched slot by slot): room for the soft cap twice over */
     const size_t want = std::max(std::min<size_t>((size_t)4 << 40, 2 * (r->soft_cap_slots + 8) * slot), 8 * slot);
     if (!r->arena.init(slot, want)) return bail("cannot reserve the inflate arena");

@@ -1057,7 +1057,15 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         ~GateGuard() { if (w->gate && !passed) { wait(); pass(); } }
     } gate{w};
     w->lane = (int)(c->lane_rr.fetch_add(1) % (unsigned)c->n_prep);
-    if (w->gate) w->lane = (int)(w->gate_ticket % c->n_prep);
+    if (w->gate) {
+        w->lane = (int)(w->gate_ticket % c->n_prep);
+        /* Lists t and t - n_prep share a lane.  The older one waits at the allocation gate while it HOLDS the lane; were the
+         * younger one to take the lane first (the older one preempted on its way to the lock), it would wait at the gate
+         * for a turn the older one can never pass.  So a list asks for its lane only once the list n_prep tickets ahead
+         * has passed the gate -- from there on that one waits for nothing this one holds. */
+        std::unique_lock<std::mutex> gl(w->gate->mu);
+        w->gate->cv.wait(gl, [&] { return w->gate->turn > w->gate_ticket - c->n_prep; });
+    }
     spx_ctx::PrepLane &PL = c->lane[w->lane];
     std::lock_guard<std::mutex> lk(PL.mu);
     const double t0 = now_s();

@@ -232,6 +232,55 @@ def test_two_ranks_on_the_device_emit_the_same_relabel_list(built, tmp_path):
     assert filecmp.cmp(log_o, str(tmp_path / "dist_gpu.out.log"), shallow=False)
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_write_the_list_one_process_writes(built, tmp_path):
+    """`python bench.py --gpus 2` itself -- the self-launch (a child started before anything touches the GPU), cost-cut
+    shards of the mixed workload, every rank deciding and formatting its own groups, the gather of the fragments, rank 0's
+    writer thread -- on a one-GPU box (ranks share the device, collectives over gloo: a rig, never a measurement).  The list
+    rank 0 wrote over ALL its steps must equal what ONE process writes for the same groups in (step, rank, group) order with
+    one rand() stream; bench's own checks against the oracle (timed groups, list prefix) must have run on rank 0."""
+    import json
+    import subprocess
+    from secphase_amd import api, records, synth
+    keep = str(tmp_path / "bench2.out.log")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--platform", "mixed", "--steps", "2", "--warmup", "1",
+           "--groups-per-step", "2048", "--keep-log", keep, "--no-build"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=dict(os.environ, GPU_MAX_HW_QUEUES="14"))
+    assert p.returncode == 0, (p.stdout[-400:], p.stderr[-1200:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
+    assert line["n_gpus"] == 2 and line["config"]["verified_timed_groups"] >= 256
+    assert line["config"]["verified_own_relabel_list"]["oracle_list_is_byte_prefix_of_this_runs_list"] is True
+    assert line["config"]["sharding"]["imbalance_by_cost"] < line["config"]["sharding"]["imbalance_by_count"] + 1e-9
+    man = [json.load(open(f"{keep}.rank{r}.json")) for r in range(2)]
+    assert man[0]["sequence"] == man[1]["sequence"] and len(man[0]["sequence"]) >= 3 + 2
+    g = synth.Genome(synth.default_cfg(synth.MIXED))
+    par = records.preset("hifi")
+    ctx = api.Context(0)
+    ctx.set_reference(g.ref)
+    L = api.lib()
+    fin = C.c_void_p()
+    api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+    one = str(tmp_path / "one_process.out.log")
+    open(one, "w").close()
+    cache = {}
+    n_tot = 0
+    for i in man[0]["sequence"]:
+        for r in range(2):
+            for start, n in man[r]["ranges"][str(i)]:
+                if (start, n) not in cache:
+                    reads = g.reads(start, n)
+                    out, _ = ctx.score_batch(reads.batch, par, finalize_seed=None)
+                    cache[(start, n)] = (reads, out)
+                reads, out = cache[(start, n)]
+                api._chk(L.spx_finalizer_apply(fin, C.byref(par), out, n), "spx_finalizer_apply")
+                api.write_relabel_log(one, reads.batch, g.ref, out, mode="a")
+                n_tot += n
+    L.spx_finalizer_free(fin)
+    ctx.close()
+    assert n_tot == 2 * 2048 * len(man[0]["sequence"])
+    assert os.path.getsize(one) > 1000 and filecmp.cmp(one, keep, shallow=False)
+
+
 def test_relabel_record_writer_on_threads_keeps_order_and_format(built, tmp_path):
     """spx_write_relabel_records formats slices of >= 4 096 records on threads: the file must be what one pass of
     print_alignment_scores (src/secphase.c:32-57) over the records in order would write"""

@@ -86,6 +86,24 @@ def test_probaln_small_and_degenerate(ctx):
     _check(ctx, probs, [30] * len(probs), pars)
 
 
+def test_probaln_band_wider_than_query_and_reference(ctx):
+    """the regime in which two readings of probaln.c's terminal guard differ (l_query <= bw, 2*bw+1 > l_ref; reached by
+    `--ont -b 50` on blocks of <= 50 bases): the 240 problems tools/pin_htslib/make_problems.py sets aside for it -- states,
+    qualities and, for a sample, every posterior product equal the oracle's (which follows the `u >= bw2*3+3` reading)"""
+    import importlib.util
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pin_htslib", "make_problems.py")
+    spec = importlib.util.spec_from_file_location("make_problems", tool)
+    mp_ = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mp_)
+    block = mp_.problems()[-240:]
+    probs = [(np.array(r, np.uint8), np.array(q, np.uint8)) for r, q, *_ in block]
+    pars = [(d, e, bw) for _, _, bw, d, e, _ in block]
+    sq = [v[5] for v in block]
+    _check(ctx, probs, sq, pars)
+    for k in range(0, 240, 12):
+        _posteriors_equal(ctx, probs[k][0], probs[k][1], sq[k], pars[k])
+
+
 def test_probaln_ambiguous_bases(ctx):
     rng = np.random.default_rng(10)
     probs = [_rand_problem(rng, int(rng.integers(100, 400)), 0.01, 0.01, n_frac=0.03) for _ in range(32)]
@@ -545,6 +563,65 @@ def test_command_line_with_device_inflate(ctx, tmp_path):
         assert p.returncode != 0 and "BAM read error" in p.stderr, p.stderr[-300:]
 
 
+def _cli_parity(tmp_path, g, n_groups, chunk, flags, par, tag, env=None, min_relabelled=1):
+    """the command-line drop-in on a BAM of n_groups synthetic groups (written by the C writer, htslib block policy) with
+    `flags`, against the oracle with the matching parameters: out.log and both BEDs byte for byte, the counters"""
+    import subprocess
+    chunks = [g.reads(k, min(chunk, n_groups - k)) for k in range(0, n_groups, chunk)]
+    whole = g.reads(0, n_groups)
+    fa, bam, outd = str(tmp_path / f"{tag}.fa"), str(tmp_path / f"{tag}.bam"), str(tmp_path / f"{tag}_out")
+    synth.write_fasta(fa, g.ref)
+    synth.write_bam(bam, [c.batch for c in chunks], g.ref, threads=4)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "secphase_amd", "bin", "secphase")
+    log_o, bm_o, bk_o = (str(tmp_path / f"{tag}.{n}") for n in ("o.log", "o.mod.bed", "o.mk.bed"))
+    nre, _ = orc.run_batch(whole.batch, g.ref, par, threads=8, seed=1, log_path=log_o, bed_modified=bm_o, bed_markers=bk_o)
+    assert nre >= min_relabelled, nre
+    p = subprocess.run([exe] + flags + ["-@", "8", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t"], capture_output=True, text=True,
+                       timeout=1200, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr[-600:]
+    assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False), tag
+    assert filecmp.cmp(bm_o, os.path.join(outd, "t.modified_read_blocks.markers.bed"), shallow=False), tag
+    assert filecmp.cmp(bk_o, os.path.join(outd, "t.marker_blocks.bed"), shallow=False), tag
+    assert f"Number of reads modified by marker score = {nre}" in p.stderr
+    return p
+
+
+def test_command_line_ont_preset_with_band_50(ctx, tmp_path):
+    """BASELINE config 3 through the command line: `secphase --ont -b 50` (src/secphase.c:491-504 + -b) on ONT-shaped groups
+    (30 kb reads, <= 4 secondaries): the wide band classes reached from a BAM file, not only through the library API"""
+    g = small_genome(synth.ONT, n_paralogs=3, contig_len=400000)
+    _cli_parity(tmp_path, g, 96, 32, ["--ont", "-b", "50"], records.preset("ont", bandwidth=50), "ont50")
+    # the preset alone (band 20) is a different parameter set and a different list
+    _cli_parity(tmp_path, g, 48, 48, ["--ont"], records.preset("ont"), "ont20")
+
+
+def test_command_line_mixed_workload_at_the_default_batch_size(ctx, tmp_path):
+    """BASELINE config 5's mix (HiFi + ONT, power-law lengths 2-100 kb, <= 8 secondaries) run as --hifi with the DEFAULT
+    --groupsPerBatch (nothing passed): records of 100 kb reads span several BGZF blocks"""
+    cfg = synth.default_cfg(synth.MIXED, n_contigs=2, contig_len=600000)
+    g = synth.Genome(cfg)
+    _cli_parity(tmp_path, g, 400, 100, ["--hifi"], records.preset("hifi"), "mixed")
+
+
+def test_command_line_non_preset_scoring_flags(ctx, tmp_path):
+    """every scoring flag given by hand, none of them a preset value (src/secphase.c:506-560): -q -c -d -e -b -t -s -m -p -r -n
+    --flankMargin"""
+    g = small_genome(synth.HIFI, read_len=6000, max_secondaries=3, n_paralogs=3, hardclip_frac=0.2, softclip_frac=0.2, paralog_snv_rate=0.002)
+    p = records.preset("hifi")
+    p.conf_d, p.conf_e, p.conf_b, p.set_q, p.min_q, p.indel_threshold = 3e-3, 0.25, 33.0, 27, 5, 4
+    p.prim_margin_score, p.prim_margin_random, p.min_score, p.flank_margin = 5.0, 3.0, -40, 300
+    flags = ["-q", "-c", "-d", "3e-3", "-e", "0.25", "-b", "33", "-t", "4", "-s", "27", "-m", "5", "-p", "5", "-r", "3", "-n", "-40",
+             "--flankMargin", "300", "--groupsPerBatch", "53"]
+    _cli_parity(tmp_path, g, 200, 50, flags, p, "odd")
+    # -q without -c, and neither: the defaults of src/secphase.c:420-449 otherwise
+    p2 = records.preset("hifi")
+    p2.consensus = 0
+    _cli_parity(tmp_path, g, 60, 60, ["-q", "--groupsPerBatch", "31"], p2, "noc", min_relabelled=0)
+    p3 = records.preset("hifi")
+    p3.consensus, p3.baq_flag = 0, 0
+    _cli_parity(tmp_path, g, 60, 60, [], p3, "none", min_relabelled=0)
+
+
 def _quals_parity(ctx, genome, reads, params):
     """all-rows work list (-w/--writeBam): record qualities after BAQ equal the oracle's, scores unchanged"""
     import copy
@@ -626,7 +703,7 @@ def test_command_line_write_bam(ctx, tmp_path):
 
 
 def _full_size_properties(ctx, platform, par, n, chunk, n_shards, min_problems, min_cells, sample):
-    """A workload at the size bench.py times: the oracle would need minutes for all of it, so the whole batch is checked
+    """A workload of bench.py's shape (a quarter of its default step): the oracle would need minutes for all of it, so the whole batch is checked
     through size-independent properties -- the same groups scored as one work list, as shards, in another order and
     several times in a row give bit-identical scores and decisions -- and a random sample of groups is compared with
     the oracle."""
@@ -685,13 +762,57 @@ def _full_size_properties(ctx, platform, par, n, chunk, n_shards, min_problems, 
     return st
 
 
+def test_work_list_of_131072_groups_in_a_pipeline_of_depth_3(ctx):
+    """The size bench.py's default step has: ONE work list of 131 072 HiFi groups (config 2, the 100 Mbp assembly), fed from
+    host memory through the in-order pipeline at depth 3 with two 65 536-group lists (its two halves) in flight beside it --
+    three preparations on their lanes at once, ~90 GB of work lists.  The halves must reproduce the whole bit for bit, the
+    whole must be in input order, and 48 random groups must equal the oracle's scores."""
+    import threading
+    n, chunk = 131072, 1024
+    g = synth.Genome(synth.default_cfg(synth.HIFI))
+    parts = [None] * (n // chunk)
+
+    def gen(k0):
+        for k in range(k0, len(parts), 8):
+            parts[k] = g.reads(k * chunk, chunk)
+    th = [threading.Thread(target=gen, args=(k,)) for k in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    ctx.set_reference(g.ref)
+    par = records.preset("hifi")
+    ptr = [p.batch for p in parts]
+    half = len(ptr) // 2
+    pipe = api.Pipe(ctx, par, depth=3, host_threads=0)
+    try:
+        for sub in (ptr, ptr[:half], ptr[half:], ptr):
+            pipe.submit(batch=sub)
+        key = lambda o: (o.n_aln, tuple(o.score[a] for a in range(max(o.n_aln, 0))), o.prim_idx, o.max_idx, o.tie_mask, o.pass_, o.n_problems, o.dp_cells)
+        got = []
+        for want in (n, n // 2, n // 2, n):
+            out, m = pipe.next()
+            assert m == want
+            got.append([key(out[k]) for k in range(m)])
+    finally:
+        pipe.close()
+    whole = got[0]
+    assert got[1] + got[2] == whole and got[3] == whole
+    assert sum(1 for x in whole if x[0] >= 2) == n and sum(x[6] for x in whole) > 8000000 and sum(x[7] for x in whole) > 8 * 10 ** 10
+    rng = np.random.default_rng(5)
+    for k in rng.choice(n, size=48, replace=False):
+        sub = g.reads(int(k), 1)
+        _, ores = orc.run_batch(sub.batch, g.ref, par, threads=1, seed=1)
+        e, o = ores[0], whole[int(k)]
+        assert o[0] == e.n_aln and o[1] == tuple(e.score[a] for a in range(e.n_aln)) and o[2] == e.prim_idx and o[7] == e.dp_cells, int(k)
+
+
 def test_full_size_workload_properties(ctx):
-    """BASELINE config 2 at the size bench.py times: 32 768 HiFi groups, 15 kb reads, the 100 Mbp assembly"""
+    """BASELINE config 2 at a quarter of the size bench.py times per step (test_work_list_of_131072_groups... has the full
+    size): 32 768 HiFi groups, 15 kb reads, the 100 Mbp assembly"""
     _full_size_properties(ctx, synth.HIFI, records.preset("hifi"), 32768, 1024, 4, 2000000, 2 * 10 ** 10, 48)
 
 
 def test_full_size_workload_properties_ont(ctx):
-    """BASELINE config 3 at the size bench.py --platform ont times: 4 096 ONT groups, 30 kb reads, <= 4 secondaries,
+    """BASELINE config 3 at a quarter of the size bench.py --platform ont times per step: 4 096 ONT groups, 30 kb reads, <= 4 secondaries,
     band 50 on the 100 Mbp assembly -- the band classes (4,26)/(4,28)/(4,30)/(8,16)+(4,32) on real work lists"""
     st = _full_size_properties(ctx, synth.ONT, records.preset("ont", bandwidth=50), 4096, 256, 4, 1000000, 2 * 10 ** 10, 48)
     wide = sum(st.problems_per_class[c] for c in (6, 7, 12, 13))

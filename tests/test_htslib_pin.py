@@ -47,6 +47,10 @@ def test_problem_list_is_deterministic():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pin_htslib", "make_problems.py")
     a = subprocess.run([sys.executable, tool], capture_output=True, text=True, check=True).stdout
     b = subprocess.run([sys.executable, tool], capture_output=True, text=True, check=True).stdout
-    assert a == b and len(a.splitlines()) == 1206
+    assert a == b and len(a.splitlines()) == 1446
     f = a.splitlines()[0].split()
     assert len(f) == 8 and len(f[6]) == int(f[0]) and len(f[7]) == int(f[1])
+    # the last 240: the regime in which the two readings of the terminal guard differ (oracle/probaln_oracle.c, "guard variants")
+    for ln in a.splitlines()[-240:]:
+        r_, l_, bw_ = (int(x) for x in ln.split()[:3])
+        assert l_ <= bw_ and 2 * bw_ + 1 > r_

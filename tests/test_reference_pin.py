@@ -73,3 +73,25 @@ def test_command_line_against_reference_goldens(built, tmp_path, name):
     assert filecmp.cmp(os.path.join(outd, "t.out.log"), os.path.join(GOLD, f"ref_{name}.out.log"), shallow=False)
     assert filecmp.cmp(os.path.join(outd, "t.modified_read_blocks.markers.bed"), os.path.join(GOLD, f"ref_{name}.modified.bed"), shallow=False)
     assert filecmp.cmp(os.path.join(outd, "t.marker_blocks.bed"), os.path.join(GOLD, f"ref_{name}.markers.bed"), shallow=False)
+
+
+def test_pin_all_argument_handling(tmp_path):
+    """tools/pin_all.sh REF_CHECKOUT: refuses what is not a checkout of the reference, and --dry-run prints the two docker
+    commands (the reference's own Dockerfile; both pin scripts inside that image) without needing docker"""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "pin_all.sh")
+    p = subprocess.run([tool], capture_output=True, text=True)
+    assert p.returncode == 2 and "usage" in p.stderr
+    p = subprocess.run([tool, str(tmp_path), "--dry-run"], capture_output=True, text=True)
+    assert p.returncode == 2 and "Dockerfile" in p.stderr
+    ref = tmp_path / "ref"
+    (ref / "programs" / "src").mkdir(parents=True)
+    (ref / "Dockerfile").write_text("FROM scratch\n# htslib-1.17\n")
+    (ref / "programs" / "src" / "secphase.c").write_text("\n")
+    p = subprocess.run([tool, str(ref), "--dry-run"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("docker build") and str(ref) in lines[0]
+    assert "tools/pin_htslib/run.sh /usr/local" in lines[1] and "tools/pin_reference/run.sh" in lines[1]
+    p = subprocess.run([tool, str(ref), "--bogus"], capture_output=True, text=True)
+    assert p.returncode == 2

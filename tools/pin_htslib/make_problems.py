@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """problems.txt for pin_probaln: the six problems of tests/golden/probaln.json + 1 200 seeded random ones (HiFi- and
-ONT-shaped windows, small and degenerate shapes, ambiguous bases, odd parameters).  Deterministic: the same file on
-every machine."""
+ONT-shaped windows, small and degenerate shapes, ambiguous bases, odd parameters) + 240 in the regime where two readings of
+the terminal / backward-start guard differ (l_query <= bw and 2*bw+1 > l_ref).  Deterministic: the same file on every
+machine."""
 import json
 import os
 import sys
@@ -53,6 +54,22 @@ def problems():
             q = [4 if rng.random() < 0.02 else b for b in q]
         e = 0.1 if kind < 3 else float(rng.choice([0.1, 0.3, 0.5]))
         out.append((ref, q, abs(len(ref) - len(q)) + bw, d, e, sq))
+    # ---- block of its own: l_query <= bw AND 2*bw + 1 > l_ref.  There the band covers the whole reference on every row
+    # (set_u's row offset is 0), and two readings of probaln.c differ: the terminal sum / backward start skip a column with
+    # `u >= bw2*3+3` (what oracle/probaln_oracle.c follows: never true here, column l_ref takes part) or with
+    # `u >= i_dim-3` (i_dim = 3*l_ref+6 when 2*bw+1 >= l_ref: column l_ref would be skipped).  secphase reaches the regime
+    # with --ont -b 50 on consensus blocks of 21-50 bases (ptMarker.c:754: bw = |l_ref - l_query| + conf_bw).
+    rng2 = np.random.default_rng(2718)
+    for k in range(240):
+        bw_in = int(rng2.choice([20, 50, 50, 70]))
+        L = int(rng2.integers(1, bw_in + 1))               # l_query <= conf_bw <= bw
+        R = max(1, L + int(rng2.integers(-min(L - 1, 6), 7)))  # l_ref within a few bases: 2*bw+1 > l_ref
+        ref = rng2.integers(0, 4, R).tolist()
+        q = [ref[min(i, R - 1)] if rng2.random() > 0.08 else int(rng2.integers(0, 4)) for i in range(L)]
+        d, sq = (1e-3, 20) if bw_in >= 50 else (1e-4, 40)
+        bw = abs(R - L) + bw_in
+        assert L <= bw and 2 * bw + 1 > R
+        out.append((ref, q, bw, d, 0.1, sq))
     return out
 
 
