@@ -82,9 +82,10 @@ def gen_parallel(genome, first, n, chunk, threads):
     return out
 
 
-def from_bam_leg(args, genome, record_chunks, n_groups, ncpu, oracle_log, oracle_groups):
-    """BASELINE.json's 'GB BAM/sec': the command-line drop-in (mmap + parallel BGZF inflate, record scan, staging, device
-    path, finalizer, relabel list, BEDs) on a BAM file holding `record_chunks` (generator chunks of the very workload
+def from_bam_leg(args, genome, record_chunks, n_groups, ncpu, oracle_log, oracle_groups, n_devices=1):
+    """BASELINE.json's 'GB BAM/sec' = SURVEY 8(d)'s metric (first byte read -> out.log closed): the command-line drop-in
+    (compressed BGZF blocks to the device(s), inflate / record chain / fields / dispatch filter / staging / scoring there,
+    finalizer, relabel list, BEDs on the host) on a BAM file holding `record_chunks` (generator chunks of the very workload
     that was timed), as a CHILD process (this one holds the GPU already).  The BAM is written by the C writer of synth/
     (htslib block policy, zlib level 6) onto tmpfs, so the file is in the page cache like a file that was just produced
     by an aligner.  Figures: the whole process (first byte -> out.log and BEDs closed; HIP start-up, FASTA parse,
@@ -112,36 +113,62 @@ def from_bam_leg(args, genome, record_chunks, n_groups, ncpu, oracle_log, oracle
         res["bam_bytes"] = size
         exe = os.path.join(ROOT, "secphase_amd", "bin", "secphase")
         flags = ["--ont", "-b", "50"] if ont else ["--hifi"]
-        cmd = [exe] + flags + ["-@", str(cli_threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "bench",
-                               "--groupsPerBatch", str(4096 if ont else 16384)]
-        runs = []
-        for _ in range(2):  # two runs, the better one is reported (boxes of the pool differ; the first also warms the page cache of the binary)
-            shutil.rmtree(outd, ignore_errors=True)
-            t0 = time.perf_counter()
-            p = subprocess.run(cmd, capture_output=True, text=True)
-            wall = time.perf_counter() - t0
-            if p.returncode != 0:
-                res["rc"] = p.returncode
-                res["stderr_tail"] = p.stderr[-400:]
-                return res
-            m = re.search(r"time in the scoring loop: ([0-9.]+) s", p.stderr)
-            runs.append((wall, float(m.group(1)) if m else None))
-        wall, loop = min(runs)
+        dev_list = ",".join(str(k) for k in range(max(1, n_devices)))
+        base_cmd = [exe] + flags + ["-@", str(cli_threads), "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "bench", "--devices", dev_list]
+
+        def run_cli(extra, times):
+            """best of `times` runs: (wall, loop, CPU core-seconds of the child: user + system)"""
+            import resource
+            runs = []
+            for _ in range(times):
+                shutil.rmtree(outd, ignore_errors=True)
+                r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
+                t0 = time.perf_counter()
+                p = subprocess.run(base_cmd + extra, capture_output=True, text=True)
+                wall = time.perf_counter() - t0
+                r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+                if p.returncode != 0:
+                    return None, p
+                m = re.search(r"time in the scoring loop: ([0-9.]+) s", p.stderr)
+                runs.append((wall, float(m.group(1)) if m else None, (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)))
+            return runs, None
+
+        # the default command line: DEVICE-RESIDENT input (compressed bytes up, inflate / record chain / fields / dispatch filter / staging as kernels)
+        runs, bad = run_cli([], 2)  # two runs, the better one is reported (boxes of the pool differ; the first also warms the page cache of the binary)
+        if runs is None:
+            res["rc"] = bad.returncode
+            res["stderr_tail"] = bad.stderr[-400:]
+            return res
+        wall, loop, cpu_s = min(runs)
         res["rc"] = 0
+        res["input"] = "device-resident (spx_dbam: BGZF inflate, record chain, fields / tags, name groups, dispatch filter, staging as kernels)"
+        res["devices"] = max(1, n_devices)
         res["wall_s"] = round(wall, 3)
         res["runs_wall_s"] = [round(r[0], 3) for r in runs]
         res["groups_per_s"] = round(n_groups / wall, 1)
         res["gb_bam_per_s"] = round(size / wall / 1e9, 4)
+        res["host_cpu_core_s"] = round(cpu_s, 2)
+        res["host_cpu_core_s_per_262144_groups"] = round(cpu_s * 262144 / max(1, n_groups), 2)
         if loop and loop > 0:
             res["loop_s"] = loop
             res["loop_groups_per_s"] = round(n_groups / loop, 1)
             res["loop_gb_bam_per_s"] = round(size / loop / 1e9, 4)
+        got = open(os.path.join(outd, "bench.out.log"), "rb").read()
         if oracle_log and os.path.exists(oracle_log):
             want = open(oracle_log, "rb").read()
-            got = open(os.path.join(outd, "bench.out.log"), "rb").read()
             res["out_log_identical_to_oracle"] = bool(got[:len(want)] == want and len(want) > 0)
             res["out_log_checked_groups"] = oracle_groups
             res["out_log_bytes"] = len(got)
+        if not getattr(args, "no_host_input_leg", False):
+            # the round-3 host reader on the same file, for comparison (one run)
+            hr, hbad = run_cli(["--hostInput", "--groupsPerBatch", str(4096 if ont else 16384)], 1)
+            if hr:
+                hw, hl, hc = hr[0]
+                res["host_input"] = {"wall_s": round(hw, 3), "groups_per_s": round(n_groups / hw, 1), "gb_bam_per_s": round(size / hw / 1e9, 4),
+                                     "loop_groups_per_s": round(n_groups / hl, 1) if hl else None, "host_cpu_core_s": round(hc, 2),
+                                     "what": "the same file with --hostInput (mmap reader, host pool + device inflate workers, host record walk / parse / staging)"}
+                got_h = open(os.path.join(outd, "bench.out.log"), "rb").read()
+                res["host_input"]["out_log_identical_to_device_input"] = bool(got_h == got)
         res["what"] = ("secphase_amd/bin/secphase on a synthetic BAM (tmpfs) of the same workload: whole process (exec -> all six output "
                        "files closed; HIP start-up, FASTA parse, reference upload included) and its scoring loop alone; the host side of the "
                        f"GPU box gives this container ~16 cores of CPU time (cgroup quota), which bounds inflate + staging (DESIGN.md 6b)")
@@ -155,7 +182,9 @@ def also_leg(platform, steps, warmup):
     this very script; its JSON line is returned (cut down to the figures the headline has)"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
-           "--no-from-bam", "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "3", "--cpu-threads", "32"]
+           "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "3", "--cpu-threads", "32", "--no-host-input-leg"]
+    # config 3 also end to end: `secphase --ont -b 50` on a BAM of one step's groups
+    cmd += ["--from-bam", "16384"] if platform == "ont" else ["--no-from-bam"]
     # (mixed: small batches whose preparations overlap -- one more in flight; ONT: the preset of BASELINE config 3, 16 384 groups
     # per step with two lists of ~70 GB in flight -- the parent has handed its device memory back (spx_trim) before this runs;
     # SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
@@ -180,6 +209,7 @@ def also_leg(platform, steps, warmup):
                          "traffic": r.get("traffic"), "phase": r.get("phase")},
             "verified_timed_groups": d["config"].get("verified_timed_groups"),
             "verified_own_relabel_list": (d["config"].get("verified_own_relabel_list") or {}).get("oracle_list_is_byte_prefix_of_this_runs_list"),
+            "from_bam": d.get("from_bam"),
             "kernel_ms_per_step": d.get("kernel_ms_per_step"), "cpu_baseline": d.get("cpu_baseline"), "wall_s": round(dt, 1)}
 
 
@@ -205,6 +235,7 @@ def main():
                          "GB of compressed BAM per second, the second half of BASELINE.json's metric); default: one step's groups; "
                          "N = 1 GPU only")
     ap.add_argument("--no-from-bam", action="store_true", help="skip the end-to-end leg")
+    ap.add_argument("--no-host-input-leg", action="store_true", help="end-to-end leg: skip the comparison run with --hostInput")
     ap.add_argument("--no-also", action="store_true", help="skip the short ONT / mixed legs that follow the headline (N = 1, --platform hifi)")
     ap.add_argument("--no-build", action="store_true", help="never build (under a profiler: no child processes)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU baseline after one warm-up; the median is reported")
@@ -586,6 +617,19 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the end-to-end leg (SURVEY 8(d)'s metric: first byte read -> out.log closed) runs the command line as a child process on
+    # ALL the job's devices (`secphase --devices 0..N-1`: one input pipeline per GPU): every rank hands its device memory back first
+    want_bam_all = not args.no_from_bam and not args.kernel_only and args.from_bam != 0
+    if world > 1 and want_bam_all:
+        if pipe is not None:
+            pipe.close()
+            pipe = None
+        for w_ in staged:
+            w_.free()
+        staged = []
+        api._chk(L.spx_trim(ctx.h), "spx_trim")
+        torch.cuda.empty_cache()
+        dist.barrier()
 
     nst = len(per_step_stats)
     n_disp = sum(int(s.n_dispatched) for s in per_step_stats) / nst
@@ -801,7 +845,7 @@ def main():
             line["relabelled_sampled"] = relabelled[0]
         # uncompressed record bytes (what spx_stage hands to the device: flags, CIGAR, SEQ, QUAL, cs/MD text) through the step
         line["gb_records_per_s"] = round(bytes_in * world * args.steps / elapsed / 1e9, 2)
-        want_bam = world == 1 and not args.no_from_bam and not args.kernel_only and args.from_bam != 0
+        want_bam = want_bam_all
         want_also = world == 1 and not args.no_also and not args.kernel_only and args.platform == "hifi"
         if want_bam or want_also:
             # the command line / the other workloads run as other processes on the same GPU: hand back what this one holds first
@@ -814,7 +858,9 @@ def main():
             api._chk(L.spx_trim(ctx.h), "spx_trim")
             torch.cuda.empty_cache()
         if want_bam:
-            nb = min(2 * gps, D * gps) if args.from_bam < 0 else args.from_bam  # (two steps' worth: the reader's read-ahead during start-up does not cover the whole file)
+            # every distinct batch of this rank (524 288 HiFi groups by default): start-up (HIP initialisation, reference upload:
+            # ~0.4 s) and the exit of the process are part of the metric, a larger file shows the steady state better
+            nb = D * gps if args.from_bam < 0 else args.from_bam
             chunks, have = [], 0
             for b in ptrs:  # the generator chunks of the timed batches, in order
                 for ch in b:
@@ -822,11 +868,22 @@ def main():
                         chunks.append(ch)
                         have += ch.contents.n_groups
             try:
-                line["from_bam"] = from_bam_leg(args, genome, chunks, have, ncpu, cpu.get("oracle_log") if cpu else None,
-                                                cpu.get("oracle_groups") if cpu else 0)
+                n_devs = world if args.dist_backend == "nccl" else min(world, torch.cuda.device_count())
+                olog = cpu.get("oracle_log") if cpu else None
+                ogr = cpu.get("oracle_groups") if cpu else 0
+                if not olog and own_log_check:
+                    olog, ogr = os.path.join(tmpdir, "oracle_first_chunk.out.log"), own_log_check["groups"]
+                line["from_bam"] = from_bam_leg(args, genome, chunks, have, ncpu, olog, ogr, n_devices=n_devs)
             except Exception as ex:  # noqa: BLE001  (a secondary figure must not cost the line its headline)
                 line["from_bam"] = {"error": str(ex)}
             line["gb_bam_per_s"] = line["from_bam"].get("gb_bam_per_s")
+            fb = line["from_bam"]
+            line["metric_8d"] = {"what": "SURVEY 8(d): groups that pass the dispatch filter / wall time from the first byte read to out.log closed, and compressed "
+                                         "BAM bytes / the same time: the command line as a child process (HIP start-up, FASTA parse, reference upload, exit included)",
+                                 "groups_per_s": fb.get("groups_per_s"), "gb_bam_per_s": fb.get("gb_bam_per_s"), "loop_groups_per_s": fb.get("loop_groups_per_s"),
+                                 "loop_over_value": round(fb["loop_groups_per_s"] / value, 3) if fb.get("loop_groups_per_s") else None,
+                                 "host_cpu_core_s_per_262144_groups": fb.get("host_cpu_core_s_per_262144_groups"), "devices": fb.get("devices"),
+                                 "out_log_identical_to_oracle": fb.get("out_log_identical_to_oracle")}
             if cpu and line["from_bam"].get("groups_per_s"):
                 line["from_bam"]["whole_process_vs_cpu_baseline"] = round(line["from_bam"]["groups_per_s"] / cpu["value"], 1)
         if cpu:

@@ -280,6 +280,7 @@ typedef struct spx_bam_reader spx_bam_reader;
 typedef struct spx_fasta spx_fasta;
 #define SPX_BAM_WANT_VOFFSETS 1 /* keep the BGZF virtual offset of every group's first record (index building) */
 #define SPX_BAM_NO_CRC 2        /* skip the CRC32 check of the inflated blocks */
+#define SPX_BAM_HEADER_ONLY 4   /* map the file and parse the header only: no batches are cut (the reader then serves spx_dbam_open) */
 typedef struct spx_bam_options {
     int32_t threads;        /* inflate / parse threads [4] */
     int32_t batch_groups;   /* > 0: batches of this many groups are cut in the background from spx_bam_open_opts on (the
@@ -344,6 +345,38 @@ int spx_inflater_create(spx_ctx *ctx, int32_t n_workers, spx_inflater **out);
 int spx_inflater_run(void *inflater, int32_t worker, const uint8_t *file, int64_t file_bytes, const spx_bgzf_block *blocks, int32_t n_blocks,
                      uint8_t *dst, int64_t dst_bytes, int32_t check_crc);
 void spx_inflater_free(spx_inflater *inf);
+
+/* ---- device-resident BAM input (round 4; spx_devin.cpp, spx_devin_kernels.hip): what sam_read1 + the group scan + the
+ * dispatch filter of src/secphase.c:230-351 do one record at a time on the reading thread happens on the device -- the host
+ * sends COMPRESSED bytes (runs of BGZF blocks, "segments"), bgzf_inflate_kernel inflates them into HBM, kernels follow the
+ * record chain, parse fields and cs / MD / CG tags, form the name groups, apply the dispatch filter (:285-288) and gather
+ * the dispatched groups' records into the staged layout: the product is a STAGED work list per segment (hand it to
+ * spx_pipe_submit as `staged`) plus a spx_batch that holds only what the relabel list prints (names, grp_first, flag,
+ * tid, pos; every other array is NULL).  Work lists come out in FILE order; with several contexts (one per GPU) the
+ * segments are dealt to whichever device is free, each device running its own upload / inflate / parse pipeline --
+ * only the few hundred KB a segment hands to the next one (its last, still open group) cross devices, through the host. ---- */
+typedef struct spx_dbam spx_dbam;
+typedef struct spx_dbam_options {
+    int32_t threads;        /* host threads for the copies into pinned memory [4] */
+    int32_t max_groups;     /* groups per work list at most [95 000 = the cap]; a segment with more is handed out as several lists */
+    int32_t ahead;          /* finished segments per device that may wait for the caller [3] */
+    int32_t flags;          /* SPX_BAM_NO_CRC */
+    int64_t segment_bytes;  /* inflated bytes per segment [1 GB] */
+    int64_t carry_bytes;    /* room for the open group + a continuing record in front of a segment [256 MB]; also the largest record */
+    int64_t start_voffset, end_voffset; /* shard of the file, as in spx_bam_options; -1: all of it */
+} spx_dbam_options;
+void spx_dbam_default_options(spx_dbam_options *opt);
+int spx_dbam_open(const char *path, const spx_dbam_options *opt, spx_dbam **out);
+/* the header of the file (target names, spx_bam_bind_reference: bind BEFORE spx_dbam_start) */
+spx_bam_reader *spx_dbam_header(spx_dbam *d);
+/* starts the input pipelines, one per context */
+int spx_dbam_start(spx_dbam *d, spx_ctx *const *ctxs, int32_t n_ctx, const spx_params *par);
+/* the next work list in file order: staged on ctxs[*ctx_index]; returns its number of input groups, 0 at the end of the file,
+ * SPX_E* on error (spx_last_error).  The caller frees the work list (spx_work_free on that context) and releases `names`. */
+int spx_dbam_next(spx_dbam *d, spx_work **work, int32_t *ctx_index, const spx_batch **names);
+int spx_dbam_release(spx_dbam *d, const spx_batch *names);
+void spx_dbam_stats(const spx_dbam *d, int64_t *segments, int64_t *bytes_uploaded, double *seconds7);
+void spx_dbam_close(spx_dbam *d);
 
 /* Index of group starts in the reference's on-disk format (src/secphase_index.c:76-119 writes, get_offset_array
  * src/secphase.c:357-385 reads: int64 count, then that many int64 BGZF virtual offsets): the offset of the first record

@@ -68,6 +68,11 @@ _u16p = C.POINTER(C.c_uint16)
 _f64p = C.POINTER(C.c_double)
 
 
+class DbamOptions(C.Structure):
+    _fields_ = [("threads", C.c_int32), ("max_groups", C.c_int32), ("ahead", C.c_int32), ("flags", C.c_int32),
+                ("segment_bytes", C.c_int64), ("carry_bytes", C.c_int64), ("start_voffset", C.c_int64), ("end_voffset", C.c_int64)]
+
+
 class PlanView(C.Structure):
     _fields_ = [
         ("n_problems", C.c_int32), ("n_rows", C.c_int32), ("n_groups", C.c_int32), ("n_markers", C.c_int32),
@@ -99,6 +104,7 @@ EXPORTS = [
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
+    "spx_dbam_default_options", "spx_dbam_open", "spx_dbam_header", "spx_dbam_start", "spx_dbam_next", "spx_dbam_release", "spx_dbam_stats", "spx_dbam_close",
     "spx_sam_write_group_of", "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
 ]
 
@@ -208,6 +214,19 @@ def lib():
     L.spx_fasta_ref.restype = C.POINTER(SpxRef)
     L.spx_fasta_free.argtypes = [vp]
     L.spx_fasta_free.restype = None
+    if hasattr(L, "spx_dbam_open"):
+        L.spx_dbam_default_options.argtypes = [C.POINTER(DbamOptions)]
+        L.spx_dbam_default_options.restype = None
+        L.spx_dbam_open.argtypes = [C.c_char_p, C.POINTER(DbamOptions), C.POINTER(vp)]
+        L.spx_dbam_header.argtypes = [vp]
+        L.spx_dbam_header.restype = vp
+        L.spx_dbam_start.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(SpxParams)]
+        L.spx_dbam_next.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.POINTER(SpxBatch))]
+        L.spx_dbam_release.argtypes = [vp, C.POINTER(SpxBatch)]
+        L.spx_dbam_stats.argtypes = [vp, _i64p, _i64p, _f64p]
+        L.spx_dbam_stats.restype = None
+        L.spx_dbam_close.argtypes = [vp]
+        L.spx_dbam_close.restype = None
     L.spx_apply_quals.argtypes = [vp, vp, C.c_int32, C.POINTER(SpxBatch), _u8p]
     L.spx_sam_open.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
     L.spx_sam_write_group.argtypes = [vp, vp, C.c_int32, _u8p]
@@ -413,6 +432,58 @@ class Pipe:
     def close(self):
         if self.h:
             lib().spx_pipe_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StagedWork(Work):
+    """a work list staged by the device input (spx_dbam_next): same handle, owned by the caller"""
+
+    def __init__(self, ctx, handle, n, params):
+        self.ctx = ctx
+        self.params = params
+        self.h = handle
+        self.n = n
+
+
+class DeviceBam:
+    """device-resident BAM input (spx_dbam_*): staged work lists + name batches in file order"""
+
+    def __init__(self, path, ctxs, params, ref, **opts):
+        L = lib()
+        o = DbamOptions()
+        L.spx_dbam_default_options(C.byref(o))
+        for k, v in opts.items():
+            setattr(o, k, v)
+        self.h = C.c_void_p()
+        _chk(L.spx_dbam_open(os.fsencode(path), C.byref(o), C.byref(self.h)), "spx_dbam_open")
+        self.ctxs = list(ctxs)
+        self.params = params
+        self.missing = L.spx_bam_bind_reference(L.spx_dbam_header(self.h), ref)
+        arr = (C.c_void_p * len(self.ctxs))(*[c.h for c in self.ctxs])
+        _chk(L.spx_dbam_start(self.h, arr, len(self.ctxs), C.byref(params)), "spx_dbam_start")
+
+    def next(self):
+        """(StagedWork, ctx index, POINTER(SpxBatch) names, n groups) or None at the end of the file"""
+        w, k, nb = C.c_void_p(), C.c_int32(0), C.POINTER(SpxBatch)()
+        n = lib().spx_dbam_next(self.h, C.byref(w), C.byref(k), C.byref(nb))
+        if n < 0:
+            raise SpxError(n, "spx_dbam_next")
+        if n == 0:
+            return None
+        return StagedWork(self.ctxs[k.value], w, n, self.params), k.value, nb, n
+
+    def release(self, names):
+        lib().spx_dbam_release(self.h, names)
+
+    def close(self):
+        if self.h:
+            lib().spx_dbam_close(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

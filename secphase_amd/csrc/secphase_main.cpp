@@ -95,6 +95,7 @@ static struct option long_options[] = {{"inputBam", required_argument, NULL, 'i'
                                        {"device", required_argument, NULL, 1002},
                                        {"devices", required_argument, NULL, 1003},
                                        {"gpuInflate", required_argument, NULL, 1004},
+                                       {"hostInput", no_argument, NULL, 1005},
                                        {NULL, 0, NULL, 0}};
 
 static void usage(const char *prog)
@@ -115,7 +116,9 @@ static void usage(const char *prog)
             "         --device               GPU index [0]\n"
             "         --devices              several GPUs, e.g. 0-7 or 0,2,5: batches are dealt round-robin, the output is\n"
             "                                the same file-order list\n"
-            "         --gpuInflate           BGZF inflate workers per GPU beside the host threads [8]; 0: host only\n"
+            "         --gpuInflate           (with --hostInput) BGZF inflate workers per GPU beside the host threads [8]; 0: host only\n"
+            "         --hostInput            read, inflate and parse the BAM on the host (the round-3 reader) instead of on the\n"
+            "                                device(s); implied by --writeBam\n"
             "         --writeBam, -w         Write <prefix>.quality_modified.out.bam (SAM text, as the reference does) with\n"
             "                                the base qualities modified by BAQ\n"
             "Not supported by this build: --inputVcf/-v, --variantBed/-B, -g, -G (variant mode)\n");
@@ -132,6 +135,7 @@ int main(int argc, char *argv[])
     par.conf_b = 20; par.flank_margin = 500;
     std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
     bool preset_ont = false, preset_hifi = false, marker_mode = true, write_bam = false, batch_given = false;
+    bool host_input = getenv("SPX_HOST_INPUT") != nullptr;
     int threads = 4, groups_per_batch = 16384, gpu_inflate = 8, c;
     if (const char *e = getenv("SPX_GPU_INFLATE")) gpu_inflate = atoi(e);
     std::vector<int> devices;
@@ -182,6 +186,7 @@ int main(int argc, char *argv[])
         case 'M': marker_mode = false; break;
         case 1001: groups_per_batch = atoi(optarg); batch_given = true; break;
         case 1004: gpu_inflate = atoi(optarg); break;
+        case 1005: host_input = true; break;
         case 1002: case 1003:
             if (!parse_devices(optarg)) { fprintf(stderr, "[%s] cannot parse the device list %s\n", timestamp(), optarg); return 1; }
             break;
@@ -248,11 +253,25 @@ int main(int argc, char *argv[])
     bo.keep_batches = n_dev * (depth + 1) + 2 * n_dev + 6;
     bo.ahead_batches = 3; /* the reader keeps cutting batches while the devices start up */
     if (const char *e = getenv("SPX_BAM_AHEAD")) bo.ahead_batches = std::max(1, atoi(e));
+    /* The input side.  Default: DEVICE-RESIDENT -- the host sends compressed BGZF blocks, inflate / record chain / fields /
+     * name groups / dispatch filter / staging run on the device(s), one input pipeline per GPU (spx_devin.cpp).  --hostInput
+     * (and -w, whose output needs every record's bytes on the host): the round-3 host reader. */
+    const bool dev_input = marker_mode && !write_bam && !host_input;
+    auto die = [](int code) { fflush(NULL); _exit(code); }; /* (reader / pool / context threads are running: no static destructors under them) */
     spx_bam_reader *bam = nullptr;
-    if (spx_bam_open_opts(inputPath.c_str(), &bo, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); return 1; }
+    spx_dbam *dbam = nullptr;
+    if (dev_input) {
+        spx_dbam_options dopt;
+        spx_dbam_default_options(&dopt);
+        dopt.threads = std::max(1, std::min(threads, spx_effective_cpus()));
+        if (batch_given) dopt.max_groups = groups_per_batch;
+        dopt.ahead = 2;
+        if (spx_dbam_open(inputPath.c_str(), &dopt, &dbam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_last_error()); join_ctx(); die(1); }
+        bam = spx_dbam_header(dbam);
+    } else if (spx_bam_open_opts(inputPath.c_str(), &bo, &bam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); return 1; }
     const double t_bam_open = now_s();
     spx_fasta *fa = nullptr;
-    if (spx_fasta_load(fastaPath.c_str(), &fa) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); return 1; }
+    if (spx_fasta_load(fastaPath.c_str(), &fa) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error()); join_ctx(); die(1); }
     const spx_ref *ref = spx_fasta_ref(fa);
     const double t_fasta = now_s();
     int missing = spx_bam_bind_reference(bam, ref);
@@ -262,14 +281,14 @@ int main(int argc, char *argv[])
     if (write_bam && spx_sam_open(out_path(".quality_modified.out.bam").c_str(), bam, &sam) != SPX_OK) {
         fprintf(stderr, "[%s] %s\n", timestamp(), spx_io_last_error());
         join_ctx();
-        return 1;
+        die(1);
     }
 
     join_ctx();
     const double t_ctx = now_s();
     int rc = SPX_OK;
     for (int d = 0; d < n_dev; ++d)
-        if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); return 1; }
+        if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); die(1); }
     { /* the assembly into every device's HBM, in parallel */
         std::vector<std::thread> th;
         for (int d = 0; d < n_dev; ++d)
@@ -279,13 +298,13 @@ int main(int argc, char *argv[])
             });
         for (auto &t : th) t.join();
         for (int d = 0; d < n_dev; ++d)
-            if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); return 1; }
+            if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); die(1); }
     }
     const double t_ref = now_s();
     /* BGZF inflate on the device(s) beside the host pool: the host pool claims chunks from the front of the reader's queue, idle device
      * workers from its back */
     struct InflateRoute { std::vector<spx_inflater *> inf; int per_dev = 0; } route;
-    if (gpu_inflate > 0 && marker_mode) {
+    if (gpu_inflate > 0 && marker_mode && !dev_input) {
         /* the reader takes at most 32 device workers in all: with many devices each contributes fewer */
         route.per_dev = std::max(1, std::min(std::min(gpu_inflate, 16), 32 / n_dev));
         for (int d = 0; d < n_dev && (int)route.inf.size() * route.per_dev + route.per_dev <= 32; ++d) {
@@ -330,8 +349,12 @@ int main(int argc, char *argv[])
     for (int d = 0; d < n_dev && marker_mode; ++d)
         if ((rc = spx_pipe_create(ctxs[(size_t)d], &par, depth, stage_threads, &pipes[(size_t)d])) != SPX_OK) {
             fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
-            return 1;
+            die(1);
         }
+    if (dev_input && (rc = spx_dbam_start(dbam, ctxs.data(), n_dev, &par)) != SPX_OK) {
+        fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
+        die(1);
+    }
     /* BED bookkeeping (marker arrays come back from the device) and the release of a work list's device memory happen on
      * a helper thread: the sets are order-independent (sorted and merged at the end), only the counts come back */
     struct Post { spx_work *w; int lane; const spx_batch *bt; std::vector<spx_group_out> out; };
@@ -356,7 +379,8 @@ int main(int argc, char *argv[])
             /* the queue is FIFO and this is its only consumer: the list grows in file order */
             const double t9 = now_s();
             if (spx_write_relabel_log(log_path.c_str(), "a", ps.bt, ref, ps.out.data()) != SPX_OK) post_failed = true;
-            spx_bam_release_batch(bam, ps.bt); /* its share of the inflate arena is recycled */
+            if (dev_input) spx_dbam_release(dbam, ps.bt);
+            else spx_bam_release_batch(bam, ps.bt); /* its share of the inflate arena is recycled */
             const double ta = now_s();
             const double cpu0 = thread_cpu_s();
             const int nm = spx_relabel_blocks(ps.w, ref, ps.out.data(), bed_mod, bed_mk);
@@ -385,31 +409,51 @@ int main(int argc, char *argv[])
     long long submitted = 0, received = 0;
     std::vector<spx_group_out> out;
     int fail_rc = 0;
+    struct Sub { const spx_batch *bt; int lane; int ng; };
+    std::deque<Sub> order; /* submissions in file order: which pipeline holds them */
+    /* the next batch, fetched but not yet submitted: the device input deals segments to whichever GPU is free, so several
+     * lists in a row may belong to ONE pipeline -- a full pipeline is drained (oldest submission first, in file order)
+     * before the batch goes in, instead of blocking in spx_pipe_submit with nobody left to take results */
+    struct { bool have = false; const spx_batch *bt = nullptr; spx_work *staged = nullptr; int32_t lane = 0; int ng = 0; } nxt;
     for (;;) {
-        while (!eof && submitted - received < (long long)n_dev * (depth + 1)) {
-            const spx_batch *bt = nullptr;
+        if (!nxt.have && !eof && submitted - received < (long long)n_dev * (depth + 1)) {
+            nxt.lane = (int32_t)(submitted % n_dev);
+            nxt.staged = nullptr;
             double t0 = now_s();
-            int ng = spx_bam_next_batch(bam, groups_per_batch, &bt);
+            nxt.ng = dev_input ? spx_dbam_next(dbam, &nxt.staged, &nxt.lane, &nxt.bt) : spx_bam_next_batch(bam, groups_per_batch, &nxt.bt);
             t_read += now_s() - t0;
-            if (ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), spx_io_last_error()); fail_rc = 1; break; }
-            if (ng == 0) { eof = true; break; }
-            n_alns += bt->n_alns;
-            n_reads += ng;
-            if (!marker_mode) { spx_bam_release_batch(bam, bt); continue; }
-            if ((rc = spx_pipe_submit(pipes[(size_t)(submitted % n_dev)], &bt, 1, nullptr, 0, (void *)bt)) != SPX_OK) {
+            if (nxt.ng < 0) { fprintf(stderr, "[%s] BAM read error: %s\n", timestamp(), dev_input ? spx_last_error() : spx_io_last_error()); fail_rc = 1; break; }
+            if (nxt.ng == 0) { eof = true; continue; }
+            n_alns += nxt.bt->n_alns;
+            n_reads += nxt.ng;
+            if (!marker_mode) { spx_bam_release_batch(bam, nxt.bt); continue; }
+            nxt.have = true;
+        }
+        if (nxt.have && spx_pipe_pending(pipes[(size_t)nxt.lane]) < depth + 1) {
+            rc = dev_input ? spx_pipe_submit(pipes[(size_t)nxt.lane], nullptr, 0, nxt.staged, nxt.ng, (void *)nxt.bt)
+                           : spx_pipe_submit(pipes[(size_t)nxt.lane], &nxt.bt, 1, nullptr, 0, (void *)nxt.bt);
+            if (rc != SPX_OK) {
                 fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
                 fail_rc = 1;
                 break;
             }
+            order.push_back(Sub{nxt.bt, nxt.lane, nxt.ng});
             ++submitted;
+            nxt.have = false;
+            continue;
         }
-        if (fail_rc || submitted == received) break;
-        const int lane = (int)(received % n_dev);
+        if (submitted == received) {
+            if (eof && !nxt.have) break;
+            continue;
+        }
+        const Sub sub = order.front();
+        order.pop_front();
+        const int lane = sub.lane;
         spx_work *w = nullptr;
         void *tag = nullptr;
         double t0 = now_s();
-        out.resize((size_t)groups_per_batch + 1);
-        const int ng = spx_pipe_next(pipes[(size_t)lane], out.data(), groups_per_batch, &w, &tag);
+        out.resize((size_t)sub.ng + 1);
+        const int ng = spx_pipe_next(pipes[(size_t)lane], out.data(), sub.ng, &w, &tag);
         t_wait += now_s() - t0;
         ++received;
         if (ng < 0) { fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(ng), spx_last_error()); fail_rc = 1; break; }
@@ -460,7 +504,7 @@ int main(int argc, char *argv[])
     stop_post();
     n_modified = post_modified;
     for (spx_pipe *p : pipes) if (p) spx_pipe_destroy(p);
-    if (fail_rc || post_failed) return 1;
+    if (fail_rc || post_failed) die(1);
     fprintf(stderr, "[%s] time in the scoring loop: %.3f s (BAM read+inflate not hidden by the read-ahead %.3f, waiting for results %.3f, "
                     "finalise+write %.3f); on pipeline threads: staging %.3f; GPU kernels %.3f; %d device(s)\n", timestamp(), now_s() - t_start, t_read, t_wait, t_out, t_hostprep, t_kernel, n_dev);
     if (getenv("SPX_TIMING"))
@@ -481,14 +525,22 @@ int main(int argc, char *argv[])
     spx_finalizer_free(fin);
     if (sam && spx_sam_close(sam) != SPX_OK) { fprintf(stderr, "[%s] could not finish the quality-modified output\n", timestamp()); return 1; }
     const double t_end1 = now_s();
-    if (getenv("SPX_TIMING")) {
+    if (getenv("SPX_TIMING") && !dev_input) {
         int64_t ch = 0, cd = 0;
         spx_bam_inflate_counts(bam, &ch, &cd);
         fprintf(stderr, "[%s] inflate chunks: %lld on the host pool, %lld on the device(s)\n", timestamp(), (long long)ch, (long long)cd);
     }
+    if (getenv("SPX_TIMING") && dev_input) {
+        int64_t nseg = 0, up = 0;
+        double sec[7] = {0};
+        spx_dbam_stats(dbam, &nseg, &up, sec);
+        fprintf(stderr, "[%s] device input: %lld segments, %.2f GB of compressed bytes uploaded; summed over the lanes' threads: upload (copies into pinned memory + "
+                        "enqueue) %.3f s, parsing %.3f s = waiting for the carry %.3f + for inflate %.3f + record chain %.3f + fields / groups %.3f + image %.3f\n",
+                timestamp(), (long long)nseg, up / 1e9, sec[0], sec[1], sec[2], sec[3], sec[4], sec[5], sec[6]);
+    }
     if (!getenv("SPX_TIDY_EXIT")) {
         const double t_drop0 = now_s();
-        spx_bam_drop_pages(bam); /* in parallel, instead of by the kernel's single-threaded teardown while the parent waits */
+        spx_bam_drop_pages(bam); /* (device input: the header reader owns the mapping) */ /* in parallel, instead of by the kernel's single-threaded teardown while the parent waits */
         const double t_drop = now_s() - t_drop0;
         /* Every output file is complete and closed.  What is left is giving back memory -- tens of GB of inflate arena, pinned
          * staging chunks, device arenas -- page by page (munmap, hipHostFree, hipFree: 0.5-0.7 s), only for the process to
@@ -506,7 +558,8 @@ int main(int argc, char *argv[])
         fflush(NULL);
         _exit(0);
     }
-    spx_bam_close(bam);
+    if (dev_input) spx_dbam_close(dbam); /* (closes its header reader) */
+    else spx_bam_close(bam);
     for (spx_inflater *inf : route.inf) spx_inflater_free(inf);
     const double t_end2 = now_s();
     for (spx_ctx *c_ : ctxs) spx_destroy(c_);

@@ -219,6 +219,9 @@ struct Reader {
     int ahead = 2, keep = SPX_BAM_KEEP;
     bool want_voff = false, check_crc = true;
     size_t soft_cap_slots = 0;
+    bool header_only = false; /* SPX_BAM_HEADER_ONLY: no arena, no walker -- the device-resident input (spx_devin.cpp) reads the mapping itself */
+    size_t start_coff = 0;    /* where the records start: compressed offset of the block, offset inside its inflated bytes */
+    uint32_t start_uoff = 0;
     /* block-chain walk (dispatcher state; reader thread only) */
     size_t populated = 0; /* the mapping is faulted in up to here (tasks on the pool, ahead of the walk) */
     size_t fpos = 0;
@@ -956,6 +959,17 @@ extern "C" int spx_bam_open_opts(const char *path, const spx_bam_options *opt, s
     if (o.end_voffset >= 0) { r->end_coff = (size_t)((uint64_t)o.end_voffset >> 16); r->end_uoff = (uint32_t)(o.end_voffset & 0xffff); }
     if (start_coff > r->fsize) return bail("start offset beyond the end of the file");
     hb.clear(); hb.shrink_to_fit();
+    r->start_coff = start_coff;
+    r->start_uoff = start_uoff;
+    if (o.flags & SPX_BAM_HEADER_ONLY) {
+        r->header_only = true;
+        r->threads = o.threads > 0 ? o.threads : 4;
+        r->check_crc = !(o.flags & SPX_BAM_NO_CRC) && !getenv("SPX_BAM_NOCRC");
+        r->pool.reset(new spx::Pool(r->threads));
+        r->fpos = start_coff;
+        *out = h.release();
+        return SPX_OK;
+    }
     /* ---- configuration ---- */
     r->threads = o.threads > 0 ? o.threads : 4;
     r->ahead = o.ahead_batches > 0 ? o.ahead_batches : 2;
@@ -1056,6 +1070,7 @@ extern "C" int spx_bam_next_batch(spx_bam_reader *h, int32_t max_groups, const s
 {
     if (!h || !out || max_groups <= 0) return SPX_EINVAL;
     Reader *r = &h->r;
+    if (r->header_only) { g_io_err = "reader was opened with SPX_BAM_HEADER_ONLY"; return SPX_EINVAL; }
     Batch *B = nullptr;
     {
         std::unique_lock<std::mutex> lk(r->mu);
@@ -1101,10 +1116,44 @@ extern "C" int spx_bam_release_batch(spx_bam_reader *h, const spx_batch *bt)
     return SPX_EINVAL;
 }
 
+/* internal (spx_devin.cpp): the mapping and where the records start / end in it */
+extern "C" int spx_internal_bam_layout(spx_bam_reader *h, const uint8_t **map, int64_t *fsize, int64_t *start_coff, int32_t *start_uoff,
+                                       int64_t *end_coff, int32_t *end_uoff, int32_t *check_crc)
+{
+    if (!h) return SPX_EINVAL;
+    Reader *r = &h->r;
+    *map = r->map; *fsize = (int64_t)r->fsize; *start_coff = (int64_t)r->start_coff; *start_uoff = (int32_t)r->start_uoff;
+    *end_coff = r->end_coff == (size_t)-1 ? -1 : (int64_t)r->end_coff; *end_uoff = (int32_t)r->end_uoff;
+    *check_crc = r->check_crc ? 1 : 0;
+    return SPX_OK;
+}
+/* internal: the target-id map of spx_bam_bind_reference (n entries) */
+extern "C" int32_t spx_internal_bam_tmap(spx_bam_reader *h, int32_t *dst, int32_t cap)
+{
+    if (!h) return 0;
+    Reader *r = &h->r;
+    std::lock_guard<std::mutex> lk(r->mu);
+    const int32_t n = (int32_t)r->tmap.size();
+    for (int32_t i = 0; i < n && i < cap; ++i) dst[i] = r->tmap[(size_t)i];
+    return n;
+}
+/* internal: a task on the reader's thread pool (faulting the mapping in ahead of the device input, copies into pinned memory) */
+extern "C" void spx_internal_bam_parallel(spx_bam_reader *h, int64_t n, int64_t grain, void (*fn)(void *, int64_t, int64_t), void *user)
+{
+    if (!h || !h->r.pool) { fn(user, 0, n); return; }
+    h->r.pool->parallel_for(n, grain, [&](int64_t a, int64_t b) { fn(user, a, b); });
+}
+extern "C" void spx_internal_bam_submit(spx_bam_reader *h, void (*fn)(void *), void *user)
+{
+    if (!h || !h->r.pool) { fn(user); return; }
+    h->r.pool->submit([fn, user] { fn(user); });
+}
+
 extern "C" int spx_bam_attach_device_inflate(spx_bam_reader *h, spx_bgzf_inflate_fn fn, void *user, int32_t n_workers)
 {
     if (!h || !fn || n_workers < 1 || n_workers > 32) return SPX_EINVAL;
     Reader *r = &h->r;
+    if (r->header_only) return SPX_EINVAL;
     std::lock_guard<std::mutex> lk(r->mu);
     if (r->dev_fn) return SPX_EINVAL;
     r->dev_user = user;

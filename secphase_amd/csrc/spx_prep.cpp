@@ -354,17 +354,22 @@ int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, S
         spxl::aln_caps(st.recs[(size_t)s], oc, cc, mc);
         L.ops_bound += oc; L.conf_bound += cc; L.mm_bound += mc;
     }
+    stage_layout_offsets(L);
+    return SPX_OK;
+}
+
+void stage_layout_offsets(StageLayout &L)
+{
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
-    L.o_recs = take((size_t)ns * sizeof(spxl::Rec));
+    L.o_recs = take((size_t)L.n_slots * sizeof(spxl::Rec));
     L.o_slot0 = take(((size_t)L.n_dgroups + 1) * 4);
     L.o_gidx = take((size_t)L.n_dgroups * 4);
-    L.o_cigar = take((size_t)cw * 4 + 16);
-    L.o_seq = take((size_t)sb + 16);
-    L.o_qual = take((size_t)qb + 16);
-    L.o_text = take((size_t)tb + 16);
+    L.o_cigar = take((size_t)L.cigar_words * 4 + 16);
+    L.o_seq = take((size_t)L.seq_bytes + 16);
+    L.o_qual = take((size_t)L.qual_bytes + 16);
+    L.o_text = take((size_t)L.text_bytes + 16);
     L.bytes = o;
-    return SPX_OK;
 }
 
 void stage_copy(const Stage &st, char *dst, int threads)

@@ -91,6 +91,8 @@ struct Stage {
 };
 /* measure: dispatch filter, per-alignment payload sizes (strlen of the tags), layout */
 int stage_measure(const spx_batch *const *bts, int32_t n_batches, int threads, Stage &st);
+/* byte offsets of the image's sections from its counts (n_slots, n_dgroups, cigar_words, seq / qual / text bytes) */
+void stage_layout_offsets(StageLayout &L);
 /* copy the payload into dst (lay.bytes bytes) on `threads` threads */
 void stage_copy(const Stage &st, char *dst, int threads);
 /* The same image piecewise, for staging through a ring of pinned chunks: byte range [b0, b1) of payload section `sec`

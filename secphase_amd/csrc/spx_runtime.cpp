@@ -27,6 +27,7 @@
 #include "spx_device.h"
 #include "spx_prep.h"
 #include "spx_prep_dev.h"
+#include "spx_devin.h"
 #include "spx_cpuacc.h"
 #include "spx_pool.h"
 
@@ -279,6 +280,8 @@ extern "C" int spx_internal_work_claim(spx_work *w, int claim)
     int expect = 0;
     return w->in_pipe.compare_exchange_strong(expect, 1) ? SPX_OK : SPX_EINVAL;
 }
+
+extern "C" int spx_internal_ctx_device(spx_ctx *c) { return c ? c->device : -1; }
 
 extern "C" int spx_device_count(void)
 {
@@ -987,6 +990,89 @@ extern "C" int spx_stage(spx_ctx *c, const spx_batch *const *bts, int32_t n_batc
     rc = spx_internal_stage_finish(c, w);
     if (rc != SPX_OK) { spx_work_free(c, w); return rc; }
     *out = w;
+    return SPX_OK;
+}
+
+/* ---- records staged BY THE DEVICE (spx_devin.cpp: BGZF blocks inflated in HBM, record chain / fields / tags / dispatch
+ * filter / gather as kernels).  begin: a work list with the image's layout from the device-side counts and the memory of
+ * part A; the caller's kernels then write the image (O points into it) and `info_bytes` of host-bound data behind it.
+ * finish: the host-side vectors from the dispatch flags, pad fills and the staged event on the caller's stream. ---- */
+struct spx_devstage_sizes {
+    int64_t n_groups_in, n_dgroups, n_slots, cigar_words, seq_bytes, qual_bytes, text_bytes, ops_bound, conf_bound, mm_bound, info_bytes;
+};
+extern "C" int spx_internal_devstage_begin(spx_ctx *c, const spx_params *par, const spx_devstage_sizes *sz, spx_work **out, spx_din_out *O, char **d_info)
+{
+    if (!c || !par || !sz || !out || !O || !d_info) return fail(SPX_EINVAL, "NULL argument");
+    if (!c->d_ref4) return fail(SPX_ENOREF, "spx_set_reference has not been called");
+    *out = nullptr;
+    if (sz->n_slots > SPX_MAX_STAGE_SLOTS || sz->n_dgroups > SPX_MAX_STAGE_SLOTS || sz->n_groups_in > 0x7fffffff)
+        return fail(SPX_EINVAL, "more than 2^20 alignments in one work list");
+    HIPCHK(hipSetDevice(c->device));
+    spx_work *w = new spx_work();
+    memset(&w->st, 0, sizeof w->st);
+    memset(&w->pa, 0, sizeof w->pa);
+    memset(&w->tot, 0, sizeof w->tot);
+    w->par = *par;
+    w->owner = c;
+    spx::StageLayout &L = w->stage.lay;
+    L = spx::StageLayout();
+    L.n_groups_in = sz->n_groups_in; L.n_dgroups = sz->n_dgroups; L.n_slots = sz->n_slots;
+    L.cigar_words = sz->cigar_words; L.seq_bytes = sz->seq_bytes; L.qual_bytes = sz->qual_bytes; L.text_bytes = sz->text_bytes;
+    L.pk_seq_bytes = sz->seq_bytes; L.pk_qual_bytes = sz->qual_bytes;
+    L.ops_bound = sz->ops_bound; L.conf_bound = sz->conf_bound; L.mm_bound = sz->mm_bound;
+    spx::stage_layout_offsets(L);
+    w->n_groups_in = (int32_t)L.n_groups_in;
+    w->n_dgroups = (int32_t)L.n_dgroups;
+    w->st.n_groups = w->n_groups_in;
+    w->stage_threads = 1;
+    Carver cv;
+    const size_t ns = (size_t)L.n_slots, ng = (size_t)L.n_dgroups;
+    (void)cv.take<char>(L.bytes + 64);
+    w->o_code = cv.take<char>((size_t)(spx::kCodeLeadBytes + L.seq_bytes + spx::kCodeTailBytes));
+    w->o_ast = cv.take<spxl::AlnState>(ns + 1);
+    w->o_gc = cv.take<spxl::GroupCount>(ng + 1);
+    w->o_ac = cv.take<spxl::GroupCount>(ns + 1);
+    w->o_gab = cv.take<int64_t>(ng + 1);
+    w->o_gao = cv.take<int64_t>(ng + 1);
+    w->o_base = cv.take<spxl::PlanBase>(ns + 1);
+    w->o_mkb = cv.take<int64_t>(ng + 2);
+    w->o_scan = cv.take<int64_t>(5 * (std::max(ns, ng) + 8) + 5 * 1024 + 16);
+    const size_t o_info = cv.take<char>((size_t)sz->info_bytes + 64);
+    w->in_arena = arena_get(c, cv.off + 256, &w->in_cap);
+    if (!w->in_arena) { delete w; return fail(SPX_ENOMEM, "device memory for the staged records"); }
+    char *base = (char *)w->in_arena;
+    memset(O, 0, sizeof *O);
+    O->recs = (spxl::Rec *)(base + L.o_recs);
+    O->slot0 = (int32_t *)(base + L.o_slot0);
+    O->gidx = (int32_t *)(base + L.o_gidx);
+    O->cigar = (uint32_t *)(base + L.o_cigar);
+    O->seq = (uint8_t *)(base + L.o_seq);
+    O->qual = (uint8_t *)(base + L.o_qual);
+    O->text = base + L.o_text;
+    *d_info = base + o_info;
+    *out = w;
+    return SPX_OK;
+}
+
+extern "C" int spx_internal_devstage_finish(spx_ctx *c, spx_work *w, const uint8_t *grp_disp, hipStream_t st)
+{
+    if (!c || !w || w->staged || !w->in_arena) return fail(SPX_EINVAL, "work list is not waiting for its records");
+    HIPCHK(hipSetDevice(c->device));
+    const spx::StageLayout &L = w->stage.lay;
+    w->stage.grp_error.assign((size_t)L.n_groups_in, 1);
+    w->stage.grp_index.clear();
+    w->stage.grp_index.reserve((size_t)L.n_dgroups);
+    for (int64_t g = 0; g < L.n_groups_in; ++g)
+        if (grp_disp[g]) { w->stage.grp_error[(size_t)g] = 0; w->stage.grp_index.push_back((int32_t)g); }
+    if ((int64_t)w->stage.grp_index.size() != L.n_dgroups) return fail(SPX_EINVAL, "dispatch flags do not match the device's count");
+    w->hb.grp_error = w->stage.grp_error;
+    char *base = (char *)w->in_arena;
+    HIPCHK(hipMemsetAsync(base + w->o_code, 0, (size_t)spx::kCodeLeadBytes, st));
+    HIPCHK(hipMemsetAsync(base + w->o_code + spx::kCodeLeadBytes + ((L.seq_bytes + 3) & ~(int64_t)3), 0, (size_t)spx::kCodeTailBytes - 8, st));
+    HIPCHK(hipEventCreateWithFlags(&w->ev_staged, hipEventDisableTiming | hipEventBlockingSync));
+    HIPCHK(hipEventRecord(w->ev_staged, st));
+    w->st.bytes_h2d = (int64_t)L.bytes;
+    w->staged = true;
     return SPX_OK;
 }
 

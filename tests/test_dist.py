@@ -244,13 +244,15 @@ def test_bench_two_ranks_write_the_list_one_process_writes(built, tmp_path):
     from secphase_amd import api, records, synth
     keep = str(tmp_path / "bench2.out.log")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--platform", "mixed", "--steps", "2", "--warmup", "1",
-           "--groups-per-step", "2048", "--keep-log", keep, "--no-build"]
+           "--groups-per-step", "2048", "--keep-log", keep, "--no-build", "--no-host-input-leg"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=dict(os.environ, GPU_MAX_HW_QUEUES="14"))
     assert p.returncode == 0, (p.stdout[-400:], p.stderr[-1200:])
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
     assert line["n_gpus"] == 2 and line["config"]["verified_timed_groups"] >= 256
     assert line["config"]["verified_own_relabel_list"]["oracle_list_is_byte_prefix_of_this_runs_list"] is True
     assert line["config"]["sharding"]["imbalance_by_cost"] < line["config"]["sharding"]["imbalance_by_count"] + 1e-9
+    # the N > 1 line carries SURVEY 8(d)'s metric too: the command line on the job's devices, its list checked against the oracle
+    assert line["from_bam"]["rc"] == 0 and line["from_bam"]["out_log_identical_to_oracle"] is True and line["metric_8d"]["groups_per_s"] > 0
     man = [json.load(open(f"{keep}.rank{r}.json")) for r in range(2)]
     assert man[0]["sequence"] == man[1]["sequence"] and len(man[0]["sequence"]) >= 3 + 2
     g = synth.Genome(synth.default_cfg(synth.MIXED))

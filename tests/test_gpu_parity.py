@@ -514,10 +514,11 @@ def test_command_line_several_devices(ctx, tmp_path):
             mxs = max(e.score[a] for a in sec)
             ties += sum(1 for a in sec if e.score[a] >= mxs) > 1
     assert ties > 0 and nre > 5
-    for devs, batch in (("0,0,0", "17"), ("0-0", "40"), ("0,0", "1000")):
-        outd = str(tmp_path / f"out_{batch}")
+    for devs, batch, extra, env in (("0,0,0", "17", [], {}), ("0-0", "40", [], {}), ("0,0", "1000", [], {"SPX_DIN_SEG_KB": "128"}),
+                                    ("0,0,0", "17", ["--hostInput"], {}), ("0,0", "1000", ["--hostInput"], {})):
+        outd = str(tmp_path / f"out_{batch}_{len(extra)}_{len(env)}")
         p = subprocess.run([exe, "--hifi", "-p", "5", "-@", "4", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t", "--devices", devs,
-                            "--groupsPerBatch", batch], capture_output=True, text=True, timeout=600)
+                            "--groupsPerBatch", batch] + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr
         assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False), devs
         assert filecmp.cmp(bm_o, os.path.join(outd, "t.modified_read_blocks.markers.bed"), shallow=False)
@@ -545,7 +546,7 @@ def test_command_line_with_device_inflate(ctx, tmp_path):
     env = dict(os.environ, SPX_GPU_INFLATE_FIRST="1", SPX_BAM_DEVICE_ALL="1", SPX_BAM_CHUNK_KB="64", SPX_TIMING="1")
     outd = str(tmp_path / "out")
     p = subprocess.run([exe, "--hifi", "-@", "4", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t", "--groupsPerBatch", "37",
-                        "--gpuInflate", "3"], capture_output=True, text=True, timeout=600, env=env)
+                        "--gpuInflate", "3", "--hostInput"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr
     import re
     m = re.search(r"inflate chunks: (\d+) on the host pool, (\d+) on the device", p.stderr)
@@ -557,9 +558,9 @@ def test_command_line_with_device_inflate(ctx, tmp_path):
     blob[len(blob) // 2] ^= 0x20
     bad = str(tmp_path / "bad.bam")
     open(bad, "wb").write(bytes(blob))
-    for e in (env, dict(os.environ)):
+    for e, extra in ((env, ["--hostInput"]), (dict(os.environ), ["--hostInput"]), (dict(os.environ), [])):
         p = subprocess.run([exe, "--hifi", "-@", "4", "-i", bad, "-f", fa, "--outDir", str(tmp_path / "outbad"), "--prefix", "t",
-                            "--groupsPerBatch", "37"], capture_output=True, text=True, timeout=600, env=e)
+                            "--groupsPerBatch", "37"] + extra, capture_output=True, text=True, timeout=600, env=e)
         assert p.returncode != 0 and "BAM read error" in p.stderr, p.stderr[-300:]
 
 
@@ -576,13 +577,17 @@ def _cli_parity(tmp_path, g, n_groups, chunk, flags, par, tag, env=None, min_rel
     log_o, bm_o, bk_o = (str(tmp_path / f"{tag}.{n}") for n in ("o.log", "o.mod.bed", "o.mk.bed"))
     nre, _ = orc.run_batch(whole.batch, g.ref, par, threads=8, seed=1, log_path=log_o, bed_modified=bm_o, bed_markers=bk_o)
     assert nre >= min_relabelled, nre
-    p = subprocess.run([exe] + flags + ["-@", "8", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t"], capture_output=True, text=True,
-                       timeout=1200, env=dict(os.environ, **(env or {})))
-    assert p.returncode == 0, p.stderr[-600:]
-    assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False), tag
-    assert filecmp.cmp(bm_o, os.path.join(outd, "t.modified_read_blocks.markers.bed"), shallow=False), tag
-    assert filecmp.cmp(bk_o, os.path.join(outd, "t.marker_blocks.bed"), shallow=False), tag
-    assert f"Number of reads modified by marker score = {nre}" in p.stderr
+    # both input sides: device-resident (the default: inflate, record chain, fields, dispatch filter, staging as kernels) and the host reader
+    for extra in ([], ["--hostInput"]):
+        import shutil
+        shutil.rmtree(outd, ignore_errors=True)
+        p = subprocess.run([exe] + flags + extra + ["-@", "8", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t"], capture_output=True, text=True,
+                           timeout=1200, env=dict(os.environ, **(env or {})))
+        assert p.returncode == 0, (extra, p.stderr[-600:])
+        assert filecmp.cmp(log_o, os.path.join(outd, "t.out.log"), shallow=False), (tag, extra)
+        assert filecmp.cmp(bm_o, os.path.join(outd, "t.modified_read_blocks.markers.bed"), shallow=False), (tag, extra)
+        assert filecmp.cmp(bk_o, os.path.join(outd, "t.marker_blocks.bed"), shallow=False), (tag, extra)
+        assert f"Number of reads modified by marker score = {nre}" in p.stderr
     return p
 
 
