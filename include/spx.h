@@ -361,6 +361,9 @@ typedef struct spx_dbam_options {
     int32_t max_groups;     /* groups per work list at most [95 000 = the cap]; a segment with more is handed out as several lists */
     int32_t ahead;          /* finished segments per device that may wait for the caller [3] */
     int32_t flags;          /* SPX_BAM_NO_CRC */
+    int32_t host_inflate_percent; /* share of every segment's inflated bytes that the HOST pool inflates and uploads raw, beside the
+                                   * inflate kernel; -1: from the CPUs the process may use and the number of devices */
+    int32_t reserved;
     int64_t segment_bytes;  /* inflated bytes per segment [1 GB] */
     int64_t carry_bytes;    /* room for the open group + a continuing record in front of a segment [256 MB]; also the largest record */
     int64_t start_voffset, end_voffset; /* shard of the file, as in spx_bam_options; -1: all of it */

@@ -70,7 +70,7 @@ _f64p = C.POINTER(C.c_double)
 
 class DbamOptions(C.Structure):
     _fields_ = [("threads", C.c_int32), ("max_groups", C.c_int32), ("ahead", C.c_int32), ("flags", C.c_int32),
-                ("segment_bytes", C.c_int64), ("carry_bytes", C.c_int64), ("start_voffset", C.c_int64), ("end_voffset", C.c_int64)]
+                ("host_inflate_percent", C.c_int32), ("reserved", C.c_int32), ("segment_bytes", C.c_int64), ("carry_bytes", C.c_int64), ("start_voffset", C.c_int64), ("end_voffset", C.c_int64)]
 
 
 class PlanView(C.Structure):

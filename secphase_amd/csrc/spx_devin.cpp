@@ -47,6 +47,7 @@ extern "C" int spx_internal_bam_layout(spx_bam_reader *h, const uint8_t **map, i
 extern "C" int32_t spx_internal_bam_tmap(spx_bam_reader *h, int32_t *dst, int32_t cap);
 extern "C" void spx_internal_bam_parallel(spx_bam_reader *h, int64_t n, int64_t grain, void (*fn)(void *, int64_t, int64_t), void *user);
 extern "C" void spx_internal_bam_submit(spx_bam_reader *h, void (*fn)(void *), void *user);
+extern "C" int spx_internal_inflate_block(const uint8_t *src, size_t clen, uint8_t *dst, size_t ulen, uint32_t crc, int check_crc);
 extern "C" void spx_internal_set_error(const char *msg);
 extern "C" int spx_internal_ctx_device(spx_ctx *c);
 struct spx_devstage_sizes {
@@ -91,6 +92,7 @@ struct Seg {
     int64_t stop_at = -1;        /* shard end (end_voffset): the records end this far into the inflated bytes */
     bool last = false;
     double t_cut = 0, t_up = 0;
+    size_t n_dev_blocks = 0;     /* blocks [0, n_dev_blocks) are inflated on the device, the rest on the host pool */
 };
 
 struct NameBatch { /* what the host keeps of a work list's groups: a spx_batch with names, flags, targets, positions only */
@@ -137,7 +139,8 @@ struct spx_dbam {
     std::string err;
     bool closing = false;
     std::vector<NameBatch *> free_names, live_names;
-    int64_t bytes_up = 0, n_segments = 0;
+    int64_t bytes_up = 0, n_segments = 0, bytes_host_inflated = 0, bytes_dev_inflated = 0;
+    double host_share = 0; /* fraction of every segment's inflated bytes that the host pool inflates (uploaded raw) */
     double t_parse = 0, t_wait_carry = 0, t_wait_inflate = 0, t_chain = 0, t_groups = 0, t_image = 0, t_upload = 0;
     std::vector<int32_t> tmap;
 };
@@ -154,21 +157,22 @@ struct Lane {
     spx_dbam *D = nullptr;
     spx_ctx *ctx = nullptr;
     int index = 0, device = 0;
-    hipStream_t up_stream = nullptr, inf_stream = nullptr, in_stream = nullptr;
+    hipStream_t up_stream = nullptr, up2_stream = nullptr, inf_stream = nullptr, in_stream = nullptr;
     struct Slot {
         uint8_t *d_buf = nullptr, *d_comp = nullptr;
         size_t buf_cap = 0, comp_cap = 0, nb_cap = 0;
         BlockDesc *d_desc = nullptr;
         int32_t *d_status = nullptr;
         int64_t *d_bstart = nullptr;
-        hipEvent_t ev_inf = nullptr;
+        hipEvent_t ev_inf = nullptr, ev_host = nullptr;
         bool busy = false;
     } slot[kSlots];
-    void *pin[kPins] = {};
-    hipEvent_t pin_ev[kPins] = {};
-    bool pin_busy[kPins] = {};
+    /* two rings of pinned chunks: [0] compressed bytes (uploader thread), [1] host-inflated bytes (helper thread) */
+    void *pin[2][kPins] = {};
+    hipEvent_t pin_ev[2][kPins] = {};
+    bool pin_busy[2][kPins] = {};
     size_t pin_bytes = (size_t)64 << 20;
-    int pin_next = 0;
+    int pin_next[2] = {0, 0};
     /* parse-time pools (grow-only) */
     void *d_pool = nullptr, *d_blk = nullptr, *d_temp = nullptr;
     size_t pool_cap = 0, blk_cap = 0, temp_cap = 0;
@@ -178,11 +182,11 @@ struct Lane {
     spx_din_slot_scan *h_s = nullptr;
     int32_t *d_tmap = nullptr;
     int32_t n_targets = 0;
-    std::thread uploader, parser;
+    std::thread uploader, helper, parser;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<Seg *> parse_q;
-    bool up_done = false;
+    std::deque<Seg *> host_q, parse_q; /* uploader -> helper (the host pool's share of the inflate) -> parser */
+    bool up_done = false, help_done = false;
 
     int fail_here(const std::string &msg, int code)
     {
@@ -203,7 +207,10 @@ struct Lane {
     void carve(spx_din_args &A);
     Seg *cut_segment();
     int upload(Seg *s);
+    int host_part(Seg *s);
+    int pin_chunk(int ring, char **h);
     void uploader_main();
+    void helper_main();
     int parse(Seg *s);
     void parser_main();
 };
@@ -212,9 +219,19 @@ int Lane::init()
 {
     DCHK(hipSetDevice(device));
     DCHK(hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));
-    DCHK(hipStreamCreateWithFlags(&inf_stream, hipStreamNonBlocking));
-    DCHK(hipStreamCreateWithFlags(&in_stream, hipStreamNonBlocking));
-    for (int k = 0; k < kSlots; ++k) DCHK(hipEventCreateWithFlags(&slot[k].ev_inf, hipEventDisableTiming | hipEventBlockingSync));
+    DCHK(hipStreamCreateWithFlags(&up2_stream, hipStreamNonBlocking));
+    /* the inflate grids (tens of thousands of workgroups of ~10 ms each) fill every CU; the small, latency-bound kernels of
+     * the record chain / parse / gather get what frees up FIRST (high priority), the inflate kernel last (low priority:
+     * the scoring kernels of the pipeline, at normal priority, go in front of it too) */
+    int pr_lo = 0, pr_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi); /* lo = numerically greatest = least urgent */
+    if (getenv("SPX_DIN_NO_PRIORITY")) pr_lo = pr_hi = 0;
+    DCHK(hipStreamCreateWithPriority(&inf_stream, hipStreamNonBlocking, pr_lo));
+    DCHK(hipStreamCreateWithPriority(&in_stream, hipStreamNonBlocking, pr_hi));
+    for (int k = 0; k < kSlots; ++k) {
+        DCHK(hipEventCreateWithFlags(&slot[k].ev_inf, hipEventDisableTiming | hipEventBlockingSync));
+        DCHK(hipEventCreateWithFlags(&slot[k].ev_host, hipEventDisableTiming | hipEventBlockingSync));
+    }
     DCHK(hipMalloc((void **)&d_counts, sizeof(spx_din_counts)));
     DCHK(hipHostMalloc((void **)&h_counts, sizeof(spx_din_counts) + 4 * sizeof(spx_din_group_scan) + 4 * sizeof(spx_din_slot_scan), hipHostMallocDefault));
     h_g = (spx_din_group_scan *)(h_counts + 1);
@@ -231,6 +248,7 @@ void Lane::destroy()
     if (in_stream) (void)hipStreamSynchronize(in_stream);
     if (inf_stream) (void)hipStreamSynchronize(inf_stream);
     if (up_stream) (void)hipStreamSynchronize(up_stream);
+    if (up2_stream) (void)hipStreamSynchronize(up2_stream);
     for (int k = 0; k < kSlots; ++k) {
         Slot &S = slot[k];
         if (S.d_buf) (void)hipFree(S.d_buf);
@@ -239,11 +257,13 @@ void Lane::destroy()
         if (S.d_status) (void)hipFree(S.d_status);
         if (S.d_bstart) (void)hipFree(S.d_bstart);
         if (S.ev_inf) (void)hipEventDestroy(S.ev_inf);
+        if (S.ev_host) (void)hipEventDestroy(S.ev_host);
     }
-    for (int k = 0; k < kPins; ++k) {
-        if (pin[k]) (void)hipHostFree(pin[k]);
-        if (pin_ev[k]) (void)hipEventDestroy(pin_ev[k]);
-    }
+    for (int r = 0; r < 2; ++r)
+        for (int k = 0; k < kPins; ++k) {
+            if (pin[r][k]) (void)hipHostFree(pin[r][k]);
+            if (pin_ev[r][k]) (void)hipEventDestroy(pin_ev[r][k]);
+        }
     if (d_pool) (void)hipFree(d_pool);
     if (d_blk) (void)hipFree(d_blk);
     if (d_temp) (void)hipFree(d_temp);
@@ -251,6 +271,7 @@ void Lane::destroy()
     if (h_counts) (void)hipHostFree(h_counts);
     if (d_tmap) (void)hipFree(d_tmap);
     if (up_stream) (void)hipStreamDestroy(up_stream);
+    if (up2_stream) (void)hipStreamDestroy(up2_stream);
     if (inf_stream) (void)hipStreamDestroy(inf_stream);
     if (in_stream) (void)hipStreamDestroy(in_stream);
 }
@@ -431,27 +452,25 @@ int Lane::upload(Seg *s)
     Slot &S = slot[s->slot];
     DCHK(hipSetDevice(device));
     const size_t nb = s->blocks.size();
-    const size_t comp = (size_t)(s->c1 - s->c0);
+    /* The host pool helps: the LAST blocks of the segment (a share of its inflated bytes) are inflated on the host into pinned
+     * memory and uploaded raw; the device inflates the first ones, whose compressed bytes go up first.  (One MI355X inflates
+     * ~13 GB/s beside nothing else; 16 host cores ~9 GB/s: neither alone feeds the scoring kernels.) */
+    size_t nd = nb;
+    if (d->host_share > 0 && nb > 1) {
+        const int64_t want_host = (int64_t)(d->host_share * (double)s->ulen);
+        while (nd > 0 && s->ulen - s->blocks[nd - 1].out_off <= want_host) --nd;
+        if (nd == 0 && d->host_share < 1.0) nd = 1;
+    }
+    s->n_dev_blocks = nd;
+    const size_t comp = nd == nb ? (size_t)(s->c1 - s->c0) : (nd == 0 ? 0 : (size_t)(s->blocks[nd - 1].in_off + s->blocks[nd - 1].clen + 8));
     int rc = ensure_slot(S, (size_t)(d->carry_cap + s->ulen) + 256, comp + 256, nb + 1);
     if (rc) return rc;
     const double t0 = now_s();
     /* compressed bytes through the ring of pinned chunks; the copies run on the reader's pool */
-    auto chunk = [&](char **h) -> int {
-        const int k = pin_next;
-        pin_next = (k + 1) % kPins;
-        if (!pin[k]) {
-            if (hipHostMalloc(&pin[k], pin_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin[k] = nullptr; return -1; }
-            if (hipEventCreateWithFlags(&pin_ev[k], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return -1;
-        }
-        if (pin_busy[k] && hipEventSynchronize(pin_ev[k]) != hipSuccess) return -1;
-        pin_busy[k] = false;
-        *h = (char *)pin[k];
-        return k;
-    };
     struct Cp { char *dst; const uint8_t *src; };
     for (size_t o = 0; o < comp; o += pin_bytes) {
         char *h = nullptr;
-        const int k = chunk(&h);
+        const int k = pin_chunk(0, &h);
         if (k < 0) return fail_here("pinned memory for the compressed bytes", SPX_ENOMEM);
         const size_t n = std::min(pin_bytes, comp - o);
         Cp cp{h, d->map + s->c0 + o};
@@ -463,25 +482,25 @@ int Lane::upload(Seg *s)
             }, &cp);
         }
         DCHK(hipMemcpyAsync(S.d_comp + o, h, n, hipMemcpyHostToDevice, up_stream));
-        DCHK(hipEventRecord(pin_ev[k], up_stream));
-        pin_busy[k] = true;
+        DCHK(hipEventRecord(pin_ev[0][k], up_stream));
+        pin_busy[0][k] = true;
     }
     { /* block table + block starts, through the ring as well */
         char *h = nullptr;
-        const int k = chunk(&h);
+        const int k = pin_chunk(0, &h);
         if (k < 0) return fail_here("pinned memory for the block table", SPX_ENOMEM);
-        const size_t b1 = nb * sizeof(BlockDesc), b2 = (nb + 1) * sizeof(int64_t);
+        const size_t b1 = nd * sizeof(BlockDesc), b2 = (nb + 1) * sizeof(int64_t);
         if (b1 + b2 > pin_bytes) return fail_here("segment has too many blocks", SPX_EINVAL);
         memcpy(h, s->blocks.data(), b1);
         memcpy(h + b1, s->bstart.data(), b2);
-        if (nb) DCHK(hipMemcpyAsync(S.d_desc, h, b1, hipMemcpyHostToDevice, up_stream));
+        if (nd) DCHK(hipMemcpyAsync(S.d_desc, h, b1, hipMemcpyHostToDevice, up_stream));
         DCHK(hipMemcpyAsync(S.d_bstart, h + b1, b2, hipMemcpyHostToDevice, up_stream));
-        DCHK(hipEventRecord(pin_ev[k], up_stream));
-        pin_busy[k] = true;
+        DCHK(hipEventRecord(pin_ev[0][k], up_stream));
+        pin_busy[0][k] = true;
         /* the inflate stream goes on behind the last copy */
-        DCHK(hipStreamWaitEvent(inf_stream, pin_ev[k], 0));
+        DCHK(hipStreamWaitEvent(inf_stream, pin_ev[0][k], 0));
     }
-    if (nb) DCHK(spx_launch_bgzf_inflate(S.d_comp, S.d_desc, (int32_t)nb, S.d_buf + d->carry_cap, S.d_status, d->check_crc, inf_stream));
+    if (nd) DCHK(spx_launch_bgzf_inflate(S.d_comp, S.d_desc, (int32_t)nd, S.d_buf + d->carry_cap, S.d_status, d->check_crc, inf_stream));
     DCHK(hipEventRecord(S.ev_inf, inf_stream));
     s->t_up = now_s();
     {
@@ -491,6 +510,93 @@ int Lane::upload(Seg *s)
         ++d->n_segments;
     }
     return SPX_OK;
+}
+
+int Lane::pin_chunk(int ring, char **h)
+{
+    const int k = pin_next[ring];
+    pin_next[ring] = (k + 1) % kPins;
+    if (!pin[ring][k]) {
+        if (hipHostMalloc(&pin[ring][k], pin_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin[ring][k] = nullptr; return -1; }
+        if (hipEventCreateWithFlags(&pin_ev[ring][k], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return -1;
+    }
+    if (pin_busy[ring][k] && hipEventSynchronize(pin_ev[ring][k]) != hipSuccess) return -1;
+    pin_busy[ring][k] = false;
+    *h = (char *)pin[ring][k];
+    return k;
+}
+
+/* the host's share of a segment (helper thread): runs of blocks whose inflated bytes fill a pinned chunk, inflated on the pool, uploaded raw */
+int Lane::host_part(Seg *s)
+{
+    spx_dbam *d = D;
+    Slot &S = slot[s->slot];
+    DCHK(hipSetDevice(device));
+    const size_t nb = s->blocks.size(), nd = s->n_dev_blocks;
+    int64_t host_bytes = 0;
+    for (size_t q0 = nd; q0 < nb;) {
+        char *h = nullptr;
+        const int k = pin_chunk(1, &h);
+        if (k < 0) return fail_here("pinned memory for the host-inflated bytes", SPX_ENOMEM);
+        const int64_t base = s->blocks[q0].out_off;
+        size_t q1 = q0;
+        while (q1 < nb && s->blocks[q1].out_off + (int64_t)s->blocks[q1].ulen - base <= (int64_t)pin_bytes) ++q1;
+        if (q1 == q0) return fail_here("pinned chunk smaller than a BGZF block", SPX_EINVAL);
+        struct HI { Seg *s; const uint8_t *file; char *dst; int64_t base; size_t q0; int check; std::atomic<int> bad{0}; } hi;
+        hi.s = s; hi.file = d->map + s->c0; hi.dst = h; hi.base = base; hi.q0 = q0; hi.check = d->check_crc;
+        spx_internal_bam_parallel(d->hdr, (int64_t)(q1 - q0), 8, [](void *u, int64_t a, int64_t b) {
+            HI *x = (HI *)u;
+            for (int64_t q = a; q < b; ++q) {
+                const BlockDesc &bd = x->s->blocks[x->q0 + (size_t)q];
+                const int r = spx_internal_inflate_block(x->file + bd.in_off, bd.clen, (uint8_t *)x->dst + (bd.out_off - x->base), bd.ulen, bd.crc, x->check);
+                if (r) x->bad = r;
+            }
+        }, &hi);
+        if (hi.bad.load()) return fail_here(hi.bad.load() == 2 ? "BGZF block CRC mismatch" : "inflate failed", SPX_EINVAL);
+        const int64_t n = s->blocks[q1 - 1].out_off + (int64_t)s->blocks[q1 - 1].ulen - base;
+        DCHK(hipMemcpyAsync(S.d_buf + d->carry_cap + base, h, (size_t)n, hipMemcpyHostToDevice, up2_stream));
+        DCHK(hipEventRecord(pin_ev[1][k], up2_stream));
+        pin_busy[1][k] = true;
+        host_bytes += n;
+        q0 = q1;
+    }
+    DCHK(hipEventRecord(S.ev_host, up2_stream));
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        d->bytes_up += host_bytes;
+        d->bytes_host_inflated += host_bytes;
+        d->bytes_dev_inflated += s->ulen - host_bytes;
+    }
+    return SPX_OK;
+}
+
+void Lane::helper_main()
+{
+    for (;;) {
+        Seg *s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !host_q.empty() || up_done; });
+            if (host_q.empty()) break;
+            s = host_q.front();
+            host_q.pop_front();
+        }
+        const int rc = stopping() ? SPX_EINVAL : host_part(s);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc == SPX_OK) parse_q.push_back(s);
+            else {
+                if (s->slot >= 0) slot[s->slot].busy = false;
+                delete s;
+            }
+        }
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        help_done = true;
+    }
+    cv.notify_all();
 }
 
 void Lane::uploader_main()
@@ -508,8 +614,11 @@ void Lane::uploader_main()
         const int rc = upload(s);
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (rc == SPX_OK) parse_q.push_back(s);
-            else delete s;
+            if (rc == SPX_OK) host_q.push_back(s);
+            else {
+                if (s->slot >= 0) slot[s->slot].busy = false;
+                delete s;
+            }
         }
         cv.notify_all();
         if (rc != SPX_OK) break;
@@ -558,6 +667,7 @@ int Lane::parse(Seg *s)
         DCHK(hipStreamSynchronize(in_stream)); /* the buffer is written again by this very segment's hand-over */
     }
     DCHK(hipStreamWaitEvent(in_stream, S.ev_inf, 0));
+    DCHK(hipStreamWaitEvent(in_stream, S.ev_host, 0));
     const int64_t nb = (int64_t)s->blocks.size();
     int rc = ensure_pools(std::max<int64_t>(rec_cap, 1), nb + 1);
     if (rc) return rc;
@@ -572,7 +682,7 @@ int Lane::parse(Seg *s)
     A.max_rec = d->carry_cap;
     carve(A);
     DCHK(hipMemsetAsync(d_counts, 0, sizeof(spx_din_counts), in_stream));
-    DCHK(spx_din_inflate_status(S.d_status, (int32_t)nb, d_counts, in_stream));
+    DCHK(spx_din_inflate_status(S.d_status, (int32_t)s->n_dev_blocks, d_counts, in_stream));
     spx_din_counts &C = *h_counts;
     double t_inf = 0;
     for (int attempt = 0;; ++attempt) {
@@ -581,6 +691,7 @@ int Lane::parse(Seg *s)
         if (attempt == 0) {
             const double tw = now_s();
             DCHK(hipEventSynchronize(S.ev_inf));
+            DCHK(hipEventSynchronize(S.ev_host));
             t_inf = now_s() - tw;
         }
         DCHK(hipStreamSynchronize(in_stream));
@@ -745,7 +856,7 @@ void Lane::parser_main()
         Seg *s = nullptr;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !parse_q.empty() || up_done; });
+            cv.wait(lk, [&] { return !parse_q.empty() || help_done; });
             if (parse_q.empty()) break;
             s = parse_q.front();
             parse_q.pop_front();
@@ -776,6 +887,7 @@ extern "C" void spx_dbam_default_options(spx_dbam_options *o)
     o->ahead = 3;
     o->start_voffset = -1;
     o->end_voffset = -1;
+    o->host_inflate_percent = -1;
 }
 
 extern "C" int spx_dbam_open(const char *path, const spx_dbam_options *opt, spx_dbam **out)
@@ -807,6 +919,8 @@ extern "C" int spx_dbam_open(const char *path, const spx_dbam_options *opt, spx_
     if (const char *e = getenv("SPX_DIN_CARRY_MB")) d->carry_cap = (int64_t)atoll(e) << 20;
     if (const char *e = getenv("SPX_DIN_CARRY_KB")) d->carry_cap = (int64_t)atoll(e) << 10;
     d->carry_cap = (std::max<int64_t>(d->carry_cap, 65536) + 255) & ~(int64_t)255;
+    d->host_share = o.host_inflate_percent < 0 ? -1.0 : o.host_inflate_percent / 100.0;
+    if (const char *e = getenv("SPX_DIN_HOST_PCT")) d->host_share = atof(e) / 100.0;
     memset(&d->par, 0, sizeof d->par);
     *out = d;
     return SPX_OK;
@@ -818,6 +932,13 @@ extern "C" int spx_dbam_start(spx_dbam *d, spx_ctx *const *ctxs, int32_t n_ctx, 
 {
     if (!d || !ctxs || n_ctx < 1 || !par || !d->lanes.empty()) return SPX_EINVAL;
     d->par = *par;
+    if (d->host_share < 0) {
+        /* default: what the host pool can carry beside the devices.  Measured on the MI355X boxes (16 cores of CPU time):
+         * libdeflate ~0.6 GB/s per core, the inflate kernel ~13 GB/s per device */
+        const double host_rate = 0.55 * (double)std::max(1, spx_effective_cpus() - 1), dev_rate = 13.0 * n_ctx;
+        d->host_share = host_rate / (host_rate + dev_rate);
+    }
+    d->host_share = std::min(1.0, std::max(0.0, d->host_share));
     d->tmap.resize(1 << 20);
     const int32_t nt = spx_internal_bam_tmap(d->hdr, d->tmap.data(), (int32_t)d->tmap.size());
     if (nt > (int32_t)d->tmap.size()) { d->tmap.resize((size_t)nt); spx_internal_bam_tmap(d->hdr, d->tmap.data(), nt); }
@@ -838,6 +959,7 @@ extern "C" int spx_dbam_start(spx_dbam *d, spx_ctx *const *ctxs, int32_t n_ctx, 
     }
     for (Lane *L : d->lanes) {
         L->uploader = std::thread([L] { L->uploader_main(); });
+        L->helper = std::thread([L] { L->helper_main(); });
         L->parser = std::thread([L] { L->parser_main(); });
     }
     return SPX_OK;
@@ -892,6 +1014,9 @@ extern "C" void spx_dbam_stats(const spx_dbam *dc, int64_t *segments, int64_t *b
     std::lock_guard<std::mutex> lk(d->mu);
     if (segments) *segments = d->n_segments;
     if (bytes_uploaded) *bytes_uploaded = d->bytes_up;
+    if (segments && getenv("SPX_TIMING"))
+        fprintf(stderr, "[spx timing] device input: %.2f GB inflated on the device(s), %.2f GB on the host pool (share %.0f %%)\n", d->bytes_dev_inflated / 1e9,
+                d->bytes_host_inflated / 1e9, 100.0 * d->host_share);
     if (seconds) {
         seconds[0] = d->t_upload; seconds[1] = d->t_parse; seconds[2] = d->t_wait_carry; seconds[3] = d->t_wait_inflate;
         seconds[4] = d->t_chain; seconds[5] = d->t_groups; seconds[6] = d->t_image;
@@ -913,6 +1038,8 @@ extern "C" void spx_dbam_close(spx_dbam *d)
     for (Lane *L : d->lanes) {
         if (L->uploader.joinable()) L->uploader.join();
         L->cv.notify_all();
+        if (L->helper.joinable()) L->helper.join();
+        L->cv.notify_all();
         if (L->parser.joinable()) L->parser.join();
     }
     /* work lists nobody took */
@@ -920,6 +1047,7 @@ extern "C" void spx_dbam_close(spx_dbam *d)
         for (Item &x : kv.second) spx_work_free(d->lanes[(size_t)x.lane]->ctx, x.work);
     for (Item &x : d->out_items) spx_work_free(d->lanes[(size_t)x.lane]->ctx, x.work);
     for (Lane *L : d->lanes) {
+        for (Seg *s : L->host_q) delete s;
         for (Seg *s : L->parse_q) delete s;
         L->destroy();
         delete L;

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void chain_spec_kernel(spx_din_args A)
     A.first_idx[b] = -1;
 }
 
-constexpr int kTile = 2048;
+/* (a small tile: the workgroup must find room on a CU that the inflate kernel of the NEXT segment keeps filled to the last
+ * KB of LDS -- with 48 KB of tiles it waited for that whole grid to drain, ~80 ms per segment) */
+constexpr int kTile = 256;
 
 __global__ __launch_bounds__(256) void chain_resolve_kernel(spx_din_args A)
 {

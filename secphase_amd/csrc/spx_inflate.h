@@ -38,24 +38,27 @@
 
 namespace spxz {
 
-constexpr int kLitRoot = 11;  /* bits of the literal/length root table: BAM payload (4-bit packed bases: 256 byte values of
-                               * ~0.1 % each; qualities) gives its literals codes of 6..11 bits -- all of them root codes */
-constexpr int kDistRoot = 9;  /* bits of the distance root table */
-
+/* Bits of the root tables are a property of the ENVIRONMENT (E::kLit, E::kDist): the tables live in LDS on the device and
+ * their size sets how many blocks a CU decodes at once.  Round 3 used 11 / 9 bits; the literals of BAM payload turn out to
+ * have short codes (synthetic HiFi / ONT BAMs at zlib level 6: 94 % of the literals <= 7 bits, 98.4 % <= 9), so round 4's
+ * kernels use 9 / 8 (1.5 KB instead of 5 KB) and send the rest through the canonical walk. */
 /* root-table entry (16 bits): bits 0-8 symbol (bit 8 set = not a literal), bits 9-12 code length; 0 = not a root code -> canonical walk.  Length and
  * distance base / extra bits are computed from the symbol (len_base ..): the rarer path pays, the table stays small */
 SPXZ_HD uint16_t mk_entry(int nbits, int sym) { return (uint16_t)((unsigned)sym | ((unsigned)nbits << 9)); }
 constexpr uint16_t kNoEntry = 0x100; /* "not a literal", length 0: the literal loop needs ONE bit test */
 
-struct Tables {
-    uint16_t lit[1 << kLitRoot];
-    uint16_t dist[1 << kDistRoot];
+template <int LR, int DR>
+struct TablesT {
+    static constexpr int kLitBits = LR, kDistBits = DR;
+    uint16_t lit[1 << LR];
+    uint16_t dist[1 << DR];
     /* canonical description (walked for codes longer than the root, and while building) */
     uint16_t lit_count[16], dist_count[16];   /* codes per length */
     uint16_t lit_sorted[288], dist_sorted[32]; /* symbols ordered by (length, symbol) */
     uint8_t lens[288 + 32];                    /* code lengths of the block being set up */
-    uint16_t code_of[288];                     /* canonical code of every symbol (table fill) */
+    uint16_t first[16], offs[16];              /* of the set being filled: canonical code / index in `sorted` of every length's first symbol */
 };
+using Tables = TablesT<11, 9>;
 
 SPXZ_HD int len_base(int sym) /* sym 257..285 */
 {
@@ -136,9 +139,10 @@ SPXZ_HD uint32_t decode_slow(const Bits<E> &b, const uint16_t *count, const uint
     return decode_slow_bits((uint32_t)b.buf, count, sorted, max_len);
 }
 
-/* counts + sorted symbols + canonical codes from lens[0..n); returns 0, or -1 for an over-subscribed / incomplete set
- * (an incomplete set is allowed when it has a single code, as zlib allows for distance trees) */
-SPXZ_HD int canon_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sorted, uint16_t *code_of)
+/* counts + sorted symbols from lens[0..n), and (first / offs0 != NULL) the canonical code and the index in `sorted` of every
+ * length's first symbol; returns 0, or -1 for an over-subscribed / incomplete set (an incomplete set is allowed when it has a
+ * single code, as zlib allows for distance trees) */
+SPXZ_HD int canon_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sorted, uint16_t *first, uint16_t *offs0)
 {
     for (int l = 0; l < 16; ++l) count[l] = 0;
     for (int s = 0; s < n; ++s) count[lens[s] & 15]++;
@@ -148,37 +152,43 @@ SPXZ_HD int canon_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *s
         left -= count[l];
         if (left < 0) return -1; /* over-subscribed */
     }
-    uint16_t offs[16], nextc[16];
+    uint16_t offs[16];
     offs[0] = 0; offs[1] = 0;
     for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
-    int code = 0;
-    nextc[0] = 0;
-    for (int l = 1; l < 16; ++l) { /* RFC 1951 3.2.2 with bl_count[0] = 0 */
-        code = (code + (l > 1 ? count[l - 1] : 0)) << 1;
-        nextc[l] = (uint16_t)code;
+    if (first) {
+        int code = 0;
+        first[0] = 0;
+        offs0[0] = 0;
+        for (int l = 1; l < 16; ++l) { /* RFC 1951 3.2.2 with bl_count[0] = 0 */
+            code = (code + (l > 1 ? count[l - 1] : 0)) << 1;
+            first[l] = (uint16_t)code;
+            offs0[l] = offs[l];
+        }
     }
     for (int s = 0; s < n; ++s) {
         const int l = lens[s] & 15;
         if (!l) continue;
         sorted[offs[l]++] = (uint16_t)s;
-        if (code_of) code_of[s] = nextc[l]++;
     }
     const int used = n - count[0];
     if (left > 0 && used > 1) return -1; /* incomplete: only a set of at most one code may be (zlib accepts those too) */
     return 0;
 }
 
-/* root-table fill for symbols s = first, first + stride, ...: every code of length <= root is replicated over the
- * high index bits; longer codes leave their (shared) root slots at 0 = "walk" */
+/* root-table fill for the coded symbols number i = first_i, first_i + stride, ... in (length, symbol) order: the canonical
+ * code of sorted[i] is first[len] + (i - offs[len]); every code of length <= root is replicated over the high index bits;
+ * longer codes leave their (shared) root slots at "walk" */
 template <bool LIT>
-SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint16_t *code_of, int n, int first, int stride)
+SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint16_t *sorted, const uint16_t *first, const uint16_t *offs, int used,
+                       int first_i, int stride)
 {
-    for (int s = first; s < n; s += stride) {
+    for (int i = first_i; i < used; i += stride) {
+        const int s = sorted[i];
         const int l = lens[s];
-        if (l == 0 || l > root) continue;
-        if (LIT ? s > 285 : s > 29) continue; /* 286, 287 / 30, 31: never valid (their slots stay 0 -> the walk rejects them) */
+        if (l > root) continue;
+        if (LIT ? s > 285 : s > 29) continue; /* 286, 287 / 30, 31: never valid (their slots stay "walk" -> the walk rejects them) */
         const uint16_t e = mk_entry(l, s);
-        const uint32_t r = rev_bits(code_of[s], l);
+        const uint32_t r = rev_bits((uint32_t)first[l] + (uint32_t)(i - offs[l]), l);
         for (uint32_t k = r; k < (1u << root); k += (1u << l)) tab[k] = e;
     }
 }
@@ -186,24 +196,24 @@ SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint1
 template <class E>
 SPXZ_HD int build_tables(E &env, int nlit, int ndist)
 {
-    Tables &T = env.tables();
+    auto &T = env.tables();
     const int lane = env.lane(), lanes = env.lanes();
-    for (int k = lane; k < (1 << kLitRoot); k += lanes) T.lit[k] = kNoEntry;
-    for (int k = lane; k < (1 << kDistRoot); k += lanes) T.dist[k] = kNoEntry;
+    for (int k = lane; k < (1 << E::kLit); k += lanes) T.lit[k] = kNoEntry;
+    for (int k = lane; k < (1 << E::kDist); k += lanes) T.dist[k] = kNoEntry;
+    /* (a set that is refused leaves `sorted` / `first` / `offs` half-written: nothing is filled from them) */
     int rc = 0;
-    if (lane == 0) {
-        rc = canon_build(T.lens, nlit, T.lit_count, T.lit_sorted, T.code_of);
-    }
+    if (lane == 0) rc = canon_build(T.lens, nlit, T.lit_count, T.lit_sorted, T.first, T.offs);
     env.sync();
-    fill_root<true>(T.lit, kLitRoot, T.lens, T.code_of, nlit, lane, lanes);
+    rc = env.uniform(rc);
+    if (rc == 0) fill_root<true>(T.lit, E::kLit, T.lens, T.lit_sorted, T.first, T.offs, nlit - (int)T.lit_count[0], lane, lanes);
     env.sync();
     int rc2 = 0;
-    if (lane == 0) rc2 = canon_build(T.lens + nlit, ndist, T.dist_count, T.dist_sorted, T.code_of);
+    if (lane == 0 && rc == 0) rc2 = canon_build(T.lens + nlit, ndist, T.dist_count, T.dist_sorted, T.first, T.offs);
     env.sync();
-    fill_root<false>(T.dist, kDistRoot, T.lens + nlit, T.code_of, ndist, lane, lanes);
+    rc2 = env.uniform(rc2);
+    if (rc == 0 && rc2 == 0) fill_root<false>(T.dist, E::kDist, T.lens + nlit, T.dist_sorted, T.first, T.offs, ndist - (int)T.dist_count[0], lane, lanes);
     env.sync();
-    rc = env.uniform(rc | rc2);
-    return rc ? -1 : 0;
+    return (rc | rc2) ? -1 : 0;
 }
 
 /* one DEFLATE stream (all its blocks).  out_limit: bytes the caller expects (ISIZE) */
@@ -211,7 +221,7 @@ template <class E>
 SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
 {
     Bits<E> b(env);
-    Tables &T = env.tables();
+    auto &T = env.tables();
     for (;;) {
         b.refill();
         const uint32_t hdr = b.take(3);
@@ -249,7 +259,7 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                 for (int k = 0; k < 19; ++k) cl[k] = 0;
                 for (int k = 0; k < ncode; ++k) { b.refill(); cl[order[k]] = (uint8_t)b.take(3); }
                 uint16_t ccount[16], csorted[19];
-                if (env.uniform(canon_build(cl, 19, ccount, csorted, nullptr)) != 0) return -1;
+                if (env.uniform(canon_build(cl, 19, ccount, csorted, nullptr, nullptr)) != 0) return -1;
                 int idx = 0;
                 int bad = 0;
                 while (idx < nlit + ndist) {
@@ -285,7 +295,7 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                 uint32_t e;
                 for (;;) {
                     b.refill();
-                    e = env.uniform_u32(T.lit[b.peek(kLitRoot)]);
+                    e = env.uniform_u32(T.lit[b.peek(E::kLit)]);
                     /* a length / end-of-block code, or no root code at all -- or no room for one more literal (the device
                      * keeps up to 64 in a register; committing them, flushing and the overrun check stay OUT of this loop:
                      * inlined into it they cost a dozen scalar moves per literal) */
@@ -316,7 +326,7 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                 b.refill();
                 const int len = len_base(sym) + (int)b.take(len_extra(sym));
                 b.refill();
-                const uint32_t d = env.uniform_u32(T.dist[b.peek(kDistRoot)]);
+                const uint32_t d = env.uniform_u32(T.dist[b.peek(E::kDist)]);
                 int dsym;
                 if (d != kNoEntry) {
                     b.drop((int)(d >> 9));
@@ -378,12 +388,14 @@ SPXZ_HD uint32_t gf2_xpow8n(uint64_t n_bytes)
 SPXZ_HD uint32_t crc_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return gf2_mul(gf2_xpow8n(len_b), crc_a) ^ crc_b; }
 
 /* ---- host environment: plain buffers ---- */
-struct HostEnv {
+template <int LR, int DR>
+struct HostEnvT {
+    static constexpr int kLit = LR, kDist = DR;
     const uint8_t *in;
     size_t in_len;
     uint8_t *out;
     uint32_t pos = 0;
-    Tables T;
+    TablesT<LR, DR> T;
     uint32_t in32(uint32_t k) const
     {
         uint32_t v = 0;
@@ -400,13 +412,14 @@ struct HostEnv {
     bool lit_commit() const { return pos < cap; }
     void copy_match(int len, int dist) { for (int k = 0; k < len; ++k, ++pos) out[pos] = out[pos - dist]; }
     uint32_t out_pos() const { return pos; }
-    Tables &tables() { return T; }
+    TablesT<LR, DR> &tables() { return T; }
     void sync() {}
     int lane() const { return 0; }
     int lanes() const { return 1; }
     int uniform(int v) const { return v; }
     uint32_t uniform_u32(uint32_t v) const { return v; }
 };
+using HostEnv = HostEnvT<11, 9>;
 
 } // namespace spxz
 #endif

@@ -4,20 +4,32 @@
  * the host reader inflates with libdeflate / zlib (spx_io.cpp), the device path with spx_inflate_kernels.hip.
  */
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/spx.h"
 #include "spx_inflate.h"
 
-extern "C" int spx_inflate_core_host(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len)
+template <int LR, int DR>
+static int run_core(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len)
 {
-    if (!in || (!out && out_len > 0) || in_len < 0 || out_len < 0 || out_len > 0xffffffffll) return SPX_EINVAL;
-    spxz::HostEnv env;
+    spxz::HostEnvT<LR, DR> env;
     env.in = in;
     env.in_len = (size_t)in_len;
     env.out = out;
     env.cap = (uint32_t)out_len;
     return spxz::inflate_stream(env, in_len * 8, (uint32_t)out_len);
+}
+
+extern "C" int spx_inflate_core_host(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len)
+{
+    if (!in || (!out && out_len > 0) || in_len < 0 || out_len < 0 || out_len > 0xffffffffll) return SPX_EINVAL;
+    /* the root-table sizes the device kernels are built with: SPX_INFLATE_ROOT = 9 (9 / 8 bits, round 4), 10 (10 / 8), 11 (11 / 9, round 3) */
+    const char *e = getenv("SPX_INFLATE_ROOT");
+    const int root = e ? atoi(e) : 9;
+    if (root == 11) return run_core<11, 9>(in, in_len, out, out_len);
+    if (root == 10) return run_core<10, 8>(in, in_len, out, out_len);
+    return run_core<9, 8>(in, in_len, out, out_len);
 }
 
 extern "C" uint32_t spx_crc32_core_host(const uint8_t *p, int64_t n, int32_t pieces)

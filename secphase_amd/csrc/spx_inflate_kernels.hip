@@ -23,6 +23,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "spx_inflate.h"
 
@@ -45,7 +46,10 @@ __device__ __forceinline__ int writelane(int v, int c, int n)
     return v;
 }
 
+template <int LR, int DR>
 struct DevEnv {
+    static constexpr int kLit = LR, kDist = DR;
+    using Tab = spxz::TablesT<LR, DR>;
     const uint32_t *in_al;
     uint32_t in_shift; /* bits: 0, 8, 16, 24 */
     uint32_t n_dw;     /* dwords of in_al that hold bytes of this block: reads beyond them return 0 (the decoder's contract; a damaged
@@ -55,7 +59,7 @@ struct DevEnv {
     uint32_t pos, flushed;
     uint32_t npend;    /* literals decoded but not yet in the ring: byte k of the run sits in lane k of litv */
     int litv;
-    spxz::Tables *T;
+    Tab *T;
     uint8_t *ring;
     int lane_;
 
@@ -64,7 +68,7 @@ struct DevEnv {
         const uint32_t lo = k < n_dw ? in_al[k] : 0u, hi = k + 1 < n_dw ? in_al[k + 1] : 0u;
         return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
     }
-    __device__ __forceinline__ spxz::Tables &tables() { return *T; }
+    __device__ __forceinline__ Tab &tables() { return *T; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ int lane() const { return lane_; }
     __device__ __forceinline__ int lanes() const { return 64; }
@@ -149,15 +153,16 @@ struct DevEnv {
     }
 };
 
+template <int LR, int DR>
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
                                                           uint8_t *__restrict__ outbuf, int32_t *__restrict__ status, int check_crc)
 {
-    __shared__ spxz::Tables T;
+    __shared__ spxz::TablesT<LR, DR> T;
     __shared__ uint8_t ring[kRing];
     const int b = blockIdx.x;
     if (b >= n_blocks) return;
     const BlockDesc d = blocks[b];
-    DevEnv env;
+    DevEnv<LR, DR> env;
     env.in_al = reinterpret_cast<const uint32_t *>(comp + (d.in_off & ~(int64_t)3));
     env.in_shift = (uint32_t)(d.in_off & 3) * 8u;
     env.n_dw = ((uint32_t)(d.in_off & 3) + d.clen + 3u) >> 2;
@@ -204,13 +209,218 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restr
     if (threadIdx.x == 0) status[b] = rc;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Round 4: SEVERAL BLOCKS PER WAVEFRONT.  The kernel above decodes on the scalar unit -- one per CU, shared by every resident
+ * wave: 45 scalar instructions per symbol (literals ~22, the 13 % of symbols that are matches the other half) at 60 % of
+ * its issue slots is where 13.5 GB/s comes from, and with the input side on the device (spx_devin.cpp) that kernel is what
+ * an end-to-end run waits for.  Here a wavefront holds 64 / G blocks: G adjacent lanes share one block and execute its
+ * decode REDUNDANTLY on the vector ALU (four SIMDs per CU, two wave-instructions per cycle), so that one instruction
+ * stream advances 64 / G blocks; the G lanes of a block split what is data parallel (table fills, LZ77 copies, flushes,
+ * CRC stripes) exactly as the 64 lanes do above.  Control flow diverges between the blocks of a wave -- a match here, a
+ * literal there -- and is handled by the hardware's execution mask: zlib cuts its DEFLATE blocks after a fixed number of
+ * symbols, so the blocks of a wave reach their table builds together.  Decoder core: the same spx_inflate.h. */
+
+template <int G, int LR, int DR, int R>
+struct GrpEnv {
+    static constexpr int kLit = LR, kDist = DR;
+    /* near matches (distance <= R / 2) are served from the ring; a far match must find its source flushed: R / 2 - 258 >= kFlushG + 3 */
+    static constexpr int kRingG = R, kFlushG = (R / 4 < R / 2 - 264) ? R / 4 : R / 2 - 264;
+    using Tab = spxz::TablesT<LR, DR>;
+    const uint32_t *in_al;
+    uint32_t in_shift, n_dw;
+    uint8_t *out;
+    uint32_t limit, pos, flushed;
+    Tab *T;
+    uint8_t *ring;
+    int lane_;
+
+    __device__ __forceinline__ uint32_t in32(uint32_t k) const
+    {
+        const uint32_t lo = k < n_dw ? in_al[k] : 0u, hi = k + 1 < n_dw ? in_al[k + 1] : 0u;
+        return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
+    }
+    __device__ __forceinline__ Tab &tables() { return *T; }
+    /* the lanes of a block run in lockstep inside one wave and LDS operations of a wave complete in order: a "barrier" only
+     * has to keep the compiler from moving LDS accesses across it */
+    __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ int lane() const { return lane_; }
+    __device__ __forceinline__ int lanes() const { return G; }
+    /* a value only lane 0 of the block has computed (return codes of its serial parts); what every lane READS is the same anyway */
+    __device__ __forceinline__ int uniform(int v) const { return __shfl(v, 0, G); }
+    __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return v; }
+    __device__ __forceinline__ uint32_t out_pos() const { return pos; }
+
+    /* ring -> HBM in whole dwords (the ring's bytes [flushed, pos) wait; `flushed` stays a multiple of 4 until the last
+     * flush, so the LDS reads are aligned; the global stores are byte-aligned, which gfx9 global memory allows) */
+    __device__ __forceinline__ void flush(bool last)
+    {
+        sync();
+        const uint32_t end = pos < limit ? pos : limit;
+        const uint32_t e4 = last ? end : (end & ~3u);
+        if (e4 > flushed) {
+            for (uint32_t base = flushed; base + 4 <= e4; base += 4u * G) {
+                const uint32_t i = base + 4u * (uint32_t)lane_;
+                if (i + 4 <= e4) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(ring + (i & (kRingG - 1)));
+                    __builtin_memcpy(out + i, &v, 4);
+                }
+            }
+            const uint32_t tail = flushed + ((e4 - flushed) & ~3u);
+            if (tail + (uint32_t)lane_ < e4) out[tail + lane_] = ring[(tail + lane_) & (kRingG - 1)];
+            flushed = last ? e4 : (pos < limit ? e4 : pos & ~3u);
+        } else if (pos > limit)
+            flushed = pos & ~3u;
+        /* far matches read what was stored here: the stores must have reached the L2 (the loads go past the vector L1) */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    __device__ __forceinline__ bool lit_full() const { return pos - flushed >= (uint32_t)kFlushG; }
+    __device__ __forceinline__ void lit_push(uint8_t c)
+    {
+        if (lane_ == 0) ring[pos & (kRingG - 1)] = c;
+        ++pos;
+    }
+    __device__ __forceinline__ bool lit_commit()
+    {
+        flush(false);
+        return pos <= limit;
+    }
+    __device__ __forceinline__ bool put_literal(uint8_t c)
+    {
+        if (lit_full() && !lit_commit()) return false;
+        lit_push(c);
+        return true;
+    }
+    __device__ __forceinline__ void copy_match(int len, int dist)
+    {
+        const uint32_t src0 = pos - (uint32_t)dist;
+        if (dist <= kRingG / 2) {
+            if (dist >= len) {
+                for (int base = 0; base < len; base += G) {
+                    const int i = base + lane_;
+                    if (i < len) ring[(pos + (uint32_t)i) & (kRingG - 1)] = ring[(src0 + (uint32_t)i) & (kRingG - 1)];
+                }
+            } else { /* overlapping: the first `dist` bytes repeated */
+                for (int base = 0; base < len; base += G) {
+                    const int i = base + lane_;
+                    if (i < len) ring[(pos + (uint32_t)i) & (kRingG - 1)] = ring[(src0 + (uint32_t)(i % dist)) & (kRingG - 1)];
+                }
+            }
+        } else {
+            /* far: the source lies below `flushed` (kFlushG + 4 + 258 <= kRingG / 2) */
+            for (int base = 0; base < len; base += G) {
+                const int i = base + lane_;
+                if (i < len) {
+                    const uint8_t v = __hip_atomic_load(out + src0 + (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ring[(pos + (uint32_t)i) & (kRingG - 1)] = v;
+                }
+            }
+        }
+        pos += (uint32_t)len;
+        if (pos - flushed >= (uint32_t)kFlushG) flush(false);
+    }
+};
+
+template <int G, int LR, int DR, int R, int WPE = 4>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void bgzf_inflate_g_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
+                                                            uint8_t *__restrict__ outbuf, int32_t *__restrict__ status, int check_crc)
+{
+    constexpr int NB = 64 / G;
+    __shared__ spxz::TablesT<LR, DR> T[NB];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[NB][R];
+    const int q = (int)threadIdx.x / G, lane = (int)threadIdx.x % G;
+    const int b = (int)blockIdx.x * NB + q;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    GrpEnv<G, LR, DR, R> env;
+    env.in_al = reinterpret_cast<const uint32_t *>(comp + (d.in_off & ~(int64_t)3));
+    env.in_shift = (uint32_t)(d.in_off & 3) * 8u;
+    env.n_dw = ((uint32_t)(d.in_off & 3) + d.clen + 3u) >> 2;
+    env.out = outbuf + d.out_off;
+    env.limit = d.ulen;
+    env.pos = 0;
+    env.flushed = 0;
+    env.T = &T[q];
+    env.ring = ring[q];
+    env.lane_ = lane;
+    int rc = 0;
+    if (d.ulen > 0) {
+        rc = spxz::inflate_stream(env, (int64_t)d.clen * 8, d.ulen);
+        env.flush(true);
+    }
+    if (rc == 0 && check_crc && d.ulen > 0) {
+        /* CRC-32: G stripes per block (byte-table recurrence per lane), folded with the GF(2) shift operator; the byte table
+         * takes the place of the block's literal table */
+        uint32_t *crc_tab = reinterpret_cast<uint32_t *>(T[q].lit);
+        env.sync();
+        for (int k = lane; k < 256; k += G) crc_tab[k] = spxz::crc_table_entry((uint32_t)k);
+        env.sync();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t n = d.ulen, step = (n + G - 1) / G;
+        const uint32_t a = min(n, step * (uint32_t)lane), e = min(n, a + step);
+        uint32_t c = 0xffffffffu;
+        const uint8_t *p = env.out;
+        for (uint32_t k = a; k < e; ++k) {
+            const uint8_t byte = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = crc_tab[(c ^ byte) & 0xff] ^ (c >> 8);
+        }
+        c ^= 0xffffffffu;
+        uint32_t len = e - a;
+        for (int s = 1; s < G; s <<= 1) {
+            const uint32_t oc = (uint32_t)__shfl_down((int)c, s, G), ol = (uint32_t)__shfl_down((int)len, s, G);
+            if ((lane & (2 * s - 1)) == 0) {
+                if (ol > 0) c = len > 0 ? spxz::crc_combine(c, oc, ol) : oc;
+                len += ol;
+            }
+        }
+        c = (uint32_t)__shfl((int)c, 0, G);
+        if (c != d.crc) rc = -4;
+    }
+    if (lane == 0) status[b] = rc;
+}
+
 } // namespace
+
+static int inflate_root_bits()
+{
+    /* SPX_INFLATE_ROOT: bits of the literal/length root table: 9 (with an 8-bit distance table; default), 10 (10 / 8), 11 (11 / 9: round 3) */
+    static const int r = [] { const char *e = getenv("SPX_INFLATE_ROOT"); const int v = e ? atoi(e) : 9; return (v == 10 || v == 11) ? v : 9; }();
+    return r;
+}
+
+#define SPX_LAUNCH_G(G, LR, DR, R) \
+    hipLaunchKernelGGL((bgzf_inflate_g_kernel<G, LR, DR, R>), dim3((unsigned)((n_blocks + (64 / G) - 1) / (64 / G))), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc)
+
+extern "C" hipError_t spx_launch_bgzf_inflate_grouped(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
+                                                      int check_crc, int lanes_per_block, hipStream_t st)
+{
+    if (n_blocks <= 0) return hipSuccess;
+    const BlockDesc *bd = (const BlockDesc *)blocks;
+    const int root = inflate_root_bits();
+    static const int ring = [] { const char *e = getenv("SPX_INFLATE_RING"); const int v = e ? atoi(e) : 2048; return (v == 1024 || v == 4096) ? v : 2048; }();
+    if (lanes_per_block == 16) {
+        if (root == 11) SPX_LAUNCH_G(16, 11, 9, 2048); else if (root == 10) SPX_LAUNCH_G(16, 10, 8, 2048); else SPX_LAUNCH_G(16, 9, 8, 2048);
+    } else {
+        if (root == 11) SPX_LAUNCH_G(32, 11, 9, 2048);
+        else if (root == 10) SPX_LAUNCH_G(32, 10, 8, 2048);
+        else if (ring == 4096) SPX_LAUNCH_G(32, 9, 8, 4096);
+        else if (ring == 1024)
+            hipLaunchKernelGGL((bgzf_inflate_g_kernel<32, 9, 8, 1024, 5>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
+        else SPX_LAUNCH_G(32, 9, 8, 2048);
+    }
+    return hipGetLastError();
+}
 
 extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
                                               int check_crc, hipStream_t st)
 {
     if (n_blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, comp, (const BlockDesc *)blocks, n_blocks, out, status,
-                       check_crc);
+    /* SPX_INFLATE_LANES: 64 = one block per wave on the scalar unit, 16 / 32 = lanes per block of the grouped kernel */
+    static const int lanes = [] { const char *e = getenv("SPX_INFLATE_LANES"); const int v = e ? atoi(e) : 64; return (v == 16 || v == 32) ? v : 64; }();
+    if (lanes != 64) return spx_launch_bgzf_inflate_grouped(comp, blocks, n_blocks, out, status, check_crc, lanes, st);
+    const BlockDesc *bd = (const BlockDesc *)blocks;
+    const int root = inflate_root_bits();
+    if (root == 11) hipLaunchKernelGGL((bgzf_inflate_kernel<11, 9>), dim3((unsigned)n_blocks), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
+    else if (root == 10) hipLaunchKernelGGL((bgzf_inflate_kernel<10, 8>), dim3((unsigned)n_blocks), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
+    else hipLaunchKernelGGL((bgzf_inflate_kernel<9, 8>), dim3((unsigned)n_blocks), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
     return hipGetLastError();
 }

@@ -1116,6 +1116,21 @@ extern "C" int spx_bam_release_batch(spx_bam_reader *h, const spx_batch *bt)
     return SPX_EINVAL;
 }
 
+/* internal (spx_devin.cpp): one BGZF block on the calling thread (its thread's inflate state): 0 ok, 1 corrupt data, 2 CRC mismatch */
+extern "C" int spx_internal_inflate_block(const uint8_t *src, size_t clen, uint8_t *dst, size_t ulen, uint32_t crc, int check_crc)
+{
+    thread_local Inflater inf;
+    {
+        spx::CpuScope cs(spx::CPU_INFLATE);
+        if (!inf.run(src, clen, dst, ulen)) return 1;
+    }
+    if (check_crc) {
+        spx::CpuScope cs(spx::CPU_CRC);
+        if (crc_of(dst, ulen) != crc) return 2;
+    }
+    return 0;
+}
+
 /* internal (spx_devin.cpp): the mapping and where the records start / end in it */
 extern "C" int spx_internal_bam_layout(spx_bam_reader *h, const uint8_t **map, int64_t *fsize, int64_t *start_coff, int32_t *start_uoff,
                                        int64_t *end_coff, int32_t *end_uoff, int32_t *check_crc)

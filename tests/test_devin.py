@@ -119,10 +119,14 @@ def test_device_input_equals_host_path(ctx, tmp_path, name):
 
     res, names, sizes = _device_run(bam, ctx, par, g.ref, compare_plans=cmp_plans)
     assert sizes == [n] and res == want and names == want_names
-    res, names, sizes = _device_run(bam, ctx, par, g.ref, env={"SPX_DIN_SEG_KB": "192"}, compare_plans=cmp_plans if name in ("hifi", "long") else None)
+    # (by default a share of every segment is inflated by the host pool and uploaded raw; 0 / 100: the inflate kernel / the host alone)
+    res, names, sizes = _device_run(bam, ctx, par, g.ref, env={"SPX_DIN_SEG_KB": "192"}, compare_plans=cmp_plans if name in ("hifi", "long") else None,
+                                    host_inflate_percent=0)
     assert len(sizes) > 3 and sum(sizes) == n and res == want and names == want_names
-    res, names, sizes = _device_run(bam, ctx, par, g.ref, env={"SPX_DIN_SEG_KB": "1024"}, max_groups=17)
+    res, names, sizes = _device_run(bam, ctx, par, g.ref, env={"SPX_DIN_SEG_KB": "1024"}, max_groups=17, host_inflate_percent=100)
     assert max(sizes) <= 17 and sum(sizes) == n and res == want and names == want_names
+    res, names, sizes = _device_run(bam, ctx, par, g.ref, env={"SPX_DIN_SEG_KB": "2048"}, host_inflate_percent=50)
+    assert sum(sizes) == n and res == want and names == want_names
 
 
 def _raw_bam(path, records_bytes, contigs, level=6, block=0xff00):

@@ -4,7 +4,7 @@
 # to end.  Usage (from the repo root):  tools/collect_profiles.sh r02 [outdir]     (outdir defaults to gpurun_out/profiles)
 # Every rocprofv3 call has the program itself after `--`; --pmc is never combined with a trace option.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=${2:-gpurun_out/profiles}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/$OUT"
@@ -41,6 +41,15 @@ python3 tools/pmc_collect.py --platform mixed --out "$OUT/${TAG}_counters_mixed.
 python3 tools/pmc_collect.py --platform hifi --full --out "$OUT/${TAG}_counters_prep.json" >> "$OUT/${TAG}_bench.err" 2>&1
 python3 tools/pmc_collect.py --platform mixed --full --out "$OUT/${TAG}_counters_prep_mixed.json" >> "$OUT/${TAG}_bench.err" 2>&1
 fi
-python3 tools/e2e_cli.py --groups 262144 --threads 64 --batch 16384 > "$OUT/${TAG}_e2e_cli.json" 2>> "$OUT/${TAG}_bench.err"
+# the command line end to end (device-resident input: the default), its kernel trace, and the round-3 host reader for comparison
+python3 tools/e2e_cli.py --groups 524288 --threads 64 --rocprof "$OUT/cli_kt" > "$OUT/${TAG}_e2e_cli.json" 2>> "$OUT/${TAG}_bench.err"
+cp "$OUT/cli_kt"/*/cli_kernel_stats.csv "$OUT/${TAG}_e2e_cli_kernel_stats.csv" 2>/dev/null || cp "$OUT/cli_kt"/cli_kernel_stats.csv "$OUT/${TAG}_e2e_cli_kernel_stats.csv" 2>/dev/null
+rm -rf "$OUT/cli_kt"
+python3 tools/e2e_cli.py --groups 262144 --threads 64 --host-input --batch 16384 > "$OUT/${TAG}_e2e_cli_host_input.json" 2>> "$OUT/${TAG}_bench.err"
+# the BGZF inflate kernel alone: GB/s and its counters
+python3 tools/inflate_bench.py --groups 16384 > "$OUT/${TAG}_inflate_bench.json" 2>> "$OUT/${TAG}_bench.err"
+if [ -z "${SKIP_PMC:-}" ]; then
+python3 tools/pmc_collect.py --inflate --platform hifi --steps 3 --out "$OUT/${TAG}_counters_inflate.json" >> "$OUT/${TAG}_bench.err" 2>&1
+fi
 rm -rf "$ROOT/gpurun_out/pmc_tmp"
 ls -la "$OUT"

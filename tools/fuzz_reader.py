@@ -4,7 +4,11 @@ with correct CRCs, so that the damage reaches the record chain, the field / tag 
 file must end in batches or in an error -- never in a crash, a hang or (under AddressSanitizer, tools/sanitize_cpu.sh) a
 report.  Every batch the reader does hand out goes through spx_plan_create as well: the host plan runs the SAME source
 (spx_logic.h) as the preparation kernels, so a walk that leaves its arrays on damaged CIGAR / cs / MD content shows up here, on
-the CPU, under the sanitizer -- instead of as a GPU fault.  Usage: python tools/fuzz_reader.py [seed] [seconds]"""
+the CPU, under the sanitizer -- instead of as a GPU fault.  Usage: python tools/fuzz_reader.py [seed] [seconds] [gpu]
+"gpu" (needs an MI355X): every damaged file ALSO goes through the device-resident input (spx_dbam: inflate, record chain,
+fields / tags, groups, dispatch filter, staging as kernels) with small segments, and through scoring on both paths: the two
+must agree -- both refuse the file, or both score every group identically (names, flags, positions, scores).  A kernel that
+walks off its buffers on damaged bytes would end the process with a GPU memory fault."""
 import ctypes as C
 import gzip
 import os
@@ -32,6 +36,7 @@ class BamOptions(C.Structure):
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+    gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"
     rng = np.random.default_rng(seed)
     L = api.lib()
     vp = C.c_void_p
@@ -55,6 +60,47 @@ def main():
     for _ in range(n_ref):
         at += 8 + struct.unpack_from("<i", raw, at)[0]
     first_rec = at
+    ctx = None
+    if gpu:
+        ctx = api.Context(0)
+        ctx.set_reference(g.ref)
+    dev_stats = {"both_ok": 0, "both_error": 0, "groups": 0}
+
+    def key(o):
+        return (o.n_aln, tuple(o.score[a] for a in range(max(o.n_aln, 0))), o.prim_idx, o.max_idx, o.tie_mask, o.pass_, o.n_problems, o.dp_cells)
+
+    def names(bp):
+        bt = bp.contents
+        return [(C.string_at(bt.qnames + bt.qname_off[k]), tuple((bt.flag[a], bt.tid[a], bt.pos[a]) for a in range(bt.grp_first[k], bt.grp_first[k + 1])))
+                for k in range(bt.n_groups)]
+
+    def device_side(path, par):
+        os.environ["SPX_DIN_SEG_KB"] = str(int(rng.choice([64, 100, 256, 4096])))
+        os.environ["SPX_DIN_CARRY_KB"] = "4096"
+        res, nms = [], []
+        try:
+            d_ = api.DeviceBam(path, [ctx], par, g.ref, max_groups=int(rng.choice([5, 95000])), host_inflate_percent=int(rng.choice([0, 50, 100])))
+        except api.SpxError:
+            return None, None
+        try:
+            while True:
+                nx = d_.next()
+                if nx is None:
+                    break
+                w, _, nb, cnt = nx
+                w.prepare_staged()
+                w.launch()
+                out = w.collect(finalize_seed=None)
+                res += [key(out[k]) for k in range(cnt)]
+                nms += names(nb)
+                w.free()
+                d_.release(nb)
+        except api.SpxError:
+            res = None
+        finally:
+            d_.close()
+        return res, nms
+
     t0, n, outcomes = time.time(), 0, {"records": 0, "error": 0}
     plans, plan_err = 0, 0
     presets = [records.preset("hifi"), records.preset("ont", bandwidth=50)]
@@ -86,6 +132,7 @@ def main():
         else:
             L.spx_bam_bind_reference(rd, g.ref)
             ok = True
+            host_res, host_names = [], []
             for _ in range(200):
                 bp = C.POINTER(records.SpxBatch)()
                 k = L.spx_bam_next_batch(rd, 7, C.byref(bp))
@@ -101,6 +148,10 @@ def main():
                         C.string_at(bt.cs + bt.cs_off[a])
                     for c_ in range(bt.n_cigar[a]):
                         _ = bt.cigar[bt.cigar_off[a] + c_]
+                if gpu:
+                    out_, _ = ctx.score_batch(bp, presets[n % 2], finalize_seed=None)
+                    host_res += [key(out_[q]) for q in range(k)]
+                    host_names += names(bp)
                 h = vp()
                 rc = L.spx_plan_create(g.ref, bp, C.byref(presets[n % 2]), C.byref(h))
                 plans += 1
@@ -110,10 +161,23 @@ def main():
                     L.spx_plan_free(h)
             outcomes["records" if ok else "error"] += 1
             L.spx_bam_close(rd)
+            if gpu:
+                dres, dnames = device_side(bad, presets[n % 2])
+                if ok:
+                    assert dres is not None, f"seed {seed}, file {n}: the host reader accepts the file, the device input refuses it"
+                    assert dres == host_res and dnames == host_names, f"seed {seed}, file {n}: device input and host reader disagree"
+                    dev_stats["both_ok"] += 1
+                    dev_stats["groups"] += len(dres)
+                else:
+                    assert dres is None, f"seed {seed}, file {n}: the host reader refuses the file, the device input accepts it"
+                    dev_stats["both_error"] += 1
         if rng.random() < 0.1:
             off = (C.c_int64 * 64)()
             L.spx_bam_index_build(bad.encode(), 2, 5, off, 64)
         n += 1
+    if gpu:
+        print(f"device input vs host reader: {dev_stats['both_ok']} files accepted by both ({dev_stats['groups']} groups, identical results), "
+              f"{dev_stats['both_error']} refused by both")
     print(f"reader fuzz: seed {seed}, {n} damaged files ({outcomes['records']} read to the end, {outcomes['error']} ended in an error); "
           f"{plans} batches through the host plan ({plan_err} rejected); no crash, {time.time() - t0:.0f} s")
 

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "pmc_tmp"))
     ap.add_argument("--extra", nargs="*", default=[], help="more arguments for bench.py")
     ap.add_argument("--full", action="store_true", help="the whole pipelined step (preparation kernels included) instead of --kernel-only")
+    ap.add_argument("--inflate", action="store_true", help="profile tools/inflate_bench.py (the BGZF inflate kernel alone on a synthetic BAM's blocks) instead of bench.py")
     a = ap.parse_args()
     os.environ.setdefault("TMPDIR", "/tmp")
     # build once, here: the profiled bench never builds (a process the profiler has initialised must not spawn compilers)
@@ -47,6 +48,9 @@ def main():
             (["--no-host-leg", "--depth", "1"] if a.full else ["--kernel-only"]) + a.extra
     if a.groups_per_step:
         bench += ["--groups-per-step", str(a.groups_per_step)]
+    if a.inflate:
+        bench = ["python3", os.path.join(ROOT, "tools", "inflate_bench.py"), "--groups", str(a.groups_per_step or 16384), "--platform", a.platform,
+                 "--repeat", str(a.steps)] + a.extra
     for k, ctrs in enumerate(PASSES):
         d = os.path.join(a.scratch, f"pass{k}")
         shutil.rmtree(d, ignore_errors=True)
@@ -58,7 +62,11 @@ def main():
             meta.setdefault("failed_passes", []).append({"counters": ctrs, "rc": p.returncode, "stderr": p.stderr[-600:]})
             continue
         bj = json.loads(line[-1])
-        meta["groups_per_step"] = bj["config"]["groups_per_step_per_gpu"]
+        if a.inflate:
+            meta["groups_per_step"] = bj["groups"]
+            meta["blocks"], meta["inflated_bytes"], meta["compressed_bytes"] = bj["blocks"], bj["inflated_bytes"], bj["compressed_bytes"]
+        else:
+            meta["groups_per_step"] = bj["config"]["groups_per_step_per_gpu"]
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         acc = {}
         for f in files:
