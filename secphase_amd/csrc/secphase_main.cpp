@@ -96,6 +96,7 @@ static struct option long_options[] = {{"inputBam", required_argument, NULL, 'i'
                                        {"devices", required_argument, NULL, 1003},
                                        {"gpuInflate", required_argument, NULL, 1004},
                                        {"hostInput", no_argument, NULL, 1005},
+                                       {"segmentMB", required_argument, NULL, 1006},
                                        {NULL, 0, NULL, 0}};
 
 static void usage(const char *prog)
@@ -117,6 +118,7 @@ static void usage(const char *prog)
             "         --devices              several GPUs, e.g. 0-7 or 0,2,5: batches are dealt round-robin, the output is\n"
             "                                the same file-order list\n"
             "         --gpuInflate           (with --hostInput) BGZF inflate workers per GPU beside the host threads [8]; 0: host only\n"
+            "         --segmentMB            device-resident input: inflated MB per segment = per GPU work list [1024]\n"
             "         --hostInput            read, inflate and parse the BAM on the host (the round-3 reader) instead of on the\n"
             "                                device(s); implied by --writeBam\n"
             "         --writeBam, -w         Write <prefix>.quality_modified.out.bam (SAM text, as the reference does) with\n"
@@ -136,6 +138,7 @@ int main(int argc, char *argv[])
     std::string inputPath, fastaPath, prefix = "secphase", dirPath = "secphase_out_dir";
     bool preset_ont = false, preset_hifi = false, marker_mode = true, write_bam = false, batch_given = false;
     bool host_input = getenv("SPX_HOST_INPUT") != nullptr;
+    int segment_mb = 0;
     int threads = 4, groups_per_batch = 16384, gpu_inflate = 8, c;
     if (const char *e = getenv("SPX_GPU_INFLATE")) gpu_inflate = atoi(e);
     std::vector<int> devices;
@@ -187,6 +190,7 @@ int main(int argc, char *argv[])
         case 1001: groups_per_batch = atoi(optarg); batch_given = true; break;
         case 1004: gpu_inflate = atoi(optarg); break;
         case 1005: host_input = true; break;
+        case 1006: segment_mb = atoi(optarg); break;
         case 1002: case 1003:
             if (!parse_devices(optarg)) { fprintf(stderr, "[%s] cannot parse the device list %s\n", timestamp(), optarg); return 1; }
             break;
@@ -265,6 +269,7 @@ int main(int argc, char *argv[])
         spx_dbam_default_options(&dopt);
         dopt.threads = std::max(1, std::min(threads, spx_effective_cpus()));
         if (batch_given) dopt.max_groups = groups_per_batch;
+        if (segment_mb > 0) dopt.segment_bytes = (int64_t)segment_mb << 20;
         dopt.ahead = 2;
         if (spx_dbam_open(inputPath.c_str(), &dopt, &dbam) != SPX_OK) { fprintf(stderr, "[%s] %s\n", timestamp(), spx_last_error()); join_ctx(); die(1); }
         bam = spx_dbam_header(dbam);
@@ -289,6 +294,12 @@ int main(int argc, char *argv[])
     int rc = SPX_OK;
     for (int d = 0; d < n_dev; ++d)
         if (ctx_rc[(size_t)d] != SPX_OK) { fprintf(stderr, "[%s] device %d: %s: %s\n", timestamp(), devices[(size_t)d], spx_strerror(ctx_rc[(size_t)d]), ctx_err[(size_t)d].c_str()); die(1); }
+    /* the input pipelines start NOW: compressed blocks go up and are inflated / parsed / staged while the assembly is still
+     * being packed and copied to the device(s) (staging does not need it; the first spx_pipe_submit comes after it) */
+    if (dev_input && (rc = spx_dbam_start(dbam, ctxs.data(), n_dev, &par)) != SPX_OK) {
+        fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
+        die(1);
+    }
     { /* the assembly into every device's HBM, in parallel */
         std::vector<std::thread> th;
         for (int d = 0; d < n_dev; ++d)
@@ -351,10 +362,6 @@ int main(int argc, char *argv[])
             fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
             die(1);
         }
-    if (dev_input && (rc = spx_dbam_start(dbam, ctxs.data(), n_dev, &par)) != SPX_OK) {
-        fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
-        die(1);
-    }
     /* BED bookkeeping (marker arrays come back from the device) and the release of a work list's device memory happen on
      * a helper thread: the sets are order-independent (sorted and merged at the end), only the counts come back */
     struct Post { spx_work *w; int lane; const spx_batch *bt; std::vector<spx_group_out> out; };
@@ -538,7 +545,12 @@ int main(int argc, char *argv[])
                         "enqueue) %.3f s, parsing %.3f s = waiting for the carry %.3f + for inflate %.3f + record chain %.3f + fields / groups %.3f + image %.3f\n",
                 timestamp(), (long long)nseg, up / 1e9, sec[0], sec[1], sec[2], sec[3], sec[4], sec[5], sec[6]);
     }
-    if (!getenv("SPX_TIDY_EXIT")) {
+    /* How to leave.  Host input: every output is closed, what is left is tens of GB of inflate arena and file mapping to give
+     * back page by page, only for the process to end right after -- the pages go back in parallel on the pool and the process
+     * _exit()s.  Device input: the host side is small and the DRIVER is what takes long with a process that dies holding
+     * gigabytes of device and pinned memory (~0.4 s until the parent's wait returns, against ~0.16 s for freeing them here). */
+    const bool quick_exit = getenv("SPX_QUICK_EXIT") ? atoi(getenv("SPX_QUICK_EXIT")) != 0 : (!dev_input && !getenv("SPX_TIDY_EXIT"));
+    if (quick_exit) {
         const double t_drop0 = now_s();
         spx_bam_drop_pages(bam); /* (device input: the header reader owns the mapping) */ /* in parallel, instead of by the kernel's single-threaded teardown while the parent waits */
         const double t_drop = now_s() - t_drop0;
@@ -565,8 +577,16 @@ int main(int argc, char *argv[])
     for (spx_ctx *c_ : ctxs) spx_destroy(c_);
     const double t_end3 = now_s();
     spx_fasta_free(fa);
-    if (getenv("SPX_TIMING"))
+    if (getenv("SPX_TIMING")) {
         fprintf(stderr, "[%s] wind-down: BED merge + write %.3f s, closing the reader %.3f s, the context(s) %.3f s; whole process %.3f s\n", timestamp(),
                 t_end1 - t_end0, t_end2 - t_end1, t_end3 - t_end2, now_s() - t_proc0);
+        spx_internal_cpu_report(stderr);
+        struct timespec rt;
+        clock_gettime(CLOCK_REALTIME, &rt);
+        fprintf(stderr, "[spx timing] main() entered at %.3f, leaving at %.3f (epoch seconds)\n", rt.tv_sec + 1e-9 * rt.tv_nsec - (now_s() - t_proc0),
+                rt.tv_sec + 1e-9 * rt.tv_nsec);
+    }
+    fflush(NULL);
+    if (dev_input) _exit(0); /* everything is freed and closed; no static destructors of the HIP runtime under a finished program */
     return 0;
 }

@@ -396,7 +396,7 @@ extern "C" hipError_t spx_launch_bgzf_inflate_grouped(const uint8_t *comp, const
     if (n_blocks <= 0) return hipSuccess;
     const BlockDesc *bd = (const BlockDesc *)blocks;
     const int root = inflate_root_bits();
-    static const int ring = [] { const char *e = getenv("SPX_INFLATE_RING"); const int v = e ? atoi(e) : 2048; return (v == 1024 || v == 4096) ? v : 2048; }();
+    static const int ring = [] { const char *e = getenv("SPX_INFLATE_RING"); const int v = e ? atoi(e) : 1024; return (v == 2048 || v == 1025 || v == 4096) ? v : 1024; }();
     if (lanes_per_block == 16) {
         if (root == 11) SPX_LAUNCH_G(16, 11, 9, 2048); else if (root == 10) SPX_LAUNCH_G(16, 10, 8, 2048); else SPX_LAUNCH_G(16, 9, 8, 2048);
     } else {
@@ -405,6 +405,8 @@ extern "C" hipError_t spx_launch_bgzf_inflate_grouped(const uint8_t *comp, const
         else if (ring == 4096) SPX_LAUNCH_G(32, 9, 8, 4096);
         else if (ring == 1024)
             hipLaunchKernelGGL((bgzf_inflate_g_kernel<32, 9, 8, 1024, 5>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
+        else if (ring == 1025) /* experiment: 8-bit literal root, six waves per SIMD */
+            hipLaunchKernelGGL((bgzf_inflate_g_kernel<32, 8, 8, 1024, 6>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
         else SPX_LAUNCH_G(32, 9, 8, 2048);
     }
     return hipGetLastError();
@@ -414,8 +416,10 @@ extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *b
                                               int check_crc, hipStream_t st)
 {
     if (n_blocks <= 0) return hipSuccess;
-    /* SPX_INFLATE_LANES: 64 = one block per wave on the scalar unit, 16 / 32 = lanes per block of the grouped kernel */
-    static const int lanes = [] { const char *e = getenv("SPX_INFLATE_LANES"); const int v = e ? atoi(e) : 64; return (v == 16 || v == 32) ? v : 64; }();
+    /* SPX_INFLATE_LANES: 32 (default) / 16 = lanes per block of the grouped kernel (2 / 4 blocks per wave, decode on the vector ALU;
+     * SPX_INFLATE_RING = 1024 (default: five waves per SIMD) / 2048 / 4096 bytes of LDS ring per block), 64 = round 3's kernel: one block
+     * per wave on the scalar unit */
+    static const int lanes = [] { const char *e = getenv("SPX_INFLATE_LANES"); const int v = e ? atoi(e) : 32; return (v == 16 || v == 64) ? v : 32; }();
     if (lanes != 64) return spx_launch_bgzf_inflate_grouped(comp, blocks, n_blocks, out, status, check_crc, lanes, st);
     const BlockDesc *bd = (const BlockDesc *)blocks;
     const int root = inflate_root_bits();

@@ -1003,7 +1003,8 @@ struct spx_devstage_sizes {
 extern "C" int spx_internal_devstage_begin(spx_ctx *c, const spx_params *par, const spx_devstage_sizes *sz, spx_work **out, spx_din_out *O, char **d_info)
 {
     if (!c || !par || !sz || !out || !O || !d_info) return fail(SPX_EINVAL, "NULL argument");
-    if (!c->d_ref4) return fail(SPX_ENOREF, "spx_set_reference has not been called");
+    /* (the reference is not needed to STAGE records: the input pipelines may start while it is still on its way to the device;
+     * spx_prepare_staged asks for it) */
     *out = nullptr;
     if (sz->n_slots > SPX_MAX_STAGE_SLOTS || sz->n_dgroups > SPX_MAX_STAGE_SLOTS || sz->n_groups_in > 0x7fffffff)
         return fail(SPX_EINVAL, "more than 2^20 alignments in one work list");
@@ -1120,6 +1121,7 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
 extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
 {
     if (!c || !w || !w->staged) return fail(SPX_EINVAL, "work list has not been staged");
+    if (!c->d_ref4) return fail(SPX_ENOREF, "spx_set_reference has not been called");
     HIPCHK(hipSetDevice(c->device));
     const spx::StageLayout &L = w->stage.lay;
     const size_t ns = (size_t)L.n_slots, ng = (size_t)L.n_dgroups;
