@@ -119,6 +119,7 @@ struct spx_dbam {
     spx_params par;
     int32_t max_groups = 95000, ahead = 3;
     int64_t seg_bytes = (int64_t)1 << 30, carry_cap = (int64_t)256 << 20;
+    int64_t seg_first = 0; /* > 0: the first segment of every lane has this size, each following one twice its predecessor's up to seg_bytes */
     std::vector<Lane *> lanes;
     /* cutting segments (any uploader, under cut_mu) */
     std::mutex cut_mu;
@@ -374,12 +375,19 @@ Seg *Lane::cut_segment()
     s->c0 = d->fpos;
     if (s->index == 0) s->p0_extra = d->start_uoff;
     int64_t u = 0;
+    /* short segments first (the pipeline behind them fills early), long ones in the steady state (the preparation kernels of a
+     * work list are chains of fixed latency: their cost per group falls with the size of the list) */
+    int64_t target = d->seg_bytes;
+    if (d->seg_first > 0) {
+        const int64_t round = s->index / (int64_t)std::max<size_t>(1, d->lanes.size());
+        target = round < 20 ? std::min(d->seg_bytes, d->seg_first << round) : d->seg_bytes;
+    }
     auto bad = [&](const char *msg) -> Seg * {
         d->cut_eof = true;
         fail_here(msg, SPX_EINVAL);
         return nullptr;
     };
-    while (u < d->seg_bytes) {
+    while (u < target) {
         if (d->fpos >= d->fsize) { d->cut_eof = true; break; }
         if (d->fpos == d->end_coff && d->end_uoff == 0) { d->cut_eof = true; break; }
         const uint8_t *p = d->map + d->fpos;
@@ -915,6 +923,7 @@ extern "C" int spx_dbam_open(const char *path, const spx_dbam_options *opt, spx_
     if (const char *e = getenv("SPX_DIN_SEG_MB")) d->seg_bytes = (int64_t)atoll(e) << 20;
     if (const char *e = getenv("SPX_DIN_SEG_KB")) d->seg_bytes = (int64_t)atoll(e) << 10;
     d->seg_bytes = std::max<int64_t>(d->seg_bytes, 65536);
+    if (const char *e = getenv("SPX_DIN_SEG_FIRST_MB")) d->seg_first = (int64_t)atoll(e) << 20;
     if (o.carry_bytes > 0) d->carry_cap = o.carry_bytes;
     if (const char *e = getenv("SPX_DIN_CARRY_MB")) d->carry_cap = (int64_t)atoll(e) << 20;
     if (const char *e = getenv("SPX_DIN_CARRY_KB")) d->carry_cap = (int64_t)atoll(e) << 10;

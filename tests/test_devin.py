@@ -419,3 +419,32 @@ def test_device_input_on_several_lanes(ctx, tmp_path):
     d.close()
     c2.close()
     assert lanes == {0, 1} and res == want and names == want_names
+
+
+def test_device_input_on_shards_of_the_file(ctx, tmp_path):
+    """start_voffset / end_voffset (the group-start index in the reference's format, src/secphase_index.c:76-119): the device input
+    on consecutive shards of a file yields exactly the file's groups -- shard starts and ends in the middle of BGZF blocks,
+    with small segments so that a shard has several"""
+    g = small_genome(synth.HIFI, max_secondaries=3, n_paralogs=3, read_len=4000)
+    n = 300
+    chunks = [g.reads(k, 50) for k in range(0, n, 50)]
+    whole = g.reads(0, n)
+    bam = str(tmp_path / "shards.bam")
+    synth.write_bam(bam, [c.batch for c in chunks], g.ref, threads=2)
+    par = records.preset("hifi")
+    ctx.set_reference(g.ref)
+    want, want_names = _expected(ctx, whole, par)
+    L = api.lib()
+    L.spx_bam_index_build.argtypes = [C.c_char_p, C.c_int, C.c_int32, C.POINTER(C.c_int64), C.c_int64]
+    L.spx_bam_index_build.restype = C.c_int64
+    off = (C.c_int64 * 64)()
+    k = L.spx_bam_index_build(bam.encode(), 2, 37, off, 64)
+    assert k == (n + 36) // 37 + 1
+    assert any(off[i] & 0xffff for i in range(k)), "no shard boundary inside a block: the test would not test much"
+    res, names = [], []
+    for cut in ((0, 3), (3, 4), (4, k - 1)):
+        r, nm, sizes = _device_run(bam, ctx, par, g.ref, env={"SPX_DIN_SEG_KB": "256"}, start_voffset=off[cut[0]], end_voffset=off[cut[1]])
+        assert sum(sizes) == min(n, cut[1] * 37) - cut[0] * 37
+        res += r
+        names += nm
+    assert res == want and names == want_names
