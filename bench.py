@@ -632,6 +632,9 @@ def main():
         staged = []
         api._chk(L.spx_trim(ctx.h), "spx_trim")
         torch.cuda.empty_cache()
+        flag_ = os.path.join(tempfile.gettempdir(), f"spx_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.done")
+        if rank == 0 and os.path.exists(flag_):
+            os.unlink(flag_)  # (a stale flag of an earlier job on the same port)
         dist.barrier()
 
     nst = len(per_step_stats)
@@ -906,6 +909,16 @@ def main():
                 except Exception as ex:  # noqa: BLE001
                     line["also"][plat] = {"error": str(ex)}
         print(json.dumps(line), flush=True)
+    if world > 1 and want_bam_all:
+        # rank 0 ran the command line on EVERY device of the job: the other ranks wait on the host (a flag file), not in a collective
+        # whose kernel would spin on their GPUs beside the child process's kernels
+        flag = os.path.join(tempfile.gettempdir(), f"spx_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.done")
+        if rank == 0:
+            open(flag, "w").close()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(flag) and time.time() - t_wait < 1500:
+                time.sleep(0.2)
     if writer is not None:
         writer_q.put(None)
         writer.join()
@@ -917,6 +930,11 @@ def main():
         w.free()
     if world > 1:
         dist.barrier()
+        if rank == 0 and want_bam_all:
+            try:
+                os.unlink(os.path.join(tempfile.gettempdir(), f"spx_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.done"))
+            except OSError:
+                pass
         dist.destroy_process_group()
 
 

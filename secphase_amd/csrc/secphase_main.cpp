@@ -587,6 +587,8 @@ int main(int argc, char *argv[])
                 rt.tv_sec + 1e-9 * rt.tv_nsec);
     }
     fflush(NULL);
-    if (dev_input) _exit(0); /* everything is freed and closed; no static destructors of the HIP runtime under a finished program */
+    /* everything is freed and closed; no static destructors of the HIP runtime under a finished program -- unless a profiler needs
+     * its exit handlers (rocprofv3 writes its files from one): SPX_PROFILER=1 */
+    if (dev_input && !getenv("SPX_PROFILER")) _exit(0);
     return 0;
 }

@@ -471,7 +471,9 @@ int Lane::upload(Seg *s)
     }
     s->n_dev_blocks = nd;
     const size_t comp = nd == nb ? (size_t)(s->c1 - s->c0) : (nd == 0 ? 0 : (size_t)(s->blocks[nd - 1].in_off + s->blocks[nd - 1].clen + 8));
-    int rc = ensure_slot(S, (size_t)(d->carry_cap + s->ulen) + 256, comp + 256, nb + 1);
+    /* sized for the LARGEST segment from the start: growing a buffer later means hipFree, which waits for the whole device */
+    const size_t full = (size_t)(d->seg_bytes + 65536);
+    int rc = ensure_slot(S, (size_t)d->carry_cap + std::max((size_t)s->ulen, full) + 256, std::max(comp, d->seg_first > 0 ? full / 4 * 3 : (size_t)0) + 256, nb + 1);
     if (rc) return rc;
     const double t0 = now_s();
     /* compressed bytes through the ring of pinned chunks; the copies run on the reader's pool */

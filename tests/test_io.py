@@ -505,3 +505,36 @@ def test_pages_dropped_before_close(built, tmp_path):
         L.spx_bam_drop_pages(rd)
         L.spx_bam_drop_pages(None)
         L.spx_bam_close(rd)
+
+
+def test_device_input_handle_without_a_device(built, tmp_path):
+    """spx_dbam_open only maps the file and parses the header (no HIP call): targets, reference binding and close work on a
+    machine without a GPU; a file that is not a BAM is refused; the header-only reader refuses to cut batches"""
+    L = api.lib()
+    _declare_opts(L)
+    g = small_genome(synth.HIFI, read_len=1500)
+    r = g.reads(0, 20)
+    bam = str(tmp_path / "d.bam")
+    synth.write_bam(bam, [r.batch], g.ref, threads=1)
+    h = C.c_void_p()
+    o = api.DbamOptions()
+    L.spx_dbam_default_options(C.byref(o))
+    assert o.max_groups == 95000 and o.host_inflate_percent == -1 and o.start_voffset == -1
+    assert L.spx_dbam_open(bam.encode(), C.byref(o), C.byref(h)) == 0
+    hdr = L.spx_dbam_header(h)
+    assert L.spx_bam_n_targets(hdr) == g.ref.contents.n_contigs
+    assert L.spx_bam_bind_reference(hdr, g.ref) == 0
+    bp = C.POINTER(records.SpxBatch)()
+    assert L.spx_bam_next_batch(hdr, 8, C.byref(bp)) == api.EINVAL
+    L.spx_dbam_close(h)
+    junk = str(tmp_path / "junk.bam")
+    open(junk, "wb").write(b"not a bam at all" * 10)
+    assert L.spx_dbam_open(junk.encode(), None, C.byref(h)) != 0
+    # SPX_BAM_HEADER_ONLY through the reader's own options
+    ob = BamOptions()
+    L.spx_bam_default_options(C.byref(ob))
+    ob.flags = 4
+    rd = C.c_void_p()
+    assert L.spx_bam_open_opts(bam.encode(), C.byref(ob), C.byref(rd)) == 0
+    assert L.spx_bam_n_targets(rd) == g.ref.contents.n_contigs
+    L.spx_bam_close(rd)

@@ -130,7 +130,7 @@ def main():
     if args.rocprof:
         os.makedirs(args.rocprof, exist_ok=True)
         rp = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.abspath(args.rocprof), "-o", "cli", "--output-format", "csv", "--"] + cmd[:-0 or None],
-                            capture_output=True, text=True, env=dict(env, TMPDIR="/tmp"), cwd="/tmp")
+                            capture_output=True, text=True, env=dict(env, TMPDIR="/tmp", SPX_PROFILER="1", SPX_QUICK_EXIT="0"), cwd="/tmp")
         if rp.returncode != 0:
             print("rocprofv3 run failed: " + rp.stderr[-400:], file=sys.stderr)
         shutil.rmtree(outd, ignore_errors=True)
