@@ -227,11 +227,11 @@ int spx_write_relabel_log(const char *path, const char *mode, const spx_batch *b
 
 /* single banded-HMM problem on the device (unit tests / drop-in for the htslib symbol).
  * Uses a process-wide context on device 0 created on first use.
- * RESTRICTION: iqual must be NULL (htslib then assumes Q30) or hold ONE value for all bases -- which is the only way
- * secphase calls it (submodules/ptMarker/ptMarker.c:747-749 fills the array with set_q before the call at :755).  The
- * kernels keep the two emission values of that quality in registers for the whole problem; base-by-base qualities
- * (samtools' BAQ use of probaln_glocal) are refused: the call returns INT_MIN and spx_last_error() says why, nothing is
- * computed with a wrong model. */
+ * iqual == NULL: Q30 for every base, as htslib.  One value for all bases -- the only way secphase calls it
+ * (submodules/ptMarker/ptMarker.c:747-749 fills the array with set_q before the call at :755) -- runs on the scoring kernels,
+ * which keep the two emission values of that quality in registers.  Base-by-base qualities (samtools' BAQ use of probaln_glocal)
+ * take a general kernel (spx_probaln_general.hip: one lane per problem, rows in HBM, the reference's own operation order): same
+ * results bit for bit, at the rate of a contract, not of the hot path. */
 int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
                        const spx_probaln_par *c, int *state, uint8_t *q);
 

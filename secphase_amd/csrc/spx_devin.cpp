@@ -745,8 +745,18 @@ int Lane::parse(Seg *s)
     const int64_t n_batch = C.n_batch;
     const spx_din_counts Cs = C; /* (h_counts is reused below) */
     std::vector<int32_t> gf_host; /* only needed when the segment is split */
-    for (int64_t g0 = 0; g0 < n_batch;) {
-        const int64_t g1 = std::min<int64_t>(n_batch, g0 + d->max_groups);
+    /* a list that fails half-way leaves nothing behind: the lists made so far (their device memory) and the name blocks go back */
+    auto drop_items = [&] {
+        for (Item &x : items) {
+            if (x.work) spx_work_free(ctx, x.work);
+            if (x.names) {
+                std::lock_guard<std::mutex> lk(d->mu);
+                d->free_names.push_back(x.names);
+            }
+        }
+        items.clear();
+    };
+    auto make_list = [&](int64_t g0, int64_t g1) -> int {
         spx_din_range Q;
         memset(&Q, 0, sizeof Q);
         Q.g0 = g0; Q.g1 = g1;
@@ -807,20 +817,14 @@ int Lane::parse(Seg *s)
         O.grp_disp = (uint8_t *)(d_info + o_disp);
         O.names = d_info + o_names;
         NameBatch *nbh = names_get(d, o + 16);
-        if (!nbh) { for (Item &x : items) spx_work_free(ctx, x.work); return fail_here("pinned memory for the group names", SPX_ENOMEM); }
+        if (!nbh) return fail_here("pinned memory for the group names", SPX_ENOMEM);
         items.back().names = nbh;
         hipError_t e = spx_din_image(&A, &O, &Q, in_stream);
         if (e == hipSuccess) e = hipMemcpyAsync(nbh->pinned, d_info, o, hipMemcpyDeviceToHost, in_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(in_stream);
-        if (e != hipSuccess) {
-            for (Item &x : items) { spx_work_free(ctx, x.work); }
-            return fail_here(std::string("device input kernels: ") + hipGetErrorString(e), SPX_EHIP);
-        }
+        if (e != hipSuccess) return fail_here(std::string("device input kernels: ") + hipGetErrorString(e), SPX_EHIP);
         char *hp = (char *)nbh->pinned;
-        if ((rc = spx_internal_devstage_finish(ctx, w, (const uint8_t *)(hp + o_disp), in_stream)) != SPX_OK) {
-            for (Item &x : items) spx_work_free(ctx, x.work);
-            return fail_here(spx_last_error(), rc);
-        }
+        if ((rc = spx_internal_devstage_finish(ctx, w, (const uint8_t *)(hp + o_disp), in_stream)) != SPX_OK) return fail_here(spx_last_error(), rc);
         spx_batch &b = nbh->view;
         memset(&b, 0, sizeof b);
         b.n_groups = (int32_t)ng;
@@ -831,6 +835,14 @@ int Lane::parse(Seg *s)
         b.flag = (const uint16_t *)(hp + o_flag);
         b.tid = (const int32_t *)(hp + o_tid);
         b.pos = (const int32_t *)(hp + o_pos);
+        return SPX_OK;
+    };
+    for (int64_t g0 = 0; g0 < n_batch;) {
+        const int64_t g1 = std::min<int64_t>(n_batch, g0 + d->max_groups);
+        if ((rc = make_list(g0, g1)) != SPX_OK) {
+            drop_items();
+            return rc;
+        }
         g0 = g1;
     }
     /* the buffer may be written again once the image kernels have run (they have: every range ended with a synchronize) */

@@ -2074,17 +2074,72 @@ extern "C" int spx_probaln_posteriors(spx_ctx *c, int32_t n, const uint8_t *ref,
 static std::mutex g_single_mu;
 static spx_ctx *g_single = nullptr;
 
+extern "C" hipError_t spx_launch_probaln_general(const uint8_t *d_ref, int32_t l_ref, const uint8_t *d_query, int32_t l_query, const float *d_qual, int32_t bw,
+                                                 const double *hmm13, double *d_f, double *d_b, double *d_s, int64_t i_dim, int32_t *d_state, uint8_t *d_q,
+                                                 const double *d_thr, hipStream_t st);
+
+/* per-base qualities (htslib's iqual[i]; samtools' BAQ passes them, secphase never does): the general kernel of
+ * spx_probaln_general.hip, one problem at a time.  Returns the phred-scaled likelihood or INT_MIN. */
+static int probaln_per_base(spx_ctx *c, const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+                            const spx_probaln_par *cpar, int *state, uint8_t *q)
+{
+    if (hipSetDevice(c->device) != hipSuccess) return INT_MIN;
+    const int bw = spx::effective_bw(l_ref, l_query, cpar->bw);
+    const int64_t i_dim = 3 * (2 * (int64_t)bw + 1) + 6, cells = ((int64_t)l_query + 1) * i_dim + 8;
+    double h[SPX_H_N];
+    spx::hmm_constants(l_ref, l_query, cpar->d, cpar->e, 30, h); /* (the emission entries are not used: they come per base) */
+    const double hmm13[13] = {h[SPX_H_M0], h[SPX_H_M1], h[SPX_H_M2], h[SPX_H_M3], h[SPX_H_M4], 0., h[SPX_H_M6], 0., h[SPX_H_M8],
+                              h[SPX_H_BM], h[SPX_H_BI], h[SPX_H_SM], h[SPX_H_SI]};
+    std::vector<float> qual((size_t)l_query);
+    for (int i = 0; i < l_query; ++i) qual[(size_t)i] = (float)pow(10, -iqual[i] / 10.); /* htslib's qual[] (host libm) */
+    char *blk = nullptr;
+    Carver cv;
+    const size_t o_f = cv.take<double>((size_t)cells), o_b = cv.take<double>((size_t)cells), o_s = cv.take<double>((size_t)l_query + 2),
+                 o_qual = cv.take<float>((size_t)l_query), o_ref = cv.take<uint8_t>((size_t)l_ref), o_qry = cv.take<uint8_t>((size_t)l_query),
+                 o_state = cv.take<int32_t>((size_t)l_query), o_q = cv.take<uint8_t>((size_t)l_query);
+    if (hipMalloc((void **)&blk, cv.off + 256) != hipSuccess) { (void)hipGetLastError(); fail(SPX_ENOMEM, "device memory for the DP matrices"); return INT_MIN; }
+    int pr = INT_MIN;
+    std::vector<double> s((size_t)l_query + 2);
+    std::vector<int32_t> st32((size_t)l_query);
+    hipError_t e = hipMemsetAsync(blk, 0, cv.off + 256, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(blk + o_qual, qual.data(), qual.size() * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(blk + o_ref, ref, (size_t)l_ref, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(blk + o_qry, query, (size_t)l_query, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = spx_launch_probaln_general((const uint8_t *)(blk + o_ref), l_ref, (const uint8_t *)(blk + o_qry), l_query, (const float *)(blk + o_qual), bw, hmm13,
+                                       (double *)(blk + o_f), (double *)(blk + o_b), (double *)(blk + o_s), i_dim, (int32_t *)(blk + o_state),
+                                       (uint8_t *)(blk + o_q), c->d_tables, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.data(), blk + o_s, s.size() * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(st32.data(), blk + o_state, st32.size() * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(q, blk + o_q, (size_t)l_query, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(blk);
+    if (e != hipSuccess) { fail(SPX_EHIP, hipGetErrorString(e)); return INT_MIN; }
+    for (int i = 0; i < l_query; ++i) state[i] = st32[(size_t)i];
+    double pp = 1., Pr1 = 0.;
+    for (int i = 0; i <= l_query + 1; ++i) {
+        pp *= s[(size_t)i];
+        if (pp < 1e-100) { Pr1 += -4.343 * log(pp); pp = 1.; }
+    }
+    Pr1 += -4.343 * log(pp * l_ref * l_query);
+    const double v = Pr1 + .499;
+    pr = (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN;
+    return pr;
+}
+
 extern "C" int spx_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
                                   const spx_probaln_par *cpar, int *state, uint8_t *q)
 {
     if (l_ref <= 0 || l_query <= 0) return 0; /* as htslib */
     if (!ref || !query || !cpar || !state || !q) return INT_MIN;
     int sq = iqual ? iqual[0] : 30;
+    bool per_base = false;
     if (iqual)
         for (int i = 1; i < l_query; ++i)
-            if (iqual[i] != sq) { fail(SPX_EUNSUPPORTED, "per-base iqual: secphase always passes a constant (ptMarker.c:747-749)"); return INT_MIN; }
+            if (iqual[i] != sq) { per_base = true; break; }
     std::lock_guard<std::mutex> lk(g_single_mu);
     if (!g_single && spx_create(0, &g_single) != SPX_OK) return INT_MIN;
+    if (per_base) return probaln_per_base(g_single, ref, l_ref, query, l_query, iqual, cpar, state, q);
     int64_t ro[2] = {0, l_ref}, qo[2] = {0, l_query};
     int32_t sq32 = sq;
     std::vector<int32_t> st32(l_query);

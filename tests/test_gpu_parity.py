@@ -869,6 +869,47 @@ def test_probaln_glocal_symbol_on_device(built):
     assert L.spx_probaln_glocal(u8(ref), 0, u8(qry), len(qry), None, C.byref(par), st.ctypes.data_as(C.POINTER(C.c_int)), u8(q)) == 0
 
 
+def test_probaln_glocal_with_per_base_qualities(built):
+    """htslib's contract in full: iqual[i] may differ from base to base (samtools' BAQ; secphase passes a constant).  Such
+    problems take the general kernel (spx_probaln_general.hip): state[], q[] and the returned likelihood equal the oracle's
+    for HiFi- and ONT-shaped windows, bands wider than the sequences, ambiguous bases, R != L, qualities from 0 to 93 -- and
+    a constant array still gives what the scoring kernels give"""
+    rng = np.random.default_rng(33)
+    L = api.lib()
+    OL = orc.lib()
+    u8 = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint8))
+    ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int))
+    cases = [(801, 0.003, 0.002, 20, 1e-4, 0.0), (640, 0.02, 0.04, 50, 1e-3, 0.0), (57, 0.05, 0.05, 7, 1e-2, 0.0), (2, 0.0, 0.0, 3, 1e-4, 0.0),
+             (300, 0.3, 0.1, 130, 1e-3, 0.02), (33, 0.05, 0.05, 50, 1e-3, 0.0), (1200, 0.01, 0.02, 35, 1e-3, 0.01)]
+    for (n, sub, ind, bw, d, nfrac) in cases:
+        ref, qry = _rand_problem(rng, n, ind, sub, n_frac=nfrac)
+        par = api.ProbalnPar(d, 0.1, abs(len(ref) - len(qry)) + bw)
+        opar = orc.ProbalnPar(d, 0.1, par.bw)
+        iq = rng.integers(0, 94, len(qry)).astype(np.uint8)
+        if len(qry) > 1 and iq[0] == iq[1]:
+            iq[1] = (iq[0] + 7) % 94
+        st, q = np.zeros(len(qry), np.int32), np.zeros(len(qry), np.uint8)
+        est, eq = np.zeros(len(qry), np.int32), np.zeros(len(qry), np.uint8)
+        pr = L.spx_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), u8(iq), C.byref(par), ip(st), u8(q))
+        epr = OL.orc_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), u8(iq), C.byref(opar), ip(est), u8(eq))
+        assert pr == epr and pr != -2 ** 31, (n, pr, epr)
+        assert np.array_equal(st, est) and np.array_equal(q, eq), (n, np.flatnonzero(st != est)[:5], np.flatnonzero(q != eq)[:5])
+    # the general kernel on a CONSTANT array = the scoring kernels (two implementations, one answer)
+    ref, qry = _rand_problem(rng, 500, 0.01, 0.01)
+    par = api.ProbalnPar(1e-4, 0.1, 24)
+    iq = np.full(len(qry), 37, np.uint8)
+    st0, q0 = np.zeros(len(qry), np.int32), np.zeros(len(qry), np.uint8)
+    pr0 = L.spx_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), u8(iq), C.byref(par), ip(st0), u8(q0))
+    iq[-1] = 36  # one base differs: the general kernel
+    st1, q1 = np.zeros(len(qry), np.int32), np.zeros(len(qry), np.uint8)
+    L.spx_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), u8(iq), C.byref(par), ip(st1), u8(q1))
+    est, eq = np.zeros(len(qry), np.int32), np.zeros(len(qry), np.uint8)
+    opar = orc.ProbalnPar(1e-4, 0.1, 24)
+    OL.orc_probaln_glocal(u8(ref), len(ref), u8(qry), len(qry), u8(iq), C.byref(opar), ip(est), u8(eq))
+    assert np.array_equal(st1, est) and np.array_equal(q1, eq) and pr0 != -2 ** 31
+    assert np.array_equal(st0[:-40], st1[:-40])  # far from the changed base nothing moves
+
+
 def test_command_line_stops_on_records_without_tags(ctx, tmp_path):
     """a dispatched group whose records carry neither cs nor MD ends the run like the reference does (cigar_it.c:64-67)"""
     import subprocess
