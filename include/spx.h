@@ -192,6 +192,12 @@ int spx_collect(spx_ctx *ctx, spx_work *work, spx_group_out *out);
  * of bt->qual (same qual_off layout) for batch number batch_index of spx_prepare_many; it is edited in place. */
 int spx_apply_quals(spx_ctx *ctx, spx_work *w, int32_t batch_index, const spx_batch *bt, uint8_t *qual);
 int spx_work_stats(const spx_work *work, spx_stats *stats);
+/* diagnostics: device bytes of the prepared list (work list + scratch + outputs; the staged records not counted) and the
+ * number of DP slices it runs in.  Slices (round 4): 1/s of every DP row and the saved forward rows -- the bulk of a list --
+ * exist for ONE range of consecutive groups at a time: forward -> backward -> MAP run range by range over the same scratch
+ * (ptMarker.c:699-806 has no such notion: it realigns one window at a time).  SPX_DP_SLICE_GB (default 16) is the scratch a
+ * slice may take, SPX_DP_SLICES forces a count. */
+int64_t spx_work_device_bytes(const spx_work *work, int32_t *n_slices);
 void spx_work_free(spx_ctx *ctx, spx_work *work);
 
 /* ---- in-order pipeline over one context: what replaces the reference's thread pool + output mutex

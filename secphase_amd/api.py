@@ -104,7 +104,7 @@ EXPORTS = [
     "spx_probaln_posteriors", "spx_apply_quals", "spx_sam_open", "spx_sam_write_group", "spx_sam_close",
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
-    "spx_dbam_default_options", "spx_dbam_open", "spx_dbam_header", "spx_dbam_start", "spx_dbam_next", "spx_dbam_release", "spx_dbam_stats", "spx_dbam_close",
+    "spx_work_device_bytes", "spx_dbam_default_options", "spx_dbam_open", "spx_dbam_header", "spx_dbam_start", "spx_dbam_next", "spx_dbam_release", "spx_dbam_stats", "spx_dbam_close",
     "spx_sam_write_group_of", "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
 ]
 
@@ -164,6 +164,9 @@ def lib():
     L.spx_pack_decisions.argtypes = [vp, vp, C.c_int32, vp, C.c_int64]
     L.spx_collect.argtypes = [vp, vp, C.POINTER(GroupOut)]
     L.spx_work_stats.argtypes = [vp, C.POINTER(Stats)]
+    if hasattr(L, "spx_work_device_bytes"):
+        L.spx_work_device_bytes.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.spx_work_device_bytes.restype = C.c_int64
     L.spx_work_free.argtypes = [vp, vp]
     L.spx_work_free.restype = None
     L.spx_finalize.argtypes = [C.POINTER(SpxParams), C.c_uint, C.POINTER(GroupOut), C.c_int32]
@@ -376,6 +379,11 @@ class Work:
         _chk(lib().spx_apply_quals(self.ctx.h, self.h, batch_index, batch, qual.ctypes.data_as(_u8p)),
              "spx_apply_quals")
         return qual
+
+    def device_bytes(self):
+        """(device bytes of the prepared list, DP slices)"""
+        k = C.c_int32(0)
+        return int(lib().spx_work_device_bytes(self.h, C.byref(k))), k.value
 
     def stats(self):
         st = Stats()

@@ -76,6 +76,11 @@ typedef struct spx_dev_batch {
     int32_t *out_state; /* may be NULL */
     uint8_t *out_q;     /* may be NULL */
     const double *qthr; /* [102] phred thresholds on 1 - max/sum */
+    /* DP slices (round 4): a launch may cover the wanted rows [row_base, row_base + n) of the list only (MAP kernel); the
+     * forward / backward kernels of a slice get that slice's launch orders, and sinv / fsave point at scratch that is
+     * shared by all slices, shifted by the slice's first offset (s_off / fsave_off stay absolute) */
+    int32_t row_base;
+    int32_t pad_;
 } spx_dev_batch;
 
 /* marker table for the scoring kernel: one entry per (position, alignment) */

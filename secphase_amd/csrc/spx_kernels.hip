@@ -916,9 +916,9 @@ __global__ __launch_bounds__(256) void map_kernel(spx_dev_batch B, int32_t n_row
      * share of the slots (coalesced reads of the 2 x slots doubles a row holds); products and the running argmax
      * are lane-local, the sum is passed from lane to lane in column order */
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = (int)(tid / LPR), g = (int)(tid & (LPR - 1));
-    const bool on = r < n_rows_total;
-    const int rr = on ? r : 0;
+    const int r = B.row_base + (int)(tid / LPR), g = (int)(tid & (LPR - 1));
+    const bool on = r < B.row_base + n_rows_total;
+    const int rr = on ? r : B.row_base;
     const int p = B.row_prob[rr];
     const int i = B.rows[rr], bw = B.bw[p], R = B.R[p];
     const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = (slots + LPR - 1) / LPR;

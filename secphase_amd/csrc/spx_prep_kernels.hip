@@ -529,7 +529,26 @@ __global__ __launch_bounds__(256) void order_keys_kernel(spx_order_args O)
     const uint64_t hi = ((uint64_t)cls << 30) | ((uint64_t)bw << 20);
     O.key_f[p] = hi | (0xfffffu - lf);
     O.key_b[p] = hi | (0xfffffu - lb);
-    O.val[p] = p;
+    O.val[p] = p + O.pad; /* (pad = first problem of the slice these arrays start at: the orders hold list-wide problem ids) */
+}
+
+/* DP slices: where the problems / rows / scratch of the dispatched groups [ng * k / K, ng * (k + 1) / K) start -- the
+ * prefix sums of the work list (PlanBase of a group's first alignment), K + 1 entries, the last = the totals */
+__global__ void slice_bounds_kernel(const int32_t *__restrict__ slot0, const spxl::PlanBase *__restrict__ base, int32_t ng, int32_t K, spxl::PlanBase tot,
+                                    spxl::PlanBase *__restrict__ out)
+{
+    const int k = (int)threadIdx.x;
+    if (k > K) return;
+    if (k == K) { out[k] = tot; return; }
+    const int32_t g = (int32_t)((int64_t)ng * k / K);
+    out[k] = base[slot0[g]];
+}
+
+extern "C" hipError_t spx_prep_slice_bounds(const int32_t *slot0, const spxl::PlanBase *base, int32_t ng, int32_t K, const spxl::PlanBase *tot,
+                                            spxl::PlanBase *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(slice_bounds_kernel, dim3(1), dim3(64), 0, st, slot0, base, ng, K, *tot, out);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void order_bins_kernel(const uint64_t *__restrict__ keys, int32_t n, int32_t *__restrict__ bin_start,

@@ -47,6 +47,9 @@ extern "C" size_t spx_order_temp_bytes(int32_t n_prob);
 extern "C" hipError_t spx_stage_expand(const void *recs, int32_t n_slots, const uint8_t *pk_seq, const uint8_t *pk_qual, uint8_t *seq, uint8_t *qual,
                                        int has_alias, hipStream_t st);
 extern "C" hipError_t spx_prep_orders(const spx_order_args *O, const spx_order_segs *sf, const spx_order_segs *sb, hipStream_t st);
+extern "C" hipError_t spx_prep_slice_bounds(const int32_t *slot0, const spxl::PlanBase *base, int32_t ng, int32_t K, const spxl::PlanBase *tot,
+                                            spxl::PlanBase *out, hipStream_t st);
+#define SPX_MAX_SLICES 32
 
 extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
                                               int check_crc, hipStream_t st);
@@ -153,6 +156,7 @@ struct spx_ctx {
         std::mutex mu;
         DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort;
         spx_prep_totals *d_tot = nullptr, *h_tot = nullptr; /* device / pinned host */
+        spxl::PlanBase *d_bounds = nullptr, *h_bounds = nullptr; /* DP slices: SPX_MAX_SLICES + 1 prefix records */
         int32_t *d_bins = nullptr;                          /* 3 x SPX_N_CLASSES x 1024 */
     } lane[SPX_N_PREP];
     std::atomic<unsigned> lane_rr{0};
@@ -224,6 +228,15 @@ struct spx_work {
     size_t arena_bytes = 0, arena_cap = 0;
     spx_dev_batch cls_batch[SPX_N_CLASSES];
     int cls_used[SPX_N_CLASSES] = {};
+    /* DP slices (round 4): the list's problems in K ranges of consecutive groups; forward -> backward -> MAP run slice by
+     * slice over ONE scratch area (1/s of every DP row + the saved forward rows) sized for the largest slice, so that a
+     * list can be LONG (the preparation's fixed latency amortised) without being LARGE.  Empty: one launch over everything. */
+    struct Slice {
+        int64_t r0 = 0, r1 = 0; /* its wanted rows */
+        spx_dev_batch cls_batch[SPX_N_CLASSES];
+        hipEvent_t ev_start = nullptr, ev_f0 = nullptr, ev_f1 = nullptr, ev_b1 = nullptr;
+    };
+    std::vector<Slice> slices;
     int main_cls = -1;
     int64_t cls_cells[SPX_N_CLASSES] = {};
     spx_dev_groups dg;
@@ -347,6 +360,8 @@ extern "C" int spx_create(int device, spx_ctx **out)
         HIPCHK(mk_stream(&PL.stream, m_prep));
         HIPCHK(hipMalloc((void **)&PL.d_tot, sizeof(spx_prep_totals)));
         HIPCHK(hipHostMalloc((void **)&PL.h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&PL.d_bounds, sizeof(spxl::PlanBase) * (SPX_MAX_SLICES + 1)));
+        HIPCHK(hipHostMalloc((void **)&PL.h_bounds, sizeof(spxl::PlanBase) * (SPX_MAX_SLICES + 1), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&PL.d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
     }
     c->prep_cus = masked ? prep_cus : 0;
@@ -417,6 +432,8 @@ extern "C" void spx_destroy(spx_ctx *c)
             if (b->p) (void)hipFree(b->p);
         if (PL.d_tot) (void)hipFree(PL.d_tot);
         if (PL.h_tot) (void)hipHostFree(PL.h_tot);
+        if (PL.d_bounds) (void)hipFree(PL.d_bounds);
+        if (PL.h_bounds) (void)hipHostFree(PL.h_bounds);
         if (PL.d_bins) (void)hipFree(PL.d_bins);
         if (PL.stream) (void)hipStreamDestroy(PL.stream);
     }
@@ -1239,7 +1256,35 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     const spx_prep_totals &T = w->tot;
     const size_t np = (size_t)T.n_prob, nr = (size_t)T.n_rows, nq = (size_t)T.n_qe, nm = (size_t)T.n_mk;
     if (np > 0x7ffffff0u || nr > 0x7ffffff0u || nm > 0x7ffffff0u) return fail(SPX_EINVAL, "work list too large: stage fewer groups at a time");
-    spx_order_segs sf, sb;
+    /* ---- DP slices: K ranges of consecutive groups that share ONE scratch area.  K from the scratch the list
+     * would need (SPX_DP_SLICE_GB per slice, default 16; SPX_DP_SLICES forces a count); >= 256 groups per slice ---- */
+    int K = 1;
+    {
+        const double scratch_gb = ((double)T.s_tot + (double)T.f_tot) * 8.0 / 1e9;
+        double budget = 16.0;
+        if (const char *e = getenv("SPX_DP_SLICE_GB")) budget = std::max(0.001, atof(e));
+        if (scratch_gb > budget) K = (int)ceil(scratch_gb / budget);
+        if (const char *e = getenv("SPX_DP_SLICES")) K = atoi(e);
+        K = std::max(1, std::min(K, std::min(SPX_MAX_SLICES, (int)std::max<size_t>(1, ng / 256))));
+    }
+    std::vector<spxl::PlanBase> bnd((size_t)K + 1);
+    bnd[0] = spxl::PlanBase{0, 0, 0, 0, 0};
+    bnd[(size_t)K] = spxl::PlanBase{(int64_t)np, (int64_t)nr, (int64_t)nq, T.s_tot, T.f_tot};
+    if (K > 1) {
+        HIPCHK(spx_prep_slice_bounds(A.slot0, d_base, (int32_t)ng, K, &bnd[(size_t)K], PL.d_bounds, PL.stream));
+        HIPCHK(hipMemcpyAsync(PL.h_bounds, PL.d_bounds, sizeof(spxl::PlanBase) * ((size_t)K + 1), hipMemcpyDeviceToHost, PL.stream));
+        HIPCHK(hipStreamSynchronize(PL.stream));
+        for (int k = 0; k <= K; ++k) bnd[(size_t)k] = PL.h_bounds[k];
+        for (int k = 0; k < K; ++k)
+            if (bnd[(size_t)k + 1].prob < bnd[(size_t)k].prob || bnd[(size_t)k + 1].s_off < bnd[(size_t)k].s_off || bnd[(size_t)k + 1].f_off < bnd[(size_t)k].f_off)
+                return fail(SPX_EINVAL, "work-list prefix sums are not monotonic");
+    }
+    int64_t max_s = 0, max_f = 0;
+    for (int k = 0; k < K; ++k) {
+        max_s = std::max(max_s, bnd[(size_t)k + 1].s_off - bnd[(size_t)k].s_off);
+        max_f = std::max(max_f, bnd[(size_t)k + 1].f_off - bnd[(size_t)k].f_off);
+    }
+    std::vector<spx_order_segs> sfk((size_t)K), sbk((size_t)K);
     size_t order_f_n = 0, order_b_n = 0;
     w->main_cls = -1;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
@@ -1247,17 +1292,23 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         w->st.problems_per_class[cls] = T.cls_prob[cls];
         w->cls_used[cls] = T.cls_prob[cls] > 0;
         if (w->cls_used[cls] && (w->main_cls < 0 || w->cls_cells[cls] > w->cls_cells[w->main_cls])) w->main_cls = cls;
-        /* a class segment holds its problems plus, per band width that can occur in the class, less than one wave of padding */
-        const int ppw_f = 64 / spx::class_lanes(cls), ppw_b = 64 / spx::class_lanes_bwd(cls);
-        const int wmax = spx::class_slots(cls);
-        const size_t widths = (size_t)std::min(1024, wmax / 2 + 1);
-        sf.off[cls] = (int64_t)order_f_n;
-        sf.cap[cls] = T.cls_prob[cls] > 0 ? (int64_t)(((size_t)T.cls_prob[cls] + widths * ppw_f + 63) & ~(size_t)63) : 0;
-        order_f_n += (size_t)sf.cap[cls];
-        sb.off[cls] = (int64_t)order_b_n;
-        sb.cap[cls] = T.cls_prob[cls] > 0 ? (int64_t)(((size_t)T.cls_prob[cls] + widths * ppw_b + 63) & ~(size_t)63) : 0;
-        order_b_n += (size_t)sb.cap[cls];
     }
+    for (int k = 0; k < K; ++k)
+        for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+            /* a class segment holds its problems plus, per band width that can occur in the class, less than one wave of padding
+             * (a slice: at most all the problems of the slice, at most all the problems of the class) */
+            const int ppw_f = 64 / spx::class_lanes(cls), ppw_b = 64 / spx::class_lanes_bwd(cls);
+            const int wmax = spx::class_slots(cls);
+            const size_t widths = (size_t)std::min(1024, wmax / 2 + 1);
+            const size_t most = (size_t)std::min<int64_t>(T.cls_prob[cls], bnd[(size_t)k + 1].prob - bnd[(size_t)k].prob);
+            spx_order_segs &sf = sfk[(size_t)k], &sb = sbk[(size_t)k];
+            sf.off[cls] = (int64_t)order_f_n;
+            sf.cap[cls] = most > 0 ? (int64_t)((most + widths * ppw_f + 63) & ~(size_t)63) : 0;
+            order_f_n += (size_t)sf.cap[cls];
+            sb.off[cls] = (int64_t)order_b_n;
+            sb.cap[cls] = most > 0 ? (int64_t)((most + widths * ppw_b + 63) & ~(size_t)63) : 0;
+            order_b_n += (size_t)sb.cap[cls];
+        }
     Carver cv;
     const size_t o_ref_nib = cv.take<int64_t>(np), o_qry_nib = cv.take<int64_t>(np), o_L = cv.take<int32_t>(np), o_R = cv.take<int32_t>(np),
                  o_bw = cv.take<int32_t>(np), o_hmm = cv.take<double>(np * SPX_H_N), o_row_off = cv.take<int32_t>(np),
@@ -1269,7 +1320,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
                  o_naln = cv.take<uint8_t>(ng + 16), o_sec = cv.take<uint16_t>(ng + 8), o_rfe = cv.take<int32_t>(ng * 10 + 10),
                  o_rfs = cv.take<int32_t>(ng * 10 + 10), o_atid = cv.take<int32_t>(ng * 10 + 10), o_info = cv.take<spx_group_info>(ng + 1);
     const size_t in_bytes = cv.off;
-    const size_t o_sinv = cv.take<double>((size_t)T.s_tot + 16), o_fsave = cv.take<double>((size_t)T.f_tot + 16), o_bq = cv.take<uint8_t>(nr + 16),
+    const size_t o_sinv = cv.take<double>((size_t)max_s + 16), o_fsave = cv.take<double>((size_t)max_f + 16), o_bq = cv.take<uint8_t>(nr + 16),
                  o_posmin = cv.take<uint8_t>(nm + 16), o_score = cv.take<double>(ng * 10 + 10), o_prim = cv.take<uint8_t>(ng + 16),
                  o_max = cv.take<uint8_t>(ng + 16), o_pass = cv.take<uint8_t>(ng + 16), o_tie = cv.take<uint16_t>(ng + 8),
                  o_results = cv.take<spx_group_out>(ng + 1);
@@ -1321,7 +1372,15 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         O.bin_start = PL.d_bins; O.bin_end = PL.d_bins + SPX_N_CLASSES * 1024; O.pad_base = PL.d_bins + 2 * SPX_N_CLASSES * 1024;
         O.temp = PL.pool_sort.p; O.temp_bytes = sort_tmp;
         O.order_f = (int32_t *)(B0 + o_order_f); O.order_b = (int32_t *)(B0 + o_order_b);
-        HIPCHK(spx_prep_orders(&O, &sf, &sb, PL.stream));
+        for (int k = 0; k < K; ++k) { /* one sort per slice: keys of its problems, values = list-wide problem ids */
+            const int64_t p0 = bnd[(size_t)k].prob, p1 = bnd[(size_t)k + 1].prob;
+            if (p1 <= p0) continue;
+            spx_order_args Ok = O;
+            Ok.n_prob = (int32_t)(p1 - p0);
+            Ok.pad = (int32_t)p0;
+            Ok.bw = O.bw + p0; Ok.L = O.L + p0; Ok.n_rows = O.n_rows + p0; Ok.row_off = O.row_off + p0;
+            HIPCHK(spx_prep_orders(&Ok, &sfk[(size_t)k], &sbk[(size_t)k], PL.stream));
+        }
     }
     if (!w->ev_ready) HIPCHK(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(w->ev_ready, PL.stream));
@@ -1342,8 +1401,15 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     w->d_row_expect = E.out.row_expect;
     w->n_rows_dev = (int64_t)nr; w->n_mk_dev = (int64_t)nm; w->n_prob_dev = (int64_t)np;
     w->mirrors_markers = w->mirrors_qe = false;
+    for (spx_work::Slice &sl : w->slices) {
+        for (hipEvent_t e : {sl.ev_start, sl.ev_f0, sl.ev_f1, sl.ev_b1}) if (e) (void)hipEventDestroy(e);
+    }
+    w->slices.clear();
+    if (K > 1) w->slices.resize((size_t)K);
+    for (int k = 0; k < K; ++k)
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
-        spx_dev_batch &B = w->cls_batch[cls];
+        const spx_order_segs &sf = sfk[(size_t)k], &sb = sbk[(size_t)k];
+        spx_dev_batch &B = K > 1 ? w->slices[(size_t)k].cls_batch[cls] : w->cls_batch[cls];
         memset(&B, 0, sizeof B);
         B.order = (const int32_t *)(B0 + o_order_f) + sf.off[cls];
         B.order_bwd = (const int32_t *)(B0 + o_order_b) + sb.off[cls];
@@ -1354,14 +1420,22 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         B.ref4 = c->d_ref4;
         B.qry4 = A.P.code4;
         B.rows = E.out.rows; B.row_expect = E.out.row_expect; B.row_rawq = E.out.row_rawq;
-        B.sinv = (double *)(B0 + o_sinv);
+        /* scratch shared by the slices: a slice's offsets start at its prefix (s_off / fsave_off stay list-wide) */
+        B.sinv = (double *)(B0 + o_sinv) - bnd[(size_t)k].s_off;
         B.s_raw = nullptr;
-        B.fsave = (double *)(B0 + o_fsave);
+        B.fsave = (double *)(B0 + o_fsave) - bnd[(size_t)k].f_off;
         B.row_prob = E.out.row_prob; B.prob_slots = E.out.prob_slots;
         B.fsave_stride = 2 * spx::class_slots(cls);
         B.fsave_off = E.out.fsave_off;
         B.out_bq = w->d_bq; B.out_state = nullptr; B.out_q = nullptr;
         B.qthr = c->d_tables;
+        if (K > 1 && k == 0) w->cls_batch[cls] = B; /* (what spx_work_export / the mirrors read: the per-problem arrays) */
+    }
+    for (int k = 0; k < K && K > 1; ++k) {
+        spx_work::Slice &sl = w->slices[(size_t)k];
+        sl.r0 = bnd[(size_t)k].row;
+        sl.r1 = bnd[(size_t)k + 1].row;
+        for (hipEvent_t *e : {&sl.ev_start, &sl.ev_f0, &sl.ev_f1, &sl.ev_b1}) HIPCHK(hipEventCreate(e));
     }
     spx_dev_groups &G = w->dg;
     memset(&G, 0, sizeof G);
@@ -1455,6 +1529,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
         if (w->cls_used[cls] && cls != mc) order[no++] = cls;
     std::sort(order, order + no, [&](int a, int b) { return w->cls_cells[a] != w->cls_cells[b] ? w->cls_cells[a] > w->cls_cells[b] : a < b; });
+    if (w->slices.empty()) {
     int64_t load[spx_ctx::SPX_N_SIDE] = {};
     bool used_side[spx_ctx::SPX_N_SIDE] = {};
     for (int k = 0; k < no; ++k) {
@@ -1482,6 +1557,49 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
         const int64_t nrows = w->staged ? w->n_rows_dev : (int64_t)w->hb.rows.size();
         HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)nrows, wide > narrow, c->stream));
+    }
+    } else {
+        /* DP slices: forward -> backward -> MAP of one slice after the other over the shared scratch; inside a slice the band
+         * classes run side by side as above.  A slice starts when the MAP kernel of the one before has read the scratch. */
+        int64_t narrow = 0, wide = 0;
+        for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
+        for (size_t k = 0; k < w->slices.size(); ++k) {
+            spx_work::Slice &sl = w->slices[k];
+            HIPCHK(hipEventRecord(sl.ev_start, c->stream));
+            int64_t load[spx_ctx::SPX_N_SIDE] = {};
+            bool used_side[spx_ctx::SPX_N_SIDE] = {};
+            for (int q = 0; q < no; ++q) {
+                const int cls = order[q];
+                if (sl.cls_batch[cls].n_order <= 0) continue;
+                if (serial) { HIPCHK(spx_launch_baq(cls, 2, &sl.cls_batch[cls], c->stream)); continue; }
+                int sidx = 0;
+                for (int t = 1; t < spx_ctx::SPX_N_SIDE; ++t) if (load[t] < load[sidx]) sidx = t;
+                if (!used_side[sidx]) { HIPCHK(hipStreamWaitEvent(c->side_stream[sidx], sl.ev_start, 0)); used_side[sidx] = true; }
+                HIPCHK(spx_launch_baq(cls, 2, &sl.cls_batch[cls], c->side_stream[sidx]));
+                load[sidx] += w->cls_cells[cls] + 1;
+            }
+            for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+                if (used_side[t]) HIPCHK(hipEventRecord(c->side_done[t], c->side_stream[t]));
+            if (mc >= 0) {
+                HIPCHK(hipEventRecord(sl.ev_f0, c->stream));
+                HIPCHK(spx_launch_baq(mc, 0, &sl.cls_batch[mc], c->stream));
+                HIPCHK(hipEventRecord(sl.ev_f1, c->stream));
+                HIPCHK(spx_launch_baq(mc, 1, &sl.cls_batch[mc], c->stream));
+                HIPCHK(hipEventRecord(sl.ev_b1, c->stream));
+            }
+            for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+                if (used_side[t]) HIPCHK(hipStreamWaitEvent(c->stream, c->side_done[t], 0));
+            if (sl.r1 > sl.r0) {
+                spx_dev_batch Bm = sl.cls_batch[0];
+                Bm.row_base = (int32_t)sl.r0;
+                HIPCHK(spx_launch_map(&Bm, (int32_t)(sl.r1 - sl.r0), wide > narrow, c->stream));
+            }
+        }
+        if (mc >= 0) { /* (the ring's slots stay defined for readers that expect them) */
+            HIPCHK(hipEventRecord(ev[3], c->stream));
+            HIPCHK(hipEventRecord(ev[4], c->stream));
+            HIPCHK(hipEventRecord(ev[5], c->stream));
+        }
     }
     HIPCHK(hipEventRecord(ev[1], c->stream));
     if (w->have_groups) {
@@ -1565,7 +1683,7 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
             baq += ms;
             ok = ok && hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess;
             sc += ms;
-            if (w->main_cls >= 0) {
+            if (w->main_cls >= 0 && w->slices.empty()) {
                 ok = ok && hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess;
                 fw += ms;
                 ok = ok && hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess;
@@ -1574,6 +1692,20 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
             ++n;
         }
         w->launch_ids.clear();
+        if (w->main_cls >= 0 && !w->slices.empty() && n > 0) {
+            /* sliced list: the main class' forward / backward time = the sum over the slices of its LATEST launch, counted once
+             * per averaged launch */
+            double f1 = 0, b1 = 0;
+            for (spx_work::Slice &sl : w->slices) {
+                float ms = 0;
+                ok = ok && hipEventElapsedTime(&ms, sl.ev_f0, sl.ev_f1) == hipSuccess;
+                f1 += ms;
+                ok = ok && hipEventElapsedTime(&ms, sl.ev_f1, sl.ev_b1) == hipSuccess;
+                b1 += ms;
+            }
+            fw = f1 * n;
+            bw = b1 * n;
+        }
         if (!ok) { (void)hipGetLastError(); n = 0; }
         const double dn = n > 0 ? (double)n : 1.0;
         if (n == 0) baq = sc = fw = bw = 0;
@@ -1742,6 +1874,13 @@ extern "C" int spx_work_stats(const spx_work *w, spx_stats *st)
     return SPX_OK;
 }
 
+extern "C" int64_t spx_work_device_bytes(const spx_work *w, int32_t *n_slices)
+{
+    if (!w) return 0;
+    if (n_slices) *n_slices = w->slices.empty() ? 1 : (int32_t)w->slices.size();
+    return (int64_t)w->arena_bytes;
+}
+
 extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
 {
     if (!w) return;
@@ -1759,6 +1898,8 @@ extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
     if (w->ev_ready) (void)hipEventDestroy(w->ev_ready);
     if (w->ev_staged) (void)hipEventDestroy(w->ev_staged);
     if (w->ev_done) (void)hipEventDestroy(w->ev_done);
+    for (spx_work::Slice &sl : w->slices)
+        for (hipEvent_t e : {sl.ev_start, sl.ev_f0, sl.ev_f1, sl.ev_b1}) if (e) (void)hipEventDestroy(e);
     delete w;
 }
 

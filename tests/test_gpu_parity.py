@@ -810,6 +810,77 @@ def test_work_list_of_131072_groups_in_a_pipeline_of_depth_3(ctx):
         assert o[0] == e.n_aln and o[1] == tuple(e.score[a] for a in range(e.n_aln)) and o[2] == e.prim_idx and o[7] == e.dp_cells, int(k)
 
 
+def test_dp_slices_share_one_scratch_area_and_change_nothing(ctx, tmp_path, monkeypatch):
+    """Work-list scratch per slice (1/s of every DP row + the saved forward rows are the bulk of a list's memory): forward ->
+    backward -> MAP run over K ranges of consecutive groups that re-use ONE scratch area.  Whatever K, every result is
+    bit-identical to the unsliced list's (markers whose rows fall into different slices included), equals the oracle's, and
+    the all-rows lists of -w give the same qualities; the scratch shrinks with K."""
+    cases = [(small_genome(synth.HIFI, read_len=6000, max_secondaries=3, n_paralogs=3, hardclip_frac=0.2, softclip_frac=0.2), 1500, records.preset("hifi")),
+             (small_genome(synth.ONT, n_paralogs=3, contig_len=300000), 600, records.preset("ont", bandwidth=50)),
+             (small_genome(synth.MIXED, n_paralogs=7, contig_len=250000, max_read_len=40000), 700, records.preset("hifi"))]
+    key = lambda o: (o.n_aln, tuple(o.score[a] for a in range(max(o.n_aln, 0))), o.prim_idx, o.max_idx, o.tie_mask, o.pass_, o.n_problems, o.n_markers, o.dp_cells)
+    for g, n, par in cases:
+        r = g.reads(0, n)
+        ctx.set_reference(g.ref)
+        res = {}
+        for K in (1, 2, 5):
+            monkeypatch.setenv("SPX_DP_SLICES", str(K))
+            w = ctx.stage(r.batch, par)
+            w.prepare_staged()
+            w.launch()
+            w.launch()  # a second launch over the same scratch
+            out = w.collect(finalize_seed=None)
+            st = w.stats()
+            res[K] = ([key(out[k]) for k in range(n)], st.main_fwd_ms, st.n_problems, w.device_bytes())
+            w.free()
+        assert res[2][0] == res[1][0] and res[5][0] == res[1][0]
+        assert res[5][1] > 0 and res[5][2] == res[1][2]
+        k5 = min(5, max(1, n // 256))  # (a slice holds at least 256 groups)
+        assert res[1][3][1] == 1 and res[2][3][1] == 2 and res[5][3][1] == k5 and res[5][3][0] <= res[2][3][0] < res[1][3][0]
+        if res_first_case_holder[0] is None:
+            res_first_case_holder[0] = res[1][0]
+        _, ores = orc.run_batch(r.batch, g.ref, par, threads=8, seed=1)
+        for k in range(0, n, 7):
+            e = ores[k]
+            assert res[5][0][k][0] == e.n_aln and res[5][0][k][1] == tuple(e.score[a] for a in range(max(e.n_aln, 0))), k
+    # all-rows lists (-w): the qualities written back by sliced lists
+    g, n, par = cases[0][0], 300, copy_preset(cases[0][2])
+    par.flags |= 1
+    r = g.reads(0, n)
+    ctx.set_reference(g.ref)
+    quals = {}
+    for K in (1, 3):
+        monkeypatch.setenv("SPX_DP_SLICES", str(K))
+        w = ctx.prepare(r.batch, par)
+        w.launch()
+        w.collect(finalize_seed=None)
+        from common import batch_qual_copy
+        quals[K] = w.apply_quals(r.batch, batch_qual_copy(r.batch)).copy()
+        w.free()
+    assert np.array_equal(quals[1], quals[3])
+    monkeypatch.delenv("SPX_DP_SLICES")
+    # the automatic choice: a budget per slice
+    monkeypatch.setenv("SPX_DP_SLICE_GB", "0.05")
+    g, n, par = cases[0]
+    r = g.reads(0, n)
+    ctx.set_reference(g.ref)
+    w = ctx.stage(r.batch, par)
+    w.prepare_staged()
+    assert w.device_bytes()[1] > 1
+    w.launch()
+    out = w.collect(finalize_seed=None)
+    w.free()
+    assert [key(out[k]) for k in range(n)] == res_first_case_holder[0]
+
+
+def copy_preset(p):
+    import copy
+    return copy.copy(p)
+
+
+res_first_case_holder = [None]
+
+
 def test_full_size_workload_properties(ctx):
     """BASELINE config 2 at a quarter of the size bench.py times per step (test_work_list_of_131072_groups... has the full
     size): 32 768 HiFi groups, 15 kb reads, the 100 Mbp assembly"""
