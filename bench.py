@@ -188,12 +188,12 @@ def also_leg(platform, steps, warmup):
            "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "3", "--cpu-threads", "32", "--no-host-input-leg"]
     # config 3 also end to end: `secphase --ont -b 50` on a BAM of one step's groups
     cmd += ["--from-bam", "16384"] if platform == "ont" else ["--no-from-bam"]
-    # (mixed: small batches whose preparations overlap -- one more in flight; ONT: the preset of BASELINE config 3, 16 384 groups
-    # per step with two lists of ~70 GB in flight -- the parent has handed its device memory back (spx_trim) before this runs;
-    # SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
+    # (mixed: small batches whose preparations overlap -- six in flight; ONT: the preset of BASELINE config 3, 16 384 groups per
+    # step, four lists in flight (DP slices keep a list at ~30 GB) -- the parent has handed its device memory back (spx_trim)
+    # before this runs; SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
     ont_gps = os.environ.get("SPX_BENCH_ALSO_ONT_GPS")
-    cmd += ["--distinct", "5", "--depth", "4"] if platform == "mixed" else \
-        (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "3"])
+    cmd += ["--distinct", "7", "--depth", "6"] if platform == "mixed" else \
+        (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "5", "--depth", "4"])
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
@@ -225,8 +225,8 @@ def main():
     ap.add_argument("--kernel-only", action="store_true", help="only the replay of one prepared work list (profiles, kernel A/B)")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
     ap.add_argument("--depth", type=int, default=0,
-                    help="batches in flight in the pipeline (their device preparations run side by side); 0: 3 (hifi), 4 (mixed), "
-                         "2 (ont: a list of 16 384 ONT groups keeps ~70 GB of saved rows, four of them do not fit in 288 GB)")
+                    help="batches in flight in the pipeline (their device preparations run side by side); 0: 3 (hifi), 6 (mixed), "
+                         "4 (ont; round 3: 2 -- a list of 16 384 ONT groups kept ~70 GB of saved rows; with DP slices ~30 GB)")
     ap.add_argument("--distinct", type=int, default=4, help="at most this many distinct batches per rank (HBM / host memory)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")
@@ -300,8 +300,12 @@ def main():
     mixed = args.platform == "mixed"
     gps = args.groups_per_step or (16384 if ont else 16384 if mixed else 131072)
     if args.depth <= 0:
-        args.depth = 4 if mixed else (2 if ont and gps > 8192 else 3)
+        # round 4: the scratch of a work list (1/s of every DP row + the saved forward rows) exists per DP slice, not per list
+        # (16 GB per slice by default), so that ONT lists (70 -> ~30 GB per 16 384 groups) and mixed lists fit deeper pipelines
+        args.depth = 6 if mixed else (4 if ont else 3)
         if mixed:
+            args.distinct = max(args.distinct, 7)
+        if ont:
             args.distinct = max(args.distinct, 5)
     # (large batches: the preparation kernels are dependent chains -- one lane walks one alignment / one group -- whose
     # duration hardly depends on the number of groups, so their cost per group falls with the batch size)
