@@ -52,7 +52,8 @@ def pmc_traffic(kernel, gps, platform, with_x2=False):
             k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel) or prof.get(kernel)
             # per launch of THIS run: the kernels' traffic is proportional to the groups of a launch (same workload, same
             # per-problem volumes), the profile may have been taken at another batch size
-            scale = gps / meta["groups_per_step"]
+            # (gps = groups per KERNEL launch of this run; the profile's dispatches are kernel launches too: slices of its lists)
+            scale = gps / (meta["groups_per_step"] / max(1, meta.get("kernel_launches_per_step", 1)))
             b = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024
             if with_x2:
                 return int(b * scale), int((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 * scale), name
@@ -667,11 +668,13 @@ def main():
         st0 = per_step_stats[0]
         G, slots = st0.main_class_lanes, st0.main_class_slots
         kname = f"baq_fwd1_kernel<{slots - 1}>" if G == 1 else f"baq_fwd_kernel<{G}, {slots // G}, 0, false>"
-        fwd_ms = sum(p.main_fwd_ms for p in per_step_stats) / nst
+        # (a sliced list launches the kernel once per DP slice: the roofline is per KERNEL launch -- what a kernel trace shows)
+        n_slices = max(1, int(round(sum(max(1, p.dp_slices) for p in per_step_stats) / nst)))
+        fwd_ms = sum(p.main_fwd_ms for p in per_step_stats) / nst / n_slices
         bwd_ms = sum(p.main_bwd_ms for p in per_step_stats) / nst
         baq_ms = sum(p.baq_kernel_ms for p in per_step_stats) / nst
         score_ms = sum(p.score_kernel_ms for p in per_step_stats) / nst
-        cls_cells = sum(p.main_class_cells for p in per_step_stats) / nst
+        cls_cells = sum(p.main_class_cells for p in per_step_stats) / nst / n_slices
         achieved_tf = FWD_FLOPS_PER_CELL * cls_cells / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
         # whole BAQ phase (forward + backward + MAP, all classes) at the algorithm's 45 flop per cell
         phase_tf = FLOPS_PER_CELL * cells / (baq_ms * 1e-3) / 1e12 if baq_ms > 0 else 0.0
@@ -683,12 +686,13 @@ def main():
             "peak": PEAK_FP64_VECTOR_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved_tf / PEAK_FP64_VECTOR_TFLOPS, 4),
-            "traffic": pmc_traffic(kname, gps, args.platform),
-            "traffic_if_fetch_size_counts_half": pmc_traffic(kname, gps, args.platform, with_x2=True)[1],
+            "traffic": pmc_traffic(kname, gps / n_slices, args.platform),
+            "traffic_if_fetch_size_counts_half": pmc_traffic(kname, gps / n_slices, args.platform, with_x2=True)[1],
             "traffic_source": pmc_traffic(kname, gps, args.platform, with_x2=True)[2],
             "kernel": kname,
             "avg_launch_ms": round(fwd_ms, 4),
-            "launches_averaged": int(sum(p.n_launches_averaged for p in per_step_stats)),
+            "launches_averaged": int(sum(p.n_launches_averaged for p in per_step_stats)) * n_slices,
+            "kernel_launches_per_step": n_slices,
             "cells_per_launch": int(cls_cells),
             "flops_per_cell": FWD_FLOPS_PER_CELL,
             "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, every kernel alone on the chip). "

@@ -89,6 +89,9 @@ typedef struct spx_stats {
     int32_t main_class, main_class_lanes, main_class_slots;
     int32_t n_launches_averaged; /* the *_ms fields are averages over this many launches: those since the previous
                                   * spx_collect on the context (at most the last 64) */
+    int32_t dp_slices;           /* DP slices of the list (spx_work_device_bytes): main_fwd_ms / main_bwd_ms are the SUM over the slices'
+                                  * kernels of one launch of the list, i.e. dp_slices launches of the kernel each */
+    int32_t reserved_;
 } spx_stats;
 
 const char *spx_strerror(int code);

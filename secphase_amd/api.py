@@ -57,7 +57,7 @@ class Stats(C.Structure):
         ("d2h_seconds", C.c_double), ("baq_kernel_ms", C.c_double), ("score_kernel_ms", C.c_double),
         ("main_fwd_ms", C.c_double), ("main_bwd_ms", C.c_double), ("main_class_cells", C.c_int64),
         ("main_class", C.c_int32), ("main_class_lanes", C.c_int32), ("main_class_slots", C.c_int32),
-        ("n_launches_averaged", C.c_int32),
+        ("n_launches_averaged", C.c_int32), ("dp_slices", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -1712,6 +1712,7 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         w->st.baq_kernel_ms = baq / dn;
         w->st.score_kernel_ms = sc / dn;
         w->st.n_launches_averaged = n;
+        w->st.dp_slices = w->slices.empty() ? 1 : (int32_t)w->slices.size();
         if (w->main_cls >= 0) {
             w->st.main_fwd_ms = fw / dn;
             w->st.main_bwd_ms = bw / dn;

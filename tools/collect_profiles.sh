@@ -25,7 +25,7 @@ b = json.loads(open(f"{out}/{tag}_bench_under_rocprof.json").read().strip().spli
 k = b["roofline"]["kernel"]
 rows = [r for r in csv.DictReader(open(f"{out}/kt/run_kernel_trace.csv")) if r["Kernel_Name"].startswith("void " + k)]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-n = b["steps"]
+n = b["steps"] * b["roofline"].get("kernel_launches_per_step", 1)  # (a sliced list launches the kernel once per DP slice)
 json.dump({"kernel": k, "launches_in_trace": len(d), "all_launches_avg_ms": round(sum(d) / max(len(d), 1), 3),
            "timed_launches_avg_ms": round(sum(d[-n:]) / max(len(d[-n:]), 1), 3), "timed_launches_ms": [round(x, 2) for x in d[-n:]],
            "bench_avg_launch_ms_hip_events": b["roofline"]["avg_launch_ms"], "bench_value": b["value"],

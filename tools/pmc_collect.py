@@ -67,6 +67,7 @@ def main():
             meta["blocks"], meta["inflated_bytes"], meta["compressed_bytes"] = bj["blocks"], bj["inflated_bytes"], bj["compressed_bytes"]
         else:
             meta["groups_per_step"] = bj["config"]["groups_per_step_per_gpu"]
+            meta["kernel_launches_per_step"] = bj.get("roofline", {}).get("kernel_launches_per_step", 1)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         acc = {}
         for f in files:
