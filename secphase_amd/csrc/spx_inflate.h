@@ -11,7 +11,9 @@
  * copies, flushing literals, CRC32.
  *
  * The decoder is parameterised by an environment E that provides
- *     E::in32(k)              compressed dword k of the block (little endian; reads past the end return 0)
+ *     E::in32(k)              compressed dword k of the block (little endian; reads past the end return 0) -- in two halves: in32()
+ *                             may return a raw word and E::in32_fix(raw, k) completes it when the reader consumes it, one refill
+ *                             later (so that a device load has nothing depending on it while it is in flight)
  *     E::put_literal(b)       one output byte (checked)
  *     E::lit_full(), E::lit_push(b), E::lit_commit()   the same in three steps for the literal loop: no room for another
  *                             literal right now / append one (unchecked) / make room (false: the output is full)
@@ -102,7 +104,7 @@ struct Bits {
     SPXZ_HD void refill()
     {
         if (cnt <= 32) {
-            buf |= (uint64_t)pre << cnt;
+            buf |= (uint64_t)env.in32_fix(pre, next) << cnt;
             ++next;
             cnt += 32;
             pre = env.in32(next);
@@ -293,19 +295,31 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
              * the device), everything else outside it ---- */
             for (;;) {
                 uint32_t e;
-                for (;;) {
+                if constexpr (E::kFlat) {
+                    /* one symbol per trip, whatever it is: several blocks share a wavefront (one lane group each) and a lane group
+                     * that has a match to copy must not wait until the others have exhausted their runs of literals */
                     b.refill();
                     e = env.uniform_u32(T.lit[b.peek(E::kLit)]);
-                    /* a length / end-of-block code, or no root code at all -- or no room for one more literal (the device
-                     * keeps up to 64 in a register; committing them, flushing and the overrun check stay OUT of this loop:
-                     * inlined into it they cost a dozen scalar moves per literal) */
-                    if ((e & 0x100u) || env.lit_full()) break;
-                    b.drop((int)(e >> 9));
-                    env.lit_push((uint8_t)e);
-                }
-                if (!(e & 0x100u)) {
-                    if (!env.lit_commit()) return -2; /* false: more bytes than the block may hold */
-                    continue;
+                    if (!(e & 0x100u)) {
+                        b.drop((int)(e >> 9));
+                        if (!env.put_literal((uint8_t)e)) return -2;
+                        continue;
+                    }
+                } else {
+                    for (;;) {
+                        b.refill();
+                        e = env.uniform_u32(T.lit[b.peek(E::kLit)]);
+                        /* a length / end-of-block code, or no root code at all -- or no room for one more literal (the device
+                         * keeps up to 64 in a register; committing them, flushing and the overrun check stay OUT of this loop:
+                         * inlined into it they cost a dozen scalar moves per literal) */
+                        if ((e & 0x100u) || env.lit_full()) break;
+                        b.drop((int)(e >> 9));
+                        env.lit_push((uint8_t)e);
+                    }
+                    if (!(e & 0x100u)) {
+                        if (!env.lit_commit()) return -2; /* false: more bytes than the block may hold */
+                        continue;
+                    }
                 }
                 int sym;
                 if (e != kNoEntry) {
@@ -323,7 +337,8 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                     }
                 }
                 if (sym == 256) break;
-                b.refill();
+                /* (refill() leaves >= 33 bits: a literal/length code of <= 15 bits and its <= 5 extra bits come out of one fill, a
+                 * distance code of <= 15 bits and its <= 13 extra bits out of the next) */
                 const int len = len_base(sym) + (int)b.take(len_extra(sym));
                 b.refill();
                 const uint32_t d = env.uniform_u32(T.dist[b.peek(E::kDist)]);
@@ -338,7 +353,6 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                     dsym = (int)(r & 0xffff);
                     if (dsym > 29) return -1;
                 }
-                b.refill();
                 const int dist = dist_base(dsym) + (int)b.take(dist_extra(dsym));
                 if ((uint32_t)dist > env.out_pos()) return -1;
                 if (env.out_pos() + (uint32_t)len > out_limit) return -2;
@@ -388,9 +402,10 @@ SPXZ_HD uint32_t gf2_xpow8n(uint64_t n_bytes)
 SPXZ_HD uint32_t crc_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return gf2_mul(gf2_xpow8n(len_b), crc_a) ^ crc_b; }
 
 /* ---- host environment: plain buffers ---- */
-template <int LR, int DR>
+template <int LR, int DR, bool FLAT = false>
 struct HostEnvT {
     static constexpr int kLit = LR, kDist = DR;
+    static constexpr bool kFlat = FLAT; /* the symbol loop's shape (see inflate_stream); the CPU tests run both */
     const uint8_t *in;
     size_t in_len;
     uint8_t *out;
@@ -405,6 +420,7 @@ struct HostEnvT {
         }
         return v;
     }
+    uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
     uint32_t cap = 0xffffffffu; /* bytes out[] can take */
     bool put_literal(uint8_t c) { if (pos >= cap) return false; out[pos++] = c; return true; }
     bool lit_full() const { return pos >= cap; }

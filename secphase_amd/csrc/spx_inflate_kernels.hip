@@ -49,6 +49,7 @@ __device__ __forceinline__ int writelane(int v, int c, int n)
 template <int LR, int DR>
 struct DevEnv {
     static constexpr int kLit = LR, kDist = DR;
+    static constexpr bool kFlat = false;
     using Tab = spxz::TablesT<LR, DR>;
     const uint32_t *in_al;
     uint32_t in_shift; /* bits: 0, 8, 16, 24 */
@@ -68,6 +69,7 @@ struct DevEnv {
         const uint32_t lo = k < n_dw ? in_al[k] : 0u, hi = k + 1 < n_dw ? in_al[k + 1] : 0u;
         return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
     }
+    __device__ __forceinline__ uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
     __device__ __forceinline__ Tab &tables() { return *T; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ int lane() const { return lane_; }
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restr
 template <int G, int LR, int DR, int R>
 struct GrpEnv {
     static constexpr int kLit = LR, kDist = DR;
+    static constexpr bool kFlat = false;
     /* near matches (distance <= R / 2) are served from the ring; a far match must find its source flushed: R / 2 - 258 >= kFlushG + 3 */
     static constexpr int kRingG = R, kFlushG = (R / 4 < R / 2 - 264) ? R / 4 : R / 2 - 264;
     using Tab = spxz::TablesT<LR, DR>;
@@ -239,6 +242,7 @@ struct GrpEnv {
         const uint32_t lo = k < n_dw ? in_al[k] : 0u, hi = k + 1 < n_dw ? in_al[k + 1] : 0u;
         return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
     }
+    __device__ __forceinline__ uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
     __device__ __forceinline__ Tab &tables() { return *T; }
     /* the lanes of a block run in lockstep inside one wave and LDS operations of a wave complete in order: a "barrier" only
      * has to keep the compiler from moving LDS accesses across it */
@@ -378,6 +382,234 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     if (lane == 0) status[b] = rc;
 }
 
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Round 4, second step: MORE BLOCKS PER WAVEFRONT, ONE SYMBOL PER TRIP.  What the counters of the kernel above say
+ * (profiles/r04_counters_inflate.json): vector ALU and scalar unit are each ~half busy, a wavefront issues one instruction every
+ * ~18 cycles -- a latency chain (LDS look-ups, and a trip to the L2 for every match that lies further back than the ring: in BAM
+ * payload 79 % of the matches do, most of them 3-4 bytes long), paid per SYMBOL and shared by only two blocks.  Here
+ *   - G = 8 (or 4 / 16) lanes per block, so that one instruction stream advances 8 blocks;
+ *   - the symbol loop is flat (E::kFlat in spx_inflate.h): one symbol per trip whatever its kind, the hardware's execution mask
+ *     runs the literal path and the match path of a trip one after the other -- a block with a match does not wait for the
+ *     others' literal runs to end;
+ *   - a short far match is DEFERRED: the load from the L2 is issued, the block goes on decoding, the bytes reach the ring when
+ *     the next match, the next flush or the end of the block needs them (literals never read the ring);
+ *   - the CRC-32 moved into its own kernel (bgzf_crc_kernel below): 64 lanes per block with coalesced reads instead of G serial
+ *     stripes at the tail of every block's decode.
+ * Decoder core: the same spx_inflate.h. */
+template <int G, int LR, int DR, int R, bool FLAT = true>
+struct FlatEnv {
+    static constexpr int kLit = LR, kDist = DR;
+    static constexpr bool kFlat = FLAT;
+    static constexpr int kRingG = R, kFlushG = (R / 4 < R / 2 - 264) ? R / 4 : R / 2 - 264;
+    using Tab = spxz::TablesT<LR, DR>;
+    const uint8_t *in;       /* the block's DEFLATE bytes (any alignment: gfx9 global memory takes unaligned dwords) */
+    uint32_t clen;
+    uint8_t *out;
+    uint32_t limit, pos, flushed;
+    uint32_t pend_n, pend_at; /* a deferred far match: byte k of it (k < pend_n <= G) arrives in lane k's pend_v and belongs at ring[pend_at + k] */
+    uint32_t pend_v;
+    Tab *T;
+    uint8_t *ring;
+    int lane_;
+
+    /* one unconditional load per refill, completed (the zeros beyond the block's end) when the reader consumes the word: nothing
+     * depends on the load while it is in flight.  The clamped address reads at most the 4 bytes after the DEFLATE data: a BGZF
+     * block ends in CRC32 + ISIZE, so they belong to the block */
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    __device__ __forceinline__ uint32_t in32(uint32_t k) const
+    {
+        const uint32_t o = 4u * k < clen ? 4u * k : clen;
+        return *reinterpret_cast<const u32_unaligned *>(in + o);
+    }
+    __device__ __forceinline__ uint32_t in32_fix(uint32_t raw, uint32_t k) const
+    {
+        const uint32_t o = 4u * k, left = clen > o ? clen - o : 0u;
+        return left >= 4u ? raw : (raw & ((1u << (8u * left)) - 1u));
+    }
+    __device__ __forceinline__ Tab &tables() { return *T; }
+    __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ int lane() const { return lane_; }
+    __device__ __forceinline__ int lanes() const { return G; }
+    __device__ __forceinline__ int uniform(int v) const { return __shfl(v, 0, G); }
+    __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return v; }
+    __device__ __forceinline__ uint32_t out_pos() const { return pos; }
+
+    __device__ __forceinline__ void retire()
+    {
+        if (pend_n) {
+            if ((uint32_t)lane_ < pend_n) ring[(pend_at + (uint32_t)lane_) & (kRingG - 1)] = (uint8_t)pend_v;
+            pend_n = 0;
+        }
+    }
+    __device__ __forceinline__ void flush(bool last)
+    {
+        retire();
+        sync();
+        const uint32_t end = pos < limit ? pos : limit;
+        const uint32_t e4 = last ? end : (end & ~3u);
+        if (e4 > flushed) {
+            for (uint32_t base = flushed; base + 4 <= e4; base += 4u * G) {
+                const uint32_t i = base + 4u * (uint32_t)lane_;
+                if (i + 4 <= e4) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(ring + (i & (kRingG - 1)));
+                    __builtin_memcpy(out + i, &v, 4);
+                }
+            }
+            const uint32_t tail = flushed + ((e4 - flushed) & ~3u);
+            if (tail + (uint32_t)lane_ < e4) out[tail + lane_] = ring[(tail + lane_) & (kRingG - 1)];
+            flushed = last ? e4 : (pos < limit ? e4 : pos & ~3u);
+        } else if (pos > limit)
+            flushed = pos & ~3u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    __device__ __forceinline__ bool lit_full() const { return pos - flushed >= (uint32_t)kFlushG; }
+    __device__ __forceinline__ void lit_push(uint8_t c)
+    {
+        if (lane_ == 0) ring[pos & (kRingG - 1)] = c;
+        ++pos;
+    }
+    __device__ __forceinline__ bool lit_commit()
+    {
+        flush(false);
+        return pos <= limit;
+    }
+    __device__ __forceinline__ bool put_literal(uint8_t c)
+    {
+        if (lit_full() && !lit_commit()) return false;
+        lit_push(c);
+        return true;
+    }
+    __device__ __forceinline__ void copy_match(int len, int dist)
+    {
+        retire();
+        const uint32_t src0 = pos - (uint32_t)dist;
+        if (dist <= kRingG / 2) {
+            if (dist >= len) {
+                for (int base = 0; base < len; base += G) {
+                    const int i = base + lane_;
+                    if (i < len) ring[(pos + (uint32_t)i) & (kRingG - 1)] = ring[(src0 + (uint32_t)i) & (kRingG - 1)];
+                }
+            } else {
+                for (int base = 0; base < len; base += G) {
+                    const int i = base + lane_;
+                    if (i < len) ring[(pos + (uint32_t)i) & (kRingG - 1)] = ring[(src0 + (uint32_t)(i % dist)) & (kRingG - 1)];
+                }
+            }
+        } else if (len <= G) {
+            /* far and short: the source lies below `flushed` (kFlushG + 4 + 258 <= kRingG / 2); the load goes past the vector L1 */
+            if (lane_ < len) pend_v = __hip_atomic_load(out + src0 + (uint32_t)lane_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend_at = pos;
+            pend_n = (uint32_t)len;
+        } else {
+            /* far and long (a secondary alignment repeating the primary's SEQ / QUAL): 16 bytes per lane and round, the four loads
+             * of a round in flight together.  (A lane may read up to 3 bytes beyond the match: they lie below pos - dist + 261 < pos.) */
+            for (int base = 0; base < len; base += 16 * G) {
+                const int i = base + 16 * lane_;
+                if (i < len) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = i + 4 * q < len ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(out + src0 + (uint32_t)(i + 4 * q)), __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT)
+                                               : 0u;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (i + q < len) ring[(pos + (uint32_t)(i + q)) & (kRingG - 1)] = (uint8_t)(v[q >> 2] >> (8 * (q & 3)));
+                }
+            }
+        }
+        pos += (uint32_t)len;
+        if (pos - flushed >= (uint32_t)kFlushG) flush(false);
+    }
+};
+
+template <int G, int LR, int DR, int R, int WPE, bool FLAT = true>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void bgzf_inflate_flat_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
+                                                               uint8_t *__restrict__ outbuf, int32_t *__restrict__ status)
+{
+    constexpr int NB = 64 / G;
+    __shared__ spxz::TablesT<LR, DR> T[NB];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[NB][R];
+    const int q = (int)threadIdx.x / G, lane = (int)threadIdx.x % G;
+    const int b = (int)blockIdx.x * NB + q;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    FlatEnv<G, LR, DR, R, FLAT> env;
+    env.in = comp + d.in_off;
+    env.clen = d.clen;
+    env.out = outbuf + d.out_off;
+    env.limit = d.ulen;
+    env.pos = 0;
+    env.flushed = 0;
+    env.pend_n = 0;
+    env.pend_at = 0;
+    env.pend_v = 0;
+    env.T = &T[q];
+    env.ring = ring[q];
+    env.lane_ = lane;
+    int rc = 0;
+    if (d.ulen > 0) {
+        rc = spxz::inflate_stream(env, (int64_t)d.clen * 8, d.ulen);
+        env.flush(true);
+    }
+    if (lane == 0) status[b] = rc;
+}
+
+/* CRC-32 of every inflated block against the BGZF trailer's: one wavefront per block, 64 stripes (byte-table recurrence per lane, 16
+ * bytes per load), folded with the GF(2) shift operator; status[b] 0 -> -4 on a mismatch */
+__global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restrict__ blocks, int32_t n_blocks, const uint8_t *__restrict__ outbuf,
+                                                       int32_t *__restrict__ status)
+{
+    __shared__ uint32_t crc_tab[256];
+    crc_tab[threadIdx.x] = spxz::crc_table_entry(threadIdx.x);
+    __syncthreads();
+    const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    if (d.ulen == 0 || status[b] != 0) return;
+    const uint8_t *p = outbuf + d.out_off;
+    /* stripes of whole 16-byte pieces (aligned in memory), the unaligned head goes to lane 0, the tail to the last stripe */
+    const uint32_t n = d.ulen;
+    const uint32_t head = min(n, (uint32_t)((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u));
+    const uint32_t pieces = (n - head) / 16u, per = (pieces + 63u) / 64u;
+    const uint32_t a_pc = min(pieces, per * (uint32_t)lane), e_pc = min(pieces, a_pc + per);
+    uint32_t a = head + 16u * a_pc, e = head + 16u * e_pc;
+    uint32_t c = 0xffffffffu;
+    uint32_t len = e - a;
+    if (lane == 0) {
+        for (uint32_t k = 0; k < head; ++k) c = crc_tab[(c ^ p[k]) & 0xff] ^ (c >> 8);
+        len += head;
+    }
+    const uint4 *p16 = reinterpret_cast<const uint4 *>(p + a);
+    for (uint32_t k = 0; k < e_pc - a_pc; ++k) {
+        const uint4 w = p16[k];
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c ^= ws[j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c = crc_tab[c & 0xff] ^ (c >> 8);
+        }
+    }
+    /* the last stripe that has bytes takes the tail; with no whole piece at all that is lane 0 */
+    const uint32_t tail0 = head + 16u * pieces;
+    const uint32_t last_lane = pieces ? (pieces - 1u) / per : 0u;
+    if ((uint32_t)lane == last_lane) {
+        for (uint32_t k = tail0; k < n; ++k) c = crc_tab[(c ^ p[k]) & 0xff] ^ (c >> 8);
+        len += n - tail0;
+    }
+    c ^= 0xffffffffu;
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t oc = (uint32_t)__shfl_down((int)c, s), ol = (uint32_t)__shfl_down((int)len, s);
+        if ((lane & (2 * s - 1)) == 0) {
+            if (ol > 0) c = len > 0 ? spxz::crc_combine(c, oc, ol) : oc;
+            len += ol;
+        }
+    }
+    if (lane == 0 && c != d.crc) status[b] = -4;
+}
+
 } // namespace
 
 static int inflate_root_bits()
@@ -420,6 +652,21 @@ extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *b
      * SPX_INFLATE_RING = 1024 (default: five waves per SIMD) / 2048 / 4096 bytes of LDS ring per block), 64 = round 3's kernel: one block
      * per wave on the scalar unit */
     static const int lanes = [] { const char *e = getenv("SPX_INFLATE_LANES"); const int v = e ? atoi(e) : 32; return (v == 16 || v == 64) ? v : 32; }();
+    /* SPX_INFLATE_FLAT = 4 / 8 / 16 / 32: the flat kernel with that many lanes per block (9 / 8-bit root tables, 1 KB ring) + the CRC kernel */
+    static const int flat = [] { const char *e = getenv("SPX_INFLATE_FLAT"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 132) ? v : 0; }();
+    if (flat) {
+        const BlockDesc *bd = (const BlockDesc *)blocks;
+#define SPX_LAUNCH_FLAT(G, WPE) \
+    hipLaunchKernelGGL((bgzf_inflate_flat_kernel<G, 9, 8, 1024, WPE>), dim3((unsigned)((n_blocks + (64 / G) - 1) / (64 / G))), dim3(64), 0, st, comp, bd, n_blocks, out, status)
+        if (flat == 4) SPX_LAUNCH_FLAT(4, 1);
+        else if (flat == 8) SPX_LAUNCH_FLAT(8, 2);
+        else if (flat == 16) SPX_LAUNCH_FLAT(16, 3);
+        else if (flat == 132) /* 32 lanes, the symbol loop with the inner literal loop */
+            hipLaunchKernelGGL((bgzf_inflate_flat_kernel<32, 9, 8, 1024, 5, false>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
+        else SPX_LAUNCH_FLAT(32, 5);
+        if (check_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, bd, n_blocks, out, status);
+        return hipGetLastError();
+    }
     if (lanes != 64) return spx_launch_bgzf_inflate_grouped(comp, blocks, n_blocks, out, status, check_crc, lanes, st);
     const BlockDesc *bd = (const BlockDesc *)blocks;
     const int root = inflate_root_bits();
