@@ -55,6 +55,9 @@ struct spx_devstage_sizes {
 };
 extern "C" int spx_internal_devstage_begin(spx_ctx *c, const spx_params *par, const spx_devstage_sizes *sz, spx_work **out, spx_din_out *O, char **d_info);
 extern "C" int spx_internal_devstage_finish(spx_ctx *c, spx_work *w, const uint8_t *grp_disp, hipStream_t st);
+extern "C" size_t spx_bgzf_inflate_scratch_bytes(int32_t n_blocks);
+extern "C" hipError_t spx_launch_bgzf_inflate2(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc,
+                                               void *scratch, hipStream_t st);
 extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
                                               int check_crc, hipStream_t st);
 extern "C" size_t spx_din_scan_temp_bytes(int64_t n_items);
@@ -165,6 +168,7 @@ struct Lane {
         BlockDesc *d_desc = nullptr;
         int32_t *d_status = nullptr;
         int64_t *d_bstart = nullptr;
+        void *d_scratch = nullptr; /* the inflate kernels' (spx_bgzf_inflate_scratch_bytes) */
         hipEvent_t ev_inf = nullptr, ev_host = nullptr;
         bool busy = false;
     } slot[kSlots];
@@ -257,6 +261,7 @@ void Lane::destroy()
         if (S.d_desc) (void)hipFree(S.d_desc);
         if (S.d_status) (void)hipFree(S.d_status);
         if (S.d_bstart) (void)hipFree(S.d_bstart);
+        if (S.d_scratch) (void)hipFree(S.d_scratch);
         if (S.ev_inf) (void)hipEventDestroy(S.ev_inf);
         if (S.ev_host) (void)hipEventDestroy(S.ev_host);
     }
@@ -295,11 +300,13 @@ int Lane::ensure_slot(Slot &S, size_t buf, size_t comp, size_t nb)
         if (S.d_desc) (void)hipFree(S.d_desc);
         if (S.d_status) (void)hipFree(S.d_status);
         if (S.d_bstart) (void)hipFree(S.d_bstart);
-        S.d_desc = nullptr; S.d_status = nullptr; S.d_bstart = nullptr;
+        if (S.d_scratch) (void)hipFree(S.d_scratch);
+        S.d_desc = nullptr; S.d_status = nullptr; S.d_bstart = nullptr; S.d_scratch = nullptr;
         const size_t take = nb + nb / 4 + 64;
         DCHK(hipMalloc((void **)&S.d_desc, take * sizeof(BlockDesc)));
         DCHK(hipMalloc((void **)&S.d_status, take * sizeof(int32_t)));
         DCHK(hipMalloc((void **)&S.d_bstart, (take + 1) * sizeof(int64_t)));
+        DCHK(hipMalloc(&S.d_scratch, spx_bgzf_inflate_scratch_bytes((int32_t)take) + 64));
         S.nb_cap = take;
     }
     return SPX_OK;
@@ -510,7 +517,7 @@ int Lane::upload(Seg *s)
         /* the inflate stream goes on behind the last copy */
         DCHK(hipStreamWaitEvent(inf_stream, pin_ev[0][k], 0));
     }
-    if (nd) DCHK(spx_launch_bgzf_inflate(S.d_comp, S.d_desc, (int32_t)nd, S.d_buf + d->carry_cap, S.d_status, d->check_crc, inf_stream));
+    if (nd) DCHK(spx_launch_bgzf_inflate2(S.d_comp, S.d_desc, (int32_t)nd, S.d_buf + d->carry_cap, S.d_status, d->check_crc, S.d_scratch, inf_stream));
     DCHK(hipEventRecord(S.ev_inf, inf_stream));
     s->t_up = now_s();
     {

@@ -28,6 +28,7 @@
 #define SPX_INFLATE_H
 
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -48,6 +49,25 @@ namespace spxz {
  * distance base / extra bits are computed from the symbol (len_base ..): the rarer path pays, the table stays small */
 SPXZ_HD uint16_t mk_entry(int nbits, int sym) { return (uint16_t)((unsigned)sym | ((unsigned)nbits << 9)); }
 constexpr uint16_t kNoEntry = 0x100; /* "not a literal", length 0: the literal loop needs ONE bit test */
+
+/* PACKED entries (environments with their own symbol loop): what a match needs without another computation.
+ *   literal/length table: a literal as above; otherwise bit 8 set, bits 0-7 = length base - 3, bits 9-12 code length, bits 13-15 number of
+ *     extra bits (0..5; 7 = the end-of-block code)
+ *   distance table: bits 0-1 = h, bits 2-5 = number of extra bits x, bits 9-12 code length: distance base = 1 + (h << x)  (h = the symbol
+ *     for symbols 0, 1; 2 + (symbol & 1) beyond) */
+SPXZ_HD int len_base(int sym);
+SPXZ_HD int len_extra(int sym);
+SPXZ_HD int dist_extra(int sym);
+SPXZ_HD uint16_t mk_len_entry(int nbits, int sym) /* sym 256..285 */
+{
+    if (sym == 256) return (uint16_t)(0x100u | ((unsigned)nbits << 9) | (7u << 13));
+    return (uint16_t)((unsigned)(len_base(sym) - 3) | 0x100u | ((unsigned)nbits << 9) | ((unsigned)len_extra(sym) << 13));
+}
+SPXZ_HD uint16_t mk_dist_entry(int nbits, int sym) /* sym 0..29 */
+{
+    const unsigned h = sym < 2 ? (unsigned)sym : 2u + ((unsigned)sym & 1u);
+    return (uint16_t)(h | ((unsigned)dist_extra(sym) << 2) | ((unsigned)nbits << 9));
+}
 
 template <int LR, int DR>
 struct TablesT {
@@ -180,7 +200,7 @@ SPXZ_HD int canon_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *s
 /* root-table fill for the coded symbols number i = first_i, first_i + stride, ... in (length, symbol) order: the canonical
  * code of sorted[i] is first[len] + (i - offs[len]); every code of length <= root is replicated over the high index bits;
  * longer codes leave their (shared) root slots at "walk" */
-template <bool LIT>
+template <bool LIT, bool PACKED = false>
 SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint16_t *sorted, const uint16_t *first, const uint16_t *offs, int used,
                        int first_i, int stride)
 {
@@ -189,11 +209,19 @@ SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint1
         const int l = lens[s];
         if (l > root) continue;
         if (LIT ? s > 285 : s > 29) continue; /* 286, 287 / 30, 31: never valid (their slots stay "walk" -> the walk rejects them) */
-        const uint16_t e = mk_entry(l, s);
+        const uint16_t e = !PACKED ? mk_entry(l, s) : !LIT ? mk_dist_entry(l, s) : s < 256 ? mk_entry(l, s) : mk_len_entry(l, s);
         const uint32_t r = rev_bits((uint32_t)first[l] + (uint32_t)(i - offs[l]), l);
         for (uint32_t k = r; k < (1u << root); k += (1u << l)) tab[k] = e;
     }
 }
+
+/* an environment may bring its own symbol loop (E::kOwnLoop, int E::symbol_loop(Bits<E> &): 0 at the end-of-block code, < 0 = error): the
+ * device's decode kernel does, hand-scheduled around its own bit reader; everything else of a stream (block headers, stored blocks,
+ * table set-up) stays here */
+template <class E, class = void>
+struct own_loop : std::false_type {};
+template <class E>
+struct own_loop<E, std::void_t<decltype(E::kOwnLoop)>> : std::bool_constant<E::kOwnLoop> {};
 
 template <class E>
 SPXZ_HD int build_tables(E &env, int nlit, int ndist)
@@ -207,13 +235,13 @@ SPXZ_HD int build_tables(E &env, int nlit, int ndist)
     if (lane == 0) rc = canon_build(T.lens, nlit, T.lit_count, T.lit_sorted, T.first, T.offs);
     env.sync();
     rc = env.uniform(rc);
-    if (rc == 0) fill_root<true>(T.lit, E::kLit, T.lens, T.lit_sorted, T.first, T.offs, nlit - (int)T.lit_count[0], lane, lanes);
+    if (rc == 0) fill_root<true, own_loop<E>::value>(T.lit, E::kLit, T.lens, T.lit_sorted, T.first, T.offs, nlit - (int)T.lit_count[0], lane, lanes);
     env.sync();
     int rc2 = 0;
     if (lane == 0 && rc == 0) rc2 = canon_build(T.lens + nlit, ndist, T.dist_count, T.dist_sorted, T.first, T.offs);
     env.sync();
     rc2 = env.uniform(rc2);
-    if (rc == 0 && rc2 == 0) fill_root<false>(T.dist, E::kDist, T.lens + nlit, T.dist_sorted, T.first, T.offs, ndist - (int)T.dist_count[0], lane, lanes);
+    if (rc == 0 && rc2 == 0) fill_root<false, own_loop<E>::value>(T.dist, E::kDist, T.lens + nlit, T.dist_sorted, T.first, T.offs, ndist - (int)T.dist_count[0], lane, lanes);
     env.sync();
     return (rc | rc2) ? -1 : 0;
 }
@@ -293,6 +321,10 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
             if (build_tables(env, nlit, ndist) != 0) return -1;
             /* ---- the symbol loop: a tight inner loop over runs of literals (one table look-up, one v_writelane each on
              * the device), everything else outside it ---- */
+            if constexpr (own_loop<E>::value) {
+                const int r = env.symbol_loop(b);
+                if (r != 0) return r;
+            } else
             for (;;) {
                 uint32_t e;
                 if constexpr (E::kFlat) {

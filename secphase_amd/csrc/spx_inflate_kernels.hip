@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
  *   - the CRC-32 moved into its own kernel (bgzf_crc_kernel below): 64 lanes per block with coalesced reads instead of G serial
  *     stripes at the tail of every block's decode.
  * Decoder core: the same spx_inflate.h. */
-template <int G, int LR, int DR, int R, bool FLAT = true>
+template <int G, int LR, int DR, int R, bool FLAT = true, int DRY = 0> /* DRY (timing experiments only, wrong output): 1 = far matches load nothing, 2 = and nothing is flushed */
 struct FlatEnv {
     static constexpr int kLit = LR, kDist = DR;
     static constexpr bool kFlat = FLAT;
@@ -446,6 +446,7 @@ struct FlatEnv {
     {
         retire();
         sync();
+        if (DRY >= 2) { flushed = pos & ~3u; return; }
         const uint32_t end = pos < limit ? pos : limit;
         const uint32_t e4 = last ? end : (end & ~3u);
         if (e4 > flushed) {
@@ -496,6 +497,7 @@ struct FlatEnv {
                     if (i < len) ring[(pos + (uint32_t)i) & (kRingG - 1)] = ring[(src0 + (uint32_t)(i % dist)) & (kRingG - 1)];
                 }
             }
+        } else if (DRY >= 1) {
         } else if (len <= G) {
             /* far and short: the source lies below `flushed` (kFlushG + 4 + 258 <= kRingG / 2); the load goes past the vector L1 */
             if (lane_ < len) pend_v = __hip_atomic_load(out + src0 + (uint32_t)lane_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -524,7 +526,7 @@ struct FlatEnv {
     }
 };
 
-template <int G, int LR, int DR, int R, int WPE, bool FLAT = true>
+template <int G, int LR, int DR, int R, int WPE, bool FLAT = true, int DRY = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void bgzf_inflate_flat_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
                                                                uint8_t *__restrict__ outbuf, int32_t *__restrict__ status)
 {
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     const int b = (int)blockIdx.x * NB + q;
     if (b >= n_blocks) return;
     const BlockDesc d = blocks[b];
-    FlatEnv<G, LR, DR, R, FLAT> env;
+    FlatEnv<G, LR, DR, R, FLAT, DRY> env;
     env.in = comp + d.in_off;
     env.clen = d.clen;
     env.out = outbuf + d.out_off;
@@ -610,6 +612,836 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restri
     if (lane == 0 && c != d.crc) status[b] = -4;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Round 4, third step: DECODE AND COPY IN TWO KERNELS.  In BAM payload one symbol in eight is a match, 95 % of the matches are
+ * 3-4 bytes long and four out of five lie further back than a ring in LDS can reach (tools/deflate_stats): every one of them
+ * was a trip to the L2 -- or, with 10 000 blocks x 32 KB of window in flight, to HBM -- in the middle of a chain that is
+ * sequential by nature.  The Huffman decoder does not need the bytes a match copies, only its length:
+ *   kernel 1 (bgzf_decode_kernel) decodes the symbols of a block and writes every LITERAL at its final position of the output
+ *     (it knows the position: literals count 1, matches their length).  A match leaves a hole of >= 3 bytes: the hole's first
+ *     three bytes take the match itself (distance - 1 in 16 bits, length - 3 in 8), and a bitmap (1 bit per output byte, 8 KB
+ *     per block) marks where holes start.  No window, no ring, no flush: LDS holds the decode tables and 256 bytes of staged
+ *     input per block, nothing in the symbol loop waits for global memory;
+ *   kernel 2 (bgzf_resolve_kernel) fills the holes, one wavefront per block, 64 matches at a time: a match may be copied as soon
+ *     as its source lies below the first hole that is still open (in the batch the holes are ordered; the first open one always
+ *     qualifies), so a batch takes a few rounds of 64-wide gathers instead of 64 dependent trips; long matches (a secondary
+ *     alignment repeating the primary's SEQ / QUAL) are copied by the whole wavefront when their turn has come;
+ *   kernel 3 (bgzf_crc_kernel) checks the CRC-32.
+ */
+constexpr int kBitmapWords = 2048; /* per block: 65536 positions / 32 */
+
+template <int G, int LR, int DR>
+struct TokEnv {
+    static constexpr int kLit = LR, kDist = DR;
+    static constexpr bool kFlat = true, kOwnLoop = true;
+    static constexpr int kNW = 32 / G > 0 ? 32 / G : 1; /* dwords of a 128-byte input chunk per lane */
+    using Tab = spxz::TablesT<LR, DR>;
+    const uint8_t *in;
+    uint32_t clen;
+    uint8_t *out;
+    uint32_t *bm;        /* the block's bitmap (zeroed before the launch) */
+    uint32_t limit, pos;
+    uint32_t bm_word, bm_idx; /* bits of output positions [32 * bm_idx, 32 * bm_idx + 32) gathered so far */
+    uint32_t staged;     /* the input chunk that waits in stage_v for its turn in LDS; chunks staged - 2, staged - 1 are in ibuf */
+    uint32_t stage_v[kNW];
+    Tab *T;
+    uint32_t *ibuf;      /* 64 dwords: two input chunks of 128 bytes */
+    int lane_;
+
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+    /* (nothing may depend on the loaded words before store_chunk: the zeros beyond the block's end are put in there) */
+    __device__ __forceinline__ void load_chunk(uint32_t c)
+    {
+#pragma unroll
+        for (int j = 0; j < kNW; ++j) {
+            const uint32_t o = 128u * c + 4u * (uint32_t)(lane_ * kNW + j);
+            const uint32_t oc = o < clen ? o : clen; /* (reads at most the 4 bytes behind the data: CRC32 of the BGZF trailer) */
+            stage_v[j] = *reinterpret_cast<const u32_unaligned *>(in + oc);
+        }
+    }
+    __device__ __forceinline__ void store_chunk(uint32_t c)
+    {
+#pragma unroll
+        for (int j = 0; j < kNW; ++j) {
+            const uint32_t o = 128u * c + 4u * (uint32_t)(lane_ * kNW + j);
+            const uint32_t left = clen > o ? clen - o : 0u;
+            const uint32_t v = left >= 4u ? stage_v[j] : (stage_v[j] & ((1u << (8u * left)) - 1u));
+            ibuf[(c & 1u) * 32u + (uint32_t)(lane_ * kNW + j)] = v;
+        }
+    }
+    __device__ __forceinline__ void start()
+    {
+        static_assert(G * kNW * 4 == 128, "a chunk is 128 bytes");
+        load_chunk(0);
+        store_chunk(0);
+        load_chunk(1);
+        staged = 1;
+        sync();
+    }
+    /* dword k of the input is wanted next (k never decreases by more than a chunk): bring its chunk into LDS */
+    __device__ __forceinline__ void want(uint32_t k)
+    {
+        if ((k >> 5) >= staged) {
+            store_chunk(staged);
+            ++staged;
+            load_chunk(staged);
+            sync();
+        }
+    }
+    __device__ __forceinline__ uint32_t in32(uint32_t k)
+    {
+        want(k);
+        return ibuf[k & 63u];
+    }
+    __device__ __forceinline__ uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
+    __device__ __forceinline__ Tab &tables() { return *T; }
+    __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ int lane() const { return lane_; }
+    __device__ __forceinline__ int lanes() const { return G; }
+    __device__ __forceinline__ int uniform(int v) const { return __shfl(v, 0, G); }
+    __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return v; }
+    __device__ __forceinline__ uint32_t out_pos() const { return pos; }
+
+    /* outside the symbol loop (stored blocks): a literal beyond the block's size is counted, not written; the stream's final check
+     * (out_pos() == ISIZE) reports it */
+    __device__ __forceinline__ bool put_literal(uint8_t c)
+    {
+        if (pos >= limit) return false;
+        if (lane_ == 0) out[pos] = c;
+        ++pos;
+        return true;
+    }
+    __device__ __forceinline__ bool lit_full() const { return pos >= limit; }
+    __device__ __forceinline__ void lit_push(uint8_t c) { (void)put_literal(c); }
+    __device__ __forceinline__ bool lit_commit() const { return pos < limit; }
+    /* a match = a hole of `len` bytes: (distance - 1, length - 3) go into its first three bytes, its start into the bitmap.  (The
+     * caller has checked dist <= pos and pos + len <= limit.) */
+    __device__ __forceinline__ void copy_match(int len, int dist)
+    {
+        const uint32_t w = pos >> 5;
+        if (w != bm_idx) {
+            if (lane_ == 0 && bm_word) bm[bm_idx] = bm_word;
+            bm_word = 0;
+            bm_idx = w;
+        }
+        bm_word |= 1u << (pos & 31u);
+        if (lane_ == 0) {
+            *reinterpret_cast<u16_unaligned *>(out + pos) = (uint16_t)(dist - 1);
+            out[pos + 2] = (uint8_t)(len - 3);
+        }
+        pos += (uint32_t)len;
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (lane_ == 0 && bm_word) bm[bm_idx] = bm_word;
+    }
+
+    /* ---- the symbol loop of one DEFLATE block.  Its own bit reader: the two input dwords around the read position in registers
+     * (w0 = dword k, w1 = dword k + 1), the position inside w0 in `off`: v_alignbit_b32 gives the next 32 bits in one instruction,
+     * consuming is an add, and every fourth symbol or so moves on by one dword (one LDS read).  The tables are PACKED (spx_inflate.h):
+     * a length's base and extra bits come out of the entry.  A literal costs a look-up, one byte store and a dozen VALU instructions;
+     * nothing in here waits for global memory (want() does, once per 128 input bytes). ---- */
+    __device__ __forceinline__ int symbol_loop(spxz::Bits<TokEnv> &b)
+    {
+        const uint32_t P = b.next * 32u - (uint32_t)b.cnt; /* bits consumed so far */
+        uint32_t k = P >> 5, off = P & 31u;
+        want(k + 1u);
+        uint32_t w0 = ibuf[k & 63u], w1 = ibuf[(k + 1u) & 63u];
+        const uint32_t k_end = ((clen + 3u) >> 2) + 1u; /* the reader may look at (zero) bits beyond the data, not consume them */
+        const uint16_t *lit = T->lit, *dis = T->dist;
+        int rc = 1;
+        for (;;) {
+            if (off >= 32u) { /* move on by one dword */
+                off -= 32u;
+                ++k;
+                w0 = w1;
+                if (k > k_end) { rc = -3; break; }
+                want(k + 1u);
+                w1 = ibuf[(k + 1u) & 63u];
+            }
+            uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, off);
+            uint32_t e = lit[bits & ((1u << LR) - 1u)];
+            if (!(e & 0x100u)) {
+                /* a literal (beyond the block's size: counted, not written; the stream's final check reports it) */
+                if (lane_ == 0 && pos < limit) out[pos] = (uint8_t)e;
+                ++pos;
+                off += e >> 9;
+                continue;
+            }
+            if (e == spxz::kNoEntry) { /* a code longer than the root table */
+                const uint32_t r = spxz::decode_slow_bits(bits, T->lit_count, T->lit_sorted, 15);
+                if (r == 0xffffffffu) { rc = -1; break; }
+                const uint32_t sym = r & 0xffffu;
+                if (sym > 285u) { rc = -1; break; }
+                if (sym < 256u) {
+                    if (lane_ == 0 && pos < limit) out[pos] = (uint8_t)sym;
+                    ++pos;
+                    off += r >> 16;
+                    continue;
+                }
+                e = spxz::mk_len_entry((int)(r >> 16), (int)sym);
+            }
+            uint32_t n = (e >> 9) & 15u, x = e >> 13;
+            if (x == 7u) { /* end of block */
+                off += n;
+                rc = 0;
+                break;
+            }
+            const uint32_t len = (e & 0xffu) + 3u + ((bits >> n) & ((1u << x) - 1u));
+            off += n + x;
+            if (off >= 32u) {
+                off -= 32u;
+                ++k;
+                w0 = w1;
+                if (k > k_end) { rc = -3; break; }
+                want(k + 1u);
+                w1 = ibuf[(k + 1u) & 63u];
+            }
+            bits = __builtin_amdgcn_alignbit(w1, w0, off);
+            uint32_t de = dis[bits & ((1u << DR) - 1u)];
+            if (de == spxz::kNoEntry) {
+                const uint32_t r = spxz::decode_slow_bits(bits, T->dist_count, T->dist_sorted, 15);
+                if (r == 0xffffffffu) { rc = -1; break; }
+                if ((r & 0xffffu) > 29u) { rc = -1; break; }
+                de = spxz::mk_dist_entry((int)(r >> 16), (int)(r & 0xffffu));
+            }
+            n = de >> 9;
+            x = (de >> 2) & 15u;
+            const uint32_t dist = 1u + ((de & 3u) << x) + ((bits >> n) & ((1u << x) - 1u));
+            off += n + x;
+            if (dist > pos) { rc = -1; break; }
+            if (pos + len > limit) { rc = -2; break; }
+            copy_match((int)len, (int)dist);
+        }
+        /* hand the position back to the stream's reader */
+        if (rc == 0) {
+            if (off >= 32u) {
+                off -= 32u;
+                ++k;
+                w0 = w1;
+                if (k > k_end) return -3;
+                want(k + 1u);
+                w1 = ibuf[(k + 1u) & 63u];
+            }
+            b.buf = (uint64_t)(w0 >> off);
+            b.cnt = 32 - (int)off;
+            b.next = k + 1u;
+            b.pre = w1;
+        }
+        return rc;
+    }
+};
+
+template <int G, int LR, int DR, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void bgzf_decode_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
+                                                           uint8_t *__restrict__ outbuf, uint32_t *__restrict__ bitmap, int32_t *__restrict__ status)
+{
+    constexpr int NB = 64 / G;
+    __shared__ spxz::TablesT<LR, DR> T[NB];
+    __shared__ uint32_t ibuf[NB][64];
+    const int q = (int)threadIdx.x / G, lane = (int)threadIdx.x % G;
+    const int b = (int)blockIdx.x * NB + q;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    TokEnv<G, LR, DR> env;
+    env.in = comp + d.in_off;
+    env.clen = d.clen;
+    env.out = outbuf + d.out_off;
+    env.bm = bitmap + (size_t)b * kBitmapWords;
+    env.limit = d.ulen;
+    env.pos = 0;
+    env.bm_word = 0;
+    env.bm_idx = 0;
+    env.T = &T[q];
+    env.ibuf = ibuf[q];
+    env.lane_ = lane;
+    int rc = 0;
+    if (d.ulen > 0) {
+        env.start();
+        rc = spxz::inflate_stream(env, (int64_t)d.clen * 8, d.ulen);
+        if (rc == 0) env.finish();
+    }
+    if (lane == 0) status[b] = rc;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The decode kernel's own DEFLATE decoder (TokEnv above runs the shared core of spx_inflate.h with a hand-written symbol loop; this
+ * one is the whole stream, written for the lane group):
+ *   - ONE bit reader everywhere: two input dwords in registers, v_alignbit_b32 for the next 32 bits, input staged through LDS in
+ *     128-byte chunks;
+ *   - block headers in PARALLEL: the code-length code through a 128-entry table, the canonical order of the 286 + 30 symbols by
+ *     ballots (rank among the symbols of one length = population count of the lanes before me), the root tables filled by all
+ *     lanes -- the serial version of these loops was a third of the kernel's vector instructions;
+ *   - literals gather in a register (lane n takes the n-th) and leave as ONE store per run;
+ *   - LDS per block: 2.2 KB of tables (the code lengths of a header live where the literal table is built afterwards) + 256
+ *     bytes of input.
+ * Same contract as the core: 0, -1 corrupt stream, -2 output overrun, -3 input overrun. */
+template <int G>
+struct TokDec {
+    static constexpr int LR = 9, DR = 8;
+    static constexpr int kNW = 32 / G;             /* dwords of a 128-byte input chunk per lane */
+    static constexpr int kNC = (288 + G - 1) / G;  /* literal/length symbols per lane */
+    static constexpr int kND = (32 + G - 1) / G;
+    static_assert(G == 32 || G == 16, "lanes per block");
+    struct Lds {
+        union {
+            uint16_t lit[1 << LR];
+            uint8_t lens[320];           /* a header's code lengths: dead once the symbols are in canonical order */
+        };
+        union {
+            uint16_t dist[1 << DR];
+            struct {
+                uint8_t dlens[32];       /* the distance code lengths, set aside while the literal table is built over `lens` */
+                uint16_t first[16], offs[16]; /* canonical code / index in `sorted` of every length's first symbol */
+                uint8_t cltab[128];      /* the code-length code: (length << 5) | symbol by the next 7 bits, 0xff = no code */
+            } h;
+        };
+        uint16_t lit_sorted[288], dist_sorted[32]; /* (length << 9) | symbol in (length, symbol) order */
+        uint16_t lit_count[16], dist_count[16];
+        uint32_t ibuf[64];
+    };
+    const uint8_t *in;
+    uint32_t clen, k_end;
+    uint8_t *out;
+    uint32_t *bm;
+    uint32_t limit, pos;
+    uint32_t bm_word, bm_idx;
+    uint32_t staged;
+    uint32_t stage_v[kNW];
+    uint32_t w0, w1, k, off; /* the reader: w0 = input dword k, w1 = dword k + 1, `off` bits of w0 consumed (may pass 32: step()) */
+    uint32_t lit_room;       /* (see build()) */
+    uint32_t npend;          /* literals waiting in litv: the n-th in lane n; they end at `pos` */
+    uint32_t litv;
+    Lds *L;
+    int lane;
+
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+    __device__ __forceinline__ static void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ uint32_t gballot(bool p) const
+    {
+        const unsigned long long m = __ballot(p);
+        return G == 32 ? (uint32_t)(m >> (threadIdx.x & 32u)) : ((uint32_t)(m >> (threadIdx.x & 48u)) & 0xffffu);
+    }
+    /* ---- input ---- */
+    __device__ __forceinline__ void load_chunk(uint32_t c)
+    {
+#pragma unroll
+        for (int j = 0; j < kNW; ++j) {
+            const uint32_t o = 128u * c + 4u * (uint32_t)(lane * kNW + j);
+            const uint32_t oc = o < clen ? o : clen; /* (at most the 4 bytes behind the data: the CRC32 of the BGZF trailer) */
+            stage_v[j] = *reinterpret_cast<const u32_unaligned *>(in + oc);
+        }
+    }
+    __device__ __forceinline__ void store_chunk(uint32_t c)
+    {
+#pragma unroll
+        for (int j = 0; j < kNW; ++j) {
+            const uint32_t o = 128u * c + 4u * (uint32_t)(lane * kNW + j);
+            const uint32_t left = clen > o ? clen - o : 0u;
+            const uint32_t v = left >= 4u ? stage_v[j] : (stage_v[j] & ((1u << (8u * left)) - 1u));
+            L->ibuf[(c & 1u) * 32u + (uint32_t)(lane * kNW + j)] = v;
+        }
+    }
+    /* the reader at bit `p` of the input */
+    __device__ __forceinline__ void seek(uint32_t p)
+    {
+        k = p >> 5;
+        off = p & 31u;
+        const uint32_t c = k >> 5;
+        load_chunk(c);
+        store_chunk(c);
+        load_chunk(c + 1u);
+        store_chunk(c + 1u);
+        load_chunk(c + 2u);
+        staged = c + 2u;
+        lds_fence();
+        w0 = L->ibuf[k & 63u];
+        w1 = L->ibuf[(k + 1u) & 63u];
+    }
+    /* off >= 32: on to the next dword; false = beyond the input */
+    __device__ __forceinline__ bool step()
+    {
+        off -= 32u;
+        ++k;
+        w0 = w1;
+        if (k > k_end) return false;
+        if (((k + 1u) >> 5) >= staged) {
+            store_chunk(staged);
+            ++staged;
+            load_chunk(staged);
+            lds_fence();
+        }
+        w1 = L->ibuf[(k + 1u) & 63u];
+        return true;
+    }
+    __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w1, w0, off); }
+    /* n <= 16 bits; -1 (as uint32) can not be a value: the input is exhausted */
+    __device__ __forceinline__ bool bits(uint32_t n, uint32_t *v)
+    {
+        if (off >= 32u && !step()) return false;
+        *v = peek() & ((1u << n) - 1u);
+        off += n;
+        return true;
+    }
+    /* ---- output ---- */
+    __device__ __forceinline__ void push(uint32_t c)
+    {
+        litv = (uint32_t)lane == npend ? c : litv;
+        ++npend;
+        ++pos;
+    }
+    __device__ __forceinline__ void flush_literals()
+    {
+        if (npend) {
+            const uint32_t p = pos - npend + (uint32_t)lane;
+            if ((uint32_t)lane < npend && p < limit) out[p] = (uint8_t)litv; /* (beyond the block's size: counted, not written) */
+            npend = 0;
+        }
+    }
+    __device__ __forceinline__ void token(uint32_t len, uint32_t dist)
+    {
+        const uint32_t w = pos >> 5;
+        if (w != bm_idx) {
+            if (lane == 0 && bm_word) bm[bm_idx] = bm_word;
+            bm_word = 0;
+            bm_idx = w;
+        }
+        bm_word |= 1u << (pos & 31u);
+        if (lane == 0) {
+            *reinterpret_cast<u16_unaligned *>(out + pos) = (uint16_t)(dist - 1u);
+            out[pos + 2] = (uint8_t)(len - 3u);
+        }
+        pos += len;
+    }
+
+    /* ---- canonical order of `n` symbols (their lengths: mine[c] = length of symbol c * G + lane, 0 = unused) into sorted / count,
+     * first / offs; -1 for an over-subscribed set or an incomplete one of more than one code.  `used` = coded symbols ---- */
+    template <int NC>
+    __device__ __forceinline__ int canonical(const uint32_t (&mine)[NC], uint16_t *sorted, uint16_t *count, int *used, uint32_t *min_len)
+    {
+        const uint32_t lt = (1u << lane) - 1u;
+        int left = 1, bad = 0;
+        *min_len = 16;
+        uint32_t run = 0, code = 0, n_prev = 0;
+        for (uint32_t l = 1; l < 16; ++l) {
+            code = (code + n_prev) << 1;
+            uint32_t at = run;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bool m = mine[c] == l;
+                const uint32_t mask = gballot(m);
+                if (m) sorted[at + (uint32_t)__popc(mask & lt)] = (uint16_t)((l << 9) | (uint32_t)(c * G + lane));
+                at += (uint32_t)__popc(mask);
+            }
+            const uint32_t n_l = at - run;
+            if (n_l && *min_len == 16u) *min_len = l;
+            left = (left << 1) - (int)n_l;
+            if (left < 0) bad = 1;
+            if (lane == 0) {
+                L->h.first[l] = (uint16_t)code;
+                L->h.offs[l] = (uint16_t)run;
+                count[l] = (uint16_t)n_l;
+            }
+            run = at;
+            n_prev = n_l;
+        }
+        *used = (int)run;
+        if (left > 0 && run > 1u) bad = 1;
+        lds_fence();
+        return bad ? -1 : 0;
+    }
+    /* root table from the canonical order: symbol number i has code first[len] + (i - offs[len]), replicated over the high index bits */
+    template <bool LIT>
+    __device__ __forceinline__ void fill(uint16_t *tab, int root, const uint16_t *sorted, int used)
+    {
+        constexpr int NR = LIT ? kNC : kND;
+        uint32_t packed[LIT ? 1 : NR]; /* entry | start index << 16 | length << 25 */
+        /* the distance table goes where first / offs lie: everything is read before anything is written.  (The literal table lies
+         * over the code lengths, which are dead by now.) */
+        auto one = [&](int i) -> uint32_t {
+            if (i >= used) return 0u;
+            const uint32_t v = sorted[i], s = v & 511u, ll = v >> 9;
+            if ((int)ll > root || (LIT ? s > 285u : s > 29u)) return 0u;
+            const uint32_t e = !LIT ? spxz::mk_dist_entry((int)ll, (int)s) : s < 256u ? spxz::mk_entry((int)ll, (int)s) : spxz::mk_len_entry((int)ll, (int)s);
+            const uint32_t r = __brev((uint32_t)L->h.first[ll] + ((uint32_t)i - (uint32_t)L->h.offs[ll])) >> (32u - ll);
+            return e | (r << 16) | (ll << 25);
+        };
+        auto put = [&](uint32_t pk) {
+            if (pk)
+                for (uint32_t q = (pk >> 16) & 511u; q < (1u << root); q += 1u << (pk >> 25)) tab[q] = (uint16_t)pk;
+        };
+        if (!LIT) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) packed[c] = one(c * G + lane);
+            lds_fence();
+        }
+        uint32_t *t32 = reinterpret_cast<uint32_t *>(tab);
+        for (int q = lane; q < (1 << root) / 2; q += G) t32[q] = (uint32_t)spxz::kNoEntry * 0x10001u;
+        lds_fence();
+        if (LIT) {
+            for (int i = lane; i < used; i += G) put(one(i));
+        } else {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) put(packed[c]);
+        }
+        lds_fence();
+    }
+    /* both tables from L->lens[0 .. nlit) and L->lens[nlit .. nlit + ndist) */
+    __device__ __forceinline__ int build(int nlit, int ndist)
+    {
+        for (int j = lane; j < 32; j += G) L->h.dlens[j] = j < ndist ? L->lens[nlit + j] : (uint8_t)0;
+        uint32_t mine[kNC];
+#pragma unroll
+        for (int c = 0; c < kNC; ++c) {
+            const int s = c * G + lane;
+            mine[c] = s < nlit ? (uint32_t)L->lens[s] : 0u;
+        }
+        lds_fence();
+        int used = 0;
+        uint32_t min_len;
+        if (canonical<kNC>(mine, L->lit_sorted, L->lit_count, &used, &min_len) != 0) return -1;
+        /* literals gather in a register of G lanes between two steps of the reader (32 bits): with codes of >= 2 bits at most 16
+         * arrive, and the register is emptied at a step once it holds 16; a 1-bit code empties it at every step */
+        lit_room = (G == 32 && min_len >= 2u) ? 16u : 1u;
+        fill<true>(L->lit, LR, L->lit_sorted, used);
+        uint32_t dmine[kND];
+#pragma unroll
+        for (int c = 0; c < kND; ++c) dmine[c] = (uint32_t)L->h.dlens[c * G + lane];
+        lds_fence();
+        if (canonical<kND>(dmine, L->dist_sorted, L->dist_count, &used, &min_len) != 0) return -1;
+        fill<false>(L->dist, DR, L->dist_sorted, used);
+        return 0;
+    }
+    /* a code longer than the root table: the canonical walk (Mark Adler's puff), one bit at a time */
+    __device__ __forceinline__ static uint32_t walk(uint32_t bits, const uint16_t *count, const uint16_t *sorted)
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; ++len) {
+            code |= (int)(bits & 1u);
+            bits >>= 1;
+            const int c = count[len];
+            if (code - c < first) return ((uint32_t)len << 16) | ((uint32_t)sorted[index + (code - first)] & 511u);
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return 0xffffffffu;
+    }
+
+    /* ---- a dynamic block's header: the code lengths into L->lens ---- */
+    __device__ __forceinline__ int header(int *nlit_out, int *ndist_out)
+    {
+        uint32_t v;
+        if (!bits(14, &v)) return -3;
+        const int nlit = (int)(v & 31u) + 257, ndist = (int)((v >> 5) & 31u) + 1, ncode = (int)(v >> 10) + 4;
+        if (nlit > 286 || ndist > 30) return -1;
+        /* the code-length code: 3 bits per symbol, packed */
+        unsigned long long cl = 0;
+        {
+            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+#pragma unroll
+            for (int q = 0; q < 19; ++q) {
+                if (q < ncode) {
+                    if (!bits(3, &v)) return -3;
+                    cl |= (unsigned long long)v << (3 * order[q]);
+                }
+            }
+        }
+        unsigned long long cnt = 0; /* symbols per length, 8 bits each */
+#pragma unroll
+        for (int j = 0; j < 19; ++j) cnt += 1ull << (8u * (uint32_t)((cl >> (3 * j)) & 7u));
+        int left = 1;
+        unsigned long long first = 0; /* canonical first code per length, 8 bits each */
+        {
+            uint32_t code = 0, n_prev = 0;
+#pragma unroll
+            for (uint32_t l = 1; l < 8; ++l) {
+                code = (code + n_prev) << 1;
+                first |= (unsigned long long)(code & 0xffu) << (8u * l);
+                n_prev = (uint32_t)(cnt >> (8u * l)) & 0xffu;
+                left = (left << 1) - (int)n_prev;
+                if (left < 0) return -1;
+            }
+        }
+        const int used = 19 - (int)(cnt & 0xffu);
+        if (left > 0 && used > 1) return -1;
+        for (int q = lane; q < 32; q += G) reinterpret_cast<uint32_t *>(L->h.cltab)[q] = 0xffffffffu;
+        lds_fence();
+        for (int j = lane; j < 19; j += G) {
+            const uint32_t l = (uint32_t)(cl >> (3 * j)) & 7u;
+            if (l) {
+                uint32_t rank = 0;
+#pragma unroll
+                for (int q = 0; q < 18; ++q)
+                    if (q < j && ((uint32_t)(cl >> (3 * q)) & 7u) == l) ++rank;
+                const uint32_t code = ((uint32_t)(first >> (8u * l)) & 0xffu) + rank;
+                for (uint32_t q = __brev(code) >> (32u - l); q < 128u; q += 1u << l) L->h.cltab[q] = (uint8_t)((l << 5) | (uint32_t)j);
+            }
+        }
+        lds_fence();
+        const int total = nlit + ndist;
+        int idx = 0;
+        uint32_t prev = 0;
+        while (idx < total) {
+            if (off >= 32u && !step()) return -3;
+            uint32_t b = peek();
+            const uint32_t e = L->h.cltab[b & 127u];
+            if (e == 0xffu) return -1;
+            const uint32_t sym = e & 31u;
+            off += e >> 5;
+            b >>= e >> 5;
+            if (sym < 16u) {
+                if (lane == 0) L->lens[idx] = (uint8_t)sym;
+                prev = sym;
+                ++idx;
+                continue;
+            }
+            int rep;
+            uint32_t val = 0;
+            if (sym == 16u) {
+                if (idx == 0) return -1;
+                val = prev;
+                rep = 3 + (int)(b & 3u);
+                off += 2u;
+            } else if (sym == 17u) {
+                rep = 3 + (int)(b & 7u);
+                off += 3u;
+            } else {
+                rep = 11 + (int)(b & 127u);
+                off += 7u;
+            }
+            if (idx + rep > total) return -1;
+            for (int q = lane; q < rep; q += G) L->lens[idx + q] = (uint8_t)val;
+            idx += rep;
+            prev = val;
+        }
+        lds_fence();
+        if (L->lens[256] == 0) return -1; /* no end-of-block code */
+        *nlit_out = nlit;
+        *ndist_out = ndist;
+        return 0;
+    }
+
+    /* ---- the symbols of one block, to its end-of-block code ---- */
+    __device__ __forceinline__ int symbols()
+    {
+        const uint16_t *lit = L->lit, *dis = L->dist;
+        int rc = 1;
+        for (;;) {
+            if (off >= 32u) {
+                if (npend >= lit_room) flush_literals();
+                if (!step()) { rc = -3; break; }
+            }
+            uint32_t b = peek();
+            uint32_t e = lit[b & ((1u << LR) - 1u)];
+            if (!(e & 0x100u)) {
+                if (G < 32 && npend == (uint32_t)G) flush_literals();
+                push(e & 0xffu);
+                off += e >> 9;
+                continue;
+            }
+            if (e == spxz::kNoEntry) {
+                const uint32_t r = walk(b, L->lit_count, L->lit_sorted);
+                if (r == 0xffffffffu) { rc = -1; break; }
+                const uint32_t sym = r & 0xffffu;
+                if (sym > 285u) { rc = -1; break; }
+                if (sym < 256u) {
+                    if (npend == (uint32_t)G) flush_literals();
+                    push(sym);
+                    off += r >> 16;
+                    continue;
+                }
+                e = spxz::mk_len_entry((int)(r >> 16), (int)sym);
+            }
+            uint32_t n = (e >> 9) & 15u, x = e >> 13;
+            if (x == 7u) {
+                off += n;
+                rc = 0;
+                break;
+            }
+            const uint32_t len = (e & 0xffu) + 3u + ((b >> n) & ((1u << x) - 1u));
+            off += n + x;
+            flush_literals();
+            if (off >= 32u && !step()) { rc = -3; break; }
+            b = peek();
+            uint32_t de = dis[b & ((1u << DR) - 1u)];
+            if (de == spxz::kNoEntry) {
+                const uint32_t r = walk(b, L->dist_count, L->dist_sorted);
+                if (r == 0xffffffffu) { rc = -1; break; }
+                if ((r & 0xffffu) > 29u) { rc = -1; break; }
+                de = spxz::mk_dist_entry((int)(r >> 16), (int)(r & 0xffffu));
+            }
+            n = de >> 9;
+            x = (de >> 2) & 15u;
+            const uint32_t dist = 1u + ((de & 3u) << x) + ((b >> n) & ((1u << x) - 1u));
+            off += n + x;
+            if (dist > pos) { rc = -1; break; }
+            if (pos + len > limit) { rc = -2; break; }
+            token(len, dist);
+        }
+        flush_literals();
+        return rc;
+    }
+
+    __device__ __forceinline__ int run()
+    {
+        npend = 0;
+        litv = 0;
+        bm_word = 0;
+        bm_idx = 0;
+        pos = 0;
+        k_end = ((clen + 3u) >> 2) + 1u;
+        seek(0);
+        for (;;) {
+            uint32_t hdr;
+            if (!bits(3, &hdr)) return -3;
+            const int final_blk = (int)(hdr & 1u), type = (int)(hdr >> 1);
+            if (type == 0) {
+                /* stored: LEN, NLEN at the next byte boundary, then LEN bytes straight from the input */
+                const uint32_t at = (32u * k + off + 7u) >> 3; /* byte offset of LEN */
+                if (at + 4u > clen) return -3;
+                const uint32_t len = (uint32_t)in[at] | ((uint32_t)in[at + 1] << 8), nlen = (uint32_t)in[at + 2] | ((uint32_t)in[at + 3] << 8);
+                if ((len ^ 0xffffu) != nlen) return -1;
+                if (at + 4u + len > clen) return -3;
+                if (pos + len > limit) return -2;
+                for (uint32_t q = (uint32_t)lane; q < len; q += (uint32_t)G) out[pos + q] = in[at + 4u + q];
+                pos += len;
+                seek(8u * (at + 4u + len));
+            } else if (type == 1 || type == 2) {
+                int nlit = 288, ndist = 32;
+                if (type == 1) {
+                    for (int s = lane; s < 288; s += G) L->lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                    for (int s = lane; s < 32; s += G) L->lens[288 + s] = 5;
+                    lds_fence();
+                } else {
+                    const int rc = header(&nlit, &ndist);
+                    if (rc != 0) return rc;
+                }
+                if (build(nlit, ndist) != 0) return -1;
+                const int rc = symbols();
+                if (rc != 0) return rc;
+            } else
+                return -1;
+            if ((unsigned long long)32u * k + off > (unsigned long long)clen * 8u) return -3;
+            if (final_blk) break;
+        }
+        if (lane == 0 && bm_word) bm[bm_idx] = bm_word;
+        return pos == limit ? 0 : -2;
+    }
+};
+
+template <int G, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void bgzf_decode2_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
+                                                            uint8_t *__restrict__ outbuf, uint32_t *__restrict__ bitmap, int32_t *__restrict__ status)
+{
+    constexpr int NB = 64 / G;
+    __shared__ typename TokDec<G>::Lds lds[NB];
+    const int q = (int)threadIdx.x / G, lane = (int)threadIdx.x % G;
+    const int b = (int)blockIdx.x * NB + q;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    TokDec<G> dec;
+    dec.in = comp + d.in_off;
+    dec.clen = d.clen;
+    dec.out = outbuf + d.out_off;
+    dec.bm = bitmap + (size_t)b * kBitmapWords;
+    dec.limit = d.ulen;
+    dec.L = &lds[q];
+    dec.lane = lane;
+    int rc = 0;
+    if (d.ulen > 0) rc = dec.run();
+    if (lane == 0) status[b] = rc;
+}
+
+constexpr int kLongMatch = 16; /* longer matches are copied by the whole wavefront */
+
+__global__ __launch_bounds__(64) void bgzf_resolve_kernel(const BlockDesc *__restrict__ blocks, int32_t n_blocks, uint8_t *__restrict__ outbuf,
+                                                          const uint32_t *__restrict__ bitmap, const int32_t *__restrict__ status)
+{
+    __shared__ uint16_t list[2048 / 3 + 4];
+    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (b >= n_blocks) return;
+    const BlockDesc d = blocks[b];
+    if (d.ulen == 0 || status[b] != 0) return;
+    uint8_t *out = outbuf + d.out_off;
+    const uint32_t *bm = bitmap + (size_t)b * kBitmapWords;
+    const uint32_t nwords = (d.ulen + 31u) >> 5;
+    for (uint32_t w0 = 0; w0 < nwords; w0 += 64) {
+        const uint32_t w = w0 + (uint32_t)lane < nwords ? bm[w0 + lane] : 0u;
+        const int cnt = __popc(w);
+        int incl = cnt;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int t = __shfl_up(incl, s);
+            if (lane >= s) incl += t;
+        }
+        const int total = __shfl(incl, 63);
+        if (total == 0) continue;
+        __syncthreads(); /* the previous chunk's list is done with */
+        {
+            uint32_t ww = w;
+            int j = incl - cnt;
+            while (ww) {
+                const int bit = __ffs((int)ww) - 1;
+                ww &= ww - 1u;
+                list[j++] = (uint16_t)(((w0 + (uint32_t)lane) << 5) + (uint32_t)bit);
+            }
+        }
+        __syncthreads();
+        for (int i0 = 0; i0 < total; i0 += 64) {
+            const int i = i0 + lane;
+            bool pending = i < total;
+            uint32_t pos = 0, len = 0, dist = 1;
+            if (pending) {
+                pos = list[i];
+                const uint32_t t0 = out[pos], t1 = out[pos + 1], t2 = out[pos + 2];
+                dist = (t0 | (t1 << 8)) + 1u;
+                len = t2 + 3u;
+            }
+            const uint32_t src = pos - dist;
+            for (;;) {
+                const unsigned long long pm = __ballot(pending);
+                if (!pm) break;
+                const int first = __ffsll((long long)pm) - 1;
+                const uint32_t hwm = (uint32_t)__shfl((int)pos, first), flen = (uint32_t)__shfl((int)len, first);
+                if (flen > (uint32_t)kLongMatch) {
+                    /* the first open hole is a long one: everything below it is final, the whole wavefront copies it (an overlapping
+                     * match repeats its first `dist` bytes) */
+                    const uint32_t fsrc = (uint32_t)__shfl((int)src, first), fdist = (uint32_t)__shfl((int)dist, first);
+                    for (uint32_t k = (uint32_t)lane; k < flen; k += 64u) {
+                        const uint32_t idx = fdist >= flen ? k : k % fdist;
+                        out[hwm + k] = __hip_atomic_load(out + fsrc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (lane == first) pending = false;
+                } else {
+                    const bool ready = pending && (lane == first || (len <= (uint32_t)kLongMatch && src + len <= hwm));
+                    if (ready) {
+                        for (uint32_t k0 = 0; k0 < len; k0 += 4u) {
+                            uint8_t v[4];
+#pragma unroll
+                            for (uint32_t j = 0; j < 4u; ++j) {
+                                const uint32_t k = k0 + j;
+                                v[j] = 0;
+                                if (k < len) v[j] = __hip_atomic_load(out + src + (dist >= len ? k : k % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                            for (uint32_t j = 0; j < 4u; ++j)
+                                if (k0 + j < len) out[pos + k0 + j] = v[j];
+                        }
+                        pending = false;
+                    }
+                }
+                /* what this round stored is the next round's source: the stores must have reached the L2 (the loads go past the L1) */
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
+        }
+    }
+}
+
 } // namespace
 
 static int inflate_root_bits()
@@ -644,6 +1476,46 @@ extern "C" hipError_t spx_launch_bgzf_inflate_grouped(const uint8_t *comp, const
     return hipGetLastError();
 }
 
+extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc, hipStream_t st);
+
+/* the two-kernel path (decode, then copy) needs a bitmap of 8 KB per block */
+extern "C" size_t spx_bgzf_inflate_scratch_bytes(int32_t n_blocks) { return (size_t)(n_blocks > 0 ? n_blocks : 0) * kBitmapWords * 4u; }
+
+/* SPX_INFLATE_TOK: 234 (default) = the decode kernel with 32 lanes per block, seven waves per SIMD; 232 / 233 / 235 = five / six / eight waves, 216 =
+ * 16 lanes per block; 32 / 16 / 8 = the shared decoder core with its hand-written symbol loop (TokEnv); 0 = one kernel (bgzf_inflate_g_kernel) */
+static int inflate_tok_lanes()
+{
+    static const int v = [] { const char *e = getenv("SPX_INFLATE_TOK"); const int v = e ? atoi(e) : 234; return (v == 8 || v == 16 || v == 32 || v == 33 || v == 17 || (v >= 200 && v < 300)) ? v : 0; }();
+    return v;
+}
+
+extern "C" hipError_t spx_launch_bgzf_inflate2(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc,
+                                               void *scratch, hipStream_t st)
+{
+    if (n_blocks <= 0) return hipSuccess;
+    const int g = inflate_tok_lanes();
+    if (g == 0 || !scratch) return spx_launch_bgzf_inflate(comp, blocks, n_blocks, out, status, check_crc, st); /* SPX_INFLATE_TOK=0: round 4's first kernel */
+    const BlockDesc *bd = (const BlockDesc *)blocks;
+    uint32_t *bitmap = (uint32_t *)scratch;
+    const int stage = [] { const char *e = getenv("SPX_INFLATE_TOK_STAGE"); return e ? atoi(e) : 3; }(); /* experiments: 1 = decode only, 2 = + copy */
+    if (hipMemsetAsync(bitmap, 0, spx_bgzf_inflate_scratch_bytes(n_blocks), st) != hipSuccess) return hipGetLastError();
+#define SPX_LAUNCH_DEC2(G, WPE) \
+    hipLaunchKernelGGL((bgzf_decode2_kernel<G, WPE>), dim3((unsigned)((n_blocks + (64 / G) - 1) / (64 / G))), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status)
+    if (g == 232) SPX_LAUNCH_DEC2(32, 5);
+    else if (g == 233) SPX_LAUNCH_DEC2(32, 6);
+    else if (g == 234) SPX_LAUNCH_DEC2(32, 7);
+    else if (g == 235) SPX_LAUNCH_DEC2(32, 8);
+    else if (g == 216) SPX_LAUNCH_DEC2(16, 4);
+    else if (g == 8) hipLaunchKernelGGL((bgzf_decode_kernel<8, 9, 8, 2>), dim3((unsigned)((n_blocks + 7) / 8)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
+    else if (g == 16) hipLaunchKernelGGL((bgzf_decode_kernel<16, 9, 8, 4>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
+    else if (g == 17) hipLaunchKernelGGL((bgzf_decode_kernel<16, 9, 8, 3>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
+    else if (g == 33) hipLaunchKernelGGL((bgzf_decode_kernel<32, 9, 8, 6>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
+    else hipLaunchKernelGGL((bgzf_decode_kernel<32, 9, 8, 5>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
+    if (stage >= 2) hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, bd, n_blocks, out, bitmap, status);
+    if (stage >= 3 && check_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, bd, n_blocks, out, status);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
                                               int check_crc, hipStream_t st)
 {
@@ -653,7 +1525,7 @@ extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *b
      * per wave on the scalar unit */
     static const int lanes = [] { const char *e = getenv("SPX_INFLATE_LANES"); const int v = e ? atoi(e) : 32; return (v == 16 || v == 64) ? v : 32; }();
     /* SPX_INFLATE_FLAT = 4 / 8 / 16 / 32: the flat kernel with that many lanes per block (9 / 8-bit root tables, 1 KB ring) + the CRC kernel */
-    static const int flat = [] { const char *e = getenv("SPX_INFLATE_FLAT"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 132) ? v : 0; }();
+    static const int flat = [] { const char *e = getenv("SPX_INFLATE_FLAT"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 132 || (v >= 1000 && v < 3000)) ? v : 0; }();
     if (flat) {
         const BlockDesc *bd = (const BlockDesc *)blocks;
 #define SPX_LAUNCH_FLAT(G, WPE) \
@@ -661,10 +1533,15 @@ extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *b
         if (flat == 4) SPX_LAUNCH_FLAT(4, 1);
         else if (flat == 8) SPX_LAUNCH_FLAT(8, 2);
         else if (flat == 16) SPX_LAUNCH_FLAT(16, 3);
+        else if (flat == 1032) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<32, 9, 8, 1024, 5, true, 1>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
+        else if (flat == 2032) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<32, 9, 8, 1024, 5, true, 2>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
+        else if (flat == 1016) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<16, 9, 8, 1024, 3, true, 1>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
+        else if (flat == 2016) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<16, 9, 8, 1024, 3, true, 2>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
+        else if (flat == 2008) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<8, 9, 8, 1024, 2, true, 2>), dim3((unsigned)((n_blocks + 7) / 8)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
         else if (flat == 132) /* 32 lanes, the symbol loop with the inner literal loop */
             hipLaunchKernelGGL((bgzf_inflate_flat_kernel<32, 9, 8, 1024, 5, false>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
         else SPX_LAUNCH_FLAT(32, 5);
-        if (check_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, bd, n_blocks, out, status);
+        if (check_crc && flat < 1000) hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, bd, n_blocks, out, status);
         return hipGetLastError();
     }
     if (lanes != 64) return spx_launch_bgzf_inflate_grouped(comp, blocks, n_blocks, out, status, check_crc, lanes, st);

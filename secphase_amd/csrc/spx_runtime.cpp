@@ -51,6 +51,9 @@ extern "C" hipError_t spx_prep_slice_bounds(const int32_t *slot0, const spxl::Pl
                                             spxl::PlanBase *out, hipStream_t st);
 #define SPX_MAX_SLICES 32
 
+extern "C" size_t spx_bgzf_inflate_scratch_bytes(int32_t n_blocks);
+extern "C" hipError_t spx_launch_bgzf_inflate2(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc,
+                                               void *scratch, hipStream_t st);
 extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
                                               int check_crc, hipStream_t st);
 
@@ -2363,6 +2366,7 @@ extern "C" int64_t spx_inflate_bgzf_device(spx_ctx *c, const uint8_t *file, cons
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     SpxBgzfDesc *d_desc = nullptr;
     int32_t *d_status = nullptr;
+    void *d_scratch = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SPX_OK;
     auto cleanup = [&]() {
@@ -2370,6 +2374,7 @@ extern "C" int64_t spx_inflate_bgzf_device(spx_ctx *c, const uint8_t *file, cons
         if (d_out) (void)hipFree(d_out);
         if (d_desc) (void)hipFree(d_desc);
         if (d_status) (void)hipFree(d_status);
+        if (d_scratch) (void)hipFree(d_scratch);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
@@ -2378,13 +2383,14 @@ extern "C" int64_t spx_inflate_bgzf_device(spx_ctx *c, const uint8_t *file, cons
     ZCHK(hipMalloc((void **)&d_out, (size_t)utot + 64));
     ZCHK(hipMalloc((void **)&d_desc, desc.size() * sizeof(SpxBgzfDesc)));
     ZCHK(hipMalloc((void **)&d_status, (size_t)n_blocks * 4));
+    ZCHK(hipMalloc(&d_scratch, spx_bgzf_inflate_scratch_bytes(n_blocks) + 64));
     ZCHK(hipMemset(d_comp + cbytes, 0, 64));
     ZCHK(hipMemcpy(d_comp, file + base, cbytes, hipMemcpyHostToDevice));
     ZCHK(hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(SpxBgzfDesc), hipMemcpyHostToDevice));
     ZCHK(hipEventCreate(&e0));
     ZCHK(hipEventCreate(&e1));
     ZCHK(hipEventRecord(e0, c->stream));
-    ZCHK(spx_launch_bgzf_inflate(d_comp, d_desc, n_blocks, d_out, d_status, 1, c->stream));
+    ZCHK(spx_launch_bgzf_inflate2(d_comp, d_desc, n_blocks, d_out, d_status, 1, d_scratch, c->stream));
     ZCHK(hipEventRecord(e1, c->stream));
     ZCHK(hipStreamSynchronize(c->stream));
     if (kernel_ms) { float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); *kernel_ms = ms; }
@@ -2409,6 +2415,7 @@ struct spx_inflater {
         uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
         SpxBgzfDesc *h_desc = nullptr, *d_desc = nullptr;
         int32_t *h_status = nullptr, *d_status = nullptr;
+        void *d_scratch = nullptr; /* the inflate kernels' (spx_bgzf_inflate_scratch_bytes) */
         size_t in_cap = 0, out_cap = 0, desc_cap = 0;
         std::mutex mu;
     };
@@ -2451,6 +2458,7 @@ extern "C" void spx_inflater_free(spx_inflater *inf)
         if (k.d_out) (void)hipFree(k.d_out);
         if (k.d_desc) (void)hipFree(k.d_desc);
         if (k.d_status) (void)hipFree(k.d_status);
+        if (k.d_scratch) (void)hipFree(k.d_scratch);
     }
     if (inf->st_h2d) { (void)hipStreamSynchronize(inf->st_h2d); (void)hipStreamDestroy(inf->st_h2d); }
     if (inf->st_d2h) { (void)hipStreamSynchronize(inf->st_d2h); (void)hipStreamDestroy(inf->st_d2h); }
@@ -2498,12 +2506,14 @@ extern "C" int spx_inflater_run(void *user, int32_t worker, const uint8_t *file,
         if (W.d_desc) (void)hipFree(W.d_desc);
         if (W.h_status) (void)hipHostFree(W.h_status);
         if (W.d_status) (void)hipFree(W.d_status);
-        W.h_desc = nullptr; W.d_desc = nullptr; W.h_status = nullptr; W.d_status = nullptr;
+        if (W.d_scratch) (void)hipFree(W.d_scratch);
+        W.h_desc = nullptr; W.d_desc = nullptr; W.h_status = nullptr; W.d_status = nullptr; W.d_scratch = nullptr;
         W.desc_cap = (size_t)n_blocks + 1024;
         WCHK(hipHostMalloc((void **)&W.h_desc, W.desc_cap * sizeof(SpxBgzfDesc), hipHostMallocDefault));
         WCHK(hipMalloc((void **)&W.d_desc, W.desc_cap * sizeof(SpxBgzfDesc)));
         WCHK(hipHostMalloc((void **)&W.h_status, W.desc_cap * 4, hipHostMallocDefault));
         WCHK(hipMalloc((void **)&W.d_status, W.desc_cap * 4));
+        WCHK(hipMalloc(&W.d_scratch, spx_bgzf_inflate_scratch_bytes((int32_t)W.desc_cap) + 64));
     }
     memcpy(W.h_in, file + lo, in_bytes);
     memset(W.h_in + in_bytes, 0, 64);
@@ -2520,7 +2530,7 @@ extern "C" int spx_inflater_run(void *user, int32_t worker, const uint8_t *file,
         WCHK(hipEventRecord(W.ev_in, inf->st_h2d));
     }
     WCHK(hipStreamWaitEvent(W.st, W.ev_in, 0));
-    WCHK(spx_launch_bgzf_inflate(W.d_in, W.d_desc, n_blocks, W.d_out, W.d_status, check_crc, W.st));
+    WCHK(spx_launch_bgzf_inflate2(W.d_in, W.d_desc, n_blocks, W.d_out, W.d_status, check_crc, W.d_scratch, W.st));
     WCHK(hipEventRecord(W.ev_k, W.st));
     /* the HOST waits for the kernel (asleep): a copy stream that waits for a kernel's event is served by the copy kernel
      * from then on, like one that has run a kernel itself */

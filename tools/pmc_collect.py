@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "pmc_tmp"))
     ap.add_argument("--extra", nargs="*", default=[], help="more arguments for bench.py")
     ap.add_argument("--full", action="store_true", help="the whole pipelined step (preparation kernels included) instead of --kernel-only")
+    ap.add_argument("--more", action="store_true", help="extra passes: instruction-cache, LDS and scalar activity counters (a pass whose counter this chip lacks is listed under failed_passes)")
     ap.add_argument("--inflate", action="store_true", help="profile tools/inflate_bench.py (the BGZF inflate kernel alone on a synthetic BAM's blocks) instead of bench.py")
     a = ap.parse_args()
     os.environ.setdefault("TMPDIR", "/tmp")
@@ -51,7 +52,12 @@ def main():
     if a.inflate:
         bench = ["python3", os.path.join(ROOT, "tools", "inflate_bench.py"), "--groups", str(a.groups_per_step or 16384), "--platform", a.platform,
                  "--repeat", str(a.steps)] + a.extra
-    for k, ctrs in enumerate(PASSES):
+    passes = list(PASSES)
+    if a.more:
+        passes += [["SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS"], ["SQ_INST_CYCLES_SALU", "SQ_THREAD_CYCLES_VALU", "SQ_IFETCH"],
+                   ["SQC_ICACHE_REQ", "SQC_ICACHE_MISSES", "SQC_ICACHE_HITS"], ["SQ_INST_LEVEL_LDS", "SQ_INST_LEVEL_VMEM", "SQ_LEVEL_WAVES"]]
+        meta["passes"] = passes
+    for k, ctrs in enumerate(passes):
         d = os.path.join(a.scratch, f"pass{k}")
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d, exist_ok=True)
