@@ -11,9 +11,7 @@
  * copies, flushing literals, CRC32.
  *
  * The decoder is parameterised by an environment E that provides
- *     E::in32(k)              compressed dword k of the block (little endian; reads past the end return 0) -- in two halves: in32()
- *                             may return a raw word and E::in32_fix(raw, k) completes it when the reader consumes it, one refill
- *                             later (so that a device load has nothing depending on it while it is in flight)
+ *     E::in32(k)              compressed dword k of the block (little endian; reads past the end return 0)
  *     E::put_literal(b)       one output byte (checked)
  *     E::lit_full(), E::lit_push(b), E::lit_commit()   the same in three steps for the literal loop: no room for another
  *                             literal right now / append one (unchecked) / make room (false: the output is full)
@@ -28,7 +26,6 @@
 #define SPX_INFLATE_H
 
 #include <stdint.h>
-#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -49,25 +46,6 @@ namespace spxz {
  * distance base / extra bits are computed from the symbol (len_base ..): the rarer path pays, the table stays small */
 SPXZ_HD uint16_t mk_entry(int nbits, int sym) { return (uint16_t)((unsigned)sym | ((unsigned)nbits << 9)); }
 constexpr uint16_t kNoEntry = 0x100; /* "not a literal", length 0: the literal loop needs ONE bit test */
-
-/* PACKED entries (environments with their own symbol loop): what a match needs without another computation.
- *   literal/length table: a literal as above; otherwise bit 8 set, bits 0-7 = length base - 3, bits 9-12 code length, bits 13-15 number of
- *     extra bits (0..5; 7 = the end-of-block code)
- *   distance table: bits 0-1 = h, bits 2-5 = number of extra bits x, bits 9-12 code length: distance base = 1 + (h << x)  (h = the symbol
- *     for symbols 0, 1; 2 + (symbol & 1) beyond) */
-SPXZ_HD int len_base(int sym);
-SPXZ_HD int len_extra(int sym);
-SPXZ_HD int dist_extra(int sym);
-SPXZ_HD uint16_t mk_len_entry(int nbits, int sym) /* sym 256..285 */
-{
-    if (sym == 256) return (uint16_t)(0x100u | ((unsigned)nbits << 9) | (7u << 13));
-    return (uint16_t)((unsigned)(len_base(sym) - 3) | 0x100u | ((unsigned)nbits << 9) | ((unsigned)len_extra(sym) << 13));
-}
-SPXZ_HD uint16_t mk_dist_entry(int nbits, int sym) /* sym 0..29 */
-{
-    const unsigned h = sym < 2 ? (unsigned)sym : 2u + ((unsigned)sym & 1u);
-    return (uint16_t)(h | ((unsigned)dist_extra(sym) << 2) | ((unsigned)nbits << 9));
-}
 
 template <int LR, int DR>
 struct TablesT {
@@ -124,7 +102,7 @@ struct Bits {
     SPXZ_HD void refill()
     {
         if (cnt <= 32) {
-            buf |= (uint64_t)env.in32_fix(pre, next) << cnt;
+            buf |= (uint64_t)pre << cnt;
             ++next;
             cnt += 32;
             pre = env.in32(next);
@@ -200,7 +178,7 @@ SPXZ_HD int canon_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *s
 /* root-table fill for the coded symbols number i = first_i, first_i + stride, ... in (length, symbol) order: the canonical
  * code of sorted[i] is first[len] + (i - offs[len]); every code of length <= root is replicated over the high index bits;
  * longer codes leave their (shared) root slots at "walk" */
-template <bool LIT, bool PACKED = false>
+template <bool LIT>
 SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint16_t *sorted, const uint16_t *first, const uint16_t *offs, int used,
                        int first_i, int stride)
 {
@@ -209,19 +187,11 @@ SPXZ_HD void fill_root(uint16_t *tab, int root, const uint8_t *lens, const uint1
         const int l = lens[s];
         if (l > root) continue;
         if (LIT ? s > 285 : s > 29) continue; /* 286, 287 / 30, 31: never valid (their slots stay "walk" -> the walk rejects them) */
-        const uint16_t e = !PACKED ? mk_entry(l, s) : !LIT ? mk_dist_entry(l, s) : s < 256 ? mk_entry(l, s) : mk_len_entry(l, s);
+        const uint16_t e = mk_entry(l, s);
         const uint32_t r = rev_bits((uint32_t)first[l] + (uint32_t)(i - offs[l]), l);
         for (uint32_t k = r; k < (1u << root); k += (1u << l)) tab[k] = e;
     }
 }
-
-/* an environment may bring its own symbol loop (E::kOwnLoop, int E::symbol_loop(Bits<E> &): 0 at the end-of-block code, < 0 = error): the
- * device's decode kernel does, hand-scheduled around its own bit reader; everything else of a stream (block headers, stored blocks,
- * table set-up) stays here */
-template <class E, class = void>
-struct own_loop : std::false_type {};
-template <class E>
-struct own_loop<E, std::void_t<decltype(E::kOwnLoop)>> : std::bool_constant<E::kOwnLoop> {};
 
 template <class E>
 SPXZ_HD int build_tables(E &env, int nlit, int ndist)
@@ -235,13 +205,13 @@ SPXZ_HD int build_tables(E &env, int nlit, int ndist)
     if (lane == 0) rc = canon_build(T.lens, nlit, T.lit_count, T.lit_sorted, T.first, T.offs);
     env.sync();
     rc = env.uniform(rc);
-    if (rc == 0) fill_root<true, own_loop<E>::value>(T.lit, E::kLit, T.lens, T.lit_sorted, T.first, T.offs, nlit - (int)T.lit_count[0], lane, lanes);
+    if (rc == 0) fill_root<true>(T.lit, E::kLit, T.lens, T.lit_sorted, T.first, T.offs, nlit - (int)T.lit_count[0], lane, lanes);
     env.sync();
     int rc2 = 0;
     if (lane == 0 && rc == 0) rc2 = canon_build(T.lens + nlit, ndist, T.dist_count, T.dist_sorted, T.first, T.offs);
     env.sync();
     rc2 = env.uniform(rc2);
-    if (rc == 0 && rc2 == 0) fill_root<false, own_loop<E>::value>(T.dist, E::kDist, T.lens + nlit, T.dist_sorted, T.first, T.offs, ndist - (int)T.dist_count[0], lane, lanes);
+    if (rc == 0 && rc2 == 0) fill_root<false>(T.dist, E::kDist, T.lens + nlit, T.dist_sorted, T.first, T.offs, ndist - (int)T.dist_count[0], lane, lanes);
     env.sync();
     return (rc | rc2) ? -1 : 0;
 }
@@ -321,37 +291,21 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
             if (build_tables(env, nlit, ndist) != 0) return -1;
             /* ---- the symbol loop: a tight inner loop over runs of literals (one table look-up, one v_writelane each on
              * the device), everything else outside it ---- */
-            if constexpr (own_loop<E>::value) {
-                const int r = env.symbol_loop(b);
-                if (r != 0) return r;
-            } else
             for (;;) {
                 uint32_t e;
-                if constexpr (E::kFlat) {
-                    /* one symbol per trip, whatever it is: several blocks share a wavefront (one lane group each) and a lane group
-                     * that has a match to copy must not wait until the others have exhausted their runs of literals */
+                for (;;) {
                     b.refill();
                     e = env.uniform_u32(T.lit[b.peek(E::kLit)]);
-                    if (!(e & 0x100u)) {
-                        b.drop((int)(e >> 9));
-                        if (!env.put_literal((uint8_t)e)) return -2;
-                        continue;
-                    }
-                } else {
-                    for (;;) {
-                        b.refill();
-                        e = env.uniform_u32(T.lit[b.peek(E::kLit)]);
-                        /* a length / end-of-block code, or no root code at all -- or no room for one more literal (the device
-                         * keeps up to 64 in a register; committing them, flushing and the overrun check stay OUT of this loop:
-                         * inlined into it they cost a dozen scalar moves per literal) */
-                        if ((e & 0x100u) || env.lit_full()) break;
-                        b.drop((int)(e >> 9));
-                        env.lit_push((uint8_t)e);
-                    }
-                    if (!(e & 0x100u)) {
-                        if (!env.lit_commit()) return -2; /* false: more bytes than the block may hold */
-                        continue;
-                    }
+                    /* a length / end-of-block code, or no root code at all -- or no room for one more literal (the device
+                     * keeps up to 64 in a register; committing them, flushing and the overrun check stay OUT of this loop:
+                     * inlined into it they cost a dozen scalar moves per literal) */
+                    if ((e & 0x100u) || env.lit_full()) break;
+                    b.drop((int)(e >> 9));
+                    env.lit_push((uint8_t)e);
+                }
+                if (!(e & 0x100u)) {
+                    if (!env.lit_commit()) return -2; /* false: more bytes than the block may hold */
+                    continue;
                 }
                 int sym;
                 if (e != kNoEntry) {
@@ -369,8 +323,7 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                     }
                 }
                 if (sym == 256) break;
-                /* (refill() leaves >= 33 bits: a literal/length code of <= 15 bits and its <= 5 extra bits come out of one fill, a
-                 * distance code of <= 15 bits and its <= 13 extra bits out of the next) */
+                b.refill();
                 const int len = len_base(sym) + (int)b.take(len_extra(sym));
                 b.refill();
                 const uint32_t d = env.uniform_u32(T.dist[b.peek(E::kDist)]);
@@ -385,6 +338,7 @@ SPXZ_HD int inflate_stream(E &env, int64_t in_bits_limit, uint32_t out_limit)
                     dsym = (int)(r & 0xffff);
                     if (dsym > 29) return -1;
                 }
+                b.refill();
                 const int dist = dist_base(dsym) + (int)b.take(dist_extra(dsym));
                 if ((uint32_t)dist > env.out_pos()) return -1;
                 if (env.out_pos() + (uint32_t)len > out_limit) return -2;
@@ -434,10 +388,9 @@ SPXZ_HD uint32_t gf2_xpow8n(uint64_t n_bytes)
 SPXZ_HD uint32_t crc_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) { return gf2_mul(gf2_xpow8n(len_b), crc_a) ^ crc_b; }
 
 /* ---- host environment: plain buffers ---- */
-template <int LR, int DR, bool FLAT = false>
+template <int LR, int DR>
 struct HostEnvT {
     static constexpr int kLit = LR, kDist = DR;
-    static constexpr bool kFlat = FLAT; /* the symbol loop's shape (see inflate_stream); the CPU tests run both */
     const uint8_t *in;
     size_t in_len;
     uint8_t *out;
@@ -452,7 +405,6 @@ struct HostEnvT {
         }
         return v;
     }
-    uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
     uint32_t cap = 0xffffffffu; /* bytes out[] can take */
     bool put_literal(uint8_t c) { if (pos >= cap) return false; out[pos++] = c; return true; }
     bool lit_full() const { return pos >= cap; }

@@ -10,10 +10,10 @@
 #include "../../include/spx.h"
 #include "spx_inflate.h"
 
-template <int LR, int DR, bool FLAT = false>
+template <int LR, int DR>
 static int run_core(const uint8_t *in, int64_t in_len, uint8_t *out, int64_t out_len)
 {
-    spxz::HostEnvT<LR, DR, FLAT> env;
+    spxz::HostEnvT<LR, DR> env;
     env.in = in;
     env.in_len = (size_t)in_len;
     env.out = out;
@@ -27,9 +27,6 @@ extern "C" int spx_inflate_core_host(const uint8_t *in, int64_t in_len, uint8_t 
     /* the root-table sizes the device kernels are built with: SPX_INFLATE_ROOT = 9 (9 / 8 bits, round 4), 10 (10 / 8), 11 (11 / 9, round 3) */
     const char *e = getenv("SPX_INFLATE_ROOT");
     const int root = e ? atoi(e) : 9;
-    /* SPX_INFLATE_FLAT=0: the symbol loop with the inner literal loop (the one-block-per-wave kernel's), default: one symbol per trip */
-    const char *f = getenv("SPX_INFLATE_FLAT");
-    if (root == 9 && !(f && atoi(f) == 0)) return run_core<9, 8, true>(in, in_len, out, out_len);
     if (root == 11) return run_core<11, 9>(in, in_len, out, out_len);
     if (root == 10) return run_core<10, 8>(in, in_len, out, out_len);
     return run_core<9, 8>(in, in_len, out, out_len);

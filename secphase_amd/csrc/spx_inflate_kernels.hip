@@ -49,7 +49,6 @@ __device__ __forceinline__ int writelane(int v, int c, int n)
 template <int LR, int DR>
 struct DevEnv {
     static constexpr int kLit = LR, kDist = DR;
-    static constexpr bool kFlat = false;
     using Tab = spxz::TablesT<LR, DR>;
     const uint32_t *in_al;
     uint32_t in_shift; /* bits: 0, 8, 16, 24 */
@@ -69,7 +68,6 @@ struct DevEnv {
         const uint32_t lo = k < n_dw ? in_al[k] : 0u, hi = k + 1 < n_dw ? in_al[k + 1] : 0u;
         return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
     }
-    __device__ __forceinline__ uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
     __device__ __forceinline__ Tab &tables() { return *T; }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ int lane() const { return lane_; }
@@ -225,7 +223,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t *__restr
 template <int G, int LR, int DR, int R>
 struct GrpEnv {
     static constexpr int kLit = LR, kDist = DR;
-    static constexpr bool kFlat = false;
     /* near matches (distance <= R / 2) are served from the ring; a far match must find its source flushed: R / 2 - 258 >= kFlushG + 3 */
     static constexpr int kRingG = R, kFlushG = (R / 4 < R / 2 - 264) ? R / 4 : R / 2 - 264;
     using Tab = spxz::TablesT<LR, DR>;
@@ -242,7 +239,6 @@ struct GrpEnv {
         const uint32_t lo = k < n_dw ? in_al[k] : 0u, hi = k + 1 < n_dw ? in_al[k + 1] : 0u;
         return in_shift ? (lo >> in_shift) | (hi << (32 - in_shift)) : lo;
     }
-    __device__ __forceinline__ uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
     __device__ __forceinline__ Tab &tables() { return *T; }
     /* the lanes of a block run in lockstep inside one wave and LDS operations of a wave complete in order: a "barrier" only
      * has to keep the compiler from moving LDS accesses across it */
@@ -383,181 +379,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 }
 
 
-/* ---------------------------------------------------------------------------------------------------------------------
- * Round 4, second step: MORE BLOCKS PER WAVEFRONT, ONE SYMBOL PER TRIP.  What the counters of the kernel above say
- * (profiles/r04_counters_inflate.json): vector ALU and scalar unit are each ~half busy, a wavefront issues one instruction every
- * ~18 cycles -- a latency chain (LDS look-ups, and a trip to the L2 for every match that lies further back than the ring: in BAM
- * payload 79 % of the matches do, most of them 3-4 bytes long), paid per SYMBOL and shared by only two blocks.  Here
- *   - G = 8 (or 4 / 16) lanes per block, so that one instruction stream advances 8 blocks;
- *   - the symbol loop is flat (E::kFlat in spx_inflate.h): one symbol per trip whatever its kind, the hardware's execution mask
- *     runs the literal path and the match path of a trip one after the other -- a block with a match does not wait for the
- *     others' literal runs to end;
- *   - a short far match is DEFERRED: the load from the L2 is issued, the block goes on decoding, the bytes reach the ring when
- *     the next match, the next flush or the end of the block needs them (literals never read the ring);
- *   - the CRC-32 moved into its own kernel (bgzf_crc_kernel below): 64 lanes per block with coalesced reads instead of G serial
- *     stripes at the tail of every block's decode.
- * Decoder core: the same spx_inflate.h. */
-template <int G, int LR, int DR, int R, bool FLAT = true, int DRY = 0> /* DRY (timing experiments only, wrong output): 1 = far matches load nothing, 2 = and nothing is flushed */
-struct FlatEnv {
-    static constexpr int kLit = LR, kDist = DR;
-    static constexpr bool kFlat = FLAT;
-    static constexpr int kRingG = R, kFlushG = (R / 4 < R / 2 - 264) ? R / 4 : R / 2 - 264;
-    using Tab = spxz::TablesT<LR, DR>;
-    const uint8_t *in;       /* the block's DEFLATE bytes (any alignment: gfx9 global memory takes unaligned dwords) */
-    uint32_t clen;
-    uint8_t *out;
-    uint32_t limit, pos, flushed;
-    uint32_t pend_n, pend_at; /* a deferred far match: byte k of it (k < pend_n <= G) arrives in lane k's pend_v and belongs at ring[pend_at + k] */
-    uint32_t pend_v;
-    Tab *T;
-    uint8_t *ring;
-    int lane_;
-
-    /* one unconditional load per refill, completed (the zeros beyond the block's end) when the reader consumes the word: nothing
-     * depends on the load while it is in flight.  The clamped address reads at most the 4 bytes after the DEFLATE data: a BGZF
-     * block ends in CRC32 + ISIZE, so they belong to the block */
-    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-    __device__ __forceinline__ uint32_t in32(uint32_t k) const
-    {
-        const uint32_t o = 4u * k < clen ? 4u * k : clen;
-        return *reinterpret_cast<const u32_unaligned *>(in + o);
-    }
-    __device__ __forceinline__ uint32_t in32_fix(uint32_t raw, uint32_t k) const
-    {
-        const uint32_t o = 4u * k, left = clen > o ? clen - o : 0u;
-        return left >= 4u ? raw : (raw & ((1u << (8u * left)) - 1u));
-    }
-    __device__ __forceinline__ Tab &tables() { return *T; }
-    __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    __device__ __forceinline__ int lane() const { return lane_; }
-    __device__ __forceinline__ int lanes() const { return G; }
-    __device__ __forceinline__ int uniform(int v) const { return __shfl(v, 0, G); }
-    __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return v; }
-    __device__ __forceinline__ uint32_t out_pos() const { return pos; }
-
-    __device__ __forceinline__ void retire()
-    {
-        if (pend_n) {
-            if ((uint32_t)lane_ < pend_n) ring[(pend_at + (uint32_t)lane_) & (kRingG - 1)] = (uint8_t)pend_v;
-            pend_n = 0;
-        }
-    }
-    __device__ __forceinline__ void flush(bool last)
-    {
-        retire();
-        sync();
-        if (DRY >= 2) { flushed = pos & ~3u; return; }
-        const uint32_t end = pos < limit ? pos : limit;
-        const uint32_t e4 = last ? end : (end & ~3u);
-        if (e4 > flushed) {
-            for (uint32_t base = flushed; base + 4 <= e4; base += 4u * G) {
-                const uint32_t i = base + 4u * (uint32_t)lane_;
-                if (i + 4 <= e4) {
-                    const uint32_t v = *reinterpret_cast<const uint32_t *>(ring + (i & (kRingG - 1)));
-                    __builtin_memcpy(out + i, &v, 4);
-                }
-            }
-            const uint32_t tail = flushed + ((e4 - flushed) & ~3u);
-            if (tail + (uint32_t)lane_ < e4) out[tail + lane_] = ring[(tail + lane_) & (kRingG - 1)];
-            flushed = last ? e4 : (pos < limit ? e4 : pos & ~3u);
-        } else if (pos > limit)
-            flushed = pos & ~3u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    }
-    __device__ __forceinline__ bool lit_full() const { return pos - flushed >= (uint32_t)kFlushG; }
-    __device__ __forceinline__ void lit_push(uint8_t c)
-    {
-        if (lane_ == 0) ring[pos & (kRingG - 1)] = c;
-        ++pos;
-    }
-    __device__ __forceinline__ bool lit_commit()
-    {
-        flush(false);
-        return pos <= limit;
-    }
-    __device__ __forceinline__ bool put_literal(uint8_t c)
-    {
-        if (lit_full() && !lit_commit()) return false;
-        lit_push(c);
-        return true;
-    }
-    __device__ __forceinline__ void copy_match(int len, int dist)
-    {
-        retire();
-        const uint32_t src0 = pos - (uint32_t)dist;
-        if (dist <= kRingG / 2) {
-            if (dist >= len) {
-                for (int base = 0; base < len; base += G) {
-                    const int i = base + lane_;
-                    if (i < len) ring[(pos + (uint32_t)i) & (kRingG - 1)] = ring[(src0 + (uint32_t)i) & (kRingG - 1)];
-                }
-            } else {
-                for (int base = 0; base < len; base += G) {
-                    const int i = base + lane_;
-                    if (i < len) ring[(pos + (uint32_t)i) & (kRingG - 1)] = ring[(src0 + (uint32_t)(i % dist)) & (kRingG - 1)];
-                }
-            }
-        } else if (DRY >= 1) {
-        } else if (len <= G) {
-            /* far and short: the source lies below `flushed` (kFlushG + 4 + 258 <= kRingG / 2); the load goes past the vector L1 */
-            if (lane_ < len) pend_v = __hip_atomic_load(out + src0 + (uint32_t)lane_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pend_at = pos;
-            pend_n = (uint32_t)len;
-        } else {
-            /* far and long (a secondary alignment repeating the primary's SEQ / QUAL): 16 bytes per lane and round, the four loads
-             * of a round in flight together.  (A lane may read up to 3 bytes beyond the match: they lie below pos - dist + 261 < pos.) */
-            for (int base = 0; base < len; base += 16 * G) {
-                const int i = base + 16 * lane_;
-                if (i < len) {
-                    uint32_t v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] = i + 4 * q < len ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(out + src0 + (uint32_t)(i + 4 * q)), __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_AGENT)
-                                               : 0u;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (i + q < len) ring[(pos + (uint32_t)(i + q)) & (kRingG - 1)] = (uint8_t)(v[q >> 2] >> (8 * (q & 3)));
-                }
-            }
-        }
-        pos += (uint32_t)len;
-        if (pos - flushed >= (uint32_t)kFlushG) flush(false);
-    }
-};
-
-template <int G, int LR, int DR, int R, int WPE, bool FLAT = true, int DRY = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void bgzf_inflate_flat_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
-                                                               uint8_t *__restrict__ outbuf, int32_t *__restrict__ status)
-{
-    constexpr int NB = 64 / G;
-    __shared__ spxz::TablesT<LR, DR> T[NB];
-    __shared__ __attribute__((aligned(16))) uint8_t ring[NB][R];
-    const int q = (int)threadIdx.x / G, lane = (int)threadIdx.x % G;
-    const int b = (int)blockIdx.x * NB + q;
-    if (b >= n_blocks) return;
-    const BlockDesc d = blocks[b];
-    FlatEnv<G, LR, DR, R, FLAT, DRY> env;
-    env.in = comp + d.in_off;
-    env.clen = d.clen;
-    env.out = outbuf + d.out_off;
-    env.limit = d.ulen;
-    env.pos = 0;
-    env.flushed = 0;
-    env.pend_n = 0;
-    env.pend_at = 0;
-    env.pend_v = 0;
-    env.T = &T[q];
-    env.ring = ring[q];
-    env.lane_ = lane;
-    int rc = 0;
-    if (d.ulen > 0) {
-        rc = spxz::inflate_stream(env, (int64_t)d.clen * 8, d.ulen);
-        env.flush(true);
-    }
-    if (lane == 0) status[b] = rc;
-}
-
 /* CRC-32 of every inflated block against the BGZF trailer's: one wavefront per block, 64 stripes (byte-table recurrence per lane, 16
  * bytes per load), folded with the GF(2) shift operator; status[b] 0 -> -4 on a mismatch */
 __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restrict__ blocks, int32_t n_blocks, const uint8_t *__restrict__ outbuf,
@@ -613,11 +434,11 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restri
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
- * Round 4, third step: DECODE AND COPY IN TWO KERNELS.  In BAM payload one symbol in eight is a match, 95 % of the matches are
- * 3-4 bytes long and four out of five lie further back than a ring in LDS can reach (tools/deflate_stats): every one of them
+ * Round 4, second step: DECODE AND COPY IN TWO KERNELS.  In BAM payload one symbol in eight is a match, 95 % of the matches are
+ * 3-4 bytes long and four out of five lie further back than a ring in LDS can reach (tools/deflate_stats.cpp): every one of them
  * was a trip to the L2 -- or, with 10 000 blocks x 32 KB of window in flight, to HBM -- in the middle of a chain that is
  * sequential by nature.  The Huffman decoder does not need the bytes a match copies, only its length:
- *   kernel 1 (bgzf_decode_kernel) decodes the symbols of a block and writes every LITERAL at its final position of the output
+ *   kernel 1 (bgzf_decode2_kernel) decodes the symbols of a block and writes every LITERAL at its final position of the output
  *     (it knows the position: literals count 1, matches their length).  A match leaves a hole of >= 3 bytes: the hole's first
  *     three bytes take the match itself (distance - 1 in 16 bits, length - 3 in 8), and a bitmap (1 bit per output byte, 8 KB
  *     per block) marks where holes start.  No window, no ring, no flush: LDS holds the decode tables and 256 bytes of staged
@@ -630,245 +451,9 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restri
  */
 constexpr int kBitmapWords = 2048; /* per block: 65536 positions / 32 */
 
-template <int G, int LR, int DR>
-struct TokEnv {
-    static constexpr int kLit = LR, kDist = DR;
-    static constexpr bool kFlat = true, kOwnLoop = true;
-    static constexpr int kNW = 32 / G > 0 ? 32 / G : 1; /* dwords of a 128-byte input chunk per lane */
-    using Tab = spxz::TablesT<LR, DR>;
-    const uint8_t *in;
-    uint32_t clen;
-    uint8_t *out;
-    uint32_t *bm;        /* the block's bitmap (zeroed before the launch) */
-    uint32_t limit, pos;
-    uint32_t bm_word, bm_idx; /* bits of output positions [32 * bm_idx, 32 * bm_idx + 32) gathered so far */
-    uint32_t staged;     /* the input chunk that waits in stage_v for its turn in LDS; chunks staged - 2, staged - 1 are in ibuf */
-    uint32_t stage_v[kNW];
-    Tab *T;
-    uint32_t *ibuf;      /* 64 dwords: two input chunks of 128 bytes */
-    int lane_;
-
-    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-    typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
-    /* (nothing may depend on the loaded words before store_chunk: the zeros beyond the block's end are put in there) */
-    __device__ __forceinline__ void load_chunk(uint32_t c)
-    {
-#pragma unroll
-        for (int j = 0; j < kNW; ++j) {
-            const uint32_t o = 128u * c + 4u * (uint32_t)(lane_ * kNW + j);
-            const uint32_t oc = o < clen ? o : clen; /* (reads at most the 4 bytes behind the data: CRC32 of the BGZF trailer) */
-            stage_v[j] = *reinterpret_cast<const u32_unaligned *>(in + oc);
-        }
-    }
-    __device__ __forceinline__ void store_chunk(uint32_t c)
-    {
-#pragma unroll
-        for (int j = 0; j < kNW; ++j) {
-            const uint32_t o = 128u * c + 4u * (uint32_t)(lane_ * kNW + j);
-            const uint32_t left = clen > o ? clen - o : 0u;
-            const uint32_t v = left >= 4u ? stage_v[j] : (stage_v[j] & ((1u << (8u * left)) - 1u));
-            ibuf[(c & 1u) * 32u + (uint32_t)(lane_ * kNW + j)] = v;
-        }
-    }
-    __device__ __forceinline__ void start()
-    {
-        static_assert(G * kNW * 4 == 128, "a chunk is 128 bytes");
-        load_chunk(0);
-        store_chunk(0);
-        load_chunk(1);
-        staged = 1;
-        sync();
-    }
-    /* dword k of the input is wanted next (k never decreases by more than a chunk): bring its chunk into LDS */
-    __device__ __forceinline__ void want(uint32_t k)
-    {
-        if ((k >> 5) >= staged) {
-            store_chunk(staged);
-            ++staged;
-            load_chunk(staged);
-            sync();
-        }
-    }
-    __device__ __forceinline__ uint32_t in32(uint32_t k)
-    {
-        want(k);
-        return ibuf[k & 63u];
-    }
-    __device__ __forceinline__ uint32_t in32_fix(uint32_t v, uint32_t) const { return v; }
-    __device__ __forceinline__ Tab &tables() { return *T; }
-    __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-    __device__ __forceinline__ int lane() const { return lane_; }
-    __device__ __forceinline__ int lanes() const { return G; }
-    __device__ __forceinline__ int uniform(int v) const { return __shfl(v, 0, G); }
-    __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) const { return v; }
-    __device__ __forceinline__ uint32_t out_pos() const { return pos; }
-
-    /* outside the symbol loop (stored blocks): a literal beyond the block's size is counted, not written; the stream's final check
-     * (out_pos() == ISIZE) reports it */
-    __device__ __forceinline__ bool put_literal(uint8_t c)
-    {
-        if (pos >= limit) return false;
-        if (lane_ == 0) out[pos] = c;
-        ++pos;
-        return true;
-    }
-    __device__ __forceinline__ bool lit_full() const { return pos >= limit; }
-    __device__ __forceinline__ void lit_push(uint8_t c) { (void)put_literal(c); }
-    __device__ __forceinline__ bool lit_commit() const { return pos < limit; }
-    /* a match = a hole of `len` bytes: (distance - 1, length - 3) go into its first three bytes, its start into the bitmap.  (The
-     * caller has checked dist <= pos and pos + len <= limit.) */
-    __device__ __forceinline__ void copy_match(int len, int dist)
-    {
-        const uint32_t w = pos >> 5;
-        if (w != bm_idx) {
-            if (lane_ == 0 && bm_word) bm[bm_idx] = bm_word;
-            bm_word = 0;
-            bm_idx = w;
-        }
-        bm_word |= 1u << (pos & 31u);
-        if (lane_ == 0) {
-            *reinterpret_cast<u16_unaligned *>(out + pos) = (uint16_t)(dist - 1);
-            out[pos + 2] = (uint8_t)(len - 3);
-        }
-        pos += (uint32_t)len;
-    }
-    __device__ __forceinline__ void finish()
-    {
-        if (lane_ == 0 && bm_word) bm[bm_idx] = bm_word;
-    }
-
-    /* ---- the symbol loop of one DEFLATE block.  Its own bit reader: the two input dwords around the read position in registers
-     * (w0 = dword k, w1 = dword k + 1), the position inside w0 in `off`: v_alignbit_b32 gives the next 32 bits in one instruction,
-     * consuming is an add, and every fourth symbol or so moves on by one dword (one LDS read).  The tables are PACKED (spx_inflate.h):
-     * a length's base and extra bits come out of the entry.  A literal costs a look-up, one byte store and a dozen VALU instructions;
-     * nothing in here waits for global memory (want() does, once per 128 input bytes). ---- */
-    __device__ __forceinline__ int symbol_loop(spxz::Bits<TokEnv> &b)
-    {
-        const uint32_t P = b.next * 32u - (uint32_t)b.cnt; /* bits consumed so far */
-        uint32_t k = P >> 5, off = P & 31u;
-        want(k + 1u);
-        uint32_t w0 = ibuf[k & 63u], w1 = ibuf[(k + 1u) & 63u];
-        const uint32_t k_end = ((clen + 3u) >> 2) + 1u; /* the reader may look at (zero) bits beyond the data, not consume them */
-        const uint16_t *lit = T->lit, *dis = T->dist;
-        int rc = 1;
-        for (;;) {
-            if (off >= 32u) { /* move on by one dword */
-                off -= 32u;
-                ++k;
-                w0 = w1;
-                if (k > k_end) { rc = -3; break; }
-                want(k + 1u);
-                w1 = ibuf[(k + 1u) & 63u];
-            }
-            uint32_t bits = __builtin_amdgcn_alignbit(w1, w0, off);
-            uint32_t e = lit[bits & ((1u << LR) - 1u)];
-            if (!(e & 0x100u)) {
-                /* a literal (beyond the block's size: counted, not written; the stream's final check reports it) */
-                if (lane_ == 0 && pos < limit) out[pos] = (uint8_t)e;
-                ++pos;
-                off += e >> 9;
-                continue;
-            }
-            if (e == spxz::kNoEntry) { /* a code longer than the root table */
-                const uint32_t r = spxz::decode_slow_bits(bits, T->lit_count, T->lit_sorted, 15);
-                if (r == 0xffffffffu) { rc = -1; break; }
-                const uint32_t sym = r & 0xffffu;
-                if (sym > 285u) { rc = -1; break; }
-                if (sym < 256u) {
-                    if (lane_ == 0 && pos < limit) out[pos] = (uint8_t)sym;
-                    ++pos;
-                    off += r >> 16;
-                    continue;
-                }
-                e = spxz::mk_len_entry((int)(r >> 16), (int)sym);
-            }
-            uint32_t n = (e >> 9) & 15u, x = e >> 13;
-            if (x == 7u) { /* end of block */
-                off += n;
-                rc = 0;
-                break;
-            }
-            const uint32_t len = (e & 0xffu) + 3u + ((bits >> n) & ((1u << x) - 1u));
-            off += n + x;
-            if (off >= 32u) {
-                off -= 32u;
-                ++k;
-                w0 = w1;
-                if (k > k_end) { rc = -3; break; }
-                want(k + 1u);
-                w1 = ibuf[(k + 1u) & 63u];
-            }
-            bits = __builtin_amdgcn_alignbit(w1, w0, off);
-            uint32_t de = dis[bits & ((1u << DR) - 1u)];
-            if (de == spxz::kNoEntry) {
-                const uint32_t r = spxz::decode_slow_bits(bits, T->dist_count, T->dist_sorted, 15);
-                if (r == 0xffffffffu) { rc = -1; break; }
-                if ((r & 0xffffu) > 29u) { rc = -1; break; }
-                de = spxz::mk_dist_entry((int)(r >> 16), (int)(r & 0xffffu));
-            }
-            n = de >> 9;
-            x = (de >> 2) & 15u;
-            const uint32_t dist = 1u + ((de & 3u) << x) + ((bits >> n) & ((1u << x) - 1u));
-            off += n + x;
-            if (dist > pos) { rc = -1; break; }
-            if (pos + len > limit) { rc = -2; break; }
-            copy_match((int)len, (int)dist);
-        }
-        /* hand the position back to the stream's reader */
-        if (rc == 0) {
-            if (off >= 32u) {
-                off -= 32u;
-                ++k;
-                w0 = w1;
-                if (k > k_end) return -3;
-                want(k + 1u);
-                w1 = ibuf[(k + 1u) & 63u];
-            }
-            b.buf = (uint64_t)(w0 >> off);
-            b.cnt = 32 - (int)off;
-            b.next = k + 1u;
-            b.pre = w1;
-        }
-        return rc;
-    }
-};
-
-template <int G, int LR, int DR, int WPE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void bgzf_decode_kernel(const uint8_t *__restrict__ comp, const BlockDesc *__restrict__ blocks, int32_t n_blocks,
-                                                           uint8_t *__restrict__ outbuf, uint32_t *__restrict__ bitmap, int32_t *__restrict__ status)
-{
-    constexpr int NB = 64 / G;
-    __shared__ spxz::TablesT<LR, DR> T[NB];
-    __shared__ uint32_t ibuf[NB][64];
-    const int q = (int)threadIdx.x / G, lane = (int)threadIdx.x % G;
-    const int b = (int)blockIdx.x * NB + q;
-    if (b >= n_blocks) return;
-    const BlockDesc d = blocks[b];
-    TokEnv<G, LR, DR> env;
-    env.in = comp + d.in_off;
-    env.clen = d.clen;
-    env.out = outbuf + d.out_off;
-    env.bm = bitmap + (size_t)b * kBitmapWords;
-    env.limit = d.ulen;
-    env.pos = 0;
-    env.bm_word = 0;
-    env.bm_idx = 0;
-    env.T = &T[q];
-    env.ibuf = ibuf[q];
-    env.lane_ = lane;
-    int rc = 0;
-    if (d.ulen > 0) {
-        env.start();
-        rc = spxz::inflate_stream(env, (int64_t)d.clen * 8, d.ulen);
-        if (rc == 0) env.finish();
-    }
-    if (lane == 0) status[b] = rc;
-}
-
-
 /* ---------------------------------------------------------------------------------------------------------------------
- * The decode kernel's own DEFLATE decoder (TokEnv above runs the shared core of spx_inflate.h with a hand-written symbol loop; this
- * one is the whole stream, written for the lane group):
+ * The decode kernel's own DEFLATE decoder (the kernels above run the shared core of spx_inflate.h; this one is the whole stream, written
+ * for the lane group):
  *   - ONE bit reader everywhere: two input dwords in registers, v_alignbit_b32 for the next 32 bits, input staged through LDS in
  *     128-byte chunks;
  *   - block headers in PARALLEL: the code-length code through a 128-entry table, the canonical order of the 286 + 30 symbols by
@@ -899,7 +484,11 @@ struct TokDec {
             } h;
         };
         uint16_t lit_sorted[288], dist_sorted[32]; /* (length << 9) | symbol in (length, symbol) order */
-        uint16_t lit_count[16], dist_count[16];
+        /* codes longer than the root tables: limit[l] = (first code of length l + number of codes) << (15 - l), i.e. the first 15 bits
+         * of the stream (most significant first) lie below limit[l] for every code of at most l bits; base[l] = index in `sorted` of
+         * the length's first symbol - its first code */
+        uint16_t lit_limit[16], dist_limit[16];
+        int16_t lit_base[16], dist_base[16];
         uint32_t ibuf[64];
     };
     const uint8_t *in;
@@ -917,6 +506,23 @@ struct TokDec {
     Lds *L;
     int lane;
 
+    /* table entries (16 bits, read sign-extended: a literal is >= 0):
+     *   literal           bits 0-7 the byte, bits 8-11 code length
+     *   length / end      bit 15, bits 0-7 length base - 3, bits 8-11 code length, bits 12-14 number of extra bits (7 = end of block)
+     *   distance          bits 0-1 h, bits 2-5 number of extra bits x, bits 8-11 code length: base = 1 + (h << x)
+     *   kNone             bit 15 alone: not a root code */
+    static constexpr uint32_t kNone = 0x8000u;
+    __device__ __forceinline__ static uint32_t lit_entry(uint32_t nbits, uint32_t sym)
+    {
+        if (sym < 256u) return sym | (nbits << 8);
+        if (sym == 256u) return 0x8000u | (nbits << 8) | (7u << 12);
+        return 0x8000u | (uint32_t)(spxz::len_base((int)sym) - 3) | (nbits << 8) | ((uint32_t)spxz::len_extra((int)sym) << 12);
+    }
+    __device__ __forceinline__ static uint32_t dist_entry(uint32_t nbits, uint32_t sym)
+    {
+        const uint32_t h = sym < 2u ? sym : 2u + (sym & 1u);
+        return h | ((uint32_t)spxz::dist_extra((int)sym) << 2) | (nbits << 8);
+    }
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
     typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
     __device__ __forceinline__ static void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -967,8 +573,8 @@ struct TokDec {
         off -= 32u;
         ++k;
         w0 = w1;
-        if (k > k_end) return false;
         if (((k + 1u) >> 5) >= staged) {
+            if (k > k_end) return false; /* (checked once per chunk: up to 128 bytes of zeros beyond the data may be looked at) */
             store_chunk(staged);
             ++staged;
             load_chunk(staged);
@@ -987,17 +593,18 @@ struct TokDec {
         return true;
     }
     /* ---- output ---- */
+    /* (pos = output bytes up to the last match or flush; the literals in litv come on top) */
     __device__ __forceinline__ void push(uint32_t c)
     {
         litv = (uint32_t)lane == npend ? c : litv;
         ++npend;
-        ++pos;
     }
     __device__ __forceinline__ void flush_literals()
     {
         if (npend) {
-            const uint32_t p = pos - npend + (uint32_t)lane;
+            const uint32_t p = pos + (uint32_t)lane;
             if ((uint32_t)lane < npend && p < limit) out[p] = (uint8_t)litv; /* (beyond the block's size: counted, not written) */
+            pos += npend;
             npend = 0;
         }
     }
@@ -1020,7 +627,7 @@ struct TokDec {
     /* ---- canonical order of `n` symbols (their lengths: mine[c] = length of symbol c * G + lane, 0 = unused) into sorted / count,
      * first / offs; -1 for an over-subscribed set or an incomplete one of more than one code.  `used` = coded symbols ---- */
     template <int NC>
-    __device__ __forceinline__ int canonical(const uint32_t (&mine)[NC], uint16_t *sorted, uint16_t *count, int *used, uint32_t *min_len)
+    __device__ __forceinline__ int canonical(const uint32_t (&mine)[NC], uint16_t *sorted, uint16_t *limit_, int16_t *base_, int *used, uint32_t *min_len)
     {
         const uint32_t lt = (1u << lane) - 1u;
         int left = 1, bad = 0;
@@ -1043,7 +650,9 @@ struct TokDec {
             if (lane == 0) {
                 L->h.first[l] = (uint16_t)code;
                 L->h.offs[l] = (uint16_t)run;
-                count[l] = (uint16_t)n_l;
+                const uint32_t lim = (code + n_l) << (15u - l);
+                limit_[l] = (uint16_t)(lim > 0xffffu ? 0xffffu : lim); /* (an over-subscribed set is refused below) */
+                base_[l] = (int16_t)((int)run - (int)code);
             }
             run = at;
             n_prev = n_l;
@@ -1065,13 +674,13 @@ struct TokDec {
             if (i >= used) return 0u;
             const uint32_t v = sorted[i], s = v & 511u, ll = v >> 9;
             if ((int)ll > root || (LIT ? s > 285u : s > 29u)) return 0u;
-            const uint32_t e = !LIT ? spxz::mk_dist_entry((int)ll, (int)s) : s < 256u ? spxz::mk_entry((int)ll, (int)s) : spxz::mk_len_entry((int)ll, (int)s);
+            const uint32_t e = LIT ? lit_entry(ll, s) : dist_entry(ll, s);
             const uint32_t r = __brev((uint32_t)L->h.first[ll] + ((uint32_t)i - (uint32_t)L->h.offs[ll])) >> (32u - ll);
-            return e | (r << 16) | (ll << 25);
+            return e | (r << 16) | (ll << 25) | 0x40000000u; /* (never 0) */
         };
         auto put = [&](uint32_t pk) {
             if (pk)
-                for (uint32_t q = (pk >> 16) & 511u; q < (1u << root); q += 1u << (pk >> 25)) tab[q] = (uint16_t)pk;
+                for (uint32_t q = (pk >> 16) & 511u; q < (1u << root); q += 1u << ((pk >> 25) & 15u)) tab[q] = (uint16_t)pk;
         };
         if (!LIT) {
 #pragma unroll
@@ -1079,7 +688,7 @@ struct TokDec {
             lds_fence();
         }
         uint32_t *t32 = reinterpret_cast<uint32_t *>(tab);
-        for (int q = lane; q < (1 << root) / 2; q += G) t32[q] = (uint32_t)spxz::kNoEntry * 0x10001u;
+        for (int q = lane; q < (1 << root) / 2; q += G) t32[q] = kNone * 0x10001u;
         lds_fence();
         if (LIT) {
             for (int i = lane; i < used; i += G) put(one(i));
@@ -1102,7 +711,7 @@ struct TokDec {
         lds_fence();
         int used = 0;
         uint32_t min_len;
-        if (canonical<kNC>(mine, L->lit_sorted, L->lit_count, &used, &min_len) != 0) return -1;
+        if (canonical<kNC>(mine, L->lit_sorted, L->lit_limit, L->lit_base, &used, &min_len) != 0) return -1;
         /* literals gather in a register of G lanes between two steps of the reader (32 bits): with codes of >= 2 bits at most 16
          * arrive, and the register is emptied at a step once it holds 16; a 1-bit code empties it at every step */
         lit_room = (G == 32 && min_len >= 2u) ? 16u : 1u;
@@ -1111,25 +720,24 @@ struct TokDec {
 #pragma unroll
         for (int c = 0; c < kND; ++c) dmine[c] = (uint32_t)L->h.dlens[c * G + lane];
         lds_fence();
-        if (canonical<kND>(dmine, L->dist_sorted, L->dist_count, &used, &min_len) != 0) return -1;
+        if (canonical<kND>(dmine, L->dist_sorted, L->dist_limit, L->dist_base, &used, &min_len) != 0) return -1;
         fill<false>(L->dist, DR, L->dist_sorted, used);
         return 0;
     }
-    /* a code longer than the root table: the canonical walk (Mark Adler's puff), one bit at a time */
-    __device__ __forceinline__ static uint32_t walk(uint32_t bits, const uint16_t *count, const uint16_t *sorted)
+    /* a code longer than the root table (ROOT bits), from the next bits of the stream: (length << 16) | symbol, or 0xffffffff.  The
+     * first 15 bits, most significant first, are compared with the lengths' limits */
+    template <int ROOT>
+    __device__ __forceinline__ static uint32_t slow(uint32_t bits, const uint16_t *limit_, const int16_t *base_, const uint16_t *sorted)
     {
-        int code = 0, first = 0, index = 0;
-        for (int len = 1; len <= 15; ++len) {
-            code |= (int)(bits & 1u);
-            bits >>= 1;
-            const int c = count[len];
-            if (code - c < first) return ((uint32_t)len << 16) | ((uint32_t)sorted[index + (code - first)] & 511u);
-            index += c;
-            first += c;
-            first <<= 1;
-            code <<= 1;
-        }
-        return 0xffffffffu;
+        const uint32_t c15 = __brev(bits) >> 17;
+        if (c15 < (uint32_t)limit_[ROOT]) return 0xffffffffu; /* a code of <= ROOT bits without a root entry: symbols 286, 287 / 30, 31 */
+        uint32_t len = 0;
+#pragma unroll
+        for (int l = 15; l > ROOT; --l)
+            if (c15 < (uint32_t)limit_[l]) len = (uint32_t)l;
+        if (!len) return 0xffffffffu;
+        const int idx = (int)base_[len] + (int)(c15 >> (15u - len));
+        return (len << 16) | ((uint32_t)sorted[idx] & 511u);
     }
 
     /* ---- a dynamic block's header: the code lengths into L->lens ---- */
@@ -1229,7 +837,7 @@ struct TokDec {
     /* ---- the symbols of one block, to its end-of-block code ---- */
     __device__ __forceinline__ int symbols()
     {
-        const uint16_t *lit = L->lit, *dis = L->dist;
+        const int16_t *lit = reinterpret_cast<const int16_t *>(L->lit), *dis = reinterpret_cast<const int16_t *>(L->dist);
         int rc = 1;
         for (;;) {
             if (off >= 32u) {
@@ -1237,15 +845,16 @@ struct TokDec {
                 if (!step()) { rc = -3; break; }
             }
             uint32_t b = peek();
-            uint32_t e = lit[b & ((1u << LR) - 1u)];
-            if (!(e & 0x100u)) {
+            int e = lit[b & ((1u << LR) - 1u)];
+            if (e >= 0) { /* a literal */
                 if (G < 32 && npend == (uint32_t)G) flush_literals();
-                push(e & 0xffu);
-                off += e >> 9;
+                push((uint32_t)e);
+                off += (uint32_t)e >> 8;
                 continue;
             }
-            if (e == spxz::kNoEntry) {
-                const uint32_t r = walk(b, L->lit_count, L->lit_sorted);
+            uint32_t ue = (uint32_t)e & 0xffffu;
+            if (ue == kNone) {
+                const uint32_t r = slow<LR>(b, L->lit_limit, L->lit_base, L->lit_sorted);
                 if (r == 0xffffffffu) { rc = -1; break; }
                 const uint32_t sym = r & 0xffffu;
                 if (sym > 285u) { rc = -1; break; }
@@ -1255,27 +864,27 @@ struct TokDec {
                     off += r >> 16;
                     continue;
                 }
-                e = spxz::mk_len_entry((int)(r >> 16), (int)sym);
+                ue = lit_entry(r >> 16, sym);
             }
-            uint32_t n = (e >> 9) & 15u, x = e >> 13;
+            uint32_t n = (ue >> 8) & 15u, x = (ue >> 12) & 7u;
             if (x == 7u) {
                 off += n;
                 rc = 0;
                 break;
             }
-            const uint32_t len = (e & 0xffu) + 3u + ((b >> n) & ((1u << x) - 1u));
+            const uint32_t len = (ue & 0xffu) + 3u + ((b >> n) & ((1u << x) - 1u));
             off += n + x;
             flush_literals();
             if (off >= 32u && !step()) { rc = -3; break; }
             b = peek();
-            uint32_t de = dis[b & ((1u << DR) - 1u)];
-            if (de == spxz::kNoEntry) {
-                const uint32_t r = walk(b, L->dist_count, L->dist_sorted);
+            uint32_t de = (uint32_t)dis[b & ((1u << DR) - 1u)] & 0xffffu;
+            if (de == kNone) {
+                const uint32_t r = slow<DR>(b, L->dist_limit, L->dist_base, L->dist_sorted);
                 if (r == 0xffffffffu) { rc = -1; break; }
                 if ((r & 0xffffu) > 29u) { rc = -1; break; }
-                de = spxz::mk_dist_entry((int)(r >> 16), (int)(r & 0xffffu));
+                de = dist_entry(r >> 16, r & 0xffffu);
             }
-            n = de >> 9;
+            n = de >> 8;
             x = (de >> 2) & 15u;
             const uint32_t dist = 1u + ((de & 3u) << x) + ((b >> n) & ((1u << x) - 1u));
             off += n + x;
@@ -1444,111 +1053,38 @@ __global__ __launch_bounds__(64) void bgzf_resolve_kernel(const BlockDesc *__res
 
 } // namespace
 
-static int inflate_root_bits()
-{
-    /* SPX_INFLATE_ROOT: bits of the literal/length root table: 9 (with an 8-bit distance table; default), 10 (10 / 8), 11 (11 / 9: round 3) */
-    static const int r = [] { const char *e = getenv("SPX_INFLATE_ROOT"); const int v = e ? atoi(e) : 9; return (v == 10 || v == 11) ? v : 9; }();
-    return r;
-}
-
-#define SPX_LAUNCH_G(G, LR, DR, R) \
-    hipLaunchKernelGGL((bgzf_inflate_g_kernel<G, LR, DR, R>), dim3((unsigned)((n_blocks + (64 / G) - 1) / (64 / G))), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc)
-
-extern "C" hipError_t spx_launch_bgzf_inflate_grouped(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
-                                                      int check_crc, int lanes_per_block, hipStream_t st)
-{
-    if (n_blocks <= 0) return hipSuccess;
-    const BlockDesc *bd = (const BlockDesc *)blocks;
-    const int root = inflate_root_bits();
-    static const int ring = [] { const char *e = getenv("SPX_INFLATE_RING"); const int v = e ? atoi(e) : 1024; return (v == 2048 || v == 1025 || v == 4096) ? v : 1024; }();
-    if (lanes_per_block == 16) {
-        if (root == 11) SPX_LAUNCH_G(16, 11, 9, 2048); else if (root == 10) SPX_LAUNCH_G(16, 10, 8, 2048); else SPX_LAUNCH_G(16, 9, 8, 2048);
-    } else {
-        if (root == 11) SPX_LAUNCH_G(32, 11, 9, 2048);
-        else if (root == 10) SPX_LAUNCH_G(32, 10, 8, 2048);
-        else if (ring == 4096) SPX_LAUNCH_G(32, 9, 8, 4096);
-        else if (ring == 1024)
-            hipLaunchKernelGGL((bgzf_inflate_g_kernel<32, 9, 8, 1024, 5>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
-        else if (ring == 1025) /* experiment: 8-bit literal root, six waves per SIMD */
-            hipLaunchKernelGGL((bgzf_inflate_g_kernel<32, 8, 8, 1024, 6>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
-        else SPX_LAUNCH_G(32, 9, 8, 2048);
-    }
-    return hipGetLastError();
-}
-
-extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc, hipStream_t st);
-
-/* the two-kernel path (decode, then copy) needs a bitmap of 8 KB per block */
-extern "C" size_t spx_bgzf_inflate_scratch_bytes(int32_t n_blocks) { return (size_t)(n_blocks > 0 ? n_blocks : 0) * kBitmapWords * 4u; }
-
-/* SPX_INFLATE_TOK: 234 (default) = the decode kernel with 32 lanes per block, seven waves per SIMD; 232 / 233 / 235 = five / six / eight waves, 216 =
- * 16 lanes per block; 32 / 16 / 8 = the shared decoder core with its hand-written symbol loop (TokEnv); 0 = one kernel (bgzf_inflate_g_kernel) */
-static int inflate_tok_lanes()
-{
-    static const int v = [] { const char *e = getenv("SPX_INFLATE_TOK"); const int v = e ? atoi(e) : 234; return (v == 8 || v == 16 || v == 32 || v == 33 || v == 17 || (v >= 200 && v < 300)) ? v : 0; }();
-    return v;
-}
-
-extern "C" hipError_t spx_launch_bgzf_inflate2(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc,
-                                               void *scratch, hipStream_t st)
-{
-    if (n_blocks <= 0) return hipSuccess;
-    const int g = inflate_tok_lanes();
-    if (g == 0 || !scratch) return spx_launch_bgzf_inflate(comp, blocks, n_blocks, out, status, check_crc, st); /* SPX_INFLATE_TOK=0: round 4's first kernel */
-    const BlockDesc *bd = (const BlockDesc *)blocks;
-    uint32_t *bitmap = (uint32_t *)scratch;
-    const int stage = [] { const char *e = getenv("SPX_INFLATE_TOK_STAGE"); return e ? atoi(e) : 3; }(); /* experiments: 1 = decode only, 2 = + copy */
-    if (hipMemsetAsync(bitmap, 0, spx_bgzf_inflate_scratch_bytes(n_blocks), st) != hipSuccess) return hipGetLastError();
-#define SPX_LAUNCH_DEC2(G, WPE) \
-    hipLaunchKernelGGL((bgzf_decode2_kernel<G, WPE>), dim3((unsigned)((n_blocks + (64 / G) - 1) / (64 / G))), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status)
-    if (g == 232) SPX_LAUNCH_DEC2(32, 5);
-    else if (g == 233) SPX_LAUNCH_DEC2(32, 6);
-    else if (g == 234) SPX_LAUNCH_DEC2(32, 7);
-    else if (g == 235) SPX_LAUNCH_DEC2(32, 8);
-    else if (g == 216) SPX_LAUNCH_DEC2(16, 4);
-    else if (g == 8) hipLaunchKernelGGL((bgzf_decode_kernel<8, 9, 8, 2>), dim3((unsigned)((n_blocks + 7) / 8)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
-    else if (g == 16) hipLaunchKernelGGL((bgzf_decode_kernel<16, 9, 8, 4>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
-    else if (g == 17) hipLaunchKernelGGL((bgzf_decode_kernel<16, 9, 8, 3>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
-    else if (g == 33) hipLaunchKernelGGL((bgzf_decode_kernel<32, 9, 8, 6>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
-    else hipLaunchKernelGGL((bgzf_decode_kernel<32, 9, 8, 5>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
-    if (stage >= 2) hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, bd, n_blocks, out, bitmap, status);
-    if (stage >= 3 && check_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, bd, n_blocks, out, status);
-    return hipGetLastError();
-}
-
+/* the earlier kernels, kept for comparisons (tools/inflate_bench.py) and as the path without scratch memory:
+ * SPX_INFLATE_LANES = 32 (default): round 4's first kernel, two blocks per wavefront (9 / 8-bit root tables, 1 KB ring, five waves per SIMD);
+ * 64: round 3's kernel, one block per wavefront on the scalar unit (11 / 9-bit root tables) */
 extern "C" hipError_t spx_launch_bgzf_inflate(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status,
                                               int check_crc, hipStream_t st)
 {
     if (n_blocks <= 0) return hipSuccess;
-    /* SPX_INFLATE_LANES: 32 (default) / 16 = lanes per block of the grouped kernel (2 / 4 blocks per wave, decode on the vector ALU;
-     * SPX_INFLATE_RING = 1024 (default: five waves per SIMD) / 2048 / 4096 bytes of LDS ring per block), 64 = round 3's kernel: one block
-     * per wave on the scalar unit */
-    static const int lanes = [] { const char *e = getenv("SPX_INFLATE_LANES"); const int v = e ? atoi(e) : 32; return (v == 16 || v == 64) ? v : 32; }();
-    /* SPX_INFLATE_FLAT = 4 / 8 / 16 / 32: the flat kernel with that many lanes per block (9 / 8-bit root tables, 1 KB ring) + the CRC kernel */
-    static const int flat = [] { const char *e = getenv("SPX_INFLATE_FLAT"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32 || v == 132 || (v >= 1000 && v < 3000)) ? v : 0; }();
-    if (flat) {
-        const BlockDesc *bd = (const BlockDesc *)blocks;
-#define SPX_LAUNCH_FLAT(G, WPE) \
-    hipLaunchKernelGGL((bgzf_inflate_flat_kernel<G, 9, 8, 1024, WPE>), dim3((unsigned)((n_blocks + (64 / G) - 1) / (64 / G))), dim3(64), 0, st, comp, bd, n_blocks, out, status)
-        if (flat == 4) SPX_LAUNCH_FLAT(4, 1);
-        else if (flat == 8) SPX_LAUNCH_FLAT(8, 2);
-        else if (flat == 16) SPX_LAUNCH_FLAT(16, 3);
-        else if (flat == 1032) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<32, 9, 8, 1024, 5, true, 1>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
-        else if (flat == 2032) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<32, 9, 8, 1024, 5, true, 2>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
-        else if (flat == 1016) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<16, 9, 8, 1024, 3, true, 1>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
-        else if (flat == 2016) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<16, 9, 8, 1024, 3, true, 2>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
-        else if (flat == 2008) hipLaunchKernelGGL((bgzf_inflate_flat_kernel<8, 9, 8, 1024, 2, true, 2>), dim3((unsigned)((n_blocks + 7) / 8)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
-        else if (flat == 132) /* 32 lanes, the symbol loop with the inner literal loop */
-            hipLaunchKernelGGL((bgzf_inflate_flat_kernel<32, 9, 8, 1024, 5, false>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status);
-        else SPX_LAUNCH_FLAT(32, 5);
-        if (check_crc && flat < 1000) hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, bd, n_blocks, out, status);
-        return hipGetLastError();
-    }
-    if (lanes != 64) return spx_launch_bgzf_inflate_grouped(comp, blocks, n_blocks, out, status, check_crc, lanes, st);
+    static const int lanes = [] { const char *e = getenv("SPX_INFLATE_LANES"); const int v = e ? atoi(e) : 32; return v == 64 ? 64 : 32; }();
     const BlockDesc *bd = (const BlockDesc *)blocks;
-    const int root = inflate_root_bits();
-    if (root == 11) hipLaunchKernelGGL((bgzf_inflate_kernel<11, 9>), dim3((unsigned)n_blocks), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
-    else if (root == 10) hipLaunchKernelGGL((bgzf_inflate_kernel<10, 8>), dim3((unsigned)n_blocks), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
-    else hipLaunchKernelGGL((bgzf_inflate_kernel<9, 8>), dim3((unsigned)n_blocks), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
+    if (lanes == 64) hipLaunchKernelGGL((bgzf_inflate_kernel<11, 9>), dim3((unsigned)n_blocks), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
+    else hipLaunchKernelGGL((bgzf_inflate_g_kernel<32, 9, 8, 1024, 5>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, status, check_crc);
+    return hipGetLastError();
+}
+
+/* the decode kernel's bitmap: 8 KB per block */
+extern "C" size_t spx_bgzf_inflate_scratch_bytes(int32_t n_blocks) { return (size_t)(n_blocks > 0 ? n_blocks : 0) * kBitmapWords * 4u; }
+
+/* Inflate `n_blocks` BGZF blocks: decode, copy, CRC (three kernels on `st`).  `scratch`: spx_bgzf_inflate_scratch_bytes(n_blocks) bytes.
+ * SPX_INFLATE_TOK = 32 (default: 32 lanes per block, seven waves per SIMD) / 16 (16 lanes per block) / 0 (the one-kernel path above) */
+extern "C" hipError_t spx_launch_bgzf_inflate2(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc,
+                                               void *scratch, hipStream_t st)
+{
+    if (n_blocks <= 0) return hipSuccess;
+    static const int g = [] { const char *e = getenv("SPX_INFLATE_TOK"); const int v = e ? atoi(e) : 32; return (v == 16 || v == 0) ? v : 32; }();
+    if (g == 0 || !scratch) return spx_launch_bgzf_inflate(comp, blocks, n_blocks, out, status, check_crc, st);
+    const BlockDesc *bd = (const BlockDesc *)blocks;
+    uint32_t *bitmap = (uint32_t *)scratch;
+    static const int stage = [] { const char *e = getenv("SPX_INFLATE_TOK_STAGE"); return e ? atoi(e) : 3; }(); /* timing experiments: 1 = decode only, 2 = + copy */
+    if (hipMemsetAsync(bitmap, 0, spx_bgzf_inflate_scratch_bytes(n_blocks), st) != hipSuccess) return hipGetLastError();
+    if (g == 16) hipLaunchKernelGGL((bgzf_decode2_kernel<16, 4>), dim3((unsigned)((n_blocks + 3) / 4)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
+    else hipLaunchKernelGGL((bgzf_decode2_kernel<32, 7>), dim3((unsigned)((n_blocks + 1) / 2)), dim3(64), 0, st, comp, bd, n_blocks, out, bitmap, status);
+    if (stage >= 2) hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, bd, n_blocks, out, bitmap, status);
+    if (stage >= 3 && check_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, bd, n_blocks, out, status);
     return hipGetLastError();
 }
