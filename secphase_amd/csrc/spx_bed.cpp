@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <map>
 #include <string>
 #include <thread>
@@ -30,12 +31,53 @@
 
 struct Blk3 { int32_t s, e, c; };
 
+/* std::sort on `threads` threads: sorted runs, then pairwise merges level by level (a contig of a small assembly can hold millions of
+ * marker positions while the save has only a handful of contigs to spread over its threads) */
+template <class T, class Cmp>
+static void parallel_sort(std::vector<T> &v, Cmp cmp, unsigned threads)
+{
+    const size_t n = v.size();
+    if (threads <= 1 || n < 65536) { std::sort(v.begin(), v.end(), cmp); return; }
+    unsigned runs = 1;
+    while (runs * 2 <= threads && n / (runs * 2) >= 16384) runs *= 2;
+    std::vector<size_t> cut(runs + 1);
+    for (unsigned r = 0; r <= runs; ++r) cut[r] = n * r / runs;
+    {
+        std::vector<std::thread> th;
+        for (unsigned r = 0; r < runs; ++r) th.emplace_back([&, r]() { std::sort(v.begin() + (ptrdiff_t)cut[r], v.begin() + (ptrdiff_t)cut[r + 1], cmp); });
+        for (auto &t : th) t.join();
+    }
+    for (unsigned w = 1; w < runs; w *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned r = 0; r + w < runs; r += 2 * w)
+            th.emplace_back([&, r, w]() {
+                std::inplace_merge(v.begin() + (ptrdiff_t)cut[r], v.begin() + (ptrdiff_t)cut[r + w], v.begin() + (ptrdiff_t)cut[std::min(runs, r + 2 * w)], cmp);
+            });
+        for (auto &t : th) t.join();
+    }
+}
+
 /* coverage segmentation of blocks (any order); has_count=0: c ignored, output c = 0 */
-static void merge_count(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &out)
+static void merge_count(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &out, unsigned threads = 1)
 {
     out.clear();
     if (v.empty()) return;
-    std::sort(v.begin(), v.end(), [](const Blk3 &a, const Blk3 &b) { return a.s != b.s ? a.s < b.s : a.e < b.e; });
+    if (!has_count) {
+        /* single-base blocks without counts (marker positions): the segmentation is the set of distinct positions */
+        bool points = true;
+        for (const Blk3 &b : v)
+            if (b.s != b.e) { points = false; break; }
+        if (points) {
+            std::vector<int32_t> p(v.size());
+            for (size_t i = 0; i < v.size(); ++i) p[i] = v[i].s;
+            parallel_sort(p, std::less<int32_t>(), threads);
+            p.erase(std::unique(p.begin(), p.end()), p.end());
+            out.resize(p.size());
+            for (size_t i = 0; i < p.size(); ++i) out[i] = {p[i], p[i], 0};
+            return;
+        }
+    }
+    parallel_sort(v, [](const Blk3 &a, const Blk3 &b) { return a.s != b.s ? a.s < b.s : a.e < b.e; }, threads);
     /* break points: every start, every end+1 */
     std::vector<int64_t> bp;
     bp.reserve(v.size() * 2);
@@ -44,7 +86,7 @@ static void merge_count(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &
         bp.push_back(b.s);
         bp.push_back((int64_t)b.e + 1);
     }
-    std::sort(bp.begin(), bp.end());
+    parallel_sort(bp, std::less<int64_t>(), threads);
     bp.erase(std::unique(bp.begin(), bp.end()), bp.end());
     /* coverage difference array over the break points */
     std::vector<int64_t> dc(bp.size() + 1, 0), dn(bp.size() + 1, 0);
@@ -144,12 +186,14 @@ extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_
     for (const auto &kv : b->per_contig) items.push_back(&kv);
     std::vector<std::string> text(items.size());
     std::atomic<size_t> next(0);
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const unsigned inner = (unsigned)std::max<size_t>(1, hw / std::max<size_t>(1, items.size())); /* threads per contig when contigs are few */
     auto work = [&]() {
         std::vector<Blk3> merged;
         for (;;) {
             const size_t k = next.fetch_add(1);
             if (k >= items.size()) break;
-            merge_count(items[k]->second, print_count != 0, merged);
+            merge_count(items[k]->second, print_count != 0, merged, inner);
             std::string &t = text[k];
             t.reserve(merged.size() * (items[k]->first.size() + 24));
             for (const Blk3 &m : merged) {
@@ -162,7 +206,7 @@ extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_
             }
         }
     };
-    const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(32, std::thread::hardware_concurrency()), items.size()));
+    const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(hw, items.size()));
     if (nthr <= 1) work();
     else {
         std::vector<std::thread> th;

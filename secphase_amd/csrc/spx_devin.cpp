@@ -964,8 +964,9 @@ extern "C" int spx_dbam_start(spx_dbam *d, spx_ctx *const *ctxs, int32_t n_ctx, 
     d->par = *par;
     if (d->host_share < 0) {
         /* default: what the host pool can carry beside the devices.  Measured on the MI355X boxes (16 cores of CPU time):
-         * libdeflate ~0.6 GB/s per core, the inflate kernel ~13 GB/s per device */
-        const double host_rate = 0.55 * (double)std::max(1, spx_effective_cpus() - 1), dev_rate = 13.0 * n_ctx;
+         * libdeflate ~0.6 GB/s per core; the inflate kernels, 44 GB/s alone on a device, get ~20 GB/s of it beside the scoring kernels
+         * (a sweep of the share on 524 288 HiFi groups: 20 % .. 39 % within 5 % of each other, 30 % the best) */
+        const double host_rate = 0.55 * (double)std::max(1, spx_effective_cpus() - 1), dev_rate = 20.0 * n_ctx;
         d->host_share = host_rate / (host_rate + dev_rate);
     }
     d->host_share = std::min(1.0, std::max(0.0, d->host_share));

@@ -81,3 +81,32 @@ def test_product_merge_equals_oracle_on_random_blocks(built):
         counts = [int(c) for c in rng.integers(1, 4, n)]
         assert product_merge(blocks, counts) == oracle_merge_v2(blocks, counts), blocks
         assert product_merge(blocks, None) == oracle_merge_v2(blocks, None), blocks
+
+
+def test_bed_save_of_one_large_contig_on_several_threads(built, tmp_path):
+    """few contigs, many blocks: the save sorts one contig's blocks on several threads (runs + merges) -- the same text as the
+    single-threaded merge of spx_merge_blocks_count, with counts and for bare marker positions"""
+    L = api.lib()
+    rng = np.random.default_rng(5)
+    n = 150000
+    starts = rng.integers(0, 3_000_000, n).astype(np.int32)
+    lens = rng.integers(0, 400, n).astype(np.int32)
+    cnts = rng.integers(1, 4, n).astype(np.int32)
+    for with_count in (1, 0):
+        h = C.c_void_p()
+        assert L.spx_bedset_create(C.byref(h)) == 0
+        if with_count:
+            for s, l, c in zip(starts.tolist(), lens.tolist(), cnts.tolist()):
+                L.spx_bedset_add(h, b"ctg", s, s + l, c)
+            want = product_merge([[s, s + l] for s, l in zip(starts.tolist(), lens.tolist())], cnts.tolist())
+        else:
+            L.spx_bedset_add_points.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_int32]
+            L.spx_bedset_add_points(h, b"ctg", starts.ctypes.data_as(C.POINTER(C.c_int32)), n)
+            want = product_merge([[s, s] for s in starts.tolist()], None)
+        path = str(tmp_path / f"x{with_count}.bed")
+        assert L.spx_bedset_save(h, path.encode(), with_count) == 0
+        L.spx_bedset_free(h)
+        got = [l.split("\t") for l in open(path).read().splitlines()]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g[0] == "ctg" and int(g[1]) == w[0] and int(g[2]) == w[1] + 1 and (not with_count or int(g[3]) == w[2])

@@ -51,8 +51,9 @@ def main():
     ap.add_argument("--env", action="append", default=[], help="NAME=VALUE for the command line's environment")
     ap.add_argument("--rocprof", default="", metavar="DIR", help="after the runs: the same command once under `rocprofv3 --kernel-trace --stats` "
                     "(the binary itself after `--`), its CSV files under DIR")
-    ap.add_argument("--sweep", default="", help="NAME=v1,v2,...: after the main run, the same command with each value of NAME in its environment "
-                    "(best of --runs each); their wall / loop times are reported under `sweep`")
+    ap.add_argument("--sweep", action="append", default=[], help="NAME=v1,v2,... (may be given several times; NAME may be A+B: both variables get the value pair a+b): "
+                    "after the main run, the same command with each value of NAME in its environment (--runs each); their wall / loop times are "
+                    "reported under `sweep`")
     ap.add_argument("--check-groups", type=int, default=4096)
     ap.add_argument("--devices", default="0")
     ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -103,21 +104,23 @@ def main():
             best = (t1 - t0, p, t0, t1)
     wall, p, t0, t1 = best
     sweep = {}
-    if args.sweep:
+    for sw in args.sweep:
         import re
-        name, _, vals = args.sweep.partition("=")
+        name, _, vals = sw.partition("=")
         for v in vals.split(","):
             ws, loops = [], []
+            extra = dict(zip(name.split("+"), v.split("+")))
             for _ in range(max(1, args.runs)):
                 shutil.rmtree(outd, ignore_errors=True)
                 ta = time.time()
-                q = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, **{name: v}))
+                q = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, **extra))
                 ws.append(round(time.time() - ta, 3))
                 m = re.search(r"time in the scoring loop: ([0-9.]+) s", q.stderr)
                 loops.append(float(m.group(1)) if m else None)
                 if q.returncode != 0:
                     ws[-1] = "rc %d: %s" % (q.returncode, q.stderr[-200:])
             sweep[f"{name}={v}"] = {"wall_s": ws, "loop_s": loops}
+    if args.sweep:
         shutil.rmtree(outd, ignore_errors=True)
         subprocess.run(cmd, capture_output=True, text=True, env=env)  # (the checks below read the main configuration's list)
     outside = None
