@@ -490,13 +490,16 @@ struct TokDec {
         uint16_t lit_limit[16], dist_limit[16];
         int16_t lit_base[16], dist_base[16];
         uint32_t ibuf[64];
+        uint32_t bm_word, bm_idx; /* the bitmap word being gathered: bits of output positions [32 * bm_idx, 32 * bm_idx + 32).  (In LDS, not in
+                                   * registers: a match is one symbol in eight, and at seven waves per SIMD the compiler kept these two in scratch
+                                   * memory -- a load the match path then waited for) */
     };
     const uint8_t *in;
     uint32_t clen, k_end;
     uint8_t *out;
-    uint32_t *bm;
+    uint32_t *bitmap;        /* of the launch; this block's words start at bm_at() (recomputed where needed: one register less in the symbol loop) */
+    __device__ __forceinline__ static uint32_t bm_at() { return ((uint32_t)blockIdx.x * (64u / G) + (uint32_t)threadIdx.x / G) * (uint32_t)kBitmapWords; }
     uint32_t limit, pos;
-    uint32_t bm_word, bm_idx;
     uint32_t staged;
     uint32_t stage_v[kNW];
     uint32_t w0, w1, k, off; /* the reader: w0 = input dword k, w1 = dword k + 1, `off` bits of w0 consumed (may pass 32: step()) */
@@ -611,12 +614,15 @@ struct TokDec {
     __device__ __forceinline__ void token(uint32_t len, uint32_t dist)
     {
         const uint32_t w = pos >> 5;
-        if (w != bm_idx) {
-            if (lane == 0 && bm_word) bm[bm_idx] = bm_word;
-            bm_word = 0;
-            bm_idx = w;
+        uint32_t word = L->bm_word;
+        const uint32_t idx = L->bm_idx;
+        if (w != idx) {
+            if (lane == 0 && word) bitmap[bm_at() + idx] = word;
+            word = 0;
+            if (lane == 0) L->bm_idx = w;
         }
-        bm_word |= 1u << (pos & 31u);
+        word |= 1u << (pos & 31u);
+        if (lane == 0) L->bm_word = word;
         if (lane == 0) {
             *reinterpret_cast<u16_unaligned *>(out + pos) = (uint16_t)(dist - 1u);
             out[pos + 2] = (uint8_t)(len - 3u);
@@ -900,8 +906,7 @@ struct TokDec {
     {
         npend = 0;
         litv = 0;
-        bm_word = 0;
-        bm_idx = 0;
+        if (lane == 0) { L->bm_word = 0; L->bm_idx = 0; }
         pos = 0;
         k_end = ((clen + 3u) >> 2) + 1u;
         seek(0);
@@ -938,7 +943,8 @@ struct TokDec {
             if ((unsigned long long)32u * k + off > (unsigned long long)clen * 8u) return -3;
             if (final_blk) break;
         }
-        if (lane == 0 && bm_word) bm[bm_idx] = bm_word;
+        lds_fence();
+        if (lane == 0 && L->bm_word) bitmap[bm_at() + L->bm_idx] = L->bm_word;
         return pos == limit ? 0 : -2;
     }
 };
@@ -957,7 +963,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     dec.in = comp + d.in_off;
     dec.clen = d.clen;
     dec.out = outbuf + d.out_off;
-    dec.bm = bitmap + (size_t)b * kBitmapWords;
+    dec.bitmap = bitmap; /* (the block's words: dec.bm_at(), b * kBitmapWords) */
     dec.limit = d.ulen;
     dec.L = &lds[q];
     dec.lane = lane;

@@ -46,10 +46,19 @@ python3 tools/e2e_cli.py --groups 524288 --threads 64 --rocprof "$OUT/cli_kt" > 
 cp "$OUT/cli_kt"/*/cli_kernel_stats.csv "$OUT/${TAG}_e2e_cli_kernel_stats.csv" 2>/dev/null || cp "$OUT/cli_kt"/cli_kernel_stats.csv "$OUT/${TAG}_e2e_cli_kernel_stats.csv" 2>/dev/null
 rm -rf "$OUT/cli_kt"
 python3 tools/e2e_cli.py --groups 262144 --threads 64 --host-input --batch 16384 > "$OUT/${TAG}_e2e_cli_host_input.json" 2>> "$OUT/${TAG}_bench.err"
-# the BGZF inflate kernel alone: GB/s and its counters
-python3 tools/inflate_bench.py --groups 16384 > "$OUT/${TAG}_inflate_bench.json" 2>> "$OUT/${TAG}_bench.err"
+# the BGZF inflate kernels alone (decode + copy + CRC: the default; the decode kernel by itself; round 4's first kernel; round 3's): GB/s, and the
+# default's counters
+{
+  echo '{"default_decode_copy_crc":'; python3 tools/inflate_bench.py --groups 49152 2>> "$OUT/${TAG}_bench.err"
+  echo ',"decode_kernel_only":'; SPX_INFLATE_TOK_STAGE=1 python3 tools/inflate_bench.py --groups 49152 2>> "$OUT/${TAG}_bench.err"
+  echo ',"sixteen_lanes_per_block":'; SPX_INFLATE_TOK=16 python3 tools/inflate_bench.py --groups 49152 2>> "$OUT/${TAG}_bench.err"
+  echo ',"round4_first_kernel_two_blocks_per_wave":'; SPX_INFLATE_TOK=0 python3 tools/inflate_bench.py --groups 49152 2>> "$OUT/${TAG}_bench.err"
+  echo ',"round3_kernel_one_block_per_wave":'; SPX_INFLATE_TOK=0 SPX_INFLATE_LANES=64 python3 tools/inflate_bench.py --groups 49152 2>> "$OUT/${TAG}_bench.err"
+  echo ',"default_on_ont_blocks":'; python3 tools/inflate_bench.py --groups 8192 --platform ont 2>> "$OUT/${TAG}_bench.err"
+  echo '}'
+} > "$OUT/${TAG}_inflate_bench.json"
 if [ -z "${SKIP_PMC:-}" ]; then
-python3 tools/pmc_collect.py --inflate --platform hifi --steps 3 --out "$OUT/${TAG}_counters_inflate.json" >> "$OUT/${TAG}_bench.err" 2>&1
+python3 tools/pmc_collect.py --inflate --more --platform hifi --groups-per-step 32768 --steps 2 --out "$OUT/${TAG}_counters_inflate.json" >> "$OUT/${TAG}_bench.err" 2>&1
 fi
 rm -rf "$ROOT/gpurun_out/pmc_tmp"
 ls -la "$OUT"
