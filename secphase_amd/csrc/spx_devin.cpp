@@ -963,10 +963,12 @@ extern "C" int spx_dbam_start(spx_dbam *d, spx_ctx *const *ctxs, int32_t n_ctx, 
     if (!d || !ctxs || n_ctx < 1 || !par || !d->lanes.empty()) return SPX_EINVAL;
     d->par = *par;
     if (d->host_share < 0) {
-        /* default: what the host pool can carry beside the devices.  Measured on the MI355X boxes (16 cores of CPU time):
-         * libdeflate ~0.6 GB/s per core; the inflate kernels, 44 GB/s alone on a device, get ~20 GB/s of it beside the scoring kernels
-         * (a sweep of the share on 524 288 HiFi groups: 20 % .. 39 % within 5 % of each other, 30 % the best) */
-        const double host_rate = 0.55 * (double)std::max(1, spx_effective_cpus() - 1), dev_rate = 20.0 * n_ctx;
+        /* default: the host pool as a HELPER.  Measured on the MI355X boxes (16 cores of CPU time): libdeflate ~0.55 GB/s per core beside
+         * the pipelines' own threads; the inflate kernels 44 GB/s alone on a device, about half of that beside the scoring kernels.  A
+         * sweep of the share on 524 288 HiFi groups (loop time): 0 % 1.49 s, 15-39 % 1.32-1.47 s with nothing to choose between them
+         * -- so the share is set where the host's CPU time stays under 8 core-s per 262 144 groups: host / (host + 40 GB/s per device),
+         * 17 % on a 16-core quota with one device */
+        const double host_rate = 0.55 * (double)std::max(1, spx_effective_cpus() - 1), dev_rate = 40.0 * n_ctx;
         d->host_share = host_rate / (host_rate + dev_rate);
     }
     d->host_share = std::min(1.0, std::max(0.0, d->host_share));

@@ -112,12 +112,12 @@ def test_striped_crc_equals_zlib(built):
 
 
 # ---------------------------------------------------------------- the kernel itself
-def _bgzf_file(payloads, level=6):
+def _bgzf_file(payloads, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
     """BGZF blocks (one per payload) + their start offsets"""
     import struct
     blob, offs = b"", [0]
     for data in payloads:
-        comp = _raw(data, level)
+        comp = _raw(data, level, strategy)
         hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25)
         blob += hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
         offs.append(len(blob))
@@ -155,6 +155,37 @@ def test_kernel_equals_zlib(built):
         assert got == sum(len(p) for p in payloads), L.spx_last_error()
         assert all(s == 0 for s in st), [k for k, s in enumerate(st) if s][:5]
         assert out == b"".join(payloads)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_kernel_on_the_decode_kernels_special_paths(built):
+    """what the decode / copy kernels treat specially: 1-bit literal codes (the literal register is emptied at every step of the
+    reader), a code set of ONE code, fixed-code blocks, runs (matches that overlap themselves, distance 1..3), matches of 258 bytes
+    30 KB back (copied by the whole wavefront), many short far matches (rounds of the copy kernel), codes longer than the root
+    tables, blocks whose neighbours in the wavefront are empty or tiny"""
+    L = _lib()
+    ctx = api.Context(0)
+    rng = np.random.default_rng(33)
+    far = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+    short_far = bytearray(rng.integers(0, 256, 8000, dtype=np.uint8).tobytes())
+    while len(short_far) < 65000:
+        at = int(rng.integers(0, len(short_far) - 4))
+        short_far += short_far[at:at + int(rng.integers(3, 6))] + bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+    skew = np.minimum(rng.geometric(0.02, 60000), 255).astype(np.uint8).tobytes()  # code lengths 2..15
+    sets = [
+        (zlib.Z_HUFFMAN_ONLY, [bytes(rng.integers(0, 2, 60000, dtype=np.uint8)), bytes(65000), b"", b"a", bytes(rng.integers(0, 2, 7, dtype=np.uint8))]),
+        (zlib.Z_FIXED, [far[:20000], b"abc" * 9000, b"", far[:5]]),
+        (zlib.Z_RLE, [b"x" * 65000, b"xy" * 30000, b"xyz" * 20000, far[:100] + b"q" * 300 + far[:100]]),
+        (zlib.Z_DEFAULT_STRATEGY, [far + far, bytes(short_far[:65000]), skew, far[:1000] * 60, b"", b"z"]),
+    ]
+    for strategy, payloads in sets:
+        for level in (6, 9, 1):
+            blob, offs = _bgzf_file(payloads, level, strategy)
+            got, out, st, _ = _device_inflate(L, ctx, blob, offs)
+            assert got == sum(len(p) for p in payloads), L.spx_last_error()
+            assert all(s == 0 for s in st), (strategy, level, [k for k, s in enumerate(st) if s])
+            assert out == b"".join(payloads), (strategy, level)
     ctx.close()
 
 
