@@ -16,7 +16,9 @@
  * Writer = ptBlock_save_in_bed (:573-602): contigs in strcmp order, "ctg\tstart\tend+1[\tcount]".
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -57,17 +59,64 @@ static void parallel_sort(std::vector<T> &v, Cmp cmp, unsigned threads)
     }
 }
 
+static void merge_count_sorted(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &out, unsigned threads);
+
 /* coverage segmentation of blocks (any order); has_count=0: c ignored, output c = 0 */
-static void merge_count(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &out, unsigned threads = 1)
+static void merge_count(const std::vector<Blk3> &v_in, bool has_count, std::vector<Blk3> &out, unsigned threads = 1)
 {
     out.clear();
-    if (v.empty()) return;
+    if (v_in.empty()) return;
+    const std::vector<Blk3> &v = v_in;
     if (!has_count) {
         /* single-base blocks without counts (marker positions): the segmentation is the set of distinct positions */
         bool points = true;
         for (const Blk3 &b : v)
             if (b.s != b.e) { points = false; break; }
         if (points) {
+            /* dense sets (a run that relabels most reads puts tens of millions of positions on a few contigs): one bit per reference
+             * position between the smallest and the largest, set from all threads, read back in order -- O(n + range) instead of a sort */
+            int32_t lo = v[0].s, hi = v[0].s;
+            for (const Blk3 &b : v) { lo = std::min(lo, b.s); hi = std::max(hi, b.s); }
+            const uint64_t range = (uint64_t)((int64_t)hi - (int64_t)lo) + 1;
+            if (v.size() >= 65536 && range <= (uint64_t)v.size() * 64u) {
+                const size_t words = (size_t)((range + 63) / 64);
+                std::vector<std::atomic<uint64_t>> bits(words);
+                for (auto &w : bits) w.store(0, std::memory_order_relaxed);
+                const unsigned T = std::max(1u, threads);
+                auto run = [&](auto fn) {
+                    if (T == 1) { fn(0u); return; }
+                    std::vector<std::thread> th;
+                    for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t);
+                    for (auto &x : th) x.join();
+                };
+                run([&](unsigned t) {
+                    for (size_t i = v.size() * t / T, e = v.size() * (t + 1) / T; i < e; ++i) {
+                        const uint64_t d = (uint64_t)((int64_t)v[i].s - (int64_t)lo), bit = 1ull << (d & 63);
+                        std::atomic<uint64_t> &w = bits[(size_t)(d >> 6)];
+                        if (!(w.load(std::memory_order_relaxed) & bit)) w.fetch_or(bit, std::memory_order_relaxed); /* (most positions repeat) */
+                    }
+                });
+                std::vector<size_t> first(T + 1, 0);
+                run([&](unsigned t) {
+                    size_t n = 0;
+                    for (size_t w = words * t / T, e = words * (t + 1) / T; w < e; ++w) n += (size_t)__builtin_popcountll(bits[w].load(std::memory_order_relaxed));
+                    first[t + 1] = n;
+                });
+                for (unsigned t = 0; t < T; ++t) first[t + 1] += first[t];
+                out.resize(first[T]);
+                run([&](unsigned t) {
+                    size_t at = first[t];
+                    for (size_t w = words * t / T, e = words * (t + 1) / T; w < e; ++w) {
+                        uint64_t x = bits[w].load(std::memory_order_relaxed);
+                        while (x) {
+                            const int32_t p = (int32_t)((int64_t)lo + (int64_t)(w * 64 + (size_t)__builtin_ctzll(x)));
+                            out[at++] = {p, p, 0};
+                            x &= x - 1;
+                        }
+                    }
+                });
+                return;
+            }
             std::vector<int32_t> p(v.size());
             for (size_t i = 0; i < v.size(); ++i) p[i] = v[i].s;
             parallel_sort(p, std::less<int32_t>(), threads);
@@ -77,6 +126,11 @@ static void merge_count(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &
             return;
         }
     }
+    return merge_count_sorted(std::vector<Blk3>(v_in), has_count, out, threads);
+}
+
+static void merge_count_sorted(std::vector<Blk3> v, bool has_count, std::vector<Blk3> &out, unsigned threads)
+{
     parallel_sort(v, [](const Blk3 &a, const Blk3 &b) { return a.s != b.s ? a.s < b.s : a.e < b.e; }, threads);
     /* break points: every start, every end+1 */
     std::vector<int64_t> bp;
@@ -166,15 +220,27 @@ extern "C" int64_t spx_bedset_size(const spx_bedset *b)
 
 /* merge_and_save_blocks (src/secphase.c:59-72): merge per contig, write the BED.  The file is created even
  * when there is nothing to write (the WDLs glob for it, wdls/workflows/secphase.wdl:100-107). */
-static void put_i32(std::string &s, int32_t v)
+static char *put_i32(char *o, int32_t v)
 {
     char b[16];
     int n = 0;
     uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
     do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
     if (v < 0) b[n++] = '-';
-    while (n) s += b[--n];
+    while (n) *o++ = b[--n];
+    return o;
 }
+
+/* the text of some lines, written into one allocation (a line is at most name + 3 tabs + 3 numbers of 11 characters + newline) */
+struct BedText {
+    char *p = nullptr;
+    size_t n = 0;
+    BedText() = default;
+    BedText(const BedText &) = delete;
+    BedText &operator=(const BedText &) = delete;
+    BedText(BedText &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    ~BedText() { free(p); }
+};
 
 extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_count)
 {
@@ -184,8 +250,9 @@ extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_
     /* contigs are independent: merged and formatted on threads, written in strcmp order */
     std::vector<const std::pair<const std::string, std::vector<Blk3>> *> items;
     for (const auto &kv : b->per_contig) items.push_back(&kv);
-    std::vector<std::string> text(items.size());
+    std::vector<std::vector<BedText>> text(items.size()); /* per contig: its pieces in order */
     std::atomic<size_t> next(0);
+    std::atomic<bool> oom(false);
     const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     const unsigned inner = (unsigned)std::max<size_t>(1, hw / std::max<size_t>(1, items.size())); /* threads per contig when contigs are few */
     auto work = [&]() {
@@ -194,15 +261,33 @@ extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_
             const size_t k = next.fetch_add(1);
             if (k >= items.size()) break;
             merge_count(items[k]->second, print_count != 0, merged, inner);
-            std::string &t = text[k];
-            t.reserve(merged.size() * (items[k]->first.size() + 24));
-            for (const Blk3 &m : merged) {
-                if (m.e < m.s) continue;
-                t += items[k]->first; t += '\t';
-                put_i32(t, m.s); t += '\t';
-                put_i32(t, m.e + 1);
-                if (print_count) { t += '\t'; put_i32(t, m.c); }
-                t += '\n';
+            /* the text of a contig in `inner` pieces, formatted side by side */
+            const std::string &name = items[k]->first;
+            auto fmt = [&](size_t a, size_t b, BedText &t) {
+                if (b <= a) return;
+                t.p = (char *)malloc((b - a) * (name.size() + 40));
+                if (!t.p) { oom = true; return; }
+                char *o = t.p;
+                for (size_t i = a; i < b; ++i) {
+                    const Blk3 &m = merged[i];
+                    if (m.e < m.s) continue;
+                    memcpy(o, name.data(), name.size()); o += name.size();
+                    *o++ = '\t';
+                    o = put_i32(o, m.s); *o++ = '\t';
+                    o = put_i32(o, m.e + 1);
+                    if (print_count) { *o++ = '\t'; o = put_i32(o, m.c); }
+                    *o++ = '\n';
+                }
+                t.n = (size_t)(o - t.p);
+            };
+            const unsigned pieces = merged.size() >= 65536 ? inner : 1;
+            std::vector<BedText> &part = text[k];
+            part.resize(pieces);
+            if (pieces <= 1) fmt(0, merged.size(), part[0]);
+            else {
+                std::vector<std::thread> th;
+                for (unsigned q = 0; q < pieces; ++q) th.emplace_back([&, q]() { fmt(merged.size() * q / pieces, merged.size() * (q + 1) / pieces, part[q]); });
+                for (auto &x : th) x.join();
             }
         }
     };
@@ -213,9 +298,39 @@ extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_
         for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work);
         for (auto &t : th) t.join();
     }
-    bool ok = true;
-    for (const std::string &t : text)
-        if (!t.empty() && fwrite(t.data(), 1, t.size(), fp) != t.size()) ok = false;
+    bool ok = !oom;
+    /* the pieces go to their offsets side by side (a run that relabels most reads writes ~200 MB here; on tmpfs the copy is the cost) */
+    std::vector<const BedText *> flat;
+    std::vector<size_t> at;
+    size_t total = 0;
+    for (const auto &parts : text)
+        for (const BedText &t : parts)
+            if (t.n) { flat.push_back(&t); at.push_back(total); total += t.n; }
+    if (fflush(fp) != 0) ok = false;
+    const int fd = fileno(fp);
+    if (flat.size() < 2 || total < ((size_t)8 << 20)) {
+        for (const BedText *t : flat)
+            if (fwrite(t->p, 1, t->n, fp) != t->n) ok = false;
+    } else {
+        std::atomic<size_t> nx(0);
+        std::atomic<bool> bad(false);
+        auto wr = [&]() {
+            for (;;) {
+                const size_t k = nx.fetch_add(1);
+                if (k >= flat.size()) break;
+                size_t done = 0;
+                while (done < flat[k]->n) {
+                    const ssize_t w = pwrite(fd, flat[k]->p + done, flat[k]->n - done, (off_t)(at[k] + done));
+                    if (w <= 0) { bad = true; break; }
+                    done += (size_t)w;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < std::min<size_t>(hw, flat.size()); ++t) th.emplace_back(wr);
+        for (auto &t : th) t.join();
+        if (bad) ok = false;
+    }
     if (fclose(fp) != 0) ok = false;
     return ok ? SPX_OK : SPX_EINVAL;
 }

@@ -101,12 +101,19 @@ def test_bed_save_of_one_large_contig_on_several_threads(built, tmp_path):
             want = product_merge([[s, s + l] for s, l in zip(starts.tolist(), lens.tolist())], cnts.tolist())
         else:
             L.spx_bedset_add_points.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_int32]
-            L.spx_bedset_add_points(h, b"ctg", starts.ctypes.data_as(C.POINTER(C.c_int32)), n)
+            L.spx_bedset_add_points(h, b"ctg", starts.ctypes.data_as(C.POINTER(C.c_int32)), n)  # dense: one bit per position
+            far = np.array([2_000_000_000, 5, 1_999_999_999], np.int32)  # ... and a second contig that is sparse: sorted
+            L.spx_bedset_add_points(h, b"sparse", np.concatenate([starts[:70000] * 300, far]).astype(np.int32).ctypes.data_as(C.POINTER(C.c_int32)), 70003)
             want = product_merge([[s, s] for s in starts.tolist()], None)
+            want_sparse = product_merge([[s, s] for s in (starts[:70000].astype(np.int64) * 300).tolist() + far.tolist()], None)
         path = str(tmp_path / f"x{with_count}.bed")
         assert L.spx_bedset_save(h, path.encode(), with_count) == 0
         L.spx_bedset_free(h)
         got = [l.split("\t") for l in open(path).read().splitlines()]
+        if not with_count:
+            sp = [g for g in got if g[0] == "sparse"]
+            got = [g for g in got if g[0] == "ctg"]
+            assert [(int(g[1]), int(g[2])) for g in sp] == [(w[0], w[1] + 1) for w in want_sparse]
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert g[0] == "ctg" and int(g[1]) == w[0] and int(g[2]) == w[1] + 1 and (not with_count or int(g[3]) == w[2])
