@@ -379,14 +379,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
 }
 
 
-/* CRC-32 of every inflated block against the BGZF trailer's: one wavefront per block, 64 stripes (byte-table recurrence per lane, 16
- * bytes per load), folded with the GF(2) shift operator; status[b] 0 -> -4 on a mismatch */
+/* CRC-32 of every inflated block against the BGZF trailer's: one wavefront per block, 64 stripes of 16-byte loads, four bytes per step
+ * through four 256-entry tables (slicing by 4: the look-ups of a dword do not depend on each other), the stripes folded with the GF(2)
+ * shift operator; status[b] 0 -> -4 on a mismatch */
 __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restrict__ blocks, int32_t n_blocks, const uint8_t *__restrict__ outbuf,
                                                        int32_t *__restrict__ status)
 {
-    __shared__ uint32_t crc_tab[256];
-    crc_tab[threadIdx.x] = spxz::crc_table_entry(threadIdx.x);
-    __syncthreads();
+    __shared__ uint32_t tab[4][256]; /* tab[k][x] = CRC of byte x followed by k zero bytes */
+    {
+        const uint32_t t0 = spxz::crc_table_entry(threadIdx.x);
+        tab[0][threadIdx.x] = t0;
+        __syncthreads();
+        uint32_t c = t0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            c = tab[0][c & 0xffu] ^ (c >> 8);
+            tab[k][threadIdx.x] = c;
+        }
+        __syncthreads();
+    }
     const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     if (b >= n_blocks) return;
     const BlockDesc d = blocks[b];
@@ -397,11 +408,11 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restri
     const uint32_t head = min(n, (uint32_t)((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u));
     const uint32_t pieces = (n - head) / 16u, per = (pieces + 63u) / 64u;
     const uint32_t a_pc = min(pieces, per * (uint32_t)lane), e_pc = min(pieces, a_pc + per);
-    uint32_t a = head + 16u * a_pc, e = head + 16u * e_pc;
+    const uint32_t a = head + 16u * a_pc, e = head + 16u * e_pc;
     uint32_t c = 0xffffffffu;
     uint32_t len = e - a;
     if (lane == 0) {
-        for (uint32_t k = 0; k < head; ++k) c = crc_tab[(c ^ p[k]) & 0xff] ^ (c >> 8);
+        for (uint32_t k = 0; k < head; ++k) c = tab[0][(c ^ p[k]) & 0xff] ^ (c >> 8);
         len += head;
     }
     const uint4 *p16 = reinterpret_cast<const uint4 *>(p + a);
@@ -411,15 +422,14 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             c ^= ws[j];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) c = crc_tab[c & 0xff] ^ (c >> 8);
+            c = tab[3][c & 0xffu] ^ tab[2][(c >> 8) & 0xffu] ^ tab[1][(c >> 16) & 0xffu] ^ tab[0][c >> 24];
         }
     }
     /* the last stripe that has bytes takes the tail; with no whole piece at all that is lane 0 */
     const uint32_t tail0 = head + 16u * pieces;
     const uint32_t last_lane = pieces ? (pieces - 1u) / per : 0u;
     if ((uint32_t)lane == last_lane) {
-        for (uint32_t k = tail0; k < n; ++k) c = crc_tab[(c ^ p[k]) & 0xff] ^ (c >> 8);
+        for (uint32_t k = tail0; k < n; ++k) c = tab[0][(c ^ p[k]) & 0xff] ^ (c >> 8);
         len += n - tail0;
     }
     c ^= 0xffffffffu;
@@ -718,9 +728,10 @@ struct TokDec {
         int used = 0;
         uint32_t min_len;
         if (canonical<kNC>(mine, L->lit_sorted, L->lit_limit, L->lit_base, &used, &min_len) != 0) return -1;
-        /* literals gather in a register of G lanes between two steps of the reader (32 bits): with codes of >= 2 bits at most 16
-         * arrive, and the register is emptied at a step once it holds 16; a 1-bit code empties it at every step */
-        lit_room = (G == 32 && min_len >= 2u) ? 16u : 1u;
+        /* literals gather in a register of G lanes: a trip of the symbol loop adds up to three and makes room first; at a step of the
+         * reader the register is emptied once it is half full (one store per ~16 literals instead of one per literal) */
+        lit_room = (uint32_t)G / 2u;
+        (void)min_len;
         fill<true>(L->lit, LR, L->lit_sorted, used);
         uint32_t dmine[kND];
 #pragma unroll
@@ -852,10 +863,21 @@ struct TokDec {
             }
             uint32_t b = peek();
             int e = lit[b & ((1u << LR) - 1u)];
-            if (e >= 0) { /* a literal */
-                if (G < 32 && npend == (uint32_t)G) flush_literals();
+            if (e >= 0) { /* a literal -- and, seven times out of eight, another one behind it: the 32 bits at hand hold three codes of <= 9 bits */
+                if (npend > (uint32_t)G - 3u) flush_literals(); /* room for three */
                 push((uint32_t)e);
-                off += (uint32_t)e >> 8;
+                uint32_t used = (uint32_t)e >> 8;
+                const int e2 = lit[(b >> used) & ((1u << LR) - 1u)];
+                if (e2 >= 0) {
+                    push((uint32_t)e2);
+                    used += (uint32_t)e2 >> 8;
+                    const int e3 = lit[(b >> used) & ((1u << LR) - 1u)];
+                    if (e3 >= 0) {
+                        push((uint32_t)e3);
+                        used += (uint32_t)e3 >> 8;
+                    }
+                }
+                off += used;
                 continue;
             }
             uint32_t ue = (uint32_t)e & 0xffffu;
@@ -865,7 +887,7 @@ struct TokDec {
                 const uint32_t sym = r & 0xffffu;
                 if (sym > 285u) { rc = -1; break; }
                 if (sym < 256u) {
-                    if (npend == (uint32_t)G) flush_literals();
+                    if (npend > (uint32_t)G - 3u) flush_literals();
                     push(sym);
                     off += r >> 16;
                     continue;
