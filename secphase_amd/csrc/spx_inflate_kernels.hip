@@ -433,11 +433,16 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const BlockDesc *__restri
         len += n - tail0;
     }
     c ^= 0xffffffffu;
+    /* tree: lane l absorbs lane l + s (the bytes that FOLLOW its own): crc(A || B) = x^(8 |B|) * crc(A) + crc(B).  Every lane carries the
+     * operator of its own length along (one exponentiation per lane, then one multiplication per level) instead of raising x to the
+     * partner's length at every level: the exponentiations were two thirds of this kernel */
+    uint32_t pw = spxz::gf2_xpow8n(len);
     for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t oc = (uint32_t)__shfl_down((int)c, s), ol = (uint32_t)__shfl_down((int)len, s);
+        const uint32_t oc = (uint32_t)__shfl_down((int)c, s), ol = (uint32_t)__shfl_down((int)len, s), opw = (uint32_t)__shfl_down((int)pw, s);
         if ((lane & (2 * s - 1)) == 0) {
-            if (ol > 0) c = len > 0 ? spxz::crc_combine(c, oc, ol) : oc;
+            if (ol > 0) c = len > 0 ? (spxz::gf2_mul(opw, c) ^ oc) : oc;
             len += ol;
+            pw = spxz::gf2_mul(pw, opw);
         }
     }
     if (lane == 0 && c != d.crc) status[b] = -4;
