@@ -2,6 +2,7 @@
 stored / fixed / dynamic blocks, every compression level, data shaped like BAM records, random and degenerate inputs,
 damaged streams; the striped CRC-32 with the GF(2) combine against zlib.crc32."""
 import ctypes as C
+import os
 import zlib
 
 import numpy as np
@@ -187,6 +188,19 @@ def test_kernel_on_the_decode_kernels_special_paths(built):
             assert all(s == 0 for s in st), (strategy, level, [k for k, s in enumerate(st) if s])
             assert out == b"".join(payloads), (strategy, level)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SPX_INFLATE_TOK": "16"}, {"SPX_INFLATE_TOK": "0"}, {"SPX_INFLATE_TOK": "0", "SPX_INFLATE_LANES": "64"}],
+                         ids=["decode kernel, 16 lanes per block", "round 4's first kernel", "round 3's kernel"])
+def test_the_other_kernel_generations_still_agree_with_zlib(built, env):
+    """the kernels kept for comparisons run the same payloads in a child process (the choice is read once per process)"""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_kernel_equals_zlib or special_paths or damage_per_block"], env=dict(os.environ, **env), capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
 
 
 @pytest.mark.gpu
