@@ -19,11 +19,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <sys/mman.h>
+#include <fcntl.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -171,18 +175,42 @@ extern "C" int spx_merge_blocks_count(int32_t n, const int32_t *s, const int32_t
     return (int32_t)out.size();
 }
 
+/* single-base blocks without counts (marker positions) are kept as a SET while they arrive: one bit per reference position, in chunks
+ * of 65 536 positions that exist once a position falls into them.  A run that relabels most reads adds tens of millions of positions
+ * (each marker of each relabelled alignment) that collapse to a few million distinct ones: the bit costs less than the 12-byte block
+ * did, and what is left for the save is reading the bits in order. */
+struct PointSet {
+    static constexpr int kShift = 16, kWords = 1 << (kShift - 6);
+    std::vector<std::unique_ptr<uint64_t[]>> chunk;
+    int64_t added = 0;
+    void add(int32_t pos)
+    {
+        const size_t c = (size_t)((uint32_t)pos >> kShift);
+        if (c >= chunk.size()) chunk.resize(c + 1);
+        if (!chunk[c]) { chunk[c].reset(new uint64_t[kWords]); memset(chunk[c].get(), 0, sizeof(uint64_t) * kWords); }
+        const uint32_t d = (uint32_t)pos & ((1u << kShift) - 1u);
+        chunk[c][d >> 6] |= 1ull << (d & 63);
+        ++added;
+    }
+    bool empty() const { return added == 0; }
+};
+struct BedContig {
+    std::vector<Blk3> list; /* blocks with counts or of more than one base, and positions below 0 */
+    PointSet points;
+};
+
 struct spx_bedset {
-    std::map<std::string, std::vector<Blk3>> per_contig; /* std::map iterates in strcmp order for plain ASCII names */
-    /* callers pass the same name POINTERS over and over (the contig table of the assembly): pointer -> list, in front of
+    std::map<std::string, BedContig> per_contig; /* std::map iterates in strcmp order for plain ASCII names */
+    /* callers pass the same name POINTERS over and over (the contig table of the assembly): pointer -> entry, in front of
      * the string-keyed map (std::map nodes never move) */
-    std::unordered_map<const char *, std::pair<const std::string *, std::vector<Blk3> *>> by_ptr;
-    std::vector<Blk3> &list(const char *contig)
+    std::unordered_map<const char *, std::pair<const std::string *, BedContig *>> by_ptr;
+    BedContig &entry(const char *contig)
     {
         auto it = by_ptr.find(contig);
         /* (the text is compared too: an address may be re-used for another name by a caller with short-lived strings) */
         if (it != by_ptr.end() && strcmp(it->second.first->c_str(), contig) == 0) return *it->second.second;
         auto node = per_contig.find(contig);
-        if (node == per_contig.end()) node = per_contig.emplace(contig, std::vector<Blk3>()).first;
+        if (node == per_contig.end()) node = per_contig.emplace(contig, BedContig()).first;
         by_ptr[contig] = {&node->first, &node->second};
         return node->second;
     }
@@ -198,7 +226,7 @@ extern "C" void spx_bedset_free(spx_bedset *b) { delete b; }
 extern "C" int spx_bedset_add(spx_bedset *b, const char *contig, int32_t start, int32_t end, int32_t count)
 {
     if (!b || !contig) return SPX_EINVAL;
-    b->list(contig).push_back({start, end, count});
+    b->entry(contig).list.push_back({start, end, count});
     return SPX_OK;
 }
 /* n single-base blocks on one contig (the marker positions of one relabelled alignment): one look-up of the contig
@@ -207,16 +235,59 @@ extern "C" int spx_bedset_add_points(spx_bedset *b, const char *contig, const in
 {
     if (!b || !contig || (!pos && n > 0)) return SPX_EINVAL;
     if (n <= 0) return SPX_OK;
-    auto &v = b->list(contig); /* (no reserve: an exact reserve per call would defeat the vector's geometric growth) */
-    for (int32_t k = 0; k < n; ++k) v.push_back({pos[k], pos[k], 0});
+    BedContig &e = b->entry(contig);
+    for (int32_t k = 0; k < n; ++k) {
+        if (pos[k] >= 0) e.points.add(pos[k]);
+        else e.list.push_back({pos[k], pos[k], 0});
+    }
     return SPX_OK;
 }
 extern "C" int64_t spx_bedset_size(const spx_bedset *b)
 {
     int64_t n = 0;
-    if (b) for (const auto &kv : b->per_contig) n += (int64_t)kv.second.size();
+    if (b) for (const auto &kv : b->per_contig) n += (int64_t)kv.second.list.size() + kv.second.points.added;
     return n;
 }
+
+/* the positions of a point set in ascending order, as blocks {p, p, 0}: chunks are read side by side */
+static void points_in_order(const PointSet &ps, std::vector<Blk3> &out, unsigned threads)
+{
+    const size_t nc = ps.chunk.size();
+    std::vector<size_t> first(nc + 1, 0);
+    const unsigned T = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(1, nc)));
+    auto run = [&](auto fn) {
+        if (T == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+    };
+    run([&](unsigned t) {
+        for (size_t c = nc * t / T; c < nc * (t + 1) / T; ++c) {
+            size_t n = 0;
+            if (ps.chunk[c])
+                for (int w = 0; w < PointSet::kWords; ++w) n += (size_t)__builtin_popcountll(ps.chunk[c][w]);
+            first[c + 1] = n;
+        }
+    });
+    for (size_t c = 0; c < nc; ++c) first[c + 1] += first[c];
+    const size_t base = out.size();
+    out.resize(base + first[nc]);
+    run([&](unsigned t) {
+        for (size_t c = nc * t / T; c < nc * (t + 1) / T; ++c) {
+            if (!ps.chunk[c]) continue;
+            size_t at = base + first[c];
+            for (int w = 0; w < PointSet::kWords; ++w) {
+                uint64_t x = ps.chunk[c][w];
+                while (x) {
+                    const int32_t p = (int32_t)((c << PointSet::kShift) + (size_t)w * 64 + (size_t)__builtin_ctzll(x));
+                    out[at++] = {p, p, 0};
+                    x &= x - 1;
+                }
+            }
+        }
+    });
+}
+
 
 /* merge_and_save_blocks (src/secphase.c:59-72): merge per contig, write the BED.  The file is created even
  * when there is nothing to write (the WDLs glob for it, wdls/workflows/secphase.wdl:100-107). */
@@ -231,45 +302,90 @@ static char *put_i32(char *o, int32_t v)
     return o;
 }
 
-/* the text of some lines, written into one allocation (a line is at most name + 3 tabs + 3 numbers of 11 characters + newline) */
-struct BedText {
-    char *p = nullptr;
-    size_t n = 0;
-    BedText() = default;
-    BedText(const BedText &) = delete;
-    BedText &operator=(const BedText &) = delete;
-    BedText(BedText &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    ~BedText() { free(p); }
-};
+static inline int digits_i32(int32_t v)
+{
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    int n = v < 0 ? 2 : 1;
+    while (u >= 10) { u /= 10; ++n; }
+    return n;
+}
 
 extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_count)
 {
     if (!b || !path) return SPX_EINVAL;
-    FILE *fp = fopen(path, "w");
-    if (!fp) return SPX_EINVAL;
-    /* contigs are independent: merged and formatted on threads, written in strcmp order */
-    std::vector<const std::pair<const std::string, std::vector<Blk3>> *> items;
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return SPX_EINVAL;
+    const bool timing = getenv("SPX_TIMING") != nullptr;
+    const auto t_a = std::chrono::steady_clock::now();
+    /* 1. contigs are independent: merged on threads (a handful of contigs: several threads inside each) */
+    std::vector<const std::pair<const std::string, BedContig> *> items;
     for (const auto &kv : b->per_contig) items.push_back(&kv);
-    std::vector<std::vector<BedText>> text(items.size()); /* per contig: its pieces in order */
-    std::atomic<size_t> next(0);
-    std::atomic<bool> oom(false);
+    std::vector<std::vector<Blk3>> merged(items.size());
     const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const unsigned inner = (unsigned)std::max<size_t>(1, hw / std::max<size_t>(1, items.size())); /* threads per contig when contigs are few */
-    auto work = [&]() {
-        std::vector<Blk3> merged;
-        for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= items.size()) break;
-            merge_count(items[k]->second, print_count != 0, merged, inner);
-            /* the text of a contig in `inner` pieces, formatted side by side */
-            const std::string &name = items[k]->first;
-            auto fmt = [&](size_t a, size_t b, BedText &t) {
-                if (b <= a) return;
-                t.p = (char *)malloc((b - a) * (name.size() + 40));
-                if (!t.p) { oom = true; return; }
-                char *o = t.p;
-                for (size_t i = a; i < b; ++i) {
-                    const Blk3 &m = merged[i];
+    const unsigned inner = (unsigned)std::max<size_t>(1, hw / std::max<size_t>(1, items.size()));
+    auto on_threads = [&](size_t n_tasks, const std::function<void(size_t)> &task) {
+        std::atomic<size_t> next(0);
+        auto loop = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n_tasks) break;
+                task(k);
+            }
+        };
+        const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(hw, n_tasks));
+        if (nthr <= 1) { loop(); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; ++t) th.emplace_back(loop);
+        for (auto &t : th) t.join();
+    };
+    on_threads(items.size(), [&](size_t k) {
+        const BedContig &bc = items[k]->second;
+        if (bc.list.empty()) points_in_order(bc.points, merged[k], inner); /* marker positions only: the set IS the merged list */
+        else if (bc.points.empty()) merge_count(bc.list, print_count != 0, merged[k], inner);
+        else { /* both kinds on one contig: the general merge over all of them */
+            std::vector<Blk3> all(bc.list);
+            points_in_order(bc.points, all, inner);
+            merge_count(all, print_count != 0, merged[k], inner);
+        }
+    });
+    /* 2. the text in pieces of <= 128 k lines: their exact sizes first, so that every piece knows its place in the file */
+    struct Piece { size_t k, a, b, bytes, at; };
+    std::vector<Piece> pieces;
+    for (size_t k = 0; k < items.size(); ++k)
+        for (size_t a = 0; a < merged[k].size(); a += (size_t)1 << 17) pieces.push_back({k, a, std::min(merged[k].size(), a + ((size_t)1 << 17)), 0, 0});
+    on_threads(pieces.size(), [&](size_t q) {
+        Piece &pc = pieces[q];
+        const size_t fixed = items[pc.k]->first.size() + 3 + (print_count ? 1 : 0);
+        size_t n = 0;
+        for (size_t i = pc.a; i < pc.b; ++i) {
+            const Blk3 &m = merged[pc.k][i];
+            if (m.e < m.s) continue;
+            n += fixed + (size_t)digits_i32(m.s) + (size_t)digits_i32(m.e + 1) + (print_count ? (size_t)digits_i32(m.c) : 0);
+        }
+        pc.bytes = n;
+    });
+    size_t total = 0;
+    for (Piece &pc : pieces) { pc.at = total; total += pc.bytes; }
+    const auto t_b = std::chrono::steady_clock::now();
+    /* 3. formatted straight into the file's pages (a run that relabels most reads writes ~200 MB here: no second copy); a file that
+     * cannot be mapped gets the same bytes through one buffer */
+    bool ok = true;
+    if (total) {
+        char *map = nullptr, *buf = nullptr;
+        if (ftruncate(fd, (off_t)total) == 0) {
+            void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) map = (char *)m;
+        }
+        if (!map) buf = (char *)malloc(total);
+        char *dst = map ? map : buf;
+        if (!dst) ok = false;
+        else {
+            on_threads(pieces.size(), [&](size_t q) {
+                const Piece &pc = pieces[q];
+                const std::string &name = items[pc.k]->first;
+                char *o = dst + pc.at;
+                for (size_t i = pc.a; i < pc.b; ++i) {
+                    const Blk3 &m = merged[pc.k][i];
                     if (m.e < m.s) continue;
                     memcpy(o, name.data(), name.size()); o += name.size();
                     *o++ = '\t';
@@ -278,59 +394,23 @@ extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_
                     if (print_count) { *o++ = '\t'; o = put_i32(o, m.c); }
                     *o++ = '\n';
                 }
-                t.n = (size_t)(o - t.p);
-            };
-            const unsigned pieces = merged.size() >= 65536 ? inner : 1;
-            std::vector<BedText> &part = text[k];
-            part.resize(pieces);
-            if (pieces <= 1) fmt(0, merged.size(), part[0]);
+            });
+            if (map) { if (munmap(map, total) != 0) ok = false; }
             else {
-                std::vector<std::thread> th;
-                for (unsigned q = 0; q < pieces; ++q) th.emplace_back([&, q]() { fmt(merged.size() * q / pieces, merged.size() * (q + 1) / pieces, part[q]); });
-                for (auto &x : th) x.join();
-            }
-        }
-    };
-    const unsigned nthr = (unsigned)std::max<size_t>(1, std::min<size_t>(hw, items.size()));
-    if (nthr <= 1) work();
-    else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nthr; ++t) th.emplace_back(work);
-        for (auto &t : th) t.join();
-    }
-    bool ok = !oom;
-    /* the pieces go to their offsets side by side (a run that relabels most reads writes ~200 MB here; on tmpfs the copy is the cost) */
-    std::vector<const BedText *> flat;
-    std::vector<size_t> at;
-    size_t total = 0;
-    for (const auto &parts : text)
-        for (const BedText &t : parts)
-            if (t.n) { flat.push_back(&t); at.push_back(total); total += t.n; }
-    if (fflush(fp) != 0) ok = false;
-    const int fd = fileno(fp);
-    if (flat.size() < 2 || total < ((size_t)8 << 20)) {
-        for (const BedText *t : flat)
-            if (fwrite(t->p, 1, t->n, fp) != t->n) ok = false;
-    } else {
-        std::atomic<size_t> nx(0);
-        std::atomic<bool> bad(false);
-        auto wr = [&]() {
-            for (;;) {
-                const size_t k = nx.fetch_add(1);
-                if (k >= flat.size()) break;
                 size_t done = 0;
-                while (done < flat[k]->n) {
-                    const ssize_t w = pwrite(fd, flat[k]->p + done, flat[k]->n - done, (off_t)(at[k] + done));
-                    if (w <= 0) { bad = true; break; }
+                while (done < total) {
+                    const ssize_t w = pwrite(fd, buf + done, total - done, (off_t)done);
+                    if (w <= 0) { ok = false; break; }
                     done += (size_t)w;
                 }
+                if (ok && ftruncate(fd, (off_t)total) != 0) ok = false;
             }
-        };
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < std::min<size_t>(hw, flat.size()); ++t) th.emplace_back(wr);
-        for (auto &t : th) t.join();
-        if (bad) ok = false;
+        }
+        free(buf);
     }
-    if (fclose(fp) != 0) ok = false;
+    if (close(fd) != 0) ok = false;
+    if (timing)
+        fprintf(stderr, "[spx timing] BED %s: merge + sizes %.3f s, text into the file %.3f s (%zu bytes)\n", path, std::chrono::duration<double>(t_b - t_a).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count(), total);
     return ok ? SPX_OK : SPX_EINVAL;
 }

@@ -117,3 +117,36 @@ def test_bed_save_of_one_large_contig_on_several_threads(built, tmp_path):
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert g[0] == "ctg" and int(g[1]) == w[0] and int(g[2]) == w[1] + 1 and (not with_count or int(g[3]) == w[2])
+
+
+def test_bed_point_sets_and_blocks_on_one_contig(built, tmp_path):
+    """marker positions are kept as a set of bits while they arrive; blocks on the same contig go through the general merge together
+    with them -- with and without counts the text equals the merge of everything as plain blocks"""
+    L = api.lib()
+    L.spx_bedset_add_points.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.c_int32]
+    rng = np.random.default_rng(9)
+    pts = np.concatenate([rng.integers(0, 300_000, 5000), rng.integers(2_000_000, 2_000_400, 300), [0, 65535, 65536, 131071]]).astype(np.int32)
+    blocks = [[int(s), int(s + l)] for s, l in zip(rng.integers(0, 300_000, 400), rng.integers(0, 3000, 400))]
+    cnts = [int(c) for c in rng.integers(1, 4, 400)]
+    for with_count in (0, 1):
+        h = C.c_void_p()
+        assert L.spx_bedset_create(C.byref(h)) == 0
+        for k in range(0, len(pts), 97):  # in several calls, like one alignment at a time
+            part = np.ascontiguousarray(pts[k:k + 97])
+            L.spx_bedset_add_points(h, b"both", part.ctypes.data_as(C.POINTER(C.c_int32)), len(part))
+        L.spx_bedset_add_points(h, b"only_points", pts.ctypes.data_as(C.POINTER(C.c_int32)), len(pts))
+        for (s, e), c in zip(blocks, cnts):
+            L.spx_bedset_add(h, b"both", s, e, c)
+        assert L.spx_bedset_size(h) == 2 * len(pts) + len(blocks)
+        path = str(tmp_path / f"m{with_count}.bed")
+        assert L.spx_bedset_save(h, path.encode(), with_count) == 0
+        L.spx_bedset_free(h)
+        got = [l.split("\t") for l in open(path).read().splitlines()]
+        as_blocks = [[int(p), int(p)] for p in pts.tolist()]
+        want_both = product_merge(as_blocks + blocks, ([0] * len(as_blocks) + cnts) if with_count else None)
+        want_pts = product_merge(as_blocks, ([0] * len(as_blocks)) if with_count else None)
+        for name, want in (("both", want_both), ("only_points", want_pts)):
+            g = [x for x in got if x[0] == name]
+            assert [(int(x[1]), int(x[2])) for x in g] == [(w[0], w[1] + 1) for w in want], name
+            if with_count:
+                assert [int(x[3]) for x in g] == [w[2] for w in want], name
