@@ -300,6 +300,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "[%s] %s: %s\n", timestamp(), spx_strerror(rc), spx_last_error());
         die(1);
     }
+    const double t_dstart = now_s();
     { /* the assembly into every device's HBM, in parallel */
         std::vector<std::thread> th;
         for (int d = 0; d < n_dev; ++d)
@@ -346,8 +347,8 @@ int main(int argc, char *argv[])
 
     fprintf(stderr, "[%s] Started parsing alignments\n", timestamp());
     if (getenv("SPX_TIMING"))
-        fprintf(stderr, "[%s] start-up %.3f s: BAM open (header) %.3f, FASTA parse %.3f, waiting for the device context(s) %.3f, reference to HBM %.3f\n",
-                timestamp(), t_ref - t_proc0, t_bam_open - t_proc0, t_fasta - t_bam_open, t_ctx - t_fasta, t_ref - t_ctx);
+        fprintf(stderr, "[%s] start-up %.3f s: BAM open (header) %.3f, FASTA parse %.3f, waiting for the device context(s) %.3f, input pipelines started %.3f, reference to HBM %.3f\n",
+                timestamp(), t_ref - t_proc0, t_bam_open - t_proc0, t_fasta - t_bam_open, t_ctx - t_fasta, t_dstart - t_ctx, t_ref - t_dstart);
     long long n_alns = 0, n_reads = 0, n_modified = 0, n_rejected = 0;
     double t_read = 0, t_wait = 0, t_out = 0, t_start = now_s(), t_hostprep = 0, t_kernel = 0;
     double t_fin = 0;
