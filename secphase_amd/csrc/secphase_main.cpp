@@ -236,6 +236,10 @@ int main(int argc, char *argv[])
     /* ---- start-up, overlapped: (a) one thread per device initialises HIP and creates the scoring context, (b) the BAM
      * reader starts inflating and cutting batches right away, (c) this thread parses the FASTA; then the reference goes
      * to every device and the loop starts with batches already waiting ---- */
+    /* (device-resident input stages nothing on the host: the contexts need not pin their 512 MB staging ring behind our back -- 0.15 s of
+     * pinning that the input pipelines' own pinned buffers queued behind, and as much again when the contexts are destroyed; a host-side
+     * staging that happens after all allocates its chunks when it needs them) */
+    if (marker_mode && !write_bam && !host_input) setenv("SPX_NO_WARM", "1", 0);
     std::vector<spx_ctx *> ctxs((size_t)n_dev, nullptr);
     std::vector<int> ctx_rc((size_t)n_dev, SPX_OK);
     std::vector<std::string> ctx_err((size_t)n_dev);
@@ -524,7 +528,7 @@ int main(int argc, char *argv[])
     /* device input: the input pipelines and the scoring contexts are done -- their device and pinned memory goes back on a
      * thread of its own while the BED sets are merged and written (0.1-0.3 s of host work that needs none of it) */
     std::thread teardown;
-    double t_teardown = 0;
+    double t_teardown = 0, t_teardown_in = 0;
     int64_t dbam_nseg = 0, dbam_up = 0;
     double dbam_sec[7] = {0};
     if (dev_input) spx_dbam_stats(dbam, &dbam_nseg, &dbam_up, dbam_sec);
@@ -533,6 +537,7 @@ int main(int argc, char *argv[])
         teardown = std::thread([&] {
             const double t0 = now_s();
             spx_dbam_close(dbam);
+            t_teardown_in = now_s() - t0;
             for (spx_ctx *c_ : ctxs) spx_destroy(c_);
             t_teardown = now_s() - t0;
         });
@@ -593,7 +598,8 @@ int main(int argc, char *argv[])
     if (!early_teardown) for (spx_ctx *c_ : ctxs) spx_destroy(c_);
     const double t_end3 = now_s();
     if (early_teardown && getenv("SPX_TIMING"))
-        fprintf(stderr, "[%s] input pipelines and contexts closed beside the BED merge: %.3f s\n", timestamp(), t_teardown);
+        fprintf(stderr, "[%s] input pipelines and contexts closed beside the BED merge: %.3f s (input pipelines %.3f, contexts %.3f)\n", timestamp(), t_teardown,
+                t_teardown_in, t_teardown - t_teardown_in);
     spx_fasta_free(fa);
     if (getenv("SPX_TIMING")) {
         fprintf(stderr, "[%s] wind-down: BED merge + write %.3f s, closing the reader %.3f s, the context(s) %.3f s; whole process %.3f s\n", timestamp(),

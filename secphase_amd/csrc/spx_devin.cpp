@@ -122,6 +122,7 @@ struct spx_dbam {
     spx_params par;
     int32_t max_groups = 95000, ahead = 3;
     int64_t seg_bytes = (int64_t)1 << 30, carry_cap = (int64_t)256 << 20;
+    size_t carry_host_cap = 0; /* bytes of the pinned carry_host buffer */
     int64_t seg_first = 0; /* > 0: the first segment of every lane has this size, each following one twice its predecessor's up to seg_bytes */
     std::vector<Lane *> lanes;
     /* cutting segments (any uploader, under cut_mu) */
@@ -733,6 +734,16 @@ int Lane::parse(Seg *s)
         if (cl2 > d->carry_cap || cl2 < 0)
             return fail_here("a read group (or a record) is larger than the carry buffer of the device input (SPX_DIN_CARRY_MB); use --hostInput", SPX_EUNSUPPORTED);
         if (cl2 > 0) {
+            if ((size_t)cl2 + 64 > d->carry_host_cap) { /* (this segment has consumed its own carry: nobody reads the buffer now) */
+                (void)hipHostFree(d->carry_host);
+                d->carry_host = nullptr;
+                d->carry_host_cap = std::min<size_t>((size_t)d->carry_cap, (size_t)cl2 * 2) + 64;
+                if (hipHostMalloc((void **)&d->carry_host, d->carry_host_cap, hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    d->carry_host_cap = 0;
+                    return fail_here("pinned memory for the carry buffer", SPX_ENOMEM);
+                }
+            }
             DCHK(hipMemcpyAsync(d->carry_host, S.d_buf + C.carry_start, (size_t)cl2, hipMemcpyDeviceToHost, in_stream));
             DCHK(hipStreamSynchronize(in_stream));
         }
@@ -976,7 +987,10 @@ extern "C" int spx_dbam_start(spx_dbam *d, spx_ctx *const *ctxs, int32_t n_ctx, 
     const int32_t nt = spx_internal_bam_tmap(d->hdr, d->tmap.data(), (int32_t)d->tmap.size());
     if (nt > (int32_t)d->tmap.size()) { d->tmap.resize((size_t)nt); spx_internal_bam_tmap(d->hdr, d->tmap.data(), nt); }
     d->tmap.resize((size_t)nt);
-    if (hipHostMalloc((void **)&d->carry_host, (size_t)d->carry_cap + 64, hipHostMallocDefault) != hipSuccess) {
+    /* (the carry between two segments is a few hundred KB -- one open name group; the device buffers reserve carry_cap for it, the pinned
+     * host buffer it travels through starts small and grows when a hand-over needs more: pinning 256 MB up front was 0.1 s of start-up) */
+    d->carry_host_cap = std::min<size_t>((size_t)d->carry_cap, (size_t)4 << 20) + 64;
+    if (hipHostMalloc((void **)&d->carry_host, d->carry_host_cap, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         spx_internal_set_error("pinned memory for the carry buffer");
         return SPX_ENOMEM;

@@ -153,7 +153,7 @@ def main():
         got = open(os.path.join(outd, "e2e.out.log"), "rb").read()
         same = got[:len(want)] == want and (args.groups > ncheck or len(got) == len(want))
     size = os.path.getsize(bam)
-    keep = ("start-up", "time in the scoring loop", "finalise", "wind-down", "inflate chunks", "reader closed", "CPU time", "device input:", "hipMalloc")
+    keep = ("start-up", "time in the scoring loop", "finalise", "wind-down", "inflate chunks", "reader closed", "CPU time", "device input:", "hipMalloc", "closed beside", "BED ")
     print(json.dumps({"groups": args.groups, "platform": args.platform, "devices": args.devices, "bam_bytes": size, "wall_s": round(wall, 3), "runs_wall_s": walls, "host_input": args.host_input,
                       "groups_per_s": round(args.groups / wall, 1), "GB_bam_per_s": round(size / wall / 1e9, 4),
                       "cpu_oracle_groups_per_s": round(ncheck / cpu, 1) if cpu else None, "cpu_threads": args.threads, "cli_threads": cli_threads,
