@@ -1,14 +1,21 @@
 /*
- * spx_inflate_kernels.hip -- BGZF inflate on gfx950: ONE WAVEFRONT PER BGZF BLOCK (a block is an independent DEFLATE
- * stream of at most 64 KB), the decoder core of spx_inflate.h.
+ * spx_inflate_kernels.hip -- BGZF inflate on gfx950 (a BGZF block is an independent DEFLATE stream of at most 64 KB).
  *
  * What replaces what: htslib inflates every block on the reading thread (bgzf_read_block under sam_read1,
  * /root/reference/programs/src/secphase.c:268); the host reader of spx_io.cpp does it on a thread pool.  The MI355X boxes
  * give a container ~16 cores of CPU time, which caps host inflate at ~10 GB/s of inflated bytes (~150 k HiFi groups/s)
- * beside a device that scores 780 k groups/s -- so the compressed bytes cross PCIe (26 KB per group instead of 57) and
+ * beside a device that scores 800 k groups/s -- so the compressed bytes cross PCIe (26 KB per group instead of 57) and
  * are inflated here.
  *
- * Mapping onto a wavefront:
+ * Three generations live in this file (DESIGN.md 3.4 has the measurements; tools/inflate_bench.py runs each of them alone):
+ *   1. bgzf_inflate_kernel<LR,DR>            round 3: ONE WAVEFRONT PER BLOCK, the decode on the scalar unit (below)         16.7 GB/s
+ *   2. bgzf_inflate_g_kernel<G,LR,DR,R,W>    round 4: 64 / G blocks per wavefront, the decode on the vector ALU, ring in LDS  26 GB/s
+ *   3. bgzf_decode2_kernel<G,W> + bgzf_resolve_kernel + bgzf_crc_kernel   round 4, the default: Huffman decode (literals placed,
+ *      matches left as holes), LZ77 copies 64 at a time, CRC -- spx_launch_bgzf_inflate2                                     50 GB/s
+ * 1 and 2 run the decoder core of spx_inflate.h (shared with the host build that the CPU tests check against zlib); 3 has a
+ * decoder of its own, written for the lane group (TokDec).
+ *
+ * Generation 1, mapping onto a wavefront:
  *   - the bit-serial Huffman decode is WAVE-UNIFORM: every lane executes the same decode of the same block, so the
  *     compiler keeps bit buffer, counters and table indices in SGPRs / on the scalar unit; the root tables (11-bit
  *     literal/length, 9-bit distance) live in LDS and are read back through v_readfirstlane;
