@@ -181,6 +181,65 @@ def from_bam_leg(args, genome, record_chunks, n_groups, ncpu, oracle_log, oracle
     return res
 
 
+def guard_exposure(genome, params, first, n_groups, ctx, ncpu):
+    """PARITY-UNPINNED exposure of this workload (include/spx.h SPX_GUARD_*): how many DP problems lie in the regime
+    in which the two readings of probaln.c's terminal guard differ (l_query <= bw and 2*bw+1 > l_ref), and how many records of the
+    relabel list change when the reading is flipped -- from a CPU run of the ORACLE over `n_groups` groups under both readings
+    (checker only; nothing here is timed), and from the HIP path over the same groups under both readings."""
+    import numpy as np
+    from oracle import orc
+    from secphase_amd import api
+    sub = genome.reads(first, n_groups)
+    plan = api.Plan(genome.ref, sub.batch, params)
+    v = plan.view
+    n = int(v.n_problems)
+    L_ = np.ctypeslib.as_array(v.L, shape=(n,)) if n else np.zeros(0, np.int32)
+    R_ = np.ctypeslib.as_array(v.R, shape=(n,)) if n else np.zeros(0, np.int32)
+    bw = np.ctypeslib.as_array(v.bw, shape=(n,)) if n else np.zeros(0, np.int32)
+    regime = int(((L_ <= bw) & (2 * bw + 1 > R_)).sum())
+    res = {"groups": n_groups, "dp_problems": n, "guard_regime_problems": regime, "guard_regime_fraction": round(regime / max(1, n), 5),
+           "default_reading": "band (u >= bw2*3+3)"}
+    d = tempfile.mkdtemp(prefix="spx_guard_")
+
+    def records_of(path):
+        out = {}
+        for rec in open(path).read().split("\n\n"):
+            ln = rec.strip("\n").split("\n")
+            if len(ln) >= 2 and ln[1].startswith("$"):
+                out[ln[1]] = rec
+        return out
+
+    try:
+        logs, scored = {}, {}
+        t0 = time.perf_counter()
+        for name, reading in (("band", 0), ("row", 1)):
+            orc.set_terminal_guard(reading)
+            logs[name] = os.path.join(d, f"oracle.{name}.out.log")
+            _, r_ = orc.run_batch(sub.batch, genome.ref, params, threads=min(ncpu, 64), seed=1, reuse_scratch=True, log_path=logs[name])
+            scored[name] = [[r_[g].score[a] for a in range(max(r_[g].n_aln, 0))] + [r_[g].best_idx] for g in range(n_groups)]
+        orc.set_terminal_guard(0)
+        a, b = records_of(logs["band"]), records_of(logs["row"])
+        res["oracle"] = {"relabel_records_band": len(a), "relabel_records_row": len(b),
+                         "relabel_records_that_differ": sum(1 for k in set(a) | set(b) if a.get(k) != b.get(k)),
+                         "groups_whose_scores_or_decision_differ": sum(1 for x, y in zip(scored["band"], scored["row"]) if x != y),
+                         "seconds": round(time.perf_counter() - t0, 1)}
+        if ctx is not None:
+            gpu = {}
+            for name, reading in (("band", 0), ("row", 1)):
+                api.set_terminal_guard(reading)
+                out, _ = ctx.score_batch(sub.batch, params, finalize_seed=1)
+                gpu[name] = [[out[g].score[a_] for a_ in range(max(out[g].n_aln, 0))] + [out[g].best_idx] for g in range(n_groups)]
+            api.set_terminal_guard(0)
+            res["hip_path"] = {"groups_whose_scores_or_decision_differ": sum(1 for x, y in zip(gpu["band"], gpu["row"]) if x != y),
+                               "equals_oracle_under_band": gpu["band"] == scored["band"], "equals_oracle_under_row": gpu["row"] == scored["row"]}
+    finally:
+        orc.set_terminal_guard(0)
+        api.set_terminal_guard(0)
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def also_leg(platform, steps, warmup):
     """the other BASELINE workloads on one GPU, each as a child process of its own (own context, own HBM): a short run of
     this very script; its JSON line is returned (cut down to the figures the headline has)"""
@@ -213,7 +272,7 @@ def also_leg(platform, steps, warmup):
                          "traffic": r.get("traffic"), "phase": r.get("phase")},
             "verified_timed_groups": d["config"].get("verified_timed_groups"),
             "verified_own_relabel_list": (d["config"].get("verified_own_relabel_list") or {}).get("oracle_list_is_byte_prefix_of_this_runs_list"),
-            "from_bam": d.get("from_bam"),
+            "from_bam": d.get("from_bam"), "guard_exposure": d.get("guard_exposure"),
             "kernel_ms_per_step": d.get("kernel_ms_per_step"), "cpu_baseline": d.get("cpu_baseline"), "wall_s": round(dt, 1)}
 
 
@@ -245,6 +304,9 @@ def main():
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU baseline after one warm-up; the median is reported")
     ap.add_argument("--cpu-threads", type=int, default=0, help="thread count of the CPU baseline (0: all hardware threads and 32, the better one)")
     ap.add_argument("--verify", type=int, default=256, help="groups checked against the oracle before timing")
+    ap.add_argument("--guard-exposure", type=int, default=-1, metavar="N",
+                    help="groups of the workload run through the oracle (CPU) and the HIP path under BOTH readings of probaln.c's terminal guard "
+                         "(parity-unpinned switch, include/spx.h); -1: 4096 for --platform ont, 0 otherwise")
     ap.add_argument("--keep-log", default="", metavar="PATH", help="tests: rank 0 copies the relabel list of the whole run (set-up, warm-up and timed "
                     "steps: one rand() stream) to PATH, and every rank writes PATH.rank<r>.json = which generator ranges made up its batches "
                     "and the order the batches were run in")
@@ -423,6 +485,13 @@ def main():
             if not ok:
                 sys.exit(f"parity check failed on group {i}: GPU result differs from the oracle")
         verified = nchk
+    guard_exp = None
+    n_ge = args.guard_exposure if args.guard_exposure >= 0 else (4096 if ont else 0)
+    if rank == 0 and world == 1 and n_ge > 0 and not args.kernel_only:
+        try:
+            guard_exp = guard_exposure(genome, params, first, min(n_ge, gps), ctx, ncpu)
+        except Exception as ex:  # noqa: BLE001  (a side figure must not cost the line its headline)
+            guard_exp = {"error": str(ex)}
 
     def ctx_sync():
         api._chk(L.spx_sync(ctx.h), "spx_sync")
@@ -852,6 +921,8 @@ def main():
             "dp_problems_per_s": round(n_prob_all * args.steps / elapsed, 1),
             "setup_s": {"genome": round(t_genome, 2), "generate": round(t_gen, 2), "stage_records_to_hbm": round(t_stage, 2)},
         }
+        if guard_exp is not None:
+            line["guard_exposure"] = guard_exp
         if host_leg:
             hs, el_h = host_leg
             line["pipelined_from_host"] = {"value": round(n_disp * hs / el_h, 2), "unit": "groups/s", "steps": hs,

@@ -260,6 +260,18 @@ int spx_probaln_posteriors(spx_ctx *ctx, int32_t n, const uint8_t *ref, const in
                            const int64_t *qry_off, const int32_t *set_q, const spx_probaln_par *pars, int32_t which,
                            double *scale, double *zM, double *zI);
 
+/* PARITY-UNPINNED switch.  htslib's probaln.c guards the termination sum s[l_query+1] and the backward start with
+ * `if (u < 3 || u >= LIMIT) continue;`.  No htslib exists on the build machine, and two recollections of LIMIT in release 1.17 disagree:
+ *   SPX_GUARD_BAND (default): bw2*3+3 (kprobaln's band test);  SPX_GUARD_ROW: i_dim-3 (the shrunken row's length).
+ * They differ for one cell only -- column l_ref of row l_query when l_query <= bw && 2*bw+1 > l_ref (reached by `--ont -b 50` on blocks of
+ * <= 50 bases) -- which the ROW reading leaves out.  The setting is process-wide, is read when a work list is prepared (work lists already
+ * prepared keep theirs) and is honoured by every DP kernel and by spx_probaln_glocal; the environment variable SPX_TERMINAL_GUARD=band|row
+ * sets the initial value.  Call sites replaced: /root/reference/programs/submodules/ptMarker/ptMarker.c:754-757. */
+#define SPX_GUARD_BAND 0
+#define SPX_GUARD_ROW 1
+int spx_set_terminal_guard(int reading);
+int spx_get_terminal_guard(void);
+
 /* ---- BED side outputs (src/secphase.c:59-72,201-212,713-732; ptBlock.c:228-428,573-602) ------------ */
 typedef struct spx_bedset spx_bedset;
 int spx_bedset_create(spx_bedset **out);

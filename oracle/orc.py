@@ -73,6 +73,9 @@ def _load(path):
                                      C.POINTER(C.c_int), u8p]
     L.orc_phred_from_posterior.restype = C.c_int
     L.orc_phred_from_posterior.argtypes = [C.c_double]
+    L.orc_set_terminal_guard.argtypes = [C.c_int]
+    L.orc_set_terminal_guard.restype = None
+    L.orc_get_terminal_guard.restype = C.c_int
     L.orc_set_scratch_reuse.argtypes = [C.c_int]
     L.orc_set_scratch_reuse.restype = None
     L.orc_set_reference_overheads.argtypes = [C.c_int]
@@ -108,6 +111,18 @@ def _load(path):
     L.orc_walk_cigar.restype = C.c_int
     L.orc_walk_cigar.argtypes = [C.POINTER(SpxBatch), C.c_int, C.POINTER(C.POINTER(Op))]
     return L
+
+
+GUARD_BAND, GUARD_ROW = 0, 1
+
+
+def set_terminal_guard(reading, variant=None):
+    """which reading of probaln.c's terminal guard the oracle follows (probaln_oracle.c, GUARD VARIANTS)"""
+    lib(variant).orc_set_terminal_guard(int(reading))
+
+
+def get_terminal_guard(variant=None):
+    return lib(variant).orc_get_terminal_guard()
 
 
 def probaln_posteriors(ref, query, set_q, d, e, bw):

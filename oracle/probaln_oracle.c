@@ -108,6 +108,19 @@ static double *scratch_zeroed(size_t n_doubles)
     return t_buf;
 }
 
+/* which reading of the terminal guard the oracle follows: 0 = `u >= bw2*3+3` (default), 1 = `u >= i_dim-3`.  Process-wide; initial
+ * value from SPX_TERMINAL_GUARD (band|row), like the product's switch (include/spx.h spx_set_terminal_guard). */
+static int g_term_guard = -1;
+int orc_get_terminal_guard(void)
+{
+    if (g_term_guard < 0) {
+        const char *e = getenv("SPX_TERMINAL_GUARD");
+        g_term_guard = (e && (!strcmp(e, "row") || !strcmp(e, "1") || !strcmp(e, "idim"))) ? 1 : 0;
+    }
+    return g_term_guard;
+}
+void orc_set_terminal_guard(int reading) { g_term_guard = reading ? 1 : 0; }
+
 static double *g_cap_s = NULL, *g_cap_zM = NULL, *g_cap_zI = NULL; /* set by orc_probaln_posteriors (single-threaded tests) */
 
 int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query,
@@ -206,16 +219,19 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
         sum = 1. / sum;
         for (k = lo; k <= hi; ++k) fi[k] *= sum;
     }
-    { /* terminal.  GUARD VARIANTS (parity unpinned): this restatement skips a column when its slot lies outside the band,
-       * `u < 3 || u >= bw2*3+3` -- kprobaln's test, kept as far as we know by the htslib releases that shrank the row to
-       * i_dim = min(bw2, l_ref)*3+6.  The other reading, `u >= i_dim-3`, differs exactly when l_query <= bw and
-       * 2*bw+1 > l_ref (set_u's row offset is 0, u = 3*(k+1), i_dim-3 = 3*l_ref+3): it would drop column l_ref from this
-       * sum and from the backward start below.  secphase reaches that regime (--ont -b 50, blocks of <= 50 bases).  Only a
-       * real htslib 1.17 decides; tools/pin_htslib/make_problems.py carries 240 problems of that shape. */
+    /* GUARD VARIANTS (parity unpinned): by default this restatement skips a column of the termination when its slot lies
+     * outside the band, `u < 3 || u >= bw2*3+3` -- kprobaln's test.  The other reading of the htslib releases that shrank the
+     * row to i_dim = min(bw2, l_ref)*3+6 is `u >= i_dim-3`; it differs exactly when l_query <= bw and 2*bw+1 > l_ref (set_u's
+     * row offset is 0, u = 3*(k+1), i_dim-3 = 3*l_ref+3): it drops column l_ref from this sum and from the backward start
+     * below.  secphase reaches that regime (--ont -b 50, blocks of <= 50 bases).  Only a real htslib 1.17 decides
+     * (tools/pin_htslib: 240 problems of that shape; the tool reports which reading matches); orc_set_terminal_guard() /
+     * SPX_TERMINAL_GUARD select the reading here, and the same switch exists in the product (include/spx.h). */
+    const size_t guard_limit = orc_get_terminal_guard() ? i_dim - 3 : (size_t)bw2 * 3 + 3;
+    { /* terminal */
         double sum = 0.;
         for (k = 1; k <= l_ref; ++k) {
             int u = slot3(bw, l_query, k);
-            if (u < 3 || u >= bw2 * 3 + 3) continue;
+            if (u < 3 || (size_t)u >= guard_limit) continue;
             sum += f[(size_t)l_query * i_dim + u + 0] * sM + f[(size_t)l_query * i_dim + u + 1] * sI;
         }
         s[l_query + 1] = sum;
@@ -237,7 +253,7 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
     for (k = 1; k <= l_ref; ++k) {
         int u = slot3(bw, l_query, k);
         double *bi = b + (size_t)l_query * i_dim;
-        if (u < 3 || u >= bw2 * 3 + 3) continue; /* (same guard as the terminal sum: see GUARD VARIANTS above) */
+        if (u < 3 || (size_t)u >= guard_limit) continue; /* (same guard as the terminal sum: see GUARD VARIANTS above) */
         bi[u + 0] = sM / s[l_query] / s[l_query + 1];
         bi[u + 1] = sI / s[l_query] / s[l_query + 1];
     }

@@ -42,6 +42,9 @@ int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int 
 int orc_probaln_posteriors(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
                            const orc_probaln_par *c, double *s, double *zM, double *zI);
 int orc_phred_from_posterior(double max_over_sum);
+/* reading of probaln.c's terminal guard: 0 = `u >= bw2*3+3` (default), 1 = `u >= i_dim-3` (probaln_oracle.c, GUARD VARIANTS) */
+void orc_set_terminal_guard(int reading);
+int orc_get_terminal_guard(void);
 void orc_set_scratch_reuse(int on);
 /* CPU-baseline runs: per-thread scratch instead of calloc/free per call */
 void orc_set_reference_overheads(int on); /* bench bracket: per-group fai_load, per-iterator regcomp / regexec */

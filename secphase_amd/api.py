@@ -105,6 +105,7 @@ EXPORTS = [
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
     "spx_work_device_bytes", "spx_dbam_default_options", "spx_dbam_open", "spx_dbam_header", "spx_dbam_start", "spx_dbam_next", "spx_dbam_release", "spx_dbam_stats", "spx_dbam_close",
+    "spx_set_terminal_guard", "spx_get_terminal_guard",
     "spx_sam_write_group_of", "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
 ]
 
@@ -234,8 +235,23 @@ def lib():
     L.spx_sam_open.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
     L.spx_sam_write_group.argtypes = [vp, vp, C.c_int32, _u8p]
     L.spx_sam_close.argtypes = [vp]
+    L.spx_set_terminal_guard.argtypes = [C.c_int]
+    L.spx_get_terminal_guard.restype = C.c_int
     _lib = L
     return L
+
+
+GUARD_BAND, GUARD_ROW = 0, 1
+
+
+def set_terminal_guard(reading):
+    """reading of probaln.c's terminal guard (include/spx.h: SPX_GUARD_BAND default, SPX_GUARD_ROW); process-wide, read
+    when a work list is prepared"""
+    _chk(lib().spx_set_terminal_guard(int(reading)), "spx_set_terminal_guard")
+
+
+def get_terminal_guard():
+    return lib().spx_get_terminal_guard()
 
 
 def _chk(rc, where):

@@ -32,8 +32,8 @@ enum {
     SPX_H_SI,
     SPX_H_EMATCH,
     SPX_H_EMIS,
-    SPX_H_PAD0,
-    SPX_H_PAD1,
+    SPX_H_PAD0,   /* != 0: the window or the query holds an ambiguous base */
+    SPX_H_TDROP,  /* != 0: the termination / backward start leave out column l_ref (terminal-guard reading "row", spx_logic.h terminal_drop) */
     SPX_H_PAD2,
     SPX_H_N
 };

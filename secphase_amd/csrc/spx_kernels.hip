@@ -360,6 +360,7 @@ __device__ __forceinline__ void bwd_row(double (&bM)[C], double (&bI)[C], DS &D,
 /* per-lane view of one problem */
 struct Prob {
     int pid, L, R, bw, nrows, row0;
+    int Rt; /* last column of the termination sum / backward start: R, or R - 1 under the "row" reading of the terminal guard (SPX_H_TDROP) */
     int64_t ref0, qry0;
     bool act;
 };
@@ -371,7 +372,7 @@ __device__ __forceinline__ Prob load_problem(const spx_dev_batch &B, int lane, H
     Prob P;
     const int oslot = blockIdx.x * PPW + lane / G;
     P.pid = bwd ? (oslot < B.n_order_bwd ? B.order_bwd[oslot] : -1) : (oslot < B.n_order ? B.order[oslot] : -1);
-    P.L = P.R = P.bw = P.nrows = P.row0 = 0;
+    P.L = P.R = P.bw = P.nrows = P.row0 = P.Rt = 0;
     P.ref0 = P.qry0 = 0;
     hasN = 0;
     h = HmmC{0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -389,6 +390,7 @@ __device__ __forceinline__ Prob load_problem(const spx_dev_batch &B, int lane, H
         h.m0 = hp[SPX_H_M0]; h.m1 = hp[SPX_H_M1]; h.m2 = hp[SPX_H_M2]; h.m3 = hp[SPX_H_M3]; h.m4 = hp[SPX_H_M4];
         h.m6 = hp[SPX_H_M6]; h.m8 = hp[SPX_H_M8]; h.e_match = hp[SPX_H_EMATCH]; h.e_mis = hp[SPX_H_EMIS];
         hasN = hp[SPX_H_PAD0] != 0.0; /* host flag: window or query holds an ambiguous base */
+        P.Rt = hp[SPX_H_TDROP] != 0.0 ? P.R - 1 : P.R;
     }
     return P;
 }
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_F) void baq_fwd_kernel(spx_dev_batch 
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const int k = L - bw + jbase + c;
-                    const bool valid = c < nc && k >= 1 && k <= R;
+                    const bool valid = c < nc && k >= 1 && k <= P.Rt;
                     const double tt = fM[c] * sM + fI[c] * sI;
                     s = valid ? s + tt : s;
                 }
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(64, SPX_WAVES_B) void baq_bwd_kernel(spx_dev_batch 
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int j = jbase + c, k = L - bw + j;
-            const bool valid = act && j < Wu && k >= 1 && k <= R;
+            const bool valid = act && j < Wu && k >= 1 && k <= P.Rt;
             bM[c] = valid ? vM : 0.0;
             bI[c] = valid ? vI : 0.0;
             D.set(c, 0.0);
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(64, 2) void baq_fwd1_kernel(spx_dev_batch B)
         for (int c = 0; c < C; ++c) {
             const int k = L - bw + c;
             const double tt = (fM[c] * inv_prev) * sM + (fI[c] * inv_prev) * sI;
-            s = (k >= 1 && k <= R) ? s + tt : s;
+            s = (k >= 1 && k <= P.Rt) ? s + tt : s;
         }
         sinv[L] = s_cur;
         sinv[L + 1] = s;

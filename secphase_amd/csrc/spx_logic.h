@@ -102,7 +102,8 @@ struct RefView {
 };
 
 struct Params {
-    int32_t baq_flag, consensus, indel_threshold, min_q, set_q, flank_margin, all_rows, pad;
+    int32_t baq_flag, consensus, indel_threshold, min_q, set_q, flank_margin, all_rows;
+    int32_t term_guard; /* SPX_GUARD_BAND (default) or SPX_GUARD_ROW: see terminal_drop() */
     double conf_b;
     float d, e;
     float qf; /* (float)pow(10, -set_q/10.), host libm */
@@ -162,6 +163,17 @@ SPX_HD int effective_bw(int l_ref, int l_query, int bw_in)
     return bw;
 }
 
+/* The one line of probaln_glocal this repository cannot check against a real htslib 1.17 (PARITY UNPINNED):
+ * the guard of the termination sum s[l_query+1] and of the backward start, `if (u < 3 || u >= LIMIT) continue;`.
+ *   SPX_GUARD_BAND (0, default): LIMIT = bw2*3+3  -- kprobaln's test: column k of row l_query is skipped iff it lies outside the band.
+ *   SPX_GUARD_ROW  (1):          LIMIT = i_dim-3 with i_dim = min(bw2, l_ref)*3+6 (the row length of the htslib releases that shrank
+ *                                the matrices).  With u = (k - max(l_query-bw, 0) + 1)*3 the two differ for exactly one cell: column
+ *                                k = l_ref of row l_query when l_query <= bw and 2*bw+1 > l_ref -- a real band cell that this reading
+ *                                leaves out of s[l_query+1] and of the backward start (b = 0 there).
+ * Everything else of the recursion is the same under both.  One switch (spx_set_terminal_guard / SPX_TERMINAL_GUARD, and the oracle's
+ * orc_set_terminal_guard) selects the reading for the oracle, the scoring kernels and the general kernel. */
+SPX_HD int terminal_drop(int guard, int l_query, int l_ref, int bw) { return guard == 1 && l_query <= bw && 2 * bw + 1 > l_ref; }
+
 SPX_HD int64_t band_cells(int L, int R, int bw)
 {
     /* sum over rows i = 1..L of (min(R, i+bw) - max(1, i-bw) + 1), closed form; effective_bw() guarantees bw >= |R - L| */
@@ -192,7 +204,7 @@ SPX_HD void hmm_constants(int l_ref, int l_query, float d, float e, float qf, do
     h[SPX_H_SI] = sI;
     h[SPX_H_EMATCH] = 1. - (double)qf;
     h[SPX_H_EMIS] = (double)qf * .33333333333;
-    h[SPX_H_PAD0] = h[SPX_H_PAD1] = h[SPX_H_PAD2] = 0.;
+    h[SPX_H_PAD0] = h[SPX_H_TDROP] = h[SPX_H_PAD2] = 0.;
 }
 
 SPX_HD bool window_has_n(const RefView &rv, int tid, int64_t start, int64_t n)
@@ -1280,6 +1292,8 @@ SPX_HD void problem_constants(const Params &par, int L, int R, uint8_t has_n, do
 {
     hmm_constants(R, L, par.d, par.e, par.qf, h);
     h[SPX_H_PAD0] = has_n ? 1.0 : 0.0;
+    const int diff = R > L ? R - L : L - R;
+    h[SPX_H_TDROP] = terminal_drop(par.term_guard, L, R, effective_bw(R, L, (int)(diff + par.conf_b))) ? 1.0 : 0.0; /* bw as in plan_baq */
 }
 
 /* ---- the passes of a read group.  G* run one group per thread, A* one alignment per thread (the walks over ops and

@@ -91,6 +91,21 @@ void hmm_constants(int l_ref, int l_query, float d, float e, int set_q, double *
     spxl::hmm_constants(l_ref, l_query, d, e, qf, h);
 }
 
+/* the reading of probaln_glocal's terminal guard (spx_logic.h terminal_drop): process-wide, SPX_TERMINAL_GUARD=band|row
+ * (or 0|1) at the first use, spx_set_terminal_guard() afterwards.  Work lists prepared earlier keep the reading they were built with. */
+static std::atomic<int> g_term_guard{-1};
+int terminal_guard()
+{
+    int v = g_term_guard.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("SPX_TERMINAL_GUARD");
+        v = (e && (!strcmp(e, "row") || !strcmp(e, "1") || !strcmp(e, "idim"))) ? 1 : 0;
+        g_term_guard.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+void set_terminal_guard(int reading) { g_term_guard.store(reading ? 1 : 0, std::memory_order_relaxed); }
+
 spxl::Params logic_params(const spx_params *par)
 {
     spxl::Params p;
@@ -106,6 +121,7 @@ spxl::Params logic_params(const spx_params *par)
     p.d = (float)par->conf_d;
     p.e = (float)par->conf_e;
     p.qf = (float)pow(10, -par->set_q / 10.);
+    p.term_guard = terminal_guard();
     return p;
 }
 

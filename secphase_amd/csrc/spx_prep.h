@@ -106,6 +106,8 @@ void stage_fill(const Stage &st, int sec, int64_t b0, int64_t b1, char *dst,
 
 /* what the work list needs from spx_params, in the shape spx_logic.h wants (qf through the host libm) */
 spxl::Params logic_params(const spx_params *par);
+int terminal_guard();             /* 0 = SPX_GUARD_BAND (default), 1 = SPX_GUARD_ROW: spx_logic.h terminal_drop */
+void set_terminal_guard(int reading);
 
 /* host plan: the spx_logic.h passes run on the CPU; fills every array of hb */
 int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &ref, const spx_params *par, int threads,

@@ -44,6 +44,7 @@ struct Args {
     int32_t *state;
     uint8_t *q;
     const double *thr;
+    int32_t drop_last; /* terminal-guard reading "row" and l_query <= bw, 2*bw+1 > l_ref: column l_ref is left out of the termination */
 };
 
 __device__ __forceinline__ int64_t slot(int bw, int i, int k) { return ((int64_t)(k - i + bw) * 3 + 3); }
@@ -91,9 +92,12 @@ __global__ void probaln_general_kernel(Args A)
         sum = 1. / sum;
         for (int64_t k = slot(bw, i, beg); k <= slot(bw, i, end) + 2; ++k) fi[k] *= sum;
     }
+    /* (in this kernel's kprobaln addressing `u >= bw2*3+3` is plain band membership; the other reading of htslib's guard, u >= i_dim-3
+     * in ITS addressing, drops column l_ref in the regime spx_logic.h terminal_drop() names: the host passes that as drop_last) */
+    const int Rt = A.drop_last ? R - 1 : R;
     { /* termination */
         double sum = 0.;
-        for (int k = 1; k <= R; ++k) {
+        for (int k = 1; k <= Rt; ++k) {
             const int64_t u = slot(bw, L, k);
             if (u < 3 || u >= (int64_t)bw2 * 3 + 3) continue;
             sum += f[(int64_t)L * D + u + 0] * A.sM + f[(int64_t)L * D + u + 1] * A.sI;
@@ -101,7 +105,7 @@ __global__ void probaln_general_kernel(Args A)
         s[L + 1] = sum;
     }
     /* backward */
-    for (int k = 1; k <= R; ++k) {
+    for (int k = 1; k <= Rt; ++k) {
         const int64_t u = slot(bw, L, k);
         double *bi = b + (int64_t)L * D;
         if (u < 3 || u >= (int64_t)bw2 * 3 + 3) continue;
@@ -153,7 +157,7 @@ __global__ void probaln_general_kernel(Args A)
 /* one problem; f / b: zeroed device scratch of (l_query + 1) * i_dim + 8 doubles each, i_dim = 3 * (2 * bw + 1) + 6 */
 extern "C" hipError_t spx_launch_probaln_general(const uint8_t *d_ref, int32_t l_ref, const uint8_t *d_query, int32_t l_query, const float *d_qual, int32_t bw,
                                                  const double *hmm9_bM_bI_sM_sI /* host: m[0..8], bM, bI, sM, sI */, double *d_f, double *d_b, double *d_s,
-                                                 int64_t i_dim, int32_t *d_state, uint8_t *d_q, const double *d_thr, hipStream_t st)
+                                                 int64_t i_dim, int32_t *d_state, uint8_t *d_q, const double *d_thr, int32_t drop_last_column, hipStream_t st)
 {
     Args A;
     A.ref = d_ref; A.query = d_query; A.qual = d_qual;
@@ -161,7 +165,7 @@ extern "C" hipError_t spx_launch_probaln_general(const uint8_t *d_ref, int32_t l
     for (int k = 0; k < 9; ++k) A.m[k] = hmm9_bM_bI_sM_sI[k];
     A.bM = hmm9_bM_bI_sM_sI[9]; A.bI = hmm9_bM_bI_sM_sI[10]; A.sM = hmm9_bM_bI_sM_sI[11]; A.sI = hmm9_bM_bI_sM_sI[12];
     A.f = d_f; A.b = d_b; A.s = d_s; A.i_dim = i_dim;
-    A.state = d_state; A.q = d_q; A.thr = d_thr;
+    A.state = d_state; A.q = d_q; A.thr = d_thr; A.drop_last = drop_last_column;
     hipLaunchKernelGGL(probaln_general_kernel, dim3(1), dim3(64), 0, st, A);
     return hipGetLastError();
 }

@@ -2128,6 +2128,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
             for (int k = 0; k < R; ++k) has_n |= ref[ref_off[p] + k] > 3;
             for (int k = 0; k < L; ++k) has_n |= query[qry_off[p] + k] > 3;
             hb.hmm[hb.hmm.size() - SPX_H_N + SPX_H_PAD0] = has_n ? 1.0 : 0.0;
+            hb.hmm[hb.hmm.size() - SPX_H_N + SPX_H_TDROP] = spxl::terminal_drop(spx::terminal_guard(), L, R, bw) ? 1.0 : 0.0;
         }
         hb.dp_cells += spx::band_cells(L, R, bw);
     }
@@ -2221,7 +2222,15 @@ static spx_ctx *g_single = nullptr;
 
 extern "C" hipError_t spx_launch_probaln_general(const uint8_t *d_ref, int32_t l_ref, const uint8_t *d_query, int32_t l_query, const float *d_qual, int32_t bw,
                                                  const double *hmm13, double *d_f, double *d_b, double *d_s, int64_t i_dim, int32_t *d_state, uint8_t *d_q,
-                                                 const double *d_thr, hipStream_t st);
+                                                 const double *d_thr, int32_t drop_last_column, hipStream_t st);
+
+extern "C" int spx_set_terminal_guard(int reading)
+{
+    if (reading != SPX_GUARD_BAND && reading != SPX_GUARD_ROW) return fail(SPX_EINVAL, "terminal guard: SPX_GUARD_BAND or SPX_GUARD_ROW");
+    spx::set_terminal_guard(reading);
+    return SPX_OK;
+}
+extern "C" int spx_get_terminal_guard(void) { return spx::terminal_guard(); }
 
 /* per-base qualities (htslib's iqual[i]; samtools' BAQ passes them, secphase never does): the general kernel of
  * spx_probaln_general.hip, one problem at a time.  Returns the phred-scaled likelihood or INT_MIN. */
@@ -2253,7 +2262,7 @@ static int probaln_per_base(spx_ctx *c, const uint8_t *ref, int l_ref, const uin
     if (e == hipSuccess)
         e = spx_launch_probaln_general((const uint8_t *)(blk + o_ref), l_ref, (const uint8_t *)(blk + o_qry), l_query, (const float *)(blk + o_qual), bw, hmm13,
                                        (double *)(blk + o_f), (double *)(blk + o_b), (double *)(blk + o_s), i_dim, (int32_t *)(blk + o_state),
-                                       (uint8_t *)(blk + o_q), c->d_tables, c->stream);
+                                       (uint8_t *)(blk + o_q), c->d_tables, spxl::terminal_drop(spx::terminal_guard(), l_query, l_ref, bw), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(s.data(), blk + o_s, s.size() * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(st32.data(), blk + o_state, st32.size() * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(q, blk + o_q, (size_t)l_query, hipMemcpyDeviceToHost, c->stream);

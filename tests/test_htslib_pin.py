@@ -18,8 +18,35 @@ def _vectors():
     return json.load(open(VECTORS))["vectors"]
 
 
+def _pinned_guard():
+    """the reading of the terminal guard the real htslib matched (tools/pin_htslib/make_vectors.py which_guard)"""
+    return {"band": 0, "row": 1}.get(json.load(open(VECTORS)).get("terminal_guard", "band"), 0)
+
+
+@pytest.fixture
+def pinned_guard(built):
+    from oracle import orc
+    from secphase_amd import api
+    g = _pinned_guard()
+    orc.set_terminal_guard(g)
+    api.set_terminal_guard(g)
+    yield g
+    orc.set_terminal_guard(0)
+    api.set_terminal_guard(0)
+
+
 @needs_vectors
-def test_oracle_equals_htslib(built):
+def test_default_guard_is_the_pinned_one(built):
+    """fails when the real htslib matched the OTHER reading than the repository's default: flip the default (one constant in
+    secphase_amd/csrc/spx_prep.cpp terminal_guard() and in oracle/probaln_oracle.c orc_get_terminal_guard())"""
+    from oracle import orc
+    from secphase_amd import api
+    assert json.load(open(VECTORS)).get("terminal_guard") in ("band", "row"), "neither reading reproduced htslib on the regime block"
+    assert api.get_terminal_guard() == _pinned_guard() == orc.get_terminal_guard()
+
+
+@needs_vectors
+def test_oracle_equals_htslib(pinned_guard):
     for k, v in enumerate(_vectors()):
         pr, st, q = oracle_probaln(np.array(v["ref"], np.uint8), np.array(v["query"], np.uint8), v["set_q"], v["d"], v["e"], v["bw"])
         assert pr == v["Pr"] and st.tolist() == v["state"] and q.tolist() == v["q"], k
@@ -27,7 +54,7 @@ def test_oracle_equals_htslib(built):
 
 @needs_vectors
 @pytest.mark.gpu
-def test_kernels_equal_htslib(built):
+def test_kernels_equal_htslib(pinned_guard):
     from secphase_amd import api
     ctx = api.Context(0)
     vec = _vectors()
