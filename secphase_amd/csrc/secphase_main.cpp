@@ -545,14 +545,17 @@ int main(int argc, char *argv[])
     const int rc_bed2 = spx_bedset_save(bed_mk, out_path(".marker_blocks.bed").c_str(), 0);
     if (rc_bed1 != SPX_OK || rc_bed2 != SPX_OK) {
         fprintf(stderr, "[%s] could not write the BED outputs: %s\n", timestamp(), spx_last_error());
+        if (teardown.joinable()) teardown.join(); /* (never leave main with the teardown thread running) */
         fflush(NULL);
+        if (getenv("SPX_PROFILER")) return 1; /* (a profiler writes its files from an exit handler) */
         _exit(1); /* (reader, pool and context threads are still running: no static destructors under them) */
     }
     spx_bedset_free(bed_mod);
     spx_bedset_free(bed_mk);
     spx_finalizer_free(fin);
-    if (sam && spx_sam_close(sam) != SPX_OK) { fprintf(stderr, "[%s] could not finish the quality-modified output\n", timestamp()); return 1; }
-    if (teardown.joinable()) teardown.join();
+    const bool sam_failed = sam && spx_sam_close(sam) != SPX_OK;
+    if (teardown.joinable()) teardown.join(); /* before any path that leaves main */
+    if (sam_failed) { fprintf(stderr, "[%s] could not finish the quality-modified output\n", timestamp()); return 1; }
     const double t_end1 = now_s();
     if (getenv("SPX_TIMING") && !dev_input) {
         int64_t ch = 0, cd = 0;

@@ -20,6 +20,7 @@
 #include <string.h>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <errno.h>
 #include <fcntl.h>
 
 #include <algorithm>
@@ -367,47 +368,39 @@ extern "C" int spx_bedset_save(const spx_bedset *b, const char *path, int print_
     size_t total = 0;
     for (Piece &pc : pieces) { pc.at = total; total += pc.bytes; }
     const auto t_b = std::chrono::steady_clock::now();
-    /* 3. formatted straight into the file's pages (a run that relabels most reads writes ~200 MB here: no second copy); a file that
-     * cannot be mapped gets the same bytes through one buffer */
-    bool ok = true;
+    /* 3. every piece is formatted into a buffer of its own and written at its place with pwrite(): a full disk or an exceeded quota comes
+     * back as an error of the call (the page-cache copy costs a parallel memcpy; a shared mapping of the file would save it, but there
+     * ENOSPC arrives as SIGBUS inside the formatting loop and a deferred write error is never seen) */
+    std::atomic<bool> ok_all(true);
     if (total) {
-        char *map = nullptr, *buf = nullptr;
-        if (ftruncate(fd, (off_t)total) == 0) {
-            void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-            if (m != MAP_FAILED) map = (char *)m;
-        }
-        if (!map) buf = (char *)malloc(total);
-        char *dst = map ? map : buf;
-        if (!dst) ok = false;
-        else {
-            on_threads(pieces.size(), [&](size_t q) {
-                const Piece &pc = pieces[q];
-                const std::string &name = items[pc.k]->first;
-                char *o = dst + pc.at;
-                for (size_t i = pc.a; i < pc.b; ++i) {
-                    const Blk3 &m = merged[pc.k][i];
-                    if (m.e < m.s) continue;
-                    memcpy(o, name.data(), name.size()); o += name.size();
-                    *o++ = '\t';
-                    o = put_i32(o, m.s); *o++ = '\t';
-                    o = put_i32(o, m.e + 1);
-                    if (print_count) { *o++ = '\t'; o = put_i32(o, m.c); }
-                    *o++ = '\n';
-                }
-            });
-            if (map) { if (munmap(map, total) != 0) ok = false; }
-            else {
-                size_t done = 0;
-                while (done < total) {
-                    const ssize_t w = pwrite(fd, buf + done, total - done, (off_t)done);
-                    if (w <= 0) { ok = false; break; }
-                    done += (size_t)w;
-                }
-                if (ok && ftruncate(fd, (off_t)total) != 0) ok = false;
+        on_threads(pieces.size(), [&](size_t q) {
+            const Piece &pc = pieces[q];
+            if (!pc.bytes || !ok_all.load(std::memory_order_relaxed)) return;
+            const std::string &name = items[pc.k]->first;
+            char *buf = (char *)malloc(pc.bytes);
+            if (!buf) { ok_all.store(false); return; }
+            char *o = buf;
+            for (size_t i = pc.a; i < pc.b; ++i) {
+                const Blk3 &m = merged[pc.k][i];
+                if (m.e < m.s) continue;
+                memcpy(o, name.data(), name.size()); o += name.size();
+                *o++ = '\t';
+                o = put_i32(o, m.s); *o++ = '\t';
+                o = put_i32(o, m.e + 1);
+                if (print_count) { *o++ = '\t'; o = put_i32(o, m.c); }
+                *o++ = '\n';
             }
-        }
-        free(buf);
+            size_t done = 0;
+            while (done < pc.bytes) {
+                const ssize_t w = pwrite(fd, buf + done, pc.bytes - done, (off_t)(pc.at + done));
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) { ok_all.store(false); break; }
+                done += (size_t)w;
+            }
+            free(buf);
+        });
     }
+    bool ok = ok_all.load();
     if (close(fd) != 0) ok = false;
     if (timing)
         fprintf(stderr, "[spx timing] BED %s: merge + sizes %.3f s, text into the file %.3f s (%zu bytes)\n", path, std::chrono::duration<double>(t_b - t_a).count(),

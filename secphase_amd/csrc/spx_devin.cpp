@@ -323,7 +323,7 @@ int Lane::ensure_pools(int64_t recs, int64_t blocks)
         if (d_pool) (void)hipFree(d_pool);
         d_pool = nullptr;
         const int64_t want = std::max<int64_t>((int64_t)1 << 18, recs + recs / 4);
-        const size_t bytes = (size_t)(want + 2) * kPoolPerRec + 16 * 256;
+        const size_t bytes = (size_t)(want + 2) * kPoolPerRec + 20 * 256; /* carve() rounds each of its 18 arrays up to 256 bytes */
         DCHK(hipMalloc(&d_pool, bytes));
         pool_cap = bytes;
         rec_cap = want;
@@ -395,7 +395,11 @@ Seg *Lane::cut_segment()
         fail_here(msg, SPX_EINVAL);
         return nullptr;
     };
-    while (u < target) {
+    /* a cap on the blocks of a segment beside the byte target: a BAM written as many tiny BGZF blocks (samtools --write-index on a stream
+     * of short flushes, `bgzip -b`) would otherwise grow the block table past the pinned chunk it travels in, and the inflate kernel's
+     * scratch (8 KB per block) to gigabytes per slot; the carry buffer takes the records such a short segment cuts through */
+    constexpr size_t kMaxSegBlocks = (size_t)1 << 18;
+    while (u < target && s->blocks.size() < kMaxSegBlocks) {
         if (d->fpos >= d->fsize) { d->cut_eof = true; break; }
         if (d->fpos == d->end_coff && d->end_uoff == 0) { d->cut_eof = true; break; }
         const uint8_t *p = d->map + d->fpos;
@@ -1027,8 +1031,8 @@ extern "C" int spx_dbam_next(spx_dbam *d, spx_work **work, int32_t *ctx_index, c
             *names = &it.names->view;
             return it.n_groups;
         }
-        if (d->rc != SPX_OK) { spx_internal_set_error(d->err.c_str()); return d->rc; }
-        if (d->total_segments >= 0 && d->next_out >= d->total_segments) return 0;
+        /* complete segments in front of a failing one are handed out first, in file order: the relabel list then ends where the host
+         * reader's would on the same damaged file (the reference scores every group in front of the bad record) */
         auto f = d->results.find(d->next_out);
         if (f != d->results.end()) {
             for (Item &x : f->second) d->out_items.push_back(x);
@@ -1037,6 +1041,8 @@ extern "C" int spx_dbam_next(spx_dbam *d, spx_work **work, int32_t *ctx_index, c
             d->cv.notify_all();
             continue;
         }
+        if (d->rc != SPX_OK) { spx_internal_set_error(d->err.c_str()); return d->rc; }
+        if (d->total_segments >= 0 && d->next_out >= d->total_segments) return 0;
         d->cv.wait(lk);
     }
 }

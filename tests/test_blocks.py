@@ -150,3 +150,21 @@ def test_bed_point_sets_and_blocks_on_one_contig(built, tmp_path):
             assert [(int(x[1]), int(x[2])) for x in g] == [(w[0], w[1] + 1) for w in want], name
             if with_count:
                 assert [int(x[3]) for x in g] == [w[2] for w in want], name
+
+
+def test_bed_write_errors_are_reported_not_fatal(built):
+    """a full device (ENOSPC on every write) must come back as an error code of spx_bedset_save -- not as SIGBUS out of a
+    mapped file, and not as success with a truncated BED (the command line prints 'could not write the BED outputs')"""
+    import ctypes as C
+    import os
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full")
+    L = api.lib()
+    h = C.c_void_p()
+    assert L.spx_bedset_create(C.byref(h)) == 0
+    L.spx_bedset_add.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32]
+    for k in range(1000):
+        L.spx_bedset_add(h, b"ctg", 100 * k, 100 * k + 50, 1)
+    assert L.spx_bedset_save(h, b"/dev/full", 1) != 0
+    assert L.spx_bedset_save(h, b"/nonexistent-dir/x.bed", 1) != 0
+    L.spx_bedset_free(h)
