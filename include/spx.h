@@ -425,6 +425,41 @@ int spx_fasta_load(const char *path, spx_fasta **out);
 const spx_ref *spx_fasta_ref(const spx_fasta *f);
 void spx_fasta_free(spx_fasta *f);
 
+/* ---- the consumer of the relabel list: /root/reference/programs/src/correct_bam.c ---------------
+ * spx_relabel_table_*: get_phased_read_table (correct_bam.c:32-91) -- the list is parsed the way correct_bam parses it: `$` read
+ * name, `*` old primary, `@` promoted secondary, columns 3-4 = contig and 0-based start; records whose two locations coincide
+ * are ignored (:64-68,77-82).  path == NULL: an empty table.  _get iterates in name order. */
+typedef struct spx_relabel_table spx_relabel_table;
+int spx_relabel_table_load(const char *out_log_path, spx_relabel_table **out);
+int64_t spx_relabel_table_size(const spx_relabel_table *t);
+int spx_relabel_table_get(const spx_relabel_table *t, int64_t i, const char **qname, const char **contig, int32_t *start);
+int spx_relabel_table_find(const spx_relabel_table *t, const char *qname, const char **contig, int32_t *start); /* 1 found, 0 not */
+void spx_relabel_table_free(spx_relabel_table *t);
+/* spx_correct_bam: correct_bam's record loop (correct_bam.c:347-376) on this library's BAM reader: unmapped and excluded reads are
+ * dropped; a read the table names gets BAM_FSECONDARY cleared on the record at the table's location and set on all its other
+ * records (is_prim, :93-109); then --primaryOnly, the read-length / alignment-length filters, the MAPQ table, --maxMapq, the `de`
+ * divergence filter and --noTag, in the reference's order.  Output: BAM (BGZF; the reference opens "wb") or, with sam_text, SAM.
+ * Options mirror correct_bam's command line (:222-238); defaults from spx_correct_default_options (:248-252). */
+typedef struct spx_correct_options {
+    const char *phasing_log;      /* -P  <prefix>.out.log, may be NULL */
+    const char *mapq_table;       /* -M  read \t contig \t 1-based start \t mapq, may be NULL */
+    const char *exclude;          /* -e  read names, one per line, may be NULL */
+    int32_t primary_only;         /* -p */
+    int32_t no_tag;               /* -t */
+    int32_t min_read_length;      /* -m [5000] */
+    int32_t min_alignment_length; /* -a [5000] */
+    int32_t max_mapq;             /* -x [100] */
+    int32_t threads;              /* -n [2] */
+    double max_divergence;        /* -d [0.12] */
+    int32_t sam_text;             /* not in the reference: write SAM text instead of BAM */
+    int32_t reserved;
+} spx_correct_options;
+typedef struct spx_correct_stats {
+    int64_t records_in, records_out, made_primary, made_secondary, table_reads;
+} spx_correct_stats;
+void spx_correct_default_options(spx_correct_options *opt);
+int spx_correct_bam(const char *in_bam, const char *out_path, const spx_correct_options *opt, spx_correct_stats *stats);
+
 /* ---- BGZF inflate on the device (spx_inflate_kernels.hip: one wavefront per BGZF block; decoder core shared with the
  * host build in spx_inflate.h).  htslib inflates on the reading thread (bgzf_read_block under sam_read1,
  * src/secphase.c:268).  `file` + block_off[0 .. n_blocks] delimit consecutive BGZF blocks; their inflated bytes are

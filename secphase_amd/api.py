@@ -106,6 +106,8 @@ EXPORTS = [
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
     "spx_work_device_bytes", "spx_dbam_default_options", "spx_dbam_open", "spx_dbam_header", "spx_dbam_start", "spx_dbam_next", "spx_dbam_release", "spx_dbam_stats", "spx_dbam_close",
     "spx_set_terminal_guard", "spx_get_terminal_guard",
+    "spx_relabel_table_load", "spx_relabel_table_size", "spx_relabel_table_get", "spx_relabel_table_find", "spx_relabel_table_free",
+    "spx_correct_default_options", "spx_correct_bam",
     "spx_sam_write_group_of", "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
 ]
 

@@ -1567,3 +1567,44 @@ extern "C" int spx_fasta_load(const char *path, spx_fasta **out)
 }
 extern "C" const spx_ref *spx_fasta_ref(const spx_fasta *f) { return f ? &f->ref : nullptr; }
 extern "C" void spx_fasta_free(spx_fasta *f) { delete f; }
+
+/* ---- internal accessors for spx_correct.cpp (the correct_bam counterpart re-emits raw records) ---- */
+extern "C" int spx_internal_bam_record(const spx_bam_reader *src, const spx_batch *bt, int32_t a, const uint8_t **rec, int32_t *block_size)
+{
+    if (!src || !bt || !rec || !block_size) return SPX_EINVAL;
+    const Batch *B = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<Reader &>(src->r).mu);
+        for (const Batch *b : src->r.handed)
+            if (&b->view == bt && !b->released) B = b;
+    }
+    if (!B || a < 0 || (size_t)a >= B->rec_off.size()) return SPX_EINVAL;
+    const uint8_t *p = src->r.arena.aligned + B->rec_off[(size_t)a];
+    *rec = p;
+    *block_size = le32(p - 4);
+    return SPX_OK;
+}
+
+extern "C" int spx_internal_bam_header(const spx_bam_reader *src, const char **text, int64_t *text_len, int32_t *n_targets)
+{
+    if (!src) return SPX_EINVAL;
+    if (text) *text = src->r.header_text.data();
+    if (text_len) *text_len = (int64_t)src->r.header_text.size();
+    if (n_targets) *n_targets = (int32_t)src->r.tname.size();
+    return SPX_OK;
+}
+
+extern "C" int64_t spx_internal_bam_target_len(const spx_bam_reader *src, int32_t i)
+{
+    return (src && i >= 0 && (size_t)i < src->r.tlen.size()) ? src->r.tlen[(size_t)i] : -1;
+}
+
+/* one SAM line of a raw record (sam_format1) appended to *line (a std::string the caller owns) */
+extern "C" int spx_internal_format_sam(const spx_bam_reader *src, const uint8_t *rec, int32_t block_size, void *std_string_out)
+{
+    if (!src || !rec || !std_string_out) return SPX_EINVAL;
+    std::string tmp;
+    if (!format_sam(src->r, rec, block_size, nullptr, tmp)) { g_io_err = "corrupt aux block"; return SPX_EINVAL; }
+    static_cast<std::string *>(std_string_out)->append(tmp);
+    return SPX_OK;
+}

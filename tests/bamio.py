@@ -46,8 +46,9 @@ def write_fasta(path, ref, width=80):
                 f.write(seq[o:o + width] + "\n")
 
 
-def write_bam(path, batch, ref, contig_order=None, extra_tags=True):
-    """contig_order: permutation of contig indices for the BAM header (default identity)"""
+def write_bam(path, batch, ref, contig_order=None, extra_tags=True, de_of=None, mapq_of=None):
+    """contig_order: permutation of contig indices for the BAM header (default identity); de_of(a) / mapq_of(a): per-alignment `de:f`
+    tag (None: no tag) and MAPQ (default 60) -- what the correct_bam tests filter on"""
     b = batch.contents
     r = ref.contents
     names = [(_cstr(r.names, r.name_off[i]), r.seq_off[i + 1] - r.seq_off[i]) for i in range(r.n_contigs)]
@@ -74,7 +75,10 @@ def write_bam(path, batch, ref, contig_order=None, extra_tags=True):
                 aux += b"MDZ" + _cstr(b.md, b.md_off[a]) + b"\0"
             if extra_tags:
                 aux += b"zzBs" + struct.pack("<ihh", 2, -1, 7)
-            core = struct.pack("<iiBBHHHiiii", tid_of[b.tid[a]], b.pos[a], len(qn), 60, 4680, nc, b.flag[a], lq, -1, -1, 0)
+            if de_of is not None and de_of(a) is not None:
+                aux += b"def" + struct.pack("<f", de_of(a))
+            core = struct.pack("<iiBBHHHiiii", tid_of[b.tid[a]] if b.tid[a] >= 0 else -1, b.pos[a], len(qn), 60 if mapq_of is None else mapq_of(a), 4680, nc,
+                               b.flag[a], lq, -1, -1, 0)
             rec = core + qn + cig + seq + qual + aux
             out += struct.pack("<i", len(rec)) + rec
     write_bgzf(path, bytes(out))
@@ -120,3 +124,34 @@ def sam_text(batch, ref, qual=None, contig_order=None, extra_tags=True, groups=N
                 f.append("zz:B:s,-1,7")
             out.append("\t".join(f) + "\n")
     return "".join(out)
+
+
+def read_bam(path):
+    """(header text, [(name, length)], [record]) of a BAM file, read independently of the product (gzip members + struct); a record is a
+    dict with the raw bytes (without block_size) and the fields the correct_bam tests look at"""
+    import gzip
+    raw = gzip.open(path, "rb").read()
+    assert raw[:4] == b"BAM\1"
+    l_text, = struct.unpack_from("<i", raw, 4)
+    text = raw[8:8 + l_text]
+    at = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, at)
+    at += 4
+    refs = []
+    for _ in range(n_ref):
+        ln, = struct.unpack_from("<i", raw, at)
+        nm = raw[at + 4:at + 4 + ln - 1].decode()
+        tl, = struct.unpack_from("<i", raw, at + 4 + ln)
+        refs.append((nm, tl))
+        at += 8 + ln
+    recs = []
+    while at < len(raw):
+        bs, = struct.unpack_from("<i", raw, at)
+        r = raw[at + 4:at + 4 + bs]
+        at += 4 + bs
+        tid, pos, l_name, mapq, _bin, ncig, flag, lseq = struct.unpack_from("<iiBBHHHi", r, 0)
+        name = r[32:32 + l_name - 1].decode()
+        cig = struct.unpack_from("<%dI" % ncig, r, 32 + l_name)
+        aux_at = 32 + l_name + 4 * ncig + (lseq + 1) // 2 + lseq
+        recs.append(dict(raw=r, name=name, tid=tid, pos=pos, mapq=mapq, flag=flag, cigar=[(c & 15, c >> 4) for c in cig], aux=r[aux_at:], aux_at=aux_at))
+    return text, refs, recs

@@ -233,8 +233,9 @@ def test_two_ranks_on_the_device_emit_the_same_relabel_list(built, tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_write_the_list_one_process_writes(built, tmp_path):
-    """`python bench.py --gpus 2` itself -- the self-launch (a child started before anything touches the GPU), cost-cut
+@pytest.mark.parametrize("world,platform,gps", [(2, "mixed", 2048), (8, "hifi", 1024)], ids=["2ranks-mixed", "8ranks-hifi"])
+def test_bench_ranks_write_the_list_one_process_writes(built, tmp_path, world, platform, gps):
+    """`python bench.py --gpus N` itself -- the self-launch (a child started before anything touches the GPU), cost-cut
     shards of the mixed workload, every rank deciding and formatting its own groups, the gather of the fragments, rank 0's
     writer thread -- on a one-GPU box (ranks share the device, collectives over gloo: a rig, never a measurement).  The list
     rank 0 wrote over ALL its steps must equal what ONE process writes for the same groups in (step, rank, group) order with
@@ -243,19 +244,20 @@ def test_bench_two_ranks_write_the_list_one_process_writes(built, tmp_path):
     import subprocess
     from secphase_amd import api, records, synth
     keep = str(tmp_path / "bench2.out.log")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--platform", "mixed", "--steps", "2", "--warmup", "1",
-           "--groups-per-step", "2048", "--keep-log", keep, "--no-build", "--no-host-input-leg"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-backend", "gloo", "--platform", platform, "--steps", "2", "--warmup", "1",
+           "--groups-per-step", str(gps), "--keep-log", keep, "--no-build", "--no-host-input-leg"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=dict(os.environ, GPU_MAX_HW_QUEUES="14"))
     assert p.returncode == 0, (p.stdout[-400:], p.stderr[-1200:])
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
-    assert line["n_gpus"] == 2 and line["config"]["verified_timed_groups"] >= 256
+    assert line["n_gpus"] == world and line["config"]["verified_timed_groups"] >= 256
     assert line["config"]["verified_own_relabel_list"]["oracle_list_is_byte_prefix_of_this_runs_list"] is True
-    assert line["config"]["sharding"]["imbalance_by_cost"] < line["config"]["sharding"]["imbalance_by_count"] + 1e-9
+    if platform == "mixed":
+        assert line["config"]["sharding"]["imbalance_by_cost"] < line["config"]["sharding"]["imbalance_by_count"] + 1e-9
     # the N > 1 line carries SURVEY 8(d)'s metric too: the command line on the job's devices, its list checked against the oracle
     assert line["from_bam"]["rc"] == 0 and line["from_bam"]["out_log_identical_to_oracle"] is True and line["metric_8d"]["groups_per_s"] > 0
-    man = [json.load(open(f"{keep}.rank{r}.json")) for r in range(2)]
-    assert man[0]["sequence"] == man[1]["sequence"] and len(man[0]["sequence"]) >= 3 + 2
-    g = synth.Genome(synth.default_cfg(synth.MIXED))
+    man = [json.load(open(f"{keep}.rank{r}.json")) for r in range(world)]
+    assert all(m["sequence"] == man[0]["sequence"] for m in man) and len(man[0]["sequence"]) >= 3 + 2
+    g = synth.Genome(synth.default_cfg(synth.MIXED if platform == "mixed" else synth.HIFI))
     par = records.preset("hifi")
     ctx = api.Context(0)
     ctx.set_reference(g.ref)
@@ -267,7 +269,7 @@ def test_bench_two_ranks_write_the_list_one_process_writes(built, tmp_path):
     cache = {}
     n_tot = 0
     for i in man[0]["sequence"]:
-        for r in range(2):
+        for r in range(world):
             for start, n in man[r]["ranges"][str(i)]:
                 if (start, n) not in cache:
                     reads = g.reads(start, n)
@@ -279,8 +281,84 @@ def test_bench_two_ranks_write_the_list_one_process_writes(built, tmp_path):
                 n_tot += n
     L.spx_finalizer_free(fin)
     ctx.close()
-    assert n_tot == 2 * 2048 * len(man[0]["sequence"])
+    assert n_tot == world * gps * len(man[0]["sequence"])
     assert os.path.getsize(one) > 1000 and filecmp.cmp(one, keep, shallow=False)
+
+
+def _nccl_worker(rank, world, port, tmp):
+    """world size 1 over backend "nccl" (= RCCL): the collectives bench.py issues at N > 1 -- all_reduce of the step statistics,
+    all_gather of the draw counts, gather of byte fragments and of the device-packed decision records -- on DEVICE tensors"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from oracle import orc
+    from secphase_amd import api
+    g, p = _setup()
+    r = g.reads(0, N_GROUPS)
+    L = api.lib()
+    ctx = api.Context(0)
+    ctx.set_reference(g.ref)
+    w = ctx.stage(r.batch, p)
+    pipe = api.Pipe(ctx, p, depth=2, host_threads=4)
+    pipe.submit(staged=w)
+    out, got = pipe.next()
+    assert got == N_GROUPS
+    # (1) the statistics reductions of bench.py
+    t = torch.tensor([1.5, 2.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.tolist() == [1.5, 2.0]
+    # (2) device-packed decision records through the gather
+    dev = torch.zeros(N_GROUPS * 16, dtype=torch.uint8, device="cuda")
+    nd = w.pack_decisions(0, dev.data_ptr(), N_GROUPS)
+    dparts = shard.gather_bytes(dev[: nd * 16], dist, torch)
+    assert len(dparts) == 1 and len(dparts[0]) == nd * 16
+    nc = L.spx_relabel_candidates(r.batch, 0, out, C.byref(p), None, 0)
+    cand = (api.RelabelRec * max(nc, 1))()
+    assert L.spx_relabel_candidates(r.batch, 0, out, C.byref(p), cand, nc) == nc
+    cparts = shard.gather_bytes(torch.from_numpy(np.frombuffer(memoryview(cand), np.uint8)[: nc * C.sizeof(api.RelabelRec)].copy()).to("cuda"), dist, torch)
+    fin = C.c_void_p()
+    api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+    log = os.path.join(tmp, "nccl_merge.out.log")
+    open(log, "w").close()
+    shard.merge_and_write(api, p, fin, g.ref, dparts, cparts, log)
+    L.spx_finalizer_free(fin)
+    # (3) the round-3 path: every rank decides its own groups (draw counts all-gathered on the device), one gather of the text
+    api._chk(L.spx_finalizer_create(1, C.byref(fin)), "spx_finalizer_create")
+    shard.decide_locally(api, p, fin, out, N_GROUPS, dist, torch, "cuda")
+    frag = shard.relabel_text(api, [r.batch], g.ref, out)
+    parts = shard.gather_bytes(torch.from_numpy(frag.copy()).to("cuda"), dist, torch)
+    log2 = os.path.join(tmp, "nccl_local.out.log")
+    open(log2, "w").close()
+    shard.append_fragments(parts, log2)
+    L.spx_finalizer_free(fin)
+    pipe.close()
+    w.free()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_branch_runs_at_world_size_one(built, tmp_path):
+    """backend "nccl" IS RCCL on ROCm: the box has one GPU, so the process group has one rank -- but every collective bench.py and
+    secphase_amd/shard.py issue at N > 1 runs through RCCL on device tensors here (the driver's 8-GPU run is the first time they
+    see a peer); both ways of producing the list equal the oracle's"""
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    from oracle import orc
+    g, p = _setup()
+    r = g.reads(0, N_GROUPS)
+    log_o = str(tmp_path / "one.out.log")
+    nre, _ = orc.run_batch(r.batch, g.ref, p, threads=2, seed=1, log_path=log_o)
+    assert nre > 3
+    assert filecmp.cmp(log_o, str(tmp_path / "nccl_merge.out.log"), shallow=False)
+    assert filecmp.cmp(log_o, str(tmp_path / "nccl_local.out.log"), shallow=False)
 
 
 def test_relabel_record_writer_on_threads_keeps_order_and_format(built, tmp_path):

@@ -464,6 +464,30 @@ def test_command_line_drop_in(ctx, tmp_path):
     for sfx in ("initial_variant_blocks.bed", "modified_read_blocks.variants.bed", "variant_blocks.bed"):
         assert os.path.getsize(os.path.join(outd, "t." + sfx)) == 0
     assert f"Number of reads modified by marker score = {nre}" in p.stderr
+    # row N2: the list the HIP path wrote, consumed the way correct_bam consumes it (correct_bam.c:32-91), and applied to the BAM
+    # (flag swap correct_bam.c:352-358): the table names, for every relabelled read, the promoted secondary's contig + 0-based start
+    import subprocess as sp
+    from test_correct_bam import EXE as CORRECT_BAM, expected_records, load_table, parse_list_like_correct_bam
+    from bamio import read_bam
+    cli_log = os.path.join(outd, "t.out.log")
+    table = load_table(cli_log)
+    b, rf = r.batch.contents, g.ref.contents
+    expect = {}
+    for i, e in enumerate(res):
+        if e.relabel:
+            a = b.grp_first[i] + e.best_idx
+            expect[C.string_at(b.qnames + b.qname_off[i]).decode()] = (C.string_at(rf.names + rf.name_off[b.tid[a]]).decode(), b.pos[a])
+    assert table == expect == parse_list_like_correct_bam(cli_log) and len(table) == nre
+    fixed = str(tmp_path / "corrected.bam")
+    q = sp.run([CORRECT_BAM, "-i", bam, "-o", fixed, "-P", cli_log, "-m", "1000", "-a", "500"], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr
+    got = read_bam(fixed)[2]
+    assert [x["raw"] for x in got] == expected_records(bam, table, min_read=1000, min_aln=500)
+    prim = {}
+    for x in got:
+        if not x["flag"] & 256:
+            prim.setdefault(x["name"], []).append((read_bam(fixed)[1][x["tid"]][0], x["pos"]))
+    assert all(prim.get(n) == [loc] for n, loc in table.items())
 
 
 def test_aliased_and_altered_secondaries(ctx, tmp_path):
@@ -514,9 +538,13 @@ def test_command_line_several_devices(ctx, tmp_path):
             mxs = max(e.score[a] for a in sec)
             ties += sum(1 for a in sec if e.score[a] >= mxs) > 1
     assert ties > 0 and nre > 5
+    # (eight contexts and eight input pipelines on the one GPU of the box, segments of 64 KB: groups -- tie groups among them --
+    # straddle every cut between pipelines; what `--devices 0-7` does on an 8-GPU node, minus the peers)
     for devs, batch, extra, env in (("0,0,0", "17", [], {}), ("0-0", "40", [], {}), ("0,0", "1000", [], {"SPX_DIN_SEG_KB": "128"}),
-                                    ("0,0,0", "17", ["--hostInput"], {}), ("0,0", "1000", ["--hostInput"], {})):
-        outd = str(tmp_path / f"out_{batch}_{len(extra)}_{len(env)}")
+                                    ("0,0,0", "17", ["--hostInput"], {}), ("0,0", "1000", ["--hostInput"], {}),
+                                    ("0,0,0,0,0,0,0,0", "9", [], {"SPX_DIN_SEG_KB": "64"}), ("0,0,0,0,0,0,0,0", "1000", [], {"SPX_DIN_SEG_KB": "64"}),
+                                    ("0,0,0,0,0,0,0,0", "11", ["--hostInput"], {})):
+        outd = str(tmp_path / f"out_{batch}_{len(devs)}_{len(extra)}_{len(env)}")
         p = subprocess.run([exe, "--hifi", "-p", "5", "-@", "4", "-i", bam, "-f", fa, "--outDir", outd, "--prefix", "t", "--devices", devs,
                             "--groupsPerBatch", batch] + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr
