@@ -63,6 +63,23 @@ def pmc_traffic(kernel, gps, platform, with_x2=False):
     return (None, None, None) if with_x2 else None
 
 
+def pmc_kernel(kernel, gps, platform):
+    """(duration alone on the chip in ms, VALU wave-instructions) per launch of `kernel` from the committed PMC passes, scaled to a launch
+    of `gps` groups of this run (same workload: both are proportional to the groups of a launch); (None, None, None) without a profile"""
+    for name in (f"r05_counters_{platform}.json", f"r04_counters_{platform}.json", f"r03_counters_{platform}.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            meta = prof.get("_meta", {})
+            if meta.get("platform", "hifi") != platform or not meta.get("groups_per_step"):
+                continue
+            k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel) or prof.get(kernel)
+            scale = gps / (meta["groups_per_step"] / max(1, meta.get("kernel_launches_per_step", 1)))
+            return k["duration_ns_alone"] * scale / 1e6, k["SQ_INSTS_VALU"] * scale, name
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None, None
+
+
 def gen_parallel(genome, first, n, chunk, threads):
     """generate n groups starting at `first` in `chunk`-sized batches on `threads` threads"""
     starts = list(range(first, first + n, chunk))
@@ -247,7 +264,8 @@ def also_leg(platform, steps, warmup):
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
            "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "3", "--cpu-threads", "32", "--no-host-input-leg"]
     # config 3 also end to end: `secphase --ont -b 50` on a BAM of one step's groups
-    cmd += ["--from-bam", "16384"] if platform == "ont" else ["--no-from-bam"]
+    # (65 536 groups = 8.4 GB of BAM: start-up no longer dominates the leg; SPX_BENCH_ALSO_ONT_BAM for another size)
+    cmd += ["--from-bam", os.environ.get("SPX_BENCH_ALSO_ONT_BAM", "65536")] if platform == "ont" else ["--no-from-bam"]
     # (mixed: small batches whose preparations overlap -- six in flight; ONT: the preset of BASELINE config 3, 16 384 groups per
     # step, four lists in flight (DP slices keep a list at ~30 GB) -- the parent has handed its device memory back (spx_trim)
     # before this runs; SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
@@ -268,8 +286,8 @@ def also_leg(platform, steps, warmup):
     return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
             "workload": d["config"]["workload"], "groups_per_step": d["config"]["groups_per_step_per_gpu"],
             "dp_cells_per_step": d["config"]["dp_cells_per_step"], "verified_groups_vs_oracle": d["config"]["verified_groups_vs_oracle"],
-            "roofline": {"kernel": r.get("kernel"), "frac": r.get("frac"), "achieved": r.get("achieved"), "avg_launch_ms": r.get("avg_launch_ms"),
-                         "traffic": r.get("traffic"), "phase": r.get("phase")},
+            "roofline": {"kernel": r.get("kernel"), "frac": r.get("frac"), "alone_frac": r.get("alone_frac"), "lane_instr_per_cell": r.get("lane_instr_per_cell"),
+                         "achieved": r.get("achieved"), "avg_launch_ms": r.get("avg_launch_ms"), "traffic": r.get("traffic"), "phase": r.get("phase")},
             "verified_timed_groups": d["config"].get("verified_timed_groups"),
             "verified_own_relabel_list": (d["config"].get("verified_own_relabel_list") or {}).get("oracle_list_is_byte_prefix_of_this_runs_list"),
             "from_bam": d.get("from_bam"), "guard_exposure": d.get("guard_exposure"),
@@ -748,9 +766,18 @@ def main():
         # whole BAQ phase (forward + backward + MAP, all classes) at the algorithm's 45 flop per cell
         phase_tf = FLOPS_PER_CELL * cells / (baq_ms * 1e-3) / 1e12 if baq_ms > 0 else 0.0
         compulsory = n_prob * 1700  # ~1.7 KB of compulsory HBM bytes per DP problem
+        alone_ms, valu_insts, pmc_src = pmc_kernel(kname, gps / n_slices, args.platform)
         roofline = {
-            "bound": "mfma",  # the compute roof of the two the contract names; see "compute_unit" and "note"
+            "bound": "mfma",  # the compute roof of the two the contract names; the kernels issue no MFMA: see "bound_actual"
+            "bound_actual": "valu_fp64",
             "compute_unit": "valu_fp64",
+            # the same kernel ALONE on the chip (rocprofv3 --pmc serialises the dispatches; committed pass, scaled to this launch size):
+            # what the kernel can do when nothing runs beside it -- `frac` is what it gets inside the pipelined step
+            "alone_frac": round(FWD_FLOPS_PER_CELL * cls_cells / (alone_ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR_TFLOPS, 4) if alone_ms else None,
+            "alone_launch_ms": round(alone_ms, 3) if alone_ms else None,
+            # VALU wave-instructions x 64 lanes per band cell of the launch (SQ_INSTS_VALU of the same pass): 19 algorithmic flops per cell
+            "lane_instr_per_cell": round(valu_insts * 64 / cls_cells, 2) if valu_insts and cls_cells else None,
+            "alone_source": pmc_src,
             "achieved": round(achieved_tf, 3),
             "peak": PEAK_FP64_VECTOR_TFLOPS,
             "unit": "TFLOP/s",
@@ -815,7 +842,11 @@ def main():
                 time_oracle(cores, True, log=oracle_log if world == 1 else None)  # warm-up; also writes the list the BAM leg is checked against
                 runs = sorted(time_oracle(cores, True) for _ in range(nrun))
                 v, dt, cps = runs[len(runs) // 2]
-                cand = {"value": round(v, 2), "unit": "groups/s", "cores": cores, "kind": "port",
+                cand = {"value": round(v, 2), "unit": "groups/s", "cores": cores, "threads": cores, "effective_cpus": int(L.spx_effective_cpus()),
+                        "host_hw_threads": ncpu, "kind": "port",
+                        "cores_note": "`cores` = `threads` = worker threads of the oracle's pool (the contract's field); the container may use "
+                                      "`effective_cpus` CPUs' worth of time (cgroup quota) of the host's `host_hw_threads` hardware threads, so "
+                                      "the figure does not scale to a host that grants more",
                         "sample": f"first {ns} groups of the same workload, oracle (C restatement, -O2 -ffp-contract=off, "
                                   f"pthread pool over groups, per-thread DP scratch instead of calloc/free per call), "
                                   f"median of {nrun} runs after a warm-up, {dt:.2f} s wall; host has {ncpu} hardware threads",
@@ -984,7 +1015,7 @@ def main():
             line["also"] = {}
             for plat in ("ont", "mixed"):
                 try:
-                    line["also"][plat] = also_leg(plat, 4, 2)
+                    line["also"][plat] = also_leg(plat, 8, 2)
                 except Exception as ex:  # noqa: BLE001
                     line["also"][plat] = {"error": str(ex)}
         print(json.dumps(line), flush=True)
