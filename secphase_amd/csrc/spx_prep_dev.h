@@ -46,6 +46,14 @@ struct spx_prep_args {
     int64_t *scan_v, *scan_tile, *scan_grand;
     int64_t scan_stride;
     spx_prep_totals *tot;
+    /* round 5: the HEAVIEST alignments / groups of a list walk alone in a wave of their own (lane 0 walks, the others idle): a lone lane does
+     * not wait for 63 others at every branch of the token loop and its loads touch one cache line per instruction instead of 64 -- a list's
+     * preparation lasts as long as its longest walk, and wave slots are what these latency-bound kernels have plenty of.  slot_heavy /
+     * group_heavy: the n_heavy_* heaviest items, heaviest first (a radix sort of (work estimate, index)); *_flag: 1 for an item that is in
+     * that list (its lane in the ordinary waves, which keep list order -- neighbours share cache lines -- then idles).  NULL: no extraction. */
+    const int32_t *slot_heavy, *group_heavy;
+    const uint8_t *slot_flag, *group_flag;
+    int32_t n_heavy_slots, n_heavy_groups;
 };
 
 struct spx_emit_args {

@@ -29,6 +29,27 @@
 
 using namespace spxl;
 
+/* the item a lane of a walking kernel takes: lane i takes the i-th heaviest alignment / group of the list (spx_prep_args::slot_perm) */
+__device__ __forceinline__ int item_of(int i, int n, int n_heavy, const int32_t *__restrict__ heavy, const uint8_t *__restrict__ flag)
+{
+    if (!heavy) return i < n ? i : -1;
+    const int w = i >> 6, l = i & 63;
+    if (w < n_heavy) { /* a wave for ONE heavy item: lane 0 (an entry of the list that is not heavy enough was left in its ordinary lane) */
+        if (l) return -1;
+        const int it = heavy[w];
+        return flag[it] ? it : -1;
+    }
+    const int j = i - (n_heavy << 6);
+    if (j >= n) return -1;
+    return flag[j] ? -1 : j;
+}
+__device__ __forceinline__ int slot_of(const spx_prep_args &A, int i) { return item_of(i, A.n_slots, A.n_heavy_slots, A.slot_heavy, A.slot_flag); }
+__device__ __forceinline__ int group_of(const spx_prep_args &A, int i) { return item_of(i, A.n_dgroups, A.n_heavy_groups, A.group_heavy, A.group_flag); }
+/* waves of 64 lanes a walking kernel needs */
+static inline unsigned walk_waves(int n, int n_heavy, const void *heavy)
+{
+    return (unsigned)((heavy ? n_heavy : 0) + (n + 63) / 64);
+}
 /* ---------------------------------------------------------------------- */
 __global__ __launch_bounds__(256) void recode_kernel(const uint32_t *__restrict__ raw, uint32_t *__restrict__ code, int64_t n_words,
                                                      const Rec *__restrict__ recs, int32_t n_slots, AlnState *__restrict__ ast)
@@ -129,8 +150,8 @@ extern "C" hipError_t spx_stage_expand(const void *recs, int32_t n_slots, const 
 
 __global__ __launch_bounds__(64) void aln_count_kernel(spx_prep_args A)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_slots) return;
+    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < 0) return;
     AlnState st;
     memset(&st, 0, sizeof st); /* (first kernel of the phase: the state starts here; recode_kernel, which flags has_n, runs after it) */
     const Rec r = A.recs[s];
@@ -153,8 +174,8 @@ __global__ __launch_bounds__(256) void aln_caps_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_slots) return;
+    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < 0) return;
     AlnState st = A.ast[s];
     if (st.err) return;
     if (st.ops_off + st.n_ops > A.ops_cap || st.conf_off + st.conf_cap > A.conf_cap || st.mm_off + st.mm_cap > A.mm_cap) {
@@ -177,8 +198,8 @@ __global__ __launch_bounds__(64) void aln_build_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void group_arena_kernel(spx_prep_args A)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.n_dgroups) return;
+    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < 0) return;
     const int s0 = A.slot0[k];
     GroupView G = {A.slot0[k + 1] - s0, A.recs + s0, A.ast + s0};
     A.ga_bytes[k] = group_arena_layout(G, A.par.all_rows != 0, A.slack).bytes;
@@ -205,8 +226,8 @@ __device__ __forceinline__ GroupCtx group_ctx(const spx_prep_args &A, int k)
 
 __global__ __launch_bounds__(64) void group_merge_kernel(spx_prep_args A)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.n_dgroups) return;
+    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < 0) return;
     GroupCtx c = group_ctx(A, k);
     GroupCount gc;
     if (!c.ok) {
@@ -222,8 +243,8 @@ __global__ __launch_bounds__(64) void group_merge_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_slots) return;
+    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
@@ -233,8 +254,8 @@ __global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_compact_kernel(spx_prep_args A)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_slots) return;
+    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
@@ -245,8 +266,8 @@ __global__ __launch_bounds__(64) void aln_compact_kernel(spx_prep_args A)
 /* consensus windows: rounds run per group, the projections of the windows onto the alignments per alignment */
 __global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.n_dgroups) return;
+    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < 0) return;
     GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
@@ -255,8 +276,8 @@ __global__ __launch_bounds__(64) void group_blocks_kernel(spx_prep_args A)
 }
 __global__ __launch_bounds__(64) void aln_project_kernel(spx_prep_args A)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_slots) return;
+    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
@@ -266,8 +287,8 @@ __global__ __launch_bounds__(64) void aln_project_kernel(spx_prep_args A)
 }
 __global__ __launch_bounds__(64) void group_resume_kernel(spx_prep_args A)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.n_dgroups) return;
+    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < 0) return;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
@@ -278,8 +299,8 @@ __global__ __launch_bounds__(64) void group_resume_kernel(spx_prep_args A)
 }
 __global__ __launch_bounds__(64) void group_blocks_end_kernel(spx_prep_args A)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.n_dgroups) return;
+    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < 0) return;
     GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
@@ -290,8 +311,8 @@ __global__ __launch_bounds__(64) void group_blocks_end_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_count_plan_kernel(spx_prep_args A)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_slots) return;
+    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     GroupCount ac;
@@ -304,8 +325,8 @@ __global__ __launch_bounds__(64) void aln_count_plan_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void group_sum_kernel(spx_prep_args A)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.n_dgroups) return;
+    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < 0) return;
     GroupCount gc = A.gc[k];
     GroupView G;
     const int s0 = A.slot0[k];
@@ -323,8 +344,8 @@ __global__ __launch_bounds__(64) void group_sum_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_emit_kernel(spx_prep_args A, spx_emit_args E)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_slots) return;
+    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || !gc.scored) return;
@@ -344,8 +365,8 @@ __global__ __launch_bounds__(256) void rows_unpack_kernel(const RowRec *__restri
 
 __global__ __launch_bounds__(64) void group_finish_kernel(spx_prep_args A, spx_emit_args E)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.n_dgroups) return;
+    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < 0) return;
     const GroupCount gc = A.gc[k];
     GroupCtx c = group_ctx(A, k);
     const int n = c.G.n;
@@ -589,10 +610,75 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint64_t *__re
 }
 
 /* ---------------------------------------------------------------------- */
+/* work estimate of an alignment: what its walks are proportional to -- the characters of its cs / MD tag (one op per token) and its CIGAR
+ * operations; of a group: the sum over its alignments.  Sorted descending (hipcub radix sort of (estimate, index) pairs). */
+__device__ __forceinline__ int32_t work_estimate(const Rec &r)
+{
+    const int32_t t = r.cs_len >= 0 ? r.cs_len : (r.md_len >= 0 ? r.md_len : 0);
+    return t + 4 * r.n_cigar + (r.l_qseq >> 6);
+}
+__global__ __launch_bounds__(256) void heavy_keys_kernel(spx_prep_args A, int32_t *__restrict__ key_s, int32_t *__restrict__ val_s, int32_t *__restrict__ key_g,
+                                                         int32_t *__restrict__ val_g, uint8_t *__restrict__ flag_s, uint8_t *__restrict__ flag_g)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < A.n_slots) { key_s[i] = work_estimate(A.recs[i]); val_s[i] = i; flag_s[i] = 0; }
+    if (i < A.n_dgroups) {
+        int64_t w = 0;
+        for (int s = A.slot0[i]; s < A.slot0[i + 1]; ++s) w += work_estimate(A.recs[s]);
+        key_g[i] = (int32_t)(w > 0x7fffffff ? 0x7fffffff : w);
+        val_g[i] = i;
+        flag_g[i] = 0;
+    }
+}
+/* the first n_heavy entries of the sorted list are extracted if they are heavy in absolute terms (min_work) AND against the list's own
+ * median (4 x: a list of alignments that are all long -- ONT reads of one length -- gains nothing from moving 2 048 of them) */
+__global__ __launch_bounds__(256) void heavy_mark_kernel(const int32_t *__restrict__ key_sorted, const int32_t *__restrict__ heavy, int32_t n, int32_t n_heavy,
+                                                         int32_t min_work, uint8_t *__restrict__ flag)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t med4 = 4 * (int64_t)key_sorted[n / 2];
+    if (w < n_heavy && key_sorted[w] >= min_work && key_sorted[w] >= med4) flag[heavy[w]] = 1;
+}
+
+extern "C" size_t spx_prep_heavy_temp_bytes(int32_t n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr,
+                                                   n > 0 ? n : 1, 0, 31);
+    return bytes;
+}
+
+/* with n = max(n_slots, n_dgroups): keys 3n, vals 2n int32; slot_heavy [n_slots] / group_heavy [n_dgroups] (the whole sorted index lists: the first
+ * n_heavy_* entries are used); flags one byte per item */
+extern "C" hipError_t spx_prep_heavy(const spx_prep_args *A, int32_t *keys, int32_t *vals, void *temp, size_t temp_bytes, int32_t *slot_heavy, int32_t *group_heavy,
+                                     uint8_t *slot_flag, uint8_t *group_flag, int32_t min_work, hipStream_t st)
+{
+    const int n = std::max(A->n_slots, A->n_dgroups);
+    if (n <= 0) return hipSuccess;
+    int32_t *key_s = keys, *key_g = keys + n, *key_out = keys + 2 * (size_t)n, *val_s = vals, *val_g = vals + n;
+    hipLaunchKernelGGL(heavy_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *A, key_s, val_s, key_g, val_g, slot_flag, group_flag);
+    size_t tb = temp_bytes;
+    hipError_t e = hipSuccess;
+    if (A->n_slots > 0 && A->n_heavy_slots > 0) {
+        e = hipcub::DeviceRadixSort::SortPairsDescending(temp, tb, (const int32_t *)key_s, key_out, (const int32_t *)val_s, slot_heavy, A->n_slots, 0, 31, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(heavy_mark_kernel, dim3((A->n_heavy_slots + 255) / 256), dim3(256), 0, st, key_out, slot_heavy, A->n_slots, A->n_heavy_slots, min_work, slot_flag);
+    }
+    tb = temp_bytes;
+    if (A->n_dgroups > 0 && A->n_heavy_groups > 0) {
+        e = hipcub::DeviceRadixSort::SortPairsDescending(temp, tb, (const int32_t *)key_g, key_out, (const int32_t *)val_g, group_heavy, A->n_dgroups, 0, 31, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(heavy_mark_kernel, dim3((A->n_heavy_groups + 255) / 256), dim3(256), 0, st, key_out, group_heavy, A->n_dgroups, A->n_heavy_groups, 4 * min_work, group_flag); /* (a group: the sum over its alignments) */
+    }
+    return hipGetLastError();
+}
+
+/* ---------------------------------------------------------------------- */
 extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *raw_seq, int64_t seq_words, hipStream_t st)
 {
     if (A->n_slots <= 0) return hipSuccess;
-    if (A->exact_counts) hipLaunchKernelGGL(aln_count_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
+    const dim3 ga(walk_waves(A->n_slots, A->n_heavy_slots, A->slot_heavy));
+    if (A->exact_counts) hipLaunchKernelGGL(aln_count_kernel, ga, dim3(64), 0, st, *A);
     else hipLaunchKernelGGL(aln_caps_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
     if (seq_words > 0)
         hipLaunchKernelGGL(recode_kernel, dim3((unsigned)std::min<int64_t>((seq_words + 255) / 256, 2048)), dim3(256), 0, st, raw_seq,
@@ -600,14 +686,14 @@ extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *ra
     hipLaunchKernelGGL(slots_extract_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
     { hipError_t e = run_scan(A, A->n_slots, 3, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(slots_apply_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
-    hipLaunchKernelGGL(aln_build_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A);
+    hipLaunchKernelGGL(aln_build_kernel, ga, dim3(64), 0, st, *A);
     return hipGetLastError();
 }
 
 extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *base_out, int64_t *mk_base, hipStream_t st)
 {
     if (A->n_dgroups <= 0) return hipSuccess;
-    const dim3 gg((A->n_dgroups + 63) / 64), ga((A->n_slots + 63) / 64), b64(64);
+    const dim3 gg(walk_waves(A->n_dgroups, A->n_heavy_groups, A->group_heavy)), ga(walk_waves(A->n_slots, A->n_heavy_slots, A->slot_heavy)), b64(64);
     hipLaunchKernelGGL(group_arena_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(arena_extract_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
     { hipError_t e = run_scan(A, A->n_dgroups, 1, st); if (e != hipSuccess) return e; }
@@ -635,11 +721,11 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
 extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st)
 {
     if (A->n_dgroups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aln_emit_kernel, dim3((A->n_slots + 63) / 64), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(aln_emit_kernel, dim3(walk_waves(A->n_slots, A->n_heavy_slots, A->slot_heavy)), dim3(64), 0, st, *A, *E);
     if (E->out.rr && E->n_rows > 0)
         hipLaunchKernelGGL(rows_unpack_kernel, dim3((unsigned)((E->n_rows + 255) / 256)), dim3(256), 0, st, E->out.rr, E->n_rows, E->out.rows,
                            E->out.row_expect, E->out.row_prob, E->out.row_rawq);
-    hipLaunchKernelGGL(group_finish_kernel, dim3((A->n_dgroups + 63) / 64), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(group_finish_kernel, dim3(walk_waves(A->n_dgroups, A->n_heavy_groups, A->group_heavy)), dim3(64), 0, st, *A, *E);
     if (E->n_prob > 0)
         hipLaunchKernelGGL(problem_constants_kernel, dim3((E->n_prob + 255) / 256), dim3(256), 0, st, A->par, E->n_prob, E->out.L, E->out.R,
                            E->out.has_n, E->hmm);

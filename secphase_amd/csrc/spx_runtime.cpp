@@ -41,6 +41,9 @@ extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *g
 extern "C" hipError_t spx_launch_results(const spx_dev_groups *Gd, const spx_group_info *info, const int32_t *rfe,
                                          spx_group_out *out, hipStream_t st);
 extern "C" hipError_t spx_prep_phase1(const spx_prep_args *A, const uint32_t *raw_seq, int64_t seq_words, hipStream_t st);
+extern "C" size_t spx_prep_heavy_temp_bytes(int32_t n);
+extern "C" hipError_t spx_prep_heavy(const spx_prep_args *A, int32_t *keys, int32_t *vals, void *temp, size_t temp_bytes, int32_t *slot_heavy, int32_t *group_heavy,
+                                     uint8_t *slot_flag, uint8_t *group_flag, int32_t min_work, hipStream_t st);
 extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *base_out, int64_t *mk_base, hipStream_t st);
 extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st);
 extern "C" size_t spx_order_temp_bytes(int32_t n_prob);
@@ -157,7 +160,7 @@ struct spx_ctx {
     struct PrepLane {
         hipStream_t stream = nullptr;
         std::mutex mu;
-        DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort;
+        DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort, pool_perm;
         spx_prep_totals *d_tot = nullptr, *h_tot = nullptr; /* device / pinned host */
         spxl::PlanBase *d_bounds = nullptr, *h_bounds = nullptr; /* DP slices: SPX_MAX_SLICES + 1 prefix records */
         int32_t *d_bins = nullptr;                          /* 3 x SPX_N_CLASSES x 1024 */
@@ -431,7 +434,7 @@ extern "C" void spx_destroy(spx_ctx *c)
     c->stage_pool.reset();
     for (int l = 0; l < spx_ctx::SPX_N_PREP; ++l) {
         spx_ctx::PrepLane &PL = c->lane[l];
-        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort})
+        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_perm})
             if (b->p) (void)hipFree(b->p);
         if (PL.d_tot) (void)hipFree(PL.d_tot);
         if (PL.h_tot) (void)hipHostFree(PL.h_tot);
@@ -1207,6 +1210,27 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     int64_t *d_mkb = (int64_t *)(base + w->o_mkb);
     if (w->ev_staged) HIPCHK(hipStreamWaitEvent(PL.stream, w->ev_staged, 0));
     HIPCHK(hipMemsetAsync(PL.d_tot, 0, sizeof(spx_prep_totals), PL.stream));
+    /* the heaviest alignments / groups of the list walk alone in waves of their own (spx_prep_dev.h): SPX_PREP_HEAVY = how many alignments at
+     * most (default 1024; half as many groups; 0: none), SPX_PREP_HEAVY_MIN = the work estimate (tag characters + 4 x CIGAR operations) from
+     * which an item counts as heavy (default 2048: a HiFi read of 15 kb stays where it is, an ONT-like read of 20 kb moves out) */
+    static const int heavy = [] { const char *e = getenv("SPX_PREP_HEAVY"); return e ? std::max(0, atoi(e)) : 1024; }();
+    static const int heavy_min = [] { const char *e = getenv("SPX_PREP_HEAVY_MIN"); return e ? std::max(1, atoi(e)) : 2048; }();
+    if (heavy > 0 && ns >= 64) {
+        const size_t n = std::max(ns, ng), tb = spx_prep_heavy_temp_bytes((int32_t)n);
+        Carver pc;
+        const size_t o_keys = pc.take<int32_t>(3 * n), o_vals = pc.take<int32_t>(2 * n), o_sh = pc.take<int32_t>(ns + 1), o_gh = pc.take<int32_t>(ng + 1),
+                     o_sf = pc.take<uint8_t>(ns + 1), o_gf = pc.take<uint8_t>(ng + 1), o_tmp = pc.take<char>(tb + 256);
+        if ((rc = ensure_pool(PL, PL.pool_perm, pc.off + 256))) return fail(rc, "device memory for the list of heavy alignments");
+        char *pb = (char *)PL.pool_perm.p;
+        A.n_heavy_slots = (int32_t)std::min<size_t>((size_t)heavy, ns / 16);
+        A.n_heavy_groups = (int32_t)std::min<size_t>((size_t)heavy / 2, ng / 16);
+        HIPCHK(spx_prep_heavy(&A, (int32_t *)(pb + o_keys), (int32_t *)(pb + o_vals), pb + o_tmp, tb, (int32_t *)(pb + o_sh), (int32_t *)(pb + o_gh),
+                              (uint8_t *)(pb + o_sf), (uint8_t *)(pb + o_gf), heavy_min, PL.stream));
+        A.slot_heavy = (const int32_t *)(pb + o_sh);
+        A.group_heavy = (const int32_t *)(pb + o_gh);
+        A.slot_flag = (const uint8_t *)(pb + o_sf);
+        A.group_flag = (const uint8_t *)(pb + o_gf);
+    }
     bool phase1 = true;
     for (int attempt = 0;; ++attempt) {
         /* (the per-alignment state is initialised by the first kernel of phase 1, not by a fill launch) */
@@ -1642,7 +1666,7 @@ extern "C" int spx_trim(spx_ctx *c)
         spx_ctx::PrepLane &PL = c->lane[l];
         std::lock_guard<std::mutex> pl(PL.mu);
         HIPCHK(hipStreamSynchronize(PL.stream));
-        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort})
+        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_perm})
             if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
