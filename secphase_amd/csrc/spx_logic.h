@@ -224,40 +224,56 @@ SPX_HD bool lower_c(char c) { return c >= 'a' && c <= 'z'; }
 SPX_HD bool upper_c(char c) { return c >= 'A' && c <= 'Z'; }
 SPX_HD bool digit_c(char c) { return c >= '0' && c <= '9'; }
 
-/* decimal prefix of s like atoi (no sign / blanks occur here); wraps like 32-bit arithmetic on absurd input */
-SPX_HD int atoi_c(const char *s)
-{
-    uint32_t v = 0;
-    while (digit_c(*s)) { v = v * 10u + (uint32_t)(*s - '0'); ++s; }
-    return (int)v;
-}
+/* A tag string as the walks read it.  On the device a character comes out of an 8-byte window that is re-loaded when the cursor leaves
+ * it: ONE load per eight characters instead of one or more per character -- the tokenizers are chains of dependent loads, and a lone
+ * lane walking a 35 KB cs string spends its time waiting for them (round 5).  The window is an ALIGNED 8-byte word: up to seven bytes in
+ * front of the string and behind its NUL are read and never looked at; the text pool starts on a 256-byte boundary and ends with 16
+ * spare bytes (spx_prep.cpp stage_layout).  On the host the same code reads byte by byte. */
+struct TextView {
+    const char *s;
+    uint64_t w;
+    uintptr_t wa;
+    SPX_HD explicit TextView(const char *p) : s(p), w(0), wa(1) {} /* (no aligned address equals 1) */
+    SPX_HD char operator[](int i)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uintptr_t a = (uintptr_t)(s + i), al = a & ~(uintptr_t)7;
+        if (al != wa) { w = *reinterpret_cast<const uint64_t *>(al); wa = al; }
+        return (char)(w >> ((a & 7) * 8));
+#else
+        return s[i];
+#endif
+    }
+};
 
-/* first short-form cs token at or after s (what an un-anchored POSIX search of
- * (:[0-9]+)|([+-][a-z]+)|((\*[a-z]+)+) returns); false if none */
-SPX_HD bool next_cs_token(const char *s, int &so, int &eo)
+/* first short-form cs token at or after t[at] (what an un-anchored POSIX search of
+ * (:[0-9]+)|([+-][a-z]+)|((\*[a-z]+)+) returns); false if none.  so / eo are relative to `at`; num = the decimal value of a ':' token
+ * (atoi of its digits: wraps like 32-bit arithmetic on absurd input) */
+SPX_HD bool next_cs_token(TextView &t, int at, int &so, int &eo, int &num)
 {
-    for (int p = 0; s[p]; ++p) {
-        const char c = s[p];
+    for (int p = 0; t[at + p]; ++p) {
+        const char c = t[at + p];
         if (c == ':') {
-            if (!digit_c(s[p + 1])) continue;
+            if (!digit_c(t[at + p + 1])) continue;
             int e = p + 1;
-            while (digit_c(s[e])) ++e;
-            so = p; eo = e;
+            uint32_t v = 0;
+            for (char d = t[at + e]; digit_c(d); d = t[at + ++e]) v = v * 10u + (uint32_t)(d - '0');
+            so = p; eo = e; num = (int)v;
             return true;
         }
         if (c == '+' || c == '-') {
-            if (!lower_c(s[p + 1])) continue;
+            if (!lower_c(t[at + p + 1])) continue;
             int e = p + 1;
-            while (lower_c(s[e])) ++e;
+            while (lower_c(t[at + e])) ++e;
             so = p; eo = e;
             return true;
         }
         if (c == '*') {
-            if (!lower_c(s[p + 1])) continue;
+            if (!lower_c(t[at + p + 1])) continue;
             int e = p;
-            while (s[e] == '*' && lower_c(s[e + 1])) {
+            while (t[at + e] == '*' && lower_c(t[at + e + 1])) {
                 ++e;
-                while (lower_c(s[e])) ++e;
+                while (lower_c(t[at + e])) ++e;
             }
             so = p; eo = e;
             return true;
@@ -266,26 +282,26 @@ SPX_HD bool next_cs_token(const char *s, int &so, int &eo)
     return false;
 }
 
-/* first MD token at or after s: a mismatch run X(0X)*, a match count, or a deletion ^XXX (cigar_it.h:10) */
-SPX_HD bool next_md_token(const char *s, int &so, int &eo)
+/* first MD token at or after t[at]: a mismatch run X(0X)*, a match count, or a deletion ^XXX (cigar_it.h:10) */
+SPX_HD bool next_md_token(TextView &t, int at, int &so, int &eo)
 {
-    for (int p = 0; s[p]; ++p) {
-        const char c = s[p];
+    for (int p = 0; t[at + p]; ++p) {
+        const char c = t[at + p];
         if (upper_c(c)) {
             int e = p + 1;
-            while (s[e] == '0' && upper_c(s[e + 1])) e += 2;
+            while (t[at + e] == '0' && upper_c(t[at + e + 1])) e += 2;
             so = p; eo = e;
             return true;
         }
         if (digit_c(c)) {
             int e = p + 1;
-            while (digit_c(s[e])) ++e;
+            while (digit_c(t[at + e])) ++e;
             so = p; eo = e;
             return true;
         }
-        if (c == '^' && upper_c(s[p + 1])) {
+        if (c == '^' && upper_c(t[at + p + 1])) {
             int e = p + 1;
-            while (upper_c(s[e])) ++e;
+            while (upper_c(t[at + e])) ++e;
             so = p; eo = e;
             return true;
         }
@@ -294,13 +310,12 @@ SPX_HD bool next_md_token(const char *s, int &so, int &eo)
 }
 
 /* one MD step (cigar_it.c:72-141): a lone "0" separates two mismatches and is skipped */
-SPX_HD int md_step(const char *md, int &at, Op &cur)
+SPX_HD int md_step(TextView &md, int &at, Op &cur)
 {
     for (;;) {
-        const char *s = md + at;
         int so, eo;
-        if (!next_md_token(s, so, eo)) return 0;
-        const char c = s[so];
+        if (!next_md_token(md, at, so, eo)) return 0;
+        const char c = md[at + so];
         if (c == '0') { cur.op = SPX_CDIFF; cur.len = 0; }
         else if (c <= '9') {
             /* sic: the reference copies eo - so characters from the START of the shifted string (not from so) and
@@ -308,7 +323,7 @@ SPX_HD int md_step(const char *md, int &at, Op &cur)
             int n = eo - so;
             if (n > 19) n = 19;
             uint32_t v = 0;
-            for (int k = 0; k < n && digit_c(s[k]); ++k) v = v * 10u + (uint32_t)(s[k] - '0');
+            for (int k = 0; k < n && digit_c(md[at + k]); ++k) v = v * 10u + (uint32_t)(md[at + k] - '0');
             cur.op = SPX_CEQUAL;
             cur.len = (int)v;
         } else if (c < 90) { cur.op = SPX_CDIFF; cur.len = 1 + (eo - so - 1) / 2; }
@@ -354,7 +369,7 @@ SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, Aln
     st.rclip = ((cigar[r.n_cigar - 1] & 0xf) == SPX_CHARD_CLIP) ? (int32_t)(cigar[r.n_cigar - 1] >> 4) : 0;
     const bool use_cs = r.cs_len >= 0, use_md = !use_cs && r.md_len >= 0;
     if (!use_cs && !use_md) return SPX_ENOTAG; /* neither cs nor MD: the reference exits (cigar_it.c:64-67) */
-    const char *tag = P.text + r.tag_off;
+    TextView tag(P.text + r.tag_off);
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
     int md_at = 0;
     Op cur;
@@ -376,11 +391,10 @@ SPX_HD int build_ops(const Rec &r, const Pools &P, int min_q, int indel_thr, Aln
         int rd, sq, rf;
         const bool mtype = op == SPX_CMATCH || op == SPX_CEQUAL || op == SPX_CDIFF;
         if (use_cs && (mtype || op == SPX_CINS || op == SPX_CDEL)) {
-            int so, eo;
-            const char *s = tag + cs_at;
-            if (next_cs_token(s, so, eo)) {
-                const char c = s[so];
-                if (c == ':') { cur.op = SPX_CEQUAL; cur.len = atoi_c(s + so + 1); }
+            int so, eo, num = 0;
+            if (next_cs_token(tag, cs_at, so, eo, num)) {
+                const char c = tag[cs_at + so];
+                if (c == ':') { cur.op = SPX_CEQUAL; cur.len = num; }
                 else if (c == '*') { cur.op = SPX_CDIFF; cur.len = (eo - so + 1) / 3; }
                 else if (c == '+') { cur.op = SPX_CINS; cur.len = eo - so - 1; }
                 else { cur.op = SPX_CDEL; cur.len = eo - so - 1; }
@@ -461,15 +475,58 @@ SPX_HD int finish_alignment(const Rec &r, const Pools &P, int min_q, int thr, Al
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
     const uint8_t *qual = P.qual + r.qual_off;
     st.rfs = st.rfe = st.rds = st.rde = -1;
-    for (int t = 1; t < st.n_visit; ++t) {
-        const Op o = ops[t];
-        if (st.rfs == -1 && mx(o.op)) {
-            st.rfs = o.rfs;
-            if (rev) st.rde = o.rde; else st.rds = o.rds;
-        }
-        if (st.rfe == -1 && st.rfs != -1 && (o.op == SPX_CHARD_CLIP || o.op == SPX_CSOFT_CLIP)) {
-            st.rfe = o.rfe;
-            if (rev) st.rds = o.rde + 1; else st.rde = o.rds - 1;
+    /* ONE pass over the visited ops for the three lists (round 5; they were three passes: every op was loaded three times by a lane that
+     * does nothing but wait for its loads), four ops fetched at a time so that their loads are in flight together.  Each list is
+     * appended in op order, as before. */
+    int nc = 0, nm = 0;
+    int c_sqs = 0, c_rfs = r.pos;
+    int c_rd = rev ? ops[0].rde : ops[0].rds;
+    for (int t0 = 1; t0 < st.n_visit; t0 += 4) {
+        Op quad[4];
+        const int m = st.n_visit - t0 < 4 ? st.n_visit - t0 : 4;
+        for (int k = 0; k < 4; ++k)
+            if (k < m) quad[k] = ops[t0 + k];
+        for (int k = 0; k < 4; ++k) {
+            if (k >= m) break;
+            const Op o = quad[k];
+            /* aligned extents (ptAlignment_init_coordinates) */
+            if (st.rfs == -1 && mx(o.op)) {
+                st.rfs = o.rfs;
+                if (rev) st.rde = o.rde; else st.rds = o.rds;
+            }
+            if (st.rfe == -1 && st.rfs != -1 && (o.op == SPX_CHARD_CLIP || o.op == SPX_CSOFT_CLIP)) {
+                st.rfe = o.rfe;
+                if (rev) st.rds = o.rde + 1; else st.rde = o.rds - 1;
+            }
+            /* confident blocks (find_confident_blocks) */
+            const bool indel = o.op == SPX_CINS || o.op == SPX_CDEL;
+            const bool clip = o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP;
+            if ((indel && o.len > thr) || clip) {
+                if (c_sqs < o.sqs && c_rfs < o.rfs) {
+                    if (nc >= st.conf_cap) return SPX_ENOMEM;
+                    Blk b;
+                    b.rfs = c_rfs; b.rfe = o.rfs - 1; b.sqs = c_sqs; b.sqe = o.sqs - 1;
+                    if (rev) { b.rds = o.rde + 1; b.rde = c_rd; } else { b.rds = c_rd; b.rde = o.rds - 1; }
+                    conf[nc++] = b;
+                }
+                c_sqs = o.sqe + 1;
+                c_rfs = o.rfe + 1;
+                c_rd = rev ? o.rds - 1 : o.rde + 1;
+            }
+            /* mismatch bases with raw quality >= min_q, in op order (ascending read position on the forward strand,
+             * descending on the reverse strand) */
+            if (o.op == SPX_CDIFF) {
+                for (int j = 0; j < o.len; ++j) {
+                    const int b = o.sqs + j;
+                    if (b < 0 || b >= r.l_qseq) continue; /* cs longer than SEQ: the reference would read past the record */
+                    const int q = qual[b];
+                    if (q < min_q) continue;
+                    if (nm >= st.mm_cap) return SPX_ENOMEM;
+                    MM mrec;
+                    mrec.base_idx = b; mrec.pos = rev ? o.rde - j : o.rds + j; mrec.q = q; mrec.ref_pos = o.rfs + j;
+                    mmv[nm++] = mrec;
+                }
+            }
         }
     }
     {
@@ -478,30 +535,6 @@ SPX_HD int finish_alignment(const Rec &r, const Pools &P, int min_q, int thr, Al
             st.rfe = o.rfe;
             if (rev) st.rds = o.rds; else st.rde = o.rde;
         }
-    }
-    /* confident blocks */
-    int nc = 0;
-    {
-        int c_sqs = 0, c_rfs = r.pos;
-        int c_rd = rev ? ops[0].rde : ops[0].rds;
-        for (int t = 1; t < st.n_visit; ++t) {
-            const Op o = ops[t];
-            const bool indel = o.op == SPX_CINS || o.op == SPX_CDEL;
-            const bool clip = o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP;
-            if (!(indel || clip)) continue;
-            if (indel && o.len <= thr) continue;
-            if (c_sqs < o.sqs && c_rfs < o.rfs) {
-                if (nc >= st.conf_cap) return SPX_ENOMEM;
-                Blk b;
-                b.rfs = c_rfs; b.rfe = o.rfs - 1; b.sqs = c_sqs; b.sqe = o.sqs - 1;
-                if (rev) { b.rds = o.rde + 1; b.rde = c_rd; } else { b.rds = c_rd; b.rde = o.rds - 1; }
-                conf[nc++] = b;
-            }
-            c_sqs = o.sqe + 1;
-            c_rfs = o.rfe + 1;
-            c_rd = rev ? o.rds - 1 : o.rde + 1;
-        }
-        const Op o = ops[st.rest];
         if (c_sqs <= o.sqe) {
             if (nc >= st.conf_cap) return SPX_ENOMEM;
             Blk b;
@@ -511,23 +544,6 @@ SPX_HD int finish_alignment(const Rec &r, const Pools &P, int min_q, int thr, Al
         }
     }
     st.n_conf = nc;
-    /* mismatch bases with raw quality >= min_q, in op order (ascending read position on the forward strand,
-     * descending on the reverse strand) */
-    int nm = 0;
-    for (int t = 1; t < st.n_visit; ++t) {
-        const Op o = ops[t];
-        if (o.op != SPX_CDIFF) continue;
-        for (int j = 0; j < o.len; ++j) {
-            const int b = o.sqs + j;
-            if (b < 0 || b >= r.l_qseq) continue; /* cs longer than SEQ: the reference would read past the record */
-            const int q = qual[b];
-            if (q < min_q) continue;
-            if (nm >= st.mm_cap) return SPX_ENOMEM;
-            MM m;
-            m.base_idx = b; m.pos = rev ? o.rde - j : o.rds + j; m.q = q; m.ref_pos = o.rfs + j;
-            mmv[nm++] = m;
-        }
-    }
     st.n_mm = nm;
     return 0;
 }
@@ -648,21 +664,38 @@ SPX_HD void aln_fill(const GroupView &G, int i, const Pools &P, const int32_t *p
     MM s;
     s.pos = 0x7fffffff; s.base_idx = 0; s.q = 0; s.ref_pos = 0;
     if (left > 0) s = P.mm[st.mm_off + head];
-    for (int col = 0; col < ncol; ++col) {
-        const int p = pos[col];
-        while (left > 0 && s.pos < p) {
-            head += step;
-            if (--left > 0) s = P.mm[st.mm_off + head];
+    /* four columns at a time (round 5): their positions, and the quality a MATCH marker of this alignment would carry at each (what
+     * match_marker reads: one scattered byte per column, a cache miss each on a long read), are fetched together -- four loads in flight
+     * instead of one per column on the critical path; a column that turns out to hold this alignment's mismatch does not use its byte */
+    for (int c0 = 0; c0 < ncol; c0 += 4) {
+        int pp[4], bi[4];
+        uint8_t qq[4];
+        const int m4 = ncol - c0 < 4 ? ncol - c0 : 4;
+        for (int k = 0; k < 4; ++k) pp[k] = k < m4 ? pos[c0 + k] : 0;
+        for (int k = 0; k < 4; ++k) {
+            bi[k] = rev ? r.l_qseq + st.rclip - pp[k] - 1 : pp[k] - st.lclip;
+            qq[k] = (k < m4 && bi[k] >= 0 && bi[k] < r.l_qseq) ? qual[bi[k]] : 0;
         }
-        Mk m;
-        if (left > 0 && s.pos == p) {
-            m.base_idx = s.base_idx; m.ref_pos = s.ref_pos; m.row = -1; m.q = (uint8_t)s.q; m.is_match = 0;
-            m.pad0 = m.pad1 = 0;
-            head += step;
-            if (--left > 0) s = P.mm[st.mm_off + head];
-        } else
-            m = match_marker(r, st, qual, p);
-        mk[(int64_t)col * n + i] = m;
+        for (int k = 0; k < 4; ++k) {
+            if (k >= m4) break;
+            const int p = pp[k];
+            while (left > 0 && s.pos < p) {
+                head += step;
+                if (--left > 0) s = P.mm[st.mm_off + head];
+            }
+            Mk m;
+            if (left > 0 && s.pos == p) {
+                m.base_idx = s.base_idx; m.ref_pos = s.ref_pos; m.row = -1; m.q = (uint8_t)s.q; m.is_match = 0;
+                m.pad0 = m.pad1 = 0;
+                head += step;
+                if (--left > 0) s = P.mm[st.mm_off + head];
+            } else { /* = match_marker(r, st, qual, p) */
+                m.is_match = 1; m.row = -1; m.ref_pos = -1; m.pad0 = m.pad1 = 0;
+                m.base_idx = bi[k];
+                m.q = qq[k];
+            }
+            mk[(int64_t)(c0 + k) * n + i] = m;
+        }
     }
 }
 
@@ -678,17 +711,25 @@ SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t 
     const int step = rev ? -1 : 1;
     if (ncol <= 0) return;
     int p = pos[col];
-    for (int t = 1; t < st.n_visit && col >= 0 && col < ncol; ++t) {
-        const Op o = ops[t];
-        while (col >= 0 && col < ncol) {
-            if (!(o.rds <= p && p <= o.rde)) break;
-            /* (every alignment writes the same 0; a relaxed atomic store, so that the host plan's threads -- one per alignment,
-             * like the lanes of the kernel -- do it without a data race: ThreadSanitizer run of the CPU suite) */
-            if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) __atomic_store_n(&keep[col], (uint8_t)0, __ATOMIC_RELAXED);
-            if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
-                mk[(int64_t)col * n + i].ref_pos = rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
-            col += step;
-            if (col >= 0 && col < ncol) p = pos[col];
+    /* (four ops fetched at a time: their loads are in flight together) */
+    for (int t0 = 1; t0 < st.n_visit && col >= 0 && col < ncol; t0 += 4) {
+        Op quad[4];
+        const int m4 = st.n_visit - t0 < 4 ? st.n_visit - t0 : 4;
+        for (int k = 0; k < 4; ++k)
+            if (k < m4) quad[k] = ops[t0 + k];
+        for (int k = 0; k < 4; ++k) {
+            if (k >= m4 || !(col >= 0 && col < ncol)) break;
+            const Op o = quad[k];
+            while (col >= 0 && col < ncol) {
+                if (!(o.rds <= p && p <= o.rde)) break;
+                /* (every alignment writes the same 0; a relaxed atomic store, so that the host plan's threads -- one per alignment,
+                 * like the lanes of the kernel -- do it without a data race: ThreadSanitizer run of the CPU suite) */
+                if (o.op == SPX_CINS || o.op == SPX_CSOFT_CLIP || o.op == SPX_CHARD_CLIP) __atomic_store_n(&keep[col], (uint8_t)0, __ATOMIC_RELAXED);
+                if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
+                    mk[(int64_t)col * n + i].ref_pos = rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
+                col += step;
+                if (col >= 0 && col < ncol) p = pos[col];
+            }
         }
     }
 }

@@ -351,8 +351,18 @@ extern "C" int spx_create(int device, spx_ctx **out)
         prep_cus = (prep_cus + 7) / 8 * 8;
         for (int i = 0; i < ncu; ++i) (i < prep_cus ? m_prep : m_dp)[(size_t)i / 32] |= 1u << (i % 32);
     }
+    /* SPX_DP_EXCLUDE_CUS=k (round 5 experiment): only the DP streams are masked -- k CUs (a multiple of 8: one or more from every XCD) never
+     * run a DP wave, the preparation streams stay unmasked and find free registers there whatever the DP kernels are doing */
+    bool dp_only = false;
+    if (const char *e = getenv("SPX_DP_EXCLUDE_CUS")) {
+        int k = (atoi(e) + 7) / 8 * 8;
+        if (!masked && k > 0 && k < ncu / 2) {
+            for (int i = 0; i < ncu; ++i) if (i >= k) m_dp[(size_t)i / 32] |= 1u << (i % 32);
+            masked = dp_only = true;
+        }
+    }
     auto mk_stream = [&](hipStream_t *st, const std::vector<uint32_t> &mask) -> hipError_t {
-        if (masked) {
+        if (masked && !(dp_only && &mask == &m_prep)) {
             hipError_t e = hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
             if (e == hipSuccess) return e;
             (void)hipGetLastError();
