@@ -305,7 +305,9 @@ def main():
     ap.add_argument("--depth", type=int, default=0,
                     help="batches in flight in the pipeline (their device preparations run side by side); 0: 3 (hifi), 6 (mixed), "
                          "4 (ont; round 3: 2 -- a list of 16 384 ONT groups kept ~70 GB of saved rows; with DP slices ~30 GB)")
-    ap.add_argument("--distinct", type=int, default=4, help="at most this many distinct batches per rank (HBM / host memory)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="at most this many distinct batches per rank (HBM / host memory); 0: 8 for --platform hifi (8 x 131 072 = the 1 M reads of BASELINE "
+                         "config 2), 4 otherwise (raised to depth + 1 where the pipeline needs it)")
     ap.add_argument("--gen-chunk", type=int, default=1024, help="groups per generator call (parallel generation)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="groups in the CPU baseline sample (0: preset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -380,6 +382,8 @@ def main():
     ont = args.platform == "ont"
     mixed = args.platform == "mixed"
     gps = args.groups_per_step or (16384 if ont else 16384 if mixed else 131072)
+    if args.distinct <= 0:
+        args.distinct = 8 if not (ont or mixed) else 4
     if args.depth <= 0:
         # round 4: the scratch of a work list (1/s of every DP row + the saved forward rows) exists per DP slice, not per list
         # (16 GB per slice by default), so that ONT lists (70 -> ~30 GB per 16 384 groups) and mixed lists fit deeper pipelines
@@ -429,6 +433,12 @@ def main():
         try:
             per = max(1, batch_bytes(batches[0]))
             avail = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024
+            try:  # the container's own limit (cgroup v2): the GPU boxes show 3 TB of host memory and grant 300 GiB
+                lim = open("/sys/fs/cgroup/memory.max").read().strip()
+                if lim != "max":
+                    avail = min(avail, int(lim) - int(open("/sys/fs/cgroup/memory.current").read()))
+            except Exception:  # noqa: BLE001
+                pass
             local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
             fit = int(0.45 * avail / max(1, local_world) // per)
             D = max(2, min(D, fit))

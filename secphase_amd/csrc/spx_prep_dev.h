@@ -77,8 +77,13 @@ struct spx_order_segs { /* where each band class' launch order lives inside the 
     int64_t cap[SPX_N_CLASSES];
 };
 
+#define SPX_MAX_SLICES 32 /* DP slices of a work list */
 struct spx_order_args {
     int32_t n_prob, pad;
+    /* round 5: ONE pair of sorts per work list instead of one per DP slice: the slice of a problem is the top field of its key */
+    int32_t n_slices;
+    int32_t slice_prob[SPX_MAX_SLICES + 1]; /* first problem of every slice, [n_slices] = n_prob */
+    const spx_order_segs *segs_f, *segs_b;  /* [n_slices], device memory */
     const int32_t *bw, *L, *n_rows, *row_off, *rows;
     uint64_t *key_f, *key_b, *key_sorted;
     int32_t *val, *val_sorted;

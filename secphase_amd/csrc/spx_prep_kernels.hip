@@ -547,10 +547,12 @@ __global__ __launch_bounds__(256) void order_keys_kernel(spx_order_args O)
     /* rows the backward kernel walks: L down to the first wanted row */
     const int br = nr > 0 ? L - O.rows[O.row_off[p]] + 1 : 0;
     const uint32_t lb = (uint32_t)br > 0xfffffu ? 0xfffffu : (uint32_t)br;
-    const uint64_t hi = ((uint64_t)cls << 30) | ((uint64_t)bw << 20);
+    int sl = 0;
+    while (sl + 1 < O.n_slices && p >= O.slice_prob[sl + 1]) ++sl; /* (at most 32 slices; the bounds sit in the kernel arguments) */
+    const uint64_t hi = ((uint64_t)sl << 34) | ((uint64_t)cls << 30) | ((uint64_t)bw << 20);
     O.key_f[p] = hi | (0xfffffu - lf);
     O.key_b[p] = hi | (0xfffffu - lb);
-    O.val[p] = p + O.pad; /* (pad = first problem of the slice these arrays start at: the orders hold list-wide problem ids) */
+    O.val[p] = p;
 }
 
 /* DP slices: where the problems / rows / scratch of the dispatched groups [ng * k / K, ng * (k + 1) / K) start -- the
@@ -572,23 +574,30 @@ extern "C" hipError_t spx_prep_slice_bounds(const int32_t *slot0, const spxl::Pl
     return hipGetLastError();
 }
 
+/* bin of a key: (slice, class, band width) */
+__device__ __forceinline__ uint32_t order_bin(uint64_t key)
+{
+    const uint32_t sl = (uint32_t)(key >> 34), cls = (uint32_t)(key >> 30) & 0xfu, bw = (uint32_t)(key >> 20) & 0x3ffu;
+    return ((sl * SPX_N_CLASSES + cls) << 10) | bw;
+}
 __global__ __launch_bounds__(256) void order_bins_kernel(const uint64_t *__restrict__ keys, int32_t n, int32_t *__restrict__ bin_start,
                                                          int32_t *__restrict__ bin_end)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t b = (uint32_t)(keys[i] >> 20);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 20) != b) bin_start[b] = i;
-    if (i == n - 1 || (uint32_t)(keys[i + 1] >> 20) != b) bin_end[b] = i + 1;
+    const uint32_t b = order_bin(keys[i]);
+    if (i == 0 || order_bin(keys[i - 1]) != b) bin_start[b] = i;
+    if (i == n - 1 || order_bin(keys[i + 1]) != b) bin_end[b] = i + 1;
 }
 
-/* one workgroup: padded size of every (class, band) bin and its offset inside the class segment */
+/* one workgroup per slice: padded size of every (class, band) bin and its offset inside the class segment */
 __global__ __launch_bounds__(1024) void order_pad_kernel(const int32_t *__restrict__ bin_start, const int32_t *__restrict__ bin_end,
                                                          int32_t *__restrict__ pad_base, int bwd)
 {
     __shared__ int64_t lds[1024];
+    const int sl = blockIdx.x;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls) { /* the 1024 possible band widths of one class */
-        const int b = (cls << 10) + threadIdx.x;
+        const int b = ((sl * SPX_N_CLASSES + cls) << 10) + threadIdx.x;
         const int ppw = 64 / (bwd ? class_lanes_bwd(cls) : class_lanes(cls));
         const int cnt = bin_start[b] >= 0 ? bin_end[b] - bin_start[b] : 0;
         const int64_t padded = (cnt + ppw - 1) / ppw * ppw;
@@ -599,14 +608,15 @@ __global__ __launch_bounds__(1024) void order_pad_kernel(const int32_t *__restri
 
 __global__ __launch_bounds__(256) void order_scatter_kernel(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals, int32_t n,
                                                             const int32_t *__restrict__ bin_start, const int32_t *__restrict__ pad_base,
-                                                            spx_order_segs segs, int32_t *__restrict__ order)
+                                                            const spx_order_segs *__restrict__ segs, int32_t *__restrict__ order)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t b = (uint32_t)(keys[i] >> 20);
-    const int cls = (int)(b >> 10);
-    const int64_t dst = segs.off[cls] + pad_base[b] + (i - bin_start[b]);
-    if (dst < segs.off[cls] + segs.cap[cls]) order[dst] = vals[i];
+    const uint64_t key = keys[i];
+    const uint32_t b = order_bin(key);
+    const int sl = (int)(key >> 34), cls = (int)(key >> 30) & 0xf;
+    const int64_t dst = segs[sl].off[cls] + pad_base[b] + (i - bin_start[b]);
+    if (dst < segs[sl].off[cls] + segs[sl].cap[cls]) order[dst] = vals[i];
 }
 
 /* ---------------------------------------------------------------------- */
@@ -736,26 +746,30 @@ extern "C" size_t spx_order_temp_bytes(int32_t n_prob)
 {
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const int32_t *)nullptr,
-                                       (int32_t *)nullptr, n_prob > 0 ? n_prob : 1, 0, 34);
+                                       (int32_t *)nullptr, n_prob > 0 ? n_prob : 1, 0, 40);
     return bytes;
 }
 
-/* fills order_f / order_b (both pre-set to -1 by the caller's memset) */
-extern "C" hipError_t spx_prep_orders(const spx_order_args *O, const spx_order_segs *sf, const spx_order_segs *sb, hipStream_t st)
+/* fills order_f / order_b (both pre-set to -1 by the caller's memset) of EVERY slice of the list: one pair of sorts, the slice is the top
+ * field of the key.  bin_start holds 2 x n_slices x SPX_N_CLASSES x 1024 entries pre-set to -1 by the caller (forward half, backward half);
+ * bin_end / pad_base likewise (not pre-set) */
+extern "C" hipError_t spx_prep_orders(const spx_order_args *O, hipStream_t st)
 {
     const int32_t n = O->n_prob;
     if (n <= 0) return hipSuccess;
+    const size_t nb = (size_t)O->n_slices * SPX_N_CLASSES * 1024;
+    int end_bit = 34;
+    while ((1 << (end_bit - 34)) < O->n_slices) ++end_bit;
     hipLaunchKernelGGL(order_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *O);
     for (int pass = 0; pass < 2; ++pass) {
         size_t tb = O->temp_bytes;
-        hipError_t e = hipcub::DeviceRadixSort::SortPairs(O->temp, tb, pass ? O->key_b : O->key_f, O->key_sorted, O->val, O->val_sorted, n, 0, 34, st);
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(O->temp, tb, pass ? O->key_b : O->key_f, O->key_sorted, O->val, O->val_sorted, n, 0, end_bit, st);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(O->bin_start, 0xff, sizeof(int32_t) * SPX_N_CLASSES * 1024, st);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(order_bins_kernel, dim3((n + 255) / 256), dim3(256), 0, st, O->key_sorted, n, O->bin_start, O->bin_end);
-        hipLaunchKernelGGL(order_pad_kernel, dim3(1), dim3(1024), 0, st, O->bin_start, O->bin_end, O->pad_base, pass);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, O->key_sorted, O->val_sorted, n, O->bin_start,
-                           O->pad_base, pass ? *sb : *sf, pass ? O->order_b : O->order_f);
+        int32_t *bs = O->bin_start + pass * nb, *be = O->bin_end + pass * nb, *pb = O->pad_base + pass * nb;
+        hipLaunchKernelGGL(order_bins_kernel, dim3((n + 255) / 256), dim3(256), 0, st, O->key_sorted, n, bs, be);
+        hipLaunchKernelGGL(order_pad_kernel, dim3(O->n_slices), dim3(1024), 0, st, bs, be, pb, pass);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, O->key_sorted, O->val_sorted, n, bs, pb,
+                           pass ? O->segs_b : O->segs_f, pass ? O->order_b : O->order_f);
     }
     return hipGetLastError();
 }

@@ -49,10 +49,9 @@ extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args 
 extern "C" size_t spx_order_temp_bytes(int32_t n_prob);
 extern "C" hipError_t spx_stage_expand(const void *recs, int32_t n_slots, const uint8_t *pk_seq, const uint8_t *pk_qual, uint8_t *seq, uint8_t *qual,
                                        int has_alias, hipStream_t st);
-extern "C" hipError_t spx_prep_orders(const spx_order_args *O, const spx_order_segs *sf, const spx_order_segs *sb, hipStream_t st);
+extern "C" hipError_t spx_prep_orders(const spx_order_args *O, hipStream_t st);
 extern "C" hipError_t spx_prep_slice_bounds(const int32_t *slot0, const spxl::PlanBase *base, int32_t ng, int32_t K, const spxl::PlanBase *tot,
                                             spxl::PlanBase *out, hipStream_t st);
-#define SPX_MAX_SLICES 32
 
 extern "C" size_t spx_bgzf_inflate_scratch_bytes(int32_t n_blocks);
 extern "C" hipError_t spx_launch_bgzf_inflate2(const uint8_t *comp, const void *blocks, int32_t n_blocks, uint8_t *out, int32_t *status, int check_crc,
@@ -163,7 +162,8 @@ struct spx_ctx {
         DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort, pool_perm;
         spx_prep_totals *d_tot = nullptr, *h_tot = nullptr; /* device / pinned host */
         spxl::PlanBase *d_bounds = nullptr, *h_bounds = nullptr; /* DP slices: SPX_MAX_SLICES + 1 prefix records */
-        int32_t *d_bins = nullptr;                          /* 3 x SPX_N_CLASSES x 1024 */
+        DevBuf pool_bins;                                   /* 2 passes x 3 x slices x SPX_N_CLASSES x 1024 int32 */
+        spx_order_segs *d_segs = nullptr, *h_segs = nullptr; /* 2 x SPX_MAX_SLICES (forward, backward): device / pinned host */
     } lane[SPX_N_PREP];
     std::atomic<unsigned> lane_rr{0};
 };
@@ -378,7 +378,8 @@ extern "C" int spx_create(int device, spx_ctx **out)
         HIPCHK(hipHostMalloc((void **)&PL.h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&PL.d_bounds, sizeof(spxl::PlanBase) * (SPX_MAX_SLICES + 1)));
         HIPCHK(hipHostMalloc((void **)&PL.h_bounds, sizeof(spxl::PlanBase) * (SPX_MAX_SLICES + 1), hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&PL.d_bins, sizeof(int32_t) * 3 * SPX_N_CLASSES * 1024));
+        HIPCHK(hipMalloc((void **)&PL.d_segs, sizeof(spx_order_segs) * 2 * SPX_MAX_SLICES));
+        HIPCHK(hipHostMalloc((void **)&PL.h_segs, sizeof(spx_order_segs) * 2 * SPX_MAX_SLICES, hipHostMallocDefault));
     }
     c->prep_cus = masked ? prep_cus : 0;
     HIPCHK(mk_stream(&c->stream, m_dp));
@@ -450,7 +451,9 @@ extern "C" void spx_destroy(spx_ctx *c)
         if (PL.h_tot) (void)hipHostFree(PL.h_tot);
         if (PL.d_bounds) (void)hipFree(PL.d_bounds);
         if (PL.h_bounds) (void)hipHostFree(PL.h_bounds);
-        if (PL.d_bins) (void)hipFree(PL.d_bins);
+        if (PL.pool_bins.p) (void)hipFree(PL.pool_bins.p);
+        if (PL.d_segs) (void)hipFree(PL.d_segs);
+        if (PL.h_segs) (void)hipHostFree(PL.h_segs);
         if (PL.stream) (void)hipStreamDestroy(PL.stream);
     }
     for (int i = 0; i < 6; ++i)
@@ -1395,10 +1398,14 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     E.rfe = (int32_t *)(B0 + o_rfe); E.rfs = (int32_t *)(B0 + o_rfs); E.atid = (int32_t *)(B0 + o_atid);
     E.info = (spx_group_info *)(B0 + o_info);
     HIPCHK(spx_prep_emit(&A, &E, PL.stream)); /* (group_finish_kernel writes every entry of mk_first) */
-    /* launch orders */
-    HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (order_f_n + 64) * 4, PL.stream));
-    HIPCHK(hipMemsetAsync(B0 + o_order_b, 0xff, (order_b_n + 64) * 4, PL.stream));
+    /* launch orders: ONE fill for both order arrays (consecutive in the arena), one for the bins of both passes, one pair of sorts for all
+     * DP slices (round 4: two fills + a pair of sorts + a fill per slice) */
+    HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (o_order_b - o_order_f) + (order_b_n + 64) * 4, PL.stream));
     if (np) {
+        const size_t nbins = (size_t)K * SPX_N_CLASSES * 1024;
+        if ((rc = ensure_pool(PL, PL.pool_bins, nbins * 6 * sizeof(int32_t) + 256))) return fail(rc, "device memory for the launch-order bins");
+        int32_t *bins = (int32_t *)PL.pool_bins.p;
+        HIPCHK(hipMemsetAsync(bins, 0xff, nbins * 2 * sizeof(int32_t), PL.stream)); /* bin_start of both passes */
         spx_order_args O;
         memset(&O, 0, sizeof O);
         O.n_prob = (int32_t)np;
@@ -1406,18 +1413,16 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         char *kp = (char *)PL.pool_keys.p;
         O.key_f = (uint64_t *)kp; O.key_b = O.key_f + (np + 2); O.key_sorted = O.key_b + (np + 2);
         O.val = (int32_t *)(O.key_sorted + (np + 2)); O.val_sorted = O.val + (np + 2);
-        O.bin_start = PL.d_bins; O.bin_end = PL.d_bins + SPX_N_CLASSES * 1024; O.pad_base = PL.d_bins + 2 * SPX_N_CLASSES * 1024;
+        O.bin_start = bins; O.bin_end = bins + 2 * nbins; O.pad_base = bins + 4 * nbins;
         O.temp = PL.pool_sort.p; O.temp_bytes = sort_tmp;
         O.order_f = (int32_t *)(B0 + o_order_f); O.order_b = (int32_t *)(B0 + o_order_b);
-        for (int k = 0; k < K; ++k) { /* one sort per slice: keys of its problems, values = list-wide problem ids */
-            const int64_t p0 = bnd[(size_t)k].prob, p1 = bnd[(size_t)k + 1].prob;
-            if (p1 <= p0) continue;
-            spx_order_args Ok = O;
-            Ok.n_prob = (int32_t)(p1 - p0);
-            Ok.pad = (int32_t)p0;
-            Ok.bw = O.bw + p0; Ok.L = O.L + p0; Ok.n_rows = O.n_rows + p0; Ok.row_off = O.row_off + p0;
-            HIPCHK(spx_prep_orders(&Ok, &sfk[(size_t)k], &sbk[(size_t)k], PL.stream));
-        }
+        O.n_slices = K;
+        for (int k = 0; k <= K; ++k) O.slice_prob[k] = (int32_t)bnd[(size_t)k].prob;
+        /* (the pinned copy of the segment tables is free again: this call has synchronised the lane's stream since the last list used it) */
+        for (int k = 0; k < K; ++k) { PL.h_segs[k] = sfk[(size_t)k]; PL.h_segs[SPX_MAX_SLICES + k] = sbk[(size_t)k]; }
+        HIPCHK(hipMemcpyAsync(PL.d_segs, PL.h_segs, sizeof(spx_order_segs) * 2 * SPX_MAX_SLICES, hipMemcpyHostToDevice, PL.stream));
+        O.segs_f = PL.d_segs; O.segs_b = PL.d_segs + SPX_MAX_SLICES;
+        HIPCHK(spx_prep_orders(&O, PL.stream));
     }
     if (!w->ev_ready) HIPCHK(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(w->ev_ready, PL.stream));
@@ -1676,7 +1681,7 @@ extern "C" int spx_trim(spx_ctx *c)
         spx_ctx::PrepLane &PL = c->lane[l];
         std::lock_guard<std::mutex> pl(PL.mu);
         HIPCHK(hipStreamSynchronize(PL.stream));
-        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_perm})
+        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_perm, &PL.pool_bins})
             if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     }
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -4,7 +4,7 @@
 # to end.  Usage (from the repo root):  tools/collect_profiles.sh r02 [outdir]     (outdir defaults to gpurun_out/profiles)
 # Every rocprofv3 call has the program itself after `--`; --pmc is never combined with a trace option.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=${2:-gpurun_out/profiles}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/$OUT"
