@@ -652,7 +652,10 @@ SPX_HD int group_merge(const GroupView &G, const Pools &P, int32_t *pos, uint8_t
 
 /* this alignment's cell of every column: its mismatch at that position, or a match marker.  Its mismatches at positions
  * that are no column (every alignment mismatches there) are stepped over. */
-SPX_HD void aln_fill(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, int ncol)
+/* columns [c_lo, c_hi) only: what a lane of a wave that shares ONE heavy alignment does (round 5); the mismatch cursor starts where the
+ * walk over all columns would stand on reaching column c_lo -- behind every mismatch in front of that column's position (binary search: the
+ * list is ascending in read position in the order the cursor takes it) */
+SPX_HD void aln_fill_range(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, int ncol, int c_lo, int c_hi)
 {
     const int n = G.n;
     const Rec &r = G.rec[i];
@@ -661,16 +664,27 @@ SPX_HD void aln_fill(const GroupView &G, int i, const Pools &P, const int32_t *p
     const int step = rev ? -1 : 1;
     const uint8_t *qual = P.qual + r.qual_off;
     int left = st.n_mm, head = rev ? st.n_mm - 1 : 0;
+    if (c_hi > ncol) c_hi = ncol;
+    if (c_lo > 0 && c_lo < c_hi && left > 0) {
+        const int p0 = pos[c_lo];
+        int lo = 0, hi = st.n_mm; /* lo = mismatches, in cursor order, in front of p0 */
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (P.mm[st.mm_off + (rev ? st.n_mm - 1 - mid : mid)].pos < p0) lo = mid + 1; else hi = mid;
+        }
+        head = rev ? st.n_mm - 1 - lo : lo;
+        left = st.n_mm - lo;
+    }
     MM s;
     s.pos = 0x7fffffff; s.base_idx = 0; s.q = 0; s.ref_pos = 0;
     if (left > 0) s = P.mm[st.mm_off + head];
     /* four columns at a time (round 5): their positions, and the quality a MATCH marker of this alignment would carry at each (what
      * match_marker reads: one scattered byte per column, a cache miss each on a long read), are fetched together -- four loads in flight
      * instead of one per column on the critical path; a column that turns out to hold this alignment's mismatch does not use its byte */
-    for (int c0 = 0; c0 < ncol; c0 += 4) {
+    for (int c0 = c_lo; c0 < c_hi; c0 += 4) {
         int pp[4], bi[4];
         uint8_t qq[4];
-        const int m4 = ncol - c0 < 4 ? ncol - c0 : 4;
+        const int m4 = c_hi - c0 < 4 ? c_hi - c0 : 4;
         for (int k = 0; k < 4; ++k) pp[k] = k < m4 ? pos[c0 + k] : 0;
         for (int k = 0; k < 4; ++k) {
             bi[k] = rev ? r.l_qseq + st.rclip - pp[k] - 1 : pp[k] - st.lclip;
@@ -699,7 +713,12 @@ SPX_HD void aln_fill(const GroupView &G, int i, const Pools &P, const int32_t *p
     }
 }
 
-SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, uint8_t *keep, int ncol)
+SPX_HD void aln_fill(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, int ncol) { aln_fill_range(G, i, P, pos, mk, ncol, 0, ncol); }
+
+/* columns [c_lo, c_hi) only (see aln_fill_range).  The op cursor starts at, or one op in front of, the op whose read interval holds the
+ * first column's position (binary search over the ops' interval starts, which are monotone along the table): the ops in between are
+ * stepped over exactly as the walk over all columns steps over ops that hold no column. */
+SPX_HD void aln_filter_range(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, uint8_t *keep, int ncol, int c_lo, int c_hi)
 {
     /* positions inside an insertion / clip of any alignment are not comparable: the column goes */
     const int n = G.n;
@@ -707,20 +726,32 @@ SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t 
     const AlnState &st = G.st[i];
     const bool rev = (r.flag & SPX_FREVERSE) != 0;
     const Op *ops = P.ops + st.ops_off;
-    int col = rev ? ncol - 1 : 0;
+    if (c_hi > ncol) c_hi = ncol;
+    if (c_lo >= c_hi) return;
+    int col = rev ? c_hi - 1 : c_lo;
     const int step = rev ? -1 : 1;
-    if (ncol <= 0) return;
     int p = pos[col];
+    int t_first = 1;
+    if (!(c_lo == 0 && c_hi == ncol) && st.n_visit > 2) {
+        /* forward strand: interval starts ascend with t -- the LAST op with rds <= p; reverse strand: they descend -- the FIRST such op */
+        int lo = 1, hi = st.n_visit - 1;
+        if (!rev) {
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ops[mid].rds <= p) lo = mid; else hi = mid - 1; }
+        } else {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ops[mid].rds <= p) hi = mid; else lo = mid + 1; }
+        }
+        t_first = lo > 1 ? lo - 1 : 1;
+    }
     /* (four ops fetched at a time: their loads are in flight together) */
-    for (int t0 = 1; t0 < st.n_visit && col >= 0 && col < ncol; t0 += 4) {
+    for (int t0 = t_first; t0 < st.n_visit && col >= c_lo && col < c_hi; t0 += 4) {
         Op quad[4];
         const int m4 = st.n_visit - t0 < 4 ? st.n_visit - t0 : 4;
         for (int k = 0; k < 4; ++k)
             if (k < m4) quad[k] = ops[t0 + k];
         for (int k = 0; k < 4; ++k) {
-            if (k >= m4 || !(col >= 0 && col < ncol)) break;
+            if (k >= m4 || !(col >= c_lo && col < c_hi)) break;
             const Op o = quad[k];
-            while (col >= 0 && col < ncol) {
+            while (col >= c_lo && col < c_hi) {
                 if (!(o.rds <= p && p <= o.rde)) break;
                 /* (every alignment writes the same 0; a relaxed atomic store, so that the host plan's threads -- one per alignment,
                  * like the lanes of the kernel -- do it without a data race: ThreadSanitizer run of the CPU suite) */
@@ -728,10 +759,14 @@ SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t 
                 if (o.op == SPX_CEQUAL) /* ptMarker.c:184-187: reference position of this alignment's marker */
                     mk[(int64_t)col * n + i].ref_pos = rev ? o.rfs + o.rde - p : o.rfs + p - o.rds;
                 col += step;
-                if (col >= 0 && col < ncol) p = pos[col];
+                if (col >= c_lo && col < c_hi) p = pos[col];
             }
         }
     }
+}
+SPX_HD void aln_filter(const GroupView &G, int i, const Pools &P, const int32_t *pos, Mk *mk, uint8_t *keep, int ncol)
+{
+    aln_filter_range(G, i, P, pos, mk, keep, ncol, 0, ncol);
 }
 
 /* (the columns' marker cells are moved by aln_compact, one alignment per thread: a column of a 9-alignment group is
@@ -1142,9 +1177,18 @@ struct PlanBase { /* this group's first problem / row / edit and scratch offsets
 /* BAQ windows of one alignment (calc_local_baq's control flow).  EMIT = false: counts into gc; EMIT = true: writes
  * the problems, the wanted rows and the marker updates.  Columns are visited through this alignment's cell only:
  * the reference's loops step over every marker and skip the other alignments' cells. */
+/* Round 5: blocks [bi_lo, bi_hi) only (plan_baq_range): the blocks of an alignment are independent once the two cursors and the output
+ * offsets at the first block of a range are known, so the lanes of a wave that shares ONE heavy alignment take contiguous ranges of its
+ * blocks.  The cursors come from binary searches -- the column cursor stands on the first column (in the order it walks them) whose base
+ * index reaches the block's start, the op cursor on, or one op in front of, the first op that reaches the block's start in both
+ * coordinates; both tables are monotone along the walk -- and the offsets from the counting pass's per-range totals.  Allowed only when
+ * plan_can_split() holds: no op of length 0 in front of the table's end (the walk pauses on such an op -- `adv() == 0` -- and a search would
+ * jump over it) and not in the all-rows mode (its row scratch is per alignment). */
+SPX_HD bool plan_can_split(const Params &par, const AlnState &st) { return !par.all_rows && st.n_visit == st.n_ops; }
+
 template <bool EMIT>
-SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S, int ncol,
-                    GroupCount &gc, PlanBase &at, const PlanOut &out)
+SPX_HD int plan_baq_range(const GroupView &G, int ai, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S, int ncol,
+                          GroupCount &gc, PlanBase &at, const PlanOut &out, int bi_lo, int bi_hi)
 {
     const int n = G.n;
     const Rec &r = G.rec[ai];
@@ -1179,8 +1223,26 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
     auto exp_set = [&](int64_t i, int v) { if (out.rr) out.rr[i].expect = v; else out.row_expect[i] = v; };
     const Blk *blocks = S.proj + (int64_t)ai * S.blk_cap;
     const int nblocks = S.nproj[ai];
-    int32_t *rows_mk = S.rows_mk + (int64_t)ai * S.rows_cap;
-    for (int bi = 0; bi < nblocks; ++bi) {
+    int32_t *rows_mk = S.rows_mk + (int64_t)ai * S.rows_cap; /* (all-rows mode only) */
+    if (bi_hi > nblocks) bi_hi = nblocks;
+    if (bi_lo > 0 && bi_lo < bi_hi) {
+        const Blk b0 = blocks[bi_lo];
+        int lo = 0, hi = ncol; /* lo = columns, in walking order, whose base index lies in front of the block */
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (own(rev ? ncol - 1 - mid : mid).base_idx < b0.sqs) lo = mid + 1; else hi = mid;
+        }
+        c = rev ? ncol - 1 - lo : lo;
+        cb = (c >= 0 && c < ncol) ? own(c).base_idx : 0;
+        lo = 0; hi = last; /* first op that reaches the block's start in SEQ and in reference coordinates */
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ops[mid].sqe >= b0.sqs && ops[mid].rfe >= b0.rfs) hi = mid; else lo = mid + 1;
+        }
+        ci = lo > 0 ? lo - 1 : 0;
+        co = ops[ci];
+    }
+    for (int bi = bi_lo; bi < bi_hi; ++bi) {
         const Blk b = blocks[bi];
         while (co.sqe < b.sqs || co.rfe < b.rfs)
             if (adv() == 0) break;
@@ -1218,9 +1280,9 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
                     const int t = kb - b.sqs;
                     if (t >= margin && t < L - margin) {
                         if (par.all_rows) { if (EMIT) rows_mk[t - margin] = k; }
-                        else {
+                        else { /* (the wanted rows are the consecutive columns c, c + step, ..: their columns need no table) */
                             if (nrows >= S.rows_cap) return SPX_ENOMEM;
-                            if (EMIT) { rows_mk[nrows] = k; row_set(at.row + nrows, t + 1); }
+                            if (EMIT) row_set(at.row + nrows, t + 1);
                             ++nrows;
                         }
                     }
@@ -1274,7 +1336,7 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
             }
             if (EMIT) {
                 for (int w2 = 0; w2 < nrows; ++w2) {
-                    const int k = rows_mk[w2];
+                    const int k = par.all_rows ? rows_mk[w2] : c + w2 * step;
                     if (k < 0) continue;
                     Mk &m = own(k);
                     if (exp_get(row0 + w2) >= 0) m.row = (int32_t)(row0 + w2);
@@ -1328,6 +1390,13 @@ SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &r
     return 0;
 }
 
+template <bool EMIT>
+SPX_HD int plan_baq(const GroupView &G, int ai, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S, int ncol,
+                    GroupCount &gc, PlanBase &at, const PlanOut &out)
+{
+    return plan_baq_range<EMIT>(G, ai, P, rv, par, S, ncol, gc, at, out, 0, 0x7fffffff);
+}
+
 /* the HMM constants of problem p (one thread per problem on the device: coalesced, unlike the group passes) */
 SPX_HD void problem_constants(const Params &par, int L, int R, uint8_t has_n, double *h)
 {
@@ -1360,11 +1429,15 @@ SPX_HD void group_pass_merge(const GroupView &G, const Pools &P, const RefView &
 }
 
 /* A1 */
-SPX_HD void aln_pass_filter(const GroupView &G, int i, const Pools &P, GroupScratch &S, const GroupCount &gc)
+SPX_HD void aln_pass_filter(const GroupView &G, int i, const Pools &P, GroupScratch &S, const GroupCount &gc, int part = 0, int nparts = 1)
 {
     if (gc.err || gc.n_cols == 0) return;
-    aln_fill(G, i, P, S.pos, S.mk, gc.n_cols);
-    aln_filter(G, i, P, S.pos, S.mk, S.keep, gc.n_cols);
+    /* part / nparts: the columns are dealt in contiguous shares to the lanes of a wave that holds ONE heavy alignment; a share is filled and
+     * then filtered by its lane (the filter writes into the cells the fill has just written) */
+    const int chunk = (gc.n_cols + nparts - 1) / nparts, c_lo = part * chunk, c_hi = c_lo + chunk < gc.n_cols ? c_lo + chunk : gc.n_cols;
+    if (c_lo >= c_hi) return;
+    aln_fill_range(G, i, P, S.pos, S.mk, gc.n_cols, c_lo, c_hi);
+    aln_filter_range(G, i, P, S.pos, S.mk, S.keep, gc.n_cols, c_lo, c_hi);
 }
 /* A1b: after EVERY alignment of the group has been through aln_pass_filter (keep[] is final), before the group pass that
  * compacts the positions */
@@ -1417,6 +1490,34 @@ SPX_HD void aln_pass_count(const GroupView &G, int i, const Pools &P, const RefV
     const int rc = plan_baq<false>(G, i, P, rv, par, S, gc.n_cols, ac, at, none);
     if (rc) { count_clear(ac); ac.err = rc; }
 }
+/* the same for ONE share of the alignment's blocks (part of nparts, contiguous; plan_can_split must hold when nparts > 1): the share's
+ * counts in ac (err = its error, nothing cleared: the caller combines the shares in order -- the first error wins, as in the walk over all
+ * blocks) and what it adds to the output offsets in `add` */
+SPX_HD void block_share(int nblocks, int part, int nparts, int &lo, int &hi)
+{
+    const int chunk = (nblocks + nparts - 1) / nparts;
+    lo = part * chunk;
+    hi = lo + chunk < nblocks ? lo + chunk : nblocks;
+    if (lo > nblocks) lo = nblocks;
+}
+SPX_HD void aln_pass_count_part(const GroupView &G, int i, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S,
+                                const GroupCount &gc, GroupCount &ac, PlanBase &add, int part, int nparts)
+{
+    count_clear(ac);
+    add = PlanBase{0, 0, 0, 0, 0};
+    if (gc.err || !gc.scored || !par.baq_flag) return;
+    int lo, hi;
+    block_share(S.nproj[i], part, nparts, lo, hi);
+    if (lo >= hi) return;
+    PlanOut none = {};
+    ac.err = plan_baq_range<false>(G, i, P, rv, par, S, gc.n_cols, ac, add, none, lo, hi);
+}
+SPX_HD void count_add(GroupCount &a, const GroupCount &b)
+{
+    a.n_prob += b.n_prob; a.n_rows += b.n_rows; a.n_qe += b.n_qe;
+    a.cells += b.cells; a.s_need += b.s_need; a.f_need += b.f_need;
+    for (int k = 0; k < SPX_N_CLASSES; ++k) { a.cls_prob[k] += b.cls_prob[k]; a.cls_cells[k] += b.cls_cells[k]; }
+}
 
 /* G3: sums of the group; an alignment's error (the first in alignment order) makes the whole group an error and
  * clears every count */
@@ -1446,24 +1547,38 @@ SPX_HD int aln_pass_emit(const GroupView &G, int i, const Pools &P, const RefVie
     GroupCount dummy;
     return plan_baq<true>(G, i, P, rv, par, S, gc.n_cols, dummy, at, out); /* same control flow as the counting pass */
 }
+/* one share of the blocks, written at `at` = the alignment's offsets + what the shares in front of it add (aln_pass_count_part) */
+SPX_HD int aln_pass_emit_part(const GroupView &G, int i, const Pools &P, const RefView &rv, const Params &par, GroupScratch &S,
+                              const GroupCount &gc, PlanBase at, const PlanOut &out, int part, int nparts)
+{
+    if (gc.err || !gc.scored || !par.baq_flag) return 0;
+    int lo, hi;
+    block_share(S.nproj[i], part, nparts, lo, hi);
+    if (lo >= hi) return 0;
+    GroupCount dummy;
+    return plan_baq_range<true>(G, i, P, rv, par, S, gc.n_cols, dummy, at, out, lo, hi);
+}
 
 /* G4: the group's marker table (n_cols * n entries) */
-SPX_HD void group_pass_markers(const GroupView &G, GroupScratch &S, const GroupCount &gc, spx_dev_marker *mk_out, int32_t *mk_ref_pos)
+SPX_HD void group_pass_markers(const GroupView &G, GroupScratch &S, const GroupCount &gc, spx_dev_marker *mk_out, int32_t *mk_ref_pos, int part = 0,
+                               int nparts = 1)
 {
     if (gc.err || !gc.scored) return;
     const int n = G.n, ncol = gc.n_cols;
-    for (int c = 0; c < ncol; ++c)
-        for (int i = 0; i < n; ++i) {
-            const Mk m = S.mk[(int64_t)c * n + i];
-            spx_dev_marker dm;
-            dm.row = m.row;
-            dm.qfix = m.q;
-            dm.is_match = m.is_match;
-            dm.aln = (uint8_t)i;
-            dm.first_of_pos = i == 0 ? (uint8_t)n : 0;
-            mk_out[(int64_t)c * n + i] = dm;
-            mk_ref_pos[(int64_t)c * n + i] = m.ref_pos;
-        }
+    /* every cell is independent: the lanes of a wave that shares one heavy group take the cells in turn (part / nparts, coalesced) */
+    const int64_t cells = (int64_t)ncol * n;
+    for (int64_t x = part; x < cells; x += nparts) {
+        const int i = (int)(x % n);
+        const Mk m = S.mk[x];
+        spx_dev_marker dm;
+        dm.row = m.row;
+        dm.qfix = m.q;
+        dm.is_match = m.is_match;
+        dm.aln = (uint8_t)i;
+        dm.first_of_pos = i == 0 ? (uint8_t)n : 0;
+        mk_out[x] = dm;
+        mk_ref_pos[x] = m.ref_pos;
+    }
 }
 
 } // namespace spxl

@@ -579,6 +579,8 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
         return G;
     };
     int slack = 1;
+    static const int plan_parts = [] { const char *e = getenv("SPX_PLAN_PARTS"); return e ? std::max(1, atoi(e)) : 1; }();
+    std::vector<spxl::PlanBase> part_add(plan_parts > 1 ? (size_t)ns * (size_t)plan_parts : 0);
     std::vector<char> arena;
     for (;;) {
         for (int64_t k = 0; k < ng; ++k) {
@@ -599,7 +601,11 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
             for (int64_t q = q0; q < q1; ++q) {
                 const int64_t k = slot_grp[(size_t)q];
                 spxl::GroupScratch S = scratch(k);
-                spxl::aln_pass_filter(view(k), (int)(q - st.slot0[(size_t)k]), P, S, gc[(size_t)k]);
+                /* SPX_PLAN_PARTS=n (CPU tests): the columns in n contiguous shares, one after the other -- what the lanes of a wave that
+                 * shares one heavy alignment do side by side on the device; the result must not depend on n */
+                static const int parts = [] { const char *e = getenv("SPX_PLAN_PARTS"); return e ? std::max(1, atoi(e)) : 1; }();
+                for (int pt = parts - 1; pt >= 0; --pt) /* (descending: no share may rely on an earlier one having run) */
+                    spxl::aln_pass_filter(view(k), (int)(q - st.slot0[(size_t)k]), P, S, gc[(size_t)k], pt, parts);
             }
         });
         parallel_for(ns, threads, [&](int64_t q0, int64_t q1) { /* A1b */
@@ -621,7 +627,20 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
                 for (int64_t q = q0; q < q1; ++q) {
                     const int64_t k = slot_grp[(size_t)q];
                     spxl::GroupScratch S = scratch(k);
-                    spxl::aln_pass_count(view(k), (int)(q - st.slot0[(size_t)k]), P, rv, lp, S, gc[(size_t)k], ac[(size_t)q]);
+                    const int ai = (int)(q - st.slot0[(size_t)k]);
+                    if (plan_parts > 1 && spxl::plan_can_split(lp, view(k).st[ai])) {
+                        /* (CPU tests, SPX_PLAN_PARTS: the blocks in shares, last share first; combined in share order: the first error wins) */
+                        std::vector<spxl::GroupCount> pc((size_t)plan_parts);
+                        for (int pt = plan_parts - 1; pt >= 0; --pt)
+                            spxl::aln_pass_count_part(view(k), ai, P, rv, lp, S, gc[(size_t)k], pc[(size_t)pt], part_add[(size_t)q * plan_parts + pt], pt, plan_parts);
+                        spxl::GroupCount &a = ac[(size_t)q];
+                        spxl::count_clear(a);
+                        for (int pt = 0; pt < plan_parts; ++pt) {
+                            if (pc[(size_t)pt].err) { spxl::count_clear(a); a.err = pc[(size_t)pt].err; break; }
+                            spxl::count_add(a, pc[(size_t)pt]);
+                        }
+                    } else
+                        spxl::aln_pass_count(view(k), ai, P, rv, lp, S, gc[(size_t)k], ac[(size_t)q]);
                     if (ac[(size_t)q].err == SPX_ENOMEM) overflow = 1;
                 }
             });
@@ -685,7 +704,18 @@ int host_plan(const spx_batch *const *bts, int32_t n_batches, const RefIndex &re
         for (int64_t q = q0; q < q1; ++q) {
             const int64_t k = slot_grp[(size_t)q];
             spxl::GroupScratch S = scratch(k);
-            spxl::aln_pass_emit(view(k), (int)(q - st.slot0[(size_t)k]), P, rv, lp, S, gc[(size_t)k], base[(size_t)q], out);
+            const int ai = (int)(q - st.slot0[(size_t)k]);
+            if (plan_parts > 1 && spxl::plan_can_split(lp, view(k).st[ai])) {
+                for (int pt = plan_parts - 1; pt >= 0; --pt) {
+                    spxl::PlanBase at = base[(size_t)q];
+                    for (int j = 0; j < pt; ++j) {
+                        const spxl::PlanBase &d = part_add[(size_t)q * plan_parts + j];
+                        at.prob += d.prob; at.row += d.row; at.qe += d.qe; at.s_off += d.s_off; at.f_off += d.f_off;
+                    }
+                    spxl::aln_pass_emit_part(view(k), ai, P, rv, lp, S, gc[(size_t)k], at, out, pt, plan_parts);
+                }
+            } else
+                spxl::aln_pass_emit(view(k), ai, P, rv, lp, S, gc[(size_t)k], base[(size_t)q], out);
         }
     });
     parallel_for(ng, threads, [&](int64_t k0, int64_t k1) { /* G4 + the per-group arrays */

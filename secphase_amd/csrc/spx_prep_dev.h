@@ -54,6 +54,11 @@ struct spx_prep_args {
     const int32_t *slot_heavy, *group_heavy;
     const uint8_t *slot_flag, *group_flag;
     int32_t n_heavy_slots, n_heavy_groups;
+    /* two tiers (the flag is the tier: 2 = one of the n_heavy_* heaviest, 1 = one of the n_share_* heaviest, 0 neither): the kernels whose walk
+     * can be SHARED by the 64 lanes of a wave (marker fill / filter, BAQ plan count / emit, marker table) extract many more items than those
+     * where the item's wave has one working lane */
+    int32_t n_share_slots, n_share_groups;
+    spxl::PlanBase *heavy_plan; /* [n_share_slots][64]: what each lane's share of a heavy alignment's blocks adds to the output offsets (counting pass -> emitting pass) */
 };
 
 struct spx_emit_args {

@@ -29,22 +29,46 @@
 
 using namespace spxl;
 
-/* the item a lane of a walking kernel takes: lane i takes the i-th heaviest alignment / group of the list (spx_prep_args::slot_perm) */
-__device__ __forceinline__ int item_of(int i, int n, int n_heavy, const int32_t *__restrict__ heavy, const uint8_t *__restrict__ flag)
+/* The item a lane of a walking kernel takes.  Ordinary waves keep list order (neighbours share cache lines); an item that was EXTRACTED
+ * (spx_prep_args: flag = its tier) idles in its ordinary lane and has a wave of its own in front of the ordinary waves.
+ * item_of: kernels whose walk is one lane's -- the wave's lane 0 walks, tier 2 items only.
+ * part_of: kernels whose walk can be shared -- every lane of the wave gets the item, with its lane as the share (part of nparts), tier >= 1. */
+__device__ __forceinline__ int item_of(int i, int n, int n_heavy, const int32_t *__restrict__ heavy, const uint8_t *__restrict__ flag, int tier = 2)
 {
     if (!heavy) return i < n ? i : -1;
     const int w = i >> 6, l = i & 63;
-    if (w < n_heavy) { /* a wave for ONE heavy item: lane 0 (an entry of the list that is not heavy enough was left in its ordinary lane) */
+    if (w < n_heavy) { /* (an entry of the list that is not heavy enough was left in its ordinary lane) */
         if (l) return -1;
         const int it = heavy[w];
-        return flag[it] ? it : -1;
+        return flag[it] >= tier ? it : -1;
     }
     const int j = i - (n_heavy << 6);
     if (j >= n) return -1;
-    return flag[j] ? -1 : j;
+    return flag[j] >= tier ? -1 : j;
+}
+__device__ __forceinline__ int part_of(int i, int n, int n_share, const int32_t *__restrict__ heavy, const uint8_t *__restrict__ flag, int &part, int &nparts)
+{
+    part = 0; nparts = 1;
+    if (!heavy) return i < n ? i : -1;
+    const int w = i >> 6;
+    if (w < n_share) {
+        const int it = heavy[w];
+        if (flag[it] < 1) return -1;
+        part = i & 63; nparts = 64;
+        return it;
+    }
+    return item_of(i, n, n_share, heavy, flag, 1);
 }
 __device__ __forceinline__ int slot_of(const spx_prep_args &A, int i) { return item_of(i, A.n_slots, A.n_heavy_slots, A.slot_heavy, A.slot_flag); }
 __device__ __forceinline__ int group_of(const spx_prep_args &A, int i) { return item_of(i, A.n_dgroups, A.n_heavy_groups, A.group_heavy, A.group_flag); }
+__device__ __forceinline__ int slot_part(const spx_prep_args &A, int i, int &part, int &nparts)
+{
+    return part_of(i, A.n_slots, A.n_share_slots, A.slot_heavy, A.slot_flag, part, nparts);
+}
+__device__ __forceinline__ int group_part(const spx_prep_args &A, int i, int &part, int &nparts)
+{
+    return part_of(i, A.n_dgroups, A.n_share_groups, A.group_heavy, A.group_flag, part, nparts);
+}
 /* waves of 64 lanes a walking kernel needs */
 static inline unsigned walk_waves(int n, int n_heavy, const void *heavy)
 {
@@ -243,13 +267,16 @@ __global__ __launch_bounds__(64) void group_merge_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_filter_kernel(spx_prep_args A)
 {
-    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    /* a heavy alignment's wave deals the marker columns to its 64 lanes in contiguous shares (round 5: the walk over the 45 000 columns of a
+     * 100 kb read was one lane's); an ordinary lane takes all the columns of its alignment */
+    int part = 0, nparts = 1;
+    const int s = slot_part(A, blockIdx.x * blockDim.x + threadIdx.x, part, nparts);
     if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || gc.n_cols == 0) return;
     GroupCtx c = group_ctx(A, k);
-    aln_pass_filter(c.G, s - A.slot0[k], A.P, c.S, gc);
+    aln_pass_filter(c.G, s - A.slot0[k], A.P, c.S, gc, part, nparts);
 }
 
 __global__ __launch_bounds__(64) void aln_compact_kernel(spx_prep_args A)
@@ -309,20 +336,62 @@ __global__ __launch_bounds__(64) void group_blocks_end_kernel(spx_prep_args A)
     A.gc[k] = gc;
 }
 
+/* wave-wide helpers of the shared walks (all 64 lanes of a heavy alignment's wave call them) */
+__device__ __forceinline__ int64_t wave_sum64(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int64_t wave_exscan64(int64_t v)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+
 __global__ __launch_bounds__(64) void aln_count_plan_kernel(spx_prep_args A)
 {
-    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    int part = 0, nparts = 1;
+    const int s = slot_part(A, blockIdx.x * blockDim.x + threadIdx.x, part, nparts);
     if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     GroupCount ac;
-    if (gc.err || !gc.scored) { count_clear(ac); A.ac[s] = ac; return; }
+    if (gc.err || !gc.scored) { count_clear(ac); if (part == 0) A.ac[s] = ac; return; }
     GroupCtx c = group_ctx(A, k);
-    aln_pass_count(c.G, s - A.slot0[k], A.P, A.rv, A.par, c.S, gc, ac);
+    const int ai = s - A.slot0[k];
+    if (nparts > 1 && plan_can_split(A.par, c.G.st[ai])) {
+        /* a heavy alignment: the 64 lanes of its wave count contiguous shares of its blocks (spx_logic.h plan_baq_range); the shares' offsets go
+         * to heavy_plan for the emitting pass, their counts are added up -- or the error of the FIRST share that has one is taken */
+        PlanBase add;
+        aln_pass_count_part(c.G, ai, A.P, A.rv, A.par, c.S, gc, ac, add, part, nparts);
+        A.heavy_plan[(size_t)blockIdx.x * 64 + part] = add;
+        const unsigned long long em = __ballot(ac.err != 0);
+        GroupCount tot;
+        count_clear(tot);
+        if (em) tot.err = __shfl(ac.err, __ffsll((long long)em) - 1);
+        else {
+            tot.n_prob = (int32_t)wave_sum64(ac.n_prob); tot.n_rows = (int32_t)wave_sum64(ac.n_rows); tot.n_qe = (int32_t)wave_sum64(ac.n_qe);
+            tot.cells = wave_sum64(ac.cells); tot.s_need = wave_sum64(ac.s_need); tot.f_need = wave_sum64(ac.f_need);
+            for (int q = 0; q < SPX_N_CLASSES; ++q) { tot.cls_prob[q] = (int32_t)wave_sum64(ac.cls_prob[q]); tot.cls_cells[q] = wave_sum64(ac.cls_cells[q]); }
+        }
+        if (part == 0) {
+            if (tot.err == SPX_ENOMEM) atomicOr(&A.tot->overflow, 2);
+            A.ac[s] = tot;
+        }
+        return;
+    }
+    if (part != 0) return;
+    aln_pass_count(c.G, ai, A.P, A.rv, A.par, c.S, gc, ac);
     if (ac.err == SPX_ENOMEM) atomicOr(&A.tot->overflow, 2);
     A.ac[s] = ac;
 }
-
 __global__ __launch_bounds__(64) void group_sum_kernel(spx_prep_args A)
 {
     const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
@@ -344,16 +413,27 @@ __global__ __launch_bounds__(64) void group_sum_kernel(spx_prep_args A)
 
 __global__ __launch_bounds__(64) void aln_emit_kernel(spx_prep_args A, spx_emit_args E)
 {
-    const int s = slot_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    int part = 0, nparts = 1;
+    const int s = slot_part(A, blockIdx.x * blockDim.x + threadIdx.x, part, nparts);
     if (s < 0) return;
     const int k = A.recs[s].grp;
     const GroupCount gc = A.gc[k];
     if (gc.err || !gc.scored) return;
     GroupCtx c = group_ctx(A, k);
-    aln_pass_emit(c.G, s - A.slot0[k], A.P, A.rv, A.par, c.S, gc, E.base[s], E.out);
+    const int ai = s - A.slot0[k];
+    if (nparts > 1 && plan_can_split(A.par, c.G.st[ai])) {
+        /* (the same shares as in the counting pass; a share starts where the shares in front of it end) */
+        const PlanBase add = A.heavy_plan[(size_t)blockIdx.x * 64 + part];
+        PlanBase at = E.base[s];
+        at.prob += wave_exscan64(add.prob); at.row += wave_exscan64(add.row); at.qe += wave_exscan64(add.qe);
+        at.s_off += wave_exscan64(add.s_off); at.f_off += wave_exscan64(add.f_off);
+        aln_pass_emit_part(c.G, ai, A.P, A.rv, A.par, c.S, gc, at, E.out, part, nparts);
+        return;
+    }
+    if (part != 0) return;
+    aln_pass_emit(c.G, ai, A.P, A.rv, A.par, c.S, gc, E.base[s], E.out);
 }
 
-/* one thread per wanted row: the emitting pass' 16-byte records -> the arrays the DP / MAP kernels read (coalesced) */
 __global__ __launch_bounds__(256) void rows_unpack_kernel(const RowRec *__restrict__ rr, int64_t n_rows, int32_t *__restrict__ rows,
                                                           int32_t *__restrict__ expect, int32_t *__restrict__ prob, uint8_t *__restrict__ rawq)
 {
@@ -365,13 +445,15 @@ __global__ __launch_bounds__(256) void rows_unpack_kernel(const RowRec *__restri
 
 __global__ __launch_bounds__(64) void group_finish_kernel(spx_prep_args A, spx_emit_args E)
 {
-    const int k = group_of(A, blockIdx.x * blockDim.x + threadIdx.x);
+    int part = 0, nparts = 1;
+    const int k = group_part(A, blockIdx.x * blockDim.x + threadIdx.x, part, nparts);
     if (k < 0) return;
     const GroupCount gc = A.gc[k];
     GroupCtx c = group_ctx(A, k);
     const int n = c.G.n;
     const int64_t mk0 = E.mk_base[k];
-    group_pass_markers(c.G, c.S, gc, E.markers + mk0, E.mk_ref_pos + mk0);
+    group_pass_markers(c.G, c.S, gc, E.markers + mk0, E.mk_ref_pos + mk0, part, nparts); /* (a heavy group: the cells dealt to the wave's 64 lanes) */
+    if (part != 0) return;
     const bool ok = gc.err == 0;
     E.mk_first[k] = (int32_t)mk0;
     if (k == A.n_dgroups - 1) E.mk_first[k + 1] = (int32_t)(mk0 + (ok ? (int64_t)gc.n_cols * n : 0));
@@ -640,14 +722,15 @@ __global__ __launch_bounds__(256) void heavy_keys_kernel(spx_prep_args A, int32_
         flag_g[i] = 0;
     }
 }
-/* the first n_heavy entries of the sorted list are extracted if they are heavy in absolute terms (min_work) AND against the list's own
- * median (4 x: a list of alignments that are all long -- ONT reads of one length -- gains nothing from moving 2 048 of them) */
+/* the first n_share entries of the sorted list are extracted (tier 1; the first n_heavy of them tier 2) if they are heavy in absolute terms
+ * (min_work) AND against the list's own median (4 x: a list of alignments that are all long -- ONT reads of one length -- gains nothing from
+ * moving some of them) */
 __global__ __launch_bounds__(256) void heavy_mark_kernel(const int32_t *__restrict__ key_sorted, const int32_t *__restrict__ heavy, int32_t n, int32_t n_heavy,
-                                                         int32_t min_work, uint8_t *__restrict__ flag)
+                                                         int32_t n_share, int32_t min_work, uint8_t *__restrict__ flag)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t med4 = 4 * (int64_t)key_sorted[n / 2];
-    if (w < n_heavy && key_sorted[w] >= min_work && key_sorted[w] >= med4) flag[heavy[w]] = 1;
+    if (w < n_share && key_sorted[w] >= min_work && key_sorted[w] >= med4) flag[heavy[w]] = w < n_heavy ? 2 : 1;
 }
 
 extern "C" size_t spx_prep_heavy_temp_bytes(int32_t n)
@@ -669,16 +752,16 @@ extern "C" hipError_t spx_prep_heavy(const spx_prep_args *A, int32_t *keys, int3
     hipLaunchKernelGGL(heavy_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, *A, key_s, val_s, key_g, val_g, slot_flag, group_flag);
     size_t tb = temp_bytes;
     hipError_t e = hipSuccess;
-    if (A->n_slots > 0 && A->n_heavy_slots > 0) {
+    if (A->n_slots > 0 && A->n_share_slots > 0) {
         e = hipcub::DeviceRadixSort::SortPairsDescending(temp, tb, (const int32_t *)key_s, key_out, (const int32_t *)val_s, slot_heavy, A->n_slots, 0, 31, st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(heavy_mark_kernel, dim3((A->n_heavy_slots + 255) / 256), dim3(256), 0, st, key_out, slot_heavy, A->n_slots, A->n_heavy_slots, min_work, slot_flag);
+        hipLaunchKernelGGL(heavy_mark_kernel, dim3((A->n_share_slots + 255) / 256), dim3(256), 0, st, key_out, slot_heavy, A->n_slots, A->n_heavy_slots, A->n_share_slots, min_work, slot_flag);
     }
     tb = temp_bytes;
-    if (A->n_dgroups > 0 && A->n_heavy_groups > 0) {
+    if (A->n_dgroups > 0 && A->n_share_groups > 0) {
         e = hipcub::DeviceRadixSort::SortPairsDescending(temp, tb, (const int32_t *)key_g, key_out, (const int32_t *)val_g, group_heavy, A->n_dgroups, 0, 31, st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(heavy_mark_kernel, dim3((A->n_heavy_groups + 255) / 256), dim3(256), 0, st, key_out, group_heavy, A->n_dgroups, A->n_heavy_groups, 4 * min_work, group_flag); /* (a group: the sum over its alignments) */
+        hipLaunchKernelGGL(heavy_mark_kernel, dim3((A->n_share_groups + 255) / 256), dim3(256), 0, st, key_out, group_heavy, A->n_dgroups, A->n_heavy_groups, A->n_share_groups, 4 * min_work, group_flag); /* (a group: the sum over its alignments) */
     }
     return hipGetLastError();
 }
@@ -704,12 +787,13 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
 {
     if (A->n_dgroups <= 0) return hipSuccess;
     const dim3 gg(walk_waves(A->n_dgroups, A->n_heavy_groups, A->group_heavy)), ga(walk_waves(A->n_slots, A->n_heavy_slots, A->slot_heavy)), b64(64);
+    const dim3 gas(walk_waves(A->n_slots, A->n_share_slots, A->slot_heavy)); /* the kernels that share an extracted alignment among the lanes of its wave */
     hipLaunchKernelGGL(group_arena_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(arena_extract_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
     { hipError_t e = run_scan(A, A->n_dgroups, 1, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(arena_apply_kernel, dim3((A->n_dgroups + 255) / 256), dim3(256), 0, st, *A);
     hipLaunchKernelGGL(group_merge_kernel, gg, b64, 0, st, *A);
-    hipLaunchKernelGGL(aln_filter_kernel, ga, b64, 0, st, *A);
+    hipLaunchKernelGGL(aln_filter_kernel, gas, b64, 0, st, *A);
     hipLaunchKernelGGL(aln_compact_kernel, ga, b64, 0, st, *A);
     hipLaunchKernelGGL(group_blocks_kernel, gg, b64, 0, st, *A);
     for (int round = 0; round < 3; ++round) { /* nearly every group needs one or two projection rounds */
@@ -717,7 +801,7 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
         hipLaunchKernelGGL(group_resume_kernel, gg, b64, 0, st, *A);
     }
     hipLaunchKernelGGL(group_blocks_end_kernel, gg, b64, 0, st, *A);
-    hipLaunchKernelGGL(aln_count_plan_kernel, ga, b64, 0, st, *A);
+    hipLaunchKernelGGL(aln_count_plan_kernel, gas, b64, 0, st, *A);
     hipLaunchKernelGGL(group_sum_kernel, gg, b64, 0, st, *A);
     hipLaunchKernelGGL(plan_extract_slots_kernel, dim3((A->n_slots + 255) / 256), dim3(256), 0, st, *A);
     { hipError_t e = run_scan(A, A->n_slots, 5, st); if (e != hipSuccess) return e; }
@@ -731,11 +815,11 @@ extern "C" hipError_t spx_prep_phase2(const spx_prep_args *A, spxl::PlanBase *ba
 extern "C" hipError_t spx_prep_emit(const spx_prep_args *A, const spx_emit_args *E, hipStream_t st)
 {
     if (A->n_dgroups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aln_emit_kernel, dim3(walk_waves(A->n_slots, A->n_heavy_slots, A->slot_heavy)), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(aln_emit_kernel, dim3(walk_waves(A->n_slots, A->n_share_slots, A->slot_heavy)), dim3(64), 0, st, *A, *E);
     if (E->out.rr && E->n_rows > 0)
         hipLaunchKernelGGL(rows_unpack_kernel, dim3((unsigned)((E->n_rows + 255) / 256)), dim3(256), 0, st, E->out.rr, E->n_rows, E->out.rows,
                            E->out.row_expect, E->out.row_prob, E->out.row_rawq);
-    hipLaunchKernelGGL(group_finish_kernel, dim3(walk_waves(A->n_dgroups, A->n_heavy_groups, A->group_heavy)), dim3(64), 0, st, *A, *E);
+    hipLaunchKernelGGL(group_finish_kernel, dim3(walk_waves(A->n_dgroups, A->n_share_groups, A->group_heavy)), dim3(64), 0, st, *A, *E);
     if (E->n_prob > 0)
         hipLaunchKernelGGL(problem_constants_kernel, dim3((E->n_prob + 255) / 256), dim3(256), 0, st, A->par, E->n_prob, E->out.L, E->out.R,
                            E->out.has_n, E->hmm);

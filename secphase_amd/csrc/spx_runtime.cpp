@@ -1228,21 +1228,27 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
      * which an item counts as heavy (default 2048: a HiFi read of 15 kb stays where it is, an ONT-like read of 20 kb moves out) */
     static const int heavy = [] { const char *e = getenv("SPX_PREP_HEAVY"); return e ? std::max(0, atoi(e)) : 1024; }();
     static const int heavy_min = [] { const char *e = getenv("SPX_PREP_HEAVY_MIN"); return e ? std::max(1, atoi(e)) : 2048; }();
+    static const int share = [] { const char *e = getenv("SPX_PREP_SHARE"); return e ? std::max(0, atoi(e)) : 32768; }();
     if (heavy > 0 && ns >= 64) {
         const size_t n = std::max(ns, ng), tb = spx_prep_heavy_temp_bytes((int32_t)n);
-        Carver pc;
-        const size_t o_keys = pc.take<int32_t>(3 * n), o_vals = pc.take<int32_t>(2 * n), o_sh = pc.take<int32_t>(ns + 1), o_gh = pc.take<int32_t>(ng + 1),
-                     o_sf = pc.take<uint8_t>(ns + 1), o_gf = pc.take<uint8_t>(ng + 1), o_tmp = pc.take<char>(tb + 256);
-        if ((rc = ensure_pool(PL, PL.pool_perm, pc.off + 256))) return fail(rc, "device memory for the list of heavy alignments");
-        char *pb = (char *)PL.pool_perm.p;
         A.n_heavy_slots = (int32_t)std::min<size_t>((size_t)heavy, ns / 16);
         A.n_heavy_groups = (int32_t)std::min<size_t>((size_t)heavy / 2, ng / 16);
+        /* the kernels that SHARE an extracted item among the 64 lanes of its wave extract many more (SPX_PREP_SHARE, default 32 768, at most a quarter of the list) */
+        A.n_share_slots = (int32_t)std::max<size_t>((size_t)A.n_heavy_slots, std::min<size_t>((size_t)share, ns / 4));
+        A.n_share_groups = (int32_t)std::max<size_t>((size_t)A.n_heavy_groups, std::min<size_t>((size_t)share / 2, ng / 4));
+        Carver pc;
+        const size_t o_keys = pc.take<int32_t>(3 * n), o_vals = pc.take<int32_t>(2 * n), o_sh = pc.take<int32_t>(ns + 1), o_gh = pc.take<int32_t>(ng + 1),
+                     o_sf = pc.take<uint8_t>(ns + 1), o_gf = pc.take<uint8_t>(ng + 1), o_tmp = pc.take<char>(tb + 256),
+                     o_hp = pc.take<spxl::PlanBase>((size_t)A.n_share_slots * 64 + 64);
+        if ((rc = ensure_pool(PL, PL.pool_perm, pc.off + 256))) return fail(rc, "device memory for the list of heavy alignments");
+        char *pb = (char *)PL.pool_perm.p;
         HIPCHK(spx_prep_heavy(&A, (int32_t *)(pb + o_keys), (int32_t *)(pb + o_vals), pb + o_tmp, tb, (int32_t *)(pb + o_sh), (int32_t *)(pb + o_gh),
                               (uint8_t *)(pb + o_sf), (uint8_t *)(pb + o_gf), heavy_min, PL.stream));
         A.slot_heavy = (const int32_t *)(pb + o_sh);
         A.group_heavy = (const int32_t *)(pb + o_gh);
         A.slot_flag = (const uint8_t *)(pb + o_sf);
         A.group_flag = (const uint8_t *)(pb + o_gf);
+        A.heavy_plan = (spxl::PlanBase *)(pb + o_hp);
     }
     bool phase1 = true;
     for (int attempt = 0;; ++attempt) {
