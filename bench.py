@@ -732,7 +732,7 @@ def main():
         for w_ in staged:
             w_.free()
         staged = []
-        api._chk(L.spx_trim(ctx.h), "spx_trim")
+        ctx.close()  # memory AND hardware queues: see the N = 1 case below
         torch.cuda.empty_cache()
         flag_ = os.path.join(tempfile.gettempdir(), f"spx_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.done")
         if rank == 0 and os.path.exists(flag_):
@@ -987,7 +987,10 @@ def main():
             for w_ in staged:
                 w_.free()
             staged = []
-            api._chk(L.spx_trim(ctx.h), "spx_trim")
+            # (the whole context, not only its memory: a context holds 14 hardware queues, and with this process, an `also` child and ITS
+            # command-line child alive the GPU's queue slots are oversubscribed -- the scheduler then time-slices the processes: the ONT
+            # end-to-end leg ran at 18.8 k groups/s as a grandchild of a process with a live context, at 33.4 k on its own)
+            ctx.close()
             torch.cuda.empty_cache()
         if want_bam:
             # every distinct batch of this rank (524 288 HiFi groups by default): start-up (HIP initialisation, reference upload:

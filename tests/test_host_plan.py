@@ -234,3 +234,52 @@ def test_secondaries_that_repeat_the_primary_stay_on_the_host(built):
             missed += dropped != 1
     assert missed <= 5   # (at most one of the 40 records is neither a source nor aliased: its 5 changes alter nothing)
     assert stats()[1] == n_sec
+
+
+_SHARE_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from common import small_genome
+from secphase_amd import api, records, synth
+h = hashlib.sha256()
+for kw, first, n, par in (
+        (dict(platform=synth.MIXED, n_paralogs=7, contig_len=250000, max_read_len=40000), 7, 10, records.preset("hifi")),
+        (dict(platform=synth.ONT, n_paralogs=3, read_len=6000), 0, 8, records.preset("ont", bandwidth=50)),
+        (dict(platform=synth.HIFI, hardclip_frac=0.5, softclip_frac=0.5, shuffle_records=1, inverted_paralogs=1, n_paralogs=3, max_secondaries=4,
+              n_base_frac=0.002, read_len=5000), 100, 30, records.preset("hifi")),
+        (dict(platform=synth.HIFI, tag_mode=1, read_len=5000, max_secondaries=3, n_paralogs=2, hardclip_frac=0.3, softclip_frac=0.3), 0, 20,
+         records.preset("hifi"))):
+    plat = kw.pop("platform")
+    g = small_genome(plat, **kw)
+    r = g.reads(first, n)
+    plan = api.Plan(g.ref, r.batch, par)
+    v = plan.view
+    h.update(np.array([v.n_problems, v.n_rows, v.n_groups, v.n_markers, v.n_qedits], np.int64).tobytes())
+    for name, cnt in (("L", v.n_problems), ("R", v.n_problems), ("bw", v.n_problems), ("ref_rfs", v.n_problems), ("qry_nib", v.n_problems),
+                      ("row_off", v.n_problems), ("n_rows_of", v.n_problems), ("rows", v.n_rows), ("row_expect", v.n_rows), ("row_rawq", v.n_rows),
+                      ("mk_first", v.n_groups + 1), ("mk_row", v.n_markers), ("mk_qfix", v.n_markers), ("mk_is_match", v.n_markers),
+                      ("mk_aln", v.n_markers), ("n_aln", v.n_groups), ("rfe", v.n_groups * 10), ("grp_error", n)):
+        if cnt:
+            h.update(np.ctypeslib.as_array(getattr(v, name), shape=(cnt,)).tobytes())
+    assert v.n_problems > 0
+print(h.hexdigest())
+"""
+
+
+def test_plan_does_not_depend_on_how_the_walks_are_shared(built):
+    """Round 5: on the device the 64 lanes of a wave share ONE heavy alignment -- contiguous ranges of its marker columns (aln_fill_range /
+    aln_filter_range) and of its BAQ blocks (plan_baq_range), cursors from binary searches, output offsets from the counting pass's
+    per-range totals.  SPX_PLAN_PARTS=n makes the host plan walk the same ranges one after the other (last range first): every array of
+    the work list must come out as with one range (which test_plan_* above check against the oracle)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for parts in ("1", "2", "7", "64"):
+        p = subprocess.run([sys.executable, "-c", _SHARE_SCRIPT, root], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, SPX_PLAN_PARTS=parts))
+        assert p.returncode == 0, p.stderr[-800:]
+        digests[parts] = p.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests
