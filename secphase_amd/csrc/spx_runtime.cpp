@@ -166,6 +166,9 @@ struct spx_ctx {
         spx_order_segs *d_segs = nullptr, *h_segs = nullptr; /* 2 x SPX_MAX_SLICES (forward, backward): device / pinned host */
     } lane[SPX_N_PREP];
     std::atomic<unsigned> lane_rr{0};
+    /* the scratch slack the consensus rounds of some list of this context needed (1, 4, 16 ..): later lists start with it instead of finding it
+     * out again by an overflow and a second run of the whole group phase (round 5: two of seven mixed batches paid that at EVERY preparation) */
+    std::atomic<int> slack_hint{1};
 };
 
 /* grow-only device buffer of a preparation lane; the caller holds the lane's mutex.  Kernels of an earlier preparation
@@ -1142,7 +1145,7 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.ga_off = (int64_t *)(base + w->o_gao);
     A.arena = (char *)PL.pool_garena.p;
     A.arena_cap = (int64_t)PL.pool_garena.cap;
-    A.slack = 1;
+    A.slack = c->slack_hint.load(std::memory_order_relaxed);
     A.scan_stride = (int64_t)std::max(L.n_slots, L.n_dgroups) + 8;
     A.scan_v = (int64_t *)(base + w->o_scan);
     A.scan_tile = A.scan_v + 5 * A.scan_stride;
@@ -1273,6 +1276,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
             A.ops_cap = (int64_t)ops_bound; A.conf_cap = (int64_t)conf_bound; A.mm_cap = (int64_t)mm_bound;
         } else if (ov & 2) {
             A.slack *= 4;
+            { const int want = std::min(A.slack, 64); int h = c->slack_hint.load(std::memory_order_relaxed); while (h < want && !c->slack_hint.compare_exchange_weak(h, want)) {} }
             if ((rc = ensure_pool(PL, PL.pool_garena, (size_t)w->tot.arena_bytes * 4 + 4096))) return fail(rc, "device memory for the group scratch");
             A.arena = (char *)PL.pool_garena.p;
             A.arena_cap = (int64_t)PL.pool_garena.cap;
