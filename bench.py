@@ -451,9 +451,13 @@ def main():
     for i in range(1, D):
         batches.append(gen_parallel(genome, first + i * gps, gps, args.gen_chunk, host_threads))
         batch_ranges[i] = [(first + i * gps, gps)]
-    # a staged list may be in flight once: run() keeps depth + 1 submissions in flight and rotates over the D lists
+    # a staged list may be in flight once: run() keeps depth + 1 submissions in flight and rotates over S staged lists.  S >= depth + 1
+    # even when host memory bounds the DISTINCT batches below that (8 ranks under one container limit: D = 2): a batch is then staged
+    # into HBM more than once -- HBM has the room the host lacks -- and the pipeline keeps its depth
+    S = D
     if not args.kernel_only:
-        args.depth = max(1, min(args.depth, D - 1))
+        S = max(D, args.depth + 1)
+        args.depth = max(1, min(args.depth, S - 1))
     # ---- BASELINE config 5 at N > 1 (load-balance stress): the step's groups are cut by COST, not by count.  Every rank has
     # generated its count-based share; the per-group costs (bases over all alignments of the group: what the preparation
     # walks and the DP realigns) are all-gathered, the same cost boundaries come out on every rank (shard_by_cost), and a
@@ -557,7 +561,7 @@ def main():
     relabelled = [0]
     if not args.kernel_only:
         t0 = time.time()
-        staged = [ctx.stage(p, params, host_threads=host_threads) for p in ptrs]  # records -> HBM, outside the timed region
+        staged = [ctx.stage(ptrs[j % D], params, host_threads=host_threads) for j in range(S)]  # records -> HBM, outside the timed region
         ctx_sync()
         t_stage = time.time() - t0
         pipe = api.Pipe(ctx, params, depth=args.depth, host_threads=stage_threads)
@@ -621,21 +625,22 @@ def main():
 
     def run(nsteps, offset, from_host):
         submitted = received = 0
+        # staged list j of S holds batch j % D (S = D unless host memory bounds D below the pipeline depth)
         if not from_host:
-            batch_sequence.extend((offset + k) % D for k in range(nsteps))
+            batch_sequence.extend(((offset + k) % S) % D for k in range(nsteps))
         while received < nsteps:
             while submitted < nsteps and pipe.pending() < args.depth + 1:
-                i = (offset + submitted) % D
                 if from_host:
-                    pipe.submit(batch=ptrs[i])
+                    pipe.submit(batch=ptrs[(offset + submitted) % D])
                 else:
-                    pipe.submit(staged=staged[i])
+                    pipe.submit(staged=staged[(offset + submitted) % S])
                 submitted += 1
-            i = (offset + received) % D
+            j = (offset + received) % (D if from_host else S)
+            i = j % D
             _, n = pipe.next(outbuf)
-            finish_step(offset + received, i, n, staged[i] if not from_host else None)
+            finish_step(offset + received, i, n, staged[j] if not from_host else None)
             if not from_host:
-                staged[i].release()  # the list's HBM goes back to the context for the next step's list
+                staged[j].release()  # the list's HBM goes back to the context for the next step's list
             received += 1
 
     def verify_last_step(i_last):
@@ -686,7 +691,7 @@ def main():
         writer_drain()  # rank 0: the list of every timed step is on disk
         sync_all()
         elapsed = time.perf_counter() - t0
-        per_step_stats = [staged[(args.warmup + k) % D].stats() for k in range(min(args.steps, D))]
+        per_step_stats = [staged[(args.warmup + k) % S].stats() for k in range(min(args.steps, S))]
         if args.keep_log:
             import shutil
             if rank == 0:
@@ -699,7 +704,7 @@ def main():
         # results were collected into; (b) the relabel list this run wrote: the oracle's list of the run's first groups must be
         # a byte prefix of it (one rand() stream in (step, rank, group) order, so rank 0's first groups come first at any N)
         if rank == 0 and args.verify > 0:
-            verified_timed = verify_last_step((args.warmup + args.steps - 1) % D)
+            verified_timed = verify_last_step(((args.warmup + args.steps - 1) % S) % D)
         if world == 1 and not args.no_host_leg:
             # the same steps fed from HOST memory: staging (host threads) + PCIe copy inside the timed region
             hs = max(2, min(args.steps, 8))
@@ -939,6 +944,7 @@ def main():
                              "records resident in HBM, whole path records -> relabel list inside the step)"),
                 "groups_per_step_per_gpu": gps,
                 "distinct_batches_per_gpu": D,
+                "staged_lists_per_gpu": S,
                 "pipeline_depth": args.depth,
                 "dp_problems_per_step": int(n_prob_all),
                 "dp_cells_per_step": int(cells_all),
