@@ -1100,3 +1100,46 @@ def test_pipeline_reports_group_errors_in_place(ctx):
     out, n = pipe.next()
     assert n == 3 and out[0].n_aln == api.EUNSUPPORTED and out[1].n_aln == 2 and out[2].n_aln == api.ENOTAG
     pipe.close()
+
+
+_FORCED_SHARE_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from common import small_genome
+from oracle import orc
+from secphase_amd import api, records, synth
+ctx = api.Context(0)
+bad = 0
+for kw, first, n, par in (
+        (dict(platform=synth.MIXED, n_paralogs=7, contig_len=250000, max_read_len=40000), 7, 96, records.preset("hifi")),
+        (dict(platform=synth.HIFI, hardclip_frac=0.5, softclip_frac=0.5, shuffle_records=1, inverted_paralogs=1, n_paralogs=3, max_secondaries=4,
+              n_base_frac=0.002, read_len=5000), 100, 80, records.preset("hifi")),
+        (dict(platform=synth.ONT, n_paralogs=3, read_len=6000), 0, 40, records.preset("ont", bandwidth=50))):
+    plat = kw.pop("platform")
+    g = small_genome(plat, **kw)
+    r = g.reads(first, n)
+    ctx.set_reference(g.ref)
+    out, st = ctx.score_batch(r.batch, par, finalize_seed=1)
+    _, res = orc.run_batch(r.batch, g.ref, par, threads=4, seed=1)
+    for i in range(n):
+        o, e = out[i], res[i]
+        ok = o.n_aln == e.n_aln and o.best_idx == e.best_idx and all(o.score[a] == e.score[a] for a in range(max(e.n_aln, 0)))
+        bad += not ok
+    assert st.n_problems == sum(x.n_baq_calls for x in res)
+print("differing groups:", bad)
+sys.exit(1 if bad else 0)
+"""
+
+
+def test_extracted_alignments_on_small_batches(built):
+    """The extraction of heavy alignments / groups (lone-lane waves; marker columns and BAQ blocks shared by the 64 lanes of a wave,
+    spx_prep_kernels.hip) only triggers on lists with long reads.  SPX_PREP_HEAVY_MIN=1 makes every item that is four times its list's
+    median 'heavy': the mixed, the clipped / shuffled / inverted and the ONT batches of this suite then go through those paths, and
+    scores, decisions and problem counts must still equal the oracle's.  (A child process: the switches are read once per process.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _FORCED_SHARE_SCRIPT, root], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SPX_PREP_HEAVY_MIN="1", SPX_PREP_HEAVY="16", SPX_PREP_SHARE="4096", GPU_MAX_HW_QUEUES="14"))
+    assert p.returncode == 0, (p.stdout[-300:], p.stderr[-800:])
+    assert "differing groups: 0" in p.stdout
