@@ -152,6 +152,8 @@ def from_bam_leg(args, genome, record_chunks, n_groups, ncpu, oracle_log, oracle
                     return None, p
                 m = re.search(r"time in the scoring loop: ([0-9.]+) s", p.stderr)
                 runs.append((wall, float(m.group(1)) if m else None, (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)))
+            m2 = re.search(r"time in the scoring loop: .*", p.stderr)
+            res["cli_timing_line"] = m2.group(0)[:400] if m2 else None
             return runs, None
 
         # the default command line: DEVICE-RESIDENT input (compressed bytes up, inflate / record chain / fields / dispatch filter / staging as kernels)
@@ -366,6 +368,20 @@ def main():
         if not os.path.exists(api.LIB_PATH):
             ge.build()
         ge.build_cpu_helpers()
+    # The short ONT / mixed legs run FIRST, as child processes, while this process has not touched the GPU yet: a leg -- and the command line
+    # its end-to-end part starts as a child of its own -- then shares the device with nobody.  Run after the headline, under a parent that
+    # still held a GPU context (torch's cannot be given up), the ONT command line's kernels took 1.85 x as long (three processes with
+    # contexts on one GPU are time-sliced: 19 k groups/s in the loop against 33 k on its own).
+    also_results = None
+    if world == 1 and not args.no_also and not args.kernel_only and args.platform == "hifi":
+        also_results = {}
+        for plat in ("ont", "mixed"):
+            try:
+                # (a timed region starts with an empty pipeline: its first list waits for a whole preparation -- ~160 ms on the mixed
+                # workload, where a step is 90 ms: 16 steps there, 8 of the 325 ms ONT steps)
+                also_results[plat] = also_leg(plat, 16 if plat == "mixed" else 8, 2)
+            except Exception as ex:  # noqa: BLE001
+                also_results[plat] = {"error": str(ex)}
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the scoring path has no CPU fallback")
     if args.dist_backend == "gloo":
@@ -984,8 +1000,7 @@ def main():
         # uncompressed record bytes (what spx_stage hands to the device: flags, CIGAR, SEQ, QUAL, cs/MD text) through the step
         line["gb_records_per_s"] = round(bytes_in * world * args.steps / elapsed / 1e9, 2)
         want_bam = want_bam_all
-        want_also = world == 1 and not args.no_also and not args.kernel_only and args.platform == "hifi"
-        if want_bam or want_also:
+        if want_bam:
             # the command line / the other workloads run as other processes on the same GPU: hand back what this one holds first
             if pipe is not None:
                 pipe.close()
@@ -1030,15 +1045,8 @@ def main():
         if cpu:
             cpu.pop("oracle_log", None)
             cpu.pop("oracle_groups", None)
-        if want_also:
-            line["also"] = {}
-            for plat in ("ont", "mixed"):
-                try:
-                    # (a timed region starts with an empty pipeline: its first list waits for a whole preparation -- ~160 ms on the mixed
-                    # workload, where a step is 90 ms: 16 steps there, 8 of the 325 ms ONT steps)
-                    line["also"][plat] = also_leg(plat, 16 if plat == "mixed" else 8, 2)
-                except Exception as ex:  # noqa: BLE001
-                    line["also"][plat] = {"error": str(ex)}
+        if also_results is not None:
+            line["also"] = also_results
         print(json.dumps(line), flush=True)
     if world > 1 and want_bam_all:
         # rank 0 ran the command line on EVERY device of the job: the other ranks wait on the host (a flag file), not in a collective
