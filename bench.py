@@ -266,14 +266,16 @@ def also_leg(platform, steps, warmup):
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
            "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "3", "--cpu-threads", "32", "--no-host-input-leg"]
     # config 3 also end to end: `secphase --ont -b 50` on a BAM of one step's groups
-    # (65 536 groups = 8.4 GB of BAM: start-up no longer dominates the leg; SPX_BENCH_ALSO_ONT_BAM for another size)
-    cmd += ["--from-bam", os.environ.get("SPX_BENCH_ALSO_ONT_BAM", "65536")] if platform == "ont" else ["--no-from-bam"]
+    # both legs end to end too, on >= 100 k groups each: ONT 131 072 groups = 16.7 GB of BAM (8 distinct batches), mixed 114 688
+    # groups (its 7 batches); SPX_BENCH_ALSO_ONT_BAM / SPX_BENCH_ALSO_MIXED_BAM for other sizes (0: no leg)
+    nbam = os.environ.get("SPX_BENCH_ALSO_ONT_BAM", "131072") if platform == "ont" else os.environ.get("SPX_BENCH_ALSO_MIXED_BAM", "114688")
+    cmd += ["--from-bam", nbam] if int(nbam) > 0 else ["--no-from-bam"]
     # (mixed: small batches whose preparations overlap -- six in flight; ONT: the preset of BASELINE config 3, 16 384 groups per
     # step, four lists in flight (DP slices keep a list at ~30 GB) -- the parent has handed its device memory back (spx_trim)
     # before this runs; SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
     ont_gps = os.environ.get("SPX_BENCH_ALSO_ONT_GPS")
     cmd += ["--distinct", "7", "--depth", "6"] if platform == "mixed" else \
-        (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "5", "--depth", "4"])
+        (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "8", "--depth", "4"])
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.perf_counter() - t0
