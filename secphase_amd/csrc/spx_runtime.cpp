@@ -159,7 +159,7 @@ struct spx_ctx {
     struct PrepLane {
         hipStream_t stream = nullptr;
         std::mutex mu;
-        DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort, pool_perm;
+        DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort, pool_heavy;
         spx_prep_totals *d_tot = nullptr, *h_tot = nullptr; /* device / pinned host */
         spxl::PlanBase *d_bounds = nullptr, *h_bounds = nullptr; /* DP slices: SPX_MAX_SLICES + 1 prefix records */
         DevBuf pool_bins;                                   /* 2 passes x 3 x slices x SPX_N_CLASSES x 1024 int32 */
@@ -448,7 +448,7 @@ extern "C" void spx_destroy(spx_ctx *c)
     c->stage_pool.reset();
     for (int l = 0; l < spx_ctx::SPX_N_PREP; ++l) {
         spx_ctx::PrepLane &PL = c->lane[l];
-        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_perm})
+        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_heavy})
             if (b->p) (void)hipFree(b->p);
         if (PL.d_tot) (void)hipFree(PL.d_tot);
         if (PL.h_tot) (void)hipHostFree(PL.h_tot);
@@ -1243,8 +1243,8 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         const size_t o_keys = pc.take<int32_t>(3 * n), o_vals = pc.take<int32_t>(2 * n), o_sh = pc.take<int32_t>(ns + 1), o_gh = pc.take<int32_t>(ng + 1),
                      o_sf = pc.take<uint8_t>(ns + 1), o_gf = pc.take<uint8_t>(ng + 1), o_tmp = pc.take<char>(tb + 256),
                      o_hp = pc.take<spxl::PlanBase>((size_t)A.n_share_slots * 64 + 64);
-        if ((rc = ensure_pool(PL, PL.pool_perm, pc.off + 256))) return fail(rc, "device memory for the list of heavy alignments");
-        char *pb = (char *)PL.pool_perm.p;
+        if ((rc = ensure_pool(PL, PL.pool_heavy, pc.off + 256))) return fail(rc, "device memory for the list of heavy alignments");
+        char *pb = (char *)PL.pool_heavy.p;
         HIPCHK(spx_prep_heavy(&A, (int32_t *)(pb + o_keys), (int32_t *)(pb + o_vals), pb + o_tmp, tb, (int32_t *)(pb + o_sh), (int32_t *)(pb + o_gh),
                               (uint8_t *)(pb + o_sf), (uint8_t *)(pb + o_gf), heavy_min, PL.stream));
         A.slot_heavy = (const int32_t *)(pb + o_sh);
@@ -1691,7 +1691,7 @@ extern "C" int spx_trim(spx_ctx *c)
         spx_ctx::PrepLane &PL = c->lane[l];
         std::lock_guard<std::mutex> pl(PL.mu);
         HIPCHK(hipStreamSynchronize(PL.stream));
-        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_perm, &PL.pool_bins})
+        for (spx_ctx::DevBuf *b : {&PL.pool_ops, &PL.pool_conf, &PL.pool_mm, &PL.pool_garena, &PL.pool_keys, &PL.pool_sort, &PL.pool_heavy, &PL.pool_bins})
             if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
