@@ -1566,6 +1566,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (w->staged && !w->prepared) return fail(SPX_EINVAL, "work list has been staged but not prepared");
     std::lock_guard<std::mutex> lk(c->launch_mu);
     if (w->ev_ready) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_ready, 0)); /* the list is built on the preparation stream */
+    if (w->launched && w->ev_done) HIPCHK(hipStreamWaitEvent(c->stream, w->ev_done, 0)); /* a replay: behind the scoring kernels of the launch before (result stream) */
     const int64_t launch_id = c->n_launch.load();
     hipEvent_t *ev = c->evr[launch_id % spx_ctx::SPX_EV_RING];
     w->launch_ids.push_back(launch_id);
@@ -1654,14 +1655,21 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         }
     }
     HIPCHK(hipEventRecord(ev[1], c->stream));
+    /* The marker filter / score / decision / result kernels go to the RESULT stream, behind the DP kernels' event (round 5): on the main stream
+     * they stood between this list's MAP kernel and the next list's heaviest forward kernel -- one lane adds up the 45 000 marker positions
+     * of a 100 kb read's group in order: 4 ms per mixed list with the rest of the chip idle. */
+    hipStream_t tail = c->stream;
+    static const bool score_main = getenv("SPX_SCORE_MAIN") != nullptr; /* (experiment switch: the round-4 placement) */
     if (w->have_groups) {
+        if (!score_main) tail = c->result_stream;
+        if (tail != c->stream) HIPCHK(hipStreamWaitEvent(tail, ev[1], 0));
         const int64_t nmk = w->staged ? w->n_mk_dev : (int64_t)w->hb.markers.size();
-        HIPCHK(spx_launch_score(&w->dg, (int32_t)nmk, w->d_posmin, c->stream));
-        if (w->staged) HIPCHK(spx_launch_results(&w->dg, w->d_info, w->d_rfe, w->d_results, c->stream));
+        HIPCHK(spx_launch_score(&w->dg, (int32_t)nmk, w->d_posmin, tail));
+        if (w->staged) HIPCHK(spx_launch_results(&w->dg, w->d_info, w->d_rfe, w->d_results, tail));
     }
-    HIPCHK(hipEventRecord(ev[2], c->stream));
+    HIPCHK(hipEventRecord(ev[2], tail));
     if (!w->ev_done) HIPCHK(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming | hipEventBlockingSync));
-    HIPCHK(hipEventRecord(w->ev_done, c->stream));
+    HIPCHK(hipEventRecord(w->ev_done, tail));
     w->launched = true;
     return SPX_OK;
 }
@@ -1695,6 +1703,7 @@ extern "C" int spx_trim(spx_ctx *c)
             if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->result_stream));
     {
         std::lock_guard<std::mutex> lk(c->arena_mu);
         for (auto &a : c->arena_cache) (void)hipFree(a.first);
@@ -1710,6 +1719,7 @@ extern "C" int spx_sync(spx_ctx *c)
 {
     if (!c) return fail(SPX_EINVAL, "NULL argument");
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->result_stream)); /* (the scoring kernels of the launched lists) */
     return SPX_OK;
 }
 
