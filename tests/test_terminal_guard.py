@@ -179,7 +179,8 @@ def test_every_band_class_under_both_readings(ctx, guard):
     from test_gpu_parity import _posteriors_equal
     rng = np.random.default_rng(21)
     shapes = [(15, 18, 20), (20, 22, 21), (22, 20, 22), (18, 30, 23), (30, 41, 40), (40, 50, 52), (45, 60, 55), (57, 70, 58),
-              (50, 60, 60), (100, 110, 120), (200, 220, 250), (300, 333, 400), (500, 480, 700), (100, 100, 20), (300, 290, 52)]
+              (50, 60, 60), (100, 110, 120), (200, 220, 250), (300, 333, 400), (500, 480, 700), (100, 100, 20), (300, 290, 52),
+              (18, 30, 24), (22, 40, 25), (60, 34, 26), (25, 52, 27), (300, 276, 24), (280, 307, 27), (90, 118, 28), (70, 40, 31)]
     n_reg = 0
     for (L, R, bw) in shapes:
         n_reg += in_regime(L, R, bw)
