@@ -380,8 +380,8 @@ def main():
         for plat in ("ont", "mixed"):
             try:
                 # (a timed region starts with an empty pipeline: its first list waits for a whole preparation -- ~160 ms on the mixed
-                # workload, where a step is 90 ms: 16 steps there, 8 of the 325 ms ONT steps)
-                also_results[plat] = also_leg(plat, 16 if plat == "mixed" else 8, 2)
+                # workload, where a step is 85 ms: 32 steps = 524 288 groups there, 8 of the 325 ms ONT steps)
+                also_results[plat] = also_leg(plat, 32 if plat == "mixed" else 8, 2)
             except Exception as ex:  # noqa: BLE001
                 also_results[plat] = {"error": str(ex)}
     if not torch.cuda.is_available():

@@ -81,7 +81,8 @@ typedef struct spx_stats {
     int64_t problems_per_class[16];
     double prep_seconds, h2d_seconds, kernel_seconds, d2h_seconds;
     /* dominant kernel, measured with HIP events on the launch stream, averaged (see n_launches_averaged) */
-    double baq_kernel_ms;   /* all BAQ launches of the work list (forward, backward, MAP; every band class) */
+    double baq_kernel_ms;   /* all BAQ launches of the work list (forward, backward, MAP; every band class): start -> last backward kernel on the
+                             * main stream + the span of the last MAP kernel on the result stream (where it runs beside the next list's DP kernels) */
     double score_kernel_ms;
     /* the band class holding most cells: its forward / backward kernel alone */
     double main_fwd_ms, main_bwd_ms;

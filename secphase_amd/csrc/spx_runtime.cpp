@@ -99,9 +99,10 @@ struct spx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     /* HIP events around the kernels of the last SPX_EV_RING launches (0 start, 1 after MAP, 2 after scoring, 3..5 around
-     * the main class' forward and backward kernels): spx_collect averages over the launches since the previous collect */
+     * the main class' forward and backward kernels, 6 behind the last backward kernels on the main stream, 7 in front of the last MAP kernel on
+     * the stream it runs on): spx_collect averages over the launches since the previous collect */
     static const int SPX_EV_RING = 64;
-    hipEvent_t evr[SPX_EV_RING][6] = {};
+    hipEvent_t evr[SPX_EV_RING][8] = {};
     std::atomic<int64_t> n_launch{0}; /* written under launch_mu, read by collects of other lists (ThreadSanitizer run on the GPU box) */
     /* the band classes run concurrently: a handful of wide-band problems must not serialise behind
      * (or in front of) the bulk class */
@@ -387,7 +388,7 @@ extern "C" int spx_create(int device, spx_ctx **out)
     c->prep_cus = masked ? prep_cus : 0;
     HIPCHK(mk_stream(&c->stream, m_dp));
     for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
-        for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
+        for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
     for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
         HIPCHK(mk_stream(&c->side_stream[i], m_dp));
         HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming | hipEventBlockingSync));
@@ -459,7 +460,7 @@ extern "C" void spx_destroy(spx_ctx *c)
         if (PL.h_segs) (void)hipHostFree(PL.h_segs);
         if (PL.stream) (void)hipStreamDestroy(PL.stream);
     }
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
         for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
             if (c->evr[r][i]) (void)hipEventDestroy(c->evr[r][i]);
     for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
@@ -1578,6 +1579,27 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
      * has the least work so far */
     const int mc = w->main_cls;
     static const bool serial = getenv("SPX_SERIAL") != nullptr; /* diagnostics: one class after the other */
+    /* What follows the last backward kernel of a list with groups -- the MAP kernel (of its last slice), the marker filter / score / decision /
+     * result kernels -- goes to the RESULT stream (round 5): on the main stream it stood between this list's DP kernels and the next list's
+     * heaviest forward kernel.  MAP streams the z rows at ~2 TB/s with the ALUs idle (2.8 ms per HiFi slice, 3.8 ms per mixed list); in the
+     * score kernel one lane adds up the 45 000 marker positions of a 100 kb read's group in order (4 ms per mixed list).  The lists have
+     * scratch of their own, so the next list's DP kernels may run beside them; the SLICES of one list share theirs and stay in order. */
+    static const bool score_main = getenv("SPX_SCORE_MAIN") != nullptr; /* (experiment switch: the round-4 placement) */
+    hipStream_t tail = (w->have_groups && !score_main) ? c->result_stream : c->stream;
+    bool tail_open = false;
+    auto open_tail = [&]() -> int { /* ev[0] .. ev[6]: the DP kernels on the main and side streams; ev[7] .. ev[1]: the last MAP kernel where it runs */
+        if (tail_open) return SPX_OK;
+        tail_open = true;
+        HIPCHK(hipEventRecord(ev[6], c->stream));
+        if (tail != c->stream) HIPCHK(hipStreamWaitEvent(tail, ev[6], 0));
+        HIPCHK(hipEventRecord(ev[7], tail));
+        return SPX_OK;
+    };
+    auto last_map = [&](const spx_dev_batch *Bm, int32_t nrows, bool wide_first) -> int {
+        { const int rc = open_tail(); if (rc) return rc; }
+        HIPCHK(spx_launch_map(Bm, nrows, wide_first, tail));
+        return SPX_OK;
+    };
     int order[SPX_N_CLASSES], no = 0;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
         if (w->cls_used[cls] && cls != mc) order[no++] = cls;
@@ -1609,7 +1631,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         int64_t narrow = 0, wide = 0;
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
         const int64_t nrows = w->staged ? w->n_rows_dev : (int64_t)w->hb.rows.size();
-        HIPCHK(spx_launch_map(&w->cls_batch[0], (int32_t)nrows, wide > narrow, c->stream));
+        { const int rc = last_map(&w->cls_batch[0], (int32_t)nrows, wide > narrow); if (rc) return rc; }
     }
     } else {
         /* DP slices: forward -> backward -> MAP of one slice after the other over the shared scratch; inside a slice the band
@@ -1645,7 +1667,8 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
             if (sl.r1 > sl.r0) {
                 spx_dev_batch Bm = sl.cls_batch[0];
                 Bm.row_base = (int32_t)sl.r0;
-                HIPCHK(spx_launch_map(&Bm, (int32_t)(sl.r1 - sl.r0), wide > narrow, c->stream));
+                if (k + 1 == w->slices.size()) { const int rc = last_map(&Bm, (int32_t)(sl.r1 - sl.r0), wide > narrow); if (rc) return rc; }
+                else HIPCHK(spx_launch_map(&Bm, (int32_t)(sl.r1 - sl.r0), wide > narrow, c->stream));
             }
         }
         if (mc >= 0) { /* (the ring's slots stay defined for readers that expect them) */
@@ -1654,15 +1677,9 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
             HIPCHK(hipEventRecord(ev[5], c->stream));
         }
     }
-    HIPCHK(hipEventRecord(ev[1], c->stream));
-    /* The marker filter / score / decision / result kernels go to the RESULT stream, behind the DP kernels' event (round 5): on the main stream
-     * they stood between this list's MAP kernel and the next list's heaviest forward kernel -- one lane adds up the 45 000 marker positions
-     * of a 100 kb read's group in order: 4 ms per mixed list with the rest of the chip idle. */
-    hipStream_t tail = c->stream;
-    static const bool score_main = getenv("SPX_SCORE_MAIN") != nullptr; /* (experiment switch: the round-4 placement) */
+    { const int rc = open_tail(); if (rc) return rc; } /* (a last slice without rows launched no MAP kernel: the tail still starts behind the DP kernels) */
+    HIPCHK(hipEventRecord(ev[1], tail));
     if (w->have_groups) {
-        if (!score_main) tail = c->result_stream;
-        if (tail != c->stream) HIPCHK(hipStreamWaitEvent(tail, ev[1], 0));
         const int64_t nmk = w->staged ? w->n_mk_dev : (int64_t)w->hb.markers.size();
         HIPCHK(spx_launch_score(&w->dg, (int32_t)nmk, w->d_posmin, tail));
         if (w->staged) HIPCHK(spx_launch_results(&w->dg, w->d_info, w->d_rfe, w->d_results, tail));
@@ -1741,7 +1758,9 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
             if (c->n_launch.load() - l > spx_ctx::SPX_EV_RING) continue; /* slot reused since */
             hipEvent_t *ev = c->evr[l % spx_ctx::SPX_EV_RING];
             float ms = 0;
-            ok = ok && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+            ok = ok && hipEventElapsedTime(&ms, ev[0], ev[6]) == hipSuccess; /* the DP kernels ... */
+            baq += ms;
+            ok = ok && hipEventElapsedTime(&ms, ev[7], ev[1]) == hipSuccess; /* ... + the last MAP kernel where it ran (not the time it waited for the stream) */
             baq += ms;
             ok = ok && hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess;
             sc += ms;
@@ -1882,6 +1901,7 @@ static int pull_marker_mirrors(spx_ctx *c, spx_work *w)
 static int pull_qe_mirrors(spx_ctx *c, spx_work *w)
 {
     if (!w->staged || w->mirrors_qe) return SPX_OK;
+    if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done));
     HIPCHK(hipStreamSynchronize(c->stream));
     spx::HostBatch &hb = w->hb;
     const size_t nq = (size_t)w->tot.n_qe, nr = (size_t)w->n_rows_dev;
@@ -1908,6 +1928,7 @@ extern "C" int spx_apply_quals(spx_ctx *c, spx_work *w, int32_t batch_index, con
     if (!(w->par.flags & SPX_PAR_ALL_ROWS)) return fail(SPX_EINVAL, "work list was not prepared with SPX_PAR_ALL_ROWS");
     if (!w->launched) return fail(SPX_EINVAL, "work list has not been launched");
     HIPCHK(hipSetDevice(c->device));
+    if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done)); /* (the last MAP kernel runs on the result stream) */
     HIPCHK(hipStreamSynchronize(c->stream));
     { int rc = pull_qe_mirrors(c, w); if (rc) return rc; }
     const spx::HostBatch &hb = w->hb;
@@ -2199,11 +2220,11 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
     int rc = build_device_batch(c, w, true);
     c->d_ref4 = saved;
     if (!rc) rc = spx_launch(c, w);
-    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(SPX_EHIP, "kernel execution failed");
+    if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->result_stream) != hipSuccess)) rc = fail(SPX_EHIP, "kernel execution failed");
     if (!rc) {
         float ms = 0;
         hipEvent_t *ev = c->evr[(c->n_launch.load() - 1) % spx_ctx::SPX_EV_RING];
-        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]); /* (no groups: everything on the main stream) */
         if (kernel_ms) *kernel_ms = ms;
         const size_t nr = hb.rows.size();
         if (post_scale) { /* spx_probaln_posteriors: 1/s[] and z = f*b of every slot of every row of one problem */
@@ -2657,6 +2678,7 @@ extern "C" int spx_work_export(spx_ctx *c, spx_work *w, spx_plan **out)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->lane[w->lane].stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->result_stream));
     spx_plan *p = new spx_plan();
     spx::HostBatch &hb = p->hb;
     const size_t np = (size_t)w->n_prob_dev, nr = (size_t)w->n_rows_dev, nm = (size_t)w->n_mk_dev, ng = (size_t)w->n_dgroups,
