@@ -270,11 +270,11 @@ def also_leg(platform, steps, warmup):
     # groups (its 7 batches); SPX_BENCH_ALSO_ONT_BAM / SPX_BENCH_ALSO_MIXED_BAM for other sizes (0: no leg)
     nbam = os.environ.get("SPX_BENCH_ALSO_ONT_BAM", "131072") if platform == "ont" else os.environ.get("SPX_BENCH_ALSO_MIXED_BAM", "114688")
     cmd += ["--from-bam", nbam] if int(nbam) > 0 else ["--no-from-bam"]
-    # (mixed: small batches whose preparations overlap -- six in flight; ONT: the preset of BASELINE config 3, 16 384 groups per
+    # (mixed: small batches whose preparations overlap -- eight in flight on six preparation lanes; ONT: the preset of BASELINE config 3, 16 384 groups per
     # step, four lists in flight (DP slices keep a list at ~30 GB) -- the parent has handed its device memory back (spx_trim)
     # before this runs; SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
     ont_gps = os.environ.get("SPX_BENCH_ALSO_ONT_GPS")
-    cmd += ["--distinct", "7", "--depth", "6"] if platform == "mixed" else \
+    cmd += ["--distinct", "9", "--depth", "8"] if platform == "mixed" else \
         (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "8", "--depth", "4"])
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True)
@@ -343,7 +343,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "14")  # one hardware queue per stream of the context (before HIP initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per stream of the context (before HIP initialises)
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start the one-rank-per-GPU job as a CHILD process -- nothing has touched the
         # GPU yet (torch is not even imported), and the launcher is never exec'd -- and relay its JSON line
@@ -405,9 +405,9 @@ def main():
     if args.depth <= 0:
         # round 4: the scratch of a work list (1/s of every DP row + the saved forward rows) exists per DP slice, not per list
         # (16 GB per slice by default), so that ONT lists (70 -> ~30 GB per 16 384 groups) and mixed lists fit deeper pipelines
-        args.depth = 6 if mixed else (4 if ont else 3)
+        args.depth = 8 if mixed else (4 if ont else 3)
         if mixed:
-            args.distinct = max(args.distinct, 7)
+            args.distinct = max(args.distinct, 9)
         if ont:
             args.distinct = max(args.distinct, 5)
     # (large batches: the preparation kernels are dependent chains -- one lane walks one alignment / one group -- whose
@@ -1010,7 +1010,7 @@ def main():
             for w_ in staged:
                 w_.free()
             staged = []
-            # (the whole context, not only its memory: a context holds 14 hardware queues, and with this process, an `also` child and ITS
+            # (the whole context, not only its memory: a context holds 16 hardware queues, and with this process, an `also` child and ITS
             # command-line child alive the GPU's queue slots are oversubscribed -- the scheduler then time-slices the processes: the ONT
             # end-to-end leg ran at 18.8 k groups/s as a grandchild of a process with a live context, at 33.4 k on its own)
             ctx.close()

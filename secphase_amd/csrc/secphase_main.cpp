@@ -128,7 +128,7 @@ static void usage(const char *prog)
 
 int main(int argc, char *argv[])
 {
-    setenv("GPU_MAX_HW_QUEUES", "14", 0); /* one hardware queue per stream of the scoring context */
+    setenv("GPU_MAX_HW_QUEUES", "16", 0); /* one hardware queue per stream of the scoring context */
     /* defaults: src/secphase.c:420-449 */
     spx_params par;
     memset(&par, 0, sizeof par);

@@ -108,7 +108,9 @@ struct spx_ctx {
      * (or in front of) the bulk class */
     /* (three side streams, the classes spread over them by band cells: with the main, the preparation and the copy
      * stream that is six -- one hardware queue each, see spx_create) */
-    static const int SPX_N_SIDE = 3;
+    static const int SPX_N_SIDE = 8; /* at most */
+    int n_side = 6;                  /* in use (SPX_SIDE_STREAMS; round 5: 3 before -- on the mixed workload nine classes queued on three side streams
+                                      * and the chain 45 -> 47 -> (4,26) of small, latency-bound launches was the longest path of a slice) */
     hipStream_t side_stream[SPX_N_SIDE] = {};
     hipEvent_t side_done[SPX_N_SIDE] = {};
     /* host -> HBM copies of staged records, and NOTHING else: once a kernel or a memset has gone through a stream the
@@ -155,8 +157,9 @@ struct spx_ctx {
      * that leave most of the chip idle, and their duration is set by the longest alignment of the batch, not by the number
      * of groups.  So the preparations of several batches run SIDE BY SIDE, each on its own stream with its own pools
      * (a lane's mutex serialises the preparations that share it; work list w uses lane w->lane). */
-    static const int SPX_N_PREP = 12; /* lanes that exist; n_prep of them are used (SPX_PREP_LANES, default 4) */
-    int n_prep = 4;
+    static const int SPX_N_PREP = 12; /* lanes that exist; n_prep of them are used (SPX_PREP_LANES, default 6; 4 until round 5: once the DP kernels of
+                                       * the mixed workload's classes stopped queueing behind one another, four lanes prepared a list every ~70 ms and were the bound) */
+    int n_prep = 6;
     struct PrepLane {
         hipStream_t stream = nullptr;
         std::mutex mu;
@@ -318,9 +321,9 @@ extern "C" int spx_create(int device, spx_ctx **out)
     if (!out) return fail(SPX_EINVAL, "out is NULL");
     *out = nullptr;
     /* HIP multiplexes streams onto hardware queues (4 by default): two streams that share one run their kernels one
-     * after the other.  Ask for 14 (main, three side, copy, unpack, result and the preparation lanes' streams) before the runtime initialises; a process that has initialised HIP already (e.g.
+     * after the other.  Ask for 16 (main, six side, copy, unpack, result and the six preparation lanes' streams) before the runtime initialises; a process that has initialised HIP already (e.g.
      * after importing torch) must have set the variable itself -- bench.py and the command line do. */
-    setenv("GPU_MAX_HW_QUEUES", "14", 0);
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     const double tc0 = now_s();
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SPX_ENODEVICE, "hipGetDeviceCount found no device");
@@ -389,7 +392,8 @@ extern "C" int spx_create(int device, spx_ctx **out)
     HIPCHK(mk_stream(&c->stream, m_dp));
     for (int r = 0; r < spx_ctx::SPX_EV_RING; ++r)
         for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
-    for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
+    if (const char *e = getenv("SPX_SIDE_STREAMS")) c->n_side = std::max(1, std::min((int)spx_ctx::SPX_N_SIDE, atoi(e)));
+    for (int i = 0; i < c->n_side; ++i) {
         HIPCHK(mk_stream(&c->side_stream[i], m_dp));
         HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming | hipEventBlockingSync));
     }
@@ -1611,12 +1615,12 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         const int cls = order[k];
         if (serial) { HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->stream)); continue; }
         int sidx = 0;
-        for (int t = 1; t < spx_ctx::SPX_N_SIDE; ++t) if (load[t] < load[sidx]) sidx = t;
+        for (int t = 1; t < c->n_side; ++t) if (load[t] < load[sidx]) sidx = t;
         if (!used_side[sidx]) { HIPCHK(hipStreamWaitEvent(c->side_stream[sidx], ev[0], 0)); used_side[sidx] = true; }
         HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->side_stream[sidx]));
         load[sidx] += w->cls_cells[cls] + 1;
     }
-    for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+    for (int t = 0; t < c->n_side; ++t)
         if (used_side[t]) HIPCHK(hipEventRecord(c->side_done[t], c->side_stream[t]));
     if (mc >= 0) {
         HIPCHK(hipEventRecord(ev[3], c->stream));
@@ -1625,7 +1629,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         HIPCHK(spx_launch_baq(mc, 1, &w->cls_batch[mc], c->stream));
         HIPCHK(hipEventRecord(ev[5], c->stream));
     }
-    for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+    for (int t = 0; t < c->n_side; ++t)
         if (used_side[t]) HIPCHK(hipStreamWaitEvent(c->stream, c->side_done[t], 0));
     {
         int64_t narrow = 0, wide = 0;
@@ -1648,12 +1652,12 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
                 if (sl.cls_batch[cls].n_order <= 0) continue;
                 if (serial) { HIPCHK(spx_launch_baq(cls, 2, &sl.cls_batch[cls], c->stream)); continue; }
                 int sidx = 0;
-                for (int t = 1; t < spx_ctx::SPX_N_SIDE; ++t) if (load[t] < load[sidx]) sidx = t;
+                for (int t = 1; t < c->n_side; ++t) if (load[t] < load[sidx]) sidx = t;
                 if (!used_side[sidx]) { HIPCHK(hipStreamWaitEvent(c->side_stream[sidx], sl.ev_start, 0)); used_side[sidx] = true; }
                 HIPCHK(spx_launch_baq(cls, 2, &sl.cls_batch[cls], c->side_stream[sidx]));
                 load[sidx] += w->cls_cells[cls] + 1;
             }
-            for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+            for (int t = 0; t < c->n_side; ++t)
                 if (used_side[t]) HIPCHK(hipEventRecord(c->side_done[t], c->side_stream[t]));
             if (mc >= 0) {
                 HIPCHK(hipEventRecord(sl.ev_f0, c->stream));
@@ -1662,7 +1666,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
                 HIPCHK(spx_launch_baq(mc, 1, &sl.cls_batch[mc], c->stream));
                 HIPCHK(hipEventRecord(sl.ev_b1, c->stream));
             }
-            for (int t = 0; t < spx_ctx::SPX_N_SIDE; ++t)
+            for (int t = 0; t < c->n_side; ++t)
                 if (used_side[t]) HIPCHK(hipStreamWaitEvent(c->stream, c->side_done[t], 0));
             if (sl.r1 > sl.r0) {
                 spx_dev_batch Bm = sl.cls_batch[0];
