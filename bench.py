@@ -276,8 +276,11 @@ def also_leg(platform, steps, warmup):
     ont_gps = os.environ.get("SPX_BENCH_ALSO_ONT_GPS")
     cmd += ["--distinct", "9", "--depth", "8"] if platform == "mixed" else \
         (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "8", "--depth", "4"])
+    env = dict(os.environ)
+    if platform == "mixed":
+        env.setdefault("SPX_PREP_LANES", "6")  # small lists (pools of a few GB per lane): six preparation lanes instead of the library's four
     t0 = time.perf_counter()
-    p = subprocess.run(cmd, capture_output=True, text=True)
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
     dt = time.perf_counter() - t0
     line = None
     for ln in p.stdout.splitlines():
@@ -542,6 +545,11 @@ def main():
             guard_exp = guard_exposure(genome, params, first, min(n_ge, gps), ctx, ncpu)
         except Exception as ex:  # noqa: BLE001  (a side figure must not cost the line its headline)
             guard_exp = {"error": str(ex)}
+        # the context keeps the work-list memory of those two unsliced 4 096-group lists for re-use (~2 x 20 GB on the ONT preset): hand it back,
+        # or the timed pipeline -- five 30 GB lists in flight and the preparation pools of as many lanes -- waits for memory at the allocation
+        # gate (measured: 424 instead of 325 ms per ONT step once the context had six preparation lanes)
+        if not os.environ.get("SPX_BENCH_KEEP_GUARD_BLOCKS"):  # (set: leaves it to the library, which returns waiting blocks when the driver runs short)
+            api._chk(L.spx_trim(ctx.h), "spx_trim")
 
     def ctx_sync():
         api._chk(L.spx_sync(ctx.h), "spx_sync")

@@ -157,10 +157,12 @@ struct spx_ctx {
      * that leave most of the chip idle, and their duration is set by the longest alignment of the batch, not by the number
      * of groups.  So the preparations of several batches run SIDE BY SIDE, each on its own stream with its own pools
      * (a lane's mutex serialises the preparations that share it; work list w uses lane w->lane). */
-    static const int SPX_N_PREP = 12; /* lanes that exist; n_prep of them are used (SPX_PREP_LANES, default 6; 4 until round 5: once the DP kernels of
-                                       * the mixed workload's classes stopped queueing behind one another, four lanes prepared a list every ~70 ms and were the bound) */
-    int n_prep = 6;
+    static const int SPX_N_PREP = 12; /* lanes that exist; n_prep of them are used (SPX_PREP_LANES, default 4).  A lane keeps its pools: ~29 GB for lists of
+                                       * 16 384 ONT groups, so six lanes + five such lists in flight over-commit the device (measured: 424 instead of 325 ms
+                                       * per step); workloads with small lists gain from more lanes (mixed 2-100 kb, 16 384 groups: +3 % with six) */
+    int n_prep = 4;
     struct PrepLane {
+        spx_ctx *owner = nullptr;
         hipStream_t stream = nullptr;
         std::mutex mu;
         DevBuf pool_ops, pool_conf, pool_mm, pool_garena, pool_keys, pool_sort, pool_heavy;
@@ -177,6 +179,7 @@ struct spx_ctx {
 
 /* grow-only device buffer of a preparation lane; the caller holds the lane's mutex.  Kernels of an earlier preparation
  * may still read the old allocation, so the lane's stream is drained before it is released. */
+static void arena_flush(spx_ctx *c);
 static int ensure_pool(spx_ctx::PrepLane &PL, spx_ctx::DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return SPX_OK;
@@ -186,8 +189,17 @@ static int ensure_pool(spx_ctx::PrepLane &PL, spx_ctx::DevBuf &b, size_t bytes)
         b.p = nullptr;
         b.cap = 0;
     }
-    const size_t want = bytes + bytes / 4 + (1u << 20);
-    if (hipMalloc(&b.p, want) != hipSuccess) { (void)hipGetLastError(); return SPX_ENOMEM; }
+    size_t want = bytes + bytes / 4 + (1u << 20);
+    const double tp0 = now_s();
+    const hipError_t pe = hipMalloc(&b.p, want);
+    if (timing_on()) fprintf(stderr, "[spx timing] preparation pool of %.2f GB (lane %d): hipMalloc %.3f s%s\n", want / 1e9, PL.owner ? (int)(&PL - PL.owner->lane) : -1, now_s() - tp0, pe == hipSuccess ? "" : " (failed)");
+    if (pe != hipSuccess) {
+        /* the blocks the context keeps for re-use go back to the driver, then once more without the head room */
+        (void)hipGetLastError();
+        if (PL.owner) arena_flush(PL.owner);
+        want = bytes + (1u << 20);
+        if (hipMalloc(&b.p, want) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return SPX_ENOMEM; }
+    }
     b.cap = want;
     return SPX_OK;
 }
@@ -321,7 +333,7 @@ extern "C" int spx_create(int device, spx_ctx **out)
     if (!out) return fail(SPX_EINVAL, "out is NULL");
     *out = nullptr;
     /* HIP multiplexes streams onto hardware queues (4 by default): two streams that share one run their kernels one
-     * after the other.  Ask for 16 (main, six side, copy, unpack, result and the six preparation lanes' streams) before the runtime initialises; a process that has initialised HIP already (e.g.
+     * after the other.  Ask for 16 (main, six side, copy, unpack, result and up to six preparation lanes' streams) before the runtime initialises; a process that has initialised HIP already (e.g.
      * after importing torch) must have set the variable itself -- bench.py and the command line do. */
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
@@ -380,6 +392,7 @@ extern "C" int spx_create(int device, spx_ctx **out)
     if (const char *e = getenv("SPX_PREP_LANES")) c->n_prep = std::max(1, std::min(atoi(e), (int)spx_ctx::SPX_N_PREP));
     for (int l = 0; l < c->n_prep; ++l) {
         spx_ctx::PrepLane &PL = c->lane[l];
+        PL.owner = c;
         HIPCHK(mk_stream(&PL.stream, m_prep));
         HIPCHK(hipMalloc((void **)&PL.d_tot, sizeof(spx_prep_totals)));
         HIPCHK(hipHostMalloc((void **)&PL.h_tot, sizeof(spx_prep_totals), hipHostMallocDefault));
@@ -739,6 +752,17 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
 
 /* ------------------------------------------------------------------ */
 /* device allocations of finished work lists are kept for the next one (hipMalloc of several GB costs ~0.2 s) */
+/* every block waiting for re-use goes back to the driver */
+static void arena_flush(spx_ctx *c)
+{
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lk(c->arena_mu);
+        for (auto &a : c->arena_cache) drop.push_back(a.first);
+        c->arena_cache.clear();
+    }
+    for (void *d : drop) (void)hipFree(d);
+}
 static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
 {
     /* When HBM is full -- several large work lists in flight: 16 384 ONT groups need ~70 GB of saved rows -- the caller
@@ -777,7 +801,13 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
                 size_t held = 0;
                 for (auto &a : c->arena_cache) held += a.second;
                 const size_t budget = c->hbm_bytes - c->hbm_bytes / 8;
-                while (!c->arena_cache.empty() && c->arena_in_use + held + *cap > budget) {
+                /* ... and what the driver reports as free covers the request with 1/32 of the device to spare: the preparation pools of the
+                 * lanes, the staged records and other processes' memory are not in arena_in_use (round 5: with six lanes the blocks of two
+                 * earlier 4 096-group ONT lists waited for re-use while the pipeline's lists failed their hipMalloc -- 424 instead of 325 ms per step) */
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = ~(size_t)0 >> 1; }
+                while (!c->arena_cache.empty() && (c->arena_in_use + held + *cap > budget || free_b < *cap + c->hbm_bytes / 32)) {
+                    free_b += c->arena_cache.front().second;
                     held -= c->arena_cache.front().second;
                     drop.push_back(c->arena_cache.front().first);
                     c->arena_cache.erase(c->arena_cache.begin());
