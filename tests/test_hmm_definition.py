@@ -35,8 +35,9 @@ def _f32(x):
     return Fraction(float(np.float32(x)))
 
 
-def model_posteriors(ref, qry, set_q, d, e, bw_in):
-    """exact posteriors zM[i][k], zI[i][k] (1-based, 0 outside the band) and the likelihood P, as Fractions"""
+def model_posteriors(ref, qry, set_q, d, e, bw_in, last_column_may_end=True):
+    """exact posteriors zM[i][k], zI[i][k] (1-based, 0 outside the band) and the likelihood P, as Fractions.
+    last_column_may_end=False: the variant of the model in which an alignment may not END in reference column R."""
     L, R = len(qry), len(ref)
     bw = max(R, L)
     bw = min(bw, bw_in)
@@ -78,12 +79,13 @@ def model_posteriors(ref, qry, set_q, d, e, bw_in):
             fM[i][k] = emit(i, k) * (mMM * fM[i - 1][k - 1] + mIM * fI[i - 1][k - 1] + mDM * fD[i - 1][k - 1])
             fI[i][k] = EI * (mMI * fM[i - 1][k] + mII * fI[i - 1][k])
             fD[i][k] = mMD * fM[i][k - 1] + mDD * fD[i][k - 1]
-    P = sum(fM[L][k] * sM + fI[L][k] * sI for k in range(1, R + 1))
+    may_end = lambda k: inband(L, k) and (last_column_may_end or k != R)
+    P = sum((fM[L][k] * sM + fI[L][k] * sI for k in range(1, R + 1) if may_end(k)), Z)
     bM = [[Z] * (R + 3) for _ in range(L + 3)]
     bI = [[Z] * (R + 3) for _ in range(L + 3)]
     bD = [[Z] * (R + 3) for _ in range(L + 3)]
     for k in range(1, R + 1):
-        if inband(L, k):
+        if may_end(k):
             bM[L][k], bI[L][k] = sM, sI
     for i in range(L - 1, 0, -1):
         for k in range(R, 0, -1):
@@ -160,3 +162,44 @@ def test_oracle_posteriors_equal_the_model_definition(built):
         exp_pr = -4.343 * math.log(float(P) * R * L)
         assert abs(pr - (exp_pr + .499)) <= 1.0 + 1e-9  # (int) truncation of exp_pr + .499
     assert checked_state > 2000 and checked_q > 2000
+
+
+def test_the_two_readings_of_the_terminal_guard_as_models(built):
+    """The open line of probaln.c (include/spx.h SPX_GUARD_*), read as a MODEL: in the regime l_query <= bw and
+    2*bw+1 > l_ref the BAND reading (the default) is the model above; the ROW reading is exactly the model in which an alignment may
+    not end in the last reference column -- and where that ending is likely the two differ by far more than rounding.  Outside the
+    regime both readings are the model above.  (Evidence for the default, not a pin: only a real htslib 1.17 decides.)"""
+    rng = np.random.default_rng(3)
+    seen = visible = 0
+
+    def worst(zM, zI, s, oM, oI, L, R):
+        return max(max(abs(float(zM[i][k]) - oM[i - 1, k - 1] * s[i]), abs(float(zI[i][k]) - oI[i - 1, k - 1] * s[i]))
+                   for i in range(1, L + 1) for k in range(1, R + 1))
+    try:
+        for (L, R, bw_in) in ((9, 30, 25), (15, 15, 40), (1, 6, 10), (10, 14, 12), (8, 9, 30), (5, 16, 11), (7, 7, 7), (20, 24, 5), (12, 12, 3)):
+            ref = rng.integers(0, 4, R).astype(np.uint8)
+            qry = np.resize(ref, L).copy()
+            if L <= R and (L + R) % 2 == 0:
+                qry = ref[R - L:].copy()  # the query is the END of the window: its alignment ends in the last reference column
+            mut = rng.random(L) < 0.1
+            qry[mut] = (qry[mut] + 1) % 4
+            fullM, fullI, _, bw = model_posteriors(ref, qry, 20, 1e-3, 0.1, bw_in)
+            cutM, cutI, _, _ = model_posteriors(ref, qry, 20, 1e-3, 0.1, bw_in, last_column_may_end=False)
+            reg = L <= bw and 2 * bw + 1 > R
+            seen += reg
+            orc.set_terminal_guard(orc.GUARD_BAND)
+            s, oM, oI = orc.probaln_posteriors(ref, qry, 20, 1e-3, 0.1, bw_in)
+            assert worst(fullM, fullI, s, oM, oI, L, R) < 1e-11, (L, R, bw_in)
+            orc.set_terminal_guard(orc.GUARD_ROW)
+            s, rM, rI = orc.probaln_posteriors(ref, qry, 20, 1e-3, 0.1, bw_in)
+            if reg:
+                assert worst(cutM, cutI, s, rM, rI, L, R) < 1e-11, (L, R, bw_in)
+                end_mass = float(fullM[L][R] + fullI[L][R])  # posterior of "the last query base sits in the last reference column"
+                if end_mass > 1e-3:
+                    visible += 1
+                    assert worst(fullM, fullI, s, rM, rI, L, R) > 1e-4, (L, R, bw_in, end_mass)
+            else:
+                assert worst(fullM, fullI, s, rM, rI, L, R) < 1e-11, (L, R, bw_in)
+    finally:
+        orc.set_terminal_guard(orc.GUARD_BAND)
+    assert seen >= 5 and visible >= 2
