@@ -107,7 +107,7 @@ struct Params {
     double conf_b;
     float d, e;
     float qf; /* (float)pow(10, -set_q/10.), host libm */
-    float pad2;
+    int32_t table_min_cols, table_rounds; /* flank_break_rounds(): groups with at least so many columns, the first so many rounds (<= kTableRounds) */
 };
 
 /* ---------------- band classes = DP kernel instantiations (keep in step with spx_launch_baq) ---------------- */
@@ -841,6 +841,76 @@ SPX_HD int flank_blocks(const AlnState &st, const int32_t *pos, int ncol, int n,
     return cnt;
 }
 
+/* The windows of the consensus rounds WITHOUT clamping (blocks_rounds' shared case: margin > 0, every position inside every alignment's
+ * extent) depend on the positions through their gaps only: with cs = p - margin, ce = p + margin and cs < ce the walk above opens a new
+ * window at column c iff pos[c] - pos[c-1] >= 2 * margin, and a window is {first position - margin, last position + margin}.  The margins of
+ * the rounds are a fixed sequence (margin <- (int)(margin * 0.8), from the flank margin), so every column has ONE round from which on it
+ * starts a window: break_round[c] = the first round r with 2 * margin_r <= gap(c) = the number of rounds whose doubled margin exceeds the
+ * gap, kept in one byte per column (the `keep` flags of the column filter are dead by then).  A round then finds its windows by scanning
+ * the bytes eight at a time instead of walking the positions: a 100 kb read's group has ~45 000 columns and ~12 rounds, and this walk was
+ * the bulk of the group pass (3.3 M of its 3.6 M loop steps per 1 024 mixed groups).  The table covers the first kTableRounds rounds (the
+ * doubled margins sit in registers: one pass of compares, no look-ups); later rounds and groups of few columns take the walk. */
+constexpr int kNoBreak = 127;     /* break_round of column 0 (it starts the first window by itself) */
+constexpr int kTableRounds = 16;      /* at most (Params.table_rounds; SPX_WINDOW_TABLE=min_cols,rounds on the host, for CPU tests) */
+constexpr int kTableMinCols = 1024;   /* default of Params.table_min_cols */
+SPX_HD void flank_break_rounds(const int32_t *pos, int ncol, int flank_margin, int rounds, uint8_t *br)
+{
+    uint32_t thr[kTableRounds]; /* 2 * margin of round r (0 once the margin is used up: such rounds do not take this path) */
+    {
+        int m = flank_margin;
+#pragma unroll
+        for (int r = 0; r < kTableRounds; ++r) {
+            m = (int)(m * 0.8);
+            thr[r] = (m > 0 && r < rounds) ? 2u * (uint32_t)m : 0u;
+        }
+    }
+    if (ncol > 0) br[0] = (uint8_t)kNoBreak;
+    int prev = ncol > 0 ? pos[0] : 0;
+    for (int c = 1; c < ncol; ++c) {
+        const int p = pos[c];
+        const int gap = p - prev;
+        prev = p;
+        const uint32_t g = gap < 0 ? 0u : (uint32_t)gap;
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < kTableRounds; ++r) cnt += thr[r] > g ? 1 : 0; /* thr is non-increasing: the count is the first r with thr[r] <= g */
+        br[c] = (uint8_t)cnt; /* = the number of table rounds: no window starts here in a round of the table */
+    }
+}
+/* the windows of round `round` (margin = its margin, > 0): same list, same overflow behaviour as flank_blocks() over unclamped extents */
+SPX_HD int flank_blocks_by_round(const int32_t *pos, const uint8_t *br, int ncol, int round, int margin, Iv *out, int cap)
+{
+    int cnt = 0, first = 0;
+    auto open_at = [&](int c) -> bool { /* the window [first, c) ends; the next one starts at column c */
+        if (cnt >= cap) return false;
+        Iv b = {pos[first] - margin, pos[c - 1] + margin};
+        out[cnt++] = b;
+        first = c;
+        return true;
+    };
+    int c = 1;
+    for (; c < ncol && (((uintptr_t)(br + c)) & 7u); ++c)
+        if (br[c] <= round && !open_at(c)) return -1;
+    const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
+    for (; c + 8 <= ncol; c += 8) {
+        uint64_t w;
+        __builtin_memcpy(&w, __builtin_assume_aligned(br + c, 8), 8);
+        /* every byte is <= 127: (b | 0x80) - (round + 1) borrows from no neighbour and keeps its top bit iff b > round */
+        uint64_t hit = ~((w | high) - (uint64_t)(round + 1) * ones) & high;
+        while (hit) {
+            const int k = __builtin_ctzll(hit) >> 3;
+            if (!open_at(c + k)) return -1;
+            hit &= hit - 1;
+        }
+    }
+    for (; c < ncol; ++c)
+        if (br[c] <= round && !open_at(c)) return -1;
+    if (cnt >= cap) return -1;
+    Iv b = {pos[first] - margin, pos[ncol - 1] + margin};
+    out[cnt++] = b;
+    return cnt;
+}
+
 /* ascending by start; the lists are ascending already except in degenerate cases */
 SPX_HD void sort_intervals(Iv *b, int n)
 {
@@ -976,6 +1046,7 @@ SPX_HD void blocks_rounds(const GroupView &G, const Pools &P, const Params &par,
     while (par.consensus && B.too_long) {
         B.margin = (int)(B.margin * 0.8);
         const int margin = B.margin;
+        const int round = B.pad[0]++; /* margin = the margin of round `round` of flank_break_rounds() */
         /* intersect every alignment's blocks, then every alignment's flanking windows, in read coordinates.  Once a
          * list has been intersected with one copy of another list, every interval lies inside ONE interval of that
          * list; intersecting it with the same list again changes nothing as long as no interval is empty (strict '<'
@@ -1016,9 +1087,15 @@ SPX_HD void blocks_rounds(const GroupView &G, const Pools &P, const Params &par,
             shared = G.st[i].rde > G.st[i].rds && S.pos[0] >= G.st[i].rds && S.pos[ncol - 1] <= G.st[i].rde;
         int nu = 0;
         if (shared) {
-            AlnState wide = G.st[0];
-            wide.rds = -0x3fffffff; wide.rde = 0x3fffffff;
-            nu = flank_blocks(wide, S.pos, ncol, n, margin, fl, cap);
+            const int table_rounds = par.table_rounds < kTableRounds ? par.table_rounds : kTableRounds;
+            if (round < table_rounds && ncol >= par.table_min_cols) {
+                if (!B.pad[1]) { flank_break_rounds(S.pos, ncol, par.flank_margin, table_rounds, S.keep); B.pad[1] = 1; } /* once per group, at its first shared round */
+                nu = flank_blocks_by_round(S.pos, S.keep, ncol, round, margin, fl, cap);
+            } else {
+                AlnState wide = G.st[0];
+                wide.rds = -0x3fffffff; wide.rde = 0x3fffffff;
+                nu = flank_blocks(wide, S.pos, ncol, n, margin, fl, cap);
+            }
             if (nu < 0) return fail(SPX_ENOMEM);
         }
         positive = false;

@@ -122,6 +122,15 @@ spxl::Params logic_params(const spx_params *par)
     p.e = (float)par->conf_e;
     p.qf = (float)pow(10, -par->set_q / 10.);
     p.term_guard = terminal_guard();
+    /* windows of the consensus rounds from the break-round table (spx_logic.h flank_break_rounds): groups of >= 1024 columns, 16 rounds;
+     * SPX_WINDOW_TABLE=min_cols,rounds for the CPU tests (a short table hands over to the walk in mid-group; rounds 0 = the walk only) */
+    static const std::pair<int, int> table = [] {
+        int mc = spxl::kTableMinCols, r = spxl::kTableRounds;
+        if (const char *e = getenv("SPX_WINDOW_TABLE")) { if (sscanf(e, "%d,%d", &mc, &r) < 2) r = spxl::kTableRounds; }
+        return std::make_pair(mc < 2 ? 2 : mc, r < 0 ? 0 : (r > spxl::kTableRounds ? spxl::kTableRounds : r));
+    }();
+    p.table_min_cols = table.first;
+    p.table_rounds = table.second;
     return p;
 }
 

@@ -283,3 +283,25 @@ def test_plan_does_not_depend_on_how_the_walks_are_shared(built):
         assert p.returncode == 0, p.stderr[-800:]
         digests[parts] = p.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_plan_does_not_depend_on_how_the_round_windows_are_found(built):
+    """Round 5: the flanking windows of a consensus round come from a one-byte-per-column table of break rounds scanned eight columns at a
+    time (spx_logic.h flank_break_rounds / flank_blocks_by_round) for groups of >= 1024 columns and the first 16 rounds, from the walk over
+    the positions otherwise.  SPX_WINDOW_TABLE=min_cols,rounds (host plan only) moves both limits: the table for EVERY group, a table of 3
+    rounds or of 1 that hands over to the walk in mid-group, no table at all -- every array of the work list must come out the same (and
+    test_plan_* above check the default against the oracle)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for table in ("", "2,16", "2,3", "2,1", "2,0", "300,5"):
+        env = dict(os.environ)
+        env.pop("SPX_WINDOW_TABLE", None)
+        if table:
+            env["SPX_WINDOW_TABLE"] = table
+        p = subprocess.run([sys.executable, "-c", _SHARE_SCRIPT, root], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-800:]
+        digests[table] = p.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests
