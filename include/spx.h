@@ -93,6 +93,10 @@ typedef struct spx_stats {
     int32_t dp_slices;           /* DP slices of the list (spx_work_device_bytes): main_fwd_ms / main_bwd_ms are the SUM over the slices'
                                   * kernels of one launch of the list, i.e. dp_slices launches of the kernel each */
     int32_t reserved_;
+    /* two-tier DP (round 6): problems of band classes that have a fast tier, and how many of them the exact kernels re-ran because a
+     * wanted row was not certified / the problem is outside the fast tier's model (ambiguous base, degenerate constants) / a row's values
+     * spanned too many binades; rows not certified.  Per launch, averaged like the *_ms fields.  All 0 when the tiers are off. */
+    int64_t tier_fast_problems, tier_rerun_certificate, tier_rerun_model, tier_rerun_range, tier_rows_uncertified;
 } spx_stats;
 
 const char *spx_strerror(int code);
@@ -272,6 +276,16 @@ int spx_probaln_posteriors(spx_ctx *ctx, int32_t n, const uint8_t *ref, const in
 #define SPX_GUARD_ROW 1
 int spx_set_terminal_guard(int reading);
 int spx_get_terminal_guard(void);
+
+/* Two-tier DP (round 6): a fast evaluation of the same HMM (fused multiply-adds, no row sums) whose (state, q) are
+ * CERTIFIED equal to the exact tier's per wanted row; problems with a row that is not certified are re-run by the exact (bit-exact)
+ * kernels on the device.  Process-wide, read when a work list is prepared; SPX_DP_TIERS=0|1 sets the initial value (default 1).  The
+ * diagnostics entry points (spx_probaln_posteriors, spx_probaln_glocal's likelihood) always take the exact kernels. */
+int spx_set_dp_tiers(int on); /* 0 off, 1 on, 2 test mode: the fast tier runs but certifies nothing, so that every problem is re-run */
+int spx_get_dp_tiers(void);
+/* diagnostics of the latest spx_collect / spx_probaln_batch of the process: problems of band classes with a fast tier; of those,
+ * re-run because a row was not certified / outside the model / dynamic range; rows not certified */
+int spx_last_tier_stats(int64_t *out5);
 
 /* ---- BED side outputs (src/secphase.c:59-72,201-212,713-732; ptBlock.c:228-428,573-602) ------------ */
 typedef struct spx_bedset spx_bedset;

@@ -58,6 +58,8 @@ class Stats(C.Structure):
         ("main_fwd_ms", C.c_double), ("main_bwd_ms", C.c_double), ("main_class_cells", C.c_int64),
         ("main_class", C.c_int32), ("main_class_lanes", C.c_int32), ("main_class_slots", C.c_int32),
         ("n_launches_averaged", C.c_int32), ("dp_slices", C.c_int32), ("reserved_", C.c_int32),
+        ("tier_fast_problems", C.c_int64), ("tier_rerun_certificate", C.c_int64), ("tier_rerun_model", C.c_int64),
+        ("tier_rerun_range", C.c_int64), ("tier_rows_uncertified", C.c_int64),
     ]
 
 
@@ -105,7 +107,7 @@ EXPORTS = [
     "spx_stage", "spx_prepare_staged", "spx_work_export", "spx_work_release",
     "spx_pipe_create", "spx_pipe_submit", "spx_pipe_next", "spx_pipe_pending", "spx_pipe_destroy",
     "spx_work_device_bytes", "spx_dbam_default_options", "spx_dbam_open", "spx_dbam_header", "spx_dbam_start", "spx_dbam_next", "spx_dbam_release", "spx_dbam_stats", "spx_dbam_close",
-    "spx_set_terminal_guard", "spx_get_terminal_guard",
+    "spx_set_terminal_guard", "spx_get_terminal_guard", "spx_set_dp_tiers", "spx_get_dp_tiers", "spx_last_tier_stats",
     "spx_relabel_table_load", "spx_relabel_table_size", "spx_relabel_table_get", "spx_relabel_table_find", "spx_relabel_table_free",
     "spx_correct_default_options", "spx_correct_bam",
     "spx_sam_write_group_of", "spx_decisions_from_results", "spx_relabel_candidates", "spx_finalizer_apply_decisions", "spx_write_relabel_records",
@@ -250,6 +252,22 @@ def set_terminal_guard(reading):
     """reading of probaln.c's terminal guard (include/spx.h: SPX_GUARD_BAND default, SPX_GUARD_ROW); process-wide, read
     when a work list is prepared"""
     _chk(lib().spx_set_terminal_guard(int(reading)), "spx_set_terminal_guard")
+
+
+def set_dp_tiers(on):
+    """two-tier DP (certified fast kernels + exact re-run of uncertified problems) on / off for lists prepared from now on"""
+    _chk(lib().spx_set_dp_tiers(int(on)), "spx_set_dp_tiers")
+
+
+def last_tier_stats():
+    """(fast-class problems, re-run by certificate, by model, by range, rows not certified) of the latest collect / probaln_batch"""
+    v = (C.c_int64 * 5)()
+    _chk(lib().spx_last_tier_stats(v), "spx_last_tier_stats")
+    return tuple(int(x) for x in v)
+
+
+def get_dp_tiers():
+    return lib().spx_get_dp_tiers()
 
 
 def get_terminal_guard():

@@ -80,8 +80,29 @@ typedef struct spx_dev_batch {
      * forward / backward kernels of a slice get that slice's launch orders, and sinv / fsave point at scratch that is
      * shared by all slices, shifted by the slice's first offset (s_off / fsave_off stay absolute) */
     int32_t row_base;
-    int32_t pad_;
+    /* Two-tier DP (round 6).  tier[p]: SPX_TIER_EXACT = exact tier only (band class without a fast kernel; the
+     * value the list's 0xff fill leaves), SPX_TIER_FAST = computed by the fast tier (written by the fast forward kernel at every launch),
+     * SPX_TIER_RERUN = not certified / outside the fast tier's model: the exact kernels re-run the problem.  NULL: no tiers (every problem
+     * takes the exact kernels).  The exact kernels and MAP kernel process a problem only if tier[p] == tier_want (SPX_TIER_ALL: every
+     * problem). */
+    int32_t tier_want;
+    int32_t *tier;
+    int32_t *tier_counts; /* diagnostics, each starting at -1 (the same fill): [0] problems flagged by the certificate, [1] by the model
+                           * conditions at entry, [2] by the dynamic-range check, [3] rows not certified */
 } spx_dev_batch;
+#define SPX_TIER_ALL (-2)
+#define SPX_TIER_EXACT (-1)
+#define SPX_TIER_FAST 1
+#define SPX_TIER_RERUN 2
+
+/* constants of the fast tier that are the same for every problem of a launch: powers of m8 = D->D (the gap-extension probability) */
+#define SPX_FAST_MAXC 32
+typedef struct spx_fast_consts {
+    double pw[SPX_FAST_MAXC + 1]; /* pw[c] = m8^c */
+    double m8;
+    int32_t range_bits; /* a row spanning more than 2^range_bits flags its problem */
+    int32_t mu_bits;    /* problems whose smallest per-row factor is below 2^-mu_bits are outside the model */
+} spx_fast_consts;
 
 /* marker table for the scoring kernel: one entry per (position, alignment) */
 typedef struct spx_dev_marker {

@@ -36,6 +36,9 @@ struct spx_bedset;
 extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B, hipStream_t st);
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st);
+extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B, const spx_fast_consts *K, hipStream_t st);
+extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st);
+extern "C" int spx_fast_class(int cls);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
                                       spx_decision *out, hipStream_t st);
 extern "C" hipError_t spx_launch_results(const spx_dev_groups *Gd, const spx_group_info *info, const int32_t *rfe,
@@ -273,6 +276,11 @@ struct spx_work {
     int32_t *d_grp_index = nullptr;
     uint8_t *d_bq = nullptr, *d_q = nullptr, *d_posmin = nullptr;
     int32_t *d_state = nullptr;
+    /* two-tier DP: per problem tier + 4 counters (device), the launch-uniform constants, whether this list uses the tiers */
+    int32_t *d_tier = nullptr, *d_tier_counts = nullptr;
+    spx_fast_consts fk;
+    bool fast = false, any_fast_cls = false, any_exact_cls = false;
+    int64_t n_launches_counted = 0; /* launches since the counters were last reset by a preparation */
     spx_stats st;
     spx_params par;
     bool launched = false;
@@ -566,7 +574,46 @@ struct Carver {
 };
 
 static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap);
-static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
+
+/* ---- two-tier DP switch and constants ---- */
+static std::atomic<int> g_dp_tiers{-1};
+extern "C" int spx_get_dp_tiers(void)
+{
+    int v = g_dp_tiers.load();
+    if (v < 0) {
+        const char *e = getenv("SPX_DP_TIERS");
+        v = (e && (!strcmp(e, "0") || !strcmp(e, "off") || !strcmp(e, "exact"))) ? 0 : 1;
+        g_dp_tiers.store(v);
+    }
+    return v;
+}
+extern "C" int spx_set_dp_tiers(int on)
+{
+    g_dp_tiers.store(on < 0 ? 0 : (on > 2 ? 1 : on)); /* 2 = test mode: the fast tier runs but certifies nothing (every problem is re-run) */
+    return SPX_OK;
+}
+static std::atomic<int64_t> g_last_tier[5];
+extern "C" int spx_last_tier_stats(int64_t *out /* 5: fast problems, re-run by certificate / model / range, rows not certified */)
+{
+    if (!out) return fail(SPX_EINVAL, "NULL argument");
+    for (int k = 0; k < 5; ++k) out[k] = g_last_tier[k].load();
+    return SPX_OK;
+}
+/* constants every problem of a launch shares: powers of m8 = (double)(float)conf_e (hmm_constants), the range / model limits.
+ * range_bits + 16 rows x mu_bits + 100 (constant factors between the carried rows and the exact tier's M, I, D) must stay
+ * below 1022: a row of the exact tier, normalised to sum 1, then keeps every value in the normal FP64 range between two checks. */
+static void fast_constants(double m8, spx_fast_consts *K)
+{
+    memset(K, 0, sizeof *K);
+    K->m8 = m8;
+    K->pw[0] = 1.0;
+    for (int c = 1; c <= SPX_FAST_MAXC; ++c) K->pw[c] = K->pw[c - 1] * m8;
+    static const int rb = [] { const char *e = getenv("SPX_FAST_RANGE_BITS"); const int v = e ? atoi(e) : 600; return v < 64 ? 64 : (v > 700 ? 700 : v); }();
+    K->range_bits = spx_get_dp_tiers() == 2 ? -1 : rb; /* (test mode: every range check fails) */
+    K->mu_bits = (1000 - 100 - rb) / 16;
+}
+
+static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool allow_fast = true)
 {
     spx::HostBatch &hb = w->hb;
     const size_t np = hb.L.size(), nr = hb.rows.size(), ng = hb.grp_index.size(), nm = hb.markers.size();
@@ -661,10 +708,19 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
            o_score = cv.take<double>(ng * 10),
            o_prim = cv.take<uint8_t>(ng), o_max = cv.take<uint8_t>(ng), o_pass = cv.take<uint8_t>(ng),
            o_tie = cv.take<uint16_t>(ng);
+    const size_t o_tier = cv.take<int32_t>(np + 8);
     w->arena_bytes = cv.off + 256;
     w->arena = arena_get(c, w->arena_bytes, &w->arena_cap);
     if (!w->arena) return fail(SPX_ENOMEM, "device memory for the work list");
     char *base = (char *)w->arena;
+    w->fast = allow_fast && spx_get_dp_tiers() != 0 && np > 0;
+    w->d_tier = (int32_t *)(base + o_tier);
+    w->d_tier_counts = w->d_tier + np;
+    w->n_launches_counted = 0;
+    if (w->fast) {
+        fast_constants(hb.hmm[SPX_H_M8], &w->fk);
+        HIPCHK(hipMemsetAsync(w->d_tier, 0xff, (np + 8) * sizeof(int32_t), c->stream));
+    }
     double t0 = now_s();
     if (timing_on()) fprintf(stderr, "[spx timing] device batch: launch orders %.3f s, offsets+arena %.3f s (%.2f GB)\n", tb1 - tb0, t0 - tb1, w->arena_bytes / 1e9);
 #define UP(off, vec)                                                                                         \
@@ -727,7 +783,13 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q)
         B.out_state = w->d_state;
         B.out_q = w->d_q;
         B.qthr = c->d_tables;
+        B.tier = w->fast ? w->d_tier : nullptr;
+        B.tier_counts = w->fast ? w->d_tier_counts : nullptr;
+        B.tier_want = SPX_TIER_ALL;
     }
+    w->any_fast_cls = w->any_exact_cls = false;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
+        if (w->cls_used[cls]) (w->fast && spx_fast_class(cls) ? w->any_fast_cls : w->any_exact_cls) = true;
     spx_dev_groups &G = w->dg;
     memset(&G, 0, sizeof G);
     G.n_groups = (int32_t)ng;
@@ -1401,6 +1463,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
                  o_prob_slots = cv.take<int32_t>(np), o_hasn = cv.take<uint8_t>(np + 16), o_rows = cv.take<int32_t>(nr), o_expect = cv.take<int32_t>(nr),
                  o_rawq = cv.take<uint8_t>(nr + 16), o_row_prob = cv.take<int32_t>(nr), o_rr = cv.take<spxl::RowRec>(nr + 1), o_qe = cv.take<int32_t>(5 * nq + 4),
                  o_order_f = cv.take<int32_t>(order_f_n + 64), o_order_b = cv.take<int32_t>(order_b_n + 64),
+                 o_tier = cv.take<int32_t>(np + 8), /* (behind the launch orders: ONE 0xff fill covers orders, tiers and tier counters) */
                  o_mk_first = cv.take<int32_t>(ng + 2), o_markers = cv.take<spx_dev_marker>(nm + 1), o_mkref = cv.take<int32_t>(nm + 1),
                  o_naln = cv.take<uint8_t>(ng + 16), o_sec = cv.take<uint16_t>(ng + 8), o_rfe = cv.take<int32_t>(ng * 10 + 10),
                  o_rfs = cv.take<int32_t>(ng * 10 + 10), o_atid = cv.take<int32_t>(ng * 10 + 10), o_info = cv.take<spx_group_info>(ng + 1);
@@ -1445,7 +1508,19 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     HIPCHK(spx_prep_emit(&A, &E, PL.stream)); /* (group_finish_kernel writes every entry of mk_first) */
     /* launch orders: ONE fill for both order arrays (consecutive in the arena), one for the bins of both passes, one pair of sorts for all
      * DP slices (round 4: two fills + a pair of sorts + a fill per slice) */
-    HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (o_order_b - o_order_f) + (order_b_n + 64) * 4, PL.stream));
+    HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (o_tier - o_order_f) + (np + 8) * 4, PL.stream));
+    w->fast = spx_get_dp_tiers() != 0 && np > 0;
+    w->d_tier = (int32_t *)(B0 + o_tier);
+    w->d_tier_counts = w->d_tier + np;
+    w->n_launches_counted = 0;
+    if (w->fast) {
+        double hc[SPX_H_N];
+        spx::hmm_constants(100, 100, (float)w->par.conf_d, (float)w->par.conf_e, w->par.set_q, hc);
+        fast_constants(hc[SPX_H_M8], &w->fk);
+    }
+    w->any_fast_cls = w->any_exact_cls = false;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
+        if (w->cls_used[cls]) (w->fast && spx_fast_class(cls) ? w->any_fast_cls : w->any_exact_cls) = true;
     if (np) {
         const size_t nbins = (size_t)K * SPX_N_CLASSES * 1024;
         if ((rc = ensure_pool(PL, PL.pool_bins, nbins * 6 * sizeof(int32_t) + 256))) return fail(rc, "device memory for the launch-order bins");
@@ -1516,6 +1591,9 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         B.fsave_off = E.out.fsave_off;
         B.out_bq = w->d_bq; B.out_state = nullptr; B.out_q = nullptr;
         B.qthr = c->d_tables;
+        B.tier = w->fast ? w->d_tier : nullptr;
+        B.tier_counts = w->fast ? w->d_tier_counts : nullptr;
+        B.tier_want = SPX_TIER_ALL;
         if (K > 1 && k == 0) w->cls_batch[cls] = B; /* (what spx_work_export / the mirrors read: the per-problem arrays) */
     }
     for (int k = 0; k < K && K > 1; ++k) {
@@ -1629,10 +1707,40 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         HIPCHK(hipEventRecord(ev[7], tail));
         return SPX_OK;
     };
-    auto last_map = [&](const spx_dev_batch *Bm, int32_t nrows, bool wide_first) -> int {
-        { const int rc = open_tail(); if (rc) return rc; }
-        HIPCHK(spx_launch_map(Bm, nrows, wide_first, tail));
+    /* Two-tier DP: a class with a fast tier runs the fast kernels (which sort their problems into tiers), any other class the exact ones.
+     * What follows the last backward kernel of a slice -- finish_rows: (1) fast MAP + certificate over the rows of fast-tier problems,
+     * (2) exact MAP over the rows of the other classes, (3) the exact forward / backward kernels once more, restricted to the problems
+     * that were not certified (SPX_TIER_RERUN; a launch of the class' whole order in which every other wave leaves at once), (4) exact
+     * MAP over their rows. */
+    const bool fast = w->fast;
+    auto launch_cls = [&](int cls, int phase, const spx_dev_batch *Bc, hipStream_t st) -> hipError_t {
+        if (fast && spx_fast_class(cls)) return spx_launch_fast(cls, phase, Bc, &w->fk, st);
+        return spx_launch_baq(cls, phase, Bc, st);
+    };
+    auto finish_rows = [&](const spx_dev_batch *cb /* [SPX_N_CLASSES] of the slice */, int64_t r0, int64_t r1, bool wide_first, hipStream_t st) -> int {
+        const int32_t nrows = (int32_t)(r1 - r0);
+        spx_dev_batch Bm = cb[0];
+        Bm.row_base = (int32_t)r0;
+        if (!fast) {
+            if (nrows > 0) HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st));
+            return SPX_OK;
+        }
+        if (nrows > 0 && w->any_fast_cls) HIPCHK(spx_launch_fast_map(&Bm, nrows, st));
+        if (nrows > 0 && w->any_exact_cls) { Bm.tier_want = SPX_TIER_EXACT; HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); }
+        if (w->any_fast_cls) {
+            for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+                if (!w->cls_used[cls] || !spx_fast_class(cls) || cb[cls].n_order <= 0) continue;
+                spx_dev_batch Br = cb[cls];
+                Br.tier_want = SPX_TIER_RERUN;
+                HIPCHK(spx_launch_baq(cls, 2, &Br, st));
+            }
+            if (nrows > 0) { Bm.tier_want = SPX_TIER_RERUN; HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); }
+        }
         return SPX_OK;
+    };
+    auto last_map = [&](const spx_dev_batch *cb, int64_t r0, int64_t r1, bool wide_first) -> int {
+        { const int rc = open_tail(); if (rc) return rc; }
+        return finish_rows(cb, r0, r1, wide_first, tail);
     };
     int order[SPX_N_CLASSES], no = 0;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
@@ -1643,20 +1751,20 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     bool used_side[spx_ctx::SPX_N_SIDE] = {};
     for (int k = 0; k < no; ++k) {
         const int cls = order[k];
-        if (serial) { HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->stream)); continue; }
+        if (serial) { HIPCHK(launch_cls(cls, 2, &w->cls_batch[cls], c->stream)); continue; }
         int sidx = 0;
         for (int t = 1; t < c->n_side; ++t) if (load[t] < load[sidx]) sidx = t;
         if (!used_side[sidx]) { HIPCHK(hipStreamWaitEvent(c->side_stream[sidx], ev[0], 0)); used_side[sidx] = true; }
-        HIPCHK(spx_launch_baq(cls, 2, &w->cls_batch[cls], c->side_stream[sidx]));
+        HIPCHK(launch_cls(cls, 2, &w->cls_batch[cls], c->side_stream[sidx]));
         load[sidx] += w->cls_cells[cls] + 1;
     }
     for (int t = 0; t < c->n_side; ++t)
         if (used_side[t]) HIPCHK(hipEventRecord(c->side_done[t], c->side_stream[t]));
     if (mc >= 0) {
         HIPCHK(hipEventRecord(ev[3], c->stream));
-        HIPCHK(spx_launch_baq(mc, 0, &w->cls_batch[mc], c->stream));
+        HIPCHK(launch_cls(mc, 0, &w->cls_batch[mc], c->stream));
         HIPCHK(hipEventRecord(ev[4], c->stream));
-        HIPCHK(spx_launch_baq(mc, 1, &w->cls_batch[mc], c->stream));
+        HIPCHK(launch_cls(mc, 1, &w->cls_batch[mc], c->stream));
         HIPCHK(hipEventRecord(ev[5], c->stream));
     }
     for (int t = 0; t < c->n_side; ++t)
@@ -1665,7 +1773,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         int64_t narrow = 0, wide = 0;
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
         const int64_t nrows = w->staged ? w->n_rows_dev : (int64_t)w->hb.rows.size();
-        { const int rc = last_map(&w->cls_batch[0], (int32_t)nrows, wide > narrow); if (rc) return rc; }
+        { const int rc = last_map(w->cls_batch, 0, nrows, wide > narrow); if (rc) return rc; }
     }
     } else {
         /* DP slices: forward -> backward -> MAP of one slice after the other over the shared scratch; inside a slice the band
@@ -1680,29 +1788,27 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
             for (int q = 0; q < no; ++q) {
                 const int cls = order[q];
                 if (sl.cls_batch[cls].n_order <= 0) continue;
-                if (serial) { HIPCHK(spx_launch_baq(cls, 2, &sl.cls_batch[cls], c->stream)); continue; }
+                if (serial) { HIPCHK(launch_cls(cls, 2, &sl.cls_batch[cls], c->stream)); continue; }
                 int sidx = 0;
                 for (int t = 1; t < c->n_side; ++t) if (load[t] < load[sidx]) sidx = t;
                 if (!used_side[sidx]) { HIPCHK(hipStreamWaitEvent(c->side_stream[sidx], sl.ev_start, 0)); used_side[sidx] = true; }
-                HIPCHK(spx_launch_baq(cls, 2, &sl.cls_batch[cls], c->side_stream[sidx]));
+                HIPCHK(launch_cls(cls, 2, &sl.cls_batch[cls], c->side_stream[sidx]));
                 load[sidx] += w->cls_cells[cls] + 1;
             }
             for (int t = 0; t < c->n_side; ++t)
                 if (used_side[t]) HIPCHK(hipEventRecord(c->side_done[t], c->side_stream[t]));
             if (mc >= 0) {
                 HIPCHK(hipEventRecord(sl.ev_f0, c->stream));
-                HIPCHK(spx_launch_baq(mc, 0, &sl.cls_batch[mc], c->stream));
+                HIPCHK(launch_cls(mc, 0, &sl.cls_batch[mc], c->stream));
                 HIPCHK(hipEventRecord(sl.ev_f1, c->stream));
-                HIPCHK(spx_launch_baq(mc, 1, &sl.cls_batch[mc], c->stream));
+                HIPCHK(launch_cls(mc, 1, &sl.cls_batch[mc], c->stream));
                 HIPCHK(hipEventRecord(sl.ev_b1, c->stream));
             }
             for (int t = 0; t < c->n_side; ++t)
                 if (used_side[t]) HIPCHK(hipStreamWaitEvent(c->stream, c->side_done[t], 0));
-            if (sl.r1 > sl.r0) {
-                spx_dev_batch Bm = sl.cls_batch[0];
-                Bm.row_base = (int32_t)sl.r0;
-                if (k + 1 == w->slices.size()) { const int rc = last_map(&Bm, (int32_t)(sl.r1 - sl.r0), wide > narrow); if (rc) return rc; }
-                else HIPCHK(spx_launch_map(&Bm, (int32_t)(sl.r1 - sl.r0), wide > narrow, c->stream));
+            if (sl.r1 > sl.r0 || fast) {
+                if (k + 1 == w->slices.size()) { const int rc = last_map(sl.cls_batch, sl.r0, sl.r1, wide > narrow); if (rc) return rc; }
+                else { const int rc = finish_rows(sl.cls_batch, sl.r0, sl.r1, wide > narrow, c->stream); if (rc) return rc; }
             }
         }
         if (mc >= 0) { /* (the ring's slots stay defined for readers that expect them) */
@@ -1722,6 +1828,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
     if (!w->ev_done) HIPCHK(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(w->ev_done, tail));
     w->launched = true;
+    w->n_launches_counted++;
     return SPX_OK;
 }
 
@@ -1837,6 +1944,20 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
             w->st.main_class_slots = spx::class_slots(w->main_cls);
         }
         w->st.kernel_seconds = (w->st.baq_kernel_ms + w->st.score_kernel_ms) * 1e-3;
+    }
+    w->st.tier_fast_problems = w->st.tier_rerun_certificate = w->st.tier_rerun_model = w->st.tier_rerun_range = w->st.tier_rows_uncertified = 0;
+    if (w->fast && w->launched && w->d_tier_counts) {
+        int32_t cnt[4] = {-1, -1, -1, -1}; /* (the counters start at -1: the launch orders' 0xff fill) */
+        if (hipMemcpy(cnt, w->d_tier_counts, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+        const int64_t nl = std::max<int64_t>(1, w->n_launches_counted);
+        for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
+            if (spx_fast_class(cls)) w->st.tier_fast_problems += w->st.problems_per_class[cls];
+        w->st.tier_rerun_certificate = ((int64_t)cnt[0] + 1) / nl;
+        w->st.tier_rerun_model = ((int64_t)cnt[1] + 1) / nl;
+        w->st.tier_rerun_range = ((int64_t)cnt[2] + 1) / nl;
+        w->st.tier_rows_uncertified = ((int64_t)cnt[3] + 1) / nl;
+        const int64_t v[5] = {w->st.tier_fast_problems, w->st.tier_rerun_certificate, w->st.tier_rerun_model, w->st.tier_rerun_range, w->st.tier_rows_uncertified};
+        for (int k = 0; k < 5; ++k) g_last_tier[k].store(v[k]);
     }
     if (w->staged) {
         /* device-prepared list: one packed record per dispatched group (results_kernel), one copy */
@@ -2251,7 +2372,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
     HIPCHK(hipMalloc((void **)&d_ref, ref4.size()));
     HIPCHK(hipMemcpy(d_ref, ref4.data(), ref4.size(), hipMemcpyHostToDevice));
     c->d_ref4 = d_ref;
-    int rc = build_device_batch(c, w, true);
+    int rc = build_device_batch(c, w, true, /*allow_fast=*/!post_scale && !pr_out);
     c->d_ref4 = saved;
     if (!rc) rc = spx_launch(c, w);
     if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess || hipStreamSynchronize(c->result_stream) != hipSuccess)) rc = fail(SPX_EHIP, "kernel execution failed");
@@ -2305,6 +2426,15 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
                 s_at += 8 + ((L + 2 + 7) & ~7);
             }
         }
+        if (w->fast) {
+            int32_t cnt[4] = {-1, -1, -1, -1};
+            if (hipMemcpy(cnt, w->d_tier_counts, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+            int64_t nf = 0;
+            for (int32_t p = 0; p < n; ++p) nf += spx_fast_class(spx::band_class(2 * hb.bw[p] + 1)) ? 1 : 0;
+            g_last_tier[0].store(nf);
+            for (int k = 0; k < 4; ++k) g_last_tier[k + 1].store((int64_t)cnt[k] + 1);
+        } else
+            for (int k = 0; k < 5; ++k) g_last_tier[k].store(0);
         if (hipMemcpy(state, w->d_state, nr * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(q, w->d_q, nr, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(SPX_EHIP, "copy back failed");
