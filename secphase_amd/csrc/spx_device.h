@@ -95,11 +95,21 @@ typedef struct spx_dev_batch {
 #define SPX_TIER_FAST 1
 #define SPX_TIER_RERUN 2
 
-/* constants of the fast tier that are the same for every problem of a launch: powers of m8 = D->D (the gap-extension probability) */
+/* Constants of the fast tier: the same for every problem of a launch.  The exact tier's transition constants carry a factor
+ * (1 - sM), sM = 1/(2 l_query + 2), on every transition OUT of an M or I state (probaln_glocal's m[0..4]); a path that has reached row i
+ * has left exactly i - 1 such states whatever its shape, so that factor is common to the whole row and cancels in the row-normalised
+ * posteriors: the fast tier drops it, and its constants depend on (d, e, set_q) only -- they live in SGPRs. */
 #define SPX_FAST_MAXC 32
 typedef struct spx_fast_consts {
     double pw[SPX_FAST_MAXC + 1]; /* pw[c] = m8^c */
-    double m8;
+    double m8;                    /* D->D = (double)e */
+    double m0h, m1h, m3h, m4h, m6; /* (double)((1-d)-d), (double)d, (double)(1-e), (double)e, (double)(1-e): m[] without (1 - sM) */
+    double e_match, e_mis;
+    /* derived (spx_runtime.cpp fast_constants) */
+    double emU, exU, cU0, cU1, c4; /* forward:  M = (e m6 m2) U',  U = cU0 M + cU1 It + Dt,  V = M + c4 It */
+    double emB, exB, cB1, cB2;     /* backward: X = (e m0) Bm',  Bm = X + cB1 Y + cB2 Dt,  Bi = X + c4 Y */
+    double rho;                    /* z_I / z_M correction = EI m1 m3 / m0 */
+    double ups, gam;               /* m6 m2, EI m1 */
     int32_t range_bits; /* a row spanning more than 2^range_bits flags its problem */
     int32_t mu_bits;    /* problems whose smallest per-row factor is below 2^-mu_bits are outside the model */
 } spx_fast_consts;

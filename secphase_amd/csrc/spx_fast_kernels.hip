@@ -27,6 +27,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -38,41 +39,30 @@
 #ifndef SPX_FAST_WAVES
 #define SPX_FAST_WAVES 2
 #endif
+#ifndef SPX_FAST_HIFI_WAVES
+#define SPX_FAST_HIFI_WAVES 3 /* waves per SIMD the two-lane backward kernels of the HiFi classes are compiled for (forward: 4; measured: forward 13.3 -> 10.8 ms
+                               * at four, backward 9.4 -> 12.4: it spills there) */
+#endif
 #define FAST_RESCALE_MASK 15 /* rows between two rescales / range checks - 1 */
 /* the unrolled slot loops are fenced every SPX_FAST_FENCE slots: left alone, the scheduler hoists the emission selects and the loads of
  * many slots to the top of a row and the register file spills */
 #ifndef SPX_FAST_FENCE
 #define SPX_FAST_FENCE 1
 #endif
-#define FAST_FENCE(c) do { if (SPX_FAST_FENCE > 0 && ((c) % (SPX_FAST_FENCE > 0 ? SPX_FAST_FENCE : 1)) == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FAST_FENCE(c) do { if (FENCE > 0 && ((c) % (FENCE > 0 ? FENCE : 1)) == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 
-struct FastC {
-    double emU, exU, cU0, cU1; /* forward */
-    double emB, exB, cB1, cB2; /* backward */
-    double c4, m8;
-};
-
-__device__ __forceinline__ FastC fast_consts(const HmmC &h)
-{
-    const double ups = h.m6 * h.m2, gam = FAST_EI * h.m1;
-    FastC f;
-    f.emU = h.e_match * ups; f.exU = h.e_mis * ups;
-    f.cU0 = h.m0 / ups; f.cU1 = (h.m3 * gam) / ups;
-    f.emB = h.e_match * h.m0; f.exB = h.e_mis * h.m0;
-    f.cB1 = (gam * h.m3) / h.m0; f.cB2 = (h.m2 * h.m6) / h.m0;
-    f.c4 = FAST_EI * h.m4; f.m8 = h.m8;
-    return f;
-}
-
-/* the model conditions of the fast tier (fastdp_model.c FDP_F_MODEL + the static range condition) */
+/* the model conditions of the fast tier (fastdp_model.c FDP_F_MODEL): no ambiguous base; the problem's constants are the launch's
+ * (the same expressions as spxl::hmm_constants, so equality is exact); positive and finite; the static range condition */
 __device__ __forceinline__ bool fast_eligible(const HmmC &h, double bM, double bI, double sM, double sI, int hasN, const spx_fast_consts &K)
 {
-    bool ok = !hasN && h.m8 == K.m8;
+    bool ok = !hasN && sM == sI;
+    ok = ok && h.m0 == K.m0h * (1 - sM) && h.m1 == K.m1h * (1 - sM) && h.m2 == h.m1 && h.m3 == K.m3h * (1 - sI) && h.m4 == K.m4h * (1 - sI);
+    ok = ok && h.m6 == K.m6 && h.m8 == K.m8 && h.e_match == K.e_match && h.e_mis == K.e_mis;
     const double cs[13] = {h.m0, h.m1, h.m2, h.m3, h.m4, h.m6, h.m8, bM, bI, sM, sI, h.e_match, h.e_mis};
 #pragma unroll
     for (int t = 0; t < 13; ++t) ok = ok && cs[t] > 1e-30 && cs[t] < 1e30;
     /* the smallest factor a value can take per row: between two range checks a row's spread grows by at most that per row */
-    const double mu = fmin(h.m0 * h.e_mis, FAST_EI * h.m4);
+    const double mu = fmin(K.m0h * K.e_mis, FAST_EI * K.m4h);
     ok = ok && mu >= __hiloint2double((1023 - K.mu_bits) << 20, 0);
     return ok;
 }
@@ -117,22 +107,22 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t v)
     return v;
 }
 
-/* range check + power-of-two rescale of two rows A, Bv of one problem (G lanes x C slots; slot c of this lane = column k0 + c).
- * Only slots of real cells count (1 <= column <= R, slot inside the band); exact zeros are structural (a positive value cannot reach
- * zero between two checks that passed: fast_eligible's mu condition) and do not count either.  Returns true when the problem must be
- * flagged: non-finite or denormal values, or a spread of more than 2^range_bits. */
-template <int G, int C>
-__device__ __forceinline__ bool range_rescale(double (&A)[C], double (&Bv)[C], double &carry, int k0, int R, int jbase, int Wu, int range_bits)
+/* range check of the row A + power-of-two rescale of A and Bv, one problem = G lanes x C slots.  Slots [c_lo, c_hi] of this lane hold real
+ * cells; exact zeros are structural (a positive value cannot reach zero between two checks that passed: fast_eligible's mu condition) and
+ * do not count.  A alone is checked: the other row is within constant factors of it cell by cell and column sum by column sum (forward:
+ * V >= M and U <= (cU0 + cU1/c4 + 1/(1-m8)) max V; backward: Bi >= X and Bm <= (1 + cB1/c4 + cB2/(1-m8)) max Bi) -- part of the 100 bits
+ * fast_constants leaves.  Returns true when the problem must be flagged: non-finite or denormal values, or a spread over 2^range_bits. */
+template <int G, int C, bool MASKED>
+__device__ __forceinline__ bool range_rescale(double (&A)[C], double (&Bv)[C], int c_lo, int c_hi, int range_bits)
 {
-    const int c_lo = max(0, 1 - k0), c_hi = min(min(C - 1, R - k0), Wu - 1 - jbase);
     uint32_t mx = 0, mn1 = 0xffffffffu; /* mn1 = (smallest non-zero high word) - 1 */
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         __builtin_amdgcn_sched_barrier(0);
-        const bool valid = c >= c_lo && c <= c_hi;
-        const uint32_t ha = valid ? (uint32_t)__double2hiint(A[c]) : 0u, hb = valid ? (uint32_t)__double2hiint(Bv[c]) : 0u;
-        mx = max(mx, max(ha, hb));
-        mn1 = min(mn1, min(ha - 1u, hb - 1u));
+        uint32_t ha = (uint32_t)__double2hiint(A[c]);
+        if constexpr (MASKED) ha = (c >= c_lo && c <= c_hi) ? ha : 0u;
+        mx = max(mx, ha);
+        mn1 = min(mn1, ha - 1u);
     }
     __builtin_amdgcn_sched_barrier(0);
     mx = group_max_u32<G>(mx);
@@ -146,26 +136,24 @@ __device__ __forceinline__ bool range_rescale(double (&A)[C], double (&Bv)[C], d
             __builtin_amdgcn_sched_barrier(0);
             A[c] *= sc; Bv[c] *= sc;
         }
-        carry *= sc;
     }
     return bad;
 }
 
 /* ====================================================================== */
-template <int G, int C, int W0>
-__global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_batch B, spx_fast_consts K)
+template <int G, int C, int W0, int WAVES = SPX_FAST_WAVES, int FENCE = SPX_FAST_FENCE>
+__global__ __launch_bounds__(64, WAVES) void fast_fwd_kernel(spx_dev_batch B, spx_fast_consts K)
 {
     constexpr int NW = NibWin<C>::NW;
     /* FAST rows mask the emission of the last PADMAX slots of a lane (slots beyond the band in the last lane); waves with more
      * padding than that run every row through the masked variant */
-    constexpr int PADMAX = (G == 1) ? 0 : (C < 8 ? C : 8);
+    constexpr int PADMAX = (G == 1) ? 0 : (W0 ? G * C - W0 : (C < 8 ? C : 8));
     const int lane = threadIdx.x & 63;
     const int g = lane % G;
     HmmC h;
     int hasN;
     Prob P = load_problem<G>(B, lane, h, hasN);
     bool act = P.act;
-    const FastC fc = fast_consts(h);
     double bM = 0, bI = 0;
     if (act) {
         const double *hp = B.hmm + (int64_t)P.pid * SPX_H_N;
@@ -177,7 +165,9 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_ba
         }
         act = ok;
     }
-    const int L = act ? P.L : 0, R = P.R, bw = P.bw;
+    /* rows behind the LAST wanted row have no observable effect (the exact tier walks them for its scaling factors, which this tier
+     * does not need): L below = the rows this kernel walks */
+    const int L = act ? B.rows[P.row0 + P.nrows - 1] : 0, R = P.R, bw = P.bw;
     const int Wu = W0 ? W0 : wave_max(act ? 2 * bw + 1 : 0);
     const int Lw = wave_max(L);
     if (Lw == 0) return;
@@ -187,8 +177,8 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_ba
     const int SLOTS = (int)(B.fsave_stride >> 1);
 
     double U[C], V[C];
-    double cin = 0.0; /* D carry into this lane's slots, not yet added to U (U_true[c] = U[c] + pw[c] * cin) */
-    NibWin<C> cw, padn;
+    NibWin<C> cw;
+    uint32_t padn[G > 1 ? NW : 1]; /* SPX_CODE_OUT in the slots beyond the band (last lanes of a multi-lane problem) */
     int32_t padm[PADMAX > 0 ? PADMAX : 1];
     double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
     const int64_t fstride = B.fsave_stride;
@@ -200,10 +190,10 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_ba
     /* row 1: M = e bM, I = EI bI on columns 1 .. min(R, bw + 1); no D */
     {
         const uint32_t qy = act ? fetch_code(B.qry4, P.qry0, 0, L) : 0;
-        const double It1 = act ? (FAST_EI * bI) / (FAST_EI * h.m1) : 0.0;
-        const double U0 = act ? bM / (h.m6 * h.m2) : 0.0; /* what the MAP kernel multiplies by e m6 m2 */
+        const double It1 = act ? (FAST_EI * bI) / K.gam : 0.0;
+        const double U0 = act ? bM / K.ups : 0.0; /* what the MAP kernel multiplies by e m6 m2 */
 #pragma unroll
-        for (int k = 0; k < NW; ++k) { cw.w[k] = 0; padn.w[k] = 0; }
+        for (int k = 0; k < NW; ++k) { cw.w[k] = 0; if (G > 1) padn[k] = 0; }
         double *dst = fsave + jbase;
         const bool sv = act && next_row == 1;
 #pragma unroll
@@ -211,12 +201,12 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_ba
             const int j = jbase + c;
             const uint32_t code = act ? fetch_code(B.ref4, P.ref0, j - bw, R) : (uint32_t)SPX_CODE_OUT;
             cw.set(c, code);
-            padn.set(c, j < Wu ? 0u : (uint32_t)SPX_CODE_OUT);
+            if (G > 1 && j >= Wu) padn[c >> 3] |= (uint32_t)SPX_CODE_OUT << (4 * (c & 7));
             const bool valid = !(code & SPX_CODE_OUT) && j < Wu;
-            const double e = code == qy ? h.e_match : h.e_mis;
+            const double e = code == qy ? K.e_match : K.e_mis;
             const double M = valid ? e * bM : 0.0, It = valid ? It1 : 0.0;
-            U[c] = fma(fc.cU0, M, fc.cU1 * It);
-            V[c] = fma(fc.c4, It, M);
+            U[c] = fma(K.cU0, M, K.cU1 * It);
+            V[c] = fma(K.c4, It, M);
             if (sv) { dst[c] = valid ? U0 : 0.0; dst[SLOTS + c] = It; }
         }
         if (PADMAX > 0) {
@@ -230,14 +220,9 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_ba
     auto qry_chunk = [&](int ib) { return fetch8(B.qry4, P.qry0 + (ib - 1)); };
     uint32_t qwin = act ? qry_chunk(1) : 0, rwin = act ? ref_chunk(1) : 0;
     uint32_t qwin_n = act ? qry_chunk(9) : 0, rwin_n = act ? ref_chunk(9) : 0;
-    /* every 16 rows: fold the pending carry, check the dynamic range of row i-1, rescale by a power of two */
+    /* every 16 rows: dynamic range of row i-1 (V: exactly zero wherever there is no cell), rescale by a power of two */
     auto rescale = [&](int i) {
-        if (G > 1) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) U[c] = fma(K.pw[c], cin, U[c]);
-            cin = 0.0;
-        }
-        const bool bad = range_rescale<G, C>(U, V, cin, (i - 1) - bw + jbase, R, jbase, Wu, K.range_bits);
+        const bool bad = range_rescale<G, C, false>(V, U, 0, C - 1, K.range_bits);
         if (act && i <= L && bad) flagged = true;
     };
     auto row = [&](int i, auto fast_tag) {
@@ -254,47 +239,47 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_ba
             cw.shift_down(rc);
             uint32_t ew[NW], eq[NW];
 #pragma unroll
-            for (int k = 0; k < NW; ++k) ew[k] = cw.w[k] | padn.w[k];
+            for (int k = 0; k < NW; ++k) ew[k] = G > 1 ? (cw.w[k] | padn[k]) : cw.w[k];
             eq_masks<NW>(ew, qy, eq);
             double Vn = shfl_down1<G>(V[0]);
             if (g == G - 1) Vn = 0.0;
             /* wanted row: the MAP kernel needs M(i,k) = e (m6 m2) U(i-1,k-1) and It(i,k) = V(i-1,k): store the two raw rows */
-#ifndef SPX_X_NOSAVE
             if (i == next_row) {
                 double *dst = fsave + (int64_t)wnext * fstride + jbase;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    dst[c] = G > 1 ? fma(K.pw[c], cin, U[c]) : U[c];
+                    dst[c] = U[c];
                     dst[SLOTS + c] = (c + 1 < C) ? V[c + 1] : Vn;
                 }
                 wnext++;
                 next_row = wnext < nrows ? B.rows[row0 + wnext] : 0x7fffffff;
             }
-#endif
             double Dloc = 0.0, Mprev = 0.0;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 FAST_FENCE(c);
-                const double Ueff = G > 1 ? fma(K.pw[c], cin, U[c]) : U[c];
-                const double e = select_bits(nib_bit3<NW>(eq, c), fc.emU, fc.exU);
-                double M = e * Ueff;
+                const double e = select_bits(nib_bit3<NW>(eq, c), K.emU, K.exU);
+                double M = e * U[c];
                 if constexpr (!FAST) M = zero_if(M, nib_bit3<NW>(ew, c)); /* no such cell: column > R, or a slot beyond the band */
                 else if constexpr (PADMAX > 0) { if (c >= C - PADMAX) M = zero_if(M, padm[c - (C - PADMAX)]); }
                 const double It = (c + 1 < C) ? V[c + 1] : Vn;
-                if (c > 0) Dloc = fma(fc.m8, Dloc, Mprev);
-                U[c] = fma(fc.cU0, M, fma(fc.cU1, It, Dloc));
-                V[c] = fma(fc.c4, It, M);
+                if (c > 0) Dloc = fma(K.m8, Dloc, Mprev);
+                U[c] = fma(K.cU0, M, fma(K.cU1, It, Dloc));
+                V[c] = fma(K.c4, It, M);
                 Mprev = M;
             }
             if constexpr (G > 1) {
-                const double E = fma(fc.m8, Dloc, Mprev); /* local D at the slot behind this lane's last one */
-                double cnew = 0.0;
+                /* D carry across the lanes of the problem: the lane-local chains started from 0; lane g's slots lack pw[c] * (true D at the
+                 * slot in front of its first one) */
+                const double E = fma(K.m8, Dloc, Mprev); /* local D at the slot behind this lane's last one */
+                double cin = 0.0;
 #pragma unroll
                 for (int t = 1; t < G; ++t) {
-                    const double up = shfl_up1<G>(fma(K.pw[C], cnew, E));
-                    if (g == t) cnew = up;
+                    const double up = shfl_up1<G>(fma(K.pw[C], cin, E));
+                    if (g == t) cin = up;
                 }
-                cin = cnew;
+#pragma unroll
+                for (int c = 0; c < C; ++c) U[c] = fma(K.pw[c], cin, U[c]);
             }
         }
     };
@@ -312,18 +297,17 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_fwd_kernel(spx_dev_ba
 }
 
 /* ====================================================================== */
-template <int G, int C, int W0>
-__global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_bwd_kernel(spx_dev_batch B, spx_fast_consts K)
+template <int G, int C, int W0, int WAVES = SPX_FAST_WAVES, int FENCE = SPX_FAST_FENCE>
+__global__ __launch_bounds__(64, WAVES) void fast_bwd_kernel(spx_dev_batch B, spx_fast_consts K)
 {
     constexpr int NW = NibWin<C>::NW;
-    constexpr int PADMAX = (G == 1) ? 0 : (C < 8 ? C : 8);
+    constexpr int PADMAX = (G == 1) ? 0 : (W0 ? G * C - W0 : (C < 8 ? C : 8));
     const int lane = threadIdx.x & 63;
     const int g = lane % G;
     HmmC h;
     int hasN;
     Prob P = load_problem<G>(B, lane, h, hasN, true);
     bool act = P.act && B.tier[P.pid] == SPX_TIER_FAST; /* (problems the forward kernel found outside the model, or flagged) */
-    const FastC fc = fast_consts(h);
     const int L = act ? P.L : 0, R = P.R, bw = P.bw;
     const int Wu = W0 ? W0 : wave_max(act ? 2 * bw + 1 : 0);
     const int Lw = wave_max(L);
@@ -335,24 +319,22 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_bwd_kernel(spx_dev_ba
     const int64_t fstride = B.fsave_stride;
 
     double Bm[C], Bi[C];
-    double cinB = 0.0; /* cB2 * (D carry into this lane from the lane above), not yet added to Bm */
-    NibWin<C> cw, padn;
+    NibWin<C> cw;
+    uint32_t padn[G > 1 ? NW : 1];
     int32_t padm[PADMAX > 0 ? PADMAX : 1];
     bool flagged = false;
     /* row L */
     {
-        const double sM = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SM] : 0.0;
-        const double sI = act ? B.hmm[(int64_t)P.pid * SPX_H_N + SPX_H_SI] : 0.0;
-        const double vM = act ? sM / h.m0 : 0.0, vI = act ? sI / h.m3 : 0.0;
+        const double vM = act ? 1.0 / K.m0h : 0.0, vI = act ? 1.0 / K.m3h : 0.0; /* bM = sM, bI = sI (sM == sI: fast_eligible), in units of m0, m3 */
 #pragma unroll
-        for (int k = 0; k < NW; ++k) { cw.w[k] = 0; padn.w[k] = 0; }
+        for (int k = 0; k < NW; ++k) { cw.w[k] = 0; if (G > 1) padn[k] = 0; }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int j = jbase + c, k = L - bw + j;
             const bool valid = act && j < Wu && k >= 1 && k <= P.Rt;
             Bm[c] = valid ? vM : 0.0;
             Bi[c] = valid ? vI : 0.0;
-            padn.set(c, j < Wu ? 0u : (uint32_t)SPX_CODE_OUT);
+            if (G > 1 && j >= Wu) padn[c >> 3] |= (uint32_t)SPX_CODE_OUT << (4 * (c & 7));
             /* window for row L-1: code of ref idx (L-1) - bw + j (= column k+1 of that row) */
             cw.set(c, (act && L >= 2) ? fetch_code(B.ref4, P.ref0, (L - 1) - bw + j, R) : (uint32_t)SPX_CODE_OUT);
         }
@@ -369,8 +351,7 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_bwd_kernel(spx_dev_ba
         double *dst = fsave + (int64_t)wprev * fstride + jbase;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double Beff = G > 1 ? fma(K.pw[C - 1 - c], cinB, Bm[c]) : Bm[c];
-            dst[c] = dst[c] * Beff;
+            dst[c] = dst[c] * Bm[c];
             dst[SLOTS + c] = dst[SLOTS + c] * Bi[c];
         }
         wprev--;
@@ -386,13 +367,11 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_bwd_kernel(spx_dev_ba
     /* masked rows: while the band still touches column R (first steps), and -- every step -- when the wave's padding is wide */
     int n_slow = min(nbw, wave_max(act ? min(nb, max(0, (L - 1) - (R - bw - 1))) : 0));
     if (G * C - Wu > PADMAX) n_slow = nbw;
-    auto rescale = [&](int t) { /* state = row L - t */
-        if (G > 1) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) Bm[c] = fma(K.pw[C - 1 - c], cinB, Bm[c]);
-            cinB = 0.0;
-        }
-        const bool bad = range_rescale<G, C>(Bm, Bi, cinB, (L - t) - bw + jbase, R, jbase, Wu, K.range_bits);
+    /* every 16 steps: dynamic range of row L - t over its real cells (columns < 1 and slots beyond the band hold values that never
+     * reach a real cell, but are not zero), rescale by a power of two */
+    auto rescale = [&](int t) {
+        const int k0 = (L - t) - bw + jbase; /* column of slot 0 */
+        const bool bad = range_rescale<G, C, true>(Bi, Bm, max(0, 1 - k0), min(min(C - 1, R - k0), Wu - 1 - jbase), K.range_bits);
         if (act && t < nb && bad) flagged = true;
     };
     auto row = [&](int t, auto fast_tag, auto first_tag) {
@@ -415,7 +394,7 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_bwd_kernel(spx_dev_ba
             }
             uint32_t ew[NW], eq[NW];
 #pragma unroll
-            for (int k = 0; k < NW; ++k) ew[k] = cw.w[k] | padn.w[k];
+            for (int k = 0; k < NW; ++k) ew[k] = G > 1 ? (cw.w[k] | padn[k]) : cw.w[k];
             eq_masks<NW>(ew, qy, eq);
             double Yh = shfl_up1<G>(Bi[C - 1]);
             if (g == 0) Yh = 0.0;
@@ -424,26 +403,28 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_bwd_kernel(spx_dev_ba
 #pragma unroll
             for (int c = C - 1; c >= 0; --c) {
                 FAST_FENCE(c);
-                const double Beff = G > 1 ? fma(K.pw[C - 1 - c], cinB, Bm[c]) : Bm[c];
-                const double e = select_bits(nib_bit3<NW>(eq, c), fc.emB, fc.exB);
-                double X = e * Beff;
+                const double e = select_bits(nib_bit3<NW>(eq, c), K.emB, K.exB);
+                double X = e * Bm[c];
                 if constexpr (!FAST) X = zero_if(X, nib_bit3<NW>(ew, c)); /* column k+1 > R, or a slot beyond the band */
                 else if constexpr (PADMAX > 0) { if (c >= C - PADMAX) X = zero_if(X, padm[c - (C - PADMAX)]); }
                 const double Y = c > 0 ? Bi[c - 1] : Yh;
-                Bm[c] = fma(fc.cB1, Y, fma(fc.cB2, Dloc, X));
-                Bi[c] = fma(fc.c4, Y, X);
-                Dloc = fma(fc.m8, Dloc, X);
+                Bm[c] = fma(K.cB1, Y, fma(K.cB2, Dloc, X));
+                Bi[c] = fma(K.c4, Y, X);
+                Dloc = fma(K.m8, Dloc, X);
                 if constexpr (FIRST) Dloc *= y;
             }
             if constexpr (G > 1) {
-                double cnew = 0.0; /* true D at slot 0 of the lane above */
+                /* D carry from the lane above: Bm[c] lacks cB2 * pw[C-1-c] * (true D at slot 0 of the lane above) */
+                double cin = 0.0;
 #pragma unroll
                 for (int tt = G - 2; tt >= 0; --tt) {
-                    const double dn = shfl_down1<G>(fma(K.pw[C], cnew, Dloc));
-                    if (g == tt) cnew = dn;
+                    const double dn = shfl_down1<G>(fma(K.pw[C], cin, Dloc));
+                    if (g == tt) cin = dn;
                 }
-                if constexpr (FIRST) cnew *= y;
-                cinB = fc.cB2 * cnew;
+                if constexpr (FIRST) cin *= y;
+                const double cb = K.cB2 * cin;
+#pragma unroll
+                for (int c = 0; c < C; ++c) Bm[c] = fma(K.pw[C - 1 - c], cb, Bm[c]);
             }
             if (i == prev_row) save_row();
         }
@@ -468,7 +449,7 @@ __global__ __launch_bounds__(64, SPX_FAST_WAVES) void fast_bwd_kernel(spx_dev_ba
 /* MAP + certificate of the fast tier: LPR adjacent lanes per wanted row of a tier-1 problem.  z_M(j) = e(i,k) m6 m2 * [U Bm](j),
  * z_I(j) = rho * [It Bi](j) with rho = EI m1 m3 / m0 (the products in brackets were left by fast_bwd_kernel). */
 template <int CQ, int LPR>
-__global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, int32_t n_rows_total)
+__global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, spx_fast_consts K, int32_t n_rows_total)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int r = B.row_base + (int)(tid / LPR), g = (int)(tid & (LPR - 1));
@@ -481,22 +462,23 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, int32_t 
     const int64_t off = B.fsave_off[p] + (int64_t)(rr - B.row_off[p]) * 2 * slots;
     const double *zM = B.fsave + off, *zI = zM + slots;
     const int j0 = max(0, bw + 1 - i), j1 = min(W - 1, R - i + bw); /* 1 <= k = i - bw + j <= R */
-    const double *hp = B.hmm + (int64_t)p * SPX_H_N;
-    const double ups = hp[SPX_H_M6] * hp[SPX_H_M2];
-    const double emU = hp[SPX_H_EMATCH] * ups, exU = hp[SPX_H_EMIS] * ups;
-    const double rho = ((FAST_EI * hp[SPX_H_M1]) * hp[SPX_H_M3]) / hp[SPX_H_M0];
+    const double emU = K.emU, exU = K.exU, rho = K.rho;
     const uint32_t qy = on ? fetch_code(B.qry4, B.qry_nib[p], i - 1, L) : 0;
     const int64_t ref0 = B.ref_nib[p];
-    /* this lane's z values (M, I per slot), 0 outside [j0, j1] */
+    /* this lane's z values (M, I per slot), 0 outside [j0, j1]; the reference codes of its slots arrive eight per fetch
+     * (slot j of row i <-> reference index i - bw + j - 1; the pool's lead pad covers the indices in front of a window) */
     double z[2 * CQ];
     const int cq_wave = wave_max(on ? Cq : 0);
     double best = 0.0, second = 0.0;
     int best_t = -1; /* index into z[] */
+    uint32_t codes[(CQ + 7) / 8];
+#pragma unroll
+    for (int k = 0; k < (CQ + 7) / 8; ++k) codes[k] = on ? fetch8(B.ref4, ref0 + (i - bw + g * Cq - 1) + 8 * k) : 0;
     auto load = [&](int c, int j) {
         const bool in = on && c < Cq && j >= j0 && j <= j1;
         double m = 0.0, ii = 0.0;
         if (in) {
-            const uint32_t code = fetch_code(B.ref4, ref0, i - bw + j - 1, R);
+            const uint32_t code = (codes[c >> 3] >> (4 * (c & 7))) & 0xfu;
             m = zM[j] * (code == qy ? emU : exU);
             ii = zI[j] * rho;
         }
@@ -558,11 +540,13 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, int32_t 
     }
 }
 
-extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st)
+extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, const spx_fast_consts *K, int32_t n_rows_total, int wide, hipStream_t st)
 {
     if (n_rows_total <= 0) return hipSuccess;
-    /* eight lanes per row, up to 16 slots each: every fast class (<= 128 slots) */
-    hipLaunchKernelGGL((fast_map_kernel<16, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, n_rows_total);
+    /* eight lanes per row; wide: up to 16 slots per lane (every fast class: <= 128 slots), else 6 (<= 48 slots) -- a wave of the narrow
+     * instantiation that meets a wider row hands its problem to the exact tier, so `wide` must be set when such classes are in the list */
+    if (wide) hipLaunchKernelGGL((fast_map_kernel<16, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, *K, n_rows_total);
+    else hipLaunchKernelGGL((fast_map_kernel<6, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, *K, n_rows_total);
     return hipGetLastError();
 }
 
@@ -581,30 +565,73 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
     if (B->n_order <= 0 && B->n_order_bwd <= 0) return hipSuccess;
     spx_dev_batch P = *B;
     P.tier_want = SPX_TIER_ALL; /* the fast kernels take every problem of the class and sort them into tiers themselves */
-#define SPX_FAST(G_, C_, W0_, GB_, CB_)                                                                                     \
+#define SPX_FAST(G_, C_, WF_, WB_)                                                                                          \
     {                                                                                                                       \
-        const int ppw = 64 / G_, ppwb = 64 / GB_;                                                                           \
-        const int blocks = (B->n_order + ppw - 1) / ppw, blocks_b = (B->n_order_bwd + ppwb - 1) / ppwb;                     \
-        if (phase != 1 && blocks > 0) hipLaunchKernelGGL((fast_fwd_kernel<G_, C_, W0_>), dim3(blocks), dim3(64), 0, st, P, *K);   \
-        if (phase != 0 && blocks_b > 0) hipLaunchKernelGGL((fast_bwd_kernel<GB_, CB_, W0_>), dim3(blocks_b), dim3(64), 0, st, P, *K); \
+        const int ppw = 64 / G_;                                                                                            \
+        const int blocks = (B->n_order + ppw - 1) / ppw, blocks_b = (B->n_order_bwd + ppw - 1) / ppw;                       \
+        if (phase != 1 && blocks > 0) hipLaunchKernelGGL((fast_fwd_kernel<G_, C_, 0, WF_>), dim3(blocks), dim3(64), 0, st, P, *K);   \
+        if (phase != 0 && blocks_b > 0) hipLaunchKernelGGL((fast_bwd_kernel<G_, C_, 0, WB_>), dim3(blocks_b), dim3(64), 0, st, P, *K); \
     }                                                                                                                       \
     break;
+    /* the exact band widths of the HiFi preset: one lane per problem (no lane exchange, 2 x W doubles of state: the register file is
+     * full at two waves per SIMD) or two lanes (half the state per lane, one carry per row) -- SPX_FAST_HIFI_G / SPX_FAST_HIFI_GB */
+    static const int hifi_g = [] { const char *e = getenv("SPX_FAST_HIFI_G"); return e ? atoi(e) : 2; }();
+    static const int hifi_gb = [] { const char *e = getenv("SPX_FAST_HIFI_GB"); return e ? atoi(e) : 2; }();
+#define SPX_FAST_HIFI(W_, C2_, WF_)                                                                                            \
+    {                                                                                                                       \
+        if (phase != 1 && B->n_order > 0) {                                                                                 \
+            if (hifi_g == 1) hipLaunchKernelGGL((fast_fwd_kernel<1, W_, W_>), dim3((B->n_order + 63) / 64), dim3(64), 0, st, P, *K); \
+            else hipLaunchKernelGGL((fast_fwd_kernel<2, C2_, W_, WF_>), dim3((B->n_order + 31) / 32), dim3(64), 0, st, P, *K);   \
+        }                                                                                                                   \
+        if (phase != 0 && B->n_order_bwd > 0) {                                                                             \
+            if (hifi_gb == 1) hipLaunchKernelGGL((fast_bwd_kernel<1, W_, W_>), dim3((B->n_order_bwd + 63) / 64), dim3(64), 0, st, P, *K); \
+            else hipLaunchKernelGGL((fast_bwd_kernel<2, C2_, W_, SPX_FAST_HIFI_WAVES>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, P, *K); \
+        }                                                                                                                   \
+    }                                                                                                                       \
+    break;
+    static const int x_fence = [] { const char *e = getenv("SPX_X_FENCE"); return e ? atoi(e) : -1; }();
+    static const int x_waves = [] { const char *e = getenv("SPX_X_WAVES"); return e ? atoi(e) : 0; }();
+#define SPX_FAST_HIFI_X(W_, C2_, G_, WV_, F_)                                                                              \
+    {                                                                                                                       \
+        constexpr int cc = G_ == 1 ? W_ : C2_;                                                                              \
+        if (phase != 1 && B->n_order > 0) hipLaunchKernelGGL((fast_fwd_kernel<G_, cc, W_, WV_, F_>), dim3((B->n_order + 64 / G_ - 1) / (64 / G_)), dim3(64), 0, st, P, *K); \
+        if (phase != 0 && B->n_order_bwd > 0) hipLaunchKernelGGL((fast_bwd_kernel<G_, cc, W_, WV_, F_>), dim3((B->n_order_bwd + 64 / G_ - 1) / (64 / G_)), dim3(64), 0, st, P, *K); \
+        return hipGetLastError();                                                                                           \
+    }
+    if (cls == 0 && x_fence >= 0) { /* experiment: fence spacing / waves per SIMD of the W = 41 kernels (fwd and bwd lanes = SPX_FAST_HIFI_G) */
+        if (hifi_g == 1) {
+            if (x_fence == 0) SPX_FAST_HIFI_X(41, 21, 1, 2, 0)
+            if (x_fence == 2) SPX_FAST_HIFI_X(41, 21, 1, 2, 2)
+            if (x_fence == 4) SPX_FAST_HIFI_X(41, 21, 1, 2, 4)
+            if (x_fence == 8) SPX_FAST_HIFI_X(41, 21, 1, 2, 8)
+        } else if (x_waves == 4) {
+            if (x_fence == 0) SPX_FAST_HIFI_X(41, 21, 2, 4, 0)
+            if (x_fence == 1) SPX_FAST_HIFI_X(41, 21, 2, 4, 1)
+            if (x_fence == 4) SPX_FAST_HIFI_X(41, 21, 2, 4, 4)
+        } else {
+            if (x_fence == 0) SPX_FAST_HIFI_X(41, 21, 2, 3, 0)
+            if (x_fence == 2) SPX_FAST_HIFI_X(41, 21, 2, 3, 2)
+            if (x_fence == 4) SPX_FAST_HIFI_X(41, 21, 2, 3, 4)
+            if (x_fence == 8) SPX_FAST_HIFI_X(41, 21, 2, 3, 8)
+        }
+    }
     switch (cls) {
-    case 0: SPX_FAST(1, 41, 41, 1, 41)
+    case 0: SPX_FAST_HIFI(41, 21, 4)
 #ifndef SPX_FAST_ONLY
-    case 1: SPX_FAST(1, 43, 43, 1, 43)
-    case 2: SPX_FAST(1, 45, 45, 1, 45)
-    case 3: SPX_FAST(1, 47, 47, 1, 47)
-    case 4: SPX_FAST(2, 24, 0, 2, 24)
-    case 5: SPX_FAST(4, 16, 0, 4, 16)
-    case 6: SPX_FAST(4, 26, 0, 4, 26)
+    case 1: SPX_FAST_HIFI(43, 22, 3)
+    case 2: SPX_FAST_HIFI(45, 23, 3)
+    case 3: SPX_FAST_HIFI(47, 24, 3)
+    case 4: SPX_FAST(2, 24, 3, 2)
+    case 5: SPX_FAST(4, 16, 4, 3)
+    case 6: SPX_FAST(4, 26, 3, 2)
 #endif
-    case 12: SPX_FAST(4, 28, 0, 4, 28)
+    case 12: SPX_FAST(4, 28, 3, 2)
 #ifndef SPX_FAST_ONLY
-    case 13: SPX_FAST(4, 30, 0, 4, 30)
+    case 13: SPX_FAST(4, 30, 2, 2)
 #endif
     default: return hipErrorInvalidValue;
     }
 #undef SPX_FAST
+#undef SPX_FAST_HIFI
     return hipGetLastError();
 }

@@ -84,7 +84,8 @@ struct spx_order_segs { /* where each band class' launch order lives inside the 
 
 #define SPX_MAX_SLICES 32 /* DP slices of a work list */
 struct spx_order_args {
-    int32_t n_prob, pad;
+    int32_t n_prob;
+    int32_t fwd_by_last_row; /* two-tier DP: the fast forward kernel stops at a problem's LAST wanted row: the forward order goes by that, not by the query length */
     /* round 5: ONE pair of sorts per work list instead of one per DP slice: the slice of a problem is the top field of its key */
     int32_t n_slices;
     int32_t slice_prob[SPX_MAX_SLICES + 1]; /* first problem of every slice, [n_slices] = n_prob */

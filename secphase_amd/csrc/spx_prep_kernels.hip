@@ -625,7 +625,8 @@ __global__ __launch_bounds__(256) void order_keys_kernel(spx_order_args O)
     if (p >= O.n_prob) return;
     const int bw = O.bw[p], L = O.L[p], nr = O.n_rows[p];
     const int cls = band_class(2 * bw + 1);
-    const uint32_t lf = (uint32_t)L > 0xfffffu ? 0xfffffu : (uint32_t)L;
+    const int fr = (O.fwd_by_last_row && nr > 0) ? O.rows[O.row_off[p] + nr - 1] : L; /* rows the forward kernel walks */
+    const uint32_t lf = (uint32_t)fr > 0xfffffu ? 0xfffffu : (uint32_t)fr;
     /* rows the backward kernel walks: L down to the first wanted row */
     const int br = nr > 0 ? L - O.rows[O.row_off[p]] + 1 : 0;
     const uint32_t lb = (uint32_t)br > 0xfffffu ? 0xfffffu : (uint32_t)br;

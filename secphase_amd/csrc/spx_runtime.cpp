@@ -37,7 +37,7 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st);
 extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B, const spx_fast_consts *K, hipStream_t st);
-extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, int32_t n_rows_total, hipStream_t st);
+extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, const spx_fast_consts *K, int32_t n_rows_total, int wide, hipStream_t st);
 extern "C" int spx_fast_class(int cls);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
                                       spx_decision *out, hipStream_t st);
@@ -280,7 +280,10 @@ struct spx_work {
     int32_t *d_tier = nullptr, *d_tier_counts = nullptr;
     spx_fast_consts fk;
     bool fast = false, any_fast_cls = false, any_exact_cls = false;
+    float fast_d = 0, fast_e = 0; /* host-built lists (spx_probaln_batch): the parameters of problem 0; problems with others take the exact tier */
+    int fast_set_q = 0;
     int64_t n_launches_counted = 0; /* launches since the counters were last reset by a preparation */
+    std::vector<hipEvent_t> rr_ev;  /* events of the re-run fan-out (one start event per slice + one per fast class), created on demand */
     spx_stats st;
     spx_params par;
     bool launched = false;
@@ -599,16 +602,34 @@ extern "C" int spx_last_tier_stats(int64_t *out /* 5: fast problems, re-run by c
     for (int k = 0; k < 5; ++k) out[k] = g_last_tier[k].load();
     return SPX_OK;
 }
-/* constants every problem of a launch shares: powers of m8 = (double)(float)conf_e (hmm_constants), the range / model limits.
+/* constants every problem of a launch shares (spx_device.h spx_fast_consts), from the list's (d, e, set_q) exactly as
+ * spxl::hmm_constants forms them (float expressions promoted), without the (1 - sM) factors.
  * range_bits + 16 rows x mu_bits + 100 (constant factors between the carried rows and the exact tier's M, I, D) must stay
  * below 1022: a row of the exact tier, normalised to sum 1, then keeps every value in the normal FP64 range between two checks. */
-static void fast_constants(double m8, spx_fast_consts *K)
+static void fast_constants(float d, float e, int set_q, spx_fast_consts *K)
 {
     memset(K, 0, sizeof *K);
-    K->m8 = m8;
+    double h[SPX_H_N];
+    spx::hmm_constants(100, 100, d, e, set_q, h); /* (for e_match / e_mis / m6 / m8: they do not depend on the lengths) */
+    K->m0h = (double)((1 - d) - d);
+    K->m1h = (double)d;
+    K->m3h = (double)(1 - e);
+    K->m4h = (double)e;
+    K->m6 = h[SPX_H_M6];
+    K->m8 = h[SPX_H_M8];
+    K->e_match = h[SPX_H_EMATCH];
+    K->e_mis = h[SPX_H_EMIS];
     K->pw[0] = 1.0;
-    for (int c = 1; c <= SPX_FAST_MAXC; ++c) K->pw[c] = K->pw[c - 1] * m8;
-    static const int rb = [] { const char *e = getenv("SPX_FAST_RANGE_BITS"); const int v = e ? atoi(e) : 600; return v < 64 ? 64 : (v > 700 ? 700 : v); }();
+    for (int c = 1; c <= SPX_FAST_MAXC; ++c) K->pw[c] = K->pw[c - 1] * K->m8;
+    K->ups = K->m6 * K->m1h;
+    K->gam = 0.25 * K->m1h;
+    K->emU = K->e_match * K->ups; K->exU = K->e_mis * K->ups;
+    K->cU0 = K->m0h / K->ups; K->cU1 = (K->m3h * K->gam) / K->ups;
+    K->c4 = 0.25 * K->m4h;
+    K->emB = K->e_match * K->m0h; K->exB = K->e_mis * K->m0h;
+    K->cB1 = (K->gam * K->m3h) / K->m0h; K->cB2 = (K->m1h * K->m6) / K->m0h;
+    K->rho = (K->gam * K->m3h) / K->m0h;
+    static const int rb = [] { const char *e2 = getenv("SPX_FAST_RANGE_BITS"); const int v = e2 ? atoi(e2) : 600; return v < 64 ? 64 : (v > 700 ? 700 : v); }();
     K->range_bits = spx_get_dp_tiers() == 2 ? -1 : rb; /* (test mode: every range check fails) */
     K->mu_bits = (1000 - 100 - rb) / 16;
 }
@@ -628,6 +649,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool a
     }
     /* rows the backward kernel walks: L down to the first wanted row */
     auto brows = [&](int32_t p) { return hb.n_rows[p] > 0 ? hb.L[p] - hb.rows[hb.row_off[p]] + 1 : 0; };
+    const bool fast_order = allow_fast && spx_get_dp_tiers() != 0; /* the fast forward kernel stops at the LAST wanted row: its order goes by that */
     /* order = (band width ascending, length descending, index ascending).  Keys are built in index order, so a stable
      * LSD radix sort of (bw, max - length) gives it in O(n); forward and backward orders of all classes are
      * independent and sorted on their own threads */
@@ -640,7 +662,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool a
         std::vector<uint64_t> a(n), b(n);
         for (size_t i = 0; i < n; ++i) {
             const int32_t p = v[i];
-            const uint32_t len = (uint32_t)(pass ? brows(p) : hb.L[p]);
+            const uint32_t len = (uint32_t)(pass ? brows(p) : (fast_order && hb.n_rows[p] > 0 ? hb.rows[hb.row_off[p] + hb.n_rows[p] - 1] : hb.L[p]));
             const uint32_t key = ((uint32_t)hb.bw[p] << 20) | (0xfffffu - (len > 0xfffffu ? 0xfffffu : len)); /* bw <= 1023 */
             a[i] = ((uint64_t)key << 32) | (uint32_t)p;
         }
@@ -718,7 +740,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool a
     w->d_tier_counts = w->d_tier + np;
     w->n_launches_counted = 0;
     if (w->fast) {
-        fast_constants(hb.hmm[SPX_H_M8], &w->fk);
+        fast_constants(w->fast_d, w->fast_e, w->fast_set_q, &w->fk);
         HIPCHK(hipMemsetAsync(w->d_tier, 0xff, (np + 8) * sizeof(int32_t), c->stream));
     }
     double t0 = now_s();
@@ -1514,9 +1536,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     w->d_tier_counts = w->d_tier + np;
     w->n_launches_counted = 0;
     if (w->fast) {
-        double hc[SPX_H_N];
-        spx::hmm_constants(100, 100, (float)w->par.conf_d, (float)w->par.conf_e, w->par.set_q, hc);
-        fast_constants(hc[SPX_H_M8], &w->fk);
+        fast_constants((float)w->par.conf_d, (float)w->par.conf_e, w->par.set_q, &w->fk);
     }
     w->any_fast_cls = w->any_exact_cls = false;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
@@ -1529,6 +1549,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         spx_order_args O;
         memset(&O, 0, sizeof O);
         O.n_prob = (int32_t)np;
+        O.fwd_by_last_row = w->fast ? 1 : 0;
         O.bw = E.out.bw; O.L = E.out.L; O.n_rows = E.out.n_rows; O.row_off = E.out.row_off; O.rows = E.out.rows;
         char *kp = (char *)PL.pool_keys.p;
         O.key_f = (uint64_t *)kp; O.key_b = O.key_f + (np + 2); O.key_sorted = O.key_b + (np + 2);
@@ -1717,24 +1738,60 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         if (fast && spx_fast_class(cls)) return spx_launch_fast(cls, phase, Bc, &w->fk, st);
         return spx_launch_baq(cls, phase, Bc, st);
     };
+    bool wide_fast = false; /* a fast class with more than 48 slots is in the list: the wide MAP instantiation */
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
+        if (w->cls_used[cls] && spx_fast_class(cls) && spx::class_slots(cls) > 48) wide_fast = true;
     auto finish_rows = [&](const spx_dev_batch *cb /* [SPX_N_CLASSES] of the slice */, int64_t r0, int64_t r1, bool wide_first, hipStream_t st) -> int {
         const int32_t nrows = (int32_t)(r1 - r0);
+        if (nrows <= 0) return SPX_OK;
         spx_dev_batch Bm = cb[0];
         Bm.row_base = (int32_t)r0;
-        if (!fast) {
-            if (nrows > 0) HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st));
-            return SPX_OK;
+        if (!fast) { HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); return SPX_OK; }
+        if (w->any_fast_cls) HIPCHK(spx_launch_fast_map(&Bm, &w->fk, nrows, wide_fast ? 1 : 0, st));
+        if (w->any_exact_cls) { Bm.tier_want = SPX_TIER_EXACT; HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); }
+        return SPX_OK;
+    };
+    /* The re-run of the problems the fast tier did not certify waits until the LAST slice's rows are done and then runs on the tail stream,
+     * slice by slice (they share one scratch area), beside the next list's DP kernels: a launch with a single problem still lasts a wave's
+     * lifetime (2-3 ms for a full-length window), so re-running per slice and class on the main stream cost 10-16 ms per slice. */
+    size_t rr_next = 0; /* next unused event of w->rr_ev */
+    auto rr_event = [&](hipEvent_t *out) -> int {
+        if (rr_next == w->rr_ev.size()) {
+            hipEvent_t e = nullptr;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            w->rr_ev.push_back(e);
         }
-        if (nrows > 0 && w->any_fast_cls) HIPCHK(spx_launch_fast_map(&Bm, nrows, st));
-        if (nrows > 0 && w->any_exact_cls) { Bm.tier_want = SPX_TIER_EXACT; HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); }
-        if (w->any_fast_cls) {
-            for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
-                if (!w->cls_used[cls] || !spx_fast_class(cls) || cb[cls].n_order <= 0) continue;
-                spx_dev_batch Br = cb[cls];
-                Br.tier_want = SPX_TIER_RERUN;
-                HIPCHK(spx_launch_baq(cls, 2, &Br, st));
+        *out = w->rr_ev[rr_next++];
+        return SPX_OK;
+    };
+    auto rerun_slice = [&](const spx_dev_batch *cb, int64_t r0, int64_t r1, bool wide_first, hipStream_t st) -> int {
+        if (!fast || !w->any_fast_cls) return SPX_OK;
+        /* the classes' re-runs side by side on the side streams (each launch lasts a wave's lifetime even for one problem): fan out behind
+         * an event on st, join before the MAP kernel.  The slices of a list share their scratch, so slice k+1's re-run starts behind slice k's MAP. */
+        hipEvent_t ev_go = nullptr;
+        { const int rc = rr_event(&ev_go); if (rc) return rc; }
+        HIPCHK(hipEventRecord(ev_go, st));
+        int si = 0;
+        for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+            if (!w->cls_used[cls] || !spx_fast_class(cls) || cb[cls].n_order <= 0) continue;
+            spx_dev_batch Br = cb[cls];
+            Br.tier_want = SPX_TIER_RERUN;
+            hipStream_t ss = serial ? st : c->side_stream[si % c->n_side];
+            if (ss != st) HIPCHK(hipStreamWaitEvent(ss, ev_go, 0));
+            HIPCHK(spx_launch_baq(cls, 2, &Br, ss));
+            if (ss != st) {
+                hipEvent_t ev_d = nullptr;
+                { const int rc = rr_event(&ev_d); if (rc) return rc; }
+                HIPCHK(hipEventRecord(ev_d, ss));
+                HIPCHK(hipStreamWaitEvent(st, ev_d, 0));
             }
-            if (nrows > 0) { Bm.tier_want = SPX_TIER_RERUN; HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); }
+            ++si;
+        }
+        if (r1 > r0) {
+            spx_dev_batch Bm = cb[0];
+            Bm.row_base = (int32_t)r0;
+            Bm.tier_want = SPX_TIER_RERUN;
+            HIPCHK(spx_launch_map(&Bm, (int32_t)(r1 - r0), wide_first, st));
         }
         return SPX_OK;
     };
@@ -1774,6 +1831,7 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls) (spx::class_slots(cls) <= 48 ? narrow : wide) += w->st.problems_per_class[cls];
         const int64_t nrows = w->staged ? w->n_rows_dev : (int64_t)w->hb.rows.size();
         { const int rc = last_map(w->cls_batch, 0, nrows, wide > narrow); if (rc) return rc; }
+        { const int rc = rerun_slice(w->cls_batch, 0, nrows, wide > narrow, tail); if (rc) return rc; }
     }
     } else {
         /* DP slices: forward -> backward -> MAP of one slice after the other over the shared scratch; inside a slice the band
@@ -1806,10 +1864,15 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
             }
             for (int t = 0; t < c->n_side; ++t)
                 if (used_side[t]) HIPCHK(hipStreamWaitEvent(c->stream, c->side_done[t], 0));
-            if (sl.r1 > sl.r0 || fast) {
+            if (sl.r1 > sl.r0 || k + 1 == w->slices.size()) {
                 if (k + 1 == w->slices.size()) { const int rc = last_map(sl.cls_batch, sl.r0, sl.r1, wide > narrow); if (rc) return rc; }
                 else { const int rc = finish_rows(sl.cls_batch, sl.r0, sl.r1, wide > narrow, c->stream); if (rc) return rc; }
             }
+        }
+        for (size_t k = 0; k < w->slices.size(); ++k) {
+            spx_work::Slice &sl = w->slices[k];
+            const int rc = rerun_slice(sl.cls_batch, sl.r0, sl.r1, wide > narrow, tail);
+            if (rc) return rc;
         }
         if (mc >= 0) { /* (the ring's slots stay defined for readers that expect them) */
             HIPCHK(hipEventRecord(ev[3], c->stream));
@@ -1958,7 +2021,8 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         w->st.tier_rows_uncertified = ((int64_t)cnt[3] + 1) / nl;
         const int64_t v[5] = {w->st.tier_fast_problems, w->st.tier_rerun_certificate, w->st.tier_rerun_model, w->st.tier_rerun_range, w->st.tier_rows_uncertified};
         for (int k = 0; k < 5; ++k) g_last_tier[k].store(v[k]);
-    }
+    } else if (w->launched)
+        for (int k = 0; k < 5; ++k) g_last_tier[k].store(0);
     if (w->staged) {
         /* device-prepared list: one packed record per dispatched group (results_kernel), one copy */
         const size_t ng = (size_t)w->n_dgroups;
@@ -2139,6 +2203,7 @@ extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
     if (w->ev_done) (void)hipEventDestroy(w->ev_done);
     for (spx_work::Slice &sl : w->slices)
         for (hipEvent_t e : {sl.ev_start, sl.ev_f0, sl.ev_f1, sl.ev_b1}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : w->rr_ev) if (e) (void)hipEventDestroy(e);
     delete w;
 }
 
@@ -2372,6 +2437,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
     HIPCHK(hipMalloc((void **)&d_ref, ref4.size()));
     HIPCHK(hipMemcpy(d_ref, ref4.data(), ref4.size(), hipMemcpyHostToDevice));
     c->d_ref4 = d_ref;
+    if (n > 0) { w->fast_d = pars[0].d; w->fast_e = pars[0].e; w->fast_set_q = set_q[0]; }
     int rc = build_device_batch(c, w, true, /*allow_fast=*/!post_scale && !pr_out);
     c->d_ref4 = saved;
     if (!rc) rc = spx_launch(c, w);
