@@ -43,13 +43,13 @@ def pmc_traffic(kernel, gps, platform, with_x2=False):
     The guide's x2 correction of FETCH_SIZE on gfx950 applies to 16 B/lane streaming reads; for the access pattern of
     these kernels the counters were calibrated on the backward kernel's known read / write volume:
     factor 1.  None when no profile matches this workload."""
-    for name in (f"r04_counters_{platform}.json", f"r03_counters_{platform}.json", f"r02_counters_{platform}.json", "r01_counters.json"):
+    for name in (f"r06_counters_{platform}.json", f"r05_counters_{platform}.json", f"r04_counters_{platform}.json", f"r03_counters_{platform}.json", f"r02_counters_{platform}.json", "r01_counters.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             meta = prof.get("_meta", {})
             if meta.get("platform", "hifi") != platform or not meta.get("groups_per_step"):
                 continue
-            k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel) or prof.get(kernel)
+            k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel + "(spx_dev_batch, spx_fast_consts)") or prof.get("void " + kernel) or prof.get(kernel)
             # per launch of THIS run: the kernels' traffic is proportional to the groups of a launch (same workload, same
             # per-problem volumes), the profile may have been taken at another batch size
             # (gps = groups per KERNEL launch of this run; the profile's dispatches are kernel launches too: slices of its lists)
@@ -66,13 +66,13 @@ def pmc_traffic(kernel, gps, platform, with_x2=False):
 def pmc_kernel(kernel, gps, platform):
     """(duration alone on the chip in ms, VALU wave-instructions) per launch of `kernel` from the committed PMC passes, scaled to a launch
     of `gps` groups of this run (same workload: both are proportional to the groups of a launch); (None, None, None) without a profile"""
-    for name in (f"r05_counters_{platform}.json", f"r04_counters_{platform}.json", f"r03_counters_{platform}.json"):
+    for name in (f"r06_counters_{platform}.json", f"r05_counters_{platform}.json", f"r04_counters_{platform}.json", f"r03_counters_{platform}.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             meta = prof.get("_meta", {})
             if meta.get("platform", "hifi") != platform or not meta.get("groups_per_step"):
                 continue
-            k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel) or prof.get(kernel)
+            k = prof.get("void " + kernel + "(spx_dev_batch)") or prof.get("void " + kernel + "(spx_dev_batch, spx_fast_consts)") or prof.get("void " + kernel) or prof.get(kernel)
             scale = gps / (meta["groups_per_step"] / max(1, meta.get("kernel_launches_per_step", 1)))
             return k["duration_ns_alone"] * scale / 1e6, k["SQ_INSTS_VALU"] * scale, name
         except Exception:  # noqa: BLE001
@@ -208,6 +208,7 @@ def guard_exposure(genome, params, first, n_groups, ctx, ncpu):
     import numpy as np
     from oracle import orc
     from secphase_amd import api
+    guard_api0, guard_orc0 = api.get_terminal_guard(), orc.get_terminal_guard()  # restored on the way out (a run started with SPX_TERMINAL_GUARD=row stays on it)
     sub = genome.reads(first, n_groups)
     plan = api.Plan(genome.ref, sub.batch, params)
     v = plan.view
@@ -236,6 +237,20 @@ def guard_exposure(genome, params, first, n_groups, ctx, ncpu):
             logs[name] = os.path.join(d, f"oracle.{name}.out.log")
             _, r_ = orc.run_batch(sub.batch, genome.ref, params, threads=min(ncpu, 64), seed=1, reuse_scratch=True, log_path=logs[name])
             scored[name] = [[r_[g].score[a] for a in range(max(r_[g].n_aln, 0))] + [r_[g].best_idx] for g in range(n_groups)]
+        # the -w / --writeBam output: every base quality calc_local_baq leaves in the records (ptMarker.c:706,759,763) under either reading
+        quals = {}
+        try:
+            import ctypes as _C
+            bb = sub.batch.contents
+            end = max((bb.qual_off[a_] + bb.l_qseq[a_] for a_ in range(bb.n_alns)), default=0)
+            q0 = np.frombuffer(_C.string_at(_C.addressof(bb.qual.contents), end), np.uint8).copy()
+            for name, reading in (("band", 0), ("row", 1)):
+                orc.set_terminal_guard(reading)
+                quals[name], _ = orc.run_batch_quals(sub.batch, genome.ref, params, q0.copy(), threads=min(ncpu, 64))
+            res["oracle_write_bam"] = {"qual_bytes": int(end), "qual_bytes_that_differ_between_the_readings": int((quals["band"] != quals["row"]).sum()),
+                                       "qual_bytes_the_baq_changed_band": int((quals["band"] != q0).sum())}
+        except Exception as e:  # noqa: BLE001
+            res["oracle_write_bam"] = {"error": str(e)[:200]}
         orc.set_terminal_guard(0)
         a, b = records_of(logs["band"]), records_of(logs["row"])
         res["oracle"] = {"relabel_records_band": len(a), "relabel_records_row": len(b),
@@ -249,11 +264,29 @@ def guard_exposure(genome, params, first, n_groups, ctx, ncpu):
                 out, _ = ctx.score_batch(sub.batch, params, finalize_seed=1)
                 gpu[name] = [[out[g].score[a_] for a_ in range(max(out[g].n_aln, 0))] + [out[g].best_idx] for g in range(n_groups)]
             api.set_terminal_guard(0)
+            if "band" in quals:
+                try:
+                    import copy
+                    p_all = copy.copy(params)
+                    p_all.flags = 1
+                    diff = {}
+                    for name, reading in (("band", 0), ("row", 1)):
+                        api.set_terminal_guard(reading)
+                        wq = ctx.prepare(sub.batch, p_all)
+                        wq.launch()
+                        wq.collect()
+                        got = wq.apply_quals(sub.batch, q0.copy())
+                        diff[name] = int((got != quals[name]).sum())
+                        wq.free()
+                    res["hip_write_bam"] = {"qual_bytes_that_differ_from_the_oracle_band": diff["band"], "qual_bytes_that_differ_from_the_oracle_row": diff["row"]}
+                except Exception as e:  # noqa: BLE001
+                    res["hip_write_bam"] = {"error": str(e)[:200]}
+                api.set_terminal_guard(0)
             res["hip_path"] = {"groups_whose_scores_or_decision_differ": sum(1 for x, y in zip(gpu["band"], gpu["row"]) if x != y),
                                "equals_oracle_under_band": gpu["band"] == scored["band"], "equals_oracle_under_row": gpu["row"] == scored["row"]}
     finally:
-        orc.set_terminal_guard(0)
-        api.set_terminal_guard(0)
+        orc.set_terminal_guard(guard_orc0)
+        api.set_terminal_guard(guard_api0)
         import shutil
         shutil.rmtree(d, ignore_errors=True)
     return res
@@ -795,22 +828,36 @@ def main():
         # FP64 vector-ALU bound (not HBM, not MFMA): 19 of the 45 flops per band cell are forward flops.
         st0 = per_step_stats[0]
         G, slots = st0.main_class_lanes, st0.main_class_slots
-        kname = f"baq_fwd1_kernel<{slots - 1}>" if G == 1 else f"baq_fwd_kernel<{G}, {slots // G}, 0, false>"
+        tiers_on = bool(L.spx_get_dp_tiers()) and any(p.tier_fast_problems > 0 for p in per_step_stats)
+        if tiers_on:
+            # the fast tier's forward kernel of that class (spx_fast_kernels.hip spx_launch_fast: lanes x slots, exact width, waves per SIMD, fence)
+            fast_names = {42: "fast_fwd_kernel<2, 21, 41, 4, 1>", 44: "fast_fwd_kernel<2, 22, 43, 3, 1>", 46: "fast_fwd_kernel<2, 23, 45, 3, 1>",
+                          (1, 48): "fast_fwd_kernel<2, 24, 47, 3, 1>", (2, 48): "fast_fwd_kernel<2, 24, 0, 3, 1>", 64: "fast_fwd_kernel<4, 16, 0, 4, 1>",
+                          104: "fast_fwd_kernel<4, 26, 0, 3, 1>", 112: "fast_fwd_kernel<4, 28, 0, 3, 1>", 120: "fast_fwd_kernel<4, 30, 0, 2, 1>"}
+            kname = fast_names.get(slots) or fast_names.get((G, slots)) or (f"baq_fwd1_kernel<{slots - 1}>" if G == 1 else f"baq_fwd_kernel<{G}, {slots // G}, 0, false>")
+        else:
+            kname = f"baq_fwd1_kernel<{slots - 1}>" if G == 1 else f"baq_fwd_kernel<{G}, {slots // G}, 0, false>"
         # (a sliced list launches the kernel once per DP slice: the roofline is per KERNEL launch -- what a kernel trace shows)
         n_slices = max(1, int(round(sum(max(1, p.dp_slices) for p in per_step_stats) / nst)))
         fwd_ms = sum(p.main_fwd_ms for p in per_step_stats) / nst / n_slices
         bwd_ms = sum(p.main_bwd_ms for p in per_step_stats) / nst
         baq_ms = sum(p.baq_kernel_ms for p in per_step_stats) / nst
         score_ms = sum(p.score_kernel_ms for p in per_step_stats) / nst
+        # round 6: the two spans separately.  dp_critical: what a list keeps the MAIN stream for (first DP kernel -> behind its last backward / MAP
+        # kernel); tail_span: re-runs of uncertified problems + scoring kernels on the result stream BESIDE the next list's DP kernels (start of its
+        # first kernel -> end of its last, waiting for the chip included).  Only the first is inside the step's critical path.
+        crit_ms = sum(p.dp_critical_ms for p in per_step_stats) / nst
+        tail_ms = sum(p.tail_span_ms for p in per_step_stats) / nst
+        fast_prob = sum(p.tier_fast_problems for p in per_step_stats) / nst
+        rerun_prob = sum(p.tier_rerun_certificate + p.tier_rerun_model + p.tier_rerun_range for p in per_step_stats) / nst
         cls_cells = sum(p.main_class_cells for p in per_step_stats) / nst / n_slices
         achieved_tf = FWD_FLOPS_PER_CELL * cls_cells / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
         # whole BAQ phase (forward + backward + MAP, all classes) at the algorithm's 45 flop per cell
-        phase_tf = FLOPS_PER_CELL * cells / (baq_ms * 1e-3) / 1e12 if baq_ms > 0 else 0.0
+        phase_tf = FLOPS_PER_CELL * cells / (crit_ms * 1e-3) / 1e12 if crit_ms > 0 else 0.0
         compulsory = n_prob * 1700  # ~1.7 KB of compulsory HBM bytes per DP problem
         alone_ms, valu_insts, pmc_src = pmc_kernel(kname, gps / n_slices, args.platform)
         roofline = {
-            "bound": "mfma",  # the compute roof of the two the contract names; the kernels issue no MFMA: see "bound_actual"
-            "bound_actual": "valu_fp64",
+            "bound": "valu_fp64",  # FP64 VECTOR ALU (no MFMA is issued; MI355X's FP64 MFMA peak equals its FP64 vector peak, so the roof is the same number)
             "compute_unit": "valu_fp64",
             # the same kernel ALONE on the chip (rocprofv3 --pmc serialises the dispatches; committed pass, scaled to this launch size):
             # what the kernel can do when nothing runs beside it -- `frac` is what it gets inside the pipelined step
@@ -836,21 +883,23 @@ def main():
                             "`traffic` takes the counters as they read: calibrated on the backward kernel's known volume (DESIGN 3.1), these 8-16 B per lane, "
                             "partly scattered accesses are not under-reported; `traffic_if_fetch_size_counts_half` applies the guide's gfx950 correction for "
                             "16 B/lane streaming reads (FETCH_SIZE x 2) anyway, as the upper bound",
-            "note": "compute-bound, but on the FP64 VECTOR ALU, not on the matrix cores: the DP has sequential dependences "
-                    "inside every row and MFMA's fused rounding would break bit-exactness; MI355X's FP64 MFMA peak equals "
-                    "its FP64 vector peak (78.6 TFLOP/s), so the roof is the same number. "
-                    "rows live in VGPRs/LDS: FP64 vector-ALU work under the package power limit (the big kernels run at "
-                    "1.8-2.0 GHz, ~85% of the VALU issue slots), not HBM/MFMA. peak = vector FP64 at 2.4 GHz with FMA counted "
-                    "as 2; the bit-exact path may not fuse mul+add, so 39.3 is the attainable ceiling. algorithmic flops: "
-                    "19 (forward) of 45 per band cell, SURVEY 8(d); avg_launch_ms = HIP events on the launch stream, "
-                    "averaged over the timed steps (the other band classes, and the preparation kernels of the next batch, "
-                    "run beside it on their own streams)",
-            "phase": {"what": "forward + backward + MAP kernels, all band classes, 45 flop per band cell",
+            "tier": ("fast (certified) + exact re-run of uncertified problems" if tiers_on else "exact"),
+            "executed_flops_per_cell": (11 if tiers_on else 19),
+            "note": "compute-bound on the FP64 VECTOR ALU, not on the matrix cores (sequential dependences inside every row). "
+                    "`achieved` = ALGORITHMIC forward flops (19 per band cell of the class, SURVEY 8(d): the reference's forward pass over every "
+                    "row) / the kernel's launch duration.  With the two-tier DP (DESIGN 3.4) the kernel that answers is the FAST forward kernel: same "
+                    "model, fused multiply-adds, no row sums, rows behind a problem's last wanted row not walked (they have no observable "
+                    "effect: 73 % of the rows of this workload are walked) -- it executes ~11 flops per cell it walks (6 FP64 instructions, 5 of "
+                    "them fma) -- and the exact kernels re-run the `flagged_problem_fraction` its certificate does not cover.  peak = vector FP64 "
+                    "at 2.4 GHz with FMA counted as 2.  avg_launch_ms = HIP events on the launch stream, averaged over the timed steps (the other "
+                    "band classes, and the preparation kernels of the next batch, run beside it on their own streams)",
+            "flagged_problem_fraction": round(rerun_prob / fast_prob, 7) if fast_prob > 0 else None,
+            "phase": {"what": "forward + backward + MAP kernels, all band classes, 45 algorithmic flop per band cell, over the list's span on the main stream (dp_critical_path)",
                       "achieved": round(phase_tf, 3), "frac": round(phase_tf / PEAK_FP64_VECTOR_TFLOPS, 4),
-                      "ms_per_launch": round(baq_ms, 4), "backward_kernel_ms": round(bwd_ms, 4)},
-            "hbm": {"bound": "hbm", "achieved": round(compulsory / (baq_ms * 1e-3) / 1e9, 2) if baq_ms > 0 else 0.0,
+                      "ms_per_launch": round(crit_ms, 4), "backward_kernel_ms": round(bwd_ms, 4)},
+            "hbm": {"bound": "hbm", "achieved": round(compulsory / (crit_ms * 1e-3) / 1e9, 2) if crit_ms > 0 else 0.0,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(compulsory / (baq_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6) if baq_ms > 0 else 0.0,
+                    "frac": round(compulsory / (crit_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6) if crit_ms > 0 else 0.0,
                     "algorithmic_bytes_per_launch": int(compulsory)},
         }
         cpu = None
@@ -989,7 +1038,12 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "kernel_ms_per_step": {"baq": round(baq_ms, 3), "score": round(score_ms, 3)},
+            # what ONE list keeps the main stream for (every figure below is <= ms_per_step; the tail runs beside the NEXT list's DP kernels)
+            "kernel_ms_per_step": {"dp_critical_path": round(crit_ms, 3), "main_class_forward": round(fwd_ms * n_slices, 3), "main_class_backward": round(bwd_ms, 3),
+                                   "score": round(score_ms, 3)},
+            "tail_span_ms": round(tail_ms, 3),
+            "dp_tiers": {"on": tiers_on, "fast_class_problems_per_step": int(fast_prob), "rerun_problems_per_step": round(rerun_prob, 1),
+                         "flagged_problem_fraction": round(rerun_prob / fast_prob, 7) if fast_prob > 0 else None},
             "dp_cells_per_s": round(cells_all * args.steps / elapsed, 1),
             "dp_problems_per_s": round(n_prob_all * args.steps / elapsed, 1),
             "setup_s": {"genome": round(t_genome, 2), "generate": round(t_gen, 2), "stage_records_to_hbm": round(t_stage, 2)},

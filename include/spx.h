@@ -97,6 +97,11 @@ typedef struct spx_stats {
      * wanted row was not certified / the problem is outside the fast tier's model (ambiguous base, degenerate constants) / a row's values
      * spanned too many binades; rows not certified.  Per launch, averaged like the *_ms fields.  All 0 when the tiers are off. */
     int64_t tier_fast_problems, tier_rerun_certificate, tier_rerun_model, tier_rerun_range, tier_rows_uncertified;
+    /* round 6: the two spans baq_kernel_ms adds up, separately.  dp_critical_ms: main stream, first DP kernel of the list -> behind its last backward
+     * kernel (and, with the two-tier DP, behind the MAP kernels of every slice): what the list keeps the main stream for.  tail_span_ms: what follows on
+     * the result stream BESIDE the next list's DP kernels -- last MAP kernel (tiers off), re-runs of uncertified problems, marker filter / score /
+     * decision / result kernels -- from its first kernel's start to its last kernel's end (waiting for the chip included). */
+    double dp_critical_ms, tail_span_ms;
 } spx_stats;
 
 const char *spx_strerror(int code);

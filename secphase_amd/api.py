@@ -60,6 +60,7 @@ class Stats(C.Structure):
         ("n_launches_averaged", C.c_int32), ("dp_slices", C.c_int32), ("reserved_", C.c_int32),
         ("tier_fast_problems", C.c_int64), ("tier_rerun_certificate", C.c_int64), ("tier_rerun_model", C.c_int64),
         ("tier_rerun_range", C.c_int64), ("tier_rows_uncertified", C.c_int64),
+        ("dp_critical_ms", C.c_double), ("tail_span_ms", C.c_double),
     ]
 
 

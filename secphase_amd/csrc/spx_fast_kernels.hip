@@ -575,17 +575,31 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
     break;
     /* the exact band widths of the HiFi preset: one lane per problem (no lane exchange, 2 x W doubles of state: the register file is
      * full at two waves per SIMD) or two lanes (half the state per lane, one carry per row) -- SPX_FAST_HIFI_G / SPX_FAST_HIFI_GB */
+    /* a class' launch may go out in several pieces (SPX_FAST_PIECES, default 1): between two pieces the chip drains for a moment and the
+     * kernels of the next list's preparation, queued on other streams, get slots (spx_kernels.hip SPX_DP_PIECES) */
+    static const int n_pieces = [] { const char *e = getenv("SPX_FAST_PIECES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    auto pieces = [&](int blocks, int ppw, bool bwd, auto &&launch) {
+        if (blocks <= 0) return;
+        int per = (blocks + n_pieces - 1) / n_pieces;
+        if (per < 2048) per = blocks < 2048 ? blocks : 2048;
+        for (int b0 = 0; b0 < blocks; b0 += per) {
+            spx_dev_batch Q = P;
+            if (bwd) { Q.order_bwd += (int64_t)b0 * ppw; Q.n_order_bwd -= b0 * ppw; }
+            else { Q.order += (int64_t)b0 * ppw; Q.n_order -= b0 * ppw; }
+            launch(Q, blocks - b0 < per ? blocks - b0 : per);
+        }
+    };
     static const int hifi_g = [] { const char *e = getenv("SPX_FAST_HIFI_G"); return e ? atoi(e) : 2; }();
     static const int hifi_gb = [] { const char *e = getenv("SPX_FAST_HIFI_GB"); return e ? atoi(e) : 2; }();
 #define SPX_FAST_HIFI(W_, C2_, WF_)                                                                                            \
     {                                                                                                                       \
         if (phase != 1 && B->n_order > 0) {                                                                                 \
             if (hifi_g == 1) hipLaunchKernelGGL((fast_fwd_kernel<1, W_, W_>), dim3((B->n_order + 63) / 64), dim3(64), 0, st, P, *K); \
-            else hipLaunchKernelGGL((fast_fwd_kernel<2, C2_, W_, WF_>), dim3((B->n_order + 31) / 32), dim3(64), 0, st, P, *K);   \
+            else pieces((B->n_order + 31) / 32, 32, false, [&](const spx_dev_batch &Q, int nb) { hipLaunchKernelGGL((fast_fwd_kernel<2, C2_, W_, WF_>), dim3(nb), dim3(64), 0, st, Q, *K); }); \
         }                                                                                                                   \
         if (phase != 0 && B->n_order_bwd > 0) {                                                                             \
             if (hifi_gb == 1) hipLaunchKernelGGL((fast_bwd_kernel<1, W_, W_>), dim3((B->n_order_bwd + 63) / 64), dim3(64), 0, st, P, *K); \
-            else hipLaunchKernelGGL((fast_bwd_kernel<2, C2_, W_, SPX_FAST_HIFI_WAVES>), dim3((B->n_order_bwd + 31) / 32), dim3(64), 0, st, P, *K); \
+            else pieces((B->n_order_bwd + 31) / 32, 32, true, [&](const spx_dev_batch &Q, int nb) { hipLaunchKernelGGL((fast_bwd_kernel<2, C2_, W_, SPX_FAST_HIFI_WAVES>), dim3(nb), dim3(64), 0, st, Q, *K); }); \
         }                                                                                                                   \
     }                                                                                                                       \
     break;

@@ -10,6 +10,7 @@
  * preparation and main streams of the context).  Results come back in SUBMISSION order, which is what the rand()
  * replay of the decision (spx_finalizer_apply) and the relabel list need: the output equals the reference at -@1.
  */
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -71,9 +72,17 @@ struct spx_pipe {
     spx_alloc_gate *gate = nullptr;
 };
 
+static double pipe_now()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
 static void run_job(spx_pipe *p, Job *j)
 {
     int rc = SPX_OK;
+    static const bool timing = getenv("SPX_TIMING") != nullptr;
+    const double t_a = pipe_now();
+    double t_b = 0, t_c = 0, t_d = 0, t_e = 0;
     const bool stage_here = !j->work;
     if (stage_here) { /* the host half runs beside the copies of the submission in front */
         rc = spx_internal_stage_begin(p->ctx, j->batches.data(), (int32_t)j->batches.size(), &p->par, p->stage_threads, &j->work);
@@ -89,17 +98,21 @@ static void run_job(spx_pipe *p, Job *j)
         ++p->stage_turn;
     }
     p->cv_turn.notify_all();
+    t_b = pipe_now();
     if (rc == SPX_OK) {
         spx_internal_work_gate(j->work, p->gate, j->ticket);
         rc = spx_prepare_staged(p->ctx, j->work);
         spx_internal_work_gate(j->work, nullptr, 0);
     }
+    t_c = pipe_now();
     spx_internal_gate_skip(p->gate, j->ticket); /* (no-op when the preparation went through the gate) */
     {
         std::unique_lock<std::mutex> lk(p->mu);
         p->cv_turn.wait(lk, [&] { return p->launch_turn == j->ticket; });
     }
+    t_d = pipe_now();
     if (rc == SPX_OK) rc = spx_launch(p->ctx, j->work);
+    t_e = pipe_now();
     {
         std::lock_guard<std::mutex> lk(p->mu);
         ++p->launch_turn;
@@ -109,6 +122,9 @@ static void run_job(spx_pipe *p, Job *j)
         j->out.resize((size_t)(j->n_groups > 0 ? j->n_groups : 1));
         rc = spx_collect(p->ctx, j->work, j->out.data());
     }
+    if (timing)
+        fprintf(stderr, "[spx timing] pipe job %lld: start %.3f | staged +%.3f | prepared (host) +%.3f | launch turn +%.3f | launched +%.3f | collected +%.3f s\n", (long long)j->ticket,
+                t_a, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, pipe_now() - t_e);
     if (rc != SPX_OK) j->err = spx_last_error();
     j->rc = rc;
 }

@@ -1795,7 +1795,12 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         }
         return SPX_OK;
     };
+    /* With the tiers on, the last slice's MAP kernels stay on the main stream (SPX_LAST_MAP_MAIN=0: on the tail stream like the exact MAP
+     * kernel): beside the next list's DP kernels the fast MAP kernel of 131 072 HiFi groups took 33 ms instead of 4, and the re-runs and
+     * the scoring kernels wait for it. */
+    static const bool last_map_main = [] { const char *e = getenv("SPX_LAST_MAP_MAIN"); return !e || atoi(e) != 0; }(); /* default on (round 6: +2 %) */
     auto last_map = [&](const spx_dev_batch *cb, int64_t r0, int64_t r1, bool wide_first) -> int {
+        if (fast && last_map_main) { const int rc = finish_rows(cb, r0, r1, wide_first, c->stream); if (rc) return rc; return open_tail(); }
         { const int rc = open_tail(); if (rc) return rc; }
         return finish_rows(cb, r0, r1, wide_first, tail);
     };
@@ -1955,7 +1960,7 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         /* averages over THIS work list's launches since its previous collect (those whose events are still in the ring);
          * other work lists launched in between have their own slots.  Timing is diagnostics: a failing event query
          * zeroes the figures instead of failing the collect */
-        double baq = 0, sc = 0, fw = 0, bw = 0;
+        double baq = 0, sc = 0, fw = 0, bw = 0, crit = 0, tailsp = 0;
         int n = 0;
         bool ok = true;
         for (int64_t l : w->launch_ids) {
@@ -1964,6 +1969,9 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
             float ms = 0;
             ok = ok && hipEventElapsedTime(&ms, ev[0], ev[6]) == hipSuccess; /* the DP kernels ... */
             baq += ms;
+            crit += ms;
+            ok = ok && hipEventElapsedTime(&ms, ev[7], ev[2]) == hipSuccess;
+            tailsp += ms;
             ok = ok && hipEventElapsedTime(&ms, ev[7], ev[1]) == hipSuccess; /* ... + the last MAP kernel where it ran (not the time it waited for the stream) */
             baq += ms;
             ok = ok && hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess;
@@ -1993,7 +2001,9 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         }
         if (!ok) { (void)hipGetLastError(); n = 0; }
         const double dn = n > 0 ? (double)n : 1.0;
-        if (n == 0) baq = sc = fw = bw = 0;
+        if (n == 0) baq = sc = fw = bw = crit = tailsp = 0;
+        w->st.dp_critical_ms = crit / dn;
+        w->st.tail_span_ms = tailsp / dn;
         w->st.baq_kernel_ms = baq / dn;
         w->st.score_kernel_ms = sc / dn;
         w->st.n_launches_averaged = n;

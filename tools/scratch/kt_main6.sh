@@ -21,6 +21,25 @@ for r in sel:
     gap = (x - prev) / 1e6 if prev else 0
     print(f'{(x-t0)/1e6:8.1f} -> {(y-t0)/1e6:8.1f} ({(y-x)/1e6:6.2f} ms; gap before {gap:6.2f})  {r["Kernel_Name"][:60]}')
     prev = y
+ms = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in sel if r["Stream_Id"] == sid)
+gaps = [(ms[i][1], ms[i + 1][0]) for i in range(len(ms) - 1) if ms[i + 1][0] - ms[i][1] > 8e6]
+for a, e in gaps[:2]:
+    print(f"gap on the main stream {(a-t0)/1e6:.1f} -> {(e-t0)/1e6:.1f} ms ({(e-a)/1e6:.1f} ms): kernels overlapping [gap - 30 ms, gap end]:")
+    for r in sel:
+        x, y = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if x < e and y > a - 30e6 and r["Stream_Id"] != sid: print(f'      {(x-t0)/1e6:8.1f} -> {(y-t0)/1e6:8.1f} ({(y-x)/1e6:6.2f}) stream {r["Stream_Id"]:>3} {r["Kernel_Name"][:70]}')
+# one preparation lane's kernels over the window
+prep = collections.Counter(r["Stream_Id"] for r in sel if "aln_emit" in r["Kernel_Name"])
+if prep:
+    ps = prep.most_common(1)[0][0]
+    print("preparation stream", ps)
+    prev = None
+    for r in sel:
+        if r["Stream_Id"] != ps: continue
+        x, y = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if (y - x) > 0.3e6 or (prev and x - prev > 1e6):
+            print(f'   {(x-t0)/1e6:8.1f} -> {(y-t0)/1e6:8.1f} ({(y-x)/1e6:6.2f} ms; gap before {((x-prev)/1e6 if prev else 0):6.2f})  {r["Kernel_Name"][:70]}')
+        prev = y
 # per-stream busy time
 busy = collections.defaultdict(float)
 for r in sel: busy[r["Stream_Id"]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
