@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64, WAVES) void fast_fwd_kernel(spx_dev_batch B, sp
     const int Wu = W0 ? W0 : wave_max(act ? 2 * bw + 1 : 0);
     const int Lw = wave_max(L);
     if (Lw == 0) return;
-    int fast_end = min(wave_min(act ? R - bw : 0x7fffffff), Lw);
+    int fast_end = Lw;
     if (G * C - Wu > PADMAX) fast_end = 1;
     const int jbase = g * C;
     const int SLOTS = (int)(B.fsave_stride >> 1);
@@ -283,9 +283,16 @@ __global__ __launch_bounds__(64, WAVES) void fast_fwd_kernel(spx_dev_batch B, sp
             }
         }
     };
+    /* A block of 16 rows takes the masked variant when some problem of the wave that is still walking reaches, inside the block, the rows
+     * whose band touches column R (the launch order goes by the rows walked, so a wave mixes reference lengths: one wave-wide bound would
+     * mask most rows), or when the wave's padding is wider than the FAST variant handles.  (Chosen per block, in two separate loops: a
+     * per-row choice inside one loop made the register allocator spill hundreds of values.) */
+    const bool all_masked = fast_end <= 1;
     for (int i0 = 2; i0 <= Lw; i0 += FAST_RESCALE_MASK + 1) {
         rescale(i0);
-        const int i1 = min(i0 + FAST_RESCALE_MASK, Lw), if1 = min(i1, fast_end);
+        const int i1 = min(i0 + FAST_RESCALE_MASK, Lw);
+        const int if1 = (all_masked || __any(act && i0 <= L && min(i1, L) + bw > R)) ? i0 - 1 : i1; /* (two loops one behind the other with
+                                                                                                       * bounds, not an if / else: register allocation) */
         int i = i0;
         for (; i <= if1; ++i) row(i, std::true_type{});
         for (; i <= i1; ++i) row(i, std::false_type{});
@@ -429,14 +436,16 @@ __global__ __launch_bounds__(64, WAVES) void fast_bwd_kernel(spx_dev_batch B, sp
             if (i == prev_row) save_row();
         }
     };
-    /* the last step of the longest problems is row 1; only steps that can be a row 1 take the FIRST variant (masked, D row times y) */
-    const int t_first = wave_min(act && nb == L - 1 && nb > 0 ? nb - 1 : 0x7fffffff);
+    /* a block of 16 steps in which some problem of the wave computes its row 1 (step L - 2) takes the FIRST variant (masked, D row times
+     * y = 0 on that row); the first n_slow steps the masked one; every other block the FAST one -- three separate loops, see the forward kernel */
     for (int t0 = 0; t0 < nbw; t0 += FAST_RESCALE_MASK + 1) {
         rescale(t0);
         const int t1 = min(t0 + FAST_RESCALE_MASK + 1, nbw);
+        const bool blk_first = __any(act && nb == L - 1 && nb > 0 && L - 2 >= t0 && L - 2 < t1), blk_slow = t0 < n_slow;
+        const int ta = blk_first ? t0 : (blk_slow ? t1 : t0), tb = blk_first ? t0 : t1; /* [t0,ta) masked, [ta,tb) fast, [tb,t1) first: one is not empty */
         int t = t0;
-        for (; t < min(t1, min(n_slow, t_first)); ++t) row(t, std::false_type{}, std::false_type{});
-        for (; t < min(t1, t_first); ++t) row(t, std::true_type{}, std::false_type{});
+        for (; t < ta; ++t) row(t, std::false_type{}, std::false_type{});
+        for (; t < tb; ++t) row(t, std::true_type{}, std::false_type{});
         for (; t < t1; ++t) row(t, std::false_type{}, std::true_type{});
     }
     if (act && flagged && g == 0) {
@@ -589,6 +598,7 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
             launch(Q, blocks - b0 < per ? blocks - b0 : per);
         }
     };
+    static const int ont_waves = [] { const char *e = getenv("SPX_X_ONT_WAVES"); return e ? atoi(e) : 0; }(); /* experiment: waves per SIMD of the (4,28) kernels */
     static const int hifi_g = [] { const char *e = getenv("SPX_FAST_HIFI_G"); return e ? atoi(e) : 2; }();
     static const int hifi_gb = [] { const char *e = getenv("SPX_FAST_HIFI_GB"); return e ? atoi(e) : 2; }();
 #define SPX_FAST_HIFI(W_, C2_, WF_)                                                                                            \
@@ -639,7 +649,10 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
     case 5: SPX_FAST(4, 16, 4, 3)
     case 6: SPX_FAST(4, 26, 3, 2)
 #endif
-    case 12: SPX_FAST(4, 28, 3, 2)
+    case 12:
+        if (ont_waves == 2) { SPX_FAST(4, 28, 2, 2) }
+        else if (ont_waves == 32) { SPX_FAST(4, 28, 3, 3) }
+        SPX_FAST(4, 28, 3, 2)
 #ifndef SPX_FAST_ONLY
     case 13: SPX_FAST(4, 30, 2, 2)
 #endif

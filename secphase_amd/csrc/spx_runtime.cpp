@@ -116,6 +116,11 @@ struct spx_ctx {
                                       * and the chain 45 -> 47 -> (4,26) of small, latency-bound launches was the longest path of a slice) */
     hipStream_t side_stream[SPX_N_SIDE] = {};
     hipEvent_t side_done[SPX_N_SIDE] = {};
+    /* two-tier DP: the exact re-runs of uncertified problems fan out over streams of their own (SPX_RERUN_STREAMS, default 3; 0: over the side
+     * streams -- where they stood in front of the NEXT list's side classes, and the main stream waited ~20 ms per mixed list at its join) */
+    static const int SPX_N_RERUN = 4;
+    int n_rerun = 3;
+    hipStream_t rerun_stream[SPX_N_RERUN] = {};
     /* host -> HBM copies of staged records, and NOTHING else: once a kernel or a memset has gone through a stream the
      * runtime serves its copies with a copy KERNEL instead of the DMA engines -- 18-24 GB/s beside the DP kernels instead
      * of 52 (tools/scratch/h2d_probe.hip) */
@@ -280,6 +285,9 @@ struct spx_work {
     int32_t *d_tier = nullptr, *d_tier_counts = nullptr;
     spx_fast_consts fk;
     bool fast = false, any_fast_cls = false, any_exact_cls = false;
+    bool cls_fast[SPX_N_CLASSES] = {}; /* the classes of THIS list that take the fast tier: those with a fast kernel that hold a share of the list's band
+                                        * cells worth it (SPX_FAST_MIN_SHARE percent, default 8) -- every class with a fast tier costs a re-run launch per
+                                        * slice, and a launch lasts a wave's lifetime however few problems it has (the mixed workload's nine classes) */
     float fast_d = 0, fast_e = 0; /* host-built lists (spx_probaln_batch): the parameters of problem 0; problems with others take the exact tier */
     int fast_set_q = 0;
     int64_t n_launches_counted = 0; /* launches since the counters were last reset by a preparation */
@@ -421,6 +429,8 @@ extern "C" int spx_create(int device, spx_ctx **out)
         HIPCHK(mk_stream(&c->side_stream[i], m_dp));
         HIPCHK(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming | hipEventBlockingSync));
     }
+    if (const char *e = getenv("SPX_RERUN_STREAMS")) c->n_rerun = std::max(0, std::min((int)spx_ctx::SPX_N_RERUN, atoi(e)));
+    for (int i = 0; i < c->n_rerun; ++i) HIPCHK(mk_stream(&c->rerun_stream[i], m_dp));
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->unpack_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->result_stream, hipStreamNonBlocking));
@@ -494,6 +504,7 @@ extern "C" void spx_destroy(spx_ctx *c)
     for (int i = 0; i < spx_ctx::SPX_N_SIDE; ++i) {
         if (c->side_done[i]) (void)hipEventDestroy(c->side_done[i]);
         if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
+        if (i < spx_ctx::SPX_N_RERUN && c->rerun_stream[i]) (void)hipStreamDestroy(c->rerun_stream[i]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->unpack_stream) (void)hipStreamDestroy(c->unpack_stream);
@@ -601,6 +612,28 @@ extern "C" int spx_last_tier_stats(int64_t *out /* 5: fast problems, re-run by c
     if (!out) return fail(SPX_EINVAL, "NULL argument");
     for (int k = 0; k < 5; ++k) out[k] = g_last_tier[k].load();
     return SPX_OK;
+}
+/* which band classes of a list take the fast tier (spx_work::cls_fast) */
+static void fast_classes(spx_work *w)
+{
+    int share = 8;
+    if (const char *e = getenv("SPX_FAST_MIN_SHARE")) share = std::max(0, std::min(100, atoi(e)));
+    int64_t tot = 0;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) tot += w->cls_used[cls] ? w->cls_cells[cls] : 0;
+    /* ... and the list as a whole takes the tiers only if those classes hold most of its cells (SPX_FAST_MIN_TOTAL percent, default 85): the mixed
+     * 2-100 kb workload spreads its cells over nine classes, its lists are small, and the fast tier's extra launches (MAP twice, re-runs) cost it more
+     * than its faster forward kernel gains (measured: 169-175 k groups/s with the tiers, 195-200 k without) */
+    int min_total = 85;
+    if (const char *e = getenv("SPX_FAST_MIN_TOTAL")) min_total = std::max(0, std::min(100, atoi(e)));
+    int64_t in_fast = 0;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
+        if (w->fast && w->cls_used[cls] && spx_fast_class(cls) && w->cls_cells[cls] * 100 >= tot * share) in_fast += w->cls_cells[cls];
+    if (w->fast && in_fast * 100 < tot * min_total) w->fast = false;
+    w->any_fast_cls = w->any_exact_cls = false;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
+        w->cls_fast[cls] = w->fast && w->cls_used[cls] && spx_fast_class(cls) && w->cls_cells[cls] * 100 >= tot * share;
+        if (w->cls_used[cls]) (w->cls_fast[cls] ? w->any_fast_cls : w->any_exact_cls) = true;
+    }
 }
 /* constants every problem of a launch shares (spx_device.h spx_fast_consts), from the list's (d, e, set_q) exactly as
  * spxl::hmm_constants forms them (float expressions promoted), without the (1 - sM) factors.
@@ -739,6 +772,8 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool a
     w->d_tier = (int32_t *)(base + o_tier);
     w->d_tier_counts = w->d_tier + np;
     w->n_launches_counted = 0;
+    for (int cls = 0; cls < SPX_N_CLASSES; ++cls) w->cls_used[cls] = !order[cls].empty();
+    fast_classes(w); /* (may decide against the tiers for this list) */
     if (w->fast) {
         fast_constants(w->fast_d, w->fast_e, w->fast_set_q, &w->fk);
         HIPCHK(hipMemsetAsync(w->d_tier, 0xff, (np + 8) * sizeof(int32_t), c->stream));
@@ -809,9 +844,6 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool a
         B.tier_counts = w->fast ? w->d_tier_counts : nullptr;
         B.tier_want = SPX_TIER_ALL;
     }
-    w->any_fast_cls = w->any_exact_cls = false;
-    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
-        if (w->cls_used[cls]) (w->fast && spx_fast_class(cls) ? w->any_fast_cls : w->any_exact_cls) = true;
     spx_dev_groups &G = w->dg;
     memset(&G, 0, sizeof G);
     G.n_groups = (int32_t)ng;
@@ -1538,9 +1570,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     if (w->fast) {
         fast_constants((float)w->par.conf_d, (float)w->par.conf_e, w->par.set_q, &w->fk);
     }
-    w->any_fast_cls = w->any_exact_cls = false;
-    for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
-        if (w->cls_used[cls]) (w->fast && spx_fast_class(cls) ? w->any_fast_cls : w->any_exact_cls) = true;
+    fast_classes(w);
     if (np) {
         const size_t nbins = (size_t)K * SPX_N_CLASSES * 1024;
         if ((rc = ensure_pool(PL, PL.pool_bins, nbins * 6 * sizeof(int32_t) + 256))) return fail(rc, "device memory for the launch-order bins");
@@ -1735,12 +1765,12 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
      * MAP over their rows. */
     const bool fast = w->fast;
     auto launch_cls = [&](int cls, int phase, const spx_dev_batch *Bc, hipStream_t st) -> hipError_t {
-        if (fast && spx_fast_class(cls)) return spx_launch_fast(cls, phase, Bc, &w->fk, st);
+        if (w->cls_fast[cls]) return spx_launch_fast(cls, phase, Bc, &w->fk, st);
         return spx_launch_baq(cls, phase, Bc, st);
     };
     bool wide_fast = false; /* a fast class with more than 48 slots is in the list: the wide MAP instantiation */
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
-        if (w->cls_used[cls] && spx_fast_class(cls) && spx::class_slots(cls) > 48) wide_fast = true;
+        if (w->cls_fast[cls] && spx::class_slots(cls) > 48) wide_fast = true;
     auto finish_rows = [&](const spx_dev_batch *cb /* [SPX_N_CLASSES] of the slice */, int64_t r0, int64_t r1, bool wide_first, hipStream_t st) -> int {
         const int32_t nrows = (int32_t)(r1 - r0);
         if (nrows <= 0) return SPX_OK;
@@ -1773,10 +1803,10 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         HIPCHK(hipEventRecord(ev_go, st));
         int si = 0;
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls) {
-            if (!w->cls_used[cls] || !spx_fast_class(cls) || cb[cls].n_order <= 0) continue;
+            if (!w->cls_fast[cls] || cb[cls].n_order <= 0) continue;
             spx_dev_batch Br = cb[cls];
             Br.tier_want = SPX_TIER_RERUN;
-            hipStream_t ss = serial ? st : c->side_stream[si % c->n_side];
+            hipStream_t ss = serial ? st : (c->n_rerun > 0 ? c->rerun_stream[si % c->n_rerun] : c->side_stream[si % c->n_side]);
             if (ss != st) HIPCHK(hipStreamWaitEvent(ss, ev_go, 0));
             HIPCHK(spx_launch_baq(cls, 2, &Br, ss));
             if (ss != st) {
@@ -2024,7 +2054,7 @@ extern "C" int spx_collect(spx_ctx *c, spx_work *w, spx_group_out *out)
         if (hipMemcpy(cnt, w->d_tier_counts, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
         const int64_t nl = std::max<int64_t>(1, w->n_launches_counted);
         for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
-            if (spx_fast_class(cls)) w->st.tier_fast_problems += w->st.problems_per_class[cls];
+            if (w->cls_fast[cls]) w->st.tier_fast_problems += w->st.problems_per_class[cls];
         w->st.tier_rerun_certificate = ((int64_t)cnt[0] + 1) / nl;
         w->st.tier_rerun_model = ((int64_t)cnt[1] + 1) / nl;
         w->st.tier_rerun_range = ((int64_t)cnt[2] + 1) / nl;
@@ -2506,7 +2536,7 @@ static int probaln_run(spx_ctx *c, int32_t n, const uint8_t *ref, const int64_t 
             int32_t cnt[4] = {-1, -1, -1, -1};
             if (hipMemcpy(cnt, w->d_tier_counts, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
             int64_t nf = 0;
-            for (int32_t p = 0; p < n; ++p) nf += spx_fast_class(spx::band_class(2 * hb.bw[p] + 1)) ? 1 : 0;
+            for (int32_t p = 0; p < n; ++p) nf += w->cls_fast[spx::band_class(2 * hb.bw[p] + 1)] ? 1 : 0;
             g_last_tier[0].store(nf);
             for (int k = 0; k < 4; ++k) g_last_tier[k + 1].store((int64_t)cnt[k] + 1);
         } else

@@ -76,8 +76,10 @@ def test_fast_tier_ont_windows(ctx, tiers):
 
 
 @pytest.mark.parametrize("bw", [3, 10, 21, 24, 27, 30, 35, 40, 45, 51, 52, 55, 59])
-def test_fast_tier_every_band_class(ctx, tiers, bw):
+def test_fast_tier_every_band_class(ctx, tiers, bw, monkeypatch):
     """generic classes (2,24), (4,16), (4,26), (4,28), (4,30) at widths that leave 0 .. many slots beyond the band"""
+    monkeypatch.setenv("SPX_FAST_MIN_SHARE", "0")  # (every class with a fast kernel takes it, however few cells it holds)
+    monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")
     tiers(1)
     rng = np.random.default_rng(100 + bw)
     probs = [_rand_problem(rng, int(rng.integers(20, 500)), 0.01, 0.02) for _ in range(64)]
@@ -85,7 +87,9 @@ def test_fast_tier_every_band_class(ctx, tiers, bw):
     _check(ctx, probs, [25] * len(probs), pars)
 
 
-def test_fast_tier_small_and_degenerate(ctx, tiers):
+def test_fast_tier_small_and_degenerate(ctx, tiers, monkeypatch):
+    monkeypatch.setenv("SPX_FAST_MIN_SHARE", "0")
+    monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")
     tiers(1)
     rng = np.random.default_rng(63)
     probs, pars = [], []
@@ -101,8 +105,10 @@ def test_fast_tier_small_and_degenerate(ctx, tiers):
     _check(ctx, probs, [30] * len(probs), pars)
 
 
-def test_fast_tier_outside_the_model(ctx, tiers):
+def test_fast_tier_outside_the_model(ctx, tiers, monkeypatch):
     """ambiguous bases, unrelated sequences (dynamic range), extreme parameters: all answered by the exact re-run"""
+    monkeypatch.setenv("SPX_FAST_MIN_SHARE", "0")
+    monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")
     tiers(1)
     rng = np.random.default_rng(64)
     probs = [_rand_problem(rng, int(rng.integers(100, 400)), 0.01, 0.01, n_frac=0.03) for _ in range(32)]
@@ -119,8 +125,10 @@ def test_fast_tier_outside_the_model(ctx, tiers):
     _check(ctx, probs, [93 if k % 4 == 0 else 5 for k in range(16)], pars)
 
 
-def test_nothing_certified_equals_everything_certified(ctx, tiers):
+def test_nothing_certified_equals_everything_certified(ctx, tiers, monkeypatch):
     """test mode 2: the fast kernels run, every range check fails, every problem is re-run by the exact kernels"""
+    monkeypatch.setenv("SPX_FAST_MIN_SHARE", "0")
+    monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")
     rng = np.random.default_rng(65)
     probs, sq, pars = _hifi_problems(rng, 96)
     p2, s2, r2 = _ont_problems(rng, 48)
@@ -132,9 +140,10 @@ def test_nothing_certified_equals_everything_certified(ctx, tiers):
 
 
 @pytest.mark.parametrize("guard", [orc.GUARD_BAND, orc.GUARD_ROW])
-def test_fast_tier_under_both_guard_readings(ctx, tiers, guard):
+def test_fast_tier_under_both_guard_readings(ctx, tiers, guard, monkeypatch):
     """blocks of <= 50 bases under `-b 50` (l_query <= bw, 2 bw + 1 > l_ref): the one band cell the two readings of probaln.c's terminal
     guard treat differently -- the fast tier follows the same switch"""
+    monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")
     tiers(1)
     rng = np.random.default_rng(66)
     old_a, old_o = api.get_terminal_guard(), orc.get_terminal_guard()
@@ -151,8 +160,9 @@ def test_fast_tier_under_both_guard_readings(ctx, tiers, guard):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_batches_in_every_tier_mode(ctx, tiers, tmp_path, mode):
+def test_batches_in_every_tier_mode(ctx, tiers, tmp_path, mode, monkeypatch):
     """whole batches (scores, decisions, relabel list byte for byte): exact kernels alone, two tiers, two tiers with nothing certified"""
+    monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")  # (also the mixed batch, whose cells spread over many classes, takes the tiers)
     tiers(mode)
     g = small_genome(synth.HIFI)
     _batch_parity(ctx, g, g.reads(0, 96), records.preset("hifi"), tmp_path, f"hifi{mode}")

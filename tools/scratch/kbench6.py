@@ -29,4 +29,5 @@ for tiers in ([int(x) for x in os.environ.get("KB_TIERS", "1,0").split(",")]):
     print(f"{plat} tiers={tiers}: {n} groups, {st.n_problems} problems, {st.dp_cells/1e9:.2f} Gcells, slices {st.dp_slices}: wall/launch {dt*1e3:.2f} ms, baq {st.baq_kernel_ms:.2f} ms, "
           f"main cls {st.main_class} fwd {st.main_fwd_ms:.2f} bwd {st.main_bwd_ms:.2f} ms ({st.main_class_cells/1e9:.2f} Gcells -> fwd {19*st.main_class_cells/max(st.main_fwd_ms,1e-9)/1e9:.1f} TFLOP/s), score {st.score_kernel_ms:.2f}; "
           f"tiers fast {st.tier_fast_problems} rerun cert/model/range {st.tier_rerun_certificate}/{st.tier_rerun_model}/{st.tier_rerun_range} rows {st.tier_rows_uncertified}", flush=True)
+    print("   problems per class:", [int(x) for x in st.problems_per_class][:14])
     w.free()
