@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64, WAVES) void fast_fwd_kernel(spx_dev_batch B, sp
     int fast_end = Lw;
     if (G * C - Wu > PADMAX) fast_end = 1;
     const int jbase = g * C;
-    const int SLOTS = (int)(B.fsave_stride >> 1);
+    const int SLOTS = (int)(B.fsave_stride >> 2); /* a wanted row of the fast tier: [U | V | Bm | Bi][slots] */
 
     double U[C], V[C];
     NibWin<C> cw;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64, WAVES) void fast_bwd_kernel(spx_dev_batch B, sp
     const int nrows = act ? P.nrows : 0, row0 = P.row0;
     const int stop = act ? B.rows[row0] : 0x7fffffff; /* first (smallest) wanted row */
     const int jbase = g * C;
-    const int SLOTS = (int)(B.fsave_stride >> 1);
+    const int SLOTS = (int)(B.fsave_stride >> 2);
     const int64_t fstride = B.fsave_stride;
 
     double Bm[C], Bi[C];
@@ -353,13 +353,15 @@ __global__ __launch_bounds__(64, WAVES) void fast_bwd_kernel(spx_dev_batch B, sp
     double *fsave = B.fsave + (act ? B.fsave_off[P.pid] : 0);
     int wprev = nrows - 1;
     int prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
-    /* wanted row: saved forward rows (U, It) times the backward rows, in place */
+    /* wanted row: the backward rows go BESIDE the saved forward rows ([row][U | V | Bm | Bi][slots]); the MAP kernel forms the products.
+     * (Round 6: multiplying in place -- load, multiply, store -- left these kernels 72 % of their wave cycles in s_waitcnt: the forward rows
+     * were written long ago and come from HBM.  Touching the next wanted row's lines ahead of time did not help: they do not survive in L2.) */
     auto save_row = [&]() {
-        double *dst = fsave + (int64_t)wprev * fstride + jbase;
+        double *dst = fsave + (int64_t)wprev * fstride + 2 * SLOTS + jbase;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            dst[c] = dst[c] * Bm[c];
-            dst[SLOTS + c] = dst[SLOTS + c] * Bi[c];
+            dst[c] = Bm[c];
+            dst[SLOTS + c] = Bi[c];
         }
         wprev--;
         prev_row = wprev >= 0 ? B.rows[row0 + wprev] : -1;
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, spx_fast
     if (B.tier[p] != SPX_TIER_FAST) on = false;
     const int i = B.rows[rr], bw = B.bw[p], R = B.R[p], L = B.L[p];
     const int W = 2 * bw + 1, slots = B.prob_slots[p], Cq = (slots + LPR - 1) / LPR;
-    const int64_t off = B.fsave_off[p] + (int64_t)(rr - B.row_off[p]) * 2 * slots;
-    const double *zM = B.fsave + off, *zI = zM + slots;
+    const int64_t off = B.fsave_off[p] + (int64_t)(rr - B.row_off[p]) * 4 * slots;
+    const double *zM = B.fsave + off, *zI = zM + slots; /* forward rows U, V; the backward rows Bm, Bi follow at 2 * slots */
     const int j0 = max(0, bw + 1 - i), j1 = min(W - 1, R - i + bw); /* 1 <= k = i - bw + j <= R */
     const double emU = K.emU, exU = K.exU, rho = K.rho;
     const uint32_t qy = on ? fetch_code(B.qry4, B.qry_nib[p], i - 1, L) : 0;
@@ -488,8 +490,8 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, spx_fast
         double m = 0.0, ii = 0.0;
         if (in) {
             const uint32_t code = (codes[c >> 3] >> (4 * (c & 7))) & 0xfu;
-            m = zM[j] * (code == qy ? emU : exU);
-            ii = zI[j] * rho;
+            m = (zM[j] * zM[2 * slots + j]) * (code == qy ? emU : exU);
+            ii = (zI[j] * zI[2 * slots + j]) * rho;
         }
         z[2 * c] = m; z[2 * c + 1] = ii;
     };
@@ -573,6 +575,7 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
 {
     if (B->n_order <= 0 && B->n_order_bwd <= 0) return hipSuccess;
     spx_dev_batch P = *B;
+    P.fsave_stride = 2 * B->fsave_stride; /* four rows of slots per wanted row (B holds the exact tier's stride: two) */
     P.tier_want = SPX_TIER_ALL; /* the fast kernels take every problem of the class and sort them into tiers themselves */
 #define SPX_FAST(G_, C_, WF_, WB_)                                                                                          \
     {                                                                                                                       \

@@ -108,6 +108,8 @@ struct Params {
     float d, e;
     float qf; /* (float)pow(10, -set_q/10.), host libm */
     int32_t table_min_cols, table_rounds; /* flank_break_rounds(): groups with at least so many columns, the first so many rounds (<= kTableRounds) */
+    int32_t row_mult; /* doubles a wanted row takes in the DP scratch, in units of its class' slots: 2 (M, I rows: the exact tier) or 4 (two-tier DP: the fast
+                       * tier's forward rows U, V and backward rows Bm, Bi side by side; the exact tier uses the first half of a problem's share) */
 };
 
 /* ---------------- band classes = DP kernel instantiations (keep in step with spx_launch_baq) ---------------- */
@@ -1447,13 +1449,13 @@ SPX_HD int plan_baq_range(const GroupView &G, int ai, const Pools &P, const RefV
                 gc.cls_prob[cls]++;
                 gc.cls_cells[cls] += cells;
                 gc.s_need += 8 + ((L + 2 + 7) & ~7);
-                gc.f_need += (int64_t)nrows * 2 * slots;
+                gc.f_need += (int64_t)nrows * (par.row_mult > 2 ? par.row_mult : 2) * slots;
             }
             at.prob++;
             at.row += nrows;
             /* whole 64-byte lines behind a lead pad of one line: the one-lane forward kernel writes 1/s[] eight rows at a time */
             at.s_off += 8 + ((L + 2 + 7) & ~7);
-            at.f_off += (int64_t)nrows * 2 * slots;
+            at.f_off += (int64_t)nrows * (par.row_mult > 2 ? par.row_mult : 2) * slots;
         }
         /* markers in the trailing margin lose their quality */
         while (c >= 0 && c < ncol && cb <= b.sqe) {

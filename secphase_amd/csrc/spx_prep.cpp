@@ -129,6 +129,7 @@ spxl::Params logic_params(const spx_params *par)
         if (const char *e = getenv("SPX_WINDOW_TABLE")) { if (sscanf(e, "%d,%d", &mc, &r) < 2) r = spxl::kTableRounds; }
         return std::make_pair(mc < 2 ? 2 : mc, r < 0 ? 0 : (r > spxl::kTableRounds ? spxl::kTableRounds : r));
     }();
+    p.row_mult = 2; /* (spx_prepare_staged raises it to 4 for the two-tier DP) */
     p.table_min_cols = table.first;
     p.table_rounds = table.second;
     return p;

@@ -729,6 +729,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool a
     }
     const double tb1 = now_s();
     /* scratch offsets */
+    const int row_mult = (allow_fast && spx_get_dp_tiers() != 0) ? 4 : 2; /* two-tier DP: forward and backward rows side by side (spxl::Params::row_mult) */
     std::vector<int64_t> s_off(np), fsave_off(np);
     std::vector<int32_t> prob_slots(np), row_prob(nr);
     int64_t s_tot = 0, f_tot = 0;
@@ -738,7 +739,7 @@ static int build_device_batch(spx_ctx *c, spx_work *w, bool want_state_q, bool a
         s_tot += 8 + ((hb.L[p] + 2 + 7) & ~7);
         fsave_off[p] = f_tot;
         prob_slots[p] = spx::class_slots(spx::band_class(2 * hb.bw[p] + 1));
-        f_tot += (int64_t)hb.n_rows[p] * 2 * prob_slots[p];
+        f_tot += (int64_t)hb.n_rows[p] * row_mult * prob_slots[p];
         for (int32_t w2 = 0; w2 < hb.n_rows[p]; ++w2) row_prob[hb.row_off[p] + w2] = (int32_t)p;
     }
     /* arena layout */
@@ -1290,6 +1291,7 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.P.mm = (spxl::MM *)PL.pool_mm.p;
     A.rv = c->d_rv;
     A.par = spx::logic_params(&w->par);
+    if (spx_get_dp_tiers() != 0) A.par.row_mult = 4; /* two-tier DP: a wanted row holds the fast tier's forward AND backward rows */
     A.gc = (spxl::GroupCount *)(base + w->o_gc);
     A.ac = (spxl::GroupCount *)(base + w->o_ac);
     A.ga_bytes = (int64_t *)(base + w->o_gab);
