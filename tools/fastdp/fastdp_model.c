@@ -38,6 +38,14 @@
 #include "fastdp_model.h"
 
 #define EI 0.25
+/* the rows saved at the wanted rows (forward M, I; backward Bm, Bi) are kept as FP32 (half the scratch, half the MAP kernel's traffic): each
+ * posterior product takes two such roundings, (1 + 2^-24)^2 - 1 < 2^-22 = FDP_DELTA_STORE, and values below the FP32 range flush to zero
+ * (a row that loses its mass that way has no largest product and is flagged) */
+#if FDP_STORE_FLOAT
+#define FDP_STORE(x) ((double)(float)(x))
+#else
+#define FDP_STORE(x) (x)
+#endif
 #define U53 1.1102230246251565e-16 /* 2^-53 */
 
 enum { H_M0 = 0, H_M1, H_M2, H_M3, H_M4, H_M6, H_M8, H_BM, H_BI, H_SM, H_SI, H_EMATCH, H_EMIS, H_HASN, H_TDROP };
@@ -63,7 +71,7 @@ int fdp_phred(double x, const double *thr)
     return lo > 100 ? 99 : lo;
 }
 
-double fdp_delta(int L, int R, int W) { return FDP_DELTA_PER_STEP * ((double)L + R + W + 16) * U53; }
+double fdp_delta(int L, int R, int W) { return FDP_DELTA_PER_STEP * ((double)L + R + W + 16) * U53 + FDP_DELTA_STORE; }
 
 /* certificate of one row from its posterior products z[0..n) (column order: M, I per column), see fastdp_model.h */
 int fdp_certify(const double *z, int n, int k0, double delta, double A, const double *thr, int *state, int *q, double *x_out)
@@ -144,7 +152,7 @@ int fdp_glocal(const uint8_t *ref, int R, const uint8_t *qry, int L, const doubl
                 M = e * h[H_BM];
                 It = (EI * h[H_BI]) / gam;
             }
-            if (sv) { sv[j] = M; sv[W + j] = rho * It; }
+            if (sv) { sv[j] = FDP_STORE(M); sv[W + j] = FDP_STORE(rho * It); }
             U[j] = fma(cU0, M, cU1 * It);
             V[j] = fma(c4, It, M);
         }
@@ -177,7 +185,7 @@ int fdp_glocal(const uint8_t *ref, int R, const uint8_t *qry, int L, const doubl
             const double M = e * U[j];
             const double It = j + 1 < W ? V[j + 1] : 0.0;
             Dt = (j > 0 && valid) ? fma(m8, Dt, Mprev) : 0.0;
-            if (sv) { sv[j] = M; sv[W + j] = rho * It; }
+            if (sv) { sv[j] = FDP_STORE(M); sv[W + j] = FDP_STORE(rho * It); }
             U[j] = fma(cU0, M, fma(cU1, It, Dt));
             V[j] = fma(c4, It, M);
             if (!valid) { U[j] = 0.0; V[j] = (k < 1) ? V[j] : 0.0; } /* (k < 1: zero by induction anyway) */
@@ -232,8 +240,8 @@ int fdp_glocal(const uint8_t *ref, int R, const uint8_t *qry, int L, const doubl
             const int j0 = bw + 1 - i > 0 ? bw + 1 - i : 0, j1 = (R - i + bw < W - 1) ? R - i + bw : W - 1;
             int n = 0;
             for (int j = j0; j <= j1; ++j) {
-                zrow[n++] = sv[j] * Bm[j];
-                zrow[n++] = sv[W + j] * Bi[j];
+                zrow[n++] = sv[j] * FDP_STORE(Bm[j]);
+                zrow[n++] = sv[W + j] * FDP_STORE(Bi[j]);
             }
             int st, qq;
             double x;

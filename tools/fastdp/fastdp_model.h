@@ -30,6 +30,14 @@ extern "C" {
 #define FDP_DELTA_PER_STEP 48.0
 #endif
 
+/* FP32 storage of the saved rows (fastdp_model.c FDP_STORE): studied in round 6 and NOT adopted -- it halves the scratch and the MAP kernel's
+ * traffic, still with 0 uncertified mismatches, but the wider delta flags 0.04 % (HiFi) / 0.6 % (ONT, mixed) of the problems through near-ties
+ * of the two largest products, and a re-run problem costs its whole wave in the exact kernels (ONT: ~9 % of the waves).  -DFDP_STORE_FLOAT=1. */
+#ifndef FDP_STORE_FLOAT
+#define FDP_STORE_FLOAT 0
+#endif
+#define FDP_DELTA_STORE (FDP_STORE_FLOAT ? 2.384185791015625e-07 /* 2^-22 */ : 0.0)
+
 /* why a row / problem is not certified */
 #define FDP_F_ARGMAX 1  /* two largest z closer than delta */
 #define FDP_F_THRESH 2  /* 1 - max/sum within its error interval of a phred threshold */
