@@ -183,6 +183,13 @@ struct spx_ctx {
     /* the scratch slack the consensus rounds of some list of this context needed (1, 4, 16 ..): later lists start with it instead of finding it
      * out again by an overflow and a second run of the whole group phase (round 5: two of seven mixed batches paid that at EVERY preparation) */
     std::atomic<int> slack_hint{1};
+    /* two-tier DP: what the latest list that looked decided (fast_classes: -1 nobody has looked yet, 1 tiers, 0 exact kernels only).  The lists of a run are
+     * alike, and the decision is only known after the counting phase, which already needs the row size (4 rows of slots per wanted row with the tiers, 2
+     * without): lists that follow a "0" are counted with 2 and do not look again, except every 32nd (the mixed 2-100 kb workload: its lists had twice the
+     * scratch for nothing, and at eight lists in flight the step went from 79 to 171 ms) */
+    std::atomic<int> tiers_hint{-1};
+    std::atomic<unsigned> tiers_looks{0};
+    std::atomic<int> tiers_epoch{0};
 };
 
 /* grow-only device buffer of a preparation lane; the caller holds the lane's mutex.  Kernels of an earlier preparation
@@ -285,6 +292,7 @@ struct spx_work {
     int32_t *d_tier = nullptr, *d_tier_counts = nullptr;
     spx_fast_consts fk;
     bool fast = false, any_fast_cls = false, any_exact_cls = false;
+    bool tiers_look = false; /* this list was counted with the fast tier's row size and decides for itself (spx_ctx::tiers_hint) */
     bool cls_fast[SPX_N_CLASSES] = {}; /* the classes of THIS list that take the fast tier: those with a fast kernel that hold a share of the list's band
                                         * cells worth it (SPX_FAST_MIN_SHARE percent, default 8) -- every class with a fast tier costs a re-run launch per
                                         * slice, and a launch lasts a wave's lifetime however few problems it has (the mixed workload's nine classes) */
@@ -591,6 +599,7 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap);
 
 /* ---- two-tier DP switch and constants ---- */
 static std::atomic<int> g_dp_tiers{-1};
+static std::atomic<int> g_dp_tiers_epoch{0}; /* bumped by spx_set_dp_tiers: contexts forget what their earlier lists decided (spx_ctx::tiers_hint) */
 extern "C" int spx_get_dp_tiers(void)
 {
     int v = g_dp_tiers.load();
@@ -604,6 +613,7 @@ extern "C" int spx_get_dp_tiers(void)
 extern "C" int spx_set_dp_tiers(int on)
 {
     g_dp_tiers.store(on < 0 ? 0 : (on > 2 ? 1 : on)); /* 2 = test mode: the fast tier runs but certifies nothing (every problem is re-run) */
+    g_dp_tiers_epoch.fetch_add(1);
     return SPX_OK;
 }
 static std::atomic<int64_t> g_last_tier[5];
@@ -620,10 +630,12 @@ static void fast_classes(spx_work *w)
     if (const char *e = getenv("SPX_FAST_MIN_SHARE")) share = std::max(0, std::min(100, atoi(e)));
     int64_t tot = 0;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls) tot += w->cls_used[cls] ? w->cls_cells[cls] : 0;
-    /* ... and the list as a whole takes the tiers only if those classes hold most of its cells (SPX_FAST_MIN_TOTAL percent, default 85): the mixed
+    /* ... and the list as a whole takes the tiers only if those classes hold most of its cells (SPX_FAST_MIN_TOTAL percent, default 92): the mixed
      * 2-100 kb workload spreads its cells over nine classes, its lists are small, and the fast tier's extra launches (MAP twice, re-runs) cost it more
-     * than its faster forward kernel gains (measured: 169-175 k groups/s with the tiers, 195-200 k without) */
-    int min_total = 85;
+     * than its faster forward kernel gains (measured at four lists in flight: 195 k groups/s either way; at eight lists in flight on six preparation
+     * lanes, the configuration that is fastest for it: 117 k with the tiers -- twice the scratch per list -- and 213 k without; its fast classes hold
+     * ~87 % of its cells, those of the HiFi and ONT presets 97-98 %) */
+    int min_total = 92;
     if (const char *e = getenv("SPX_FAST_MIN_TOTAL")) min_total = std::max(0, std::min(100, atoi(e)));
     int64_t in_fast = 0;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
@@ -1291,7 +1303,10 @@ static void fill_prep_args(spx_ctx *c, spx_work *w)
     A.P.mm = (spxl::MM *)PL.pool_mm.p;
     A.rv = c->d_rv;
     A.par = spx::logic_params(&w->par);
-    if (spx_get_dp_tiers() != 0) A.par.row_mult = 4; /* two-tier DP: a wanted row holds the fast tier's forward AND backward rows */
+    /* two-tier DP: a wanted row holds the fast tier's forward AND backward rows -- unless the lists in front of this one decided against the tiers */
+    if (c->tiers_epoch.exchange(g_dp_tiers_epoch.load()) != g_dp_tiers_epoch.load()) c->tiers_hint.store(-1);
+    w->tiers_look = spx_get_dp_tiers() != 0 && (c->tiers_hint.load() != 0 || (c->tiers_looks.fetch_add(1) % 32) == 31);
+    if (w->tiers_look) A.par.row_mult = 4;
     A.gc = (spxl::GroupCount *)(base + w->o_gc);
     A.ac = (spxl::GroupCount *)(base + w->o_ac);
     A.ga_bytes = (int64_t *)(base + w->o_gab);
@@ -1566,7 +1581,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     /* launch orders: ONE fill for both order arrays (consecutive in the arena), one for the bins of both passes, one pair of sorts for all
      * DP slices (round 4: two fills + a pair of sorts + a fill per slice) */
     HIPCHK(hipMemsetAsync(B0 + o_order_f, 0xff, (o_tier - o_order_f) + (np + 8) * 4, PL.stream));
-    w->fast = spx_get_dp_tiers() != 0 && np > 0;
+    w->fast = w->tiers_look && np > 0;
     w->d_tier = (int32_t *)(B0 + o_tier);
     w->d_tier_counts = w->d_tier + np;
     w->n_launches_counted = 0;
@@ -1574,6 +1589,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         fast_constants((float)w->par.conf_d, (float)w->par.conf_e, w->par.set_q, &w->fk);
     }
     fast_classes(w);
+    if (w->tiers_look && np > 0) c->tiers_hint.store(w->fast ? 1 : 0);
     if (np) {
         const size_t nbins = (size_t)K * SPX_N_CLASSES * 1024;
         if ((rc = ensure_pool(PL, PL.pool_bins, nbins * 6 * sizeof(int32_t) + 256))) return fail(rc, "device memory for the launch-order bins");
