@@ -476,20 +476,24 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, spx_fast
     const double emU = K.emU, exU = K.exU, rho = K.rho;
     const uint32_t qy = on ? fetch_code(B.qry4, B.qry_nib[p], i - 1, L) : 0;
     const int64_t ref0 = B.ref_nib[p];
-    /* this lane's z values (M, I per slot), 0 outside [j0, j1]; the reference codes of its slots arrive eight per fetch
-     * (slot j of row i <-> reference index i - bw + j - 1; the pool's lead pad covers the indices in front of a window) */
+    /* this lane's z values (M, I per slot), 0 outside [j0, j1].  The LPR lanes of a row take the slots INTERLEAVED, slot j = c * LPR + g: every
+     * load of the row is then one 64-byte segment (a contiguous share per lane -- 128 B apart for the 112-slot ONT rows -- made the kernel as
+     * long as the class' forward kernel: 19.7 ms per ONT slice).  The certificate needs no column order: ties flag the row.  The reference codes of
+     * eight consecutive slots arrive as one word, the same for the lanes of a row (slot j of row i <-> reference index i - bw + j - 1; the pool's
+     * lead pad covers the indices in front of a window) */
     double z[2 * CQ];
     const int cq_wave = wave_max(on ? Cq : 0);
     double best = 0.0, second = 0.0;
     int best_t = -1; /* index into z[] */
-    uint32_t codes[(CQ + 7) / 8];
+    uint32_t codes[CQ];
 #pragma unroll
-    for (int k = 0; k < (CQ + 7) / 8; ++k) codes[k] = on ? fetch8(B.ref4, ref0 + (i - bw + g * Cq - 1) + 8 * k) : 0;
+    for (int c = 0; c < CQ; ++c) codes[c] = (on && c < Cq) ? fetch8(B.ref4, ref0 + (i - bw - 1) + LPR * c) : 0;
+    static_assert(LPR == 8, "one code word (eight codes) per round of the row's lanes");
     auto load = [&](int c, int j) {
         const bool in = on && c < Cq && j >= j0 && j <= j1;
         double m = 0.0, ii = 0.0;
         if (in) {
-            const uint32_t code = (codes[c >> 3] >> (4 * (c & 7))) & 0xfu;
+            const uint32_t code = (codes[c] >> (4 * g)) & 0xfu;
             m = (zM[j] * zM[2 * slots + j]) * (code == qy ? emU : exU);
             ii = (zI[j] * zI[2 * slots + j]) * rho;
         }
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, spx_fast
         return;
     }
 #pragma unroll
-    for (int c = 0; c < CQ; ++c) load(c, g * Cq + c);
+    for (int c = 0; c < CQ; ++c) load(c, c * LPR + g);
     bool bad = false;
 #pragma unroll
     for (int t = 0; t < 2 * CQ; ++t) {
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, spx_fast
             if (atomicCAS(&B.tier[p], SPX_TIER_FAST, SPX_TIER_RERUN) == SPX_TIER_FAST && B.tier_counts) atomicAdd(&B.tier_counts[0], 1);
             if (B.tier_counts) atomicAdd(&B.tier_counts[3], 1);
         } else {
-            const int j = best_lane * Cq + (best_t >> 1);
+            const int j = (best_t >> 1) * LPR + best_lane;
             const int best_k = ((i - bw + j - 1) << 2) | (best_t & 1);
             const uint32_t q = q_lo;
             if (B.out_state) B.out_state[r] = best_k;
@@ -585,10 +589,9 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
         if (phase != 0 && blocks_b > 0) hipLaunchKernelGGL((fast_bwd_kernel<G_, C_, 0, WB_>), dim3(blocks_b), dim3(64), 0, st, P, *K); \
     }                                                                                                                       \
     break;
-    /* the exact band widths of the HiFi preset: one lane per problem (no lane exchange, 2 x W doubles of state: the register file is
-     * full at two waves per SIMD) or two lanes (half the state per lane, one carry per row) -- SPX_FAST_HIFI_G / SPX_FAST_HIFI_GB */
     /* a class' launch may go out in several pieces (SPX_FAST_PIECES, default 1): between two pieces the chip drains for a moment and the
-     * kernels of the next list's preparation, queued on other streams, get slots (spx_kernels.hip SPX_DP_PIECES) */
+     * kernels of the next list's preparation, queued on other streams, get slots (spx_kernels.hip SPX_DP_PIECES; measured with the fast
+     * kernels: 4 pieces -2 %, 8 and 16 +-0) */
     static const int n_pieces = [] { const char *e = getenv("SPX_FAST_PIECES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
     auto pieces = [&](int blocks, int ppw, bool bwd, auto &&launch) {
         if (blocks <= 0) return;
@@ -601,64 +604,29 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
             launch(Q, blocks - b0 < per ? blocks - b0 : per);
         }
     };
-    static const int ont_waves = [] { const char *e = getenv("SPX_X_ONT_WAVES"); return e ? atoi(e) : 0; }(); /* experiment: waves per SIMD of the (4,28) kernels */
-    static const int hifi_g = [] { const char *e = getenv("SPX_FAST_HIFI_G"); return e ? atoi(e) : 2; }();
-    static const int hifi_gb = [] { const char *e = getenv("SPX_FAST_HIFI_GB"); return e ? atoi(e) : 2; }();
-#define SPX_FAST_HIFI(W_, C2_, WF_)                                                                                            \
+    /* The exact band widths of the HiFi preset (W = 41, 43, 45, 47): TWO lanes per problem, C = (W + 1) / 2 slots each, W known at compile time
+     * (one slot beyond the band in the second lane).  ONE lane per problem -- no lane exchange, no carry, 28 % fewer instructions per cell --
+     * was measured too: its 2 x W doubles of state fill the register file at two waves per SIMD, the forward kernel spills its bookkeeping
+     * (54 spill instructions, one reload per row) and ran 11.4 ms against 9.1 for 32 768 groups; the backward kernel (no spills) 5.1 against 6.4,
+     * the two together no faster than two lanes.  Waves per SIMD: forward W = 41 four (128 VGPRs), every other kernel three. */
+#define SPX_FAST_HIFI(W_, C2_, WF_)                                                                                         \
     {                                                                                                                       \
-        if (phase != 1 && B->n_order > 0) {                                                                                 \
-            if (hifi_g == 1) hipLaunchKernelGGL((fast_fwd_kernel<1, W_, W_>), dim3((B->n_order + 63) / 64), dim3(64), 0, st, P, *K); \
-            else pieces((B->n_order + 31) / 32, 32, false, [&](const spx_dev_batch &Q, int nb) { hipLaunchKernelGGL((fast_fwd_kernel<2, C2_, W_, WF_>), dim3(nb), dim3(64), 0, st, Q, *K); }); \
-        }                                                                                                                   \
-        if (phase != 0 && B->n_order_bwd > 0) {                                                                             \
-            if (hifi_gb == 1) hipLaunchKernelGGL((fast_bwd_kernel<1, W_, W_>), dim3((B->n_order_bwd + 63) / 64), dim3(64), 0, st, P, *K); \
-            else pieces((B->n_order_bwd + 31) / 32, 32, true, [&](const spx_dev_batch &Q, int nb) { hipLaunchKernelGGL((fast_bwd_kernel<2, C2_, W_, SPX_FAST_HIFI_WAVES>), dim3(nb), dim3(64), 0, st, Q, *K); }); \
-        }                                                                                                                   \
+        if (phase != 1 && B->n_order > 0)                                                                                   \
+            pieces((B->n_order + 31) / 32, 32, false, [&](const spx_dev_batch &Q, int nb) { hipLaunchKernelGGL((fast_fwd_kernel<2, C2_, W_, WF_>), dim3(nb), dim3(64), 0, st, Q, *K); }); \
+        if (phase != 0 && B->n_order_bwd > 0)                                                                               \
+            pieces((B->n_order_bwd + 31) / 32, 32, true, [&](const spx_dev_batch &Q, int nb) { hipLaunchKernelGGL((fast_bwd_kernel<2, C2_, W_, SPX_FAST_HIFI_WAVES>), dim3(nb), dim3(64), 0, st, Q, *K); }); \
     }                                                                                                                       \
     break;
-    static const int x_fence = [] { const char *e = getenv("SPX_X_FENCE"); return e ? atoi(e) : -1; }();
-    static const int x_waves = [] { const char *e = getenv("SPX_X_WAVES"); return e ? atoi(e) : 0; }();
-#define SPX_FAST_HIFI_X(W_, C2_, G_, WV_, F_)                                                                              \
-    {                                                                                                                       \
-        constexpr int cc = G_ == 1 ? W_ : C2_;                                                                              \
-        if (phase != 1 && B->n_order > 0) hipLaunchKernelGGL((fast_fwd_kernel<G_, cc, W_, WV_, F_>), dim3((B->n_order + 64 / G_ - 1) / (64 / G_)), dim3(64), 0, st, P, *K); \
-        if (phase != 0 && B->n_order_bwd > 0) hipLaunchKernelGGL((fast_bwd_kernel<G_, cc, W_, WV_, F_>), dim3((B->n_order_bwd + 64 / G_ - 1) / (64 / G_)), dim3(64), 0, st, P, *K); \
-        return hipGetLastError();                                                                                           \
-    }
-    if (cls == 0 && x_fence >= 0) { /* experiment: fence spacing / waves per SIMD of the W = 41 kernels (fwd and bwd lanes = SPX_FAST_HIFI_G) */
-        if (hifi_g == 1) {
-            if (x_fence == 0) SPX_FAST_HIFI_X(41, 21, 1, 2, 0)
-            if (x_fence == 2) SPX_FAST_HIFI_X(41, 21, 1, 2, 2)
-            if (x_fence == 4) SPX_FAST_HIFI_X(41, 21, 1, 2, 4)
-            if (x_fence == 8) SPX_FAST_HIFI_X(41, 21, 1, 2, 8)
-        } else if (x_waves == 4) {
-            if (x_fence == 0) SPX_FAST_HIFI_X(41, 21, 2, 4, 0)
-            if (x_fence == 1) SPX_FAST_HIFI_X(41, 21, 2, 4, 1)
-            if (x_fence == 4) SPX_FAST_HIFI_X(41, 21, 2, 4, 4)
-        } else {
-            if (x_fence == 0) SPX_FAST_HIFI_X(41, 21, 2, 3, 0)
-            if (x_fence == 2) SPX_FAST_HIFI_X(41, 21, 2, 3, 2)
-            if (x_fence == 4) SPX_FAST_HIFI_X(41, 21, 2, 3, 4)
-            if (x_fence == 8) SPX_FAST_HIFI_X(41, 21, 2, 3, 8)
-        }
-    }
     switch (cls) {
     case 0: SPX_FAST_HIFI(41, 21, 4)
-#ifndef SPX_FAST_ONLY
     case 1: SPX_FAST_HIFI(43, 22, 3)
     case 2: SPX_FAST_HIFI(45, 23, 3)
     case 3: SPX_FAST_HIFI(47, 24, 3)
     case 4: SPX_FAST(2, 24, 3, 2)
     case 5: SPX_FAST(4, 16, 4, 3)
     case 6: SPX_FAST(4, 26, 3, 2)
-#endif
-    case 12:
-        if (ont_waves == 2) { SPX_FAST(4, 28, 2, 2) }
-        else if (ont_waves == 32) { SPX_FAST(4, 28, 3, 3) }
-        SPX_FAST(4, 28, 3, 2)
-#ifndef SPX_FAST_ONLY
+    case 12: SPX_FAST(4, 28, 3, 2)
     case 13: SPX_FAST(4, 30, 2, 2)
-#endif
     default: return hipErrorInvalidValue;
     }
 #undef SPX_FAST
