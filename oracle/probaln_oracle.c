@@ -110,14 +110,16 @@ static double *scratch_zeroed(size_t n_doubles)
 
 /* which reading of the terminal guard the oracle follows: 0 = `u >= bw2*3+3` (default), 1 = `u >= i_dim-3`.  Process-wide; initial
  * value from SPX_TERMINAL_GUARD (band|row), like the product's switch (include/spx.h spx_set_terminal_guard). */
-static int g_term_guard = -1;
+static _Atomic int g_term_guard = -1; /* (atomic: worker threads of orc_run_batch read it, the first of them initialises it) */
 int orc_get_terminal_guard(void)
 {
-    if (g_term_guard < 0) {
+    int v = g_term_guard;
+    if (v < 0) {
         const char *e = getenv("SPX_TERMINAL_GUARD");
-        g_term_guard = (e && (!strcmp(e, "row") || !strcmp(e, "1") || !strcmp(e, "idim"))) ? 1 : 0;
+        v = (e && (!strcmp(e, "row") || !strcmp(e, "1") || !strcmp(e, "idim"))) ? 1 : 0;
+        g_term_guard = v;
     }
-    return g_term_guard;
+    return v;
 }
 void orc_set_terminal_guard(int reading) { g_term_guard = reading ? 1 : 0; }
 

@@ -55,7 +55,7 @@ int main(int argc, char *argv[])
                             "\tapplies the relabel list of secphase (primary / secondary flags swapped where the list says so), sets MAPQs from a table,\n"
                             "\tfilters secondary alignments, short reads, short alignments, high MAPQ, divergent alignments; can drop the optional fields\n"
                             "Options:\n"
-                            "         --inputBam, -i         input bam file\n"
+                            "         --inputBam, -i         input bam file (BAM only: SAM and CRAM input, which the reference reads through htslib, are not read here)\n"
                             "         --outputBam, -o        output bam file\n"
                             "         --maxMapq, -x          maximum mapq [default:100]\n"
                             "         --phasingLog, -P       the phasing log path (output of secphase) [optional]\n"

@@ -342,10 +342,10 @@ extern "C" int spx_correct_bam(const char *in_path, const char *out_path, const 
     BgzfOut bz;
     bool ok = true;
     if (opt.sam_text) {
-        if (hlen) { ok = fwrite(htext, 1, (size_t)hlen, fp) == (size_t)hlen; if (htext[hlen - 1] != '\n') fputc('\n', fp); }
+        if (hlen) { ok = fwrite(htext, 1, (size_t)hlen, fp) == (size_t)hlen; if (ok && htext[hlen - 1] != '\n') ok = fputc('\n', fp) != EOF; }
         const std::string t(htext ? htext : "", (size_t)hlen);
         if (!(t.compare(0, 4, "@SQ\t") == 0 || t.find("\n@SQ\t") != std::string::npos))
-            for (int32_t i = 0; i < nt; ++i) fprintf(fp, "@SQ\tSN:%s\tLN:%lld\n", spx_bam_target_name(rd, i), (long long)spx_internal_bam_target_len(rd, i));
+            for (int32_t i = 0; i < nt && ok; ++i) ok = fprintf(fp, "@SQ\tSN:%s\tLN:%lld\n", spx_bam_target_name(rd, i), (long long)spx_internal_bam_target_len(rd, i)) > 0;
     } else {
         bz.fp = fp;
         bz.threads = std::max(1, opt.threads);
@@ -367,7 +367,8 @@ extern "C" int spx_correct_bam(const char *in_path, const char *out_path, const 
     std::vector<uint8_t> recbuf;
     std::string line;
     const spx_batch *bt = nullptr;
-    int ng;
+    int ng = 0;
+    bool specific = false; /* a specific message has been recorded (spx_last_error): the generic one below must not replace it */
     while (ok && (ng = spx_bam_next_batch(rd, 16384, &bt)) > 0) {
         for (int32_t g = 0; g < bt->n_groups && ok; ++g) {
             const char *qname = bt->qnames + bt->qname_off[g];
@@ -378,7 +379,7 @@ extern "C" int spx_correct_bam(const char *in_path, const char *out_path, const 
                 ++st.records_in;
                 const uint8_t *rec = nullptr;
                 int32_t bs = 0;
-                if (spx_internal_bam_record(rd, bt, a, &rec, &bs) != SPX_OK) { ok = false; break; }
+                if (spx_internal_bam_record(rd, bt, a, &rec, &bs) != SPX_OK) { ok = false; specific = true; break; }
                 uint32_t flag = (uint32_t)(rec[14] | (rec[15] << 8));
                 if (flag & SPX_FUNMAP) continue;  /* :349 */
                 if (excluded) continue;           /* :350 */
@@ -412,18 +413,45 @@ extern "C" int spx_correct_bam(const char *in_path, const char *out_path, const 
                         if (l.contig == contig && l.start == pos) { mapq = l.mapq; break; }
                 if (opt.max_mapq < (int32_t)mapq) continue; /* :364 */
                 const uint8_t *aux = cig + 4 * (size_t)ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq, *end = rec + bs;
-                if (aux > end) { ok = false; fail(SPX_EINVAL, "corrupt BAM record"); break; }
+                if (aux > end) { ok = false; specific = true; fail(SPX_EINVAL, "corrupt BAM record"); break; }
                 if (opt.max_divergence < de_tag(aux, end)) continue; /* :365-366 */
-                const int32_t bs_out = opt.no_tag ? (int32_t)(aux - rec) : bs; /* :367 */
+                /* :367 -- bam1_t.l_data -= l_aux.  A record of more than 65 535 CIGAR operations keeps its real CIGAR in a CG:B,I tag behind a
+                 * placeholder; htslib's sam_read1 moves it back in front of the tags before the reference cuts them and bam_write1 emits CG again,
+                 * so the reference's output keeps it: here the CG tag alone survives the cut */
+                int32_t bs_out = opt.no_tag ? (int32_t)(aux - rec) : bs;
+                const uint8_t *cg = nullptr;
+                size_t cg_len = 0;
+                if (opt.no_tag && (uint32_t)bt->n_cigar[a] != ncig) {
+                    for (const uint8_t *t = aux; t + 3 <= end;) { /* walk the tags to CG:B,I */
+                        const uint8_t *t0 = t;
+                        const char ty = (char)t[2];
+                        t += 3;
+                        size_t sz = 0;
+                        if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+                        else if (ty == 's' || ty == 'S') sz = 2;
+                        else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+                        else if (ty == 'Z' || ty == 'H') { while (t < end && *t) ++t; sz = 1; }
+                        else if (ty == 'B' && t + 5 <= end) {
+                            const char sub = (char)t[0];
+                            const uint32_t cnt = (uint32_t)rd32(t + 1);
+                            const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                            sz = 5 + es * (size_t)cnt;
+                        } else break;
+                        if (t + sz > end) break;
+                        t += sz;
+                        if (t0[0] == 'C' && t0[1] == 'G' && ty == 'B') { cg = t0; cg_len = (size_t)(t - t0); break; }
+                    }
+                }
                 recbuf.clear();
-                wr32(recbuf, bs_out);
+                wr32(recbuf, bs_out + (int32_t)cg_len);
                 recbuf.insert(recbuf.end(), rec, rec + bs_out);
+                if (cg) { recbuf.insert(recbuf.end(), cg, cg + cg_len); bs_out += (int32_t)cg_len; }
                 recbuf[4 + 9] = (uint8_t)mapq;
                 recbuf[4 + 14] = (uint8_t)(flag & 0xff);
                 recbuf[4 + 15] = (uint8_t)(flag >> 8);
                 if (opt.sam_text) {
                     line.clear();
-                    if (spx_internal_format_sam(rd, recbuf.data() + 4, bs_out, &line) != SPX_OK) { ok = false; break; }
+                    if (spx_internal_format_sam(rd, recbuf.data() + 4, bs_out, &line) != SPX_OK) { ok = false; specific = true; break; }
                     if (fwrite(line.data(), 1, line.size(), fp) != line.size()) ok = false;
                 } else
                     bz.write(recbuf.data(), recbuf.size(), true);
@@ -434,12 +462,12 @@ extern "C" int spx_correct_bam(const char *in_path, const char *out_path, const 
         }
         spx_bam_release_batch(rd, bt);
     }
-    if (ng < 0) { ok = false; fail(ng, spx_io_last_error()); }
+    if (ng < 0) { ok = false; specific = true; fail(ng, spx_io_last_error()); }
     if (opt.sam_text) { if (fclose(fp) != 0) ok = false; }
     else if (!bz.close() || !bz.ok) ok = false;
     spx_bam_close(rd);
     spx_relabel_table_free(table);
     if (stats) *stats = st;
-    if (!ok) return fail(SPX_EINVAL, std::string("correct_bam: could not read ") + in_path + " or write " + out_path);
+    if (!ok) return specific ? SPX_EINVAL : fail(SPX_EINVAL, std::string("correct_bam: could not read ") + in_path + " or write " + out_path);
     return SPX_OK;
 }
