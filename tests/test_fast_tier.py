@@ -175,3 +175,38 @@ def test_batches_in_every_tier_mode(ctx, tiers, tmp_path, mode, monkeypatch):
         assert st == (0, 0, 0, 0, 0)
     else:
         assert st[0] > 0
+
+
+@pytest.mark.parametrize("guard", [orc.GUARD_BAND, orc.GUARD_ROW])
+@pytest.mark.parametrize("name", ["hifi", "ont", "edge", "mixed"])
+def test_fixture_problems_state_and_q_on_every_row(ctx, tiers, name, guard, monkeypatch):
+    """the DP problems of the committed fixtures' batches (tests/golden: hifi, ont, edge) and of a mixed 2-100 kb batch, as the host plan
+    cuts them: fast tier + certificate + exact re-run give the oracle's (state, q) on EVERY row (the wanted rows are a subset), under both
+    readings of the terminal guard"""
+    from common import nibbles, ref_codes
+    from golden.make_golden import CASES
+    monkeypatch.setenv("SPX_FAST_MIN_SHARE", "0")
+    monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")
+    tiers(1)
+    if name == "mixed":
+        c = dict(platform=synth.MIXED, cfg=dict(n_contigs=2, contig_len=150000), first=0, n=12, preset=("hifi", None))
+    else:
+        c = CASES[name]
+    old_a, old_o = api.get_terminal_guard(), orc.get_terminal_guard()
+    try:
+        api.set_terminal_guard(guard)
+        orc.set_terminal_guard(guard)
+        g = synth.Genome(synth.default_cfg(c["platform"], **c["cfg"]))
+        r = g.reads(c["first"], c["n"])
+        par = records.preset(c["preset"][0], bandwidth=c["preset"][1])
+        plan = api.Plan(g.ref, r.batch, par)
+        v = plan.view
+        n = min(int(v.n_problems), 1500)
+        assert n > 0
+        probs = [(ref_codes(g.ref, v.ref_tid[p], v.ref_rfs[p], v.R[p]), nibbles(v.qry4, v.qry_nib[p], v.L[p])) for p in range(n)]
+        pars = [(par.conf_d, par.conf_e, int(v.bw[p])) for p in range(n)]
+        nf, by_cert, by_model, by_range, _ = _check(ctx, probs, [par.set_q] * n, pars)
+        assert nf > 0 and by_cert + by_model + by_range < nf, (nf, by_cert, by_model, by_range)   # the fast tier answered problems of its own
+    finally:
+        api.set_terminal_guard(old_a)
+        orc.set_terminal_guard(old_o)
