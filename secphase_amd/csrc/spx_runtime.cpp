@@ -294,7 +294,7 @@ struct spx_work {
     bool fast = false, any_fast_cls = false, any_exact_cls = false;
     bool tiers_look = false; /* this list was counted with the fast tier's row size and decides for itself (spx_ctx::tiers_hint) */
     bool cls_fast[SPX_N_CLASSES] = {}; /* the classes of THIS list that take the fast tier: those with a fast kernel that hold a share of the list's band
-                                        * cells worth it (SPX_FAST_MIN_SHARE percent, default 8) -- every class with a fast tier costs a re-run launch per
+                                        * cells worth it (SPX_FAST_MIN_SHARE percent, default 2) -- every class with a fast tier costs a re-run launch per
                                         * slice, and a launch lasts a wave's lifetime however few problems it has (the mixed workload's nine classes) */
     float fast_d = 0, fast_e = 0; /* host-built lists (spx_probaln_batch): the parameters of problem 0; problems with others take the exact tier */
     int fast_set_q = 0;
@@ -626,7 +626,7 @@ extern "C" int spx_last_tier_stats(int64_t *out /* 5: fast problems, re-run by c
 /* which band classes of a list take the fast tier (spx_work::cls_fast) */
 static void fast_classes(spx_work *w)
 {
-    int share = 8;
+    int share = 2;
     if (const char *e = getenv("SPX_FAST_MIN_SHARE")) share = std::max(0, std::min(100, atoi(e)));
     int64_t tot = 0;
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls) tot += w->cls_used[cls] ? w->cls_cells[cls] : 0;
