@@ -607,8 +607,8 @@ extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B
     /* The exact band widths of the HiFi preset (W = 41, 43, 45, 47): TWO lanes per problem, C = (W + 1) / 2 slots each, W known at compile time
      * (one slot beyond the band in the second lane).  ONE lane per problem -- no lane exchange, no carry, 28 % fewer instructions per cell --
      * was measured too: its 2 x W doubles of state fill the register file at two waves per SIMD, the forward kernel spills its bookkeeping
-     * (54 spill instructions, one reload per row) and ran 11.4 ms against 9.1 for 32 768 groups; the backward kernel (no spills) 5.1 against 6.4,
-     * the two together no faster than two lanes.  Waves per SIMD: forward W = 41 four (128 VGPRs), every other kernel three. */
+     * (54 spill instructions, one reload per row) and ran 11.4 ms against 9.1 for 32 768 groups; the backward kernel (no spills) 6.55 against
+     * 6.82 once both were store-only: +0.8 % on the step, within the boxes' spread -- not kept.  Waves per SIMD: forward W = 41 four (128 VGPRs), every other kernel three. */
 #define SPX_FAST_HIFI(W_, C2_, WF_)                                                                                         \
     {                                                                                                                       \
         if (phase != 1 && B->n_order > 0)                                                                                   \
