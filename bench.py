@@ -299,19 +299,18 @@ def also_leg(platform, steps, warmup):
     cmd = [sys.executable, os.path.abspath(__file__), "--platform", platform, "--steps", str(steps), "--warmup", str(warmup),
            "--no-also", "--no-host-leg", "--no-build", "--verify", "64", "--cpu-runs", "3", "--cpu-threads", "32", "--no-host-input-leg"]
     # config 3 also end to end: `secphase --ont -b 50` on a BAM of one step's groups
-    # both legs end to end too, on >= 100 k groups each: ONT 131 072 groups = 16.7 GB of BAM (8 distinct batches), mixed 114 688
-    # groups (its 7 batches); SPX_BENCH_ALSO_ONT_BAM / SPX_BENCH_ALSO_MIXED_BAM for other sizes (0: no leg)
-    nbam = os.environ.get("SPX_BENCH_ALSO_ONT_BAM", "131072") if platform == "ont" else os.environ.get("SPX_BENCH_ALSO_MIXED_BAM", "114688")
+    # both legs end to end too, on >= 100 k groups each: ONT 131 072 groups = 16.7 GB of BAM (8 distinct batches), mixed 131 072
+    # groups (two of its batches); SPX_BENCH_ALSO_ONT_BAM / SPX_BENCH_ALSO_MIXED_BAM for other sizes (0: no leg)
+    nbam = os.environ.get("SPX_BENCH_ALSO_ONT_BAM", "131072") if platform == "ont" else os.environ.get("SPX_BENCH_ALSO_MIXED_BAM", "131072")
     cmd += ["--from-bam", nbam] if int(nbam) > 0 else ["--no-from-bam"]
-    # (mixed: small batches whose preparations overlap -- eight in flight on six preparation lanes; ONT: the preset of BASELINE config 3, 16 384 groups per
-    # step, four lists in flight (DP slices keep a list at ~30 GB) -- the parent has handed its device memory back (spx_trim)
-    # before this runs; SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
+    # (mixed: lists of 65 536 groups, four in flight (round 6; up to round 5: 16 384 groups, eight in flight on six preparation lanes -- the single-lane
+    # walks of a list's heaviest groups last the same whatever the list's size, so their cost per group falls with it: 209 k -> 230 k groups/s);
+    # ONT: the preset of BASELINE config 3, 16 384 groups per step, four lists in flight (DP slices keep a list at ~30 GB) -- the parent has handed
+    # its device memory back (spx_trim) before this runs; SPX_BENCH_ALSO_ONT_GPS=8192 for a shorter leg)
     ont_gps = os.environ.get("SPX_BENCH_ALSO_ONT_GPS")
-    cmd += ["--distinct", "9", "--depth", "8"] if platform == "mixed" else \
+    cmd += ["--distinct", "3", "--depth", "4"] if platform == "mixed" else \
         (["--distinct", "4", "--depth", "3", "--groups-per-step", ont_gps] if ont_gps else ["--distinct", "8", "--depth", "4"])
     env = dict(os.environ)
-    if platform == "mixed":
-        env.setdefault("SPX_PREP_LANES", "6")  # small lists (pools of a few GB per lane): six preparation lanes instead of the library's four
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True, env=env)
     dt = time.perf_counter() - t0
@@ -343,7 +342,7 @@ def main():
     ap.add_argument("--kernel-only", action="store_true", help="only the replay of one prepared work list (profiles, kernel A/B)")
     ap.add_argument("--groups-per-step", type=int, default=0, help="groups per rank per step (0: preset)")
     ap.add_argument("--depth", type=int, default=0,
-                    help="batches in flight in the pipeline (their device preparations run side by side); 0: 3 (hifi), 6 (mixed), "
+                    help="batches in flight in the pipeline (their device preparations run side by side); 0: 3 (hifi), 4 (mixed), "
                          "4 (ont; round 3: 2 -- a list of 16 384 ONT groups kept ~70 GB of saved rows; with DP slices ~30 GB)")
     ap.add_argument("--distinct", type=int, default=0,
                     help="at most this many distinct batches per rank (HBM / host memory); 0: 8 for --platform hifi (8 x 131 072 = the 1 M reads of BASELINE "
@@ -415,9 +414,9 @@ def main():
         also_results = {}
         for plat in ("ont", "mixed"):
             try:
-                # (a timed region starts with an empty pipeline: its first list waits for a whole preparation -- ~160 ms on the mixed
-                # workload, where a step is 85 ms: 32 steps = 524 288 groups there, 8 of the 325 ms ONT steps)
-                also_results[plat] = also_leg(plat, 32 if plat == "mixed" else 8, 2)
+                # (a timed region starts with an empty pipeline: its first list waits for a whole preparation; 8 steps = 524 288 mixed groups
+                # (290 ms steps), 8 of the 195 ms ONT steps = 131 072 groups)
+                also_results[plat] = also_leg(plat, 8, 2)
             except Exception as ex:  # noqa: BLE001
                 also_results[plat] = {"error": str(ex)}
     if not torch.cuda.is_available():
@@ -435,15 +434,15 @@ def main():
 
     ont = args.platform == "ont"
     mixed = args.platform == "mixed"
-    gps = args.groups_per_step or (16384 if ont else 16384 if mixed else 131072)
+    gps = args.groups_per_step or (16384 if ont else 65536 if mixed else 131072)
     if args.distinct <= 0:
         args.distinct = 8 if not (ont or mixed) else 4
     if args.depth <= 0:
         # round 4: the scratch of a work list (1/s of every DP row + the saved forward rows) exists per DP slice, not per list
         # (16 GB per slice by default), so that ONT lists (70 -> ~30 GB per 16 384 groups) and mixed lists fit deeper pipelines
-        args.depth = 8 if mixed else (4 if ont else 3)
+        args.depth = 4 if mixed else (4 if ont else 3)
         if mixed:
-            args.distinct = max(args.distinct, 9)
+            args.distinct = max(args.distinct, 3)
         if ont:
             args.distinct = max(args.distinct, 5)
     # (large batches: the preparation kernels are dependent chains -- one lane walks one alignment / one group -- whose

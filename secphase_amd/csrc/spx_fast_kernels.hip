@@ -555,13 +555,19 @@ __global__ __launch_bounds__(256) void fast_map_kernel(spx_dev_batch B, spx_fast
     }
 }
 
-extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, const spx_fast_consts *K, int32_t n_rows_total, int wide, hipStream_t st)
+extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, const spx_fast_consts *K, int32_t n_rows_total, int max_slots, hipStream_t st)
 {
     if (n_rows_total <= 0) return hipSuccess;
-    /* eight lanes per row; wide: up to 16 slots per lane (every fast class: <= 128 slots), else 6 (<= 48 slots) -- a wave of the narrow
-     * instantiation that meets a wider row hands its problem to the exact tier, so `wide` must be set when such classes are in the list */
-    if (wide) hipLaunchKernelGGL((fast_map_kernel<16, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, *K, n_rows_total);
-    else hipLaunchKernelGGL((fast_map_kernel<6, 8>), dim3(((int64_t)n_rows_total * 8 + 255) / 256), dim3(256), 0, st, *B, *K, n_rows_total);
+    /* eight lanes per row, CQ rounds of eight slots: the instantiation that holds the list's widest fast class (<= 48 slots: the HiFi classes;
+     * 64: with (4,16); 112 / 120: ONT's (4,26), (4,28) / (4,30); 128: every fast class).  A wave of a narrower instantiation that meets a wider row hands
+     * its problem to the exact tier, so max_slots must cover every fast class of the list.  (The rounds are unrolled: on the mixed workload the
+     * 16-round kernel took 9-10 ms per slice, as long as the forward kernels, where 48-slot rows with some 64-slot ones need 8.) */
+    const dim3 grid(((int64_t)n_rows_total * 8 + 255) / 256), block(256);
+    if (max_slots <= 48) hipLaunchKernelGGL((fast_map_kernel<6, 8>), grid, block, 0, st, *B, *K, n_rows_total);
+    else if (max_slots <= 64) hipLaunchKernelGGL((fast_map_kernel<8, 8>), grid, block, 0, st, *B, *K, n_rows_total);
+    else if (max_slots <= 112) hipLaunchKernelGGL((fast_map_kernel<14, 8>), grid, block, 0, st, *B, *K, n_rows_total);
+    else if (max_slots <= 120) hipLaunchKernelGGL((fast_map_kernel<15, 8>), grid, block, 0, st, *B, *K, n_rows_total);
+    else hipLaunchKernelGGL((fast_map_kernel<16, 8>), grid, block, 0, st, *B, *K, n_rows_total);
     return hipGetLastError();
 }
 

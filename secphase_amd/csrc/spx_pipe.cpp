@@ -24,6 +24,7 @@
 extern "C" void spx_internal_set_error(const char *msg);
 extern "C" int spx_internal_work_claim(spx_work *w, int claim); /* 1: mark in flight (fails when it already is), 0: clear */
 struct spx_alloc_gate;
+extern "C" void spx_internal_lists_in_flight(spx_ctx *c, int n); /* this many work lists will hold device memory at once */
 extern "C" spx_alloc_gate *spx_internal_gate_create(void);
 extern "C" void spx_internal_gate_free(spx_alloc_gate *g);
 extern "C" void spx_internal_gate_skip(spx_alloc_gate *g, int64_t ticket);
@@ -159,6 +160,7 @@ extern "C" int spx_pipe_create(spx_ctx *ctx, const spx_params *par, int depth, i
     int ht = host_threads > 0 ? host_threads : spx::effective_cpus();
     p->stage_threads = ht > 0 ? ht : 1; /* stagings run one after the other (ticket order): each gets all the threads */
     p->gate = spx_internal_gate_create();
+    spx_internal_lists_in_flight(ctx, p->depth + 1);
     for (int t = 0; t < p->depth; ++t) p->workers.emplace_back(worker_main, p);
     *out = p;
     return SPX_OK;

@@ -37,7 +37,7 @@ extern "C" hipError_t spx_launch_baq(int cls, int phase, const spx_dev_batch *B,
 extern "C" hipError_t spx_launch_score(const spx_dev_groups *Gd, int32_t n_markers, uint8_t *posmin, hipStream_t st);
 extern "C" hipError_t spx_launch_map(const spx_dev_batch *B, int32_t n_rows_total, int wide, hipStream_t st);
 extern "C" hipError_t spx_launch_fast(int cls, int phase, const spx_dev_batch *B, const spx_fast_consts *K, hipStream_t st);
-extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, const spx_fast_consts *K, int32_t n_rows_total, int wide, hipStream_t st);
+extern "C" hipError_t spx_launch_fast_map(const spx_dev_batch *B, const spx_fast_consts *K, int32_t n_rows_total, int max_slots, hipStream_t st);
 extern "C" int spx_fast_class(int cls);
 extern "C" hipError_t spx_launch_pack(const spx_dev_groups *Gd, const int32_t *grp_index, int32_t group_base,
                                       spx_decision *out, hipStream_t st);
@@ -183,6 +183,7 @@ struct spx_ctx {
     /* the scratch slack the consensus rounds of some list of this context needed (1, 4, 16 ..): later lists start with it instead of finding it
      * out again by an overflow and a second run of the whole group phase (round 5: two of seven mixed batches paid that at EVERY preparation) */
     std::atomic<int> slack_hint{1};
+    std::atomic<int> work_arenas{0}, work_arenas_most{0}; /* staged work lists that hold their arena now / the most so far (or what a pipeline announced) */
     /* two-tier DP: what the latest list that looked decided (fast_classes: -1 nobody has looked yet, 1 tiers, 0 exact kernels only).  The lists of a run are
      * alike, and the decision is only known after the counting phase, which already needs the row size (4 rows of slots per wanted row with the tiers, 2
      * without): lists that follow a "0" are counted with 2 and do not look again, except every 32nd (the mixed 2-100 kb workload: its lists had twice the
@@ -226,6 +227,7 @@ struct spx_alloc_gate {
     int64_t turn = 0;
 };
 extern "C" spx_alloc_gate *spx_internal_gate_create(void) { return new spx_alloc_gate(); }
+extern "C" void spx_internal_lists_in_flight(spx_ctx *c, int n);
 extern "C" void spx_internal_gate_free(spx_alloc_gate *g) { delete g; }
 /* a ticket that will never reach the allocation (its job failed earlier) is passed over */
 extern "C" void spx_internal_gate_skip(spx_alloc_gate *g, int64_t ticket)
@@ -892,6 +894,15 @@ static void arena_flush(spx_ctx *c)
     }
     for (void *d : drop) (void)hipFree(d);
 }
+extern "C" void spx_internal_lists_in_flight(spx_ctx *c, int n)
+{
+    if (!c) return;
+    int h = c->work_arenas_most.load();
+    while (h < n && !c->work_arenas_most.compare_exchange_weak(h, n)) {}
+}
+static void work_arena_taken(spx_ctx *c) { spx_internal_lists_in_flight(c, ++c->work_arenas); }
+static void work_arena_back(spx_ctx *c) { --c->work_arenas; }
+
 static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
 {
     /* When HBM is full -- several large work lists in flight: 16 384 ONT groups need ~70 GB of saved rows -- the caller
@@ -1368,6 +1379,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
         if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done));
         else HIPCHK(hipStreamSynchronize(c->stream));
         arena_put(c, w->arena, w->arena_cap);
+        work_arena_back(c);
         w->arena = nullptr;
     }
     w->prepared = false;
@@ -1479,8 +1491,11 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     int K = 1;
     {
         const double scratch_gb = ((double)T.s_tot + (double)T.f_tot) * 8.0 / 1e9;
-        double budget = A.par.row_mult > 2 ? 24.0 : 16.0; /* (two-tier DP: a wanted row holds four rows of slots instead of two; HiFi lists of 131 072 groups:
-                                                            * 4 slices at 16 GB, 3 at 24, 2 at 32 -- 1.19 / 1.20 / 1.23 M groups/s) */
+        /* (two-tier DP: a wanted row holds four rows of slots instead of two; HiFi lists of 131 072 groups: 4 slices at 16 GB, 3 at 24, 2 at 32 --
+         * 1.19 / 1.20 / 1.23 M groups/s.  With more than five lists holding memory at once the slices stay at 16 GB: the mixed leg's nine lists of
+         * two 17 GB slices each filled the device and the pipeline waited for memory, 118 k groups/s instead of 212 k) */
+        const int lists = std::max(c->work_arenas_most.load(), c->work_arenas.load() + 1);
+        double budget = (A.par.row_mult > 2 && lists <= 5) ? 24.0 : 16.0;
         if (const char *e = getenv("SPX_DP_SLICE_GB")) budget = std::max(0.001, atof(e));
         if (scratch_gb > budget) K = (int)ceil(scratch_gb / budget);
         if (const char *e = getenv("SPX_DP_SLICES")) K = atoi(e);
@@ -1550,6 +1565,7 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     w->arena = arena_get(c, w->arena_bytes, &w->arena_cap);
     gate.pass();
     if (!w->arena) return fail(SPX_ENOMEM, "device memory for the work list");
+    work_arena_taken(c);
     char *B0 = (char *)w->arena;
     /* temporaries of the launch-order sort (context pools) */
     const size_t sort_tmp = spx_order_temp_bytes((int32_t)np);
@@ -1717,6 +1733,7 @@ extern "C" int spx_work_release(spx_ctx *c, spx_work *w)
     if (w->ev_ready) HIPCHK(hipEventSynchronize(w->ev_ready));
     if (w->ev_done) HIPCHK(hipEventSynchronize(w->ev_done));
     arena_put(c, w->arena, w->arena_cap);
+    work_arena_back(c);
     w->arena = nullptr;
     w->prepared = false;
     w->launched = false;
@@ -1787,16 +1804,16 @@ extern "C" int spx_launch(spx_ctx *c, spx_work *w)
         if (w->cls_fast[cls]) return spx_launch_fast(cls, phase, Bc, &w->fk, st);
         return spx_launch_baq(cls, phase, Bc, st);
     };
-    bool wide_fast = false; /* a fast class with more than 48 slots is in the list: the wide MAP instantiation */
+    int fast_slots = 0; /* the widest fast class of the list: which instantiation of the fast MAP kernel */
     for (int cls = 0; cls < SPX_N_CLASSES; ++cls)
-        if (w->cls_fast[cls] && spx::class_slots(cls) > 48) wide_fast = true;
+        if (w->cls_fast[cls]) fast_slots = std::max(fast_slots, (int)spx::class_slots(cls));
     auto finish_rows = [&](const spx_dev_batch *cb /* [SPX_N_CLASSES] of the slice */, int64_t r0, int64_t r1, bool wide_first, hipStream_t st) -> int {
         const int32_t nrows = (int32_t)(r1 - r0);
         if (nrows <= 0) return SPX_OK;
         spx_dev_batch Bm = cb[0];
         Bm.row_base = (int32_t)r0;
         if (!fast) { HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); return SPX_OK; }
-        if (w->any_fast_cls) HIPCHK(spx_launch_fast_map(&Bm, &w->fk, nrows, wide_fast ? 1 : 0, st));
+        if (w->any_fast_cls) HIPCHK(spx_launch_fast_map(&Bm, &w->fk, nrows, fast_slots, st));
         if (w->any_exact_cls) { Bm.tier_want = SPX_TIER_EXACT; HIPCHK(spx_launch_map(&Bm, nrows, wide_first, st)); }
         return SPX_OK;
     };
@@ -2254,7 +2271,7 @@ extern "C" void spx_work_free(spx_ctx *c, spx_work *w)
         if (w->ev_done) (void)hipEventSynchronize(w->ev_done);
         else (void)hipStreamSynchronize(c->stream);
     }
-    if (w->arena) arena_put(c, w->arena, w->arena_cap);
+    if (w->arena) { arena_put(c, w->arena, w->arena_cap); if (w->staged) work_arena_back(c); }
     if (w->in_arena) arena_put(c, w->in_arena, w->in_cap);
     if (w->h_stage) pinned_put(c, w->h_stage, w->h_stage_cap);
     if (w->ev_ready) (void)hipEventDestroy(w->ev_ready);
