@@ -206,6 +206,14 @@ static int ensure_pool(spx_ctx::PrepLane &PL, spx_ctx::DevBuf &b, size_t bytes)
         b.cap = 0;
     }
     size_t want = bytes + bytes / 4 + (1u << 20);
+    {
+        /* (not the device's last bytes: see arena_get) */
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if (free_b < want + total_b / 64 && PL.owner) { arena_flush(PL.owner); want = bytes + (1u << 20); (void)hipMemGetInfo(&free_b, &total_b); }
+            if (free_b < want + total_b / 128) return SPX_ENOMEM;
+        } else (void)hipGetLastError();
+    }
     const double tp0 = now_s();
     const hipError_t pe = hipMalloc(&b.p, want);
     if (timing_on()) fprintf(stderr, "[spx timing] preparation pool of %.2f GB (lane %d): hipMalloc %.3f s%s\n", want / 1e9, PL.owner ? (int)(&PL - PL.owner->lane) : -1, now_s() - tp0, pe == hipSuccess ? "" : " (failed)");
@@ -931,6 +939,7 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
         void *p = nullptr;
         /* head room so that the next, slightly larger list fits -- until memory has been tight once */
         *cap = bytes + (c->hbm_tight.load() ? 0 : bytes / 8) + 4096;
+        bool starve = false;
         {
             /* blocks in use + blocks waiting for re-use + this one stay under ~7/8 of the device: the OLDEST waiting blocks
              * go back to the driver first (a failed hipMalloc costs a flush of the whole cache and, with several lists in
@@ -952,8 +961,18 @@ static void *arena_get(spx_ctx *c, size_t bytes, size_t *cap)
                     drop.push_back(c->arena_cache.front().first);
                     c->arena_cache.erase(c->arena_cache.begin());
                 }
+                /* never the device's last bytes while older lists hold memory they will give back: the HIP runtime allocates from the same
+                 * memory (kernel scratch, queues) and ends the process with HSA_STATUS_ERROR_OUT_OF_RESOURCES when it finds none (six
+                 * preparation lanes' pools beside four 65 536-group mixed lists) */
+                starve = c->arena_in_use > 0 && free_b < *cap + c->hbm_bytes / 64;
             }
             for (void *d : drop) (void)hipFree(d);
+        }
+        if (starve && now_s() < t_end) {
+            c->hbm_tight = true;
+            std::unique_lock<std::mutex> lk(c->arena_mu);
+            c->arena_cv.wait_for(lk, std::chrono::milliseconds(50));
+            continue;
         }
         const double tm0 = now_s();
         const hipError_t me = hipMalloc(&p, *cap);
