@@ -75,9 +75,10 @@ def test_fast_tier_ont_windows(ctx, tiers):
     assert by_cert + by_model + by_range <= nf // 4, (nf, by_cert, by_model, by_range)
 
 
-@pytest.mark.parametrize("bw", [3, 10, 21, 24, 27, 30, 35, 40, 45, 51, 52, 55, 59])
+@pytest.mark.parametrize("bw", [3, 10, 21, 24, 27, 30, 35, 40, 45, 51, 52, 55, 59, 60, 62, 63])
 def test_fast_tier_every_band_class(ctx, tiers, bw, monkeypatch):
-    """generic classes (2,24), (4,16), (4,26), (4,28), (4,30) at widths that leave 0 .. many slots beyond the band"""
+    """generic classes (2,24), (4,16), (4,26), (4,28), (4,30) at widths that leave 0 .. many slots beyond the band; bw 60..63: the first class
+    WITHOUT a fast kernel (W = 121..128: exact kernels beside the tiers)"""
     monkeypatch.setenv("SPX_FAST_MIN_SHARE", "0")  # (every class with a fast kernel takes it, however few cells it holds)
     monkeypatch.setenv("SPX_FAST_MIN_TOTAL", "0")
     tiers(1)
