@@ -1510,8 +1510,8 @@ extern "C" int spx_prepare_staged(spx_ctx *c, spx_work *w)
     int K = 1;
     {
         const double scratch_gb = ((double)T.s_tot + (double)T.f_tot) * 8.0 / 1e9;
-        /* (two-tier DP: a wanted row holds four rows of slots instead of two; HiFi lists of 131 072 groups: 4 slices at 16 GB, 3 at 24, 2 at 32 --
-         * 1.19 / 1.20 / 1.23 M groups/s.  With more than five lists holding memory at once the slices stay at 16 GB: the mixed leg's nine lists of
+        /* (two-tier DP: a wanted row holds four rows of slots instead of two; HiFi lists of 131 072 groups: 4 slices at 16 GB, 3 at 24 -- 1.19 /
+         * 1.20 M groups/s on one box; 2 at 32 GB measured 1.23 M once and 0.87 / 1.21 M against 1.32 / 1.31 M later: four lists of that size wait for memory.  With more than five lists holding memory at once the slices stay at 16 GB: the mixed leg's nine lists of
          * two 17 GB slices each filled the device and the pipeline waited for memory, 118 k groups/s instead of 212 k) */
         const int lists = std::max(c->work_arenas_most.load(), c->work_arenas.load() + 1);
         double budget = (A.par.row_mult > 2 && lists <= 5) ? 24.0 : 16.0;
